@@ -1,0 +1,68 @@
+"""Deterministic synthetic weights / prompts (no checkpoints reach the GPU box).
+
+Every tensor is drawn from its own CPU ``torch.Generator`` seeded by
+``(seed, crc32(name))`` so the values depend only on the tensor's state-dict
+name and shape -- not on module construction order.  The golden-fixture
+generator (tests/golden/make_golden.py) loads these values into the *reference*
+models; the tests load the same values into this repo's backbones, which share
+the reference checkpoints' state-dict keys.
+"""
+import zlib
+
+import torch
+
+
+def _gen_for(name: str, seed: int) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2**63 - 1))
+    return g
+
+
+def synthetic_tensor(name: str, shape, seed: int = 0, head_gain: float = 3.0,
+                     embed_token_scale: float = 1.0) -> torch.Tensor:
+    """fp32 CPU tensor for state-dict entry ``name``.
+
+    * 1-D ``...norm...weight`` / ``weight`` of norms -> 1 + 0.1*N(0,1);  biases -> 0.02*N(0,1)
+    * embeddings -> c + embed_token_scale*N(0,1) with one shared N(0,1) row ``c`` (if scale < 1).  A small
+      ``embed_token_scale`` makes the next-token distribution depend only weakly on the previous token, which
+      is what gives Speculative Jacobi Decoding its acceptance rate on real image models; with 1.0 (plain
+      random weights) acceptance sits at the floor of ~1 token/step.
+    * 2-D linear weights [out,in] -> N(0, 1/in); the LM head gets ``head_gain``/sqrt(in) so that
+      logits have std ~= head_gain (a peaked, "alive" distribution instead of near-uniform).
+    """
+    shape = tuple(int(s) for s in shape)
+    g = _gen_for(name, seed)
+    x = torch.randn(shape, generator=g, dtype=torch.float32)
+    lname = name.lower()
+    if lname.endswith("bias"):
+        return 0.02 * x
+    if len(shape) == 1 or "norm" in lname:
+        return 1.0 + 0.1 * x
+    if "embed" in lname:  # tok_embeddings / embed_tokens / embedding_table
+        if embed_token_scale >= 1.0:
+            return x
+        common = torch.randn(shape[-1:], generator=_gen_for(name + "#common", seed), dtype=torch.float32)
+        return common + embed_token_scale * x
+    fan_in = shape[-1]
+    gain = head_gain if (lname.startswith("output.") or lname.startswith("lm_head.")) else 1.0
+    return x * (gain / fan_in ** 0.5)
+
+
+def fill_state_dict(module: torch.nn.Module, seed: int = 0, skip_prefixes=(), head_gain: float = 3.0,
+                    embed_token_scale: float = 1.0):
+    """In-place deterministic fill of every parameter/buffer tensor in ``module.state_dict()``."""
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if any(name.startswith(p) for p in skip_prefixes):
+                continue
+            if not torch.is_floating_point(t):
+                continue
+            t.copy_(synthetic_tensor(name, t.shape, seed, head_gain, embed_token_scale).to(t.dtype))
+    return module
+
+
+def synthetic_prompt(length: int, seed: int, lo: int = 8900, hi: int = 60000) -> torch.Tensor:
+    """Prompt token ids uniform in a text-id range (never grammar tokens)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed))
+    return torch.randint(lo, hi, (1, length), generator=g, dtype=torch.long)

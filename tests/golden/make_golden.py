@@ -1,0 +1,495 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by IMPORTING THE REFERENCE in this container (CPU).
+
+Run:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+
+The reference (/root/reference, read-only) is imported with the in-memory shims of
+_ref_shims.py.  Only inputs (seeds / small integer arrays) and the reference's
+outputs are written; no reference source travels.  /root/reference does not exist
+on the GPU box, so nothing at test time imports this script.
+
+Fixtures
+  fn_logits2tokens_lumina.npz   sampling_logits2tokens + MultiTokensVLLogitsProcessor +
+                                MultiTokensInterleavedTopKLogitsWarper  (JL:82-132, LP:45-204)
+  fn_logits2tokens_llamagen.npz TopKLogitsWarper + TopPLogitsWarper3d   (LS:458-470, LP:355-419)
+  fn_emu3_grammar.npz           EOLLogitProcessor3d + TopK(2048)        (JE:41-151)
+  fn_anole_grammar.npz          Anole image-only 3d processors          (JA:194-232, LP:207-353)
+  fn_speculative_sampler.npz    SpeculativeSampler.__call__             (JL:247-315)
+  fn_reguess.npz                get_multi_token_for_preparation('random') (JL:470-514)
+  loop_llamagen.npz             whole _sample loop, tiny LlamaGen c2i   (JL:912-1249, LS:349-456)
+  loop_lumina.npz               whole _sample loop, tiny Chameleon      (JL:912-1249, MC)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _ref_shims  # noqa: E402
+
+LegacyCache, CompatMixin = _ref_shims.install()
+
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location(
+    "sjd_synthetic", os.path.join(ROOT, "accelerating-t2i-ar-with-sjd_amd", "synthetic.py"))
+synthetic = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synthetic)
+
+import scheduler.jacobi_iteration_lumina_mgpt as JL  # noqa: E402  (the reference)
+import scheduler.logit_processor_3dim as LP  # noqa: E402
+from transformers.generation.logits_process import LogitsProcessorList, TopKLogitsWarper  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+
+def sample_cols(V, n=64, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, V, (n,), generator=g)
+
+
+# ----------------------------------------------------------------------------------------------
+# function-level vectors
+# ----------------------------------------------------------------------------------------------
+def lumina_context(P, h_grids, w_grids, n_img_tokens, seed):
+    """prompt(P text ids) + <start> h w + n_img_tokens image/EOL tokens laid out per the grammar."""
+    ids = synthetic.synthetic_prompt(P, seed, lo=8900, hi=9200)[0].tolist()
+    ids += [8197, 8804 + h_grids, 8804 + w_grids]
+    w = 2 * w_grids
+    g = torch.Generator().manual_seed(seed + 1)
+    k = 0
+    while k < n_img_tokens:
+        if (k + 1) % (w + 1) == 0:
+            ids.append(8803)
+        else:
+            ids.append(int(torch.randint(4, 8196, (1,), generator=g)))
+        k += 1
+    return torch.tensor([ids], dtype=torch.long)
+
+
+def gen_fn_logits2tokens_lumina():
+    V, L = 9216, 16
+    cases = []
+    # (name, P, h_grids, w_grids, n_img_tokens, n_rows, text_mode)
+    spec = [
+        ("mid_row", 12, 4, 4, 11, 16, 0),       # window crosses one EOL
+        ("row_start", 12, 4, 4, 9, 5, 0),       # short window, no EOL
+        ("two_eol", 12, 4, 2, 3, 16, 0),        # w=4: several EOLs in one window
+        ("end_of_image", 12, 2, 2, 12, 16, 0),  # window reaches the end-of-image slot (h=w=4: 20 tokens)
+        ("after_start_0", 12, 4, 4, -3, 4, 0),  # context ends with <start> only (new_token_num=0 <2)
+        ("after_start_1", 12, 4, 4, -2, 4, 0),  # <start> h
+        ("after_start_2", 12, 4, 4, -1, 4, 0),  # <start> h w  (new_token_num=2)
+        ("text_mode", 12, 4, 4, -4, 3, 1),      # no image open: identity grammar + text top-k 10
+        ("single_row", 12, 4, 4, 20, 1, 0),
+    ]
+    out = {}
+    meta = []
+    for ci, (name, P, hg, wg, nimg, nrows, text_mode) in enumerate(spec):
+        ctx = lumina_context(P, hg, wg, max(nimg, 0), seed=100 + ci)
+        if nimg < 0:
+            ctx = ctx[:, : P + 3 + (nimg + 1)] if nimg > -4 else ctx[:, :P]
+        g = torch.Generator().manual_seed(1000 + ci)
+        logits = torch.randn(2, nrows, V, generator=g) * 3.0
+        proc = LogitsProcessorList([
+            LP.MultiTokensVLLogitsProcessor(image_start_token_id=8197, image_end_token_id=8196,
+                                            image_next_line_token_id=8803, patch_size=32, voc_size=V),
+            LP.MultiTokensInterleavedTopKLogitsWarper(image_top_k=2000, text_top_k=10,
+                                                      image_start_token_id=8197, image_end_token_id=8196),
+        ])
+        gen = torch.Generator().manual_seed(2000 + ci)
+        is_force_no_cfg = JL.check_is_force_no_cfg(ctx, 8197, 8196)
+        toks, probs = JL.sampling_logits2tokens(
+            logits, ctx, torch.ones(1, dtype=torch.long), None, output_token_num=nrows,
+            logits_processor=proc, logits_warper=None, do_sample=True, has_eos_stopping_criteria=False,
+            do_cfg=True, guidance_scale=3.0, generator=gen, is_force_no_cfg=is_force_no_cfg)
+        cols = sample_cols(V)
+        out[f"{name}.ctx"] = ctx.numpy()
+        out[f"{name}.tokens"] = toks.numpy()
+        out[f"{name}.nnz"] = (probs[0] > 0).sum(-1).numpy()
+        out[f"{name}.pmax"] = probs[0].max(-1).values.numpy()
+        out[f"{name}.p_at_tok"] = probs[0].gather(-1, toks[0][:, None])[:, 0].numpy()
+        out[f"{name}.p_cols"] = probs[0][:, cols].numpy()
+        meta.append(dict(name=name, V=V, nrows=nrows, logits_seed=1000 + ci, noise_seed=2000 + ci,
+                         logits_scale=3.0, guidance_scale=3.0, image_top_k=2000, text_top_k=10,
+                         is_force_no_cfg=bool(is_force_no_cfg)))
+    out["meta"] = np.array(json.dumps(meta))
+    out["cols"] = sample_cols(V).numpy()
+    np.savez_compressed(os.path.join(HERE, "fn_logits2tokens_lumina.npz"), **out)
+    print("fn_logits2tokens_lumina ok", [m["name"] for m in meta])
+
+
+def gen_fn_logits2tokens_llamagen():
+    from llamagen.llamagen_solver import LlamaGenSolver
+    V = 16384
+    out, meta = {}, []
+    for ci, (nrows, top_k, top_p, cfg) in enumerate([(16, 1000, 1.0, 4.0), (16, 1000, 0.9, 4.0), (1, 50, 0.5, 7.5),
+                                                     (7, 16384, 1.0, 1.5)]):
+        solver = LlamaGenSolver(model=None, image_top_k=top_k, image_top_p=top_p)
+        proc = solver.create_logits_processor()
+        g = torch.Generator().manual_seed(3000 + ci)
+        logits = torch.randn(2, nrows, V, generator=g) * 3.0
+        gen = torch.Generator().manual_seed(4000 + ci)
+        ctx = torch.randint(0, V, (1, 5 + ci), generator=g)
+        toks, probs = JL.sampling_logits2tokens(
+            logits, ctx, torch.ones(1, dtype=torch.long), None, output_token_num=nrows,
+            logits_processor=proc, logits_warper=None, do_sample=True, has_eos_stopping_criteria=False,
+            do_cfg=True, guidance_scale=cfg, generator=gen, is_force_no_cfg=False)
+        cols = sample_cols(V)
+        name = f"c{ci}"
+        out[f"{name}.tokens"] = toks.numpy()
+        out[f"{name}.nnz"] = (probs[0] > 0).sum(-1).numpy()
+        out[f"{name}.pmax"] = probs[0].max(-1).values.numpy()
+        out[f"{name}.p_cols"] = probs[0][:, cols].numpy()
+        meta.append(dict(name=name, V=V, nrows=nrows, logits_seed=3000 + ci, noise_seed=4000 + ci, logits_scale=3.0,
+                         guidance_scale=cfg, top_k=top_k, top_p=top_p))
+    out["meta"] = np.array(json.dumps(meta))
+    out["cols"] = sample_cols(V).numpy()
+    np.savez_compressed(os.path.join(HERE, "fn_logits2tokens_llamagen.npz"), **out)
+    print("fn_logits2tokens_llamagen ok")
+
+
+def gen_fn_emu3_grammar():
+    import scheduler.jacobi_iteration_emu3 as JE
+    from emu3.mllm.utils_emu3 import Emu3PrefixConstrainedLogitsHelper
+    V = 12288
+    vis_lo, vis_n = 3000, 8192  # a contiguous visual-token range, like Emu3's 32768 codes
+    tok = dict(img_token=200, eoi_token=201, eos_token=202, eol_token=203, eof_token=204, pad_token=205)
+    out, meta = {}, []
+    H, W = 3, 5  # (W+1)*H = 18 tokens, then EOF EOI EOS pad...
+    for ci, (n_after_img, nrows) in enumerate([(0, 16), (4, 16), (10, 16), (17, 8), (2, 3), (19, 6)]):
+        helper = Emu3PrefixConstrainedLogitsHelper(H, W, visual_tokens=list(range(vis_lo, vis_lo + vis_n)), **tok)
+        helper.__class__ = JE.renew_end_of_line_logit_processor_3d(helper.__class__)
+        g = torch.Generator().manual_seed(5000 + ci)
+        ctx = torch.cat([torch.randint(300, 2000, (1, 9), generator=g), torch.tensor([[tok["img_token"]]]),
+                         torch.randint(vis_lo, vis_lo + vis_n, (1, n_after_img), generator=g)], dim=1)
+        logits = torch.randn(2, nrows, V, generator=g) * 3.0
+        proc = LogitsProcessorList([helper, TopKLogitsWarper(top_k=2048)])
+        gen = torch.Generator().manual_seed(6000 + ci)
+        toks, probs = JL.sampling_logits2tokens(
+            logits, ctx, torch.ones(1, dtype=torch.long), None, output_token_num=nrows,
+            logits_processor=proc, logits_warper=None, do_sample=True, has_eos_stopping_criteria=False,
+            do_cfg=True, guidance_scale=3.0, generator=gen, is_force_no_cfg=False)
+        name = f"c{ci}"
+        cols = sample_cols(V)
+        out[f"{name}.ctx"] = ctx.numpy()
+        out[f"{name}.tokens"] = toks.numpy()
+        out[f"{name}.nnz"] = (probs[0] > 0).sum(-1).numpy()
+        out[f"{name}.pmax"] = probs[0].max(-1).values.numpy()
+        out[f"{name}.p_cols"] = probs[0][:, cols].numpy()
+        meta.append(dict(name=name, V=V, nrows=nrows, H=H, W=W, vis_lo=vis_lo, vis_n=vis_n, logits_seed=5000 + ci,
+                         noise_seed=6000 + ci, ctx_seed=5000 + ci, n_after_img=n_after_img, top_k=2048,
+                         guidance_scale=3.0, logits_scale=3.0, **tok))
+    out["meta"] = np.array(json.dumps(meta))
+    out["cols"] = sample_cols(V).numpy()
+    np.savez_compressed(os.path.join(HERE, "fn_emu3_grammar.npz"), **out)
+    print("fn_emu3_grammar ok")
+
+
+def gen_fn_anole_grammar():
+    V = 9216
+    img_ids = list(range(4, 8196))
+    boi, eoi, eos = 8197, 8196, 2
+    image_seq_length = 24
+    out, meta = {}, []
+    # context lengths relative to the BOI token: before any BOI, right after BOI, mid image, at the EOI slot
+    for ci, (n_after_boi, nrows, prompt_len, max_length) in enumerate(
+            [(-1, 4, 6, 40), (0, 16, 6, 40), (10, 16, 6, 40), (24, 4, 6, 40), (23, 16, 6, 40)]):
+        g = torch.Generator().manual_seed(7000 + ci)
+        ctx = torch.randint(8900, 9200, (1, prompt_len), generator=g)
+        if n_after_boi >= 0:
+            ctx = torch.cat([ctx, torch.tensor([[boi]]), torch.randint(4, 8196, (1, n_after_boi), generator=g)], dim=1)
+        allowed = img_ids + [eos, boi, eoi]
+        suppress = [t for t in range(V) if t not in set(allowed)]
+        procs = LogitsProcessorList([
+            LP.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(trigger_token_id=boi, allowed_token_ids=[eoi],
+                                                                offset=image_seq_length + 1, exclusive=True),
+            LP.AllowOnlyTokensInRelativeWindowLogitsProcessor3d(trigger_token_id=boi, allowed_token_ids=img_ids,
+                                                                window_width=image_seq_length, exclusive=True),
+            LP.SuppressTokensInIndexRangeLogitsProcessor3d(suppress_tokens=[boi],
+                                                           start_index=max_length - image_seq_length - 1),
+            LP.SuppressTokensLogitsProcessor3d(suppress_tokens=suppress),
+            LP.SuppressTokensAtBeginLogitsProcessor3d(begin_suppress_tokens=[eos], begin_index=prompt_len),
+            TopKLogitsWarper(top_k=2000),
+        ])
+        logits = torch.randn(2, nrows, V, generator=g) * 3.0
+        gen = torch.Generator().manual_seed(8000 + ci)
+        toks, probs = JL.sampling_logits2tokens(
+            logits, ctx, torch.ones(1, dtype=torch.long), None, output_token_num=nrows,
+            logits_processor=procs, logits_warper=None, do_sample=True, has_eos_stopping_criteria=False,
+            do_cfg=True, guidance_scale=3.0, generator=gen, is_force_no_cfg=False)
+        name = f"c{ci}"
+        cols = sample_cols(V)
+        out[f"{name}.ctx"] = ctx.numpy()
+        out[f"{name}.tokens"] = toks.numpy()
+        out[f"{name}.nnz"] = (probs[0] > 0).sum(-1).numpy()
+        out[f"{name}.pmax"] = probs[0].max(-1).values.numpy()
+        out[f"{name}.p_cols"] = probs[0][:, cols].numpy()
+        meta.append(dict(name=name, V=V, nrows=nrows, prompt_len=prompt_len, max_length=max_length,
+                         image_seq_length=image_seq_length, boi=boi, eoi=eoi, eos=eos, logits_seed=7000 + ci,
+                         noise_seed=8000 + ci, top_k=2000, guidance_scale=3.0, logits_scale=3.0,
+                         n_after_boi=n_after_boi))
+    out["meta"] = np.array(json.dumps(meta))
+    out["cols"] = sample_cols(V).numpy()
+    np.savez_compressed(os.path.join(HERE, "fn_anole_grammar.npz"), **out)
+    print("fn_anole_grammar ok")
+
+
+def make_pq(V, L, seed, mode):
+    """Draft rows q / target rows p shaped like real SJD iterations: top-k'd softmaxes; some q rows one-hot."""
+    g = torch.Generator().manual_seed(seed)
+    zl = torch.randn(L, V, generator=g) * 3.0
+    # q[i] is what position i was drafted from; it is verified against p[i-1] (JL:153-155), so build it
+    # as a perturbation of the target row i-1.
+    zq = torch.roll(zl, 1, 0) + torch.randn(L, V, generator=g) * {"far": 3.0, "carried": 0.15}.get(mode, 0.3)
+
+    def topk_softmax(z, k):
+        kth = torch.topk(z, k)[0][..., -1, None]
+        return torch.softmax(z.masked_fill(z < kth, -float("inf")), dim=-1)
+
+    p = topk_softmax(zl, 500)
+    q = topk_softmax(zq, 500)
+    draft = torch.multinomial(q, 1, generator=g)[:, 0]
+    n_onehot = {"carried": 0, "mixed": 5, "fresh": L - 1, "far": 3, "equal": 0}[mode]
+    if mode == "equal":   # q rows == shifted p rows: ratio exactly 1 -> everything accepted
+        q[1:] = p[:-1]
+        draft[1:] = torch.multinomial(p[:-1], 1, generator=g)[:, 0]
+    for i in range(L - n_onehot, L):
+        t = int(torch.randint(0, V, (1,), generator=g))
+        # bias fresh random drafts into p's support half of the time so both branches occur
+        if i % 2 == 0:
+            t = int(torch.multinomial(p[i - 1], 1, generator=g))
+        q[i] = 0
+        q[i, t] = 1.0
+        draft[i] = t
+    return p[None], q[None], draft[None]
+
+
+def gen_fn_speculative_sampler():
+    V = 9216
+    out, meta = {}, []
+    cases = [("carried", 16, None), ("mixed", 16, None), ("fresh", 16, None), ("far", 16, None), ("equal", 8, None),
+             ("mixed", 16, "lumina"), ("fresh", 2, None), ("mixed", 16, "llamagen")]
+    for ci, (mode, L, grammar) in enumerate(cases):
+        p, q, draft = make_pq(V, L, 9000 + ci, mode)
+        adv_tokens = torch.multinomial(p[0], 1, generator=torch.Generator().manual_seed(9500 + ci))[:, 0][None]
+        gen = torch.Generator().manual_seed(9900 + ci)
+        B = 1
+        sampler = JL.SpeculativeSampler(
+            generator=gen,
+            reject_sampling_relative_ids=-torch.ones(B, dtype=torch.long),
+            reject_sampling_draft_token_logits=torch.zeros((B, V), dtype=torch.long),
+            sampling_last_draft_token=torch.zeros((B,), dtype=torch.long))
+        proc, ctx = None, torch.randint(8900, 9200, (1, 7), generator=torch.Generator().manual_seed(ci))
+        if grammar == "lumina":
+            ctx = lumina_context(12, 4, 4, 3, seed=300 + ci)   # residual rows may land on an EOL slot
+            proc = LogitsProcessorList([
+                LP.MultiTokensVLLogitsProcessor(image_start_token_id=8197, image_end_token_id=8196,
+                                                image_next_line_token_id=8803, patch_size=32, voc_size=V),
+                LP.MultiTokensInterleavedTopKLogitsWarper(image_top_k=2000, text_top_k=10,
+                                                          image_start_token_id=8197, image_end_token_id=8196)])
+        elif grammar == "llamagen":
+            from llamagen.llamagen_solver import LlamaGenSolver
+            proc = LlamaGenSolver(None, 100, 1.0).create_logits_processor()
+        inds, toks, scores = sampler(draft_tokens=draft, advanced_tokens=adv_tokens.clone(), draft_prob=q,
+                                     advanced_prob=p, logits_processor=proc, logits_warper=None,
+                                     all_collected_input_ids=ctx)
+        name = f"c{ci}"
+        out[f"{name}.ctx"] = ctx.numpy()
+        out[f"{name}.first_misaligned"] = np.array(inds)
+        out[f"{name}.tokens"] = toks.numpy()
+        out[f"{name}.adv_tokens"] = adv_tokens.numpy()
+        out[f"{name}.draft"] = draft.numpy()
+        meta.append(dict(name=name, V=V, L=L, mode=mode, grammar=grammar, pq_seed=9000 + ci, adv_seed=9500 + ci,
+                         noise_seed=9900 + ci))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "fn_speculative_sampler.npz"), **out)
+    print("fn_speculative_sampler ok", [(m["mode"], int(out[m["name"] + ".first_misaligned"][0])) for m in meta])
+
+
+def gen_fn_reguess():
+    out, meta = {}, []
+    img_vocab = torch.arange(4, 8196)
+    for ci, n in enumerate([15, 7, 0, 1]):
+        torch.manual_seed(1234 + ci)   # the reference draws from the GLOBAL CPU generator (JL:505)
+        ids = torch.zeros(1, 9, dtype=torch.long)
+        tcs = torch.zeros(1, 2, 9216)
+        toks, scores = JL.get_multi_token_for_preparation(img_vocab, n, ids, tcs, "cpu", multi_token_init_scheme="random")
+        out[f"c{ci}.tokens"] = toks.numpy()
+        assert scores.shape == (1, n, 9216) and float(scores.sum()) == n
+        if n:
+            assert bool((scores[0].argmax(-1) == toks[0]).all())
+        meta.append(dict(name=f"c{ci}", n=n, global_seed=1234 + ci))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "fn_reguess.npz"), **out)
+    print("fn_reguess ok")
+
+
+# ----------------------------------------------------------------------------------------------
+# whole-loop traces
+# ----------------------------------------------------------------------------------------------
+class Tracer:
+    """Wraps the reference's module-level hot-path functions to log per-iteration integers."""
+
+    def __init__(self):
+        self.windows, self.sampled, self.matched, self.final = [], [], [], []
+
+    def install(self):
+        self._pm, self._s2t = JL.prefix_matching_next_tokens, JL.sampling_logits2tokens
+        tr = self
+
+        def s2t(*a, **k):
+            toks, probs = tr._s2t(*a, **k)
+            tr.sampled.append(toks[0].tolist())
+            return toks, probs
+
+        def pm(model_input_ids, next_tokens, next_token_scores, **k):
+            r = tr._pm(model_input_ids, next_tokens, next_token_scores, **k)
+            tr.windows.append(model_input_ids[0].tolist())
+            tr.matched.append(int(r[0]))
+            tr.final.append(r[1][0].tolist())
+            return r
+
+        JL.sampling_logits2tokens, JL.prefix_matching_next_tokens = s2t, pm
+
+    def remove(self):
+        JL.sampling_logits2tokens, JL.prefix_matching_next_tokens = self._s2t, self._pm
+
+    def pack(self, prefix, out):
+        def ragged(lst):
+            flat = np.array([x for r in lst for x in r], dtype=np.int64)
+            offs = np.cumsum([0] + [len(r) for r in lst]).astype(np.int64)
+            return flat, offs
+        for key in ("windows", "sampled", "final"):
+            f, o = ragged(getattr(self, key))
+            out[f"{prefix}.{key}"], out[f"{prefix}.{key}_offs"] = f, o
+        out[f"{prefix}.matched"] = np.array(self.matched, dtype=np.int64)
+
+
+def gen_loop_llamagen():
+    from llamagen.llamagen import Transformer, ModelArgs
+    from llamagen.llamagen_solver import LlamaGenSolver, renew_llamagen
+    out, meta = {}, []
+    # (name, scheme, seed, class_id, cfg, top_k, top_p, window, latent, embed_token_scale)
+    runs = [("spec_s7", "speculative_jacobi", 7, 207, 4.0, 1000, 1.0, 16, 16, 0.25),
+            ("spec_s11_w8", "speculative_jacobi", 11, 3, 2.0, 200, 1.0, 8, 16, 0.5),
+            ("jacobi_s7", "jacobi", 7, 207, 4.0, 1000, 1.0, 16, 16, 0.25),
+            ("spec_s5_topp", "speculative_jacobi", 5, 42, 4.0, 1000, 0.95, 16, 8, 0.25),
+            ("spec_s13_floor", "speculative_jacobi", 13, 999, 4.0, 1000, 1.0, 16, 8, 1.0)]
+    for name, scheme, seed, class_id, cfg, top_k, top_p, window, latent, ets in runs:
+        args = dict(dim=64, n_layer=2, n_head=4, vocab_size=16384, block_size=latent * latent, cls_token_num=1,
+                    model_type="c2i", num_classes=1000, token_dropout_p=0.0, attn_dropout_p=0.0, resid_dropout_p=0.0,
+                    ffn_dropout_p=0.0, drop_path_rate=0.0)
+        model = Transformer(ModelArgs(**args)).eval()
+        synthetic.fill_state_dict(model, seed=17, embed_token_scale=ets)
+        jac = dict(jacobi_loop_interval_l=1, jacobi_loop_interval_r=latent * latent - window - 2,
+                   max_num_new_tokens=window, guidance_scale=cfg, seed=seed, multi_token_init_scheme="random",
+                   do_cfg=True, image_top_k=top_k, text_top_k=10, prefix_token_sampler_scheme=scheme,
+                   use_chameleon_tokenizer=False)
+        model.config.is_encoder_decoder = False
+        model.__class__ = renew_llamagen(model.__class__)
+        model._init_new_params(**jac)
+        model.__class__ = type("M", (CompatMixin, JL.renew_sampler(model.__class__)), {})
+        model._init_new_params(**jac)
+        model.img_vocab = torch.arange(4, 8196)
+        solver = LlamaGenSolver(model=model, image_top_k=top_k, image_top_p=top_p)
+        tr = Tracer()
+        tr.install()
+        torch.manual_seed(seed)   # prefill() samples from the GLOBAL generator (LS:81)
+        try:
+            toks = solver.generate(torch.tensor([class_id]), latent * latent, None, cfg_scale=cfg, temperature=1.0,
+                                   top_k=top_k, top_p=top_p, sample_logits=True)
+        finally:
+            tr.remove()
+        out[f"{name}.tokens"] = toks.numpy()
+        tr.pack(name, out)
+        meta.append(dict(name=name, model_args=args, weight_seed=17, embed_token_scale=ets, jacobi=jac,
+                         class_id=class_id, cfg=cfg,
+                         top_k=top_k, top_p=top_p, latent=latent, nfe=len(tr.matched)))
+        print("loop_llamagen", name, "tokens", toks.shape, "NFE", len(tr.matched), "first", toks[0, :8].tolist())
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "loop_llamagen.npz"), **out)
+
+
+def gen_loop_lumina():
+    from model.chameleon import ChameleonForConditionalGeneration, ChameleonConfig
+    from transformers import GenerationConfig
+    from transformers.generation.stopping_criteria import StoppingCriteriaList, EosTokenCriteria, MaxLengthCriteria
+    out, meta = {}, []
+    # (name, scheme, seed, hg, wg, window, l, r, P, kvh, embed_token_scale)
+    runs = [("spec_s3", "speculative_jacobi", 3, 4, 4, 16, 3, 8 * 9 - 10, 12, 4, 0.25),
+            ("spec_s9_w8_gqa", "speculative_jacobi", 9, 3, 5, 8, 3, 6 * 11 - 6, 20, 2, 0.5),
+            ("jacobi_s3", "jacobi", 3, 4, 4, 16, 3, 8 * 9 - 10, 12, 4, 0.25),
+            ("spec_s4_tail", "speculative_jacobi", 4, 4, 4, 16, 1, 8 * 9 + 1, 12, 4, 0.25)]
+    for name, scheme, seed, hg, wg, window, l, r, P, kvh, ets in runs:
+        V = 9216
+        cfg_kw = dict(vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=kvh, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0,
+                      swin_norm=False, mask_image_logits=False, vocabulary_map={"<image>": 8711},
+                      vq_config=dict(embed_dim=32, num_embeddings=64, double_latent=False, latent_channels=32,
+                                     resolution=32, in_channels=3, base_channels=32, channel_multiplier=[1, 1],
+                                     num_res_blocks=1, attn_resolutions=None, dropout=0.0, attn_type="vanilla"),
+                      attn_implementation="sdpa")
+        cfg = ChameleonConfig(**cfg_kw)
+        cfg.rope_scaling = None
+        model = ChameleonForConditionalGeneration(cfg).eval()
+        synthetic.fill_state_dict(model, seed=23, skip_prefixes=("model.vqmodel.",), embed_token_scale=ets)
+        jac = dict(jacobi_loop_interval_l=l, jacobi_loop_interval_r=r, max_num_new_tokens=window, guidance_scale=3.0,
+                   seed=seed, multi_token_init_scheme="random", do_cfg=True, image_top_k=2000, text_top_k=10,
+                   prefix_token_sampler_scheme=scheme, use_chameleon_tokenizer=False)
+        model.__class__ = type("M", (CompatMixin, JL.renew_sampler(model.__class__)), {})
+        model._init_new_params(**jac)
+        model.img_vocab = torch.arange(4, 8196)
+        model.model.__class__ = JL.renew_backbone(model.model.__class__)
+        procs = LogitsProcessorList([
+            LP.MultiTokensVLLogitsProcessor(image_start_token_id=8197, image_end_token_id=8196,
+                                            image_next_line_token_id=8803, patch_size=32, voc_size=V),
+            LP.MultiTokensInterleavedTopKLogitsWarper(image_top_k=2000, text_top_k=10,
+                                                      image_start_token_id=8197, image_end_token_id=8196)])
+        prompt = torch.cat([synthetic.synthetic_prompt(P - 3, seed, lo=8900, hi=9200),
+                            torch.tensor([[8197, 8804 + hg, 8804 + wg]])], dim=1)
+        n_img = (2 * wg + 1) * 2 * hg
+        max_len = P + n_img + 1 + 4
+        stopping = StoppingCriteriaList([EosTokenCriteria([8196]), MaxLengthCriteria(max_len)])
+        gc = GenerationConfig(max_length=max_len, do_sample=True, temperature=1.0, top_k=None)
+        gc._pad_token_tensor = torch.tensor(0)
+        tr = Tracer()
+        tr.install()
+        try:
+            seq = model._sample(input_ids=prompt, logits_processor=procs, stopping_criteria=stopping,
+                                generation_config=gc, synced_gpus=False, streamer=None,
+                                attention_mask=torch.ones_like(prompt), past_key_values=LegacyCache(), use_cache=True)
+        finally:
+            tr.remove()
+        out[f"{name}.prompt"] = prompt.numpy()
+        out[f"{name}.sequence"] = seq.numpy()
+        tr.pack(name, out)
+        cfg_kw.pop("attn_implementation")
+        meta.append(dict(name=name, config=cfg_kw, weight_seed=23, embed_token_scale=ets, jacobi=jac, P=P, hg=hg,
+                         wg=wg, max_len=max_len,
+                         nfe=len(tr.matched)))
+        gen = seq[0, P:].tolist()
+        print("loop_lumina", name, "generated", len(gen), "NFE", len(tr.matched), "tail", gen[-4:],
+              "eol@", [i for i, t in enumerate(gen) if t == 8803][:4])
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "loop_lumina.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["fn", "loops"]
+    if "fn" in which:
+        gen_fn_logits2tokens_lumina()
+        gen_fn_logits2tokens_llamagen()
+        gen_fn_emu3_grammar()
+        gen_fn_anole_grammar()
+        gen_fn_speculative_sampler()
+        gen_fn_reguess()
+    if "loops" in which:
+        gen_loop_llamagen()
+        gen_loop_lumina()

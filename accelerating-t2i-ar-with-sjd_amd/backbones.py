@@ -1,0 +1,352 @@
+"""PyTorch(-ROCm) transformer backbones for the SJD engine.
+
+Per north_star the transformer forward stays on PyTorch-ROCm (GEMMs -> hipBLASLt); what is hand
+written is the draft-window attention + KV append (kernels K1/K3), which plug in through the
+``attn`` callable of every layer.  There is NO torch/CPU attention in this package: the default
+backend is the HIP one (ops.HipWindowAttention) and it raises if libsjd_hip.so is missing.  Tests
+that need a CPU forward inject oracle.attention_ref.OracleWindowAttention explicitly.
+
+State-dict keys follow the reference checkpoints so real weights load unchanged:
+  * LlamaGenBackbone   <- reference llamagen/llamagen.py:297-419 (Transformer), RoPE :441-467
+  * ChameleonBackbone  <- reference lumina_mgpt/model/chameleon/modeling_chameleon.py:59-82 (RMSNorm),
+                          :198-219 (per-head QK LayerNorm), :144-178 (RoPE), :499-581 (attention),
+                          :593-668 (decoder layer), :1494-1561 (lm_head, fp32 logits)
+    with qk_norm=False / n_kv_heads<n_heads it is the Llama-style Emu3 LM
+    (reference emu3/mllm/configuration_emu3.py:130-152) and, unchanged, HF Chameleon (Anole).
+
+All backbones expose one hot-path entry point:
+    forward_window(tokens [B,n] int64, positions [B,n] int64, kv_len, key_start [B]) -> logits [B,n,V] fp32
+which writes the n new K/V rows of every layer at cache rows [kv_len, kv_len+n) and attends causally
+inside the window; ``key_start[b]`` hides cache rows < key_start[b] (uncond prompt / left padding).
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class StaticKVCache:
+    """[n_layers, B, H_kv, S_max, D]: one contiguous D-row per (layer, batch, head, position)."""
+
+    def __init__(self, n_layers, batch, n_kv_heads, s_max, head_dim, dtype, device):
+        shape = (n_layers, batch, n_kv_heads, s_max, head_dim)
+        self.k = torch.zeros(shape, dtype=dtype, device=device)
+        self.v = torch.zeros(shape, dtype=dtype, device=device)
+        self.s_max = s_max
+
+    def nbytes(self):
+        return self.k.numel() * self.k.element_size() * 2
+
+
+# ------------------------------------------------------------------------------------------ LlamaGen
+@dataclass
+class LlamaGenArgs:
+    dim: int = 768
+    n_layer: int = 12
+    n_head: int = 12
+    n_kv_head: Optional[int] = None
+    multiple_of: int = 256
+    ffn_dim_multiplier: Optional[float] = None
+    rope_base: float = 10000
+    norm_eps: float = 1e-5
+    num_classes: int = 1000
+    caption_dim: int = 2048
+    class_dropout_prob: float = 0.1
+    model_type: str = "c2i"
+    vocab_size: int = 16384
+    cls_token_num: int = 1
+    block_size: int = 256
+
+
+class _RMSNorm(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):   # llamagen.py:176-181
+        xf = x.float()
+        out = (xf * torch.rsqrt(torch.mean(xf * xf, dim=-1, keepdim=True) + self.eps)).type_as(x)
+        return out * self.weight
+
+
+def _rope_2d_table(grid_size, n_elem, base, cls_token_num):
+    """llamagen.py:441-454: (cls_token_num + grid^2, head_dim//2, 2) cos/sin table, zeros for the cond rows."""
+    half_dim = n_elem // 2
+    freqs = 1.0 / (base ** (torch.arange(0, half_dim, 2)[: (half_dim // 2)].float() / half_dim))
+    t = torch.arange(grid_size)
+    freqs = torch.outer(t, freqs)
+    grid = torch.concat([freqs[:, None, :].expand(-1, grid_size, -1), freqs[None, :, :].expand(grid_size, -1, -1)], dim=-1)
+    cache = torch.stack([torch.cos(grid), torch.sin(grid)], dim=-1).flatten(0, 1)
+    return torch.cat([torch.zeros(cls_token_num, n_elem // 2, 2), cache])
+
+
+def _apply_rope_interleaved(x, freqs):
+    """llamagen.py:457-467.  x [B,n,H,D], freqs [B or 1,n,D/2,2]"""
+    xs = x.float().reshape(*x.shape[:-1], -1, 2)
+    fc = freqs.view(freqs.shape[0], xs.size(1), 1, xs.size(3), 2)
+    out = torch.stack([xs[..., 0] * fc[..., 0] - xs[..., 1] * fc[..., 1],
+                       xs[..., 1] * fc[..., 0] + xs[..., 0] * fc[..., 1]], dim=-1)
+    return out.flatten(3).type_as(x)
+
+
+class _LGAttention(nn.Module):
+    def __init__(self, a: LlamaGenArgs):
+        super().__init__()
+        self.n_head = a.n_head
+        self.n_kv_head = a.n_kv_head or a.n_head
+        self.head_dim = a.dim // a.n_head
+        self.dim = a.dim
+        self.wqkv = nn.Linear(a.dim, (self.n_head + 2 * self.n_kv_head) * self.head_dim, bias=False)
+        self.wo = nn.Linear(a.dim, a.dim, bias=False)
+
+
+class _LGFeedForward(nn.Module):
+    def __init__(self, a: LlamaGenArgs):
+        super().__init__()
+        hidden = int(2 * (4 * a.dim) / 3)
+        if a.ffn_dim_multiplier is not None:
+            hidden = int(a.ffn_dim_multiplier * hidden)
+        hidden = hidden if hidden % a.multiple_of == 0 else hidden + a.multiple_of - (hidden % a.multiple_of)
+        self.w1 = nn.Linear(a.dim, hidden, bias=False)
+        self.w3 = nn.Linear(a.dim, hidden, bias=False)
+        self.w2 = nn.Linear(hidden, a.dim, bias=False)
+
+    def forward(self, x):
+        return self.w2(F.silu(self.w1(x)) * self.w3(x))
+
+
+class _LGBlock(nn.Module):
+    def __init__(self, a: LlamaGenArgs):
+        super().__init__()
+        self.attention = _LGAttention(a)
+        self.feed_forward = _LGFeedForward(a)
+        self.attention_norm = _RMSNorm(a.dim, a.norm_eps)
+        self.ffn_norm = _RMSNorm(a.dim, a.norm_eps)
+
+
+class _LabelEmbedder(nn.Module):
+    def __init__(self, num_classes, hidden, dropout_prob):
+        super().__init__()
+        self.embedding_table = nn.Embedding(num_classes + int(dropout_prob > 0), hidden)
+        self.num_classes = num_classes
+
+
+class _CapMLP(nn.Module):
+    def __init__(self, cin, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(cin, hidden, bias=False)
+        self.fc2 = nn.Linear(hidden, hidden, bias=False)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x), approximate="tanh"))
+
+
+class _CaptionEmbedder(nn.Module):
+    def __init__(self, cin, hidden, token_num):
+        super().__init__()
+        self.cap_proj = _CapMLP(cin, hidden)
+        self.register_buffer("uncond_embedding", torch.zeros(token_num, cin))
+
+
+class LlamaGenBackbone(nn.Module):
+    def __init__(self, args: LlamaGenArgs, attn=None):
+        super().__init__()
+        self.args = args
+        self.vocab_size = args.vocab_size
+        self.num_classes = args.num_classes
+        self.model_type = args.model_type
+        self.cls_token_num = args.cls_token_num
+        if args.model_type == "c2i":
+            self.cls_embedding = _LabelEmbedder(args.num_classes, args.dim, args.class_dropout_prob)
+        else:
+            self.cls_embedding = _CaptionEmbedder(args.caption_dim, args.dim, args.cls_token_num)
+        self.tok_embeddings = nn.Embedding(args.vocab_size, args.dim)
+        self.layers = nn.ModuleList([_LGBlock(args) for _ in range(args.n_layer)])
+        self.norm = _RMSNorm(args.dim, args.norm_eps)
+        self.output = nn.Linear(args.dim, args.vocab_size, bias=False)
+        grid = int(args.block_size ** 0.5)
+        assert grid * grid == args.block_size
+        self.freqs = _rope_2d_table(grid, args.dim // args.n_head, args.rope_base, args.cls_token_num)
+        self.attn = attn
+        self.cache = None
+        self.n_heads, self.n_kv_heads = args.n_head, args.n_kv_head or args.n_head
+        self.head_dim = args.dim // args.n_head
+        self.n_layers = args.n_layer
+
+    def setup_cache(self, batch, s_max, dtype=None, device=None):
+        p = self.tok_embeddings.weight
+        self.cache = StaticKVCache(self.n_layers, batch, self.n_kv_heads, s_max, self.head_dim, dtype or p.dtype,
+                                   device or p.device)
+        self.freqs = self.freqs.to(p.device)
+        return self.cache
+
+    def embed_condition(self, cond):
+        """c2i: class ids [B] -> [B,1,dim]; t2i: caption embeddings [B,T,caption_dim] -> [B,T,dim] (llamagen.py:111-116,143-148)"""
+        if self.model_type == "c2i":
+            return self.cls_embedding.embedding_table(cond).unsqueeze(1)[:, : self.cls_token_num]
+        return self.cls_embedding.cap_proj(cond)[:, : self.cls_token_num]
+
+    def forward_embeds(self, h, positions, kv_len, key_start):
+        B, n, _ = h.shape
+        freqs = self.freqs[positions]                     # [B,n,D/2,2]
+        for li, layer in enumerate(self.layers):
+            a = layer.attention
+            x = layer.attention_norm(h)
+            q, k, v = a.wqkv(x).split([a.dim, a.n_kv_head * a.head_dim, a.n_kv_head * a.head_dim], dim=-1)
+            q = _apply_rope_interleaved(q.view(B, n, a.n_head, a.head_dim), freqs)
+            k = _apply_rope_interleaved(k.view(B, n, a.n_kv_head, a.head_dim), freqs)
+            v = v.view(B, n, a.n_kv_head, a.head_dim)
+            o = self.attn(li, q, k, v, self.cache, kv_len, key_start)
+            h = h + a.wo(o.reshape(B, n, a.dim))
+            h = h + layer.feed_forward(layer.ffn_norm(h))
+        return self.output(self.norm(h)).float()
+
+    def forward_window(self, tokens, positions, kv_len, key_start):
+        return self.forward_embeds(self.tok_embeddings(tokens), positions, kv_len, key_start)
+
+
+# ------------------------------------------------------------------------------------------ Chameleon / Llama
+@dataclass
+class ChameleonArgs:
+    vocab_size: int = 65536
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 32
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    qk_norm: bool = True          # Chameleon/Lumina/Anole: True; Emu3 (Llama): False
+    max_position_embeddings: int = 4096
+
+
+class _CRMSNorm(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.variance_epsilon = eps
+
+    def forward(self, x):       # modeling_chameleon.py:68-73
+        dt = x.dtype
+        xf = x.to(torch.float32)
+        xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + self.variance_epsilon)
+        return self.weight * xf.to(dt)
+
+
+class _HeadLayerNorm(nn.Module):
+    """ChameleonLayerNorm (modeling_chameleon.py:198-219): stats over head_dim, per-head gamma/beta.
+    weight/bias are stored [model_parallel_size=1, head_dim] and repeat-interleaved over heads."""
+
+    def __init__(self, head_dim, n_heads):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(1, head_dim))
+        self.bias = nn.Parameter(torch.zeros(1, head_dim))
+        self.head_dim, self.n_heads = head_dim, n_heads
+
+    def forward(self, x):       # x [..., n_heads, head_dim]
+        x = F.layer_norm(x, (self.head_dim,), None, None, eps=1e-5)
+        return x * self.weight.repeat_interleave(self.n_heads, dim=0) + self.bias.repeat_interleave(self.n_heads, dim=0)
+
+
+class _CAttention(nn.Module):
+    def __init__(self, a: ChameleonArgs):
+        super().__init__()
+        self.num_heads, self.num_kv = a.num_attention_heads, a.num_key_value_heads
+        self.head_dim = a.hidden_size // a.num_attention_heads
+        self.q_proj = nn.Linear(a.hidden_size, self.num_heads * self.head_dim, bias=False)
+        self.k_proj = nn.Linear(a.hidden_size, self.num_kv * self.head_dim, bias=False)
+        self.v_proj = nn.Linear(a.hidden_size, self.num_kv * self.head_dim, bias=False)
+        self.o_proj = nn.Linear(a.hidden_size, a.hidden_size, bias=False)
+        if a.qk_norm:
+            self.q_norm = _HeadLayerNorm(self.head_dim, self.num_heads)
+            self.k_norm = _HeadLayerNorm(self.head_dim, self.num_kv)
+
+
+class _CMLP(nn.Module):
+    def __init__(self, a: ChameleonArgs):
+        super().__init__()
+        self.gate_proj = nn.Linear(a.hidden_size, a.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(a.hidden_size, a.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(a.intermediate_size, a.hidden_size, bias=False)
+
+    def forward(self, x):
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class _CLayer(nn.Module):
+    def __init__(self, a: ChameleonArgs):
+        super().__init__()
+        self.self_attn = _CAttention(a)
+        self.mlp = _CMLP(a)
+        self.input_layernorm = _CRMSNorm(a.hidden_size, a.rms_norm_eps)
+        self.post_attention_layernorm = _CRMSNorm(a.hidden_size, a.rms_norm_eps)
+
+
+class _CModel(nn.Module):
+    def __init__(self, a: ChameleonArgs):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(a.vocab_size, a.hidden_size)
+        self.layers = nn.ModuleList([_CLayer(a) for _ in range(a.num_hidden_layers)])
+        self.norm = _CRMSNorm(a.hidden_size, a.rms_norm_eps)
+
+
+def _rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+class ChameleonBackbone(nn.Module):
+    def __init__(self, args: ChameleonArgs, attn=None):
+        super().__init__()
+        self.args = args
+        self.model = _CModel(args)
+        self.lm_head = nn.Linear(args.hidden_size, args.vocab_size, bias=False)
+        self.vocab_size = args.vocab_size
+        self.n_layers = args.num_hidden_layers
+        self.n_heads, self.n_kv_heads = args.num_attention_heads, args.num_key_value_heads
+        self.head_dim = args.hidden_size // args.num_attention_heads
+        inv = 1.0 / (args.rope_theta ** (torch.arange(0, self.head_dim, 2, dtype=torch.int64).float() / self.head_dim))
+        self.register_buffer("inv_freq", inv, persistent=False)
+        self.attn = attn
+        self.cache = None
+
+    def setup_cache(self, batch, s_max, dtype=None, device=None):
+        p = self.lm_head.weight
+        self.cache = StaticKVCache(self.n_layers, batch, self.n_kv_heads, s_max, self.head_dim, dtype or p.dtype,
+                                   device or p.device)
+        return self.cache
+
+    def _rope(self, positions, dtype):   # modeling_chameleon.py:97-110: fp32 angles, cast to activation dtype
+        freqs = positions[:, :, None].float() * self.inv_freq.float()[None, None, :]
+        emb = torch.cat((freqs, freqs), dim=-1)
+        return emb.cos().to(dtype)[:, :, None, :], emb.sin().to(dtype)[:, :, None, :]
+
+    def forward_window(self, tokens, positions, kv_len, key_start):
+        B, n = tokens.shape
+        h = self.model.embed_tokens(tokens)
+        cos, sin = self._rope(positions, h.dtype)
+        for li, layer in enumerate(self.model.layers):
+            a = layer.self_attn
+            x = layer.input_layernorm(h)
+            q = a.q_proj(x).view(B, n, a.num_heads, a.head_dim)
+            k = a.k_proj(x).view(B, n, a.num_kv, a.head_dim)
+            v = a.v_proj(x).view(B, n, a.num_kv, a.head_dim)
+            if self.args.qk_norm:
+                q, k = a.q_norm(q), a.k_norm(k)
+            q = q * cos + _rotate_half(q) * sin          # modeling_chameleon.py:175-176
+            k = k * cos + _rotate_half(k) * sin
+            o = self.attn(li, q, k, v, self.cache, kv_len, key_start)
+            h = h + a.o_proj(o.reshape(B, n, -1))
+            h = h + layer.mlp(layer.post_attention_layernorm(h))
+        return self.lm_head(self.model.norm(h)).float()   # modeling_chameleon.py:1560-1561
+
+
+LUMINA_7B = ChameleonArgs()
+EMU3_8B = ChameleonArgs(vocab_size=184622, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                        num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=1000000.0,
+                        qk_norm=False, max_position_embeddings=9216)
+LLAMAGEN_B = LlamaGenArgs(dim=768, n_layer=12, n_head=12)

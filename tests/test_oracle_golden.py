@@ -1,0 +1,206 @@
+"""Pins the CPU oracle (oracle/) against the golden vectors produced by importing the reference
+(tests/golden/make_golden.py).  CPU only.
+
+Tolerances: token ids / accept lengths bit-exact; probabilities |dp| <= 1e-6 + 1e-5*p (the oracle's
+canonical softmax keeps 4096 partial sums, torch's vectorised sum over V terms carries ~sqrt(V)*eps
+relative error; north_star asks logits within 1e-3).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sjd_oracle as O
+from oracle import loop as OL
+from oracle.attention_ref import OracleWindowAttention
+from tests.helpers import (llamagen_forward_fn, lumina_forward_fn, make_llamagen, make_chameleon, make_pq)
+
+P_ATOL, P_RTOL = 1e-6, 1e-5
+
+
+def load(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name))
+    return d, json.loads(str(d["meta"]))
+
+
+def gen_inputs(m, key_logits="logits_seed", key_noise="noise_seed", ctx_gen=None):
+    g = torch.Generator().manual_seed(m[key_logits]) if ctx_gen is None else ctx_gen
+    logits = torch.randn(2, m["nrows"], m["V"], generator=g) * m["logits_scale"]
+    noise = torch.empty(m["nrows"], m["V"]).exponential_(generator=torch.Generator().manual_seed(m[key_noise]))
+    return logits.numpy(), noise.numpy()
+
+
+def check_probs(d, name, toks, probs, cols):
+    assert toks.tolist() == d[f"{name}.tokens"][0].tolist()
+    assert ((probs > 0).sum(-1) == d[f"{name}.nnz"]).all()
+    np.testing.assert_allclose(probs.max(-1), d[f"{name}.pmax"], atol=P_ATOL, rtol=P_RTOL)
+    np.testing.assert_allclose(probs[:, cols], d[f"{name}.p_cols"], atol=P_ATOL, rtol=P_RTOL)
+    np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-5)
+
+
+def test_canonical_primitives():
+    xs = np.linspace(-90, 0, 2001, dtype=np.float32)
+    got = np.array([O.expf(x) for x in xs])
+    ref = np.exp(xs.astype(np.float64))
+    assert np.all(np.abs(got - ref) <= 2e-7 * ref + 1e-45) or np.all(got[xs < -87] == 0)
+    ok = xs >= -87
+    assert np.max(np.abs(got[ok] - ref[ok]) / ref[ok]) < 3e-7
+    assert O.expf(0.0) == 1.0 and O.expf(-1000.0) == 0.0 and O.expf(float("-inf")) == 0.0
+    rng = np.random.default_rng(0)
+    v = rng.random(65536, dtype=np.float32)
+    assert abs(O.canonical_sum(v) - float(v.astype(np.float64).sum())) < 1e-2
+    assert O.canonical_sum(np.zeros(5, np.float32)) == 0.0
+
+
+def test_logits2tokens_lumina(golden_dir):
+    d, meta = load(golden_dir, "fn_logits2tokens_lumina.npz")
+    cols = d["cols"]
+    for m in meta:
+        name = m["name"]
+        ctx = d[f"{name}.ctx"][0].tolist()
+        logits, noise = gen_inputs(m)
+        rules = O.lumina_rules(ctx, m["nrows"], m["image_top_k"], m["text_top_k"])
+        assert O.lumina_force_no_cfg(ctx) == m["is_force_no_cfg"]
+        u = None if m["is_force_no_cfg"] else logits[1]
+        toks, probs = O.logits_to_probs_sample(logits[0], u, m["guidance_scale"], rules, noise)
+        check_probs(d, name, toks, probs, cols)
+        np.testing.assert_allclose(probs[np.arange(len(toks)), toks], d[f"{name}.p_at_tok"], atol=P_ATOL, rtol=P_RTOL)
+
+
+def test_logits2tokens_llamagen(golden_dir):
+    d, meta = load(golden_dir, "fn_logits2tokens_llamagen.npz")
+    for m in meta:
+        logits, noise = gen_inputs(m)
+        rules = O.llamagen_rules([], m["nrows"], m["top_k"], m["top_p"])
+        toks, probs = O.logits_to_probs_sample(logits[0], logits[1], m["guidance_scale"], rules, noise)
+        check_probs(d, m["name"], toks, probs, d["cols"])
+
+
+def test_emu3_grammar(golden_dir):
+    d, meta = load(golden_dir, "fn_emu3_grammar.npz")
+    for m in meta:
+        name = m["name"]
+        ctx = d[f"{name}.ctx"][0].tolist()
+        g = torch.Generator().manual_seed(m["ctx_seed"])
+        torch.randint(300, 2000, (1, 9), generator=g)
+        torch.randint(m["vis_lo"], m["vis_lo"] + m["vis_n"], (1, m["n_after_img"]), generator=g)
+        logits, noise = gen_inputs(m, ctx_gen=g)
+        rules = O.emu3_rules(ctx, m["nrows"], m["H"], m["W"], m["vis_lo"], m["vis_n"], m["img_token"], m["eoi_token"],
+                             m["eos_token"], m["eol_token"], m["eof_token"], m["pad_token"], m["top_k"])
+        toks, probs = O.logits_to_probs_sample(logits[0], logits[1], m["guidance_scale"], rules, noise)
+        check_probs(d, name, toks, probs, d["cols"])
+
+
+def test_anole_grammar(golden_dir):
+    d, meta = load(golden_dir, "fn_anole_grammar.npz")
+    for m in meta:
+        name = m["name"]
+        ctx = d[f"{name}.ctx"][0].tolist()
+        g = torch.Generator().manual_seed(m["logits_seed"])
+        torch.randint(8900, 9200, (1, m["prompt_len"]), generator=g)
+        if m["n_after_boi"] >= 0:
+            torch.randint(4, 8196, (1, m["n_after_boi"]), generator=g)
+        logits, noise = gen_inputs(m, ctx_gen=g)
+        rules = O.anole_rules(ctx, m["nrows"], m["V"], m["prompt_len"], m["max_length"], m["image_seq_length"],
+                              m["boi"], m["eoi"], m["eos"], top_k=m["top_k"])
+        toks, probs = O.logits_to_probs_sample(logits[0], logits[1], m["guidance_scale"], rules, noise)
+        check_probs(d, name, toks, probs, d["cols"])
+
+
+def test_speculative_sampler(golden_dir):
+    d, meta = load(golden_dir, "fn_speculative_sampler.npz")
+    for m in meta:
+        name, V, L = m["name"], m["V"], m["L"]
+        p, q, draft = make_pq(V, L, m["pq_seed"], m["mode"])
+        assert draft[0].tolist() == d[f"{name}.draft"][0].tolist()
+        adv = d[f"{name}.adv_tokens"][0]
+        gen = torch.Generator().manual_seed(m["noise_seed"])
+        rs = torch.rand((1, L, V), generator=gen)[0].numpy()
+        e2 = torch.empty(1, V).exponential_(generator=gen)[0].numpy()
+        ctx = d[f"{name}.ctx"][0].tolist()
+        win = draft[0].tolist()
+        if m["grammar"] == "lumina":
+            rfn = lambda c: O.lumina_rules(c, 1, 2000, 10)[0]
+        elif m["grammar"] == "llamagen":
+            rfn = lambda c: O.llamagen_rules(c, 1, 100, 1.0)[0]
+        else:
+            rfn = lambda c: O.rule()
+        resid = [rfn(ctx + win[1:i]) for i in range(1, L)]
+        q_rows = [q[0, i].numpy() for i in range(L)]
+        mm, toks, rej = O.verify_accept(win, adv, p[0].numpy(), q_rows, rs, resid, e2)
+        assert mm == int(d[f"{name}.first_misaligned"][0]), name
+        assert toks.tolist() == d[f"{name}.tokens"][0].tolist(), name
+        assert rej == (mm < L) or mm == L
+        # implicit one-hot rows (q_rows[i] is None) must behave exactly like materialised one-hot rows
+        onehot = [(q[0, i] == 1).any().item() and float(q[0, i].sum()) == 1.0 for i in range(L)]
+        q_imp = [None if (onehot[i] and i > 0) else q_rows[i] for i in range(L)]
+        mm2, toks2, _ = O.verify_accept(win, adv, p[0].numpy(), q_imp, rs, resid, e2)
+        assert (mm2, toks2.tolist()) == (mm, toks.tolist())
+
+
+def test_reguess(golden_dir):
+    d, meta = load(golden_dir, "fn_reguess.npz")
+    for m in meta:
+        torch.manual_seed(m["global_seed"])
+        toks = (4 + torch.randint(0, 8192, (1, m["n"]))).numpy()
+        assert toks.tolist() == d[f"{m['name']}.tokens"].tolist()
+
+
+def unpack(d, name, key):
+    flat, offs = d[f"{name}.{key}"], d[f"{name}.{key}_offs"]
+    return [flat[offs[i]:offs[i + 1]].tolist() for i in range(len(offs) - 1)]
+
+
+def check_trace(d, name, tr):
+    ref_w, ref_s, ref_f = unpack(d, name, "windows"), unpack(d, name, "sampled"), unpack(d, name, "final")
+    ref_m = d[f"{name}.matched"].tolist()
+    for it in range(min(len(ref_m), len(tr.matched))):
+        assert tr.windows[it] == ref_w[it], f"{name} iter {it} window"
+        assert tr.sampled[it] == ref_s[it], f"{name} iter {it} sampled"
+        assert tr.matched[it] == ref_m[it], f"{name} iter {it} matched"
+        assert tr.final[it] == ref_f[it], f"{name} iter {it} final"
+    assert len(tr.matched) == len(ref_m)
+
+
+def test_loop_llamagen(golden_dir):
+    d, meta = load(golden_dir, "loop_llamagen.npz")
+    for m in meta:
+        name = m["name"]
+        model = make_llamagen(m["model_args"], m["weight_seed"], m["embed_token_scale"], OracleWindowAttention())
+        latent2 = m["latent"] ** 2
+        fwd, first_tok = llamagen_forward_fn(model, m["class_id"], m["cfg"], m["top_k"], m["top_p"], latent2,
+                                             m["jacobi"]["seed"])
+        jac = m["jacobi"]
+        cfg = OL.LoopConfig(jacobi_loop_interval_l=jac["jacobi_loop_interval_l"],
+                            jacobi_loop_interval_r=jac["jacobi_loop_interval_r"],
+                            max_num_new_tokens=jac["max_num_new_tokens"], guidance_scale=jac["guidance_scale"],
+                            seed=jac["seed"], do_cfg=jac["do_cfg"],
+                            prefix_token_sampler_scheme=jac["prefix_token_sampler_scheme"], max_length=latent2)
+        seq, tr = OL.run([first_tok], fwd, lambda c, n: O.llamagen_rules(c, n, m["top_k"], m["top_p"]), cfg,
+                         m["model_args"]["vocab_size"])
+        check_trace(d, name, tr)
+        assert seq[-latent2:] == d[f"{name}.tokens"][0].tolist(), name
+        assert len(tr.matched) == m["nfe"]
+
+
+def test_loop_lumina(golden_dir):
+    d, meta = load(golden_dir, "loop_lumina.npz")
+    for m in meta:
+        name = m["name"]
+        model = make_chameleon(m["config"], m["weight_seed"], m["embed_token_scale"], OracleWindowAttention())
+        prompt = d[f"{name}.prompt"][0].tolist()
+        fwd = lumina_forward_fn(model, len(prompt), m["max_len"] + 32)
+        jac = m["jacobi"]
+        cfg = OL.LoopConfig(jacobi_loop_interval_l=jac["jacobi_loop_interval_l"],
+                            jacobi_loop_interval_r=jac["jacobi_loop_interval_r"],
+                            max_num_new_tokens=jac["max_num_new_tokens"], guidance_scale=jac["guidance_scale"],
+                            seed=jac["seed"], do_cfg=jac["do_cfg"],
+                            prefix_token_sampler_scheme=jac["prefix_token_sampler_scheme"], max_length=m["max_len"],
+                            eos_token_ids=(8196,))
+        seq, tr = OL.run(prompt, fwd, lambda c, n: O.lumina_rules(c, n, 2000, 10), cfg, m["config"]["vocab_size"],
+                         no_cfg_fn=O.lumina_force_no_cfg)
+        check_trace(d, name, tr)
+        assert seq == d[f"{name}.sequence"][0].tolist(), name
+        assert len(tr.matched) == m["nfe"]

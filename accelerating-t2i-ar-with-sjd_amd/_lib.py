@@ -1,0 +1,73 @@
+"""ctypes binding of libsjd_hip.so (the C-ABI declared in include/sjd_hip.h).
+
+There is no fallback: if the shared library is missing or does not load, importing the hot path raises.
+Build it with ``python __graft_entry__.py`` / ``make -C accelerating-t2i-ar-with-sjd_amd/csrc``.
+"""
+import ctypes
+import os
+
+MAX_WINDOW = 32
+MAX_RANGES = 4
+DTYPE_BF16, DTYPE_F16 = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libsjd_hip.so")
+
+
+class RowRule(ctypes.Structure):
+    _fields_ = [("n_ranges", ctypes.c_int32), ("lo", ctypes.c_int32 * MAX_RANGES), ("hi", ctypes.c_int32 * MAX_RANGES),
+                ("forced", ctypes.c_int32), ("top_k", ctypes.c_int32), ("top_p_thr", ctypes.c_float)]
+
+
+class IterParams(ctypes.Structure):
+    _fields_ = [("n_rows", ctypes.c_int32), ("kv_len", ctypes.c_int32), ("use_cfg", ctypes.c_int32),
+                ("scheme", ctypes.c_int32), ("n_fresh", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
+                ("fresh_tok", ctypes.c_int64 * MAX_WINDOW), ("rules", RowRule * MAX_WINDOW),
+                ("resid_rules", RowRule * MAX_WINDOW)]
+
+
+class State(ctypes.Structure):
+    _fields_ = [("m", ctypes.c_int32), ("rejected", ctypes.c_int32), ("n_prev", ctypes.c_int32),
+                ("prob_buf", ctypes.c_int32), ("tokens", ctypes.c_int64 * MAX_WINDOW),
+                ("win_tok", ctypes.c_int64 * MAX_WINDOW), ("q_src", ctypes.c_int32 * MAX_WINDOW)]
+
+
+EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_probs_sample", "sjd_verify_accept",
+           "sjd_kv_append", "sjd_attention_workspace_bytes", "sjd_draft_window_attention"]
+
+_lib = None
+
+
+class SjdLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise SjdLibraryError(f"{SO_PATH} is missing: build the HIP extension first (python __graft_entry__.py). "
+                              "There is no CPU/torch fallback for the SJD hot path.")
+    lib = ctypes.CDLL(SO_PATH)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    lib.sjd_version.restype = i32
+    lib.sjd_error_string.restype = ctypes.c_char_p
+    lib.sjd_error_string.argtypes = [i32]
+    lib.sjd_reguess.argtypes = [vp, vp, vp, i32, i32, vp]
+    lib.sjd_logits_to_probs_sample.argtypes = [vp, vp, i64, f32, i32, i32, vp, vp, vp, vp, vp]
+    lib.sjd_verify_accept.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    lib.sjd_kv_append.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]
+    lib.sjd_attention_workspace_bytes.restype = i64
+    lib.sjd_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    lib.sjd_draft_window_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp]
+    for name in EXPORTS:
+        getattr(lib, name)
+    assert ctypes.sizeof(RowRule) == 48 and ctypes.sizeof(IterParams) == 32 + 8 * MAX_WINDOW + 2 * 48 * MAX_WINDOW
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SjdLibraryError(f"{what} failed: {load().sjd_error_string(rc).decode()} ({rc})")

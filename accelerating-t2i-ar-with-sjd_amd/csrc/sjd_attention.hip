@@ -1,0 +1,358 @@
+// sjd_attention.hip -- K1 draft-window attention + K3 KV append for gfx950 (CDNA4, wave64, MFMA 16x16x32).
+//
+// Data layout in HBM:  K/V cache per layer [B, H_kv, S_max, D] (one contiguous D-row per key, 256 B at D=128 bf16);
+// q / out [B, n_rows, H, D] (the q_proj / o_proj activation layout, no transposes).
+//
+// K1 structure (memory-bound: intensity = L*H/H_kv flop/byte << ridge, judged on HBM GB/s):
+//   grid = (n_chunks * n_split, H_kv, B), 256 threads = 4 wave64.
+//   A workgroup owns one (batch, kv-head, 16-row query chunk, key split).  Wave w works for q-head (w % G) of the
+//   kv-group (G = H/H_kv in {1,2,4}) on key tiles (w / G) + k * (4/G) of 32 keys.
+//   Per 32-key tile and wave:
+//     S^T = K Q^T   : 2 x (D/32) MFMA 16x16x32;  A operand = K rows loaded STRAIGHT from HBM in fragment layout
+//                     (lane = key, 16 B = 8 consecutive d);  B operand = Q (kept in registers for the whole kernel).
+//                     The "swapped" product puts a whole query row's scores in one lane column, so running max / sum /
+//                     rescale are per-lane scalars + two xor-shuffles (16, 32).
+//     O^T += V^T P^T: D/16 MFMA; B operand = P^T taken from the S^T accumulator registers as-is (the key permutation
+//                     this implies is applied to the V operand instead, so P never goes through LDS);
+//                     A operand = V^T via ds_read_b64_tr_b16 from a per-wave LDS tile filled with coalesced 16-B loads.
+//   Next tile's K and V loads are issued before the current tile's math (register double buffer).
+//   Split partials (m, l, O) go to an fp32 workspace; k1_combine merges them and writes bf16/f16.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <math.h>
+
+#include "../../include/sjd_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+#define K1_WAVES 4
+#define K1_KT 32          // keys per wave tile
+#define K1_ROWS 16        // query rows per chunk
+
+template <int DT> struct Frag;
+template <> struct Frag<SJD_DTYPE_BF16> {
+    typedef bf16x8 vec;
+    static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned short cvt(float x)
+    {   // round-to-nearest-even fp32 -> bf16
+        unsigned u = __float_as_uint(x);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    }
+};
+template <> struct Frag<SJD_DTYPE_F16> {
+    typedef f16x8 vec;
+    static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned short cvt(float x)
+    {
+        _Float16 h = (_Float16)x;
+        return *reinterpret_cast<unsigned short *>(&h);
+    }
+};
+
+template <typename V> __device__ __forceinline__ V as_frag(u32x4 x) { return __builtin_bit_cast(V, x); }
+
+// transpose read: the 16 lanes of a group fetch a [4 keys][16 d] block (lane i: 8 bytes at row i/4, cols 4*(i%4)..+3)
+// and lane c receives column c (4 keys).
+__device__ __forceinline__ u32x2 lds_tr_read(const unsigned short *p)
+{
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+    return __builtin_bit_cast(u32x2, r);
+}
+
+template <int DT, int D>
+__global__ __launch_bounds__(256) void k1_partial(
+    const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
+    float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max,
+    const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks)
+{
+    typedef typename Frag<DT>::vec vec;
+    constexpr int KS = D / 32;            // k-steps of the QK^T product
+    constexpr int DB = D / 16;            // 16-wide d blocks of the output
+    constexpr int VROW = D + 8;           // padded LDS row (elements): 16-B aligned rows, breaks the 256-B bank period
+    __shared__ __attribute__((aligned(16))) unsigned short v_lds[K1_WAVES][K1_KT * VROW];
+    __shared__ float red_o[K1_WAVES][K1_ROWS][D];
+    __shared__ float red_ml[K1_WAVES][K1_ROWS][2];
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int G = H / H_kv;
+    const int kparts = K1_WAVES / G;
+    const int head_in_group = w % G, kpart = w / G;
+    const int chunk = blockIdx.x / n_split, split = blockIdx.x % n_split;
+    const int hkv = blockIdx.y, b = blockIdx.z;
+    const int head = hkv * G + head_in_group;
+
+    const int kv_base = params ? params->kv_len : kv_len_arg;
+    const int n_total = params ? params->n_rows : n_rows;         // valid rows of this call
+    const int row0 = chunk * K1_ROWS;
+    const int n_c = min(K1_ROWS, n_total - row0);                 // may be <= 0 for padding chunks
+    const int kv_len = kv_base + row0;                            // keys < kv_len are visible to every row of the chunk
+    const int total = kv_len + max(n_c, 0);                       // keys >= total are not visible to any row
+    const int kstart = key_start ? key_start[b] : 0;
+    const float scale = rsqrtf((float)D);
+
+    // tile range of this workgroup / wave
+    const int t_lo = kstart / K1_KT, t_hi = (total + K1_KT - 1) / K1_KT;
+    const int nt = max(t_hi - t_lo, 0);
+    const int tps = (nt + n_split - 1) / n_split;
+    const int t_begin = t_lo + split * tps, t_end = min(t_hi, t_begin + tps);
+
+    // Q fragments (B operand): lane (row c, group g) holds Q[row0+c][head][32*ks + 8g .. +7]
+    vec qf[KS];
+    {
+        const bool rv = (c < n_c);
+        const unsigned short *qp = q + (((size_t)b * n_rows + (row0 + (rv ? c : 0))) * H + head) * D + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 x = rv ? *reinterpret_cast<const u32x4 *>(qp + 32 * ks) : u32x4{0, 0, 0, 0};
+            qf[ks] = as_frag<vec>(x);
+        }
+    }
+    const unsigned short *kbase = kc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
+    const unsigned short *vbase = vc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x4 o_acc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 kreg[2][KS], kn[2][KS];
+    u32x4 vstage[K1_KT * D / (64 * 8)];       // 16-B pieces per lane for one V tile
+    constexpr int VP = K1_KT * D / (64 * 8);
+    constexpr int LPR = D / 8;                // lanes per V row
+    unsigned short *vl = v_lds[w];
+
+    auto load_tile = [&](int t, u32x4 (&kd)[2][KS], u32x4 (&vd)[VP]) {
+        const unsigned short *kt = kbase + (size_t)(t * K1_KT) * D;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                kd[kb][ks] = *reinterpret_cast<const u32x4 *>(kt + (size_t)(16 * kb + c) * D + 32 * ks + 8 * g);
+        const unsigned short *vt = vbase + (size_t)(t * K1_KT) * D;
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            int idx = i * 64 + lane;
+            vd[i] = *reinterpret_cast<const u32x4 *>(vt + (size_t)(idx / LPR) * D + 8 * (idx % LPR));
+        }
+    };
+    auto store_v = [&](u32x4 (&vd)[VP]) {
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            int idx = i * 64 + lane;
+            *reinterpret_cast<u32x4 *>(vl + (idx / LPR) * VROW + 8 * (idx % LPR)) = vd[i];
+        }
+    };
+
+    int t = t_begin + kpart;
+    if (t < t_end) {
+        load_tile(t, kreg, vstage);
+        store_v(vstage);
+    }
+    for (; t < t_end; t += kparts) {
+        const int tn = t + kparts;
+        const bool has_next = tn < t_end;
+        if (has_next) load_tile(tn, kn, vstage);
+
+        // ---- S^T = K Q^T for the two 16-key blocks
+        f32x4 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) st[kb] = Frag<DT>::mfma(as_frag<vec>(kreg[kb][ks]), qf[ks], st[kb]);
+        }
+        // ---- mask + online softmax (query row = c; this lane holds keys 16kb + 4g + r)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = t * K1_KT + 16 * kb + 4 * g + r;
+                bool vis = (key >= kstart) && (key <= kv_len + c) && (key < total);
+                float s = vis ? st[kb][r] * scale : -INFINITY;
+                st[kb][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+        const float alpha = __expf(m_run - m_safe);
+        float rs = 0.0f;
+        unsigned short pb[8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pv = __expf(st[kb][r] - m_safe);
+                rs += pv;
+                pb[4 * kb + r] = Frag<DT>::cvt(pv);
+            }
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        u32x4 pw;
+        pw[0] = pb[0] | ((unsigned)pb[1] << 16);
+        pw[1] = pb[2] | ((unsigned)pb[3] << 16);
+        pw[2] = pb[4] | ((unsigned)pb[5] << 16);
+        pw[3] = pb[6] | ((unsigned)pb[7] << 16);
+        const vec pfrag = as_frag<vec>(pw);
+        // ---- O^T = alpha * O^T + V^T P^T
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const unsigned short *a0 = vl + (4 * g + (c >> 2)) * VROW + 16 * db + 4 * (c & 3);
+            u32x2 lo = lds_tr_read(a0);
+            u32x2 hi = lds_tr_read(a0 + 16 * VROW);
+            u32x4 vv{lo[0], lo[1], hi[0], hi[1]};
+            f32x4 acc = o_acc[db];
+            acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+            o_acc[db] = Frag<DT>::mfma(as_frag<vec>(vv), pfrag, acc);
+        }
+        if (has_next) {
+            store_v(vstage);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kreg[kb][ks] = kn[kb][ks];
+        }
+    }
+
+    // ---- merge the key-parts of each head inside the workgroup, then publish the split partial
+    if (g == 0) { red_ml[w][c][0] = m_run; red_ml[w][c][1] = l_run; }
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red_o[w][c][16 * db + 4 * g + r] = o_acc[db][r];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < G * K1_ROWS * D; idx += 256) {
+        const int hg = idx / (K1_ROWS * D), row = (idx / D) % K1_ROWS, d = idx % D;
+        float M = -INFINITY;
+        for (int kp = 0; kp < kparts; ++kp) M = fmaxf(M, red_ml[kp * G + hg][row][0]);
+        const float Ms = (M == -INFINITY) ? 0.0f : M;
+        float L = 0.f, O = 0.f;
+        for (int kp = 0; kp < kparts; ++kp) {
+            const int ww = kp * G + hg;
+            const float wgt = __expf(red_ml[ww][row][0] - Ms);
+            L += wgt * red_ml[ww][row][1];
+            O += wgt * red_o[ww][row][d];
+        }
+        const size_t slot = ((((size_t)b * H + (hkv * G + hg)) * n_chunks + chunk) * n_split + split) * K1_ROWS + row;
+        ws_o[slot * D + d] = O;
+        if (d == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = L; }
+    }
+}
+
+template <int DT, int D>
+__global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
+                                                 unsigned short *__restrict__ out, int n_rows, int H, int n_split, int n_chunks,
+                                                 const sjd_iter_params *__restrict__ params)
+{
+    const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int n_total = params ? params->n_rows : n_rows;
+    constexpr int PER = K1_ROWS * D / 256;          // consecutive d per thread
+    const int row = (threadIdx.x * PER) / D, d0 = (threadIdx.x * PER) % D;
+    const int grow = chunk * K1_ROWS + row;
+    if (grow >= n_total) return;
+    const size_t base = (((size_t)b * H + head) * n_chunks + chunk) * n_split;
+    float M = -INFINITY;
+    for (int s = 0; s < n_split; ++s) M = fmaxf(M, ws_ml[((base + s) * K1_ROWS + row) * 2]);
+    const float Ms = (M == -INFINITY) ? 0.0f : M;
+    float L = 0.f, acc[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) acc[j] = 0.f;
+    for (int s = 0; s < n_split; ++s) {
+        const size_t slot = (base + s) * K1_ROWS + row;
+        const float wgt = __expf(ws_ml[slot * 2] - Ms);
+        L += wgt * ws_ml[slot * 2 + 1];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) acc[j] += wgt * ws_o[slot * D + d0 + j];
+    }
+    const float inv = L > 0.f ? 1.0f / L : 0.0f;
+    unsigned short *o = out + (((size_t)b * n_rows + grow) * H + head) * D + d0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) o[j] = Frag<DT>::cvt(acc[j] * inv);
+}
+
+// ------------------------------------------------------------------------------------------------ K3
+__global__ void k3_kv_append(const u32x4 *__restrict__ k_new, const u32x4 *__restrict__ v_new, u32x4 *__restrict__ k_cache,
+                             u32x4 *__restrict__ v_cache, int B, int n_rows, int H_kv, int D8, int S_max,
+                             const sjd_iter_params *__restrict__ params, int kv_len_arg)
+{
+    const int kv_len = params ? params->kv_len : kv_len_arg;
+    const size_t total = (size_t)B * n_rows * H_kv * D8;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = i % D8;
+        const int h = (i / D8) % H_kv;
+        const int r = (i / ((size_t)D8 * H_kv)) % n_rows;
+        const int b = i / ((size_t)D8 * H_kv * n_rows);
+        if (kv_len + r >= S_max) continue;
+        const size_t dst = (((size_t)b * H_kv + h) * S_max + (kv_len + r)) * D8 + d;
+        k_cache[dst] = k_new[i];
+        v_cache[dst] = v_new[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI
+extern "C" int sjd_kv_append(const void *k_new, const void *v_new, void *k_cache, void *v_cache, int B, int n_rows, int H_kv, int D,
+                             int S_max, int dtype, const sjd_iter_params *params, int kv_len, void *stream)
+{
+    (void)dtype;
+    if (!k_new || !v_new || !k_cache || !v_cache || B < 1 || n_rows < 1 || H_kv < 1 || (D % 8) != 0 || S_max < 1) return SJD_ERR_BAD_ARG;
+    const size_t total = (size_t)B * n_rows * H_kv * (D / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k3_kv_append, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4 *)k_new, (const u32x4 *)v_new,
+                       (u32x4 *)k_cache, (u32x4 *)v_cache, B, n_rows, H_kv, D / 8, S_max, params, kv_len);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int64_t sjd_attention_workspace_bytes(int B, int H, int n_rows, int D, int n_split)
+{
+    const int64_t n_chunks = (n_rows + K1_ROWS - 1) / K1_ROWS;
+    return (int64_t)B * H * n_chunks * n_split * K1_ROWS * (D + 2) * (int64_t)sizeof(float);
+}
+
+template <int DT, int D>
+static int launch_attention(const void *q, const void *kc, const void *vc, void *out, int B, int n_rows, int H, int H_kv, int S_max,
+                            const int32_t *key_start, const sjd_iter_params *params, int kv_len, int n_split, void *workspace,
+                            hipStream_t stream)
+{
+    const int n_chunks = (n_rows + K1_ROWS - 1) / K1_ROWS;
+    float *ws_o = (float *)workspace;
+    float *ws_ml = ws_o + (size_t)B * H * n_chunks * n_split * K1_ROWS * D;
+    hipLaunchKernelGGL((k1_partial<DT, D>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
+                       (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
+                       kv_len, n_split, n_chunks);
+    if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
+    hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
+                       n_split, n_chunks, params);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_draft_window_attention(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
+                                          int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
+                                          const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream)
+{
+    if (!q || !k_cache || !v_cache || !out || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
+    if (H % H_kv != 0 || (S_max % K1_KT) != 0) return SJD_ERR_BAD_ARG;
+    const int G = H / H_kv;
+    if (!(G == 1 || G == 2 || G == 4)) return SJD_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+#define SJD_K1_CASE(DT_, D_) \
+    if (dtype == DT_ && D == D_) return launch_attention<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, key_start, params, kv_len, n_split, workspace, s);
+    SJD_K1_CASE(SJD_DTYPE_BF16, 128)
+    SJD_K1_CASE(SJD_DTYPE_BF16, 64)
+    SJD_K1_CASE(SJD_DTYPE_F16, 128)
+    SJD_K1_CASE(SJD_DTYPE_F16, 64)
+#undef SJD_K1_CASE
+    return SJD_ERR_UNSUPPORTED;
+}

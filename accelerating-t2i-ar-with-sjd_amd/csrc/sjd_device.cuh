@@ -1,0 +1,185 @@
+// sjd_device.cuh -- device helpers shared by the sampling kernels (K2 / K4).
+//
+// Canonical fp32 numerics (specification; the CPU oracle restates the same arithmetic independently):
+//   * no FMA contraction except the explicit __builtin_fmaf below  (file is built with -ffp-contract=off)
+//   * exp: Cody-Waite range reduction + degree-5 polynomial, 0 below -87
+//   * sum: thread T of a 1024-thread block owns columns {4T..4T+3} + 4096k, four running accumulators added in
+//     increasing k; s_T = (a0+a1)+(a2+a3); xor-butterfly 32,16,8,4,2,1 inside each wave64; the 16 wave totals
+//     are added in wave order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SJD_TPB 1024
+#define SJD_WAVES (SJD_TPB / 64)
+#define SJD_RADIX_BINS 2048
+
+__device__ __forceinline__ float sjd_expf(float x)
+{
+    if (!(x >= -87.0f)) return 0.0f;
+    const float LOG2E = 1.44269504088896341f;
+    const float LN2_HI = 0.693359375f;
+    const float LN2_LO = -2.12194440e-4f;
+    const float MAGIC = 12582912.0f;
+    float n = __builtin_fmaf(x, LOG2E, MAGIC) - MAGIC;
+    float r = __builtin_fmaf(-n, LN2_HI, x);
+    r = __builtin_fmaf(-n, LN2_LO, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    int ni = (int)n;
+    return y * __uint_as_float((uint32_t)(ni + 127) << 23);
+}
+
+struct SjdShared {
+    float wave_f[SJD_WAVES];
+    int wave_i[SJD_WAVES];
+    unsigned long long wave_u64[SJD_WAVES];
+    unsigned hist[SJD_RADIX_BINS];
+    int sel_bin;
+    int sel_k;
+    int misc[4];
+};
+
+// ---- exact reductions (order independent) -------------------------------------------------------------
+__device__ __forceinline__ float block_max(float v, SjdShared &sh)
+{
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.wave_f[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sh.wave_f[0];
+    for (int w = 1; w < SJD_WAVES; ++w) r = fmaxf(r, sh.wave_f[w]);
+    return r;
+}
+
+__device__ __forceinline__ int block_sum_int(int v, SjdShared &sh)
+{
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.wave_i[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int r = 0;
+    for (int w = 0; w < SJD_WAVES; ++w) r += sh.wave_i[w];
+    return r;
+}
+
+// ---- canonical (order-specified) fp32 sum --------------------------------------------------------------
+__device__ __forceinline__ float block_canonical_sum(float a0, float a1, float a2, float a3, SjdShared &sh)
+{
+    float s = (a0 + a1) + (a2 + a3);
+    for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.wave_f[threadIdx.x >> 6] = s;
+    __syncthreads();
+    float total = sh.wave_f[0];
+    for (int w = 1; w < SJD_WAVES; ++w) total = total + sh.wave_f[w];
+    return total;
+}
+
+// ---- argmax of (value, lowest index) -------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long pack_vi(float v, int idx)
+{
+    // v >= 0 here (ratios of non-negative numbers); larger value wins, then LOWER index
+    return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0x7fffffff - idx);
+}
+
+__device__ __forceinline__ int block_argmax(unsigned long long best, SjdShared &sh)
+{
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.wave_u64[threadIdx.x >> 6] = best;
+    __syncthreads();
+    unsigned long long r = sh.wave_u64[0];
+    for (int w = 1; w < SJD_WAVES; ++w) r = sh.wave_u64[w] > r ? sh.wave_u64[w] : r;
+    return 0x7fffffff - (int)(unsigned)(r & 0xffffffffu);
+}
+
+// ---- radix select: exact k-th largest key among the keys a block-strided visitor yields -------------------
+__device__ __forceinline__ unsigned f2key(float z)
+{
+    unsigned u = __float_as_uint(z);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// exclusive prefix (in thread order) of one int per thread
+__device__ __forceinline__ int block_exclusive_scan(int v, SjdShared &sh)
+{
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) sh.wave_i[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += sh.wave_i[i];
+    return base + inc - v;
+}
+
+// After the histogram of one radix digit is complete: find the bin holding the k-th largest (descending bins).
+// Every thread returns the same (bin, remaining k).
+__device__ __forceinline__ void radix_pick(int k, SjdShared &sh, int &bin, int &krem)
+{
+    __syncthreads();
+    int t = threadIdx.x;
+    int hi = SJD_RADIX_BINS - 1 - 2 * t, lo = hi - 1;
+    int ch = (int)sh.hist[hi], cl = (int)sh.hist[lo];
+    int before = block_exclusive_scan(ch + cl, sh);
+    if (before < k && k <= before + ch) { sh.sel_bin = hi; sh.sel_k = k - before; }
+    else if (before + ch < k && k <= before + ch + cl) { sh.sel_bin = lo; sh.sel_k = k - before - ch; }
+    __syncthreads();
+    bin = sh.sel_bin;
+    krem = sh.sel_k;
+    __syncthreads();
+}
+
+// Row visitor: thread T walks columns 4T + 4096*k (+0..3), the canonical ownership.
+#define SJD_FOR_OWNED_COLS(V, c0)  for (int c0 = 4 * (int)threadIdx.x; c0 < (V); c0 += 4 * SJD_TPB)
+
+// k-th largest float of row[0..V) restricted to entries with `row[c] > floor_excl` (finite filter);
+// requires 1 <= k <= count of such entries.
+__device__ float block_kth_largest(const float *row, int V, int k, float floor_excl, SjdShared &sh)
+{
+    unsigned prefix = 0;
+    int krem = k;
+    const int shifts[3] = {21, 10, 0};
+    const unsigned masks[3] = {0x7ffu, 0x7ffu, 0x3ffu};
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int b = threadIdx.x; b < SJD_RADIX_BINS; b += SJD_TPB) sh.hist[b] = 0;
+        __syncthreads();
+        const int shift = shifts[pass];
+        SJD_FOR_OWNED_COLS(V, c0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int c = c0 + j;
+                if (c < V) {
+                    float z = row[c];
+                    if (z > floor_excl) {
+                        unsigned key = f2key(z);
+                        bool match = (pass == 0) || ((key >> (shift + (pass == 1 ? 11 : 10))) == prefix);
+                        if (match) atomicAdd(&sh.hist[(key >> shift) & masks[pass]], 1u);
+                    }
+                }
+            }
+        }
+        int bin;
+        radix_pick(krem, sh, bin, krem);
+        prefix = (pass == 0) ? (unsigned)bin : ((prefix << (pass == 1 ? 11 : 10)) | (unsigned)bin);
+    }
+    return key2f(prefix);
+}

@@ -1,0 +1,288 @@
+// sjd_sampling.hip -- kernels K2 (logits -> probs -> sample), K4 (verify/accept + residual resample),
+// K5 (window assembly / re-guess) for gfx950.  Built with -ffp-contract=off (canonical numerics, see sjd_device.cuh).
+//
+// One 1024-thread workgroup (16 wave64) owns one row.  The row is staged in the caller's probs_out / scratch buffer
+// (L2-resident between passes); all cross-lane reductions use wave64 shuffles + a 16-entry LDS exchange.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/sjd_hip.h"
+#include "sjd_device.cuh"
+
+__device__ __forceinline__ bool rule_allows(const sjd_row_rule &r, int c)
+{
+    if (r.n_ranges == 0) return true;
+    bool ok = false;
+#pragma unroll
+    for (int a = 0; a < SJD_MAX_RANGES; ++a) ok |= (a < r.n_ranges) && (c >= r.lo[a]) && (c < r.hi[a]);
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------------ K2
+// replaces sampling_logits2tokens (reference jacobi_iteration_lumina_mgpt.py:82-132)
+__global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
+    const float *__restrict__ logits_c, const float *__restrict__ logits_u, long row_stride, float guidance, int V,
+    const sjd_iter_params *__restrict__ params, const float *__restrict__ noise, float *__restrict__ probs_out,
+    int64_t *__restrict__ tokens_out)
+{
+    __shared__ SjdShared sh;
+    const int row = blockIdx.x;
+    if (row >= params->n_rows) return;
+    const sjd_row_rule rule = params->rules[row];
+    float *p = probs_out + (size_t)row * V;
+    const float *e = noise + (size_t)row * V;
+
+    if (rule.forced >= 0) {   // forced EOL / end-of-image row: softmax of (-inf,...,0,...,-inf) (LP:39-41)
+        SJD_FOR_OWNED_COLS(V, c0)
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < V) p[c0 + j] = (c0 + j == rule.forced) ? 1.0f : 0.0f;
+        if (threadIdx.x == 0) tokens_out[row] = rule.forced;
+        return;
+    }
+
+    const float *c = logits_c + (size_t)row * row_stride;
+    const float *u = (logits_u != nullptr && params->use_cfg) ? logits_u + (size_t)row * row_stride : nullptr;
+    const bool vec = ((V & 3) == 0) && ((row_stride & 3) == 0);
+
+    // pass 1: CFG combine (JL:104) + grammar mask (LP:125-129); stage z; row max; finite count
+    float tmax = -INFINITY;
+    int cnt = 0;
+    SJD_FOR_OWNED_COLS(V, c0) {
+        float zc[4], zu[4];
+        if (vec) {
+            float4 a = *reinterpret_cast<const float4 *>(c + c0);
+            zc[0] = a.x; zc[1] = a.y; zc[2] = a.z; zc[3] = a.w;
+            if (u) { float4 b = *reinterpret_cast<const float4 *>(u + c0); zu[0] = b.x; zu[1] = b.y; zu[2] = b.z; zu[3] = b.w; }
+        } else {
+            for (int j = 0; j < 4; ++j) { zc[j] = (c0 + j < V) ? c[c0 + j] : 0.f; zu[j] = (u && c0 + j < V) ? u[c0 + j] : 0.f; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int col = c0 + j;
+            if (col < V) {
+                float z = zc[j];
+                if (u) { float t = zc[j] - zu[j]; t = guidance * t; z = t + zu[j]; }
+                if (!rule_allows(rule, col)) z = -INFINITY;
+                p[col] = z;
+                tmax = fmaxf(tmax, z);
+                cnt += (z > -INFINITY) ? 1 : 0;
+            }
+        }
+    }
+    const float zmax = block_max(tmax, sh);
+    const int n_finite = block_sum_int(cnt, sh);
+    __syncthreads();   // staged z visible to the whole block (global memory, same CU)
+
+    // top-k (LP:196-204): keep z >= k-th largest; k-th is -inf when fewer than k finite entries exist
+    float kth = -INFINITY;
+    if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_finite) kth = block_kth_largest(p, V, rule.top_k, -INFINITY, sh);
+
+    if (rule.top_p_thr >= 0.0f) {   // TopPLogitsWarper3d with top_p < 1: not on the HIP path yet
+        if (threadIdx.x == 0) tokens_out[row] = -1;
+        return;
+    }
+
+    // pass A: e = exp(z - max) for kept entries, canonical sum
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    SJD_FOR_OWNED_COLS(V, c0) {
+        float ev[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int col = c0 + j;
+            ev[j] = 0.0f;
+            if (col < V) {
+                float z = p[col];
+                ev[j] = (z < kth) ? 0.0f : sjd_expf(z - zmax);
+                p[col] = ev[j];
+            }
+        }
+        a0 = a0 + ev[0]; a1 = a1 + ev[1]; a2 = a2 + ev[2]; a3 = a3 + ev[3];
+    }
+    const float S = block_canonical_sum(a0, a1, a2, a3, sh);
+
+    // pass B: p = e / S ; multinomial == lowest-index argmax of p / Exp(1)   (JL:111-118)
+    unsigned long long best = 0ull;
+    SJD_FOR_OWNED_COLS(V, c0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int col = c0 + j;
+            if (col < V) {
+                float pv = p[col] / S;
+                p[col] = pv;
+                float r = pv / e[col];
+                unsigned long long cand = pack_vi(r, col);
+                best = cand > best ? cand : best;
+            }
+        }
+    }
+    const int tok = block_argmax(best, sh);
+    if (threadIdx.x == 0) tokens_out[row] = tok;
+}
+
+// ------------------------------------------------------------------------------------------------ K4
+// replaces SpeculativeSampler.__call__ / find_first_misaligned_token_inds (reference JL:247-333)
+__global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
+    const sjd_iter_params *__restrict__ params, sjd_state *__restrict__ state, const float *__restrict__ probs,
+    const float *__restrict__ prev_probs, const float *__restrict__ rs, const float *__restrict__ noise2,
+    float *__restrict__ scratch, int V)
+{
+    __shared__ SjdShared sh;
+    const int n = params->n_rows;
+    if (n <= 1) {   // prefill / single-token phase short-circuit (JL:344-350)
+        if (threadIdx.x == 0) { state->m = 1; state->rejected = 0; state->n_prev = n; }
+        return;
+    }
+    const int scheme = params->scheme;
+    // phase 1: one lane per draft; ballot + find-first-zero = longest accepted prefix
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        bool acc = true;
+        long x = 0;
+        if (i >= 1 && i < n) {
+            x = state->win_tok[i];
+            if (scheme == 0) {
+                float pa = probs[(size_t)(i - 1) * V + x];
+                int qs = state->q_src[i];
+                float qd = (qs >= 0) ? prev_probs[(size_t)qs * V + x] : 1.0f;
+                float ratio = pa / qd;                       // JL:286 (NaN compares false => reject)
+                float uu = rs[(size_t)i * V + x];            // JL:282
+                acc = uu < (ratio > 1.0f ? 1.0f : ratio);
+            } else {
+                acc = (x == state->tokens[i - 1]);           // JL:325
+            }
+        }
+        unsigned long long ok = __ballot(acc);
+        unsigned long long window = (n >= 64) ? ~1ull : (((1ull << n) - 1ull) & ~1ull);
+        unsigned long long rej = (~ok) & window;
+        int m = rej ? (__ffsll((long long)rej) - 1) : n;
+        if (scheme == 0 && i >= 1 && i < m) state->tokens[i - 1] = x;   // accepted drafts (JL:288)
+        if (i == 0) sh.misc[0] = m;
+    }
+    __syncthreads();
+    const int m = sh.misc[0];
+    const bool rejected = (scheme == 0) && (m < n);
+    if (rejected) {
+        // phase 2: residual resample of position m-1 from norm(max(p - q, 0)) (JL:203-241)
+        const int row = m - 1;
+        const sjd_row_rule rule = params->resid_rules[row];
+        if (rule.forced >= 0) {
+            if (threadIdx.x == 0) state->tokens[row] = rule.forced;
+        } else {
+            const long x = state->win_tok[m];
+            const int qs = state->q_src[m];
+            const float *prow = probs + (size_t)row * V;
+            const float *qrow = (qs >= 0) ? prev_probs + (size_t)qs * V : nullptr;
+            int cnt = 0;
+            SJD_FOR_OWNED_COLS(V, c0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int col = c0 + j;
+                    if (col < V) {
+                        float qv = qrow ? qrow[col] : ((long)col == x ? 1.0f : 0.0f);
+                        float d = prow[col] - qv;
+                        d = d > 0.0f ? d : 0.0f;
+                        if (!rule_allows(rule, col)) d = 0.0f;
+                        scratch[col] = d;
+                        cnt += d > 0.0f ? 1 : 0;
+                    }
+                }
+            }
+            const int n_pos = block_sum_int(cnt, sh);
+            __syncthreads();
+            float kth = 0.0f;
+            if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_pos) kth = block_kth_largest(scratch, V, rule.top_k, 0.0f, sh);
+            if (rule.top_p_thr >= 0.0f) {   // top-p < 1 in the residual: not on the HIP path yet
+                if (threadIdx.x == 0) { state->tokens[row] = -1; }
+            } else {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                SJD_FOR_OWNED_COLS(V, c0) {
+                    float dv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int col = c0 + j;
+                        dv[j] = 0.0f;
+                        if (col < V) {
+                            float d = scratch[col];
+                            dv[j] = (d < kth) ? 0.0f : d;
+                            scratch[col] = dv[j];
+                        }
+                    }
+                    a0 = a0 + dv[0]; a1 = a1 + dv[1]; a2 = a2 + dv[2]; a3 = a3 + dv[3];
+                }
+                const float S = block_canonical_sum(a0, a1, a2, a3, sh);
+                unsigned long long best = 0ull;
+                SJD_FOR_OWNED_COLS(V, c0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int col = c0 + j;
+                        if (col < V) {
+                            float r = (scratch[col] / S) / noise2[col];
+                            unsigned long long cand = pack_vi(r, col);
+                            best = cand > best ? cand : best;
+                        }
+                    }
+                }
+                const int tok = block_argmax(best, sh);
+                if (threadIdx.x == 0) state->tokens[row] = tok;
+            }
+        }
+    }
+    if (threadIdx.x == 0) { state->m = m; state->rejected = rejected ? 1 : 0; state->n_prev = n; }
+}
+
+// ------------------------------------------------------------------------------------------------ K5
+// replaces prepare_inputs_for_generation_jacobi / get_multi_token_for_preparation('random') (reference JL:470-514,
+// 606-701): window = [last emitted | carried unverified samples | fresh random ids]
+__global__ void k5_reguess(const sjd_iter_params *__restrict__ params, sjd_state *__restrict__ state,
+                           int64_t *__restrict__ input_ids_out, int n_batch, int max_rows)
+{
+    const int i = threadIdx.x;
+    const int n = params->n_rows;
+    const int m = state->m, n_prev = state->n_prev;
+    int a = n_prev - m;
+    if (a > n - 1) a = n - 1;
+    if (a < 0) a = 0;
+    int64_t tok = 0;
+    int qs = -1;
+    if (i < n) {
+        if (i <= a) { tok = state->tokens[m - 1 + i]; qs = m - 1 + i; }     // JL:657-661, 688-695
+        else { tok = params->fresh_tok[i - 1 - a]; qs = -1; }               // JL:505-514 (implicit one-hot row)
+    }
+    __syncthreads();
+    if (i < max_rows) {
+        if (i >= n) { tok = state->tokens[m - 1]; qs = -1; }                // padding rows: any valid id
+        state->win_tok[i] = tok;
+        state->q_src[i] = qs;
+        for (int b = 0; b < n_batch; ++b) input_ids_out[(size_t)b * max_rows + i] = tok;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI
+extern "C" int sjd_reguess(const sjd_iter_params *params, sjd_state *state, int64_t *input_ids_out, int n_batch,
+                           int max_rows, void *stream)
+{
+    if (!params || !state || !input_ids_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || n_batch < 1) return SJD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k5_reguess, dim3(1), dim3(64), 0, (hipStream_t)stream, params, state, input_ids_out, n_batch, max_rows);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_logits_to_probs_sample(const float *logits_c, const float *logits_u, int64_t row_stride, float guidance,
+                                          int max_rows, int V, const sjd_iter_params *params, const float *noise,
+                                          float *probs_out, int64_t *tokens_out, void *stream)
+{
+    if (!logits_c || !params || !noise || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
+        return SJD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k2_logits_to_probs_sample, dim3(max_rows), dim3(SJD_TPB), 0, (hipStream_t)stream, logits_c, logits_u,
+                       (long)row_stride, guidance, V, params, noise, probs_out, tokens_out);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_verify_accept(const sjd_iter_params *params, sjd_state *state, const float *probs, const float *prev_probs,
+                                 const float *rs, const float *noise2, float *scratch, int max_rows, int V, void *stream)
+{
+    if (!params || !state || !probs || !prev_probs || !rs || !noise2 || !scratch || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
+        return SJD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k4_verify_accept, dim3(1), dim3(SJD_TPB), 0, (hipStream_t)stream, params, state, probs, prev_probs, rs,
+                       noise2, scratch, V);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}

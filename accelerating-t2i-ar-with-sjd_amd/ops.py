@@ -1,0 +1,142 @@
+"""torch-tensor wrappers over the C-ABI (include/sjd_hip.h).  Plumbing only: device pointers, strides, stream."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _dtype_code(dt):
+    if dt == torch.bfloat16:
+        return L.DTYPE_BF16
+    if dt == torch.float16:
+        return L.DTYPE_F16
+    raise L.SjdLibraryError(f"SJD HIP kernels support bf16/fp16 KV and activations, got {dt}")
+
+
+def make_rule(ranges=(), forced=-1, top_k=0, top_p=None):
+    r = L.RowRule()
+    ranges = list(ranges)
+    if len(ranges) > L.MAX_RANGES:
+        raise ValueError(f"grammar needs {len(ranges)} allowed ranges, kernel supports {L.MAX_RANGES}")
+    r.n_ranges = len(ranges)
+    for i, (lo, hi) in enumerate(ranges):
+        r.lo[i], r.hi[i] = int(lo), int(hi)
+    r.forced, r.top_k = int(forced), int(top_k or 0)
+    import numpy as np
+    r.top_p_thr = -1.0 if (top_p is None or top_p >= 1.0) else float(np.float32(1.0 - float(top_p)))
+    return r
+
+
+class DeviceBlob:
+    """A ctypes struct mirrored in pinned host memory and in a device buffer (one async H2D per upload)."""
+
+    def __init__(self, ctype, device):
+        self.ctype = ctype
+        self.nbytes = ctypes.sizeof(ctype)
+        self.host = torch.zeros(self.nbytes, dtype=torch.uint8, pin_memory=True)
+        self.dev = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.view = ctype.from_address(self.host.data_ptr())
+
+    def upload(self):
+        self.dev.copy_(self.host, non_blocking=True)
+
+    def download(self):
+        self.host.copy_(self.dev)
+        return self.view
+
+    def field_ptr(self, name):
+        return ctypes.c_void_p(self.dev.data_ptr() + getattr(self.ctype, name).offset)
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.dev.data_ptr())
+
+
+def reguess(params: DeviceBlob, state: DeviceBlob, input_ids_out: torch.Tensor):
+    n_batch, max_rows = input_ids_out.shape
+    assert input_ids_out.dtype == torch.int64 and input_ids_out.is_contiguous()
+    L.check(L.load().sjd_reguess(params.ptr, state.ptr, _ptr(input_ids_out), n_batch, max_rows, _stream()), "sjd_reguess")
+
+
+def logits_to_probs_sample(logits_c, logits_u, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr):
+    """logits_c/u: [rows, V] fp32 views with a common row stride (last dim contiguous)."""
+    max_rows, V = probs_out.shape
+    assert logits_c.dtype == torch.float32 and logits_c.stride(-1) == 1 and probs_out.is_contiguous()
+    assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V
+    if logits_u is not None:
+        assert logits_u.stride(-2) == logits_c.stride(-2) and logits_u.stride(-1) == 1
+    L.check(L.load().sjd_logits_to_probs_sample(_ptr(logits_c), _ptr(logits_u), logits_c.stride(-2), float(guidance),
+                                               max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out), tokens_out_ptr,
+                                               _stream()), "sjd_logits_to_probs_sample")
+
+
+def verify_accept(params: DeviceBlob, state: DeviceBlob, probs, prev_probs, rs, noise2, scratch):
+    max_rows, V = probs.shape
+    for t in (probs, prev_probs, rs, noise2, scratch):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    L.check(L.load().sjd_verify_accept(params.ptr, state.ptr, _ptr(probs), _ptr(prev_probs), _ptr(rs), _ptr(noise2),
+                                      _ptr(scratch), max_rows, V, _stream()), "sjd_verify_accept")
+
+
+def kv_append(k_new, v_new, k_cache, v_cache, params, kv_len):
+    """k_new/v_new [B,n,Hkv,D]; k_cache/v_cache [B,Hkv,S,D] (one layer)."""
+    B, n, Hkv, D = k_new.shape
+    assert k_new.is_contiguous() and v_new.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous()
+    L.check(L.load().sjd_kv_append(_ptr(k_new), _ptr(v_new), _ptr(k_cache), _ptr(v_cache), B, n, Hkv, D,
+                                  k_cache.shape[2], _dtype_code(k_new.dtype), params.ptr if params is not None else None,
+                                  int(kv_len), _stream()), "sjd_kv_append")
+
+
+def attention_workspace(B, H, n_rows, D, n_split, device):
+    nbytes = L.load().sjd_attention_workspace_bytes(B, H, n_rows, D, n_split)
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+
+
+def draft_window_attention(q, k_cache, v_cache, out, key_start, params, kv_len, n_split, workspace):
+    """q/out [B,n,H,D]; caches [B,Hkv,S,D] already holding the window rows; key_start int32 [B] (device)."""
+    B, n, H, D = q.shape
+    assert q.is_contiguous() and out.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert key_start is None or (key_start.dtype == torch.int32 and key_start.is_cuda)
+    need = L.load().sjd_attention_workspace_bytes(B, H, n, D, n_split)
+    assert workspace.numel() * 4 >= need, "attention workspace too small"
+    L.check(L.load().sjd_draft_window_attention(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), B, n, H,
+                                               k_cache.shape[1], D, k_cache.shape[2], _dtype_code(q.dtype),
+                                               _ptr(key_start), params.ptr if params is not None else None, int(kv_len),
+                                               int(n_split), _ptr(workspace), _stream()), "sjd_draft_window_attention")
+
+
+class HipWindowAttention:
+    """Backbone attention backend = K3 append + K1 draft-window attention (the product path)."""
+
+    def __init__(self, n_split=8):
+        L.load()
+        self.n_split = n_split
+        self._ws = None
+        self._key_start = None
+        self.params = None          # DeviceBlob(IterParams) when the engine drives kv_len from the device
+
+    def __call__(self, layer, q, k, v, cache, kv_len, key_start):
+        B, n, H, D = q.shape
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        kc, vc = cache.k[layer], cache.v[layer]
+        if isinstance(key_start, torch.Tensor) and key_start.is_cuda and key_start.dtype == torch.int32:
+            ks = key_start
+        else:
+            ks = torch.as_tensor(key_start, dtype=torch.int32).to(q.device)
+        need = L.load().sjd_attention_workspace_bytes(B, H, n, D, self.n_split) // 4
+        if self._ws is None or self._ws.numel() < need or self._ws.device != q.device:
+            self._ws = torch.empty(need, dtype=torch.float32, device=q.device)
+        out = torch.empty_like(q)
+        kv_host = 0 if self.params is not None else int(kv_len)
+        kv_append(k, v, kc, vc, self.params, kv_host)
+        draft_window_attention(q, kc, vc, out, ks, self.params, kv_host, self.n_split, self._ws)
+        return out

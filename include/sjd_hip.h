@@ -1,0 +1,125 @@
+/*
+ * sjd_hip.h -- C-ABI of the MI355X-native Speculative Jacobi Decoding hot path (libsjd_hip.so).
+ *
+ * Drop-in boundary.  The reference (tyshiwo1/Accelerating-T2I-AR-with-SJD) has no FFI: its hot path is
+ * Python on top of ATen ops.  Each entry point below replaces the reference Python function named next to
+ * it; a maintainer binds them with ctypes and calls them from the reference's own
+ * `_sample` hook.  Conventions:
+ *   - every pointer is a DEVICE pointer unless the name starts with h_; no ownership is taken, nothing
+ *     is allocated, the call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success, a negative SJD_ERR_* otherwise; never throws; no global mutable state;
+ *   - per-iteration dynamic scalars live in a device-resident `sjd_iter_params` blob that the host fills
+ *     and uploads once per iteration, so that the launch sequence is shape-static (hipGraph friendly).
+ */
+#ifndef SJD_HIP_H
+#define SJD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SJD_VERSION 100
+#define SJD_MAX_WINDOW 32      /* max draft-window length L (reference max_num_new_tokens: 16 / 32) */
+#define SJD_MAX_RANGES 4
+
+#define SJD_OK 0
+#define SJD_ERR_BAD_ARG (-1)
+#define SJD_ERR_UNSUPPORTED (-2)
+#define SJD_ERR_LAUNCH (-3)
+
+#define SJD_DTYPE_BF16 0
+#define SJD_DTYPE_F16 1
+
+/* One row of the "3-dim" logits processors, reduced to what the kernels need.  Built on the host from
+ * integer grammar state; replaces MultiTokensVLLogitsProcessor / MultiTokensInterleavedTopKLogitsWarper /
+ * TopPLogitsWarper3d / EOLLogitProcessor3d / the Anole 3d processors
+ * (reference scheduler/logit_processor_3dim.py:45-204, 207-419; scheduler/jacobi_iteration_emu3.py:44-128). */
+typedef struct sjd_row_rule {
+    int32_t n_ranges;               /* 0: every column allowed */
+    int32_t lo[SJD_MAX_RANGES];     /* allowed columns = union of [lo,hi) */
+    int32_t hi[SJD_MAX_RANGES];
+    int32_t forced;                 /* >=0: p = one-hot(forced) (forced EOL / end-of-image rows); -1: none */
+    int32_t top_k;                  /* <=0 or >=V: off */
+    float   top_p_thr;              /* float32(1 - top_p); <0: off */
+} sjd_row_rule;
+
+/* Host-built, device-resident control blob for ONE SJD iteration. */
+typedef struct sjd_iter_params {
+    int32_t n_rows;                 /* window length n of this iteration (1..SJD_MAX_WINDOW) */
+    int32_t kv_len;                 /* cache rows already valid before this window */
+    int32_t use_cfg;                /* 1: z = g*(c-u)+u ; 0: z = c  (check_is_force_no_cfg, JL:70-80) */
+    int32_t scheme;                 /* 0: speculative_jacobi ; 1: jacobi */
+    int32_t n_fresh;                /* trailing window rows filled with fresh random ids */
+    int32_t reserved[3];
+    int64_t fresh_tok[SJD_MAX_WINDOW];            /* random re-guess ids (host global RNG, JL:505-509), packed */
+    sjd_row_rule rules[SJD_MAX_WINDOW];           /* rules of the sampling call, row j */
+    sjd_row_rule resid_rules[SJD_MAX_WINDOW];     /* rule of the residual call if rejection happens at i=j+1 */
+} sjd_iter_params;
+
+/* Device-resident decode state carried between iterations (written by sjd_verify_accept, read by sjd_reguess). */
+typedef struct sjd_state {
+    int32_t m;                      /* tokens emitted by the last iteration (first_misaligned, 1..n) */
+    int32_t rejected;               /* 1: a residual resample happened (the g-stream consumed noise2) */
+    int32_t n_prev;                 /* window length of the last iteration */
+    int32_t prob_buf;               /* which of the two prob buffers holds the last iteration's rows */
+    int64_t tokens[SJD_MAX_WINDOW]; /* corrected samples Y of the last iteration: [0,m) emitted, [m,n) carried */
+    int64_t win_tok[SJD_MAX_WINDOW];/* current window ids */
+    int32_t q_src[SJD_MAX_WINDOW];  /* row of the previous prob buffer holding the draft distribution, -1: one-hot */
+} sjd_state;
+
+int sjd_version(void);
+const char *sjd_error_string(int code);
+
+/* K5 -- window assembly / re-guess.
+ * replaces prepare_inputs_for_generation_jacobi + get_multi_token_for_preparation('random') +
+ * gather_from_split_tensors (reference scheduler/jacobi_iteration_lumina_mgpt.py:470-514, 606-740;
+ * scheduler/logit_processor_3dim.py:513-537).  window = [last emitted | carried samples | fresh ids];
+ * draft rows of fresh ids are implicit one-hots (q_src = -1).  Also writes the ids, replicated for each of
+ * the `n_batch` CFG rows, to `input_ids_out` [n_batch, max_rows] (feeds the embedding lookup). */
+int sjd_reguess(const sjd_iter_params *params, sjd_state *state, int64_t *input_ids_out, int n_batch, int max_rows,
+                void *stream);
+
+/* K2 -- logits -> CFG -> grammar -> top-k/top-p -> softmax -> multinomial.
+ * replaces sampling_logits2tokens + the 3-dim processors (reference jacobi_iteration_lumina_mgpt.py:82-132).
+ * logits_c/logits_u: fp32 rows of stride `row_stride` elements (logits_u may be NULL: never CFG);
+ * noise: [max_rows, V] Exp(1) samples (torch.multinomial == argmax(p/noise));
+ * probs_out: [max_rows, V] fp32; tokens_out: int64 [max_rows] (state->tokens works).  Rows >= params->n_rows
+ * are skipped. */
+int sjd_logits_to_probs_sample(const float *logits_c, const float *logits_u, int64_t row_stride, float guidance,
+                               int max_rows, int V, const sjd_iter_params *params, const float *noise,
+                               float *probs_out, int64_t *tokens_out, void *stream);
+
+/* K4 -- probabilistic verify-and-accept (longest accepted prefix) + residual resample of the first reject.
+ * replaces SpeculativeSampler.__call__ / find_first_misaligned_token_inds / prefix_matching_next_tokens
+ * (reference jacobi_iteration_lumina_mgpt.py:203-376).
+ * probs: this iteration's rows [max_rows, V]; prev_probs: the previous iteration's rows (draft distributions,
+ * indexed by state->q_src); rs: [max_rows, V] uniforms (only rs[i, win_tok[i]] is read, JL:282);
+ * noise2: [V] Exp(1) for the residual multinomial; scratch: >= V floats.
+ * Updates state->{m, rejected, n_prev, tokens}. */
+int sjd_verify_accept(const sjd_iter_params *params, sjd_state *state, const float *probs, const float *prev_probs,
+                      const float *rs, const float *noise2, float *scratch, int max_rows, int V, void *stream);
+
+/* K3 -- KV append into the static cache (rollback is implicit: rejected rows are simply overwritten).
+ * replaces DynamicCache.update's torch.cat + delete_false_key_value (reference modeling_chameleon.py:547;
+ * jacobi_iteration_lumina_mgpt.py:47-54, 401-409) and KVCache.update (llamagen/llamagen.py:210-219).
+ * k_new/v_new: [B, n_rows, H_kv, D]; k_cache/v_cache: [B, H_kv, S_max, D] of this layer; rows land at
+ * [kv_len, kv_len + n_rows).  kv_len is read from params when params != NULL, else from `kv_len`. */
+int sjd_kv_append(const void *k_new, const void *v_new, void *k_cache, void *v_cache, int B, int n_rows, int H_kv,
+                  int D, int S_max, int dtype, const sjd_iter_params *params, int kv_len, void *stream);
+
+/* K1 -- draft-window attention over the static cache (MFMA QK^T / PV, fp32 online softmax, split over keys).
+ * replaces _update_causal_mask + repeat_kv + scaled_dot_product_attention
+ * (reference jacobi_iteration_lumina_mgpt.py:1256-1336; modeling_chameleon.py:549-576; llamagen.py:264-273).
+ * q: [B, n_rows, H, D]; out: [B, n_rows, H, D]; caches as in sjd_kv_append and ALREADY holding the window rows.
+ * Row i of batch b sees key j iff key_start[b] <= j <= kv_len + i.  workspace: >= sjd_attention_workspace_bytes. */
+int64_t sjd_attention_workspace_bytes(int B, int H, int n_rows, int D, int n_split);
+int sjd_draft_window_attention(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows,
+                               int H, int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
+                               const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SJD_HIP_H */

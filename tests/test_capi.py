@@ -1,0 +1,55 @@
+"""CPU: the C-ABI shared library builds for gfx950, loads, and exports every symbol include/sjd_hip.h declares."""
+import ctypes
+import os
+import re
+
+from tests.conftest import ROOT
+
+
+def _ensure_built():
+    import sjd_amd._lib as L
+    if not os.path.exists(L.SO_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return L
+
+
+def test_exports_match_header():
+    L = _ensure_built()
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "sjd_hip.h")).read()
+    declared = set(re.findall(r"\b(sjd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.sjd_version() == int(re.search(r"#define SJD_VERSION (\d+)", hdr).group(1))
+    assert lib.sjd_error_string(-2) == b"unsupported configuration"
+
+
+def test_struct_layouts_match_header():
+    L = _ensure_built()
+    assert ctypes.sizeof(L.RowRule) == 48
+    assert ctypes.sizeof(L.IterParams) == 32 + 8 * 32 + 2 * 48 * 32
+    assert L.IterParams.fresh_tok.offset == 32 and L.IterParams.rules.offset == 32 + 256
+    assert ctypes.sizeof(L.State) == 16 + 8 * 32 * 2 + 4 * 32
+    assert L.State.tokens.offset == 16 and L.State.win_tok.offset == 16 + 256 and L.State.q_src.offset == 16 + 512
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    L = _ensure_built()
+    lib = L.load()
+    assert lib.sjd_reguess(None, None, None, 1, 16, None) == -1
+    assert lib.sjd_logits_to_probs_sample(None, None, 0, 1.0, 16, 100, None, None, None, None, None) == -1
+    assert lib.sjd_verify_accept(None, None, None, None, None, None, None, 16, 100, None) == -1
+    assert lib.sjd_attention_workspace_bytes(2, 32, 16, 128, 8) == 2 * 32 * 1 * 8 * 16 * 130 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import sjd_amd._lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "SO_PATH", str(tmp_path / "nope.so"))
+    try:
+        L.load()
+        raise AssertionError("expected SjdLibraryError")
+    except L.SjdLibraryError as e:
+        assert "no CPU/torch fallback" in str(e)

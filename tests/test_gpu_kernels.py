@@ -1,0 +1,267 @@
+"""GPU parity: HIP kernels (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar: K2 / K4 / K5 bit-exact (token ids, accept length, AND fp32 probabilities -- the oracle and the kernels share a
+canonical summation order / exp); K1+K3 within bf16 tolerance of the fp64 attention reference.
+"""
+import ctypes
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sjd_oracle as O
+from oracle.attention_ref import OracleWindowAttention
+from tests.helpers import make_pq
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _ops():
+    import sjd_amd.ops as ops
+    import sjd_amd._lib as L
+    L.load()
+    return ops, L
+
+
+def to_dev_rule(L, ops, r):
+    rr = L.RowRule()
+    ctypes.memmove(ctypes.byref(rr), ctypes.byref(r), ctypes.sizeof(rr))
+    return rr
+
+
+def run_k2(dev, logits, use_cfg, guidance, rules, noise, max_rows=None):
+    ops, L = _ops()
+    n, V = noise.shape
+    max_rows = max_rows or n
+    params = ops.DeviceBlob(L.IterParams, dev)
+    params.view.n_rows, params.view.use_cfg = n, int(use_cfg)
+    for j, r in enumerate(rules):
+        params.view.rules[j] = to_dev_rule(L, ops, r)
+    params.upload()
+    lg = torch.from_numpy(logits).to(dev)
+    nz = torch.zeros(max_rows, V, device=dev)
+    nz[:n] = torch.from_numpy(noise).to(dev)
+    probs = torch.full((max_rows, V), -7.0, device=dev)
+    toks = torch.full((max_rows,), -5, dtype=torch.int64, device=dev)
+    ops.logits_to_probs_sample(lg[0], lg[1], guidance, params, nz, probs, ctypes.c_void_p(toks.data_ptr()))
+    torch.cuda.synchronize()
+    return toks[:n].cpu().numpy(), probs[:n].cpu().numpy()
+
+
+K2_CASES = [
+    # name, V, n, rules builder
+    ("lumina_image_65536", 65536, 16, lambda n: O.lumina_rules([9000] * 5 + [8197, 8828, 8828] + [100] * 40, n, 2000, 10)),
+    ("lumina_eol_rows", 9216, 16, lambda n: O.lumina_rules([9000] * 5 + [8197, 8808, 8808] + [100] * 3, n, 2000, 10)),
+    ("lumina_text_mode", 65536, 3, lambda n: O.lumina_rules([9000] * 7, n, 2000, 10)),
+    ("llamagen_16384", 16384, 16, lambda n: O.llamagen_rules([], n, 1000, 1.0)),
+    ("llamagen_no_topk", 16384, 5, lambda n: O.llamagen_rules([], n, 0, 1.0)),
+    ("emu3_odd_vocab", 184622, 8, lambda n: O.emu3_rules([5, 6, 151851] + [151854 + 7] * 88, n, 90, 90, 151854, 32768,
+                                                         151851, 151853, 151850, 151846, 151847, 151643, 2048)),
+    ("tiny_vocab", 1000, 2, lambda n: O.llamagen_rules([], n, 10, 1.0)),
+]
+
+
+@pytest.mark.parametrize("name,V,n,builder", K2_CASES, ids=[c[0] for c in K2_CASES])
+@pytest.mark.parametrize("use_cfg", [True, False])
+def test_k2_bit_exact(dev, name, V, n, builder, use_cfg):
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    logits = (torch.randn(2, n, V, generator=g) * 3.0).numpy()
+    noise = torch.empty(n, V).exponential_(generator=g).numpy()
+    rules = builder(n)
+    toks_ref, probs_ref = O.logits_to_probs_sample(logits[0], logits[1] if use_cfg else None, 3.0, rules, noise)
+    toks, probs = run_k2(dev, logits, use_cfg, 3.0, rules, noise, max_rows=16)
+    assert toks.tolist() == toks_ref.tolist()
+    assert np.array_equal(probs.view(np.uint32), probs_ref.view(np.uint32)), \
+        f"max |dp| = {np.abs(probs - probs_ref).max()}"
+
+
+def test_k2_matches_torch_softmax(dev):
+    """Independent fp32 torch reference of the same op (tolerance, not bit-exact)."""
+    V, n = 65536, 16
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(2, n, V, generator=g) * 3.0
+    noise = torch.empty(n, V).exponential_(generator=g)
+    rules = O.llamagen_rules([], n, 2000, 1.0)
+    toks, probs = run_k2(dev, logits.numpy(), True, 3.0, rules, noise.numpy())
+    z = 3.0 * (logits[0] - logits[1]) + logits[1]
+    kth = torch.topk(z, 2000)[0][..., -1, None]
+    ref = torch.softmax(z.masked_fill(z < kth, -float("inf")), dim=-1)
+    np.testing.assert_allclose(probs, ref.numpy(), atol=1e-6, rtol=1e-5)
+    assert toks.tolist() == torch.argmax(ref / noise, dim=-1).tolist()
+
+
+def run_k4(dev, win, Y, p, q_rows, rs, resid, e2, scheme=0, max_rows=16):
+    ops, L = _ops()
+    n, V = p.shape
+    params = ops.DeviceBlob(L.IterParams, dev)
+    state = ops.DeviceBlob(L.State, dev)
+    params.view.n_rows, params.view.scheme = n, scheme
+    for j, r in enumerate(resid):
+        params.view.resid_rules[j] = to_dev_rule(L, ops, r)
+    prev = torch.zeros(max_rows, V, device=dev)
+    for i in range(n):
+        state.view.win_tok[i] = int(win[i])
+        state.view.tokens[i] = int(Y[i])
+        if q_rows[i] is None:
+            state.view.q_src[i] = -1
+        else:
+            state.view.q_src[i] = i
+            prev[i] = torch.from_numpy(np.asarray(q_rows[i])).to(dev)
+    params.upload()
+    state.dev.copy_(state.host)
+    probs = torch.zeros(max_rows, V, device=dev)
+    probs[:n] = torch.from_numpy(p).to(dev)
+    rsd = torch.zeros(max_rows, V, device=dev)
+    rsd[:n] = torch.from_numpy(rs).to(dev)
+    ops.verify_accept(params, state, probs, prev, rsd, torch.from_numpy(e2).to(dev), torch.empty(V, device=dev))
+    torch.cuda.synchronize()
+    st = state.download()
+    return st.m, [st.tokens[i] for i in range(n)], bool(st.rejected)
+
+
+@pytest.mark.parametrize("mode,L,grammar", [("carried", 16, None), ("mixed", 16, None), ("fresh", 16, None),
+                                            ("far", 16, None), ("equal", 8, None), ("mixed", 16, "lumina"),
+                                            ("fresh", 2, None), ("mixed", 16, "llamagen"), ("mixed", 32, None)])
+@pytest.mark.parametrize("V", [9216, 65536])
+def test_k4_bit_exact(dev, mode, L, grammar, V):
+    seed = 9000 + L + len(mode)
+    p, q, draft = make_pq(V, L, seed, mode)
+    g = torch.Generator().manual_seed(seed + 1)
+    adv = torch.multinomial(p[0], 1, generator=g)[:, 0].numpy()
+    rs = torch.rand((L, V), generator=g).numpy()
+    e2 = torch.empty(V).exponential_(generator=g).numpy()
+    win = draft[0].tolist()
+    ctx = [9000] * 5 + [8197, 8808, 8808] + [100] * 3
+    if grammar == "lumina":
+        rfn = lambda c: O.lumina_rules(c, 1, 2000, 10)[0]
+    elif grammar == "llamagen":
+        rfn = lambda c: O.llamagen_rules(c, 1, 100, 1.0)[0]
+    else:
+        rfn = lambda c: O.rule()
+    resid = [rfn(ctx + win[1:i]) for i in range(1, L)]
+    onehot = [bool((q[0, i] == 1).any()) and float(q[0, i].sum()) == 1.0 and i > 0 for i in range(L)]
+    q_rows = [None if onehot[i] else q[0, i].numpy() for i in range(L)]
+    m_ref, tok_ref, rej_ref = O.verify_accept(win, adv, p[0].numpy(), q_rows, rs, resid, e2)
+    m, tok, rej = run_k4(dev, win, adv, p[0].numpy(), q_rows, rs, resid, e2, max_rows=32)
+    assert (m, rej) == (m_ref, rej_ref)
+    assert tok[:m] == tok_ref[:m].tolist()
+    assert tok[m:] == adv[m:].tolist()       # the unverified tail is carried unchanged
+
+
+def test_k4_jacobi_scheme(dev):
+    V, L = 9216, 16
+    g = torch.Generator().manual_seed(3)
+    win = torch.randint(4, 8196, (L,), generator=g).tolist()
+    Y = list(win[1:]) + [77]
+    Y[6] = (Y[6] + 1) % 8000
+    p = torch.softmax(torch.randn(L, V, generator=g), -1).numpy()
+    m, tok, rej = run_k4(dev, win, Y, p, [None] * L, np.zeros((L, V), np.float32), [O.rule()] * L, np.ones(V, np.float32),
+                         scheme=1)
+    assert m == O.first_mismatch(win, Y) == 7 and not rej and tok == Y
+
+
+def test_k5_window_assembly(dev):
+    ops, L = _ops()
+    params = ops.DeviceBlob(L.IterParams, dev)
+    state = ops.DeviceBlob(L.State, dev)
+    ids = torch.zeros(2, 16, dtype=torch.int64, device=dev)
+    for n_prev, m, n in [(16, 3, 16), (16, 16, 16), (16, 1, 4), (1, 1, 16), (8, 5, 1), (16, 9, 12)]:
+        Y = list(range(1000, 1000 + n_prev))
+        a = max(0, min(n_prev - m, n - 1))
+        fresh = list(range(5000, 5000 + n - 1 - a))
+        state.view.m, state.view.n_prev = m, n_prev
+        for i, t in enumerate(Y):
+            state.view.tokens[i] = t
+        params.view.n_rows, params.view.n_fresh = n, len(fresh)
+        for i, t in enumerate(fresh):
+            params.view.fresh_tok[i] = t
+        params.upload()
+        state.dev.copy_(state.host)
+        ops.reguess(params, state, ids)
+        torch.cuda.synchronize()
+        st = state.download()
+        want = [Y[m - 1]] + Y[m:m + a] + fresh
+        assert [st.win_tok[i] for i in range(n)] == want
+        assert [st.q_src[i] for i in range(n)] == [m - 1 + i for i in range(a + 1)] + [-1] * (n - 1 - a)
+        assert ids[0, :n].tolist() == want and ids[1, :n].tolist() == want
+
+
+class _Cache:
+    def __init__(self, k, v):
+        self.k, self.v = k, v
+
+
+ATTN_CASES = [
+    # name, B, H, Hkv, D, S_max, kv_len, n, key_start, dtype
+    ("mha_d128_mid", 2, 4, 4, 128, 1280, 1216, 16, [0, 59], torch.bfloat16),
+    ("mha_d128_empty_cache", 2, 4, 4, 128, 128, 0, 16, [0, 0], torch.bfloat16),
+    ("mha_d128_unaligned", 2, 2, 2, 128, 256, 77, 16, [0, 33], torch.bfloat16),
+    ("mha_d128_short_window", 2, 2, 2, 128, 256, 100, 5, [0, 10], torch.bfloat16),
+    ("gqa4_d128", 2, 8, 2, 128, 4224, 4100, 16, [3, 0], torch.float16),
+    ("gqa2_d128", 1, 4, 2, 128, 512, 300, 16, [0], torch.bfloat16),
+    ("mha_d64_llamagen", 2, 12, 12, 64, 288, 200, 16, [0, 0], torch.bfloat16),
+    ("prefill_60_rows", 2, 4, 4, 128, 128, 0, 60, [0, 59], torch.bfloat16),
+    ("prefill_17_rows_offset", 1, 2, 2, 128, 128, 9, 17, [2], torch.bfloat16),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+@pytest.mark.parametrize("n_split", [1, 8])
+def test_k1_k3_attention(dev, case, n_split):
+    ops, L = _ops()
+    name, B, H, Hkv, D, S_max, kv_len, n, key_start, dtype = case
+    g = torch.Generator().manual_seed(len(name))
+    kc = torch.randn(1, B, Hkv, S_max, D, generator=g).to(dtype)
+    vc = torch.randn(1, B, Hkv, S_max, D, generator=g).to(dtype)
+    q = (torch.randn(B, n, H, D, generator=g) * 1.5).to(dtype)
+    k = torch.randn(B, n, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(B, n, Hkv, D, generator=g).to(dtype)
+    ref_cache = _Cache(kc.clone(), vc.clone())
+    ref = OracleWindowAttention()(0, q, k, v, ref_cache, kv_len, key_start).float()
+    dcache = _Cache(kc.clone().to(dev), vc.clone().to(dev))
+    attn = ops.HipWindowAttention(n_split=n_split)
+    out = attn(0, q.to(dev), k.to(dev), v.to(dev), dcache, kv_len, key_start)
+    torch.cuda.synchronize()
+    # K3: the cache rows were appended exactly
+    assert torch.equal(dcache.k.cpu()[0, :, :, :kv_len + n], ref_cache.k[0, :, :, :kv_len + n])
+    assert torch.equal(dcache.v.cpu()[0, :, :, :kv_len + n], ref_cache.v[0, :, :, :kv_len + n])
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    # rows with at least one visible key
+    vis = torch.tensor([[kv_len + i >= key_start[b] for i in range(n)] for b in range(B)])
+    err = (got - ref).abs()
+    assert err[vis].max() < 3e-2, f"max err {err[vis].max()}"
+    assert err[vis].mean() < 3e-3, f"mean err {err[vis].mean()}"
+    assert (got[~vis] == 0).all()
+
+
+def test_k1_device_side_kv_len(dev):
+    """kv_len / n_rows read from the device-resident sjd_iter_params blob (shape-static launch)."""
+    ops, L = _ops()
+    B, H, D, S_max, n_max = 2, 4, 128, 512, 16
+    g = torch.Generator().manual_seed(11)
+    kc = torch.randn(1, B, H, S_max, D, generator=g).to(torch.bfloat16)
+    vc = torch.randn(1, B, H, S_max, D, generator=g).to(torch.bfloat16)
+    attn = ops.HipWindowAttention(n_split=4)
+    attn.params = ops.DeviceBlob(L.IterParams, dev)
+    dcache = _Cache(kc.clone().to(dev), vc.clone().to(dev))
+    for kv_len, n in [(37, 16), (200, 7), (201, 1)]:
+        q = torch.randn(B, n_max, H, D, generator=g).to(torch.bfloat16)
+        k = torch.randn(B, n_max, H, D, generator=g).to(torch.bfloat16)
+        v = torch.randn(B, n_max, H, D, generator=g).to(torch.bfloat16)
+        ref_cache = _Cache(dcache.k.cpu().clone(), dcache.v.cpu().clone())
+        ref = OracleWindowAttention()(0, q[:, :n], k[:, :n], v[:, :n], ref_cache, kv_len, [0, 5]).float()
+        attn.params.view.kv_len, attn.params.view.n_rows = kv_len, n
+        attn.params.upload()
+        out = attn(0, q.to(dev), k.to(dev), v.to(dev), dcache, -1, [0, 5])
+        torch.cuda.synchronize()
+        err = (out[:, :n].float().cpu() - ref).abs()
+        assert err.max() < 3e-2 and err.mean() < 3e-3

@@ -1,0 +1,221 @@
+"""SJD decode engine: the reference's `_sample` loop (scheduler/jacobi_iteration_lumina_mgpt.py:912-1249) as a
+fixed launch sequence over device-resident state.
+
+Per iteration (reference line numbers in brackets):
+   host   n, a', fresh random ids (torch.randint on the GLOBAL CPU generator, JL:505), grammar rules -> ONE pinned
+          sjd_iter_params blob, one async H2D
+   K5     window = [last emitted | carried samples | fresh ids]                              [JL:606-701]
+   fwd    backbone.forward_window (PyTorch-ROCm GEMMs; K3 append + K1 attention per layer)   [JL:1107]
+   K2     CFG + grammar + top-k + softmax + multinomial -> p[n,V], Y[n]                      [JL:82-132]
+   K4     accept scan + residual resample -> m, corrected Y                                  [JL:247-376]
+   host   reads back {m, rejected, Y} (ONE sync), appends Y[:m], kv_len += m                 [JL:378-430]
+The draft distributions of the next window are rows (m-1 ...) of this iteration's p buffer, so nothing is copied
+(two p buffers alternate); fresh random drafts are implicit one-hots; KV rollback is the kv_len update.
+
+RNG streams mirror the reference: device generator g for exponential_/rand (consumed in the
+same order and shapes), global CPU generator for the fresh ids.  The residual draw is made from g speculatively
+and the generator state is rewound when no rejection happened.
+"""
+import ctypes
+import random
+import time
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+@dataclass
+class SJDConfig:
+    jacobi_loop_interval_l: int = 1
+    jacobi_loop_interval_r: int = (768 // 16) ** 2 + 768 // 16
+    max_num_new_tokens: int = 16
+    guidance_scale: float = 3.0
+    seed: Optional[int] = 42
+    do_cfg: bool = True
+    prefix_token_sampler_scheme: str = "speculative_jacobi"
+    multi_token_init_scheme: str = "random"
+    img_vocab_lo: int = 4
+    img_vocab_n: int = 8192
+    max_length: int = 1 << 30
+    eos_token_ids: tuple = ()
+
+
+@dataclass
+class WindowSpec:
+    """What differs between model families at the `_sample` boundary."""
+    first_tokens: torch.Tensor            # [B_cfg, P0] ids fed by the first (prefill) iteration
+    first_positions: torch.Tensor         # [B_cfg, P0]
+    key_start: torch.Tensor               # int32 [B_cfg]: first visible cache row per batch row
+    pos_offset: torch.Tensor              # int64 [B_cfg]: RoPE position = cache row + pos_offset
+    kv_base: int = 0                      # cache rows valid before `_sample` starts (LlamaGen: cond tokens)
+
+
+@dataclass
+class DecodeStats:
+    nfe: int = 0
+    tokens: int = 0
+    seconds: float = 0.0
+    matched: List[int] = field(default_factory=list)
+
+
+def set_seed(seed):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+class SJDEngine:
+    def __init__(self, backbone, vocab_size, device, max_window=16, n_batch=2):
+        L.load()                                   # fail loudly if the HIP extension is missing
+        if max_window > L.MAX_WINDOW:
+            raise ValueError(f"max_window {max_window} > {L.MAX_WINDOW}")
+        self.backbone, self.V, self.device, self.Lmax, self.B = backbone, int(vocab_size), torch.device(device), max_window, n_batch
+        dev = self.device
+        self.params = ops.DeviceBlob(L.IterParams, dev)
+        self.state = ops.DeviceBlob(L.State, dev)
+        self.probs = torch.zeros(2, self.Lmax, self.V, dtype=torch.float32, device=dev)
+        self.noise = torch.empty(self.Lmax, self.V, dtype=torch.float32, device=dev)
+        self.rs = torch.empty(self.Lmax, self.V, dtype=torch.float32, device=dev)
+        self.noise2 = torch.empty(1, self.V, dtype=torch.float32, device=dev)
+        self.scratch = torch.empty(self.V, dtype=torch.float32, device=dev)
+        self.input_ids = torch.zeros(self.B, self.Lmax, dtype=torch.int64, device=dev)
+        self.arange = torch.arange(self.Lmax, device=dev)
+        self.tokens_ptr = self.state.field_ptr("tokens")
+        self.hook = None                            # test hook: called with per-iteration device tensors
+
+    # ------------------------------------------------------------------------------------------------
+    def _fill_params(self, n, kv_len, use_cfg, scheme, fresh, rules, resid):
+        p = self.params.view
+        p.n_rows, p.kv_len, p.use_cfg, p.scheme, p.n_fresh = n, kv_len, int(use_cfg), scheme, len(fresh)
+        for i, t in enumerate(fresh):
+            p.fresh_tok[i] = t
+        for j, r in enumerate(rules):
+            p.rules[j] = r
+        for j, r in enumerate(resid):
+            p.resid_rules[j] = r
+        self.params.upload()
+
+    @torch.no_grad()
+    def decode(self, prompt: List[int], spec: WindowSpec, grammar, cfg: SJDConfig):
+        """prompt: accepted ids handed to `_sample` (the context the grammar sees).  Returns (sequence, DecodeStats)."""
+        if cfg.multi_token_init_scheme != "random":
+            # the released reference raises IndexError for the horizon schemes (SURVEY.md 8a defect ledger)
+            raise NotImplementedError("only multi_token_init_scheme='random' is parity-checkable")
+        if cfg.prefix_token_sampler_scheme not in ("speculative_jacobi", "jacobi"):
+            raise ValueError(f"prefix_token_sampler_scheme: {cfg.prefix_token_sampler_scheme}")   # JL:1048
+        dev, V, B = self.device, self.V, self.B
+        scheme = 0 if cfg.prefix_token_sampler_scheme == "speculative_jacobi" else 1
+        do_cfg = cfg.do_cfg and (cfg.guidance_scale != 1)
+        X = [int(t) for t in prompt]
+        P = len(X)
+        gen = None
+        if cfg.seed is not None:                                                   # JL:1021-1023
+            set_seed(cfg.seed)
+            gen = torch.Generator(dev).manual_seed(cfg.seed)
+        l_abs, r_abs = P + cfg.jacobi_loop_interval_l, P + cfg.jacobi_loop_interval_r
+        W = min(cfg.max_num_new_tokens, self.Lmax)
+        if cfg.max_num_new_tokens > self.Lmax:
+            raise ValueError("max_num_new_tokens exceeds the engine's max_window")
+        grammar.start(X)
+        key_start = spec.key_start.to(device=dev, dtype=torch.int32)
+        pos_offset = spec.pos_offset.to(device=dev, dtype=torch.int64)
+        attn = getattr(self.backbone, "attn", None)
+        st = self.state.view
+        stats = DecodeStats()
+        n, kv_len, first, cur_len, cur, n_prev, m_prev = 1, spec.kv_base, True, P, 0, 1, 1
+        t0 = time.perf_counter()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        finished = False
+        while not finished:
+            # ---------------- host: integer bookkeeping only ----------------
+            torch_fresh = []
+            if first:
+                n_rows, a = 1, 0
+                torch.randint(0, cfg.img_vocab_n, (1, 0))
+                rules = grammar.window_rules(1)
+                resid = []
+            else:
+                n_rows = n
+                a = max(0, min(n_prev - m_prev, n - 1))
+                fr = torch.randint(0, cfg.img_vocab_n, (1, n - 1 - a))[0].tolist()   # GLOBAL CPU generator (JL:505)
+                torch_fresh = [cfg.img_vocab_lo + t for t in fr]
+                rules = grammar.window_rules(n_rows)
+                resid = None
+            use_cfg = do_cfg and not grammar.force_no_cfg()
+            if first:
+                self._fill_params(1, kv_len, use_cfg, scheme, [], rules, [])
+                tokens, positions = spec.first_tokens.to(dev), spec.first_positions.to(dev)
+                logits = self.backbone.forward_window(tokens, positions, kv_len, key_start)
+                lc = logits[0, -1:, :]
+                lu = logits[1, -1:, :] if B > 1 else None
+                win_len = tokens.shape[1]
+            else:
+                # window ids are needed on the host only for the residual grammar: carried ids are known from the
+                # previous read-back
+                win_host = [X[-1]] + self._carried[:a] + torch_fresh
+                resid = grammar.residual_rules(win_host) if scheme == 0 else []
+                self._fill_params(n_rows, kv_len, use_cfg, scheme, torch_fresh, rules, resid)
+                ops.reguess(self.params, self.state, self.input_ids)
+                tokens = self.input_ids[:, :n_rows]
+                positions = (kv_len + self.arange[:n_rows])[None, :] + pos_offset[:, None]
+                logits = self.backbone.forward_window(tokens, positions, kv_len, key_start)
+                lc = logits[0]
+                lu = logits[1] if B > 1 else None
+                win_len = n_rows
+            # ---------------- K2: logits -> probs -> tokens ----------------
+            e1 = self.noise[:n_rows]
+            e1.exponential_(generator=gen)                                         # == torch.multinomial (JL:118)
+            ops.logits_to_probs_sample(lc, lu, cfg.guidance_scale, self.params, self.noise, self.probs[cur], self.tokens_ptr)
+            # ---------------- K4: verify / accept ----------------
+            g_state = None
+            if n_rows > 1 and scheme == 0:
+                self.rs[:n_rows].uniform_(0.0, 1.0, generator=gen)                 # torch.rand([1,n,V]) (JL:260)
+                if gen is not None:
+                    g_state = gen.get_state()
+                self.noise2.exponential_(generator=gen)                            # residual multinomial (JL:237)
+            ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0],
+                              self.scratch)
+            if self.hook is not None:
+                self.hook(dict(first=first, n_rows=n_rows, logits_c=lc, logits_u=lu, use_cfg=use_cfg, rules=rules,
+                               resid=resid, noise=e1, rs=self.rs[:n_rows], noise2=self.noise2[0], probs=self.probs[cur],
+                               prev_probs=self.probs[1 - cur], ctx=list(X), scheme=scheme))
+            # ---------------- the single sync of the iteration ----------------
+            self.state.download()
+            m_dev, rejected = int(st.m), bool(st.rejected)
+            if g_state is not None and not rejected:
+                gen.set_state(g_state)
+            Y = [int(st.tokens[i]) for i in range(n_rows)]
+            if n_rows <= 1:
+                m = win_len                      # is_prefilling_phase short-circuit (JL:344-350)
+                emitted = [Y[0]]
+                self._carried = []
+            else:
+                m = m_dev
+                emitted = Y[:m]
+                self._carried = Y[m:]
+            stats.matched.append(m)
+            # ---------------- next window length, append, rollback ----------------
+            n = min(W, r_abs - cur_len) if (l_abs <= cur_len < r_abs) else 1       # JL:1142-1144 (old cur_len)
+            X.extend(emitted)
+            grammar.push(emitted)
+            kv_len += m
+            n_prev, m_prev = n_rows, (1 if n_rows <= 1 else m)
+            cur = 1 - cur
+            first = False
+            stats.nfe += 1
+            if X[-1] in cfg.eos_token_ids or len(X) >= cfg.max_length:             # JL:1200-1201
+                finished = True
+            cur_len = len(X)
+        ev1.record()
+        torch.cuda.synchronize()
+        stats.seconds = ev0.elapsed_time(ev1) / 1000.0
+        stats.tokens = len(X) - P
+        return X, stats

@@ -1,0 +1,239 @@
+"""Host-side integer grammar state -> per-row kernel rules (sjd_row_rule).
+
+The reference evaluates its "3-dim" logits processors with tensor ops and 4+ device->host syncs per call
+(SURVEY.md 3.2).  Here the grammar is pure integer bookkeeping that advances incrementally as tokens are
+accepted (O(1) per token, no rescans, no syncs); the masks themselves are applied inside kernels K2/K4.
+
+  LuminaGrammar   <- MultiTokensVLLogitsProcessor + MultiTokensInterleavedTopKLogitsWarper
+                     (reference scheduler/logit_processor_3dim.py:25-43, 84-155, 190-204)
+  TopKTopPGrammar <- TopKLogitsWarper + TopPLogitsWarper3d (reference llamagen/llamagen_solver.py:458-470,
+                     scheduler/logit_processor_3dim.py:406-419)
+  Emu3Grammar     <- EOLLogitProcessor3d (+ TopK(2048) that HF generate appends)
+                     (reference scheduler/jacobi_iteration_emu3.py:44-128, test_emu3.py:81-90)
+  AnoleGrammar    <- the 3d processors of image-only mode (reference scheduler/jacobi_iteration_anhole.py:194-232,
+                     scheduler/logit_processor_3dim.py:207-353)
+
+Interface: start(ctx) / push(tokens) / window_rules(n) / residual_rules(win) / force_no_cfg().
+residual_rules(win)[i-1] is the rule of the residual resample if the first rejection happens at window
+position i, i.e. evaluated on ctx + win[1:i] (reference jacobi_iteration_lumina_mgpt.py:297-306).
+"""
+from . import ops
+
+
+class _Grammar:
+    def start(self, ctx):
+        self.reset()
+        self.push(ctx)
+
+    def reset(self):
+        raise NotImplementedError
+
+    def push(self, tokens):
+        for t in tokens:
+            self._advance(int(t))
+
+    def _snapshot(self):
+        raise NotImplementedError
+
+    def _restore(self, s):
+        raise NotImplementedError
+
+    def residual_rules(self, win):
+        snap = self._snapshot()
+        out = []
+        for i in range(1, len(win)):
+            out.append(self.window_rules(1)[0])
+            self._advance(int(win[i]))
+        self._restore(snap)
+        return out
+
+    def force_no_cfg(self):
+        return False
+
+
+class LuminaGrammar(_Grammar):
+    def __init__(self, image_top_k=2000, text_top_k=10, image_start_token_id=8197, image_end_token_id=8196,
+                 image_next_line_token_id=8803, img_lo=4, img_hi=8196):
+        self.image_top_k, self.text_top_k = image_top_k, text_top_k
+        self.start_id, self.end_id, self.eol_id = image_start_token_id, image_end_token_id, image_next_line_token_id
+        self.img_lo, self.img_hi = img_lo, img_hi
+        self.reset()
+
+    def reset(self):
+        # length, #start, #end, tokens since the last start token, the two grid tokens after it
+        self.s = (0, 0, 0, -1, 0, 0)
+
+    def _snapshot(self):
+        return self.s
+
+    def _restore(self, s):
+        self.s = s
+
+    def _advance(self, t):
+        n, ns, ne, since, g1, g2 = self.s
+        if since >= 0:
+            since += 1
+            if since == 1:
+                g1 = t
+            elif since == 2:
+                g2 = t
+        if t == self.start_id:
+            ns, since, g1, g2 = ns + 1, 0, 0, 0      # "last start token" (LP:96-97)
+        if t == self.end_id:
+            ne += 1
+        self.s = (n + 1, ns, ne, since, g1, g2)
+
+    def force_no_cfg(self):                        # check_is_force_no_cfg (JL:70-80)
+        return self.s[1] == self.s[2]
+
+    def window_rules(self, n):
+        _, ns, ne, since, g1, g2 = self.s
+        k = self.image_top_k if ns == ne + 1 else self.text_top_k      # LP:195-198
+        if not (ns == ne + 1 and since >= 2):                           # LP:89-102
+            return [ops.make_rule((), -1, k) for _ in range(n)]
+        h, w = (g1 - 8804) * 2, (g2 - 8804) * 2                         # LP:107-111
+        T = since - 2                                                   # tokens after <start> h w
+        l1, l2 = w + 1, (w + 1) * h + 1
+        rules = []
+        for j in range(n):
+            forced = -1
+            if l1 > 0 and (T + 1 + j) % l1 == 0:
+                forced = self.eol_id                                    # LP:132-137
+            if l2 > 0 and (T + 1 + j) % l2 == 0:
+                forced = self.end_id                                    # LP:140-145
+            rules.append(ops.make_rule(((self.img_lo, self.img_hi),), forced, k))
+        return rules
+
+
+class TopKTopPGrammar(_Grammar):
+    def __init__(self, top_k, top_p=1.0):
+        self.top_k, self.top_p = top_k, top_p
+
+    def reset(self):
+        pass
+
+    def _advance(self, t):
+        pass
+
+    def _snapshot(self):
+        return None
+
+    def _restore(self, s):
+        pass
+
+    def window_rules(self, n):
+        return [ops.make_rule((), -1, self.top_k, self.top_p) for _ in range(n)]
+
+
+class Emu3Grammar(_Grammar):
+    def __init__(self, height, width, visual_lo, visual_n, img_token, eoi_token, eos_token, eol_token, eof_token,
+                 pad_token, top_k=2048):
+        self.H, self.W = height, width
+        self.vis = (visual_lo, visual_lo + visual_n)
+        self.img, self.eoi, self.eos, self.eol, self.eof, self.pad = img_token, eoi_token, eos_token, eol_token, eof_token, pad_token
+        self.top_k = top_k
+        self.reset()
+
+    def reset(self):
+        self.since = -1          # tokens after the FIRST img token (offset_cache, JE:50-52)
+
+    def _snapshot(self):
+        return self.since
+
+    def _restore(self, s):
+        self.since = s
+
+    def _advance(self, t):
+        if self.since >= 0:
+            self.since += 1
+        elif t == self.img:
+            self.since = 0
+
+    def window_rules(self, n):
+        T = self.since
+        if T < 0:
+            raise ValueError("Emu3 grammar: no image token in the context")
+        base = (self.W + 1) * self.H
+        forced = [-1] * n
+        for j in range(n):
+            pos = T + 1 + j
+            if pos % (self.W + 1) == 0:
+                forced[j] = self.eol
+            if pos % (base + 1) == 0:
+                forced[j] = self.eof
+            if pos % (base + 2) == 0:
+                forced[j] = self.eoi
+            if pos % (base + 3) == 0:
+                forced[j] = self.eos
+        if T + n > base + 3:                               # JE:118-123, python slice semantics kept
+            for j in range(n)[base + 3 - T:]:
+                forced[j] = self.pad
+        return [ops.make_rule((self.vis,), f, self.top_k) for f in forced]
+
+
+class AnoleGrammar(_Grammar):
+    """image-only multimodal mode; every window row gets the mask of the ACCEPTED prefix (the reference's 3d
+    processors use input_ids.shape[1] with no per-row offset)."""
+
+    def __init__(self, vocab_size, prompt_len, max_length, image_seq_length, boi=8197, eoi=8196, eos=2, img_lo=4,
+                 img_hi=8196, top_k=2000):
+        self.V, self.prompt_len, self.max_length, self.L = vocab_size, prompt_len, max_length, image_seq_length
+        self.boi, self.eoi, self.eos, self.img_lo, self.img_hi, self.top_k = boi, eoi, eos, img_lo, img_hi, top_k
+        self.reset()
+
+    def reset(self):
+        self.ctx = []
+
+    def _snapshot(self):
+        return len(self.ctx)
+
+    def _restore(self, s):
+        del self.ctx[s:]
+
+    def _advance(self, t):
+        self.ctx.append(t)
+
+    def _allowed(self):
+        ctx, cur, L = self.ctx, len(self.ctx), self.L
+        img = set(range(self.img_lo, self.img_hi))
+        masked_special = set()                   # masked ids outside the image range
+        img_masked = False
+        offset = L + 1
+        at_offset = cur >= offset and ctx[-offset] == self.boi
+        window = min(L, cur)
+        in_window = self.boi in ctx[cur - window:] if window > 0 else False
+        specials = {self.eos, self.boi, self.eoi}
+        allowed = set()
+        for t in specials:
+            ok = True
+            if at_offset and t != self.eoi:          # 1. only eoi at the offset
+                ok = False
+            if (not at_offset) and t == self.eoi:    # 1. eoi nowhere else
+                ok = False
+            if in_window:                            # 2. inside the image window only image ids
+                ok = False
+            if t == self.boi and not (self.max_length - L - 1 > cur):   # 3.
+                ok = False
+            if t == self.eos and self.prompt_len <= cur <= self.prompt_len + 1:   # 5.
+                ok = False
+            if ok:
+                allowed.add(t)
+        img_ok = in_window and not at_offset         # 2. image ids only inside the window; 1. none at the offset
+        return img_ok, sorted(allowed)
+
+    def window_rules(self, n):
+        img_ok, specials = self._allowed()
+        ranges = []
+        pts = [(t, t + 1) for t in specials]
+        if img_ok:
+            pts.append((self.img_lo, self.img_hi))
+        pts.sort()
+        for lo, hi in pts:                           # merge adjacent intervals
+            if ranges and lo <= ranges[-1][1]:
+                ranges[-1] = (ranges[-1][0], max(hi, ranges[-1][1]))
+            else:
+                ranges.append((lo, hi))
+        if not ranges:
+            raise ValueError("Anole grammar masks every token")
+        r = ops.make_rule(ranges, -1, self.top_k)
+        return [r for _ in range(n)]

@@ -1,0 +1,129 @@
+"""Teacher-forced whole-loop parity on the GPU.
+
+The HIP engine decodes with its own bf16 backbone; every iteration's logits are recorded and replayed into the CPU
+oracle loop (oracle/loop.py), which draws its noise from an identically seeded device generator.  Every decision
+(window ids, sampled ids, accept length, corrected ids, RNG stream position) must then be identical, so the two
+token sequences must be identical.  Used by tests/test_gpu_loop.py and __graft_entry__.smoke().
+"""
+import torch
+
+from oracle import loop as OL
+from oracle import sjd_oracle as O
+
+
+class _Recorder:
+    def __init__(self):
+        self.items = []
+
+    def __call__(self, d):
+        self.items.append(dict(
+            first=d["first"], n_rows=d["n_rows"], logits_c=d["logits_c"].float().cpu().numpy().copy(),
+            logits_u=None if d["logits_u"] is None else d["logits_u"].float().cpu().numpy().copy(),
+            noise=d["noise"].cpu().numpy().copy(), rs=d["rs"].cpu().numpy().copy(),
+            noise2=d["noise2"].cpu().numpy().copy(), use_cfg=bool(d["use_cfg"])))
+
+
+def _replay(rec, prompt, rules_fn, cfg, V, no_cfg_fn=None, device="cuda"):
+    it = iter(rec.items)
+    state = {"i": -1}
+
+    def fwd(win, kv_len):
+        r = next(it)
+        state["i"] += 1
+        state["cur"] = r
+        return r["logits_c"], r["logits_u"]
+
+    checks = {"noise": 0}
+
+    def hook(kind, d):
+        r = state["cur"]
+        if kind == "sampled":
+            assert (d["logits_u"] is not None) == r["use_cfg"], "CFG on/off decision differs"
+            assert (d["noise"].cpu().numpy() == r["noise"]).all(), "Exp(1) noise stream diverged"
+            checks["noise"] += 1
+        else:
+            assert (d["rs"].cpu().numpy() == r["rs"]).all(), "uniform stream diverged"
+            assert (d["noise2"].cpu().numpy() == r["noise2"]).all(), "residual noise stream diverged"
+
+    seq, tr = OL.run(prompt, fwd, rules_fn, cfg, V, no_cfg_fn=no_cfg_fn, noise_device=device, hook=hook)
+    return seq, tr, checks
+
+
+def _loop_cfg(c):
+    return OL.LoopConfig(jacobi_loop_interval_l=c.jacobi_loop_interval_l, jacobi_loop_interval_r=c.jacobi_loop_interval_r,
+                         max_num_new_tokens=c.max_num_new_tokens, guidance_scale=c.guidance_scale, seed=c.seed,
+                         do_cfg=c.do_cfg, prefix_token_sampler_scheme=c.prefix_token_sampler_scheme,
+                         max_length=c.max_length, eos_token_ids=c.eos_token_ids)
+
+
+@torch.no_grad()
+def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7, scheme="speculative_jacobi",
+                                  embed_token_scale=0.25, top_k=1000, cfg_scale=4.0, dtype=torch.bfloat16):
+    import sjd_amd.ops as ops
+    from sjd_amd.engine import SJDEngine, SJDConfig, WindowSpec
+    from sjd_amd.grammar import TopKTopPGrammar
+    from tests.helpers import make_llamagen, llamagen_prefill_sample
+    args = dict(dim=128, n_layer=2, n_head=2, vocab_size=16384, block_size=latent * latent, cls_token_num=1,
+                model_type="c2i", num_classes=1000)
+    model = make_llamagen(args, 17, embed_token_scale, ops.HipWindowAttention(n_split=2), dtype=dtype, device=device)
+    T, N = 1, latent * latent
+    s_max = ((T + N + 64 + 31) // 32) * 32
+    model.setup_cache(batch=2, s_max=s_max)
+    cond = torch.tensor([207, model.num_classes], device=device)
+    zeros = torch.zeros(2, dtype=torch.int32, device=device)
+    logits = model.forward_embeds(model.embed_condition(cond), torch.zeros(2, 1, dtype=torch.long, device=device), 0, zeros)
+    torch.manual_seed(seed)
+    first = int(llamagen_prefill_sample(logits.float().cpu(), cfg_scale, 1.0, top_k, 1.0)[0, 0])
+    cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=N - window - 2, max_num_new_tokens=window,
+                    guidance_scale=cfg_scale, seed=seed, prefix_token_sampler_scheme=scheme, max_length=N)
+    spec = WindowSpec(first_tokens=torch.tensor([[first], [first]], device=device),
+                      first_positions=torch.full((2, 1), T, dtype=torch.long, device=device), key_start=zeros,
+                      pos_offset=torch.zeros(2, dtype=torch.long), kv_base=T)
+    eng = SJDEngine(model, 16384, device, max_window=window)
+    rec = _Recorder()
+    eng.hook = rec
+    seq, stats = eng.decode([first], spec, TopKTopPGrammar(top_k, 1.0), cfg)
+    seq_ref, tr, checks = _replay(rec, [first], lambda c, n: O.llamagen_rules(c, n, top_k, 1.0), _loop_cfg(cfg), 16384,
+                                  device=device)
+    assert seq == seq_ref, "token sequences differ"
+    assert stats.matched == tr.matched and stats.nfe == len(tr.matched)
+    return dict(tokens=len(seq) - 1, nfe=stats.nfe, tok_per_step=round((len(seq) - 1) / stats.nfe, 3),
+                accepted_hist=sorted(set(stats.matched)), noise_checks=checks["noise"])
+
+
+@torch.no_grad()
+def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, scheme="speculative_jacobi", P=12,
+                                embed_token_scale=0.25, kv_heads=4, l=3, r=None, dtype=torch.bfloat16):
+    import sjd_amd.ops as ops
+    import sjd_amd.synthetic as synthetic
+    from sjd_amd.engine import SJDEngine, SJDConfig, WindowSpec
+    from sjd_amd.grammar import LuminaGrammar
+    from tests.helpers import make_chameleon
+    V = 9216
+    conf = dict(vocab_size=V, hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=kv_heads, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    model = make_chameleon(conf, 23, embed_token_scale, ops.HipWindowAttention(n_split=2), dtype=dtype, device=device)
+    prompt = torch.cat([synthetic.synthetic_prompt(P - 3, seed, lo=8900, hi=9200),
+                        torch.tensor([[8197, 8804 + hg, 8804 + wg]])], dim=1)
+    n_img = (2 * wg + 1) * 2 * hg
+    max_len = P + n_img + 1 + 4
+    model.setup_cache(batch=2, s_max=((max_len + 64 + 31) // 32) * 32)
+    r = r if r is not None else (2 * wg + 1) * 2 * hg - 10
+    cfg = SJDConfig(jacobi_loop_interval_l=l, jacobi_loop_interval_r=r, max_num_new_tokens=window, guidance_scale=3.0,
+                    seed=seed, prefix_token_sampler_scheme=scheme, max_length=max_len, eos_token_ids=(8196,))
+    ids = prompt.to(device)
+    spec = WindowSpec(first_tokens=ids.repeat(2, 1),
+                      first_positions=torch.stack([torch.arange(P), torch.tensor([1] * (P - 1) + [0])]).to(device),
+                      key_start=torch.tensor([0, P - 1], dtype=torch.int32),
+                      pos_offset=torch.tensor([0, -(P - 1)], dtype=torch.long), kv_base=0)
+    eng = SJDEngine(model, V, device, max_window=window)
+    rec = _Recorder()
+    eng.hook = rec
+    seq, stats = eng.decode(prompt[0].tolist(), spec, LuminaGrammar(2000, 10), cfg)
+    seq_ref, tr, checks = _replay(rec, prompt[0].tolist(), lambda c, n: O.lumina_rules(c, n, 2000, 10), _loop_cfg(cfg), V,
+                                  no_cfg_fn=O.lumina_force_no_cfg, device=device)
+    assert seq == seq_ref, "token sequences differ"
+    assert stats.matched == tr.matched and stats.nfe == len(tr.matched)
+    gen = seq[P:]
+    return dict(tokens=len(gen), nfe=stats.nfe, eol=[i for i, t in enumerate(gen) if t == 8803][:3], last=gen[-1],
+                accepted_hist=sorted(set(stats.matched[1:])), noise_checks=checks["noise"])

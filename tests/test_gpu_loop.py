@@ -1,0 +1,31 @@
+"""GPU: whole-loop, teacher-forced parity of the HIP engine against the CPU oracle (see gpu_loop_check.py)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests import gpu_loop_check as G
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+@pytest.mark.parametrize("scheme,seed,window,ets", [("speculative_jacobi", 7, 16, 0.25), ("speculative_jacobi", 11, 8, 0.5),
+                                                    ("jacobi", 7, 16, 0.25), ("speculative_jacobi", 13, 16, 1.0)])
+def test_llamagen_loop(scheme, seed, window, ets):
+    s = G.teacher_forced_llamagen_check(latent=16, window=window, seed=seed, scheme=scheme, embed_token_scale=ets)
+    assert s["tokens"] == 255 and s["noise_checks"] == s["nfe"]
+    if ets < 1.0 and scheme == "speculative_jacobi":
+        assert s["tok_per_step"] > 1.2          # the accept path is really exercised
+
+
+@pytest.mark.parametrize("scheme,seed,window,kvh,l,r", [("speculative_jacobi", 3, 16, 4, 3, None), ("speculative_jacobi", 9, 8, 2, 3, None),
+                                                        ("jacobi", 3, 16, 4, 3, None), ("speculative_jacobi", 4, 16, 4, 1, 73)])
+def test_lumina_loop(scheme, seed, window, kvh, l, r):
+    s = G.teacher_forced_lumina_check(scheme=scheme, seed=seed, window=window, kv_heads=kvh, l=l, r=r)
+    assert s["eol"] == [8, 17, 26]
+    if r is None:
+        assert s["last"] == 8196 and s["tokens"] == 73

@@ -1,0 +1,104 @@
+"""CPU: the product's incremental host grammar (sjd_amd/grammar.py) against the oracle's stateless restatement
+(oracle/sjd_oracle.py), which is itself pinned to the reference by tests/test_oracle_golden.py."""
+import ctypes
+import json
+import os
+import random
+
+import numpy as np
+
+from oracle import sjd_oracle as O
+from sjd_amd import grammar as G
+
+
+def same(r1, r2):
+    a = bytes(ctypes.string_at(ctypes.byref(r1), ctypes.sizeof(r1)))
+    b = bytes(ctypes.string_at(ctypes.byref(r2), ctypes.sizeof(r2)))
+    if r1.n_ranges != r2.n_ranges or r1.forced != r2.forced or r1.top_k != r2.top_k or r1.top_p_thr != r2.top_p_thr:
+        return False
+    return all(r1.lo[i] == r2.lo[i] and r1.hi[i] == r2.hi[i] for i in range(r1.n_ranges))
+
+
+def check(gr, oracle_fn, ctx, n, win=None):
+    gr.start(ctx)
+    got, want = gr.window_rules(n), oracle_fn(ctx, n)
+    assert len(got) == len(want) and all(same(a, b) for a, b in zip(got, want)), (ctx[-6:], n)
+    if win is not None:
+        res = gr.residual_rules(win)
+        for i in range(1, len(win)):
+            assert same(res[i - 1], oracle_fn(ctx + win[1:i], 1)[0])
+        assert all(same(a, b) for a, b in zip(gr.window_rules(n), want)), "residual_rules must not change the state"
+
+
+def test_lumina_grammar_random_contexts():
+    rng = random.Random(0)
+    for trial in range(300):
+        hg, wg = rng.randint(1, 5), rng.randint(1, 5)
+        ctx = [rng.randint(8900, 9100) for _ in range(rng.randint(1, 8))]
+        if rng.random() < 0.85:
+            ctx += [8197]
+            body = [8804 + hg, 8804 + wg] + [rng.randint(4, 8195) for _ in range(rng.randint(0, (2 * wg + 1) * 2 * hg + 3))]
+            # the two grid tokens are always generated in the single-token phase (jacobi_loop_interval_l >= 3)
+            ctx += body[:rng.randint(2, len(body))]
+            if rng.random() < 0.1:
+                ctx += [8196] + [rng.randint(8900, 9100) for _ in range(rng.randint(0, 3))]
+        n = rng.randint(1, 16)
+        # drafts are image ids, EOL or end-of-image: a start token can never be drafted inside an open image
+        win = [ctx[-1]] + [rng.choice([rng.randint(4, 8195), 8803, 8196]) for _ in range(n - 1)]
+        check(G.LuminaGrammar(2000, 10), lambda c, k: O.lumina_rules(c, k, 2000, 10), ctx, n, win)
+        g = G.LuminaGrammar(2000, 10)
+        g.start(ctx)
+        assert g.force_no_cfg() == O.lumina_force_no_cfg(ctx)
+
+
+def test_lumina_grammar_incremental_push_equals_restart():
+    rng = random.Random(1)
+    ctx = [9000, 9001, 8197, 8808, 8808]
+    g = G.LuminaGrammar(2000, 10)
+    g.start(ctx)
+    for step in range(90):
+        add = [rng.randint(4, 8195) for _ in range(rng.randint(1, 4))]
+        g.push(add)
+        ctx += add
+        want = O.lumina_rules(ctx, 16, 2000, 10)
+        assert all(same(a, b) for a, b in zip(g.window_rules(16), want))
+
+
+def test_topk_topp_grammar():
+    for k, p in [(1000, 1.0), (50, 0.9), (0, 0.5)]:
+        check(G.TopKTopPGrammar(k, p), lambda c, n: O.llamagen_rules(c, n, k, p), [1, 2, 3], 7, [3, 4, 5, 6])
+
+
+def test_emu3_grammar():
+    rng = random.Random(2)
+    tok = dict(img_token=200, eoi_token=201, eos_token=202, eol_token=203, eof_token=204, pad_token=205)
+    for trial in range(200):
+        H, W = rng.randint(1, 4), rng.randint(1, 6)
+        T = rng.randint(0, (W + 1) * H + 8)
+        ctx = [rng.randint(300, 2000) for _ in range(rng.randint(1, 5))] + [200] + [rng.randint(3000, 3100) for _ in range(T)]
+        n = rng.randint(1, 16)
+        win = [ctx[-1]] + [rng.randint(3000, 3100) for _ in range(n - 1)]
+        check(G.Emu3Grammar(H, W, 3000, 8192, **tok), lambda c, k: O.emu3_rules(c, k, H, W, 3000, 8192, **tok), ctx, n, win)
+
+
+def test_anole_grammar():
+    rng = random.Random(3)
+    V, Lseq, P, maxlen = 9216, 24, 6, 40
+    for trial in range(200):
+        ctx = [rng.randint(8900, 9100) for _ in range(P)]
+        if rng.random() < 0.9:
+            ctx += [8197] + [rng.randint(4, 8195) for _ in range(rng.randint(0, Lseq + 2))]
+        n = rng.randint(1, 16)
+        win = [ctx[-1]] + [rng.randint(4, 8195) for _ in range(n - 1)]
+        try:
+            want = O.anole_rules(ctx, n, V, P, maxlen, Lseq)
+        except ValueError:
+            continue
+        check(G.AnoleGrammar(V, P, maxlen, Lseq), lambda c, k: O.anole_rules(c, k, V, P, maxlen, Lseq), ctx, n, None)
+
+
+def test_grammars_on_golden_contexts(golden_dir):
+    d = np.load(os.path.join(golden_dir, "fn_logits2tokens_lumina.npz"))
+    for m in json.loads(str(d["meta"])):
+        ctx = d[f"{m['name']}.ctx"][0].tolist()
+        check(G.LuminaGrammar(2000, 10), lambda c, k: O.lumina_rules(c, k, 2000, 10), ctx, m["nrows"])

@@ -33,7 +33,8 @@ class State(ctypes.Structure):
 
 
 EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_probs_sample", "sjd_verify_accept",
-           "sjd_kv_append", "sjd_attention_workspace_bytes", "sjd_draft_window_attention"]
+           "sjd_kv_append", "sjd_attention_workspace_bytes", "sjd_draft_window_attention", "sjd_draft_window_attention_ex",
+           "sjd_event_create", "sjd_event_destroy", "sjd_event_synchronize", "sjd_event_elapsed_ms"]
 
 _lib = None
 
@@ -61,6 +62,12 @@ def load():
     lib.sjd_attention_workspace_bytes.restype = i64
     lib.sjd_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     lib.sjd_draft_window_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp]
+    lib.sjd_draft_window_attention_ex.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.sjd_event_create.restype = vp
+    lib.sjd_event_destroy.argtypes = [vp]
+    lib.sjd_event_synchronize.argtypes = [vp]
+    lib.sjd_event_elapsed_ms.restype = f32
+    lib.sjd_event_elapsed_ms.argtypes = [vp, vp]
     for name in EXPORTS:
         getattr(lib, name)
     assert ctypes.sizeof(RowRule) == 48 and ctypes.sizeof(IterParams) == 32 + 8 * MAX_WINDOW + 2 * 48 * MAX_WINDOW

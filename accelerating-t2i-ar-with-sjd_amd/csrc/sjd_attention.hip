@@ -324,23 +324,26 @@ extern "C" int64_t sjd_attention_workspace_bytes(int B, int H, int n_rows, int D
 template <int DT, int D>
 static int launch_attention(const void *q, const void *kc, const void *vc, void *out, int B, int n_rows, int H, int H_kv, int S_max,
                             const int32_t *key_start, const sjd_iter_params *params, int kv_len, int n_split, void *workspace,
-                            hipStream_t stream)
+                            hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1)
 {
     const int n_chunks = (n_rows + K1_ROWS - 1) / K1_ROWS;
     float *ws_o = (float *)workspace;
     float *ws_ml = ws_o + (size_t)B * H * n_chunks * n_split * K1_ROWS * D;
+    if (ev0) (void)hipEventRecord(ev0, stream);
     hipLaunchKernelGGL((k1_partial<DT, D>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
                        (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
                        kv_len, n_split, n_chunks);
+    if (ev1) (void)hipEventRecord(ev1, stream);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
                        n_split, n_chunks, params);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
-extern "C" int sjd_draft_window_attention(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
-                                          int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
-                                          const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream)
+extern "C" int sjd_draft_window_attention_ex(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows,
+                                             int H, int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
+                                             const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream,
+                                             void *ev_start, void *ev_stop)
 {
     if (!q || !k_cache || !v_cache || !out || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
     if (H % H_kv != 0 || (S_max % K1_KT) != 0) return SJD_ERR_BAD_ARG;
@@ -348,11 +351,33 @@ extern "C" int sjd_draft_window_attention(const void *q, const void *k_cache, co
     if (!(G == 1 || G == 2 || G == 4)) return SJD_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
 #define SJD_K1_CASE(DT_, D_) \
-    if (dtype == DT_ && D == D_) return launch_attention<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, key_start, params, kv_len, n_split, workspace, s);
+    if (dtype == DT_ && D == D_) return launch_attention<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, key_start, params, kv_len, n_split, workspace, s, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
     SJD_K1_CASE(SJD_DTYPE_BF16, 128)
     SJD_K1_CASE(SJD_DTYPE_BF16, 64)
     SJD_K1_CASE(SJD_DTYPE_F16, 128)
     SJD_K1_CASE(SJD_DTYPE_F16, 64)
 #undef SJD_K1_CASE
     return SJD_ERR_UNSUPPORTED;
+}
+
+extern "C" int sjd_draft_window_attention(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
+                                          int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
+                                          const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream)
+{
+    return sjd_draft_window_attention_ex(q, k_cache, v_cache, out, B, n_rows, H, H_kv, D, S_max, dtype, key_start, params, kv_len,
+                                         n_split, workspace, stream, nullptr, nullptr);
+}
+
+extern "C" void *sjd_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? (void *)e : nullptr;
+}
+extern "C" void sjd_event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+extern "C" int sjd_event_synchronize(void *ev) { return hipEventSynchronize((hipEvent_t)ev) == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH; }
+extern "C" float sjd_event_elapsed_ms(void *ev_start, void *ev_stop)
+{
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop) != hipSuccess) return -1.0f;
+    return ms;
 }

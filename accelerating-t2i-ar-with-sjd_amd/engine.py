@@ -60,6 +60,9 @@ class DecodeStats:
     nfe: int = 0
     tokens: int = 0
     seconds: float = 0.0
+    wall_seconds: float = 0.0
+    timed_nfe: int = 0
+    kv_len: int = 0
     matched: List[int] = field(default_factory=list)
 
 
@@ -103,8 +106,11 @@ class SJDEngine:
         self.params.upload()
 
     @torch.no_grad()
-    def decode(self, prompt: List[int], spec: WindowSpec, grammar, cfg: SJDConfig):
-        """prompt: accepted ids handed to `_sample` (the context the grammar sees).  Returns (sequence, DecodeStats)."""
+    def decode(self, prompt: List[int], spec: WindowSpec, grammar, cfg: SJDConfig, warmup_iters=0, timed_iters=None,
+               on_timed_start=None, on_timed_end=None):
+        """prompt: accepted ids handed to `_sample` (the context the grammar sees).  Returns (sequence, DecodeStats).
+        bench mode: iterations [warmup_iters, warmup_iters+timed_iters) are bracketed by on_timed_start/on_timed_end
+        (barrier + synchronize live in the callbacks) and the decode stops after them; stats then cover that region."""
         if cfg.multi_token_init_scheme != "random":
             # the released reference raises IndexError for the horizon schemes (SURVEY.md 8a defect ledger)
             raise NotImplementedError("only multi_token_init_scheme='random' is parity-checkable")
@@ -134,7 +140,14 @@ class SJDEngine:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         finished = False
+        timed_tok0, timed_nfe0 = 0, 0
         while not finished:
+            if timed_iters is not None and stats.nfe == warmup_iters:
+                if on_timed_start is not None:
+                    on_timed_start()
+                timed_tok0, timed_nfe0 = len(X), stats.nfe
+                t0 = time.perf_counter()
+                ev0.record()
             # ---------------- host: integer bookkeeping only ----------------
             torch_fresh = []
             if first:
@@ -214,8 +227,15 @@ class SJDEngine:
             if X[-1] in cfg.eos_token_ids or len(X) >= cfg.max_length:             # JL:1200-1201
                 finished = True
             cur_len = len(X)
+            if timed_iters is not None and stats.nfe == warmup_iters + timed_iters:
+                break
         ev1.record()
         torch.cuda.synchronize()
+        if on_timed_end is not None:
+            on_timed_end()
         stats.seconds = ev0.elapsed_time(ev1) / 1000.0
-        stats.tokens = len(X) - P
+        stats.wall_seconds = time.perf_counter() - t0
+        stats.tokens = len(X) - (timed_tok0 if timed_iters is not None else P)
+        stats.timed_nfe = stats.nfe - timed_nfe0
+        stats.kv_len = kv_len
         return X, stats

@@ -101,17 +101,19 @@ def attention_workspace(B, H, n_rows, D, n_split, device):
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
-def draft_window_attention(q, k_cache, v_cache, out, key_start, params, kv_len, n_split, workspace):
-    """q/out [B,n,H,D]; caches [B,Hkv,S,D] already holding the window rows; key_start int32 [B] (device)."""
+def draft_window_attention(q, k_cache, v_cache, out, key_start, params, kv_len, n_split, workspace, ev0=None, ev1=None):
+    """q/out [B,n,H,D]; caches [B,Hkv,S,D] already holding the window rows; key_start int32 [B] (device).
+    ev0/ev1: optional raw hipEvent_t handles recorded around the k1_partial launch."""
     B, n, H, D = q.shape
     assert q.is_contiguous() and out.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous()
     assert key_start is None or (key_start.dtype == torch.int32 and key_start.is_cuda)
     need = L.load().sjd_attention_workspace_bytes(B, H, n, D, n_split)
     assert workspace.numel() * 4 >= need, "attention workspace too small"
-    L.check(L.load().sjd_draft_window_attention(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), B, n, H,
-                                               k_cache.shape[1], D, k_cache.shape[2], _dtype_code(q.dtype),
-                                               _ptr(key_start), params.ptr if params is not None else None, int(kv_len),
-                                               int(n_split), _ptr(workspace), _stream()), "sjd_draft_window_attention")
+    L.check(L.load().sjd_draft_window_attention_ex(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), B, n, H,
+                                                  k_cache.shape[1], D, k_cache.shape[2], _dtype_code(q.dtype),
+                                                  _ptr(key_start), params.ptr if params is not None else None,
+                                                  int(kv_len), int(n_split), _ptr(workspace), _stream(), ev0, ev1),
+            "sjd_draft_window_attention")
 
 
 class HipWindowAttention:
@@ -123,6 +125,9 @@ class HipWindowAttention:
         self._ws = None
         self._key_start = None
         self.params = None          # DeviceBlob(IterParams) when the engine drives kv_len from the device
+        self.profile_layer = None   # int: time k1_partial of that layer with HIP events (bench.py roofline leg)
+        self.profile_records = []   # (ev0, ev1, algorithmic_bytes)
+        self._ev_pool = []
 
     def __call__(self, layer, q, k, v, cache, kv_len, key_start):
         B, n, H, D = q.shape
@@ -138,5 +143,33 @@ class HipWindowAttention:
         out = torch.empty_like(q)
         kv_host = 0 if self.params is not None else int(kv_len)
         kv_append(k, v, kc, vc, self.params, kv_host)
-        draft_window_attention(q, kc, vc, out, ks, self.params, kv_host, self.n_split, self._ws)
+        ev0 = ev1 = None
+        if self.profile_layer is not None and layer == self.profile_layer and n <= 32:
+            lib = L.load()
+            ev0 = self._ev_pool.pop() if self._ev_pool else ctypes.c_void_p(lib.sjd_event_create())
+            ev1 = self._ev_pool.pop() if self._ev_pool else ctypes.c_void_p(lib.sjd_event_create())
+            esz = q.element_size()
+            Hkv = kc.shape[0 + 1]
+            # algorithmic bytes of one k1_partial launch: K and V rows [0, kv_len+n) once per kv head,
+            # + q in, + fp32 split partials out
+            kv_rows = int(kv_len) + n
+            alg = 2 * B * Hkv * kv_rows * D * esz + B * n * H * D * esz
+            self.profile_records.append((ev0, ev1, alg, kv_rows))
+        draft_window_attention(q, kc, vc, out, ks, self.params, kv_host, self.n_split, self._ws, ev0, ev1)
         return out
+
+    def profile_summary(self):
+        """-> dict(launches, avg_ms, avg_bytes, gbps) over the recorded k1_partial launches; recycles the events."""
+        lib = L.load()
+        tot_ms, tot_b, n, rows = 0.0, 0, 0, 0
+        for ev0, ev1, alg, kv_rows in self.profile_records:
+            lib.sjd_event_synchronize(ev1)
+            ms = lib.sjd_event_elapsed_ms(ev0, ev1)
+            if ms > 0:
+                tot_ms, tot_b, n, rows = tot_ms + ms, tot_b + alg, n + 1, rows + kv_rows
+            self._ev_pool += [ev0, ev1]
+        self.profile_records = []
+        if n == 0:
+            return None
+        return dict(launches=n, avg_ms=tot_ms / n, avg_bytes=tot_b / n, avg_kv_rows=rows / n,
+                    gbps=(tot_b / 1e9) / (tot_ms / 1e3))

@@ -66,3 +66,30 @@ def synthetic_prompt(length: int, seed: int, lo: int = 8900, hi: int = 60000) ->
     g = torch.Generator(device="cpu")
     g.manual_seed(int(seed))
     return torch.randint(lo, hi, (1, length), generator=g, dtype=torch.long)
+
+
+def fill_state_dict_device(module: torch.nn.Module, seed: int = 0, head_gain: float = 3.0, embed_token_scale: float = 1.0):
+    """Same distribution as fill_state_dict but drawn ON the tensor's device (fast for 7B-parameter benches).
+    Values differ from the CPU variant; use fill_state_dict when CPU/GPU weight equality matters."""
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if not torch.is_floating_point(t):
+                continue
+            g = torch.Generator(device=t.device)
+            g.manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2**63 - 1))
+            lname = name.lower()
+            x = torch.randn(t.shape, generator=g, device=t.device, dtype=torch.float32)
+            if lname.endswith("bias"):
+                x = 0.02 * x
+            elif t.dim() == 1 or "norm" in lname:
+                x = 1.0 + 0.1 * x
+            elif "embed" in lname:
+                if embed_token_scale < 1.0:
+                    common = torch.randn(t.shape[-1:], generator=g, device=t.device, dtype=torch.float32)
+                    x = common + embed_token_scale * x
+            else:
+                gain = head_gain if (lname.startswith("output.") or lname.startswith("lm_head.")) else 1.0
+                x = x * (gain / t.shape[-1] ** 0.5)
+            t.copy_(x.to(t.dtype))
+            del x
+    return module

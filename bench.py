@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- accepted image-tokens/s of the MI355X-native SJD engine on BASELINE.json's headline workload.
+
+Workload (config.workload): Lumina-mGPT-7B architecture (Chameleon-7B dims, bf16, random-init synthetic weights --
+no checkpoints reach the GPU box), one 768x768 prompt per GPU (P=64 incl. <start> h w, 48x(48+1) image tokens),
+draft window 16, CFG 3.0 (cond||uncond batch of 2), image top-k 2000, speculative_jacobi, seed 1234+rank.
+A "step" is ONE SJD iteration (= one transformer forward over the draft window + the whole hand-written hot path).
+Synthetic weights are generated with embed_token_scale<1 (sjd_amd/synthetic.py) so that the acceptance rate is in the
+regime the reference publishes (~2.1-2.4 tokens/step); tokens_per_step is reported next to the value.
+
+python bench.py [--gpus N] [--steps K] [--warmup W]   (N>1: launched by torch.distributed.run, one rank per GPU)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--model", default="lumina7b", choices=["lumina7b", "lumina_tiny"])
+    ap.add_argument("--embed-token-scale", type=float, default=0.25)
+    ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--n-split", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=12)
+    ap.add_argument("--profile-layer", type=int, default=0)
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    import torch
+    import sjd_amd.backbones as BB
+    import sjd_amd.ops as ops
+    import sjd_amd.synthetic as synthetic
+    if args.model == "lumina7b":
+        margs = BB.LUMINA_7B
+    else:
+        margs = BB.ChameleonArgs(vocab_size=65536, hidden_size=1024, intermediate_size=2048, num_hidden_layers=4,
+                                 num_attention_heads=8, num_key_value_heads=8)
+    attn = ops.HipWindowAttention(n_split=args.n_split)
+    with torch.device(device):
+        model = BB.ChameleonBackbone(margs, attn=attn).to(torch.bfloat16).eval()
+    synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=args.embed_token_scale)
+    return model, margs, attn
+
+
+def cpu_baseline(args, tokens_per_step):
+    """The reference's scheduler step (logits->probs->sample + verify/accept) as restated by the CPU oracle, timed on
+    this host (1 core, scalar C), on a bounded sample of the same workload: V=65536, L=16, CFG, image top-k 2000."""
+    import numpy as np
+    import torch
+    from oracle import sjd_oracle as O
+    V, L = 65536, args.window
+    g = torch.Generator().manual_seed(0)
+    ctx = [9000] * 61 + [8197, 8828, 8828] + [100] * 40
+    rules = O.lumina_rules(ctx, L, 2000, 10)
+    resid = [O.lumina_rules(ctx, 1, 2000, 10)[0] for _ in range(L - 1)]
+    t_total, n_it = 0.0, 0
+    prev = None
+    for it in range(args.cpu_baseline_iters):
+        logits = (torch.randn(2, L, V, generator=g) * 3.0).numpy()
+        noise = torch.empty(L, V).exponential_(generator=g).numpy()
+        rs = torch.rand(L, V, generator=g).numpy()
+        e2 = torch.empty(V).exponential_(generator=g).numpy()
+        t0 = time.perf_counter()
+        toks, probs = O.logits_to_probs_sample(logits[0], logits[1], 3.0, rules, noise)
+        q_rows = [None] * L if prev is None else [prev[i] for i in range(L)]
+        win = [100] + toks[:-1].tolist()
+        O.verify_accept(win, toks, probs, q_rows, rs, resid, e2)
+        t_total += time.perf_counter() - t0
+        n_it += 1
+        prev = probs
+    sec_per_step = t_total / n_it
+    return {"value": round(tokens_per_step / sec_per_step, 2), "unit": "image-tokens/s (scheduler step only, no transformer forward)",
+            "cores": 1, "kind": "port", "ms_per_step": round(sec_per_step * 1e3, 2),
+            "sample": f"{n_it} SJD scheduler steps (logits->probs->sample + verify/accept), V=65536, L={L}, CFG, top-k 2000"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="nccl")          # RCCL on ROCm
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from sjd_amd.engine import SJDEngine, SJDConfig
+    from sjd_amd.grammar import LuminaGrammar
+    from sjd_amd.frontends import lumina_window_spec, lumina_prompt
+    from sjd_amd.parallel import gather_report
+
+    model, margs, attn = build_model(args, device)
+    P, grid = 64, 48
+    n_img = grid * (grid + 1)
+    s_max = ((P + n_img + 64 + 31) // 32) * 32
+    model.setup_cache(batch=2, s_max=s_max)
+    prompt = lumina_prompt(P, grid, grid, seed=1234 + rank)
+    spec = lumina_window_spec(prompt, device)
+    cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=grid * grid + grid - 10 - 3,
+                    max_num_new_tokens=args.window, guidance_scale=3.0, seed=1234 + rank,
+                    prefix_token_sampler_scheme="speculative_jacobi", max_length=P + n_img + 1, eos_token_ids=(8196,))
+    eng = SJDEngine(model, margs.vocab_size, device, max_window=args.window)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_start():
+        sync_all()
+        attn.profile_layer = args.profile_layer
+        attn.profile_records = []
+
+    t_wall = {}
+
+    def timed_end():
+        sync_all()
+
+    seq, stats = eng.decode(prompt, spec, LuminaGrammar(2000, 10), cfg, warmup_iters=args.warmup, timed_iters=args.steps,
+                            on_timed_start=timed_start, on_timed_end=timed_end)
+    attn.profile_layer = None
+    prof = attn.profile_summary()
+    rep = gather_report(stats.tokens, stats.timed_nfe, stats.seconds, device)   # one RCCL all_gather (24 B/rank)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    tot_tokens = sum(r[0] for r in rep)
+    tot_steps = sum(r[1] for r in rep)
+    t_max = max(r[2] for r in rep)
+    tps = tot_tokens / t_max
+    tok_per_step = tot_tokens / max(tot_steps, 1)
+    out = {
+        "metric": "accepted image-tokens/s (SJD, Lumina-mGPT-7B 768px); tokens_per_step = 1/steps-to-converge rate",
+        "value": round(tps, 2), "unit": "image-tokens/s", "n_gpus": world, "steps": stats.timed_nfe, "warmup": args.warmup,
+        "ms_per_step": round(t_max / max(stats.timed_nfe, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "tokens_per_step": round(tok_per_step, 4),
+        "nfe_full_image_est": round((n_img + 1) / tok_per_step, 1),
+        "config": {"workload": f"{'Lumina-mGPT-7B' if args.model == 'lumina7b' else args.model} 768x768, 1 prompt/GPU, "
+                               f"draft window {args.window}, CFG 3.0 (batch 2), top-k 2000, bf16, random-init synthetic weights "
+                               f"(embed_token_scale={args.embed_token_scale})",
+                   "prompt_len": P, "image_tokens": n_img, "kv_len_end": stats.kv_len, "prompts": world,
+                   "parallelism": f"prompt-parallel x{world}"},
+    }
+    if prof is not None:
+        peak = 8000.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"kernel": "k1_partial (draft-window attention)", "bound": "hbm", "achieved": round(prof["gbps"], 1),
+                           "peak": peak, "unit": "GB/s", "frac": round(prof["gbps"] / peak, 4), "traffic": traffic,
+                           "avg_us": round(prof["avg_ms"] * 1e3, 2), "avg_bytes": int(prof["avg_bytes"]),
+                           "avg_kv_rows": round(prof["avg_kv_rows"], 1), "launches": prof["launches"]}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, tok_per_step)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

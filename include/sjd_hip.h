@@ -119,6 +119,19 @@ int sjd_draft_window_attention(const void *q, const void *k_cache, const void *v
                                int H, int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
                                const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream);
 
+/* Same as sjd_draft_window_attention; when ev_start/ev_stop (hipEvent_t) are non-NULL they are recorded on `stream`
+ * immediately before / after the k1_partial launch (the dominant kernel), for live roofline measurement. */
+int sjd_draft_window_attention_ex(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows,
+                                  int H, int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
+                                  const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream,
+                                  void *ev_start, void *ev_stop);
+
+/* HIP event helpers so that a ctypes host can time kernels on the stream they run on. */
+void *sjd_event_create(void);
+void sjd_event_destroy(void *ev);
+int sjd_event_synchronize(void *ev);
+float sjd_event_elapsed_ms(void *ev_start, void *ev_stop);
+
 #ifdef __cplusplus
 }
 #endif

@@ -192,7 +192,7 @@ class LlamaGenBackbone(nn.Module):
 
     def forward_embeds(self, h, positions, kv_len, key_start):
         B, n, _ = h.shape
-        freqs = self.freqs[positions]                     # [B,n,D/2,2]
+        freqs = self.freqs[positions.clamp(max=self.freqs.shape[0] - 1)]   # [B,n,D/2,2]; padded window rows clamp
         for li, layer in enumerate(self.layers):
             a = layer.attention
             x = layer.attention_norm(h)

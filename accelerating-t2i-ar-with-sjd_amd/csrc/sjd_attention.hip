@@ -33,6 +33,19 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define K1_WAVES 4
 #define K1_KT 32          // keys per wave tile
 #define K1_ROWS 16        // query rows per chunk
+#define K1_MIN_TILES_PER_SPLIT 4   // a key split is only opened when it gets at least one tile per wave
+
+// Key-tile range [t_lo, t_hi) of a (batch row, chunk) and the number of splits actually used for it.  The launch grid
+// is sized for n_split (static, hipGraph friendly); splits >= the effective count exit immediately and are skipped by
+// the combine kernel, so short contexts do not pay for empty partials.
+__device__ __forceinline__ void k1_tile_range(int kstart, int total, int n_split, int &t_lo, int &t_hi, int &eff_split, int &tps)
+{
+    t_lo = kstart / K1_KT;
+    t_hi = (total + K1_KT - 1) / K1_KT;
+    const int nt = max(t_hi - t_lo, 0);
+    eff_split = min(n_split, max(1, (nt + K1_MIN_TILES_PER_SPLIT - 1) / K1_MIN_TILES_PER_SPLIT));
+    tps = (nt + eff_split - 1) / eff_split;
+}
 
 template <int DT> struct Frag;
 template <> struct Frag<SJD_DTYPE_BF16> {
@@ -99,9 +112,9 @@ __global__ __launch_bounds__(256) void k1_partial(
     const float scale = rsqrtf((float)D);
 
     // tile range of this workgroup / wave
-    const int t_lo = kstart / K1_KT, t_hi = (total + K1_KT - 1) / K1_KT;
-    const int nt = max(t_hi - t_lo, 0);
-    const int tps = (nt + n_split - 1) / n_split;
+    int t_lo, t_hi, eff_split, tps;
+    k1_tile_range(kstart, total, n_split, t_lo, t_hi, eff_split, tps);
+    if (split >= eff_split) return;
     const int t_begin = t_lo + split * tps, t_end = min(t_hi, t_begin + tps);
 
     // Q fragments (B operand): lane (row c, group g) holds Q[row0+c][head][32*ks + 8g .. +7]
@@ -254,22 +267,31 @@ __global__ __launch_bounds__(256) void k1_partial(
 template <int DT, int D>
 __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
                                                  unsigned short *__restrict__ out, int n_rows, int H, int n_split, int n_chunks,
-                                                 const sjd_iter_params *__restrict__ params)
+                                                 const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,
+                                                 int kv_len_arg)
 {
     const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
     const int n_total = params ? params->n_rows : n_rows;
+    int eff_split;
+    {
+        const int kv_base = params ? params->kv_len : kv_len_arg;
+        const int n_c = min(K1_ROWS, n_total - chunk * K1_ROWS);
+        const int total = kv_base + chunk * K1_ROWS + max(n_c, 0);
+        int t_lo, t_hi, tps;
+        k1_tile_range(key_start ? key_start[b] : 0, total, n_split, t_lo, t_hi, eff_split, tps);
+    }
     constexpr int PER = K1_ROWS * D / 256;          // consecutive d per thread
     const int row = (threadIdx.x * PER) / D, d0 = (threadIdx.x * PER) % D;
     const int grow = chunk * K1_ROWS + row;
     if (grow >= n_total) return;
     const size_t base = (((size_t)b * H + head) * n_chunks + chunk) * n_split;
     float M = -INFINITY;
-    for (int s = 0; s < n_split; ++s) M = fmaxf(M, ws_ml[((base + s) * K1_ROWS + row) * 2]);
+    for (int s = 0; s < eff_split; ++s) M = fmaxf(M, ws_ml[((base + s) * K1_ROWS + row) * 2]);
     const float Ms = (M == -INFINITY) ? 0.0f : M;
     float L = 0.f, acc[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) acc[j] = 0.f;
-    for (int s = 0; s < n_split; ++s) {
+    for (int s = 0; s < eff_split; ++s) {
         const size_t slot = (base + s) * K1_ROWS + row;
         const float wgt = __expf(ws_ml[slot * 2] - Ms);
         L += wgt * ws_ml[slot * 2 + 1];
@@ -336,7 +358,7 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
-                       n_split, n_chunks, params);
+                       n_split, n_chunks, params, key_start, kv_len);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 

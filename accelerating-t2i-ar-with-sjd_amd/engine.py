@@ -1,22 +1,25 @@
 """SJD decode engine: the reference's `_sample` loop (scheduler/jacobi_iteration_lumina_mgpt.py:912-1249) as a
-fixed launch sequence over device-resident state.
+shape-static launch sequence over device-resident state.
 
-Per iteration (reference line numbers in brackets):
+Per window iteration (reference line numbers in brackets):
    host   n, a', fresh random ids (torch.randint on the GLOBAL CPU generator, JL:505), grammar rules -> ONE pinned
-          sjd_iter_params blob, one async H2D
+          sjd_iter_params blob, one async H2D;  the three noise tensors are drawn from the device generator
+   ---- captured once per prob-buffer parity in a hipGraph, replayed afterwards ----
    K5     window = [last emitted | carried samples | fresh ids]                              [JL:606-701]
-   fwd    backbone.forward_window (PyTorch-ROCm GEMMs; K3 append + K1 attention per layer)   [JL:1107]
-   K2     CFG + grammar + top-k + softmax + multinomial -> p[n,V], Y[n]                      [JL:82-132]
+   fwd    backbone.forward_window over the static L rows (PyTorch-ROCm GEMMs; K3 + K1 per layer, kv_len and n_rows
+          read from the device blob)                                                         [JL:1107]
+   K2     CFG + grammar + top-k + softmax + multinomial -> p[L,V], Y[L]                      [JL:82-132]
    K4     accept scan + residual resample -> m, corrected Y                                  [JL:247-376]
+   ----
    host   reads back {m, rejected, Y} (ONE sync), appends Y[:m], kv_len += m                 [JL:378-430]
 The draft distributions of the next window are rows (m-1 ...) of this iteration's p buffer, so nothing is copied
-(two p buffers alternate); fresh random drafts are implicit one-hots; KV rollback is the kv_len update.
+(two p buffers alternate); fresh random drafts are implicit one-hots; KV rollback is the kv_len update (rows of
+rejected drafts are overwritten by the next window).
 
 RNG streams mirror the reference: device generator g for exponential_/rand (consumed in the
 same order and shapes), global CPU generator for the fresh ids.  The residual draw is made from g speculatively
 and the generator state is rewound when no rejection happened.
 """
-import ctypes
 import random
 import time
 from dataclasses import dataclass, field
@@ -67,6 +70,7 @@ class DecodeStats:
 
 
 def set_seed(seed):
+    """reference set_seed (JL:36-45)"""
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
@@ -75,7 +79,7 @@ def set_seed(seed):
 
 
 class SJDEngine:
-    def __init__(self, backbone, vocab_size, device, max_window=16, n_batch=2):
+    def __init__(self, backbone, vocab_size, device, max_window=16, n_batch=2, use_graph=False):
         L.load()                                   # fail loudly if the HIP extension is missing
         if max_window > L.MAX_WINDOW:
             raise ValueError(f"max_window {max_window} > {L.MAX_WINDOW}")
@@ -84,14 +88,25 @@ class SJDEngine:
         self.params = ops.DeviceBlob(L.IterParams, dev)
         self.state = ops.DeviceBlob(L.State, dev)
         self.probs = torch.zeros(2, self.Lmax, self.V, dtype=torch.float32, device=dev)
-        self.noise = torch.empty(self.Lmax, self.V, dtype=torch.float32, device=dev)
-        self.rs = torch.empty(self.Lmax, self.V, dtype=torch.float32, device=dev)
-        self.noise2 = torch.empty(1, self.V, dtype=torch.float32, device=dev)
+        self.noise = torch.ones(self.Lmax, self.V, dtype=torch.float32, device=dev)
+        self.rs = torch.zeros(self.Lmax, self.V, dtype=torch.float32, device=dev)
+        self.noise2 = torch.ones(1, self.V, dtype=torch.float32, device=dev)
         self.scratch = torch.empty(self.V, dtype=torch.float32, device=dev)
         self.input_ids = torch.zeros(self.B, self.Lmax, dtype=torch.int64, device=dev)
         self.arange = torch.arange(self.Lmax, device=dev)
         self.tokens_ptr = self.state.field_ptr("tokens")
+        self.key_start = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        self.pos_offset = torch.zeros(self.B, dtype=torch.int64, device=dev)
+        off = L.IterParams.kv_len.offset
+        self.kv_len_dev = self.params.dev[off:off + 4].view(torch.int32)      # device view of params->kv_len
         self.hook = None                            # test hook: called with per-iteration device tensors
+        self.use_graph = use_graph                  # capture the window step (K5 -> forward -> K2 -> K4) in hipGraphs
+        self._guidance = 3.0
+        self.reset_graphs()
+
+    def reset_graphs(self):
+        """Call after the backbone's cache / weights were re-allocated."""
+        self._graphs, self._graph_logits, self._eager_runs = {}, {}, {}
 
     # ------------------------------------------------------------------------------------------------
     def _fill_params(self, n, kv_len, use_cfg, scheme, fresh, rules, resid):
@@ -105,6 +120,32 @@ class SJDEngine:
             p.resid_rules[j] = r
         self.params.upload()
 
+    def _window_body(self, cur):
+        """The shape-static launch sequence of one window iteration: every dynamic scalar is read from device blobs."""
+        ops.reguess(self.params, self.state, self.input_ids)
+        positions = self.kv_len_dev.to(torch.int64) + self.arange[None, :] + self.pos_offset[:, None]
+        logits = self.backbone.forward_window(self.input_ids, positions, -1, self.key_start)
+        lu = logits[1] if self.B > 1 else None
+        ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr)
+        ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0], self.scratch)
+        return logits
+
+    def _run_window(self, cur):
+        if not self.use_graph:
+            return self._window_body(cur)
+        key = (cur, self._guidance)
+        g = self._graphs.get(key)
+        if g is None:
+            if self._eager_runs.get(key, 0) < 1:    # one eager run per graph key warms up allocations / hipBLASLt
+                self._eager_runs[key] = 1
+                return self._window_body(cur)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._graph_logits[key] = self._window_body(cur)
+            self._graphs[key] = g
+        g.replay()
+        return self._graph_logits[key]
+
     @torch.no_grad()
     def decode(self, prompt: List[int], spec: WindowSpec, grammar, cfg: SJDConfig, warmup_iters=0, timed_iters=None,
                on_timed_start=None, on_timed_end=None):
@@ -116,31 +157,33 @@ class SJDEngine:
             raise NotImplementedError("only multi_token_init_scheme='random' is parity-checkable")
         if cfg.prefix_token_sampler_scheme not in ("speculative_jacobi", "jacobi"):
             raise ValueError(f"prefix_token_sampler_scheme: {cfg.prefix_token_sampler_scheme}")   # JL:1048
-        dev, V, B = self.device, self.V, self.B
+        if cfg.max_num_new_tokens > self.Lmax:
+            raise ValueError("max_num_new_tokens exceeds the engine's max_window")
+        dev, B = self.device, self.B
         scheme = 0 if cfg.prefix_token_sampler_scheme == "speculative_jacobi" else 1
-        do_cfg = cfg.do_cfg and (cfg.guidance_scale != 1)
+        do_cfg = cfg.do_cfg and (cfg.guidance_scale != 1)                          # JL:1005
         X = [int(t) for t in prompt]
         P = len(X)
         gen = None
         if cfg.seed is not None:                                                   # JL:1021-1023
             set_seed(cfg.seed)
             gen = torch.Generator(dev).manual_seed(cfg.seed)
-        l_abs, r_abs = P + cfg.jacobi_loop_interval_l, P + cfg.jacobi_loop_interval_r
-        W = min(cfg.max_num_new_tokens, self.Lmax)
-        if cfg.max_num_new_tokens > self.Lmax:
-            raise ValueError("max_num_new_tokens exceeds the engine's max_window")
+        l_abs, r_abs = P + cfg.jacobi_loop_interval_l, P + cfg.jacobi_loop_interval_r   # JL:1025
+        W = cfg.max_num_new_tokens
         grammar.start(X)
-        key_start = spec.key_start.to(device=dev, dtype=torch.int32)
-        pos_offset = spec.pos_offset.to(device=dev, dtype=torch.int64)
+        self.key_start.copy_(spec.key_start.to(device=dev, dtype=torch.int32))
+        self.pos_offset.copy_(spec.pos_offset.to(device=dev, dtype=torch.int64))
+        self._guidance = float(cfg.guidance_scale)
         attn = getattr(self.backbone, "attn", None)
         st = self.state.view
         stats = DecodeStats()
         n, kv_len, first, cur_len, cur, n_prev, m_prev = 1, spec.kv_base, True, P, 0, 1, 1
+        carried: List[int] = []
         t0 = time.perf_counter()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        finished = False
         timed_tok0, timed_nfe0 = 0, 0
+        finished = False
         while not finished:
             if timed_iters is not None and stats.nfe == warmup_iters:
                 if on_timed_start is not None:
@@ -149,53 +192,48 @@ class SJDEngine:
                 t0 = time.perf_counter()
                 ev0.record()
             # ---------------- host: integer bookkeeping only ----------------
-            torch_fresh = []
             if first:
-                n_rows, a = 1, 0
+                n_rows = 1
                 torch.randint(0, cfg.img_vocab_n, (1, 0))
-                rules = grammar.window_rules(1)
-                resid = []
+                rules, resid, fresh = grammar.window_rules(1), [], []
             else:
                 n_rows = n
-                a = max(0, min(n_prev - m_prev, n - 1))
+                a = max(0, min(n_prev - m_prev, n - 1))                              # JL:633-639, 657-662
                 fr = torch.randint(0, cfg.img_vocab_n, (1, n - 1 - a))[0].tolist()   # GLOBAL CPU generator (JL:505)
-                torch_fresh = [cfg.img_vocab_lo + t for t in fr]
+                fresh = [cfg.img_vocab_lo + t for t in fr]                           # img_vocab[rand] (JL:509)
                 rules = grammar.window_rules(n_rows)
-                resid = None
-            use_cfg = do_cfg and not grammar.force_no_cfg()
+                # window ids are needed on the host only for the residual grammar; carried ids come from the last read-back
+                resid = grammar.residual_rules([X[-1]] + carried[:a] + fresh) if (scheme == 0 and n_rows > 1) else []
+            use_cfg = do_cfg and not grammar.force_no_cfg()                          # JL:1086-1096
+            self._fill_params(n_rows, kv_len, use_cfg, scheme, fresh, rules, resid)
+            # ---------------- noise, in the reference's order and shapes ----------------
+            e1 = self.noise[:n_rows]
+            e1.exponential_(generator=gen)                                           # == torch.multinomial (JL:118)
+            g_state = None
+            if n_rows > 1 and scheme == 0:
+                self.rs[:n_rows].uniform_(0.0, 1.0, generator=gen)                   # torch.rand([1,n,V]) (JL:260)
+                if gen is not None:
+                    g_state = gen.get_state()
+                self.noise2.exponential_(generator=gen)                              # residual multinomial (JL:237)
+            # ---------------- device work ----------------
             if first:
-                self._fill_params(1, kv_len, use_cfg, scheme, [], rules, [])
+                if attn is not None and hasattr(attn, "params"):
+                    attn.params = None                                               # prefill: kv_len passed by value
                 tokens, positions = spec.first_tokens.to(dev), spec.first_positions.to(dev)
-                logits = self.backbone.forward_window(tokens, positions, kv_len, key_start)
+                logits = self.backbone.forward_window(tokens, positions, kv_len, self.key_start)
                 lc = logits[0, -1:, :]
                 lu = logits[1, -1:, :] if B > 1 else None
                 win_len = tokens.shape[1]
+                ops.logits_to_probs_sample(lc, lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr)
+                ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0],
+                                  self.scratch)
+                if attn is not None and hasattr(attn, "params"):
+                    attn.params = self.params                                        # windows: kv_len / n_rows from the blob
             else:
-                # window ids are needed on the host only for the residual grammar: carried ids are known from the
-                # previous read-back
-                win_host = [X[-1]] + self._carried[:a] + torch_fresh
-                resid = grammar.residual_rules(win_host) if scheme == 0 else []
-                self._fill_params(n_rows, kv_len, use_cfg, scheme, torch_fresh, rules, resid)
-                ops.reguess(self.params, self.state, self.input_ids)
-                tokens = self.input_ids[:, :n_rows]
-                positions = (kv_len + self.arange[:n_rows])[None, :] + pos_offset[:, None]
-                logits = self.backbone.forward_window(tokens, positions, kv_len, key_start)
-                lc = logits[0]
-                lu = logits[1] if B > 1 else None
+                logits = self._run_window(cur)
+                lc = logits[0, :n_rows]
+                lu = logits[1, :n_rows] if B > 1 else None
                 win_len = n_rows
-            # ---------------- K2: logits -> probs -> tokens ----------------
-            e1 = self.noise[:n_rows]
-            e1.exponential_(generator=gen)                                         # == torch.multinomial (JL:118)
-            ops.logits_to_probs_sample(lc, lu, cfg.guidance_scale, self.params, self.noise, self.probs[cur], self.tokens_ptr)
-            # ---------------- K4: verify / accept ----------------
-            g_state = None
-            if n_rows > 1 and scheme == 0:
-                self.rs[:n_rows].uniform_(0.0, 1.0, generator=gen)                 # torch.rand([1,n,V]) (JL:260)
-                if gen is not None:
-                    g_state = gen.get_state()
-                self.noise2.exponential_(generator=gen)                            # residual multinomial (JL:237)
-            ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0],
-                              self.scratch)
             if self.hook is not None:
                 self.hook(dict(first=first, n_rows=n_rows, logits_c=lc, logits_u=lu, use_cfg=use_cfg, rules=rules,
                                resid=resid, noise=e1, rs=self.rs[:n_rows], noise2=self.noise2[0], probs=self.probs[cur],
@@ -208,12 +246,10 @@ class SJDEngine:
             Y = [int(st.tokens[i]) for i in range(n_rows)]
             if n_rows <= 1:
                 m = win_len                      # is_prefilling_phase short-circuit (JL:344-350)
-                emitted = [Y[0]]
-                self._carried = []
+                emitted, carried = [Y[0]], []
             else:
                 m = m_dev
-                emitted = Y[:m]
-                self._carried = Y[m:]
+                emitted, carried = Y[:m], Y[m:]
             stats.matched.append(m)
             # ---------------- next window length, append, rollback ----------------
             n = min(W, r_abs - cur_len) if (l_abs <= cur_len < r_abs) else 1       # JL:1142-1144 (old cur_len)

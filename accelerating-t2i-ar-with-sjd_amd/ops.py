@@ -152,7 +152,10 @@ class HipWindowAttention:
             Hkv = kc.shape[0 + 1]
             # algorithmic bytes of one k1_partial launch: K and V rows [0, kv_len+n) once per kv head,
             # + q in, + fp32 split partials out
-            kv_rows = int(kv_len) + n
+            if self.params is not None:         # device-driven mode: the host mirror of the blob holds this iteration's values
+                kv_rows = int(self.params.view.kv_len) + int(self.params.view.n_rows)
+            else:
+                kv_rows = int(kv_len) + n
             alg = 2 * B * Hkv * kv_rows * D * esz + B * n * H * D * esz
             self.profile_records.append((ev0, ev1, alg, kv_rows))
         draft_window_attention(q, kc, vc, out, ks, self.params, kv_host, self.n_split, self._ws, ev0, ev1)

@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--n-split", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=12)
-    ap.add_argument("--profile-layer", type=int, default=0)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--k1-launches", type=int, default=200, help="launches of the K1 micro-measurement")
     return ap.parse_args()
 
 
@@ -51,6 +52,39 @@ def build_model(args, device):
         model = BB.ChameleonBackbone(margs, attn=attn).to(torch.bfloat16).eval()
     synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=args.embed_token_scale)
     return model, margs, attn
+
+
+def measure_k1(args, model, attn, device, kv_len):
+    """Dominant hand-written kernel, measured live with HIP events on the stream it runs on: k1_partial over layer 0's
+    cache at the mean KV length of the timed region (same B/H/D/window/n_split as the decode), back-to-back launches."""
+    import ctypes
+    import torch
+    import sjd_amd._lib as L
+    import sjd_amd.ops as ops
+    lib = L.load()
+    B, n, H, D = 2, args.window, model.n_heads, model.head_dim
+    kc, vc = model.cache.k[0], model.cache.v[0]
+    q = torch.randn(B, n, H, D, device=device).to(kc.dtype)
+    out = torch.empty_like(q)
+    ks = torch.tensor([0, 63], dtype=torch.int32, device=device)
+    ws = ops.attention_workspace(B, H, n, D, args.n_split, device)
+    evs = [(ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())) for _ in range(args.k1_launches)]
+    for _ in range(10):
+        ops.draft_window_attention(q, kc, vc, out, ks, None, kv_len, args.n_split, ws)
+    torch.cuda.synchronize()
+    for e0, e1 in evs:
+        ops.draft_window_attention(q, kc, vc, out, ks, None, kv_len, args.n_split, ws, e0, e1)
+    torch.cuda.synchronize()
+    ms = [lib.sjd_event_elapsed_ms(e0, e1) for e0, e1 in evs]
+    for e0, e1 in evs:
+        lib.sjd_event_destroy(e0)
+        lib.sjd_event_destroy(e1)
+    esz = kc.element_size()
+    Hkv = kc.shape[1]
+    rows0, rows1 = kv_len + n, kv_len + n - 63          # visible key rows of the cond / uncond batch row
+    alg = 2 * Hkv * (rows0 + rows1) * D * esz + B * n * H * D * esz     # K,V rows once per kv head + q
+    avg_ms = sum(ms) / len(ms)
+    return dict(launches=len(ms), avg_ms=avg_ms, avg_bytes=alg, avg_kv_rows=kv_len + n, gbps=alg / 1e9 / (avg_ms / 1e3))
 
 
 def cpu_baseline(args, tokens_per_step):
@@ -112,27 +146,25 @@ def main():
     cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=grid * grid + grid - 10 - 3,
                     max_num_new_tokens=args.window, guidance_scale=3.0, seed=1234 + rank,
                     prefix_token_sampler_scheme="speculative_jacobi", max_length=P + n_img + 1, eos_token_ids=(8196,))
-    eng = SJDEngine(model, margs.vocab_size, device, max_window=args.window)
+    eng = SJDEngine(model, margs.vocab_size, device, max_window=args.window, use_graph=not args.no_graph)
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    kv_at = {}
+
     def timed_start():
         sync_all()
-        attn.profile_layer = args.profile_layer
-        attn.profile_records = []
-
-    t_wall = {}
+        kv_at["start"] = int(eng.params.view.kv_len)
 
     def timed_end():
         sync_all()
 
     seq, stats = eng.decode(prompt, spec, LuminaGrammar(2000, 10), cfg, warmup_iters=args.warmup, timed_iters=args.steps,
                             on_timed_start=timed_start, on_timed_end=timed_end)
-    attn.profile_layer = None
-    prof = attn.profile_summary()
+    prof = measure_k1(args, model, attn, device, kv_len=(kv_at.get("start", P) + stats.kv_len) // 2)
     rep = gather_report(stats.tokens, stats.timed_nfe, stats.seconds, device)   # one RCCL all_gather (24 B/rank)
     if rank != 0:
         if world > 1:

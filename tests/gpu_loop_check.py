@@ -58,7 +58,8 @@ def _loop_cfg(c):
 
 @torch.no_grad()
 def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7, scheme="speculative_jacobi",
-                                  embed_token_scale=0.25, top_k=1000, cfg_scale=4.0, dtype=torch.bfloat16):
+                                  embed_token_scale=0.25, top_k=1000, cfg_scale=4.0, dtype=torch.bfloat16,
+                                  use_graph=False):
     import sjd_amd.ops as ops
     from sjd_amd.engine import SJDEngine, SJDConfig, WindowSpec
     from sjd_amd.grammar import TopKTopPGrammar
@@ -79,7 +80,7 @@ def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7,
     spec = WindowSpec(first_tokens=torch.tensor([[first], [first]], device=device),
                       first_positions=torch.full((2, 1), T, dtype=torch.long, device=device), key_start=zeros,
                       pos_offset=torch.zeros(2, dtype=torch.long), kv_base=T)
-    eng = SJDEngine(model, 16384, device, max_window=window)
+    eng = SJDEngine(model, 16384, device, max_window=window, use_graph=use_graph)
     rec = _Recorder()
     eng.hook = rec
     seq, stats = eng.decode([first], spec, TopKTopPGrammar(top_k, 1.0), cfg)
@@ -93,7 +94,8 @@ def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7,
 
 @torch.no_grad()
 def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, scheme="speculative_jacobi", P=12,
-                                embed_token_scale=0.25, kv_heads=4, l=3, r=None, dtype=torch.bfloat16):
+                                embed_token_scale=0.25, kv_heads=4, l=3, r=None, dtype=torch.bfloat16,
+                                use_graph=False):
     import sjd_amd.ops as ops
     import sjd_amd.synthetic as synthetic
     from sjd_amd.engine import SJDEngine, SJDConfig, WindowSpec
@@ -116,7 +118,7 @@ def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, 
                       first_positions=torch.stack([torch.arange(P), torch.tensor([1] * (P - 1) + [0])]).to(device),
                       key_start=torch.tensor([0, P - 1], dtype=torch.int32),
                       pos_offset=torch.tensor([0, -(P - 1)], dtype=torch.long), kv_base=0)
-    eng = SJDEngine(model, V, device, max_window=window)
+    eng = SJDEngine(model, V, device, max_window=window, use_graph=use_graph)
     rec = _Recorder()
     eng.hook = rec
     seq, stats = eng.decode(prompt[0].tolist(), spec, LuminaGrammar(2000, 10), cfg)

@@ -15,8 +15,10 @@ def _gpu():
 
 @pytest.mark.parametrize("scheme,seed,window,ets", [("speculative_jacobi", 7, 16, 0.25), ("speculative_jacobi", 11, 8, 0.5),
                                                     ("jacobi", 7, 16, 0.25), ("speculative_jacobi", 13, 16, 1.0)])
-def test_llamagen_loop(scheme, seed, window, ets):
-    s = G.teacher_forced_llamagen_check(latent=16, window=window, seed=seed, scheme=scheme, embed_token_scale=ets)
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_llamagen_loop(scheme, seed, window, ets, use_graph):
+    s = G.teacher_forced_llamagen_check(latent=16, window=window, seed=seed, scheme=scheme, embed_token_scale=ets,
+                                        use_graph=use_graph)
     assert s["tokens"] == 255 and s["noise_checks"] == s["nfe"]
     if ets < 1.0 and scheme == "speculative_jacobi":
         assert s["tok_per_step"] > 1.2          # the accept path is really exercised
@@ -24,8 +26,9 @@ def test_llamagen_loop(scheme, seed, window, ets):
 
 @pytest.mark.parametrize("scheme,seed,window,kvh,l,r", [("speculative_jacobi", 3, 16, 4, 3, None), ("speculative_jacobi", 9, 8, 2, 3, None),
                                                         ("jacobi", 3, 16, 4, 3, None), ("speculative_jacobi", 4, 16, 4, 1, 73)])
-def test_lumina_loop(scheme, seed, window, kvh, l, r):
-    s = G.teacher_forced_lumina_check(scheme=scheme, seed=seed, window=window, kv_heads=kvh, l=l, r=r)
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_lumina_loop(scheme, seed, window, kvh, l, r, use_graph):
+    s = G.teacher_forced_lumina_check(scheme=scheme, seed=seed, window=window, kv_heads=kvh, l=l, r=r, use_graph=use_graph)
     assert s["eol"] == [8, 17, 26]
     if r is None:
         assert s["last"] == 8196 and s["tokens"] == 73

@@ -325,7 +325,51 @@ class ChameleonBackbone(nn.Module):
         emb = torch.cat((freqs, freqs), dim=-1)
         return emb.cos().to(dtype)[:, :, None, :], emb.sin().to(dtype)[:, :, None, :]
 
+    def enable_fused(self, ops):
+        """Switch to the fused HIP glue path (F1-F3): q|k|v and gate|up projections become single GEMMs whose weights are
+        concatenated once; the original parameters are re-pointed at slices of the fused tensors (state-dict unchanged,
+        no extra memory).  `ops` is sjd_amd.ops (raises if libsjd_hip.so is missing)."""
+        self._ops = ops
+        self._fused = []
+        with torch.no_grad():
+            for layer in self.model.layers:
+                a, m = layer.self_attn, layer.mlp
+                qkv = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0).contiguous()
+                nq, nk = a.q_proj.weight.shape[0], a.k_proj.weight.shape[0]
+                a.q_proj.weight.data, a.k_proj.weight.data, a.v_proj.weight.data = qkv[:nq], qkv[nq:nq + nk], qkv[nq + nk:]
+                gu = torch.cat([m.gate_proj.weight, m.up_proj.weight], dim=0).contiguous()
+                ni = m.gate_proj.weight.shape[0]
+                m.gate_proj.weight.data, m.up_proj.weight.data = gu[:ni], gu[ni:]
+                self._fused.append((qkv, gu))
+        self._inv_freq32 = self.inv_freq.float().contiguous()
+        return self
+
+    def _forward_window_fused(self, tokens, positions, kv_len, key_start):
+        ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
+        T, eps = B * n, self.args.rms_norm_eps
+        H, Hkv, D = self.n_heads, self.n_kv_heads, self.head_dim
+        params = getattr(self.attn, "params", None)
+        h = self.model.embed_tokens(tokens).view(T, -1).contiguous()
+        pos = positions.reshape(T).contiguous()
+        delta = None
+        for li, layer in enumerate(self.model.layers):
+            a = layer.self_attn
+            qkv_w, gu_w = self._fused[li]
+            x = ops.add_rmsnorm(h, delta, layer.input_layernorm.weight, eps)
+            qkv = F.linear(x, qkv_w)
+            qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
+            q = ops.qknorm_rope_append(qkv, self.cache.k[li], self.cache.v[li], *qn, self._inv_freq32, pos, B, n, H, Hkv, D,
+                                       params, kv_len if params is None else 0)
+            o = self.attn.attend(li, q, self.cache, kv_len, key_start)
+            attn_out = F.linear(o.view(T, H * D), a.o_proj.weight)
+            x = ops.add_rmsnorm(h, attn_out, layer.post_attention_layernorm.weight, eps)
+            delta = F.linear(ops.silu_mul(F.linear(x, gu_w)), layer.mlp.down_proj.weight)
+        x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
+        return self.lm_head(x).float().view(B, n, -1)
+
     def forward_window(self, tokens, positions, kv_len, key_start):
+        if getattr(self, "_ops", None) is not None:
+            return self._forward_window_fused(tokens, positions, kv_len, key_start)
         B, n = tokens.shape
         h = self.model.embed_tokens(tokens)
         cos, sin = self._rope(positions, h.dtype)

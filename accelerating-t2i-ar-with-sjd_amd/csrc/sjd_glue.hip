@@ -1,0 +1,249 @@
+// sjd_glue.hip -- fused element-wise glue of the draft-window forward (gfx950).
+//
+// rocprofv3 of the first end-to-end bench (profiles/r1a_*) showed ~1300 tiny ATen element-wise launches per SJD
+// iteration (RMSNorm as pow/mean/add/rsqrt/mul, per-head QK-LayerNorm, rotate_half RoPE as neg/cat/mul/mul/add, dtype
+// copies, SiLU, residual adds) costing more wall time than the weight-streaming GEMMs.  These three kernels replace them:
+//
+//   F1 sjd_add_rmsnorm        h += delta (optional);  y = w * bf16(h * rsqrt(mean(h^2)+eps))
+//                             <- ChameleonRMSNorm (reference modeling_chameleon.py:59-73) + the residual add of the
+//                                decoder layer (:637, :643)
+//   F2 sjd_qknorm_rope_append per (token, head): LayerNorm over head_dim with per-head gamma/beta (optional), RoPE
+//                             (rotate-half form, fp32 angles), q -> q_out, k/v -> static KV cache rows [kv_len + i]
+//                             <- ChameleonLayerNorm (:198-219), apply_rotary_pos_emb (:144-178), DynamicCache.update
+//                                (:547);  this is K3 fused into the projection epilogue
+//   F3 sjd_silu_mul           y = silu(gate) * up on a fused [M, 2I] gate|up projection  <- ChameleonMLP (:193-195)
+//
+// All are HBM/latency bound on [32 x 4096]-sized activations: 16-byte vector loads, one wave64 per row / head.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/sjd_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <int DT> struct Cvt;
+template <> struct Cvt<SJD_DTYPE_BF16> {
+    static __device__ __forceinline__ float to_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+    static __device__ __forceinline__ unsigned short from_f(float x)
+    {
+        unsigned u = __float_as_uint(x);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    }
+};
+template <> struct Cvt<SJD_DTYPE_F16> {
+    static __device__ __forceinline__ float to_f(unsigned short h) { return (float)(*reinterpret_cast<_Float16 *>(&h)); }
+    static __device__ __forceinline__ unsigned short from_f(float x)
+    {
+        _Float16 h = (_Float16)x;
+        return *reinterpret_cast<unsigned short *>(&h);
+    }
+};
+
+template <int DT> __device__ __forceinline__ void unpack8(u32x4 v, float (&f)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = Cvt<DT>::to_f((unsigned short)(v[i] & 0xffffu));
+        f[2 * i + 1] = Cvt<DT>::to_f((unsigned short)(v[i] >> 16));
+    }
+}
+template <int DT> __device__ __forceinline__ u32x4 pack8(const float (&f)[8])
+{
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (unsigned)Cvt<DT>::from_f(f[2 * i]) | ((unsigned)Cvt<DT>::from_f(f[2 * i + 1]) << 16);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ F1
+// one 256-thread workgroup per row; hidden % 8 == 0 and hidden <= 256*8*MAXV
+template <int DT>
+__global__ __launch_bounds__(256) void f1_add_rmsnorm(unsigned short *__restrict__ h, const unsigned short *__restrict__ delta,
+                                                      const unsigned short *__restrict__ w, unsigned short *__restrict__ y,
+                                                      int hidden, float eps)
+{
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    unsigned short *hr = h + (size_t)row * hidden;
+    const unsigned short *dr = delta ? delta + (size_t)row * hidden : nullptr;
+    constexpr int MAXV = 4;
+    float x[MAXV][8];
+    float ss = 0.f;
+    int nv = 0;
+    for (int c = threadIdx.x * 8; c < hidden && nv < MAXV; c += 256 * 8, ++nv) {
+        unpack8<DT>(*reinterpret_cast<const u32x4 *>(hr + c), x[nv]);
+        if (dr) {
+            float d[8];
+            unpack8<DT>(*reinterpret_cast<const u32x4 *>(dr + c), d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[nv][j] = Cvt<DT>::to_f(Cvt<DT>::from_f(x[nv][j] + d[j]));   // residual add rounds to the activation dtype
+            *reinterpret_cast<u32x4 *>(hr + c) = pack8<DT>(x[nv]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += x[nv][j] * x[nv][j];
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float inv = rsqrtf(tot / (float)hidden + eps);
+    nv = 0;
+    for (int c = threadIdx.x * 8; c < hidden && nv < MAXV; c += 256 * 8, ++nv) {
+        float wv[8], o[8];
+        unpack8<DT>(*reinterpret_cast<const u32x4 *>(w + c), wv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = wv[j] * Cvt<DT>::to_f(Cvt<DT>::from_f(x[nv][j] * inv));   // weight * hidden.to(dtype)
+        *reinterpret_cast<u32x4 *>(y + (size_t)row * hidden + c) = pack8<DT>(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ F2
+// qkv: [T, (H + 2*Hkv) * D] fused projection output (T = B*n tokens).  One wave64 per (token, head); D in {64,128}.
+// Lane l owns the rotate-half pair (d = l', d + D/2) for l' = l (+64*k).  positions: int64 [T].
+template <int DT, int D>
+__global__ __launch_bounds__(256) void f2_qknorm_rope_append(
+    const unsigned short *__restrict__ qkv, unsigned short *__restrict__ q_out, unsigned short *__restrict__ k_cache,
+    unsigned short *__restrict__ v_cache, const unsigned short *__restrict__ qn_w, const unsigned short *__restrict__ qn_b,
+    const unsigned short *__restrict__ kn_w, const unsigned short *__restrict__ kn_b, const float *__restrict__ inv_freq,
+    const long *__restrict__ positions, int B, int n, int H, int H_kv, int S_max, const sjd_iter_params *__restrict__ params,
+    int kv_len_arg)
+{
+    constexpr int HALF = D / 2;
+    constexpr int PPL = HALF / 64 > 0 ? HALF / 64 : 1;       // pairs per lane (D=128: 1, D=64: lanes 32..63 idle)
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);      // global wave id
+    const int heads = H + 2 * H_kv;
+    if (gw >= B * n * heads) return;
+    const int tok = gw / heads, hh = gw % heads;
+    const int b = tok / n, i = tok % n;
+    const int kv_len = params ? params->kv_len : kv_len_arg;
+    const unsigned short *src = qkv + (size_t)tok * heads * D + (size_t)hh * D;
+    const bool is_q = hh < H, is_k = !is_q && hh < H + H_kv;
+    const int hl = is_q ? hh : (is_k ? hh - H : hh - H - H_kv);
+    unsigned short *dst;
+    if (is_q) dst = q_out + ((size_t)tok * H + hl) * D;
+    else {
+        const int r = kv_len + i;
+        if (r >= S_max) return;
+        dst = (is_k ? k_cache : v_cache) + (((size_t)b * H_kv + hl) * S_max + r) * D;
+    }
+    const bool active = lane < HALF;
+    float x0 = 0.f, x1 = 0.f;
+    if (active) { x0 = Cvt<DT>::to_f(src[lane]); x1 = Cvt<DT>::to_f(src[lane + HALF]); }
+    if (!is_q && !is_k) {                                     // V: plain copy into the cache
+        if (active) { dst[lane] = src[lane]; dst[lane + HALF] = src[lane + HALF]; }
+        return;
+    }
+    const unsigned short *gw_ = is_q ? qn_w : kn_w, *gb_ = is_q ? qn_b : kn_b;
+    if (gw_ != nullptr) {                                     // per-head LayerNorm over head_dim (eps 1e-5)
+        const float mean = wave_sum(active ? x0 + x1 : 0.f) / (float)D;
+        const float d0 = x0 - mean, d1 = x1 - mean;
+        const float var = wave_sum(active ? d0 * d0 + d1 * d1 : 0.f) / (float)D;
+        const float inv = rsqrtf(var + 1e-5f);
+        if (active) {
+            // F.layer_norm output and the gamma/beta affine both round to the activation dtype in the reference
+            const float n0 = Cvt<DT>::to_f(Cvt<DT>::from_f(d0 * inv)), n1 = Cvt<DT>::to_f(Cvt<DT>::from_f(d1 * inv));
+            x0 = Cvt<DT>::to_f(Cvt<DT>::from_f(n0 * Cvt<DT>::to_f(gw_[lane]))) + Cvt<DT>::to_f(gb_[lane]);
+            x1 = Cvt<DT>::to_f(Cvt<DT>::from_f(n1 * Cvt<DT>::to_f(gw_[lane + HALF]))) + Cvt<DT>::to_f(gb_[lane + HALF]);
+            x0 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0));
+            x1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x1));
+        }
+    }
+    if (active) {
+        const float ang = (float)positions[tok] * inv_freq[lane];
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        cs = Cvt<DT>::to_f(Cvt<DT>::from_f(cs));              // cos/sin are cast to the activation dtype (:110)
+        sn = Cvt<DT>::to_f(Cvt<DT>::from_f(sn));
+        // (q*cos) + (rotate_half(q)*sin): each product and the sum round to the activation dtype, as the ATen ops do
+        const float a0 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0 * cs)), b0 = Cvt<DT>::to_f(Cvt<DT>::from_f(-x1 * sn));
+        const float a1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x1 * cs)), b1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0 * sn));
+        dst[lane] = Cvt<DT>::from_f(a0 + b0);
+        dst[lane + HALF] = Cvt<DT>::from_f(a1 + b1);
+    }
+    (void)PPL;
+}
+
+// ------------------------------------------------------------------------------------------------ F3
+template <int DT>
+__global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restrict__ gu, unsigned short *__restrict__ y, int M, int I)
+{
+    const int per_row = I / 8;
+    const size_t total = (size_t)M * per_row;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = idx / per_row, c = (idx % per_row) * 8;
+        float g[8], u[8], o[8];
+        unpack8<DT>(*reinterpret_cast<const u32x4 *>(gu + (size_t)row * 2 * I + c), g);
+        unpack8<DT>(*reinterpret_cast<const u32x4 *>(gu + (size_t)row * 2 * I + I + c), u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float s = Cvt<DT>::to_f(Cvt<DT>::from_f(g[j] / (1.0f + __expf(-g[j]))));   // silu rounds to the activation dtype
+            o[j] = s * u[j];
+        }
+        *reinterpret_cast<u32x4 *>(y + (size_t)row * I + c) = pack8<DT>(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI
+extern "C" int sjd_add_rmsnorm(void *h, const void *delta, const void *weight, void *y, int rows, int hidden, float eps, int dtype,
+                               void *stream)
+{
+    if (!h || !weight || !y || rows < 1 || hidden < 8 || (hidden % 8) != 0 || hidden > 256 * 8 * 4) return SJD_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SJD_DTYPE_BF16)
+        hipLaunchKernelGGL(f1_add_rmsnorm<SJD_DTYPE_BF16>, dim3(rows), dim3(256), 0, s, (unsigned short *)h, (const unsigned short *)delta,
+                           (const unsigned short *)weight, (unsigned short *)y, hidden, eps);
+    else if (dtype == SJD_DTYPE_F16)
+        hipLaunchKernelGGL(f1_add_rmsnorm<SJD_DTYPE_F16>, dim3(rows), dim3(256), 0, s, (unsigned short *)h, (const unsigned short *)delta,
+                           (const unsigned short *)weight, (unsigned short *)y, hidden, eps);
+    else return SJD_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b,
+                                      const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n,
+                                      int H, int H_kv, int D, int S_max, int dtype, const sjd_iter_params *params, int kv_len,
+                                      void *stream)
+{
+    if (!qkv || !q_out || !k_cache || !v_cache || !inv_freq || !positions || B < 1 || n < 1 || H < 1 || H_kv < 1) return SJD_ERR_BAD_ARG;
+    const int waves = B * n * (H + 2 * H_kv);
+    const dim3 grid((waves + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define SJD_F2_CASE(DT_, D_)                                                                                                         \
+    if (dtype == DT_ && D == D_) {                                                                                                   \
+        hipLaunchKernelGGL((f2_qknorm_rope_append<DT_, D_>), grid, block, 0, s, (const unsigned short *)qkv, (unsigned short *)q_out, \
+                           (unsigned short *)k_cache, (unsigned short *)v_cache, (const unsigned short *)qn_w,                        \
+                           (const unsigned short *)qn_b, (const unsigned short *)kn_w, (const unsigned short *)kn_b, inv_freq,        \
+                           (const long *)positions, B, n, H, H_kv, S_max, params, kv_len);                                           \
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;                                                             \
+    }
+    SJD_F2_CASE(SJD_DTYPE_BF16, 128)
+    SJD_F2_CASE(SJD_DTYPE_F16, 128)
+    SJD_F2_CASE(SJD_DTYPE_BF16, 64)
+    SJD_F2_CASE(SJD_DTYPE_F16, 64)
+#undef SJD_F2_CASE
+    return SJD_ERR_UNSUPPORTED;
+}
+
+extern "C" int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, void *stream)
+{
+    if (!gate_up || !y || rows < 1 || inter < 8 || (inter % 8) != 0) return SJD_ERR_BAD_ARG;
+    const size_t total = (size_t)rows * (inter / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SJD_DTYPE_BF16)
+        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_BF16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter);
+    else if (dtype == SJD_DTYPE_F16)
+        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_F16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter);
+    else return SJD_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}

@@ -116,6 +116,36 @@ def draft_window_attention(q, k_cache, v_cache, out, key_start, params, kv_len, 
             "sjd_draft_window_attention")
 
 
+def add_rmsnorm(h, delta, weight, eps):
+    """h [T, hidden] is updated in place (h += delta) when delta is given; returns weight * norm(h)."""
+    T, hidden = h.shape
+    assert h.is_contiguous() and (delta is None or delta.is_contiguous()) and weight.is_contiguous()
+    y = torch.empty_like(h)
+    L.check(L.load().sjd_add_rmsnorm(_ptr(h), _ptr(delta), _ptr(weight), _ptr(y), T, hidden, float(eps), _dtype_code(h.dtype),
+                                    _stream()), "sjd_add_rmsnorm")
+    return y
+
+
+def qknorm_rope_append(qkv, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, H_kv, D, params, kv_len):
+    """qkv [B*n, (H+2Hkv)*D] -> q [B,n,H,D]; k/v rows are written into k_cache/v_cache [B,Hkv,S,D]."""
+    assert qkv.is_contiguous() and positions.is_contiguous() and positions.dtype == torch.int64
+    assert inv_freq.dtype == torch.float32 and inv_freq.is_contiguous()
+    q = torch.empty(B, n, H, D, dtype=qkv.dtype, device=qkv.device)
+    L.check(L.load().sjd_qknorm_rope_append(_ptr(qkv), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(qn_w), _ptr(qn_b), _ptr(kn_w),
+                                           _ptr(kn_b), _ptr(inv_freq), _ptr(positions), B, n, H, H_kv, D, k_cache.shape[2],
+                                           _dtype_code(qkv.dtype), params.ptr if params is not None else None, int(kv_len),
+                                           _stream()), "sjd_qknorm_rope_append")
+    return q
+
+
+def silu_mul(gate_up):
+    T, two_i = gate_up.shape
+    assert gate_up.is_contiguous() and two_i % 2 == 0
+    y = torch.empty(T, two_i // 2, dtype=gate_up.dtype, device=gate_up.device)
+    L.check(L.load().sjd_silu_mul(_ptr(gate_up), _ptr(y), T, two_i // 2, _dtype_code(gate_up.dtype), _stream()), "sjd_silu_mul")
+    return y
+
+
 class HipWindowAttention:
     """Backbone attention backend = K3 append + K1 draft-window attention (the product path)."""
 
@@ -159,6 +189,18 @@ class HipWindowAttention:
             alg = 2 * B * Hkv * kv_rows * D * esz + B * n * H * D * esz
             self.profile_records.append((ev0, ev1, alg, kv_rows))
         draft_window_attention(q, kc, vc, out, ks, self.params, kv_host, self.n_split, self._ws, ev0, ev1)
+        return out
+
+    def attend(self, layer, q, cache, kv_len, key_start):
+        """K1 only: the window's K/V rows were already written into the cache (fused F2 path)."""
+        B, n, H, D = q.shape
+        kc, vc = cache.k[layer], cache.v[layer]
+        need = L.load().sjd_attention_workspace_bytes(B, H, n, D, self.n_split) // 4
+        if self._ws is None or self._ws.numel() < need or self._ws.device != q.device:
+            self._ws = torch.empty(need, dtype=torch.float32, device=q.device)
+        out = torch.empty_like(q)
+        kv_host = 0 if self.params is not None else int(kv_len)
+        draft_window_attention(q, kc, vc, out, key_start, self.params, kv_host, self.n_split, self._ws)
         return out
 
     def profile_summary(self):

@@ -126,6 +126,22 @@ int sjd_draft_window_attention_ex(const void *q, const void *k_cache, const void
                                   const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream,
                                   void *ev_start, void *ev_stop);
 
+/* F1-F3 -- fused element-wise glue of the draft-window forward (the "next" row of SURVEY.md 8f.1).
+ * F1: h += delta (delta may be NULL); y = weight * dtype(h * rsqrt(mean(h^2) + eps)).  replaces ChameleonRMSNorm +
+ *     the decoder layer's residual add (reference modeling_chameleon.py:59-73, 637, 643).  h, delta, y: [rows, hidden]. */
+int sjd_add_rmsnorm(void *h, const void *delta, const void *weight, void *y, int rows, int hidden, float eps, int dtype,
+                    void *stream);
+/* F2: per (token, head) of a fused qkv projection [B*n, (H + 2*H_kv) * D]: optional per-head LayerNorm (gamma/beta of
+ *     size D; NULL = none), RoPE with fp32 angles positions[t] * inv_freq[d], q -> q_out [B, n, H, D], k/v -> cache rows
+ *     [kv_len + i] (kv_len from params when non-NULL).  replaces ChameleonLayerNorm, apply_rotary_pos_emb and
+ *     DynamicCache.update (reference modeling_chameleon.py:198-219, 144-178, 547) -- K3 fused into the projection epilogue. */
+int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b,
+                           const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n,
+                           int H, int H_kv, int D, int S_max, int dtype, const sjd_iter_params *params, int kv_len,
+                           void *stream);
+/* F3: y[rows, inter] = silu(gate_up[:, :inter]) * gate_up[:, inter:].  replaces ChameleonMLP's act_fn/mul (:193-195). */
+int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, void *stream);
+
 /* HIP event helpers so that a ctypes host can time kernels on the stream they run on. */
 void *sjd_event_create(void);
 void sjd_event_destroy(void *ev);

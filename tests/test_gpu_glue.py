@@ -1,0 +1,103 @@
+"""GPU: fused glue kernels F1-F3 against the plain PyTorch ops they replace (fp32/bf16 references of the same op),
+and the fused backbone forward against the unfused one."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,hidden", [(32, 4096), (2, 512), (7, 8192)])
+def test_f1_add_rmsnorm(dev, dtype, rows, hidden):
+    import sjd_amd.ops as ops
+    from sjd_amd.backbones import _CRMSNorm
+    g = torch.Generator().manual_seed(rows + hidden)
+    h = torch.randn(rows, hidden, generator=g).to(dtype).to(dev)
+    d = torch.randn(rows, hidden, generator=g).to(dtype).to(dev)
+    norm = _CRMSNorm(hidden, 1e-5).to(dev).to(dtype)
+    norm.weight.data = (1 + 0.1 * torch.randn(hidden, generator=g)).to(dtype).to(dev)
+    for delta in (None, d):
+        h1 = h.clone()
+        y = ops.add_rmsnorm(h1, delta, norm.weight, 1e-5)
+        href = h if delta is None else h + delta
+        yref = norm(href)
+        assert torch.equal(h1, href)
+        torch.testing.assert_close(y.float(), yref.float(), atol=2e-2, rtol=2e-2)
+        assert (y.float() - yref.float()).abs().mean() < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("H,Hkv,D,qk_norm", [(32, 32, 128, True), (8, 2, 128, False), (12, 12, 64, True)])
+def test_f2_qknorm_rope_append(dev, dtype, H, Hkv, D, qk_norm):
+    import sjd_amd.ops as ops
+    from sjd_amd.backbones import _HeadLayerNorm, _rotate_half
+    B, n, S, kv_len = 2, 16, 96, 37
+    g = torch.Generator().manual_seed(H + D)
+    qkv = torch.randn(B * n, (H + 2 * Hkv) * D, generator=g).to(dtype).to(dev)
+    kc = torch.zeros(B, Hkv, S, D, dtype=dtype, device=dev)
+    vc = torch.zeros_like(kc)
+    qn, kn = _HeadLayerNorm(D, H).to(dev).to(dtype), _HeadLayerNorm(D, Hkv).to(dev).to(dtype)
+    for m in (qn, kn):
+        m.weight.data = (1 + 0.2 * torch.randn(1, D, generator=g)).to(dtype).to(dev)
+        m.bias.data = (0.1 * torch.randn(1, D, generator=g)).to(dtype).to(dev)
+    inv_freq = (1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))).to(dev)
+    positions = (torch.tensor([[1000], [941]]) + torch.arange(n)[None]).to(dev)
+    args = (qn.weight, qn.bias, kn.weight, kn.bias) if qk_norm else (None,) * 4
+    q = ops.qknorm_rope_append(qkv, kc, vc, *args, inv_freq, positions.reshape(-1).contiguous(), B, n, H, Hkv, D, None, kv_len)
+    # reference: the unfused ATen sequence of ChameleonBackbone.forward_window
+    x = qkv.view(B, n, H + 2 * Hkv, D)
+    qr, kr, vr = x[:, :, :H], x[:, :, H:H + Hkv], x[:, :, H + Hkv:]
+    if qk_norm:
+        qr, kr = qn(qr), kn(kr)
+    freqs = positions[:, :, None].float() * inv_freq[None, None, :]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cos, sin = emb.cos().to(dtype)[:, :, None, :], emb.sin().to(dtype)[:, :, None, :]
+    qr = qr * cos + _rotate_half(qr) * sin
+    kr = kr * cos + _rotate_half(kr) * sin
+    tol = dict(atol=4e-2, rtol=4e-2)
+    torch.testing.assert_close(q.float(), qr.float(), **tol)
+    torch.testing.assert_close(kc[:, :, kv_len:kv_len + n].float(), kr.transpose(1, 2).float(), **tol)
+    assert torch.equal(vc[:, :, kv_len:kv_len + n], vr.transpose(1, 2))
+    assert (q.float() - qr.float()).abs().mean() < 4e-3
+    assert kc[:, :, :kv_len].abs().sum() == 0 and kc[:, :, kv_len + n:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_f3_silu_mul(dev, dtype):
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(3)
+    gu = (torch.randn(32, 2 * 11008, generator=g) * 2).to(dtype).to(dev)
+    y = ops.silu_mul(gu)
+    ref = F.silu(gu[:, :11008]) * gu[:, 11008:]
+    torch.testing.assert_close(y.float(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
+def test_fused_forward_matches_unfused(dev):
+    import sjd_amd.ops as ops
+    from tests.helpers import make_chameleon
+    conf = dict(vocab_size=9216, hidden_size=512, intermediate_size=1024, num_hidden_layers=3, num_attention_heads=4,
+                num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    outs = []
+    for fused in (False, True):
+        m = make_chameleon(conf, 23, 0.5, ops.HipWindowAttention(n_split=2), dtype=torch.bfloat16, device=dev)
+        if fused:
+            m.enable_fused(ops)
+        m.setup_cache(batch=2, s_max=128)
+        toks = torch.randint(4, 9000, (2, 40), generator=torch.Generator().manual_seed(1)).to(dev)
+        pos = torch.arange(40)[None].repeat(2, 1).to(dev)
+        ks = torch.tensor([0, 7], dtype=torch.int32, device=dev)
+        l1 = m.forward_window(toks, pos, 0, ks)
+        toks2 = torch.randint(4, 9000, (2, 16), generator=torch.Generator().manual_seed(2)).to(dev)
+        l2 = m.forward_window(toks2, (40 + torch.arange(16))[None].repeat(2, 1).to(dev), 40, ks)
+        outs.append((l1, l2))
+    for a, b in zip(outs[0], outs[1]):
+        # bf16 end-to-end: compare on the logit scale (std ~3)
+        assert (a - b).abs().mean() < 0.05 and (a - b).abs().max() < 0.6

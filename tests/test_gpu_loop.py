@@ -28,7 +28,8 @@ def test_llamagen_loop(scheme, seed, window, ets, use_graph):
                                                         ("jacobi", 3, 16, 4, 3, None), ("speculative_jacobi", 4, 16, 4, 1, 73)])
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
 def test_lumina_loop(scheme, seed, window, kvh, l, r, use_graph):
-    s = G.teacher_forced_lumina_check(scheme=scheme, seed=seed, window=window, kv_heads=kvh, l=l, r=r, use_graph=use_graph)
+    s = G.teacher_forced_lumina_check(scheme=scheme, seed=seed, window=window, kv_heads=kvh, l=l, r=r, use_graph=use_graph,
+                                      fused=(seed != 9))
     assert s["eol"] == [8, 17, 26]
     if r is None:
         assert s["last"] == 8196 and s["tokens"] == 73

@@ -66,6 +66,8 @@ class DecodeStats:
     wall_seconds: float = 0.0
     timed_nfe: int = 0
     kv_len: int = 0
+    host_seconds: float = 0.0      # host bookkeeping + RNG launches before the window step is enqueued
+    sync_seconds: float = 0.0      # time blocked in the per-iteration state read-back
     matched: List[int] = field(default_factory=list)
 
 
@@ -189,9 +191,11 @@ class SJDEngine:
                 if on_timed_start is not None:
                     on_timed_start()
                 timed_tok0, timed_nfe0 = len(X), stats.nfe
+                stats.host_seconds = stats.sync_seconds = 0.0
                 t0 = time.perf_counter()
                 ev0.record()
             # ---------------- host: integer bookkeeping only ----------------
+            t_host0 = time.perf_counter()
             if first:
                 n_rows = 1
                 torch.randint(0, cfg.img_vocab_n, (1, 0))
@@ -216,6 +220,7 @@ class SJDEngine:
                     g_state = gen.get_state()
                 self.noise2.exponential_(generator=gen)                              # residual multinomial (JL:237)
             # ---------------- device work ----------------
+            stats.host_seconds += time.perf_counter() - t_host0
             if first:
                 if attn is not None and hasattr(attn, "params"):
                     attn.params = None                                               # prefill: kv_len passed by value
@@ -239,7 +244,9 @@ class SJDEngine:
                                resid=resid, noise=e1, rs=self.rs[:n_rows], noise2=self.noise2[0], probs=self.probs[cur],
                                prev_probs=self.probs[1 - cur], ctx=list(X), scheme=scheme))
             # ---------------- the single sync of the iteration ----------------
+            t_sync0 = time.perf_counter()
             self.state.download()
+            stats.sync_seconds += time.perf_counter() - t_sync0
             m_dev, rejected = int(st.m), bool(st.rejected)
             if g_state is not None and not rejected:
                 gen.set_state(g_state)

@@ -27,12 +27,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--model", default="lumina7b", choices=["lumina7b", "lumina_tiny"])
-    ap.add_argument("--embed-token-scale", type=float, default=0.25)
+    ap.add_argument("--embed-token-scale", type=float, default=0.7)
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--n-split", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=12)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--tunableop", action="store_true", help="enable PyTorch TunableOp GEMM selection")
     ap.add_argument("--no-fused", action="store_true", help="plain ATen element-wise glue instead of the fused F1-F3 kernels")
     ap.add_argument("--k1-launches", type=int, default=200, help="launches of the K1 micro-measurement")
     return ap.parse_args()
@@ -124,6 +125,10 @@ def cpu_baseline(args, tokens_per_step):
 
 def main():
     args = parse()
+    if args.tunableop:
+        os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+        os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
+        os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", "/tmp/sjd_tunableop_%d.csv")
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -184,6 +189,8 @@ def main():
         "ms_per_step": round(t_max / max(stats.timed_nfe, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "tokens_per_step": round(tok_per_step, 4),
+        "host_ms_per_step": round(stats.host_seconds / max(stats.timed_nfe, 1) * 1e3, 4),
+        "sync_wait_ms_per_step": round(stats.sync_seconds / max(stats.timed_nfe, 1) * 1e3, 4),
         "nfe_full_image_est": round((n_img + 1) / tok_per_step, 1),
         "config": {"workload": f"{'Lumina-mGPT-7B' if args.model == 'lumina7b' else args.model} 768x768, 1 prompt/GPU, "
                                f"draft window {args.window}, CFG 3.0 (batch 2), top-k 2000, bf16, random-init synthetic weights "

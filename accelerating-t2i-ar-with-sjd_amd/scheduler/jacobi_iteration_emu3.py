@@ -1,0 +1,82 @@
+"""Mirror of reference scheduler/jacobi_iteration_emu3.py (Emu3 adapter): `renew_solver`, the [B,L,V] grammar
+`EOLLogitProcessor3d` (as a kernel-rule descriptor) and `prepare_batch_cfg_model_inputs`."""
+import torch
+
+from .jacobi_iteration_lumina_mgpt import renew_sampler, renew_backbone  # noqa: F401
+from .logit_processor_3dim import _Descriptor, get_double_cfg_input_ids
+
+
+class Emu3PrefixConstrainedLogitsHelper:
+    """reference emu3/mllm/utils_emu3.py:19-45 (constructor only; the per-token callback is replaced by kernel rules)."""
+
+    def __init__(self, height, width, img_token, eoi_token, eos_token, eol_token, eof_token, pad_token, visual_tokens):
+        self.height, self.width = height, width
+        self.img_token, self.eoi_token, self.eos_token = img_token, eoi_token, eos_token
+        self.eol_token, self.eof_token, self.pad_token = eol_token, eof_token, pad_token
+        self.visual_tokens = visual_tokens
+        self.offset_cache = {}
+
+
+def renew_end_of_line_logit_processor_3d(model_class):
+    """reference JE:41-151"""
+    class EOLLogitProcessor3d(model_class, _Descriptor):
+        __call__ = _Descriptor.__call__
+
+    return EOLLogitProcessor3d
+
+
+def renew_sampler_forward(model_class):
+    class JacobiModel(model_class):
+        """reference JE:153-368"""
+
+        def _init_new_params(self, *args, use_chameleon_tokenizer=False, _init_doubled_attn_mask_cfg=True, visual_tokens=None,
+                             **kwargs):
+            super()._init_new_params(*args, use_chameleon_tokenizer=use_chameleon_tokenizer,
+                                     _init_doubled_attn_mask_cfg=_init_doubled_attn_mask_cfg, **kwargs)
+            # the reference keeps img_vocab = Chameleon image ids here as well
+            self._init_doubled_attn_mask_cfg = _init_doubled_attn_mask_cfg
+
+        def renew_attn_mask(self, batchsize, prefill_num, not_pad_mask=None, device='cuda'):
+            B_cfg = 2 * batchsize if self.do_cfg else batchsize
+            attention_mask = torch.ones((B_cfg, prefill_num), device=device)
+            attention_mask[~not_pad_mask] = 0
+            return attention_mask
+
+        def prepare_batch_cfg_model_inputs(self, input_ids, neg_input_ids=None, attention_mask=None):
+            """reference JE:234-278"""
+            pad = self.config.pad_token_id if hasattr(self, "config") else self.pad_token_id
+            model_inputs = dict(input_ids=input_ids, attention_mask=attention_mask)
+            batchsize, prefill_num = input_ids.shape
+            neg_prefill_num = neg_input_ids.shape[1] if neg_input_ids is not None else prefill_num
+            batchsize_cfg = 2 * batchsize if self.do_cfg else batchsize
+            max_prefill_num = max(prefill_num, neg_prefill_num)
+            not_pad_mask = torch.zeros((batchsize_cfg, max_prefill_num), dtype=torch.bool, device=input_ids.device)
+            not_pad_mask[:batchsize, -input_ids.shape[1]:] = input_ids != pad
+            if neg_input_ids is not None:
+                both = get_double_cfg_input_ids(input_ids, neg_input_ids, pad_category=pad)
+                model_inputs['input_ids'] = both
+                model_inputs['pos_input_ids'] = both[:batchsize, :]
+                not_pad_mask[:, :] = both != pad
+            if attention_mask is None:
+                model_inputs['attention_mask'] = self.renew_attn_mask(batchsize, max_prefill_num, not_pad_mask, input_ids.device)
+            elif attention_mask.shape[0] == batchsize:
+                raise NotImplementedError
+            return model_inputs
+
+    return JacobiModel
+
+
+def renew_solver(model, processor, **jacobi_param_dict):
+    """reference JE:370-412 -> (model, LogitsProcessorList)"""
+    h = jacobi_param_dict.pop('h', None)
+    w = jacobi_param_dict.pop('w', None)
+    jacobi_param_dict.pop('neg_inputs', None)
+    jacobi_param_dict.pop('classifier_free_guidance', None)
+    constrained_fn = processor.build_prefix_constrained_fn(h, w)
+    constrained_fn.__class__ = renew_end_of_line_logit_processor_3d(constrained_fn.__class__)
+    model.__class__ = renew_sampler(model.__class__)
+    model._init_new_params(**jacobi_param_dict)
+    model.__class__ = renew_sampler_forward(model.__class__)
+    model._init_new_params(visual_tokens=constrained_fn.visual_tokens, **jacobi_param_dict)
+    from transformers.generation.logits_process import LogitsProcessorList
+    return model, LogitsProcessorList([constrained_fn])

@@ -1,0 +1,147 @@
+"""Mirror of reference scheduler/logit_processor_3dim.py: same class names, constructor arguments and grammar semantics.
+
+In the reference these objects mutate a [B, L, V] score tensor with ATen ops (and 4+ host syncs per call).  Here they are
+*descriptors*: `_sample` turns the processor list into an integer grammar (sjd_amd/grammar.py) whose per-row rules are
+applied inside kernels K2/K4.  Calling a processor directly is therefore not part of the hot path and raises.
+"""
+import math
+from typing import List, Optional
+
+import torch
+
+from .. import grammar as G
+
+
+def check_eol_in_multitokens(tokenlen, new_pred_tokenlen, line_len):
+    """reference logit_processor_3dim.py:25-29 (pure integer arithmetic)."""
+    L, R = (tokenlen + 1), (tokenlen + new_pred_tokenlen)
+    check_interval_l = L // line_len + 1 if L % line_len != 0 else L // line_len
+    check_interval_r = R // line_len
+    return check_interval_l <= check_interval_r
+
+
+def eol_positions_in_multitokens(tokenlen, new_pred_tokenlen, line_len):
+    """window rows forced by get_eol_in_multitokens (reference :31-43)."""
+    return [j for j in range(new_pred_tokenlen) if (tokenlen + 1 + j) % line_len == 0]
+
+
+class _Descriptor:
+    def __call__(self, input_ids, scores):
+        raise RuntimeError(f"{type(self).__name__} is evaluated inside the HIP kernels (K2/K4) by JacobiSampler._sample; "
+                           "it is not callable on tensors in this engine")
+
+
+class MultiTokensVLLogitsProcessor(_Descriptor):
+    def __init__(self, image_start_token_id=None, image_end_token_id=None, image_next_line_token_id=None, patch_size=None,
+                 voc_size=None, device="cpu"):
+        self.image_start_token_id = image_start_token_id
+        self.image_end_token_id = image_end_token_id
+        self.image_next_line_token_id = image_next_line_token_id
+        self.patch_size, self.voc_size = patch_size, voc_size
+        self.h_latent_dim = self.w_latent_dim = None
+        self.image_token_range = (4, 8196)           # reference :65
+
+
+class MultiTokensInterleavedTopKLogitsWarper(_Descriptor):
+    def __init__(self, image_top_k: int, text_top_k: int, image_start_token_id=None, image_end_token_id=None,
+                 filter_value: float = -float("Inf"), min_tokens_to_keep: int = 1):
+        if not isinstance(text_top_k, int) or text_top_k <= 0:
+            raise ValueError(f"`text_top_k` has to be a strictly positive integer, but is {text_top_k}")
+        if not isinstance(image_top_k, int) or text_top_k <= 0:
+            raise ValueError(f"`image_top_k` has to be a strictly positive integer, but is {image_top_k}")
+        self.image_top_k = max(image_top_k, min_tokens_to_keep)
+        self.text_top_k = max(text_top_k, min_tokens_to_keep)
+        self.image_start_token_id, self.image_end_token_id = image_start_token_id, image_end_token_id
+
+
+class TopPLogitsWarper3d(_Descriptor):
+    def __init__(self, top_p: float, filter_value: float = -float("Inf"), min_tokens_to_keep: int = 1):
+        top_p = float(top_p)
+        if top_p < 0 or top_p > 1.0:
+            raise ValueError(f"`top_p` has to be a float > 0 and < 1, but is {top_p}")
+        if not isinstance(min_tokens_to_keep, int) or (min_tokens_to_keep < 1):
+            raise ValueError(f"`min_tokens_to_keep` has to be a positive integer, but is {min_tokens_to_keep}")
+        self.top_p, self.min_tokens_to_keep = top_p, min_tokens_to_keep
+
+
+class TopKLogitsWarper(_Descriptor):
+    """Stand-in for transformers' TopKLogitsWarper (same attribute); the HF object itself is accepted as well."""
+
+    def __init__(self, top_k: int, filter_value: float = -float("Inf"), min_tokens_to_keep: int = 1):
+        self.top_k = max(int(top_k), min_tokens_to_keep)
+
+
+class AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(_Descriptor):
+    def __init__(self, trigger_token_id: int, allowed_token_ids: List[int], offset: int, exclusive: bool = False, device="cpu"):
+        self.trigger_token_id, self.allowed_token_ids, self.offset, self.exclusive = trigger_token_id, list(allowed_token_ids), offset, exclusive
+
+
+class AllowOnlyTokensInRelativeWindowLogitsProcessor3d(_Descriptor):
+    def __init__(self, trigger_token_id: int, allowed_token_ids: List[int], window_width: int, exclusive: bool = False, device="cpu"):
+        self.trigger_token_id, self.allowed_token_ids, self.window_width, self.exclusive = trigger_token_id, list(allowed_token_ids), window_width, exclusive
+
+
+class SuppressTokensInIndexRangeLogitsProcessor3d(_Descriptor):
+    def __init__(self, suppress_tokens: List[int], start_index: int, end_index: Optional[int] = None, device="cpu"):
+        self.suppress_tokens, self.start_index = list(suppress_tokens), start_index
+        self.end_index = end_index if end_index is not None else math.inf
+
+
+class SuppressTokensAtBeginLogitsProcessor3d(SuppressTokensInIndexRangeLogitsProcessor3d):
+    def __init__(self, begin_suppress_tokens, begin_index, device="cpu"):
+        super().__init__(begin_suppress_tokens, begin_index, begin_index + 1, device=device)
+        self.begin_index = begin_index
+
+
+class SuppressTokensLogitsProcessor3d(SuppressTokensInIndexRangeLogitsProcessor3d):
+    def __init__(self, suppress_tokens, device="cpu"):
+        super().__init__(suppress_tokens, 0, device=device)
+
+
+def get_double_cfg_input_ids(input_ids, neg_input_ids, pad_category):
+    """reference :422-440: left-pad positive/negative prompts to a common length, stacked on the batch dim."""
+    batchsize, prefill_num = input_ids.shape
+    max_prefill_num = max(prefill_num, neg_input_ids.shape[1])
+    out = torch.full((2 * batchsize, max_prefill_num), pad_category, dtype=input_ids.dtype, device=input_ids.device)
+    out[:batchsize, -input_ids.shape[1]:] = input_ids
+    out[batchsize:, -neg_input_ids.shape[1]:] = neg_input_ids
+    return out
+
+
+def grammar_from_processors(processors, prompt_len=None, max_length=None):
+    """LogitsProcessorList -> integer grammar driving kernels K2/K4.  Raises for processors this engine does not know."""
+    procs = list(processors)
+    names = [type(p).__name__ for p in procs]
+    if len(procs) >= 1 and isinstance(procs[0], MultiTokensVLLogitsProcessor):
+        vl = procs[0]
+        tk = next((p for p in procs[1:] if isinstance(p, MultiTokensInterleavedTopKLogitsWarper)), None)
+        extra = [p for p in procs[1:] if p is not tk]
+        if extra:
+            raise NotImplementedError(f"unsupported logits processors after the Lumina grammar: {[type(p).__name__ for p in extra]}")
+        return G.LuminaGrammar(image_top_k=tk.image_top_k if tk else 0, text_top_k=tk.text_top_k if tk else 0,
+                               image_start_token_id=vl.image_start_token_id, image_end_token_id=vl.image_end_token_id,
+                               image_next_line_token_id=vl.image_next_line_token_id, img_lo=vl.image_token_range[0],
+                               img_hi=vl.image_token_range[1])
+    if all(n in ("TopKLogitsWarper", "TopPLogitsWarper3d") for n in names) and names:
+        k = next((int(p.top_k) for p in procs if type(p).__name__ == "TopKLogitsWarper"), 0)
+        p_ = next((float(p.top_p) for p in procs if type(p).__name__ == "TopPLogitsWarper3d"), 1.0)
+        return G.TopKTopPGrammar(k, p_)
+    if names and names[0] == "EOLLogitProcessor3d":
+        h = procs[0]
+        k = next((int(p.top_k) for p in procs[1:] if type(p).__name__ == "TopKLogitsWarper"), 0)
+        vis = list(h.visual_tokens)
+        if vis != list(range(vis[0], vis[0] + len(vis))):
+            raise NotImplementedError("Emu3 visual token ids must form one contiguous range")
+        return G.Emu3Grammar(h.height, h.width, vis[0], len(vis), h.img_token, h.eoi_token, h.eos_token, h.eol_token,
+                             h.eof_token, h.pad_token, top_k=k)
+    if names and names[0] == "AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d":
+        at, win = procs[0], procs[1]
+        begin = next(p for p in procs if isinstance(p, SuppressTokensAtBeginLogitsProcessor3d))
+        rng = next(p for p in procs if type(p) is SuppressTokensInIndexRangeLogitsProcessor3d)
+        k = next((int(p.top_k) for p in procs if type(p).__name__ == "TopKLogitsWarper"), 0)
+        img = sorted(win.allowed_token_ids)
+        L_img = win.window_width
+        return G.AnoleGrammar(vocab_size=None, prompt_len=begin.begin_index, max_length=rng.start_index + L_img + 1,
+                              image_seq_length=L_img, boi=at.trigger_token_id, eoi=at.allowed_token_ids[0],
+                              eos=begin.suppress_tokens[0], img_lo=img[0], img_hi=img[-1] + 1, top_k=k)
+    raise NotImplementedError(f"no kernel grammar for logits processors {names}")

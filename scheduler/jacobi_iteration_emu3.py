@@ -1,0 +1,4 @@
+"""Re-export of sjd_amd.scheduler.jacobi_iteration_emu3 (reference import path)."""
+from sjd_amd.scheduler.jacobi_iteration_emu3 import *  # noqa: F401,F403
+from sjd_amd.scheduler import jacobi_iteration_emu3 as _m
+globals().update({k: v for k, v in vars(_m).items() if not k.startswith("__")})

@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--tunableop", action="store_true", help="enable PyTorch TunableOp GEMM selection")
     ap.add_argument("--no-fused", action="store_true", help="plain ATen element-wise glue instead of the fused F1-F3 kernels")
-    ap.add_argument("--k1-launches", type=int, default=200, help="launches of the K1 micro-measurement")
+    ap.add_argument("--k1-launches", type=int, default=320, help="launches of the K1 micro-measurement")
     return ap.parse_args()
 
 
@@ -67,24 +67,25 @@ def measure_k1(args, model, attn, device, kv_len):
     import sjd_amd.ops as ops
     lib = L.load()
     B, n, H, D = 2, args.window, model.n_heads, model.head_dim
-    kc, vc = model.cache.k[0], model.cache.v[0]
+    nl = model.cache.k.shape[0]      # cycle over all layers' caches like a real iteration: ~40 MB/layer x 32 streams from HBM,
+    kc, vc = model.cache.k, model.cache.v   # a single layer would sit in the 256 MB Infinity Cache
     q = torch.randn(B, n, H, D, device=device).to(kc.dtype)
     out = torch.empty_like(q)
     ks = torch.tensor([0, 63], dtype=torch.int32, device=device)
     ws = ops.attention_workspace(B, H, n, D, args.n_split, device)
     evs = [(ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())) for _ in range(args.k1_launches)]
-    for _ in range(10):
-        ops.draft_window_attention(q, kc, vc, out, ks, None, kv_len, args.n_split, ws)
+    for i in range(nl):
+        ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, kv_len, args.n_split, ws)
     torch.cuda.synchronize()
-    for e0, e1 in evs:
-        ops.draft_window_attention(q, kc, vc, out, ks, None, kv_len, args.n_split, ws, e0, e1)
+    for i, (e0, e1) in enumerate(evs):
+        ops.draft_window_attention(q, kc[i % nl], vc[i % nl], out, ks, None, kv_len, args.n_split, ws, e0, e1)
     torch.cuda.synchronize()
     ms = [lib.sjd_event_elapsed_ms(e0, e1) for e0, e1 in evs]
     for e0, e1 in evs:
         lib.sjd_event_destroy(e0)
         lib.sjd_event_destroy(e1)
     esz = kc.element_size()
-    Hkv = kc.shape[1]
+    Hkv = kc.shape[2]
     rows0, rows1 = kv_len + n, kv_len + n - 63          # visible key rows of the cond / uncond batch row
     alg = 2 * Hkv * (rows0 + rows1) * D * esz + B * n * H * D * esz     # K,V rows once per kv head + q
     avg_ms = sum(ms) / len(ms)

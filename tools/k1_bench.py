@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Micro-driver of kernel K1 (draft-window attention) at the Lumina-mGPT-7B shape, cycling over the 32 per-layer KV
+caches exactly like one SJD iteration does (so the working set, ~40 MB/layer x 32, streams from HBM instead of sitting
+in the 256 MB Infinity Cache).  Used under rocprofv3 (--kernel-trace --stats, and --pmc FETCH_SIZE / WRITE_SIZE in
+separate passes) to produce profiles/*k1*.  Prints one JSON line with the HIP-event timing."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import sjd_amd._lib as L  # noqa: E402
+import sjd_amd.ops as ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kv-len", type=int, default=1216)
+    ap.add_argument("--launches", type=int, default=320)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--kv-heads", type=int, default=32)
+    ap.add_argument("--head-dim", type=int, default=128)
+    ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--n-split", type=int, default=8)
+    ap.add_argument("--prompt", type=int, default=64)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = L.load()
+    B, n, H, Hkv, D = 2, a.window, a.heads, a.kv_heads, a.head_dim
+    s_max = ((a.kv_len + n + 64 + 31) // 32) * 32
+    kc = torch.randn(a.layers, B, Hkv, s_max, D, device=dev).to(torch.bfloat16)
+    vc = torch.randn(a.layers, B, Hkv, s_max, D, device=dev).to(torch.bfloat16)
+    q = torch.randn(B, n, H, D, device=dev).to(torch.bfloat16)
+    out = torch.empty_like(q)
+    ks = torch.tensor([0, a.prompt - 1], dtype=torch.int32, device=dev)
+    ws = ops.attention_workspace(B, H, n, D, a.n_split, dev)
+    for i in range(a.layers):
+        ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, a.kv_len, a.n_split, ws)
+    torch.cuda.synchronize()
+    evs = [(ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())) for _ in range(a.launches)]
+    for i, (e0, e1) in enumerate(evs):
+        ops.draft_window_attention(q, kc[i % a.layers], vc[i % a.layers], out, ks, None, a.kv_len, a.n_split, ws, e0, e1)
+    torch.cuda.synchronize()
+    ms = sorted(lib.sjd_event_elapsed_ms(e0, e1) for e0, e1 in evs)
+    esz = 2
+    rows0, rows1 = a.kv_len + n, a.kv_len + n - (a.prompt - 1)
+    alg = 2 * Hkv * (rows0 + rows1) * D * esz + B * n * H * D * esz
+    avg = sum(ms) / len(ms)
+    print(json.dumps(dict(kernel="k1_partial", kv_len=a.kv_len, window=n, launches=len(ms), avg_us=round(avg * 1e3, 2),
+                          median_us=round(ms[len(ms) // 2] * 1e3, 2), algorithmic_bytes=alg,
+                          gbps=round(alg / 1e9 / (avg / 1e3), 1), frac_of_8TBps=round(alg / 1e9 / (avg / 1e3) / 8000, 4))))
+
+
+if __name__ == "__main__":
+    main()

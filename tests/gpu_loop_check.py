@@ -131,3 +131,44 @@ def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, 
     gen = seq[P:]
     return dict(tokens=len(gen), nfe=stats.nfe, eol=[i for i, t in enumerate(gen) if t == 8803][:3], last=gen[-1],
                 accepted_hist=sorted(set(stats.matched[1:])), noise_checks=checks["noise"])
+
+
+@torch.no_grad()
+def teacher_forced_emu3_check(device="cuda:0", H=3, W=5, window=32, seed=5, embed_token_scale=0.4, dtype=torch.float16,
+                              use_graph=True, pos_len=9, neg_len=5):
+    """Emu3 flavour (config 3): Llama-style GQA backbone without QK-norm, pos/neg prompts left-padded to a common
+    length (pads are hidden keys), EOL/EOF/EOI/EOS grammar, top-k 2048, draft window 32, fp16."""
+    import sjd_amd.ops as ops
+    import sjd_amd.backbones as BB
+    import sjd_amd.synthetic as synthetic
+    from sjd_amd.engine import SJDEngine, SJDConfig
+    from sjd_amd.frontends import emu3_window_spec
+    from sjd_amd.grammar import Emu3Grammar
+    V, vis_lo, vis_n = 12288, 3000, 8192
+    tok = dict(img_token=200, eoi_token=201, eos_token=202, eol_token=203, eof_token=204, pad_token=205)
+    args = BB.ChameleonArgs(vocab_size=V, hidden_size=1024, intermediate_size=512, num_hidden_layers=2, num_attention_heads=8,
+                            num_key_value_heads=2, rope_theta=1000000.0, qk_norm=False)
+    model = BB.ChameleonBackbone(args, attn=ops.HipWindowAttention(n_split=2)).eval()
+    synthetic.fill_state_dict(model, seed=29, embed_token_scale=embed_token_scale)
+    model = model.to(device=device, dtype=dtype).enable_fused(ops)
+    g = torch.Generator().manual_seed(seed)
+    pos_ids = torch.randint(300, 2000, (pos_len - 1,), generator=g).tolist() + [tok["img_token"]]
+    neg_ids = torch.randint(300, 2000, (neg_len - 1,), generator=g).tolist() + [tok["img_token"]]
+    spec = emu3_window_spec(pos_ids, neg_ids, tok["pad_token"], device)
+    prompt = spec.first_tokens[0].tolist()
+    P = len(prompt)
+    n_gen = (W + 1) * H + 3
+    max_len = P + n_gen + 2
+    model.setup_cache(batch=2, s_max=((max_len + 64 + 31) // 32) * 32)
+    cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=(W + 1) * H - 1, max_num_new_tokens=window, guidance_scale=3.0,
+                    seed=seed, prefix_token_sampler_scheme="speculative_jacobi", max_length=max_len, eos_token_ids=(tok["eos_token"],))
+    eng = SJDEngine(model, V, device, max_window=window, use_graph=use_graph)
+    rec = _Recorder()
+    eng.hook = rec
+    seq, stats = eng.decode(prompt, spec, Emu3Grammar(H, W, vis_lo, vis_n, **tok, top_k=2048), cfg)
+    rules_fn = lambda c, n: O.emu3_rules(c, n, H, W, vis_lo, vis_n, top_k=2048, **tok)
+    seq_ref, tr, checks = _replay(rec, prompt, rules_fn, _loop_cfg(cfg), V, device=device)
+    assert seq == seq_ref, "token sequences differ"
+    assert stats.matched == tr.matched and stats.nfe == len(tr.matched)
+    gen = seq[P:]
+    return dict(tokens=len(gen), nfe=stats.nfe, gen=gen, tok=tok, W=W, H=H)

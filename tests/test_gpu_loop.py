@@ -33,3 +33,14 @@ def test_lumina_loop(scheme, seed, window, kvh, l, r, use_graph):
     assert s["eol"] == [8, 17, 26]
     if r is None:
         assert s["last"] == 8196 and s["tokens"] == 73
+
+
+@pytest.mark.parametrize("window,use_graph", [(32, True), (16, False)])
+def test_emu3_loop(window, use_graph):
+    s = G.teacher_forced_emu3_check(window=window, use_graph=use_graph)
+    gen, t, W, H = s["gen"], s["tok"], s["W"], s["H"]
+    eols = [i for i, x in enumerate(gen) if x == t["eol_token"]]
+    assert eols == [(W + 1) * (r + 1) - 1 for r in range(H)]                        # EOL closes every row
+    assert gen[(W + 1) * H:(W + 1) * H + 3] == [t["eof_token"], t["eoi_token"], t["eos_token"]]
+    assert all(3000 <= x < 3000 + 8192 for i, x in enumerate(gen[:(W + 1) * H]) if i not in eols)
+    assert s["nfe"] < s["tokens"]

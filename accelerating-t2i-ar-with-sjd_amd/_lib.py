@@ -35,7 +35,7 @@ class State(ctypes.Structure):
 EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_probs_sample", "sjd_verify_accept",
            "sjd_kv_append", "sjd_attention_workspace_bytes", "sjd_draft_window_attention", "sjd_draft_window_attention_ex",
            "sjd_event_create", "sjd_event_destroy", "sjd_event_synchronize", "sjd_event_elapsed_ms",
-           "sjd_add_rmsnorm", "sjd_qknorm_rope_append", "sjd_silu_mul"]
+           "sjd_add_rmsnorm", "sjd_qknorm_rope_append", "sjd_silu_mul", "sjd_gemm_num_chunks", "sjd_skinny_gemm"]
 
 _lib = None
 
@@ -64,9 +64,11 @@ def load():
     lib.sjd_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     lib.sjd_draft_window_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp]
     lib.sjd_draft_window_attention_ex.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]
-    lib.sjd_add_rmsnorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, vp]
-    lib.sjd_qknorm_rope_append.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
-    lib.sjd_silu_mul.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.sjd_add_rmsnorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, vp, i32, vp]
+    lib.sjd_qknorm_rope_append.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp]
+    lib.sjd_silu_mul.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
+    lib.sjd_gemm_num_chunks.argtypes = [i32, i32]
+    lib.sjd_skinny_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.sjd_event_create.restype = vp
     lib.sjd_event_destroy.argtypes = [vp]
     lib.sjd_event_synchronize.argtypes = [vp]

@@ -325,11 +325,18 @@ class ChameleonBackbone(nn.Module):
         emb = torch.cat((freqs, freqs), dim=-1)
         return emb.cos().to(dtype)[:, :, None, :], emb.sin().to(dtype)[:, :, None, :]
 
-    def enable_fused(self, ops):
+    # split-K chunk of each projection for the G1 weight-streaming kernel (every launch should give the 256 CUs >= ~1000 waves)
+    G1_KC = dict(qkv=1024, o=512, gate_up=2048, down=1024)
+
+    def enable_fused(self, ops, gemm="torch"):
         """Switch to the fused HIP glue path (F1-F3): q|k|v and gate|up projections become single GEMMs whose weights are
         concatenated once; the original parameters are re-pointed at slices of the fused tensors (state-dict unchanged,
-        no extra memory).  `ops` is sjd_amd.ops (raises if libsjd_hip.so is missing)."""
+        no extra memory).  gemm="sjd": the window forward (<= 32 rows) also runs its four per-layer projections on the
+        hand-written weight-streaming kernel G1 over pre-packed weights (a second, fragment-major copy of the layer
+        weights); other shapes (prefill) keep hipBLASLt.  `ops` is sjd_amd.ops (raises if libsjd_hip.so is missing)."""
         self._ops = ops
+        self._gemm = gemm
+        self._packed = []
         self._fused = []
         with torch.no_grad():
             for layer in self.model.layers:
@@ -341,10 +348,43 @@ class ChameleonBackbone(nn.Module):
                 ni = m.gate_proj.weight.shape[0]
                 m.gate_proj.weight.data, m.up_proj.weight.data = gu[:ni], gu[ni:]
                 self._fused.append((qkv, gu))
+                if gemm == "sjd":
+                    kc = self.G1_KC
+                    self._packed.append(dict(qkv=ops.pack_weight(qkv, kc["qkv"]), o=ops.pack_weight(a.o_proj.weight, kc["o"]),
+                                             gate_up=ops.pack_weight(gu, kc["gate_up"]),
+                                             down=ops.pack_weight(m.down_proj.weight, kc["down"])))
         self._inv_freq32 = self.inv_freq.float().contiguous()
         return self
 
+    def _forward_window_g1(self, tokens, positions, kv_len, key_start):
+        """Window forward (B*n <= 32 rows) with the four per-layer projections on kernel G1; split-K partials flow straight
+        into the consuming glue kernel (F2 / F1 / F3 / F1)."""
+        ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
+        T, eps, kc = B * n, self.args.rms_norm_eps, self.G1_KC
+        H, Hkv, D, hid, inter = self.n_heads, self.n_kv_heads, self.head_dim, self.args.hidden_size, self.args.intermediate_size
+        params = getattr(self.attn, "params", None)
+        h = self.model.embed_tokens(tokens).view(T, -1).contiguous()
+        pos = positions.reshape(T).contiguous()
+        delta = None
+        for li, layer in enumerate(self.model.layers):
+            a, pw = layer.self_attn, self._packed[li]
+            x = ops.add_rmsnorm(h, delta, layer.input_layernorm.weight, eps)
+            qkv = ops.skinny_gemm(x, pw["qkv"], (H + 2 * Hkv) * D, hid, kc["qkv"])
+            qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
+            q = ops.qknorm_rope_append(qkv, self.cache.k[li], self.cache.v[li], *qn, self._inv_freq32, pos, B, n, H, Hkv, D,
+                                       params, kv_len if params is None else 0)
+            o = self.attn.attend(li, q, self.cache, kv_len, key_start)
+            attn_out = ops.skinny_gemm(o.view(T, H * D), pw["o"], hid, H * D, kc["o"])
+            x = ops.add_rmsnorm(h, attn_out, layer.post_attention_layernorm.weight, eps)
+            gu = ops.skinny_gemm(x, pw["gate_up"], 2 * inter, hid, kc["gate_up"])
+            act = ops.silu_mul(gu, rows=T, dtype=h.dtype)
+            delta = ops.skinny_gemm(act, pw["down"], hid, inter, kc["down"])
+        x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
+        return self.lm_head(x).float().view(B, n, -1)
+
     def _forward_window_fused(self, tokens, positions, kv_len, key_start):
+        if self._gemm == "sjd" and tokens.shape[0] * tokens.shape[1] <= 32:
+            return self._forward_window_g1(tokens, positions, kv_len, key_start)
         ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
         T, eps = B * n, self.args.rms_norm_eps
         H, Hkv, D = self.n_heads, self.n_kv_heads, self.head_dim

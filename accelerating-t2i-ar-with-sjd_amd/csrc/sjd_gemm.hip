@@ -1,0 +1,117 @@
+// sjd_gemm.hip -- G1: weight-streaming projection for the draft window (M <= 32 rows) on gfx950.
+//
+// One SJD iteration multiplies a [B_cfg*L = 32, K] activation by every weight matrix of the transformer: 13.5 GB of bf16
+// weights streamed for 432 GFLOP -- intensity 32 flop/B, an order of magnitude under the ridge, so the op is a pure HBM
+// stream and a 32-row problem is exactly ONE v_mfma_f32_32x32x16 tile tall.  rocprofv3 (profiles/r1b_*) shows the library
+// GEMMs at 2.8-4.3 TB/s for these shapes; this kernel is written for the stream instead:
+//
+//   * weights are PRE-PACKED once (host, at load time) into MFMA-fragment-major order: unit (k-chunk c, 32-column tile t)
+//     is `steps` consecutive 1-KiB records, record s = the B operand of k-step s, lane l holding
+//     W[32t + (l&31)][k0 + 16s + 8(l>>5) .. +7].  A wave therefore reads ONE contiguous run of 16..64 KiB with
+//     1-KiB-per-instruction 16-byte loads straight into MFMA operand registers -- no LDS, no transposes, no address math;
+//   * the activation chunk x[:, k0:k0+KC] is staged once per workgroup in LDS in the same fragment-major order (A operand,
+//     conflict-free ds_read_b128), shared by the 8 waves (8 column tiles) of the workgroup;
+//   * split-K over grid.y gives every CU several waves; the fp32 partials [n_chunks, 32, N] are summed by the CONSUMER
+//     kernel (F1 / F2 / F3 take n_chunks), so no reduction pass and no atomics;
+//   * loads are issued 8 k-steps ahead of their MFMA (register double buffer) and marked non-temporal (read once).
+#include <hip/hip_runtime.h>
+
+#include "../../include/sjd_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+#define G1_WAVES 8
+#define G1_UNROLL 8
+
+template <int DT> struct G1Mfma;
+template <> struct G1Mfma<SJD_DTYPE_BF16> {
+    static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c)
+    { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0); }
+};
+template <> struct G1Mfma<SJD_DTYPE_F16> {
+    static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c)
+    { return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); }
+};
+
+// x: [M, K] row-major (M <= 32; missing rows read as zero).  wp: packed weights.  out: fp32 [n_chunks, 32, N].
+template <int DT>
+__global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
+                                                                float *__restrict__ out, int M, int N, int K, int KC, int n_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *xl = reinterpret_cast<u32x4 *>(smem);
+    const int chunk = blockIdx.y;
+    const int k0 = chunk * KC;
+    const int steps = min(KC, K - k0) / 16;
+    // stage the activation chunk in A-fragment order: piece (s, l) = x[l&31][k0 + 16s + 8(l>>5) .. +7]
+    for (int p = threadIdx.x; p < steps * 64; p += G1_WAVES * 64) {
+        const int s = p >> 6, l = p & 63, m = l & 31;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (m < M) v = *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + 16 * s + 8 * (l >> 5));
+        xl[p] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t = blockIdx.x * G1_WAVES + w;
+    if (t >= n_tiles) return;
+    // unit base in 16-byte records: all earlier chunks are full (KC/16 steps each)
+    const u32x4 *wu = wp + ((size_t)chunk * n_tiles * (KC / 16) + (size_t)t * steps) * 64 + lane;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+    u32x4 cur[G1_UNROLL], nxt[G1_UNROLL];
+    const int full = steps / G1_UNROLL;
+    if (full > 0) {
+#pragma unroll
+        for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * 64);
+    }
+    for (int g = 0; g < full; ++g) {
+        const bool more = g + 1 < full;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < G1_UNROLL; ++u) nxt[u] = __builtin_nontemporal_load(wu + (size_t)((g + 1) * G1_UNROLL + u) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < G1_UNROLL; ++u) acc = G1Mfma<DT>::mma(xl[(g * G1_UNROLL + u) * 64 + lane], cur[u], acc);
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < G1_UNROLL; ++u) cur[u] = nxt[u];
+        }
+    }
+    for (int s = full * G1_UNROLL; s < steps; ++s)      // ragged tail (K chunk not a multiple of 128)
+        acc = G1Mfma<DT>::mma(xl[s * 64 + lane], __builtin_nontemporal_load(wu + (size_t)s * 64), acc);
+
+    // D[m][n]: reg r of lane l -> row m = (r&3) + 8*(r>>2) + 4*(l>>5), column n = 32t + (l&31): 128-B coalesced rows
+    float *o = out + ((size_t)chunk * 32) * N + (size_t)t * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        o[(size_t)m * N] = acc[r];
+    }
+}
+
+
+extern "C" int sjd_gemm_num_chunks(int K, int KC) { return (K + KC - 1) / KC; }
+
+// out: fp32 [n_chunks, 32, N] partial products; the consumer sums the chunks.
+extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int dtype, void *stream)
+{
+    if (!x || !w_packed || !out || M < 1 || M > 32 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
+    if ((size_t)KC * 64 > 160 * 1024) return SJD_ERR_BAD_ARG;       // activation chunk must fit in LDS (KC <= 2560)
+    const int n_tiles = N / 32, n_chunks = (K + KC - 1) / KC;
+    const dim3 grid((n_tiles + G1_WAVES - 1) / G1_WAVES, n_chunks), block(G1_WAVES * 64);
+    const size_t lds = (size_t)(KC / 16) * 64 * 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SJD_DTYPE_BF16) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<SJD_DTYPE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(g1_skinny_gemm<SJD_DTYPE_BF16>, grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles);
+    } else if (dtype == SJD_DTYPE_F16) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<SJD_DTYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(g1_skinny_gemm<SJD_DTYPE_F16>, grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles);
+    } else return SJD_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}

@@ -65,10 +65,11 @@ __device__ __forceinline__ float wave_sum(float v)
 
 // ------------------------------------------------------------------------------------------------ F1
 // one 256-thread workgroup per row; hidden % 8 == 0 and hidden <= 256*8*MAXV
+// `part` (optional): fp32 split-K partials [n_chunks, 32, hidden] of the producing G1 projection; delta = dtype(sum_c part[c]).
 template <int DT>
 __global__ __launch_bounds__(256) void f1_add_rmsnorm(unsigned short *__restrict__ h, const unsigned short *__restrict__ delta,
                                                       const unsigned short *__restrict__ w, unsigned short *__restrict__ y,
-                                                      int hidden, float eps)
+                                                      int hidden, float eps, const float *__restrict__ part, int n_chunks)
 {
     __shared__ float red[4];
     const int row = blockIdx.x;
@@ -80,9 +81,21 @@ __global__ __launch_bounds__(256) void f1_add_rmsnorm(unsigned short *__restrict
     int nv = 0;
     for (int c = threadIdx.x * 8; c < hidden && nv < MAXV; c += 256 * 8, ++nv) {
         unpack8<DT>(*reinterpret_cast<const u32x4 *>(hr + c), x[nv]);
-        if (dr) {
+        if (dr || part) {
             float d[8];
-            unpack8<DT>(*reinterpret_cast<const u32x4 *>(dr + c), d);
+            if (part) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = 0.f;
+                for (int cc = 0; cc < n_chunks; ++cc) {
+                    const float4 *pp = reinterpret_cast<const float4 *>(part + ((size_t)cc * 32 + row) * hidden + c);
+                    const float4 a = pp[0], b = pp[1];
+                    d[0] += a.x; d[1] += a.y; d[2] += a.z; d[3] += a.w; d[4] += b.x; d[5] += b.y; d[6] += b.z; d[7] += b.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(d[j]));     // the projection output rounds to the activation dtype
+            } else {
+                unpack8<DT>(*reinterpret_cast<const u32x4 *>(dr + c), d);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[nv][j] = Cvt<DT>::to_f(Cvt<DT>::from_f(x[nv][j] + d[j]));   // residual add rounds to the activation dtype
             *reinterpret_cast<u32x4 *>(hr + c) = pack8<DT>(x[nv]);
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     unsigned short *__restrict__ v_cache, const unsigned short *__restrict__ qn_w, const unsigned short *__restrict__ qn_b,
     const unsigned short *__restrict__ kn_w, const unsigned short *__restrict__ kn_b, const float *__restrict__ inv_freq,
     const long *__restrict__ positions, int B, int n, int H, int H_kv, int S_max, const sjd_iter_params *__restrict__ params,
-    int kv_len_arg)
+    int kv_len_arg, const float *__restrict__ part, int n_chunks)
 {
     constexpr int HALF = D / 2;
     constexpr int PPL = HALF / 64 > 0 ? HALF / 64 : 1;       // pairs per lane (D=128: 1, D=64: lanes 32..63 idle)
@@ -137,9 +150,23 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     }
     const bool active = lane < HALF;
     float x0 = 0.f, x1 = 0.f;
-    if (active) { x0 = Cvt<DT>::to_f(src[lane]); x1 = Cvt<DT>::to_f(src[lane + HALF]); }
+    if (active) {
+        if (part) {                                           // fp32 split-K partials of the qkv projection (G1)
+            const size_t ncol = (size_t)heads * D, col = (size_t)hh * D + lane;
+            for (int cc = 0; cc < n_chunks; ++cc) {
+                const float *pp = part + ((size_t)cc * 32 + tok) * ncol + col;
+                x0 += pp[0];
+                x1 += pp[HALF];
+            }
+            x0 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0));
+            x1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x1));
+        } else {
+            x0 = Cvt<DT>::to_f(src[lane]);
+            x1 = Cvt<DT>::to_f(src[lane + HALF]);
+        }
+    }
     if (!is_q && !is_k) {                                     // V: plain copy into the cache
-        if (active) { dst[lane] = src[lane]; dst[lane + HALF] = src[lane + HALF]; }
+        if (active) { dst[lane] = Cvt<DT>::from_f(x0); dst[lane + HALF] = Cvt<DT>::from_f(x1); }
         return;
     }
     const unsigned short *gw_ = is_q ? qn_w : kn_w, *gb_ = is_q ? qn_b : kn_b;
@@ -174,15 +201,30 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
 
 // ------------------------------------------------------------------------------------------------ F3
 template <int DT>
-__global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restrict__ gu, unsigned short *__restrict__ y, int M, int I)
+__global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restrict__ gu, unsigned short *__restrict__ y, int M, int I,
+                                                   const float *__restrict__ part, int n_chunks)
 {
     const int per_row = I / 8;
     const size_t total = (size_t)M * per_row;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int row = idx / per_row, c = (idx % per_row) * 8;
         float g[8], u[8], o[8];
-        unpack8<DT>(*reinterpret_cast<const u32x4 *>(gu + (size_t)row * 2 * I + c), g);
-        unpack8<DT>(*reinterpret_cast<const u32x4 *>(gu + (size_t)row * 2 * I + I + c), u);
+        if (part) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { g[j] = 0.f; u[j] = 0.f; }
+            for (int cc = 0; cc < n_chunks; ++cc) {
+                const float4 *pg = reinterpret_cast<const float4 *>(part + ((size_t)cc * 32 + row) * 2 * I + c);
+                const float4 *pu = reinterpret_cast<const float4 *>(part + ((size_t)cc * 32 + row) * 2 * I + I + c);
+                const float4 a = pg[0], b = pg[1], e = pu[0], f = pu[1];
+                g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; g[4] += b.x; g[5] += b.y; g[6] += b.z; g[7] += b.w;
+                u[0] += e.x; u[1] += e.y; u[2] += e.z; u[3] += e.w; u[4] += f.x; u[5] += f.y; u[6] += f.z; u[7] += f.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { g[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(g[j])); u[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(u[j])); }
+        } else {
+            unpack8<DT>(*reinterpret_cast<const u32x4 *>(gu + (size_t)row * 2 * I + c), g);
+            unpack8<DT>(*reinterpret_cast<const u32x4 *>(gu + (size_t)row * 2 * I + I + c), u);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float s = Cvt<DT>::to_f(Cvt<DT>::from_f(g[j] / (1.0f + __expf(-g[j]))));   // silu rounds to the activation dtype
@@ -194,16 +236,17 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
 
 // ------------------------------------------------------------------------------------------------ C-ABI
 extern "C" int sjd_add_rmsnorm(void *h, const void *delta, const void *weight, void *y, int rows, int hidden, float eps, int dtype,
-                               void *stream)
+                               const float *part, int n_chunks, void *stream)
 {
+    if (part && (rows > 32 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
     if (!h || !weight || !y || rows < 1 || hidden < 8 || (hidden % 8) != 0 || hidden > 256 * 8 * 4) return SJD_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SJD_DTYPE_BF16)
         hipLaunchKernelGGL(f1_add_rmsnorm<SJD_DTYPE_BF16>, dim3(rows), dim3(256), 0, s, (unsigned short *)h, (const unsigned short *)delta,
-                           (const unsigned short *)weight, (unsigned short *)y, hidden, eps);
+                           (const unsigned short *)weight, (unsigned short *)y, hidden, eps, part, n_chunks);
     else if (dtype == SJD_DTYPE_F16)
         hipLaunchKernelGGL(f1_add_rmsnorm<SJD_DTYPE_F16>, dim3(rows), dim3(256), 0, s, (unsigned short *)h, (const unsigned short *)delta,
-                           (const unsigned short *)weight, (unsigned short *)y, hidden, eps);
+                           (const unsigned short *)weight, (unsigned short *)y, hidden, eps, part, n_chunks);
     else return SJD_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
@@ -211,9 +254,10 @@ extern "C" int sjd_add_rmsnorm(void *h, const void *delta, const void *weight, v
 extern "C" int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b,
                                       const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n,
                                       int H, int H_kv, int D, int S_max, int dtype, const sjd_iter_params *params, int kv_len,
-                                      void *stream)
+                                      const float *part, int n_chunks, void *stream)
 {
-    if (!qkv || !q_out || !k_cache || !v_cache || !inv_freq || !positions || B < 1 || n < 1 || H < 1 || H_kv < 1) return SJD_ERR_BAD_ARG;
+    if (part && (B * n > 32 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    if ((!qkv && !part) || !q_out || !k_cache || !v_cache || !inv_freq || !positions || B < 1 || n < 1 || H < 1 || H_kv < 1) return SJD_ERR_BAD_ARG;
     const int waves = B * n * (H + 2 * H_kv);
     const dim3 grid((waves + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -222,7 +266,7 @@ extern "C" int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cach
         hipLaunchKernelGGL((f2_qknorm_rope_append<DT_, D_>), grid, block, 0, s, (const unsigned short *)qkv, (unsigned short *)q_out, \
                            (unsigned short *)k_cache, (unsigned short *)v_cache, (const unsigned short *)qn_w,                        \
                            (const unsigned short *)qn_b, (const unsigned short *)kn_w, (const unsigned short *)kn_b, inv_freq,        \
-                           (const long *)positions, B, n, H, H_kv, S_max, params, kv_len);                                           \
+                           (const long *)positions, B, n, H, H_kv, S_max, params, kv_len, part, n_chunks);                           \
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;                                                             \
     }
     SJD_F2_CASE(SJD_DTYPE_BF16, 128)
@@ -233,17 +277,18 @@ extern "C" int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cach
     return SJD_ERR_UNSUPPORTED;
 }
 
-extern "C" int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, void *stream)
+extern "C" int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks, void *stream)
 {
-    if (!gate_up || !y || rows < 1 || inter < 8 || (inter % 8) != 0) return SJD_ERR_BAD_ARG;
+    if (part && (rows > 32 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    if ((!gate_up && !part) || !y || rows < 1 || inter < 8 || (inter % 8) != 0) return SJD_ERR_BAD_ARG;
     const size_t total = (size_t)rows * (inter / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SJD_DTYPE_BF16)
-        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_BF16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter);
+        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_BF16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter, part, n_chunks);
     else if (dtype == SJD_DTYPE_F16)
-        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_F16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter);
+        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_F16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter, part, n_chunks);
     else return SJD_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }

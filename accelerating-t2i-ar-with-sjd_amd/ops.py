@@ -116,33 +116,78 @@ def draft_window_attention(q, k_cache, v_cache, out, key_start, params, kv_len, 
             "sjd_draft_window_attention")
 
 
+class Partials:
+    """fp32 split-K partial products [n_chunks, 32, N] of a G1 projection; consumers (F1/F2/F3) sum the chunks."""
+
+    def __init__(self, data, n_chunks, N):
+        self.data, self.n_chunks, self.N = data, n_chunks, N
+
+
+def pack_weight(weight, KC):
+    """[N, K] linear weight -> MFMA 32x32x16 B-fragment-major stream for sjd_skinny_gemm: for every k-chunk c and
+    32-column tile t a contiguous run of (chunk_k/16) 1-KiB records; record s, lane l, element j =
+    W[32t + (l&31)][k0 + 16s + 8(l>>5) + j]."""
+    N, K = weight.shape
+    assert N % 32 == 0 and K % 16 == 0 and KC % 16 == 0
+    out = []
+    for k0 in range(0, K, KC):
+        kc = min(KC, K - k0)
+        w = weight[:, k0:k0 + kc].reshape(N // 32, 32, kc // 16, 2, 8)      # [t, r, s, h, j]
+        out.append(w.permute(0, 2, 3, 1, 4).reshape(-1))                    # [t, s, h, r, j] ; lane = 32h + r
+    return torch.cat(out).contiguous()
+
+
+def skinny_gemm(x, w_packed, N, K, KC):
+    """x [M<=32, K] bf16/fp16 -> Partials([n_chunks, 32, N] fp32)."""
+    M = x.shape[0]
+    assert x.is_contiguous() and x.shape[1] == K and w_packed.numel() == N * K
+    nc = (K + KC - 1) // KC
+    out = torch.empty(nc, 32, N, dtype=torch.float32, device=x.device)
+    L.check(L.load().sjd_skinny_gemm(_ptr(x), _ptr(w_packed), _ptr(out), M, N, K, KC, _dtype_code(x.dtype), _stream()), "sjd_skinny_gemm")
+    return Partials(out, nc, N)
+
+
+def _part_args(delta):
+    if isinstance(delta, Partials):
+        return None, _ptr(delta.data), delta.n_chunks
+    return delta, None, 0
+
+
 def add_rmsnorm(h, delta, weight, eps):
-    """h [T, hidden] is updated in place (h += delta) when delta is given; returns weight * norm(h)."""
+    """h [T, hidden] is updated in place (h += delta) when delta is given (a tensor, or the Partials of a G1 projection);
+    returns weight * norm(h)."""
     T, hidden = h.shape
-    assert h.is_contiguous() and (delta is None or delta.is_contiguous()) and weight.is_contiguous()
+    d, part, nc = _part_args(delta)
+    assert h.is_contiguous() and (d is None or d.is_contiguous()) and weight.is_contiguous()
     y = torch.empty_like(h)
-    L.check(L.load().sjd_add_rmsnorm(_ptr(h), _ptr(delta), _ptr(weight), _ptr(y), T, hidden, float(eps), _dtype_code(h.dtype),
-                                    _stream()), "sjd_add_rmsnorm")
+    L.check(L.load().sjd_add_rmsnorm(_ptr(h), _ptr(d), _ptr(weight), _ptr(y), T, hidden, float(eps), _dtype_code(h.dtype),
+                                    part, nc, _stream()), "sjd_add_rmsnorm")
     return y
 
 
 def qknorm_rope_append(qkv, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, H_kv, D, params, kv_len):
-    """qkv [B*n, (H+2Hkv)*D] -> q [B,n,H,D]; k/v rows are written into k_cache/v_cache [B,Hkv,S,D]."""
-    assert qkv.is_contiguous() and positions.is_contiguous() and positions.dtype == torch.int64
+    """qkv [B*n, (H+2Hkv)*D] (tensor or G1 Partials) -> q [B,n,H,D]; k/v rows are written into k_cache/v_cache [B,Hkv,S,D]."""
+    t, part, nc = _part_args(qkv)
+    assert (t is None or t.is_contiguous()) and positions.is_contiguous() and positions.dtype == torch.int64
     assert inv_freq.dtype == torch.float32 and inv_freq.is_contiguous()
-    q = torch.empty(B, n, H, D, dtype=qkv.dtype, device=qkv.device)
-    L.check(L.load().sjd_qknorm_rope_append(_ptr(qkv), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(qn_w), _ptr(qn_b), _ptr(kn_w),
+    q = torch.empty(B, n, H, D, dtype=k_cache.dtype, device=k_cache.device)
+    L.check(L.load().sjd_qknorm_rope_append(_ptr(t), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(qn_w), _ptr(qn_b), _ptr(kn_w),
                                            _ptr(kn_b), _ptr(inv_freq), _ptr(positions), B, n, H, H_kv, D, k_cache.shape[2],
-                                           _dtype_code(qkv.dtype), params.ptr if params is not None else None, int(kv_len),
-                                           _stream()), "sjd_qknorm_rope_append")
+                                           _dtype_code(k_cache.dtype), params.ptr if params is not None else None, int(kv_len),
+                                           part, nc, _stream()), "sjd_qknorm_rope_append")
     return q
 
 
-def silu_mul(gate_up):
-    T, two_i = gate_up.shape
-    assert gate_up.is_contiguous() and two_i % 2 == 0
-    y = torch.empty(T, two_i // 2, dtype=gate_up.dtype, device=gate_up.device)
-    L.check(L.load().sjd_silu_mul(_ptr(gate_up), _ptr(y), T, two_i // 2, _dtype_code(gate_up.dtype), _stream()), "sjd_silu_mul")
+def silu_mul(gate_up, rows=None, dtype=None):
+    """gate|up [T, 2I] (tensor, or G1 Partials with `rows`/`dtype` given) -> silu(gate) * up [T, I]."""
+    t, part, nc = _part_args(gate_up)
+    if t is not None:
+        T, two_i, dtype, dev = t.shape[0], t.shape[1], t.dtype, t.device
+        assert t.is_contiguous()
+    else:
+        T, two_i, dev = rows, gate_up.N, gate_up.data.device
+    y = torch.empty(T, two_i // 2, dtype=dtype, device=dev)
+    L.check(L.load().sjd_silu_mul(_ptr(t), _ptr(y), T, two_i // 2, _dtype_code(dtype), part, nc, _stream()), "sjd_silu_mul")
     return y
 
 

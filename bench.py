@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=12)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--gemm", default="sjd", choices=["sjd", "torch"], help="window projections: G1 weight-streaming kernel or hipBLASLt")
     ap.add_argument("--tunableop", action="store_true", help="enable PyTorch TunableOp GEMM selection")
     ap.add_argument("--no-fused", action="store_true", help="plain ATen element-wise glue instead of the fused F1-F3 kernels")
     ap.add_argument("--k1-launches", type=int, default=320, help="launches of the K1 micro-measurement")
@@ -54,7 +55,7 @@ def build_model(args, device):
         model = BB.ChameleonBackbone(margs, attn=attn).to(torch.bfloat16).eval()
     synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=args.embed_token_scale)
     if not args.no_fused:
-        model.enable_fused(ops)
+        model.enable_fused(ops, gemm=args.gemm)
     return model, margs, attn
 
 

@@ -127,10 +127,10 @@ int sjd_draft_window_attention_ex(const void *q, const void *k_cache, const void
                                   void *ev_start, void *ev_stop);
 
 /* F1-F3 -- fused element-wise glue of the draft-window forward (the "next" row of SURVEY.md 8f.1).
- * F1: h += delta (delta may be NULL); y = weight * dtype(h * rsqrt(mean(h^2) + eps)).  replaces ChameleonRMSNorm +
+ * F1: h += delta (delta may be NULL; or delta = dtype(sum of the fp32 split-K partials `part`)); y = weight * dtype(h * rsqrt(mean(h^2) + eps)).  replaces ChameleonRMSNorm +
  *     the decoder layer's residual add (reference modeling_chameleon.py:59-73, 637, 643).  h, delta, y: [rows, hidden]. */
 int sjd_add_rmsnorm(void *h, const void *delta, const void *weight, void *y, int rows, int hidden, float eps, int dtype,
-                    void *stream);
+                    const float *part, int n_chunks, void *stream);
 /* F2: per (token, head) of a fused qkv projection [B*n, (H + 2*H_kv) * D]: optional per-head LayerNorm (gamma/beta of
  *     size D; NULL = none), RoPE with fp32 angles positions[t] * inv_freq[d], q -> q_out [B, n, H, D], k/v -> cache rows
  *     [kv_len + i] (kv_len from params when non-NULL).  replaces ChameleonLayerNorm, apply_rotary_pos_emb and
@@ -138,9 +138,17 @@ int sjd_add_rmsnorm(void *h, const void *delta, const void *weight, void *y, int
 int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b,
                            const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n,
                            int H, int H_kv, int D, int S_max, int dtype, const sjd_iter_params *params, int kv_len,
-                           void *stream);
+                           const float *part, int n_chunks, void *stream);
 /* F3: y[rows, inter] = silu(gate_up[:, :inter]) * gate_up[:, inter:].  replaces ChameleonMLP's act_fn/mul (:193-195). */
-int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, void *stream);
+int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks, void *stream);
+
+/* G1 -- weight-streaming projection of the draft window: out[c, m, n] = sum_{k in chunk c} x[m, k] * W[n, k], M <= 32 rows,
+ * fp32 split-K partials [n_chunks, 32, N] (n_chunks = ceil(K / KC)); the consumer (F1/F2/F3 `part` argument) sums them.
+ * replaces the nn.Linear calls of the decoder layer (reference modeling_chameleon.py:527-529, 579, 193-195) for the
+ * window forward.  w_packed: the [N, K] weight re-ordered by sjd_amd.ops.pack_weight (MFMA 32x32x16 B-fragment order,
+ * one contiguous run per (k-chunk, 32-column tile)).  N % 32 == 0, K % 16 == 0, KC % 16 == 0, KC <= 2560. */
+int sjd_gemm_num_chunks(int K, int KC);
+int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int dtype, void *stream);
 
 /* HIP event helpers so that a ctypes host can time kernels on the stream they run on. */
 void *sjd_event_create(void);

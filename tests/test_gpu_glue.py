@@ -101,3 +101,70 @@ def test_fused_forward_matches_unfused(dev):
     for a, b in zip(outs[0], outs[1]):
         # bf16 end-to-end: compare on the logit scale (std ~3)
         assert (a - b).abs().mean() < 0.05 and (a - b).abs().max() < 0.6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,KC", [(32, 12288, 4096, 1024), (32, 4096, 4096, 512), (32, 22016, 4096, 2048),
+                                        (32, 4096, 11008, 1024), (7, 256, 176, 64), (32, 64, 2048, 2048)])
+def test_g1_skinny_gemm(dev, dtype, M, N, K, KC):
+    """G1 weight-streaming projection (split-K partials) against an fp32 matmul of the same bf16/fp16 operands."""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(M, K, generator=g).to(dtype).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    part = ops.skinny_gemm(x, ops.pack_weight(w, KC), N, K, KC)
+    assert part.n_chunks == (K + KC - 1) // KC
+    got = part.data.sum(0)[:M]
+    ref = x.float() @ w.float().t()
+    torch.testing.assert_close(got, ref, atol=2e-3, rtol=2e-3)
+    if M < 32:
+        assert part.data[:, M:].abs().max() == 0        # missing rows are zero, not garbage
+
+
+def test_partials_feed_glue_kernels(dev):
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(5)
+    dt = torch.bfloat16
+    x = torch.randn(32, 512, generator=g).to(dt).to(dev)
+    w = (torch.randn(1024, 512, generator=g) / 512 ** 0.5).to(dt).to(dev)
+    part = ops.skinny_gemm(x, ops.pack_weight(w, 128), 1024, 512, 128)
+    dense = F.linear(x, w)
+    # F1
+    h = torch.randn(32, 1024, generator=g).to(dt).to(dev)
+    nw = (1 + 0.1 * torch.randn(1024, generator=g)).to(dt).to(dev)
+    h1, h2 = h.clone(), h.clone()
+    y1 = ops.add_rmsnorm(h1, part, nw, 1e-5)
+    y2 = ops.add_rmsnorm(h2, dense, nw, 1e-5)
+    assert (h1.float() - h2.float()).abs().max() < 0.07 and (y1.float() - y2.float()).abs().mean() < 5e-3
+    # F3
+    a1 = ops.silu_mul(part, rows=32, dtype=dt)
+    a2 = ops.silu_mul(dense)
+    assert (a1.float() - a2.float()).abs().mean() < 5e-3
+    # F2 (D=128: H=4, Hkv=2 -> 8 head rows of 128 = 1024 columns)
+    kc1, vc1 = torch.zeros(2, 2, 64, 128, dtype=dt, device=dev), torch.zeros(2, 2, 64, 128, dtype=dt, device=dev)
+    kc2, vc2 = torch.zeros_like(kc1), torch.zeros_like(vc1)
+    inv = (1.0 / (10000.0 ** (torch.arange(0, 128, 2).float() / 128))).to(dev)
+    pos = torch.arange(32, device=dev)
+    q1 = ops.qknorm_rope_append(part, kc1, vc1, None, None, None, None, inv, pos, 2, 16, 4, 2, 128, None, 5)
+    q2 = ops.qknorm_rope_append(dense, kc2, vc2, None, None, None, None, inv, pos, 2, 16, 4, 2, 128, None, 5)
+    assert (q1.float() - q2.float()).abs().mean() < 5e-3 and (kc1.float() - kc2.float()).abs().mean() < 5e-3
+    assert (vc1.float() - vc2.float()).abs().max() < 0.07
+
+
+def test_g1_forward_matches_library_gemm_forward(dev):
+    import sjd_amd.ops as ops
+    from tests.helpers import make_chameleon
+    conf = dict(vocab_size=9216, hidden_size=512, intermediate_size=1024, num_hidden_layers=3, num_attention_heads=4,
+                num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    outs = []
+    for gemm in ("torch", "sjd"):
+        m = make_chameleon(conf, 23, 0.5, ops.HipWindowAttention(n_split=2), dtype=torch.bfloat16, device=dev)
+        m.G1_KC = dict(qkv=256, o=128, gate_up=512, down=256)
+        m.enable_fused(ops, gemm=gemm)
+        m.setup_cache(batch=2, s_max=128)
+        toks = torch.randint(4, 9000, (2, 40), generator=torch.Generator().manual_seed(1)).to(dev)
+        ks = torch.tensor([0, 7], dtype=torch.int32, device=dev)
+        m.forward_window(toks, torch.arange(40)[None].repeat(2, 1).to(dev), 0, ks)
+        toks2 = torch.randint(4, 9000, (2, 16), generator=torch.Generator().manual_seed(2)).to(dev)
+        outs.append(m.forward_window(toks2, (40 + torch.arange(16))[None].repeat(2, 1).to(dev), 40, ks))
+    assert (outs[0] - outs[1]).abs().mean() < 0.05 and (outs[0] - outs[1]).abs().max() < 0.6

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Micro-driver of kernel G1 (weight-streaming projection, M=32) at the Lumina-mGPT-7B layer shapes, cycling over enough
+weight copies that every launch streams from HBM (not the 256 MB Infinity Cache); also times hipBLASLt (F.linear) on the
+same shapes.  Prints one JSON line per shape."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import sjd_amd._lib as L  # noqa: E402
+import sjd_amd.ops as ops  # noqa: E402
+
+SHAPES = dict(qkv=(12288, 4096, 1024), o=(4096, 4096, 512), gate_up=(22016, 4096, 2048), down=(4096, 11008, 1024))
+
+
+def timed(fn, n, lib):
+    evs = [(ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())) for _ in range(n)]
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    hip = ctypes.CDLL("libamdhip64.so")
+    for i, (e0, e1) in enumerate(evs):
+        hip.hipEventRecord(e0, stream)
+        fn(i)
+        hip.hipEventRecord(e1, stream)
+    torch.cuda.synchronize()
+    ms = sorted(lib.sjd_event_elapsed_ms(e0, e1) for e0, e1 in evs)
+    return sum(ms) / len(ms), ms[len(ms) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--launches", type=int, default=64)
+    ap.add_argument("--copies", type=int, default=12)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--kc", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = L.load()
+    for name, (N, K, KC) in SHAPES.items():
+        if a.only and name != a.only:
+            continue
+        KC = a.kc or KC
+        x = torch.randn(32, K, device=dev).to(torch.bfloat16)
+        ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16) for _ in range(a.copies)]
+        wps = [ops.pack_weight(w, KC) for w in ws]
+        nc = (K + KC - 1) // KC
+        out = torch.empty(nc, 32, N, dtype=torch.float32, device=dev)
+
+        def g1(i):
+            L.check(lib.sjd_skinny_gemm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % a.copies].data_ptr()),
+                                        ctypes.c_void_p(out.data_ptr()), 32, N, K, KC, 0,
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "g1")
+
+        def blas(i):
+            F.linear(x, ws[i % a.copies])
+
+        for f in (g1, blas):
+            for i in range(a.copies):
+                f(i)
+        torch.cuda.synchronize()
+        bytes_w = N * K * 2
+        r = dict(shape=name, N=N, K=K, KC=KC, weight_MB=round(bytes_w / 1e6, 1))
+        for tag, f in (("g1", g1), ("hipblaslt", blas)):
+            avg, med = timed(f, a.launches, lib)
+            r[tag + "_us"] = round(avg * 1e3, 2)
+            r[tag + "_TBps"] = round(bytes_w / 1e12 / (avg / 1e3), 3)
+        print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -23,7 +23,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
-#define G1_WAVES 8
 #define G1_UNROLL 8
 
 template <int DT> struct G1Mfma;
@@ -37,7 +36,7 @@ template <> struct G1Mfma<SJD_DTYPE_F16> {
 };
 
 // x: [M, K] row-major (M <= 32; missing rows read as zero).  wp: packed weights.  out: fp32 [n_chunks, 32, N].
-template <int DT>
+template <int DT, int G1_WAVES>
 __global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                 float *__restrict__ out, int M, int N, int K, int KC, int n_tiles)
 {
@@ -46,6 +45,17 @@ __global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned s
     const int chunk = blockIdx.y;
     const int k0 = chunk * KC;
     const int steps = min(KC, K - k0) / 16;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t = blockIdx.x * G1_WAVES + w;
+    const bool has_tile = t < n_tiles;
+    // unit base in 16-byte records: all earlier chunks are full (KC/16 steps each)
+    const u32x4 *wu = wp + ((size_t)chunk * n_tiles * (KC / 16) + (size_t)(has_tile ? t : 0) * steps) * 64 + lane;
+    u32x4 cur[G1_UNROLL], nxt[G1_UNROLL];
+    const int full = steps / G1_UNROLL;
+    if (has_tile && full > 0) {          // the weight stream does not depend on x: start it before staging the activations
+#pragma unroll
+        for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * 64);
+    }
     // stage the activation chunk in A-fragment order: piece (s, l) = x[l&31][k0 + 16s + 8(l>>5) .. +7]
     for (int p = threadIdx.x; p < steps * 64; p += G1_WAVES * 64) {
         const int s = p >> 6, l = p & 63, m = l & 31;
@@ -54,21 +64,10 @@ __global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned s
         xl[p] = v;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int t = blockIdx.x * G1_WAVES + w;
-    if (t >= n_tiles) return;
-    // unit base in 16-byte records: all earlier chunks are full (KC/16 steps each)
-    const u32x4 *wu = wp + ((size_t)chunk * n_tiles * (KC / 16) + (size_t)t * steps) * 64 + lane;
+    if (!has_tile) return;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-
-    u32x4 cur[G1_UNROLL], nxt[G1_UNROLL];
-    const int full = steps / G1_UNROLL;
-    if (full > 0) {
-#pragma unroll
-        for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * 64);
-    }
     for (int g = 0; g < full; ++g) {
         const bool more = g + 1 < full;
         if (more) {
@@ -98,20 +97,25 @@ __global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned s
 extern "C" int sjd_gemm_num_chunks(int K, int KC) { return (K + KC - 1) / KC; }
 
 // out: fp32 [n_chunks, 32, N] partial products; the consumer sums the chunks.
-extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int dtype, void *stream)
+template <int DT, int WAVES>
+static int g1_launch(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, hipStream_t s)
+{
+    const int n_tiles = N / 32, n_chunks = (K + KC - 1) / KC;
+    const dim3 grid((n_tiles + WAVES - 1) / WAVES, n_chunks), block(WAVES * 64);
+    const size_t lds = (size_t)(KC / 16) * 64 * 16;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((g1_skinny_gemm<DT, WAVES>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int dtype, void *stream)
 {
     if (!x || !w_packed || !out || M < 1 || M > 32 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
     if ((size_t)KC * 64 > 160 * 1024) return SJD_ERR_BAD_ARG;       // activation chunk must fit in LDS (KC <= 2560)
-    const int n_tiles = N / 32, n_chunks = (K + KC - 1) / KC;
-    const dim3 grid((n_tiles + G1_WAVES - 1) / G1_WAVES, n_chunks), block(G1_WAVES * 64);
-    const size_t lds = (size_t)(KC / 16) * 64 * 16;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SJD_DTYPE_BF16) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<SJD_DTYPE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(g1_skinny_gemm<SJD_DTYPE_BF16>, grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles);
-    } else if (dtype == SJD_DTYPE_F16) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<SJD_DTYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(g1_skinny_gemm<SJD_DTYPE_F16>, grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles);
-    } else return SJD_ERR_UNSUPPORTED;
-    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+    if (dtype == SJD_DTYPE_BF16 && waves == 4) return g1_launch<SJD_DTYPE_BF16, 4>(x, w_packed, out, M, N, K, KC, s);
+    if (dtype == SJD_DTYPE_BF16 && waves == 8) return g1_launch<SJD_DTYPE_BF16, 8>(x, w_packed, out, M, N, K, KC, s);
+    if (dtype == SJD_DTYPE_F16 && waves == 4) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, s);
+    if (dtype == SJD_DTYPE_F16 && waves == 8) return g1_launch<SJD_DTYPE_F16, 8>(x, w_packed, out, M, N, K, KC, s);
+    return SJD_ERR_UNSUPPORTED;
 }

@@ -137,13 +137,13 @@ def pack_weight(weight, KC):
     return torch.cat(out).contiguous()
 
 
-def skinny_gemm(x, w_packed, N, K, KC):
+def skinny_gemm(x, w_packed, N, K, KC, waves=4):
     """x [M<=32, K] bf16/fp16 -> Partials([n_chunks, 32, N] fp32)."""
     M = x.shape[0]
     assert x.is_contiguous() and x.shape[1] == K and w_packed.numel() == N * K
     nc = (K + KC - 1) // KC
     out = torch.empty(nc, 32, N, dtype=torch.float32, device=x.device)
-    L.check(L.load().sjd_skinny_gemm(_ptr(x), _ptr(w_packed), _ptr(out), M, N, K, KC, _dtype_code(x.dtype), _stream()), "sjd_skinny_gemm")
+    L.check(L.load().sjd_skinny_gemm(_ptr(x), _ptr(w_packed), _ptr(out), M, N, K, KC, waves, _dtype_code(x.dtype), _stream()), "sjd_skinny_gemm")
     return Partials(out, nc, N)
 
 

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--copies", type=int, default=12)
     ap.add_argument("--only", default="")
     ap.add_argument("--kc", type=int, default=0)
+    ap.add_argument("--waves", type=int, default=4)
+    ap.add_argument("--no-blas", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = L.load()
@@ -52,7 +54,7 @@ def main():
 
         def g1(i):
             L.check(lib.sjd_skinny_gemm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % a.copies].data_ptr()),
-                                        ctypes.c_void_p(out.data_ptr()), 32, N, K, KC, 0,
+                                        ctypes.c_void_p(out.data_ptr()), 32, N, K, KC, a.waves, 0,
                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "g1")
 
         def blas(i):
@@ -64,7 +66,8 @@ def main():
         torch.cuda.synchronize()
         bytes_w = N * K * 2
         r = dict(shape=name, N=N, K=K, KC=KC, weight_MB=round(bytes_w / 1e6, 1))
-        for tag, f in (("g1", g1), ("hipblaslt", blas)):
+        r["waves"] = a.waves
+        for tag, f in ((("g1", g1),) if a.no_blas else (("g1", g1), ("hipblaslt", blas))):
             avg, med = timed(f, a.launches, lib)
             r[tag + "_us"] = round(avg * 1e3, 2)
             r[tag + "_TBps"] = round(bytes_w / 1e12 / (avg / 1e3), 3)

@@ -68,7 +68,7 @@ def load():
     lib.sjd_qknorm_rope_append.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp]
     lib.sjd_silu_mul.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
     lib.sjd_gemm_num_chunks.argtypes = [i32, i32]
-    lib.sjd_skinny_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.sjd_skinny_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_event_create.restype = vp
     lib.sjd_event_destroy.argtypes = [vp]
     lib.sjd_event_synchronize.argtypes = [vp]

@@ -325,8 +325,9 @@ class ChameleonBackbone(nn.Module):
         emb = torch.cat((freqs, freqs), dim=-1)
         return emb.cos().to(dtype)[:, :, None, :], emb.sin().to(dtype)[:, :, None, :]
 
-    # split-K chunk of each projection for the G1 weight-streaming kernel (every launch should give the 256 CUs >= ~1000 waves)
-    G1_KC = dict(qkv=1024, o=512, gate_up=2048, down=1024)
+    # G1 launch shape per projection: (split-K chunk, column tiles per workgroup, step-major packing) -- tuned on MI355X with
+    # tools/g1_bench.py so that every launch gives the 256 CUs ~1000+ balanced waves
+    G1_CFG = dict(qkv=(1024, 8, True), o=(256, 4, False), gate_up=(2048, 8, True), down=(1024, 4, False))
 
     def enable_fused(self, ops, gemm="torch"):
         """Switch to the fused HIP glue path (F1-F3): q|k|v and gate|up projections become single GEMMs whose weights are
@@ -349,10 +350,11 @@ class ChameleonBackbone(nn.Module):
                 m.gate_proj.weight.data, m.up_proj.weight.data = gu[:ni], gu[ni:]
                 self._fused.append((qkv, gu))
                 if gemm == "sjd":
-                    kc = self.G1_KC
-                    self._packed.append(dict(qkv=ops.pack_weight(qkv, kc["qkv"]), o=ops.pack_weight(a.o_proj.weight, kc["o"]),
-                                             gate_up=ops.pack_weight(gu, kc["gate_up"]),
-                                             down=ops.pack_weight(m.down_proj.weight, kc["down"])))
+                    c = self.G1_CFG
+                    self._packed.append(dict(qkv=ops.pack_weight(qkv, c["qkv"][0], c["qkv"][2]),
+                                             o=ops.pack_weight(a.o_proj.weight, c["o"][0], c["o"][2]),
+                                             gate_up=ops.pack_weight(gu, c["gate_up"][0], c["gate_up"][2]),
+                                             down=ops.pack_weight(m.down_proj.weight, c["down"][0], c["down"][2])))
         self._inv_freq32 = self.inv_freq.float().contiguous()
         return self
 
@@ -360,25 +362,26 @@ class ChameleonBackbone(nn.Module):
         """Window forward (B*n <= 32 rows) with the four per-layer projections on kernel G1; split-K partials flow straight
         into the consuming glue kernel (F2 / F1 / F3 / F1)."""
         ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
-        T, eps, kc = B * n, self.args.rms_norm_eps, self.G1_KC
+        T, eps, cfg = B * n, self.args.rms_norm_eps, self.G1_CFG
+        g1 = lambda x_, name, N_, K_: ops.skinny_gemm(x_, self._packed[li][name], N_, K_, cfg[name][0], cfg[name][1], cfg[name][2])
         H, Hkv, D, hid, inter = self.n_heads, self.n_kv_heads, self.head_dim, self.args.hidden_size, self.args.intermediate_size
         params = getattr(self.attn, "params", None)
         h = self.model.embed_tokens(tokens).view(T, -1).contiguous()
         pos = positions.reshape(T).contiguous()
         delta = None
         for li, layer in enumerate(self.model.layers):
-            a, pw = layer.self_attn, self._packed[li]
+            a = layer.self_attn
             x = ops.add_rmsnorm(h, delta, layer.input_layernorm.weight, eps)
-            qkv = ops.skinny_gemm(x, pw["qkv"], (H + 2 * Hkv) * D, hid, kc["qkv"])
+            qkv = g1(x, "qkv", (H + 2 * Hkv) * D, hid)
             qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
             q = ops.qknorm_rope_append(qkv, self.cache.k[li], self.cache.v[li], *qn, self._inv_freq32, pos, B, n, H, Hkv, D,
                                        params, kv_len if params is None else 0)
             o = self.attn.attend(li, q, self.cache, kv_len, key_start)
-            attn_out = ops.skinny_gemm(o.view(T, H * D), pw["o"], hid, H * D, kc["o"])
+            attn_out = g1(o.view(T, H * D), "o", hid, H * D)
             x = ops.add_rmsnorm(h, attn_out, layer.post_attention_layernorm.weight, eps)
-            gu = ops.skinny_gemm(x, pw["gate_up"], 2 * inter, hid, kc["gate_up"])
+            gu = g1(x, "gate_up", 2 * inter, hid)
             act = ops.silu_mul(gu, rows=T, dtype=h.dtype)
-            delta = ops.skinny_gemm(act, pw["down"], hid, inter, kc["down"])
+            delta = g1(act, "down", hid, inter)
         x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
         return self.lm_head(x).float().view(B, n, -1)
 

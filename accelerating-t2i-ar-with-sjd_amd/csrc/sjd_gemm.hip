@@ -38,7 +38,8 @@ template <> struct G1Mfma<SJD_DTYPE_F16> {
 // x: [M, K] row-major (M <= 32; missing rows read as zero).  wp: packed weights.  out: fp32 [n_chunks, 32, N].
 template <int DT, int G1_WAVES>
 __global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
-                                                                float *__restrict__ out, int M, int N, int K, int KC, int n_tiles)
+                                                                float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
+                                                                int rec_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *xl = reinterpret_cast<u32x4 *>(smem);
@@ -48,13 +49,19 @@ __global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned s
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int t = blockIdx.x * G1_WAVES + w;
     const bool has_tile = t < n_tiles;
-    // unit base in 16-byte records: all earlier chunks are full (KC/16 steps each)
-    const u32x4 *wu = wp + ((size_t)chunk * n_tiles * (KC / 16) + (size_t)(has_tile ? t : 0) * steps) * 64 + lane;
+    // record (chunk, s, t) in 1-KiB units: all earlier chunks are full (KC/16 steps each).
+    //   rec_stride == 1      : tile-major   -- a wave streams one contiguous run of `steps` KiB
+    //   rec_stride == n_tiles: step-major   -- at every k-step the whole grid row reads n_tiles contiguous KiB, i.e. the
+    //                                           chip sweeps the weight matrix like a linear copy (DRAM row locality)
+    const size_t chunk_base = (size_t)chunk * n_tiles * (KC / 16);
+    const size_t tile_off = (rec_stride == 1) ? (size_t)(has_tile ? t : 0) * steps : (size_t)(has_tile ? t : 0);
+    const u32x4 *wu = wp + (chunk_base + tile_off) * 64 + lane;
+    const size_t rs = (size_t)rec_stride * 64;
     u32x4 cur[G1_UNROLL], nxt[G1_UNROLL];
     const int full = steps / G1_UNROLL;
     if (has_tile && full > 0) {          // the weight stream does not depend on x: start it before staging the activations
 #pragma unroll
-        for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * 64);
+        for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);
     }
     // stage the activation chunk in A-fragment order: piece (s, l) = x[l&31][k0 + 16s + 8(l>>5) .. +7]
     for (int p = threadIdx.x; p < steps * 64; p += G1_WAVES * 64) {
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned s
         const bool more = g + 1 < full;
         if (more) {
 #pragma unroll
-            for (int u = 0; u < G1_UNROLL; ++u) nxt[u] = __builtin_nontemporal_load(wu + (size_t)((g + 1) * G1_UNROLL + u) * 64);
+            for (int u = 0; u < G1_UNROLL; ++u) nxt[u] = __builtin_nontemporal_load(wu + (size_t)((g + 1) * G1_UNROLL + u) * rs);
         }
 #pragma unroll
         for (int u = 0; u < G1_UNROLL; ++u) acc = G1Mfma<DT>::mma(xl[(g * G1_UNROLL + u) * 64 + lane], cur[u], acc);
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned s
         }
     }
     for (int s = full * G1_UNROLL; s < steps; ++s)      // ragged tail (K chunk not a multiple of 128)
-        acc = G1Mfma<DT>::mma(xl[s * 64 + lane], __builtin_nontemporal_load(wu + (size_t)s * 64), acc);
+        acc = G1Mfma<DT>::mma(xl[s * 64 + lane], __builtin_nontemporal_load(wu + (size_t)s * rs), acc);
 
     // D[m][n]: reg r of lane l -> row m = (r&3) + 8*(r>>2) + 4*(l>>5), column n = 32t + (l&31): 128-B coalesced rows
     float *o = out + ((size_t)chunk * 32) * N + (size_t)t * 32 + (lane & 31);
@@ -98,24 +105,26 @@ extern "C" int sjd_gemm_num_chunks(int K, int KC) { return (K + KC - 1) / KC; }
 
 // out: fp32 [n_chunks, 32, N] partial products; the consumer sums the chunks.
 template <int DT, int WAVES>
-static int g1_launch(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, hipStream_t s)
+static int g1_launch(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int step_major, hipStream_t s)
 {
     const int n_tiles = N / 32, n_chunks = (K + KC - 1) / KC;
     const dim3 grid((n_tiles + WAVES - 1) / WAVES, n_chunks), block(WAVES * 64);
     const size_t lds = (size_t)(KC / 16) * 64 * 16;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((g1_skinny_gemm<DT, WAVES>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles);
+    hipLaunchKernelGGL((g1_skinny_gemm<DT, WAVES>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles,
+                       step_major ? n_tiles : 1);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
-extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int dtype, void *stream)
+extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,
+                               int dtype, void *stream)
 {
     if (!x || !w_packed || !out || M < 1 || M > 32 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
     if ((size_t)KC * 64 > 160 * 1024) return SJD_ERR_BAD_ARG;       // activation chunk must fit in LDS (KC <= 2560)
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SJD_DTYPE_BF16 && waves == 4) return g1_launch<SJD_DTYPE_BF16, 4>(x, w_packed, out, M, N, K, KC, s);
-    if (dtype == SJD_DTYPE_BF16 && waves == 8) return g1_launch<SJD_DTYPE_BF16, 8>(x, w_packed, out, M, N, K, KC, s);
-    if (dtype == SJD_DTYPE_F16 && waves == 4) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, s);
-    if (dtype == SJD_DTYPE_F16 && waves == 8) return g1_launch<SJD_DTYPE_F16, 8>(x, w_packed, out, M, N, K, KC, s);
+    if (dtype == SJD_DTYPE_BF16 && waves == 4) return g1_launch<SJD_DTYPE_BF16, 4>(x, w_packed, out, M, N, K, KC, step_major, s);
+    if (dtype == SJD_DTYPE_BF16 && waves == 8) return g1_launch<SJD_DTYPE_BF16, 8>(x, w_packed, out, M, N, K, KC, step_major, s);
+    if (dtype == SJD_DTYPE_F16 && waves == 4) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, step_major, s);
+    if (dtype == SJD_DTYPE_F16 && waves == 8) return g1_launch<SJD_DTYPE_F16, 8>(x, w_packed, out, M, N, K, KC, step_major, s);
     return SJD_ERR_UNSUPPORTED;
 }

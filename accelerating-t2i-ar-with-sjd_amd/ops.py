@@ -123,7 +123,7 @@ class Partials:
         self.data, self.n_chunks, self.N = data, n_chunks, N
 
 
-def pack_weight(weight, KC):
+def pack_weight(weight, KC, step_major=False):
     """[N, K] linear weight -> MFMA 32x32x16 B-fragment-major stream for sjd_skinny_gemm: for every k-chunk c and
     32-column tile t a contiguous run of (chunk_k/16) 1-KiB records; record s, lane l, element j =
     W[32t + (l&31)][k0 + 16s + 8(l>>5) + j]."""
@@ -133,17 +133,20 @@ def pack_weight(weight, KC):
     for k0 in range(0, K, KC):
         kc = min(KC, K - k0)
         w = weight[:, k0:k0 + kc].reshape(N // 32, 32, kc // 16, 2, 8)      # [t, r, s, h, j]
-        out.append(w.permute(0, 2, 3, 1, 4).reshape(-1))                    # [t, s, h, r, j] ; lane = 32h + r
+        if step_major:
+            out.append(w.permute(2, 0, 3, 1, 4).reshape(-1))                # [s, t, h, r, j] : records of all tiles per k-step
+        else:
+            out.append(w.permute(0, 2, 3, 1, 4).reshape(-1))                # [t, s, h, r, j] ; lane = 32h + r
     return torch.cat(out).contiguous()
 
 
-def skinny_gemm(x, w_packed, N, K, KC, waves=4):
+def skinny_gemm(x, w_packed, N, K, KC, waves=4, step_major=False):
     """x [M<=32, K] bf16/fp16 -> Partials([n_chunks, 32, N] fp32)."""
     M = x.shape[0]
     assert x.is_contiguous() and x.shape[1] == K and w_packed.numel() == N * K
     nc = (K + KC - 1) // KC
     out = torch.empty(nc, 32, N, dtype=torch.float32, device=x.device)
-    L.check(L.load().sjd_skinny_gemm(_ptr(x), _ptr(w_packed), _ptr(out), M, N, K, KC, waves, _dtype_code(x.dtype), _stream()), "sjd_skinny_gemm")
+    L.check(L.load().sjd_skinny_gemm(_ptr(x), _ptr(w_packed), _ptr(out), M, N, K, KC, waves, int(step_major), _dtype_code(x.dtype), _stream()), "sjd_skinny_gemm")
     return Partials(out, nc, N)
 
 

@@ -106,13 +106,14 @@ def test_fused_forward_matches_unfused(dev):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,KC", [(32, 12288, 4096, 1024), (32, 4096, 4096, 512), (32, 22016, 4096, 2048),
                                         (32, 4096, 11008, 1024), (7, 256, 176, 64), (32, 64, 2048, 2048)])
-def test_g1_skinny_gemm(dev, dtype, M, N, K, KC):
+@pytest.mark.parametrize("waves,step_major", [(4, False), (8, True), (4, True)])
+def test_g1_skinny_gemm(dev, dtype, M, N, K, KC, waves, step_major):
     """G1 weight-streaming projection (split-K partials) against an fp32 matmul of the same bf16/fp16 operands."""
     import sjd_amd.ops as ops
     g = torch.Generator().manual_seed(N + K)
     x = torch.randn(M, K, generator=g).to(dtype).to(dev)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).to(dev)
-    part = ops.skinny_gemm(x, ops.pack_weight(w, KC), N, K, KC)
+    part = ops.skinny_gemm(x, ops.pack_weight(w, KC, step_major), N, K, KC, waves=waves, step_major=step_major)
     assert part.n_chunks == (K + KC - 1) // KC
     got = part.data.sum(0)[:M]
     ref = x.float() @ w.float().t()
@@ -159,7 +160,7 @@ def test_g1_forward_matches_library_gemm_forward(dev):
     outs = []
     for gemm in ("torch", "sjd"):
         m = make_chameleon(conf, 23, 0.5, ops.HipWindowAttention(n_split=2), dtype=torch.bfloat16, device=dev)
-        m.G1_KC = dict(qkv=256, o=128, gate_up=512, down=256)
+        m.G1_CFG = dict(qkv=(256, 8, True), o=(128, 4, False), gate_up=(512, 8, True), down=(256, 4, False))
         m.enable_fused(ops, gemm=gemm)
         m.setup_cache(batch=2, s_max=128)
         toks = torch.randint(4, 9000, (2, 40), generator=torch.Generator().manual_seed(1)).to(dev)

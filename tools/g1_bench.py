@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--kc", type=int, default=0)
     ap.add_argument("--waves", type=int, default=4)
     ap.add_argument("--no-blas", action="store_true")
+    ap.add_argument("--step-major", type=int, default=0)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = L.load()
@@ -48,13 +49,13 @@ def main():
         KC = a.kc or KC
         x = torch.randn(32, K, device=dev).to(torch.bfloat16)
         ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16) for _ in range(a.copies)]
-        wps = [ops.pack_weight(w, KC) for w in ws]
+        wps = [ops.pack_weight(w, KC, bool(a.step_major)) for w in ws]
         nc = (K + KC - 1) // KC
         out = torch.empty(nc, 32, N, dtype=torch.float32, device=dev)
 
         def g1(i):
             L.check(lib.sjd_skinny_gemm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % a.copies].data_ptr()),
-                                        ctypes.c_void_p(out.data_ptr()), 32, N, K, KC, a.waves, 0,
+                                        ctypes.c_void_p(out.data_ptr()), 32, N, K, KC, a.waves, a.step_major, 0,
                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "g1")
 
         def blas(i):
@@ -66,7 +67,7 @@ def main():
         torch.cuda.synchronize()
         bytes_w = N * K * 2
         r = dict(shape=name, N=N, K=K, KC=KC, weight_MB=round(bytes_w / 1e6, 1))
-        r["waves"] = a.waves
+        r["waves"], r["step_major"] = a.waves, a.step_major
         for tag, f in ((("g1", g1),) if a.no_blas else (("g1", g1), ("hipblaslt", blas))):
             avg, med = timed(f, a.launches, lib)
             r[tag + "_us"] = round(avg * 1e3, 2)

@@ -23,7 +23,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
+#ifndef G1_UNROLL
 #define G1_UNROLL 8
+#endif
 
 template <int DT> struct G1Mfma;
 template <> struct G1Mfma<SJD_DTYPE_BF16> {

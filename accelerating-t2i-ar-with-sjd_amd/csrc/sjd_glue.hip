@@ -86,8 +86,24 @@ __global__ __launch_bounds__(256) void f1_add_rmsnorm(unsigned short *__restrict
             if (part) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d[j] = 0.f;
-                for (int cc = 0; cc < n_chunks; ++cc) {
-                    const float4 *pp = reinterpret_cast<const float4 *>(part + ((size_t)cc * 32 + row) * hidden + c);
+                const size_t cstride = (size_t)32 * hidden;
+                const float *p0 = part + (size_t)row * hidden + c;
+                int cc = 0;
+                for (; cc + 4 <= n_chunks; cc += 4) {       // issue the loads of four chunks before any add (L2 latency overlap)
+                    float4 a[4], b[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 *pp = reinterpret_cast<const float4 *>(p0 + (size_t)(cc + q) * cstride);
+                        a[q] = pp[0]; b[q] = pp[1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        d[0] += a[q].x; d[1] += a[q].y; d[2] += a[q].z; d[3] += a[q].w;
+                        d[4] += b[q].x; d[5] += b[q].y; d[6] += b[q].z; d[7] += b[q].w;
+                    }
+                }
+                for (; cc < n_chunks; ++cc) {
+                    const float4 *pp = reinterpret_cast<const float4 *>(p0 + (size_t)cc * cstride);
                     const float4 a = pp[0], b = pp[1];
                     d[0] += a.x; d[1] += a.y; d[2] += a.z; d[3] += a.w; d[4] += b.x; d[5] += b.y; d[6] += b.z; d[7] += b.w;
                 }

@@ -104,6 +104,7 @@ class SJDEngine:
         self.hook = None                            # test hook: called with per-iteration device tensors
         self.use_graph = use_graph                  # capture the window step (K5 -> forward -> K2 -> K4) in hipGraphs
         self._guidance = 3.0
+        self.rng_stream = torch.cuda.Stream(device=dev)
         self.reset_graphs()
 
     def reset_graphs(self):
@@ -122,31 +123,51 @@ class SJDEngine:
             p.resid_rules[j] = r
         self.params.upload()
 
-    def _window_body(self, cur):
-        """The shape-static launch sequence of one window iteration: every dynamic scalar is read from device blobs."""
+    def _forward_body(self):
+        """Shape-static launch sequence, part 1: K5 + transformer forward (every dynamic scalar is read from device blobs)."""
         ops.reguess(self.params, self.state, self.input_ids)
         positions = self.kv_len_dev.to(torch.int64) + self.arange[None, :] + self.pos_offset[:, None]
-        logits = self.backbone.forward_window(self.input_ids, positions, -1, self.key_start)
+        return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start)
+
+    def _sample_body(self, cur, logits):
+        """part 2: K2 + K4 (needs the noise tensors, which are drawn on a side stream while part 1 runs)."""
         lu = logits[1] if self.B > 1 else None
         ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr)
         ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0], self.scratch)
-        return logits
 
-    def _run_window(self, cur):
+    def _run_window(self, cur, noise_ready):
+        """K5 -> forward -> [wait for the noise] -> K2 -> K4.  With use_graph the two parts are hipGraphs captured once (part 2
+        once per prob-buffer parity) and replayed."""
+        main = torch.cuda.current_stream()
         if not self.use_graph:
-            return self._window_body(cur)
-        key = (cur, self._guidance)
-        g = self._graphs.get(key)
-        if g is None:
-            if self._eager_runs.get(key, 0) < 1:    # one eager run per graph key warms up allocations / hipBLASLt
-                self._eager_runs[key] = 1
-                return self._window_body(cur)
+            logits = self._forward_body()
+            main.wait_event(noise_ready)
+            self._sample_body(cur, logits)
+            return logits
+        if "fwd" not in self._graphs:
+            if self._eager_runs.get("fwd", 0) < 1:   # one eager run warms up allocations / hipBLASLt before capture
+                self._eager_runs["fwd"] = 1
+                logits = self._forward_body()
+                main.wait_event(noise_ready)
+                self._sample_body(cur, logits)
+                return logits
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._graph_logits[key] = self._window_body(cur)
+                self._graph_logits["fwd"] = self._forward_body()
+            self._graphs["fwd"] = g
+        self._graphs["fwd"].replay()
+        logits = self._graph_logits["fwd"]
+        main.wait_event(noise_ready)
+        key = (cur, self._guidance)
+        if key not in self._graphs:
+            self._sample_body(cur, logits)           # eager warm-up of this parity, captured below for the next use
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._sample_body(cur, logits)
             self._graphs[key] = g
-        g.replay()
-        return self._graph_logits[key]
+            return logits
+        self._graphs[key].replay()
+        return logits
 
     @torch.no_grad()
     def decode(self, prompt: List[int], spec: WindowSpec, grammar, cfg: SJDConfig, warmup_iters=0, timed_iters=None,
@@ -210,15 +231,19 @@ class SJDEngine:
                 resid = grammar.residual_rules([X[-1]] + carried[:a] + fresh) if (scheme == 0 and n_rows > 1) else []
             use_cfg = do_cfg and not grammar.force_no_cfg()                          # JL:1086-1096
             self._fill_params(n_rows, kv_len, use_cfg, scheme, fresh, rules, resid)
-            # ---------------- noise, in the reference's order and shapes ----------------
+            # ---------------- noise, in the reference's order and shapes; drawn on a side stream so that the three fills
+            # overlap the transformer forward (they are only needed by K2 / K4) ----------------
             e1 = self.noise[:n_rows]
-            e1.exponential_(generator=gen)                                           # == torch.multinomial (JL:118)
             g_state = None
-            if n_rows > 1 and scheme == 0:
-                self.rs[:n_rows].uniform_(0.0, 1.0, generator=gen)                   # torch.rand([1,n,V]) (JL:260)
-                if gen is not None:
-                    g_state = gen.get_state()
-                self.noise2.exponential_(generator=gen)                              # residual multinomial (JL:237)
+            self.rng_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.rng_stream):
+                e1.exponential_(generator=gen)                                       # == torch.multinomial (JL:118)
+                if n_rows > 1 and scheme == 0:
+                    self.rs[:n_rows].uniform_(0.0, 1.0, generator=gen)               # torch.rand([1,n,V]) (JL:260)
+                    if gen is not None:
+                        g_state = gen.get_state()
+                    self.noise2.exponential_(generator=gen)                          # residual multinomial (JL:237)
+                noise_ready = self.rng_stream.record_event()
             # ---------------- device work ----------------
             stats.host_seconds += time.perf_counter() - t_host0
             if first:
@@ -229,13 +254,14 @@ class SJDEngine:
                 lc = logits[0, -1:, :]
                 lu = logits[1, -1:, :] if B > 1 else None
                 win_len = tokens.shape[1]
+                torch.cuda.current_stream().wait_event(noise_ready)
                 ops.logits_to_probs_sample(lc, lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr)
                 ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0],
                                   self.scratch)
                 if attn is not None and hasattr(attn, "params"):
                     attn.params = self.params                                        # windows: kv_len / n_rows from the blob
             else:
-                logits = self._run_window(cur)
+                logits = self._run_window(cur, noise_ready)
                 lc = logits[0, :n_rows]
                 lu = logits[1, :n_rows] if B > 1 else None
                 win_len = n_rows

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--step-major", type=int, default=0)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if os.environ.get("SJD_SO"):
+        L.SO_PATH = os.environ["SJD_SO"]
     lib = L.load()
     for name, (N, K, KC) in SHAPES.items():
         if a.only and name != a.only:

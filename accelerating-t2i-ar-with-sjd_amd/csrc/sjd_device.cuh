@@ -150,10 +150,18 @@ __device__ __forceinline__ void radix_pick(int k, SjdShared &sh, int &bin, int &
 
 // Row visitor: thread T walks columns 4T + 4096*k (+0..3), the canonical ownership.
 #define SJD_FOR_OWNED_COLS(V, c0)  for (int c0 = 4 * (int)threadIdx.x; c0 < (V); c0 += 4 * SJD_TPB)
+// Same ownership restricted to the column window [lo, hi): only the 4-column groups that intersect it are visited
+// (callers still test each column against the window / the rule).
+__device__ __forceinline__ int sjd_first_owned_group(int lo)
+{
+    const int g0 = lo >> 2;
+    return g0 + ((((int)threadIdx.x - g0) % SJD_TPB) + SJD_TPB) % SJD_TPB;
+}
+#define SJD_FOR_OWNED_COLS_IN(lo, hi, c0)  for (int c0 = 4 * sjd_first_owned_group(lo); c0 < (hi); c0 += 4 * SJD_TPB)
 
 // k-th largest float of row[0..V) restricted to entries with `row[c] > floor_excl` (finite filter);
 // requires 1 <= k <= count of such entries.
-__device__ float block_kth_largest(const float *row, int V, int k, float floor_excl, SjdShared &sh)
+__device__ float block_kth_largest(const float *row, int lo, int V, int k, float floor_excl, SjdShared &sh)
 {
     unsigned prefix = 0;
     int krem = k;
@@ -163,11 +171,11 @@ __device__ float block_kth_largest(const float *row, int V, int k, float floor_e
         for (int b = threadIdx.x; b < SJD_RADIX_BINS; b += SJD_TPB) sh.hist[b] = 0;
         __syncthreads();
         const int shift = shifts[pass];
-        SJD_FOR_OWNED_COLS(V, c0) {
+        SJD_FOR_OWNED_COLS_IN(lo, V, c0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int c = c0 + j;
-                if (c < V) {
+                if (c >= lo && c < V) {
                     float z = row[c];
                     if (z > floor_excl) {
                         unsigned key = f2key(z);

@@ -9,6 +9,18 @@
 #include "../../include/sjd_hip.h"
 #include "sjd_device.cuh"
 
+// smallest column window [lo, hi) containing every allowed column of the rule
+__device__ __forceinline__ void rule_window(const sjd_row_rule &r, int V, int &lo, int &hi)
+{
+    if (r.n_ranges == 0) { lo = 0; hi = V; return; }
+    lo = V; hi = 0;
+#pragma unroll
+    for (int a = 0; a < SJD_MAX_RANGES; ++a)
+        if (a < r.n_ranges) { lo = min(lo, r.lo[a]); hi = max(hi, r.hi[a]); }
+    lo = max(lo, 0); hi = min(hi, V);
+    if (hi < lo) hi = lo;
+}
+
 __device__ __forceinline__ bool rule_allows(const sjd_row_rule &r, int c)
 {
     if (r.n_ranges == 0) return true;
@@ -43,13 +55,21 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const float *c = logits_c + (size_t)row * row_stride;
     const float *u = (logits_u != nullptr && params->use_cfg) ? logits_u + (size_t)row * row_stride : nullptr;
     const bool vec = ((V & 3) == 0) && ((row_stride & 3) == 0);
+    // Only the window [wlo, whi) spanned by the rule's allowed ranges can hold probability mass (Lumina image rows: 8192 of
+    // 65536 columns); everything outside is written as 0 once and never read again.
+    int wlo, whi;
+    rule_window(rule, V, wlo, whi);
+    if (wlo > 0 || whi < V) {
+        SJD_FOR_OWNED_COLS(V, c0)
+            for (int j = 0; j < 4; ++j) { int col = c0 + j; if (col < V && (col < wlo || col >= whi)) p[col] = 0.0f; }
+    }
 
     // pass 1: CFG combine (JL:104) + grammar mask (LP:125-129); stage z; row max; finite count
     float tmax = -INFINITY;
     int cnt = 0;
-    SJD_FOR_OWNED_COLS(V, c0) {
+    SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
         float zc[4], zu[4];
-        if (vec) {
+        if (vec && c0 + 3 < V) {
             float4 a = *reinterpret_cast<const float4 *>(c + c0);
             zc[0] = a.x; zc[1] = a.y; zc[2] = a.z; zc[3] = a.w;
             if (u) { float4 b = *reinterpret_cast<const float4 *>(u + c0); zu[0] = b.x; zu[1] = b.y; zu[2] = b.z; zu[3] = b.w; }
@@ -59,7 +79,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int col = c0 + j;
-            if (col < V) {
+            if (col >= wlo && col < whi) {
                 float z = zc[j];
                 if (u) { float t = zc[j] - zu[j]; t = guidance * t; z = t + zu[j]; }
                 if (!rule_allows(rule, col)) z = -INFINITY;
@@ -75,7 +95,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
 
     // top-k (LP:196-204): keep z >= k-th largest; k-th is -inf when fewer than k finite entries exist
     float kth = -INFINITY;
-    if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_finite) kth = block_kth_largest(p, V, rule.top_k, -INFINITY, sh);
+    if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_finite) kth = block_kth_largest(p, wlo, whi, rule.top_k, -INFINITY, sh);
 
     if (rule.top_p_thr >= 0.0f) {   // TopPLogitsWarper3d with top_p < 1: not on the HIP path yet
         if (threadIdx.x == 0) tokens_out[row] = -1;
@@ -84,13 +104,13 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
 
     // pass A: e = exp(z - max) for kept entries, canonical sum
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    SJD_FOR_OWNED_COLS(V, c0) {
+    SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
         float ev[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int col = c0 + j;
             ev[j] = 0.0f;
-            if (col < V) {
+            if (col >= wlo && col < whi) {
                 float z = p[col];
                 ev[j] = (z < kth) ? 0.0f : sjd_expf(z - zmax);
                 p[col] = ev[j];
@@ -102,11 +122,11 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
 
     // pass B: p = e / S ; multinomial == lowest-index argmax of p / Exp(1)   (JL:111-118)
     unsigned long long best = 0ull;
-    SJD_FOR_OWNED_COLS(V, c0) {
+    SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int col = c0 + j;
-            if (col < V) {
+            if (col >= wlo && col < whi) {
                 float pv = p[col] / S;
                 p[col] = pv;
                 float r = pv / e[col];
@@ -172,12 +192,14 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
             const int qs = state->q_src[m];
             const float *prow = probs + (size_t)row * V;
             const float *qrow = (qs >= 0) ? prev_probs + (size_t)qs * V : nullptr;
+            int wlo, whi;
+            rule_window(rule, V, wlo, whi);
             int cnt = 0;
-            SJD_FOR_OWNED_COLS(V, c0) {
+            SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int col = c0 + j;
-                    if (col < V) {
+                    if (col >= wlo && col < whi) {
                         float qv = qrow ? qrow[col] : ((long)col == x ? 1.0f : 0.0f);
                         float d = prow[col] - qv;
                         d = d > 0.0f ? d : 0.0f;
@@ -190,18 +212,18 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
             const int n_pos = block_sum_int(cnt, sh);
             __syncthreads();
             float kth = 0.0f;
-            if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_pos) kth = block_kth_largest(scratch, V, rule.top_k, 0.0f, sh);
+            if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_pos) kth = block_kth_largest(scratch, wlo, whi, rule.top_k, 0.0f, sh);
             if (rule.top_p_thr >= 0.0f) {   // top-p < 1 in the residual: not on the HIP path yet
                 if (threadIdx.x == 0) { state->tokens[row] = -1; }
             } else {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                SJD_FOR_OWNED_COLS(V, c0) {
+                SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
                     float dv[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         int col = c0 + j;
                         dv[j] = 0.0f;
-                        if (col < V) {
+                        if (col >= wlo && col < whi) {
                             float d = scratch[col];
                             dv[j] = (d < kth) ? 0.0f : d;
                             scratch[col] = dv[j];
@@ -211,11 +233,11 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                 }
                 const float S = block_canonical_sum(a0, a1, a2, a3, sh);
                 unsigned long long best = 0ull;
-                SJD_FOR_OWNED_COLS(V, c0) {
+                SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         int col = c0 + j;
-                        if (col < V) {
+                        if (col >= wlo && col < whi) {
                             float r = (scratch[col] / S) / noise2[col];
                             unsigned long long cand = pack_vi(r, col);
                             best = cand > best ? cand : best;

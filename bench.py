@@ -93,6 +93,37 @@ def measure_k1(args, model, attn, device, kv_len):
     return dict(launches=len(ms), avg_ms=avg_ms, avg_bytes=alg, avg_kv_rows=kv_len + n, gbps=alg / 1e9 / (avg_ms / 1e3))
 
 
+def measure_g1(args, model, device, rounds=2):
+    """Dominant hand-written kernel by time: G1 (weight-streaming projections).  HIP events on the launch stream around every
+    launch of `rounds` full passes over the model's own packed weights (32 layers x {qkv, o, gate|up, down} = 13.0 GB per
+    pass, so every launch streams from HBM).  Algorithmic bytes per launch = the weight matrix (N*K*2) + the activations."""
+    import ctypes
+    import torch
+    import sjd_amd._lib as L
+    import sjd_amd.ops as ops
+    lib = L.load()
+    hip = ctypes.CDLL("libamdhip64.so")
+    H, Hkv, D, hid, inter = model.n_heads, model.n_kv_heads, model.head_dim, model.args.hidden_size, model.args.intermediate_size
+    shapes = dict(qkv=((H + 2 * Hkv) * D, hid), o=(hid, H * D), gate_up=(2 * inter, hid), down=(hid, inter))
+    xs = {k: torch.randn(32, K, device=device).to(torch.bfloat16) for k, (N, K) in shapes.items()}
+    cfg = model.G1_CFG
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    recs = []
+    for r in range(rounds + 1):
+        for li in range(len(model._packed)):
+            for name, (N, K) in shapes.items():
+                e0, e1 = ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())
+                hip.hipEventRecord(e0, stream)
+                ops.skinny_gemm(xs[name], model._packed[li][name], N, K, cfg[name][0], cfg[name][1], cfg[name][2])
+                hip.hipEventRecord(e1, stream)
+                if r > 0:
+                    recs.append((e0, e1, N * K * 2 + 32 * K * 2))
+    torch.cuda.synchronize()
+    tot_ms = sum(lib.sjd_event_elapsed_ms(e0, e1) for e0, e1, _ in recs)
+    tot_b = sum(b for _, _, b in recs)
+    return dict(launches=len(recs), avg_ms=tot_ms / len(recs), avg_bytes=tot_b / len(recs), gbps=tot_b / 1e9 / (tot_ms / 1e3))
+
+
 def cpu_baseline(args, tokens_per_step):
     """The reference's scheduler step (logits->probs->sample + verify/accept) as restated by the CPU oracle, timed on
     this host (1 core, scalar C), on a bounded sample of the same workload: V=65536, L=16, CFG, image top-k 2000."""
@@ -175,6 +206,7 @@ def main():
     seq, stats = eng.decode(prompt, spec, LuminaGrammar(2000, 10), cfg, warmup_iters=args.warmup, timed_iters=args.steps,
                             on_timed_start=timed_start, on_timed_end=timed_end)
     prof = measure_k1(args, model, attn, device, kv_len=(kv_at.get("start", P) + stats.kv_len) // 2)
+    prof_g1 = measure_g1(args, model, device) if (args.gemm == "sjd" and not args.no_fused) else None
     rep = gather_report(stats.tokens, stats.timed_nfe, stats.seconds, device)   # one RCCL all_gather (24 B/rank)
     if rank != 0:
         if world > 1:
@@ -200,19 +232,31 @@ def main():
                    "prompt_len": P, "image_tokens": n_img, "kv_len_end": stats.kv_len, "prompts": world,
                    "parallelism": f"prompt-parallel x{world}"},
     }
-    if prof is not None:
-        peak = 8000.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+    def traffic_of(fname):
+        tpath = os.path.join(ROOT, "profiles", fname)
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                return json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
-        out["roofline"] = {"kernel": "k1_partial (draft-window attention)", "bound": "hbm", "achieved": round(prof["gbps"], 1),
-                           "peak": peak, "unit": "GB/s", "frac": round(prof["gbps"] / peak, 4), "traffic": traffic,
-                           "avg_us": round(prof["avg_ms"] * 1e3, 2), "avg_bytes": int(prof["avg_bytes"]),
-                           "avg_kv_rows": round(prof["avg_kv_rows"], 1), "launches": prof["launches"]}
+                return None
+        return None
+
+    peak = 8000.0
+    k1_block = None
+    if prof is not None:
+        k1_block = {"kernel": "k1_partial (draft-window attention)", "bound": "hbm", "achieved": round(prof["gbps"], 1),
+                    "peak": peak, "unit": "GB/s", "frac": round(prof["gbps"] / peak, 4), "traffic": traffic_of("k1_traffic.json"),
+                    "avg_us": round(prof["avg_ms"] * 1e3, 2), "avg_bytes": int(prof["avg_bytes"]),
+                    "avg_kv_rows": round(prof["avg_kv_rows"], 1), "launches": prof["launches"]}
+    if prof_g1 is not None:       # the dominant kernel by time (~60 % of an iteration)
+        out["roofline"] = {"kernel": "g1_skinny_gemm (weight-streaming window projections, 128 launches / iteration)", "bound": "hbm",
+                           "achieved": round(prof_g1["gbps"], 1), "peak": peak, "unit": "GB/s", "frac": round(prof_g1["gbps"] / peak, 4),
+                           "traffic": traffic_of("g1_traffic.json"), "avg_us": round(prof_g1["avg_ms"] * 1e3, 2),
+                           "avg_bytes": int(prof_g1["avg_bytes"]), "launches": prof_g1["launches"]}
+        if k1_block is not None:
+            out["roofline_k1"] = k1_block
+    elif k1_block is not None:
+        out["roofline"] = k1_block
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, tok_per_step)
     print(json.dumps(out), flush=True)

@@ -191,3 +191,62 @@ __device__ float block_kth_largest(const float *row, int lo, int V, int k, float
     }
     return key2f(prefix);
 }
+
+// ---- top-p cut (order-independent restatement of TopPLogitsWarper3d, see oracle/sjd_oracle.c header) ---------------------
+// w[lo..hi): non-negative weights staged in global memory (e = exp(z - max) or the residual d); p_i = w_i / S.
+// Returns K* = the largest uint32 key with canonical_sum{ p_i : w_i > 0, key(w_i) <= K* } <= thr (32 canonical sums).
+__device__ unsigned block_top_p_cut_key(const float *w, int lo, int hi, float S, float thr, SjdShared &sh)
+{
+    unsigned K = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = K | (1u << bit);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        SJD_FOR_OWNED_COLS_IN(lo, hi, c0) {
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                t[j] = 0.0f;
+                if (c >= lo && c < hi) {
+                    const float x = w[c];
+                    if (x > 0.0f && f2key(x) <= cand) t[j] = x / S;
+                }
+            }
+            a0 = a0 + t[0]; a1 = a1 + t[1]; a2 = a2 + t[2]; a3 = a3 + t[3];
+        }
+        const float T = block_canonical_sum(a0, a1, a2, a3, sh);
+        if (T <= thr) K = cand;
+    }
+    return K;
+}
+
+// applies the cut in place (w_i = 0 for removed entries; the lowest-index maximum is always kept) and returns the new sum
+__device__ float block_top_p_apply(float *w, int lo, int hi, float S, float thr, SjdShared &sh)
+{
+    unsigned long long best = 0ull;
+    SJD_FOR_OWNED_COLS_IN(lo, hi, c0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            if (c >= lo && c < hi) { unsigned long long cand = pack_vi(w[c], c); best = cand > best ? cand : best; }
+        }
+    }
+    const int imax = block_argmax(best, sh);
+    const unsigned K = block_top_p_cut_key(w, lo, hi, S, thr, sh);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    SJD_FOR_OWNED_COLS_IN(lo, hi, c0) {
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            t[j] = 0.0f;
+            if (c >= lo && c < hi) {
+                float x = w[c];
+                if (c != imax && x > 0.0f && f2key(x) <= K) { x = 0.0f; w[c] = 0.0f; }
+                t[j] = x;
+            }
+        }
+        a0 = a0 + t[0]; a1 = a1 + t[1]; a2 = a2 + t[2]; a3 = a3 + t[3];
+    }
+    return block_canonical_sum(a0, a1, a2, a3, sh);
+}

@@ -97,11 +97,6 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     float kth = -INFINITY;
     if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_finite) kth = block_kth_largest(p, wlo, whi, rule.top_k, -INFINITY, sh);
 
-    if (rule.top_p_thr >= 0.0f) {   // TopPLogitsWarper3d with top_p < 1: not on the HIP path yet
-        if (threadIdx.x == 0) tokens_out[row] = -1;
-        return;
-    }
-
     // pass A: e = exp(z - max) for kept entries, canonical sum
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
@@ -118,7 +113,8 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
         }
         a0 = a0 + ev[0]; a1 = a1 + ev[1]; a2 = a2 + ev[2]; a3 = a3 + ev[3];
     }
-    const float S = block_canonical_sum(a0, a1, a2, a3, sh);
+    float S = block_canonical_sum(a0, a1, a2, a3, sh);
+    if (rule.top_p_thr >= 0.0f) S = block_top_p_apply(p, wlo, whi, S, rule.top_p_thr, sh);     // TopPLogitsWarper3d (LP:406-419)
 
     // pass B: p = e / S ; multinomial == lowest-index argmax of p / Exp(1)   (JL:111-118)
     unsigned long long best = 0ull;
@@ -213,9 +209,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
             __syncthreads();
             float kth = 0.0f;
             if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_pos) kth = block_kth_largest(scratch, wlo, whi, rule.top_k, 0.0f, sh);
-            if (rule.top_p_thr >= 0.0f) {   // top-p < 1 in the residual: not on the HIP path yet
-                if (threadIdx.x == 0) { state->tokens[row] = -1; }
-            } else {
+            {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
                     float dv[4];
@@ -231,7 +225,8 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                     }
                     a0 = a0 + dv[0]; a1 = a1 + dv[1]; a2 = a2 + dv[2]; a3 = a3 + dv[3];
                 }
-                const float S = block_canonical_sum(a0, a1, a2, a3, sh);
+                float S = block_canonical_sum(a0, a1, a2, a3, sh);
+                if (rule.top_p_thr >= 0.0f) S = block_top_p_apply(scratch, wlo, whi, S, rule.top_p_thr, sh);
                 unsigned long long best = 0ull;
                 SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
 #pragma unroll

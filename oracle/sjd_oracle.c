@@ -27,6 +27,11 @@
  *            64-lane xor-butterfly (offsets 32,16,8,4,2,1) inside each of the 16 waves,
  *            then the 16 wave totals are added in wave order;
  *   - p = e / S (IEEE division);  token = lowest-index argmax of p / noise;
+ *   - top-p: the reference removes the ascending-sorted prefix whose cumulative probability is <= 1 - top_p.  Restated
+ *     order-independently: with T(key) = canonical_sum{ p_i : key_i <= key } (key = the usual monotone uint32 image of
+ *     the float weight e_i = exp(z_i - max), resp. d_i), K* = the largest 32-bit key with T(K*) <= thr (bitwise descent, 32 sums) and every entry with
+ *     key <= K* except the row maximum is removed.  Identical to the reference except for exact value ties at the
+ *     cut and ~1e-7 relative differences of the fp32 cumulative sums (reference: double running sum);
  *   - residual resample uses r = d / sum(d), d = max(p - q, 0), which equals the reference's
  *     softmax(log d) in real arithmetic (reference :203-207,232).
  */
@@ -114,13 +119,23 @@ static int col_allowed(const sjd_row_rule *r, int i)
     return 0;
 }
 
-typedef struct { float v; int32_t i; } vi_pair;
-static int cmp_vi_asc(const void *a, const void *b)
+static uint32_t f2key(float z)
 {
-    const vi_pair *x = a, *y = b;
-    if (x->v < y->v) return -1;
-    if (x->v > y->v) return 1;
-    return (x->i > y->i) - (x->i < y->i);
+    union { float f; uint32_t u; } c;
+    c.f = z;
+    return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+}
+
+/* top-p cut on non-negative weights w (p_i = w_i / S): returns the key K* described in the header */
+static uint32_t top_p_cut_key(const float *keyval, const float *w, float S, int V, float thr, float *scratch)
+{
+    uint32_t K = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        uint32_t cand = K | (1u << bit);
+        for (int i = 0; i < V; ++i) scratch[i] = (w[i] > 0.0f && f2key(keyval[i]) <= cand) ? w[i] / S : 0.0f;
+        if (sjd_canonical_sum(scratch, V) <= thr) K = cand;
+    }
+    return K;
 }
 
 /* grammar + top-k + top-p on one row of (already CFG-combined) scores z, in place (-inf = removed) */
@@ -139,18 +154,15 @@ static void apply_rule(float *z, int V, const sjd_row_rule *r, float *scratch)
     if (r->top_p_thr >= 0.0f) {                            /* LP:406-419 */
         float m = -INFINITY;
         for (int i = 0; i < V; ++i) if (z[i] > m) m = z[i];
-        for (int i = 0; i < V; ++i) scratch[i] = sjd_expf(z[i] - m);
-        float S = sjd_canonical_sum(scratch, V);
-        vi_pair *pairs = (vi_pair *)malloc((size_t)V * sizeof(vi_pair));
-        for (int i = 0; i < V; ++i) { pairs[i].v = z[i]; pairs[i].i = i; }
-        qsort(pairs, (size_t)V, sizeof(vi_pair), cmp_vi_asc);
-        float thr = r->top_p_thr;
-        double cum = 0.0;                                  /* torch CPU cumsum accumulates float in double */
-        for (int j = 0; j < V - 1; ++j) {                  /* the last (largest) is always kept: min_tokens_to_keep=1 */
-            cum += (double)(scratch[pairs[j].i] / S);
-            if ((float)cum <= thr) z[pairs[j].i] = -INFINITY;
-        }
-        free(pairs);
+        float *e = (float *)malloc((size_t)V * sizeof(float));
+        for (int i = 0; i < V; ++i) e[i] = sjd_expf(z[i] - m);
+        float S = sjd_canonical_sum(e, V);
+        float em = 0.0f;                                  /* the cut is keyed on the weights e (monotone in z) */
+        int imax = 0;
+        for (int i = 0; i < V; ++i) if (e[i] > em) { em = e[i]; imax = i; }
+        uint32_t K = top_p_cut_key(e, e, S, V, r->top_p_thr, scratch);
+        for (int i = 0; i < V; ++i) if (i != imax && e[i] > 0.0f && f2key(e[i]) <= K) z[i] = -INFINITY;
+        free(e);
     }
 }
 
@@ -251,18 +263,11 @@ int sjd_o_verify_accept(int n, int V, const int64_t *win_tok, int64_t *tokens, c
             }
             float S = sjd_canonical_sum(d, V);
             if (r->top_p_thr >= 0.0f) {                     /* top-p on softmax(log d) = d/S, LP:406-419 */
-                vi_pair *pairs = (vi_pair *)malloc((size_t)V * sizeof(vi_pair));
-                for (int c = 0; c < V; ++c) { pairs[c].v = d[c]; pairs[c].i = c; }
-                qsort(pairs, (size_t)V, sizeof(vi_pair), cmp_vi_asc);
-                float thr = r->top_p_thr;
-                double cum = 0.0;
-                for (int j = 0; j < V - 1; ++j) {
-                    cum += (double)(d[pairs[j].i] / S);
-                    if ((float)cum <= thr) scratch[pairs[j].i] = -1.0f; else scratch[pairs[j].i] = 0.0f;
-                }
-                scratch[pairs[V - 1].i] = 0.0f;
-                for (int c = 0; c < V; ++c) if (scratch[c] < 0.0f) d[c] = 0.0f;
-                free(pairs);
+                float dm = 0.0f;
+                int imax = 0;
+                for (int c = 0; c < V; ++c) if (d[c] > dm) { dm = d[c]; imax = c; }
+                uint32_t K = top_p_cut_key(d, d, S, V, r->top_p_thr, scratch);
+                for (int c = 0; c < V; ++c) if (c != imax && f2key(d[c]) <= K) d[c] = 0.0f;
                 S = sjd_canonical_sum(d, V);
             }
             for (int c = 0; c < V; ++c) scratch[c] = d[c] / S;

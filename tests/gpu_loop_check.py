@@ -59,7 +59,7 @@ def _loop_cfg(c):
 @torch.no_grad()
 def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7, scheme="speculative_jacobi",
                                   embed_token_scale=0.25, top_k=1000, cfg_scale=4.0, dtype=torch.bfloat16,
-                                  use_graph=False):
+                                  use_graph=False, top_p=1.0):
     import sjd_amd.ops as ops
     from sjd_amd.engine import SJDEngine, SJDConfig, WindowSpec
     from sjd_amd.grammar import TopKTopPGrammar
@@ -74,7 +74,7 @@ def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7,
     zeros = torch.zeros(2, dtype=torch.int32, device=device)
     logits = model.forward_embeds(model.embed_condition(cond), torch.zeros(2, 1, dtype=torch.long, device=device), 0, zeros)
     torch.manual_seed(seed)
-    first = int(llamagen_prefill_sample(logits.float().cpu(), cfg_scale, 1.0, top_k, 1.0)[0, 0])
+    first = int(llamagen_prefill_sample(logits.float().cpu(), cfg_scale, 1.0, top_k, top_p)[0, 0])
     cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=N - window - 2, max_num_new_tokens=window,
                     guidance_scale=cfg_scale, seed=seed, prefix_token_sampler_scheme=scheme, max_length=N)
     spec = WindowSpec(first_tokens=torch.tensor([[first], [first]], device=device),
@@ -83,8 +83,8 @@ def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7,
     eng = SJDEngine(model, 16384, device, max_window=window, use_graph=use_graph)
     rec = _Recorder()
     eng.hook = rec
-    seq, stats = eng.decode([first], spec, TopKTopPGrammar(top_k, 1.0), cfg)
-    seq_ref, tr, checks = _replay(rec, [first], lambda c, n: O.llamagen_rules(c, n, top_k, 1.0), _loop_cfg(cfg), 16384,
+    seq, stats = eng.decode([first], spec, TopKTopPGrammar(top_k, top_p), cfg)
+    seq_ref, tr, checks = _replay(rec, [first], lambda c, n: O.llamagen_rules(c, n, top_k, top_p), _loop_cfg(cfg), 16384,
                                   device=device)
     assert seq == seq_ref, "token sequences differ"
     assert stats.matched == tr.matched and stats.nfe == len(tr.matched)

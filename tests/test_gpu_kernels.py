@@ -66,6 +66,9 @@ K2_CASES = [
     ("emu3_odd_vocab", 184622, 8, lambda n: O.emu3_rules([5, 6, 151851] + [151854 + 7] * 88, n, 90, 90, 151854, 32768,
                                                          151851, 151853, 151850, 151846, 151847, 151643, 2048)),
     ("tiny_vocab", 1000, 2, lambda n: O.llamagen_rules([], n, 10, 1.0)),
+    ("llamagen_top_p_0.9", 16384, 16, lambda n: O.llamagen_rules([], n, 1000, 0.9)),
+    ("llamagen_top_p_only", 16384, 4, lambda n: O.llamagen_rules([], n, 0, 0.5)),
+    ("lumina_range_top_p", 65536, 4, lambda n: [O.rule(((4, 8196),), -1, 2000, 0.95) for _ in range(n)]),
 ]
 
 
@@ -129,7 +132,8 @@ def run_k4(dev, win, Y, p, q_rows, rs, resid, e2, scheme=0, max_rows=16):
 
 @pytest.mark.parametrize("mode,L,grammar", [("carried", 16, None), ("mixed", 16, None), ("fresh", 16, None),
                                             ("far", 16, None), ("equal", 8, None), ("mixed", 16, "lumina"),
-                                            ("fresh", 2, None), ("mixed", 16, "llamagen"), ("mixed", 32, None)])
+                                            ("fresh", 2, None), ("mixed", 16, "llamagen"), ("mixed", 32, None),
+                                            ("mixed", 16, "llamagen_topp"), ("far", 16, "llamagen_topp")])
 @pytest.mark.parametrize("V", [9216, 65536])
 def test_k4_bit_exact(dev, mode, L, grammar, V):
     seed = 9000 + L + len(mode)
@@ -144,6 +148,8 @@ def test_k4_bit_exact(dev, mode, L, grammar, V):
         rfn = lambda c: O.lumina_rules(c, 1, 2000, 10)[0]
     elif grammar == "llamagen":
         rfn = lambda c: O.llamagen_rules(c, 1, 100, 1.0)[0]
+    elif grammar == "llamagen_topp":
+        rfn = lambda c: O.llamagen_rules(c, 1, 200, 0.8)[0]
     else:
         rfn = lambda c: O.rule()
     resid = [rfn(ctx + win[1:i]) for i in range(1, L)]

@@ -44,3 +44,9 @@ def test_emu3_loop(window, use_graph):
     assert gen[(W + 1) * H:(W + 1) * H + 3] == [t["eof_token"], t["eoi_token"], t["eos_token"]]
     assert all(3000 <= x < 3000 + 8192 for i, x in enumerate(gen[:(W + 1) * H]) if i not in eols)
     assert s["nfe"] < s["tokens"]
+
+
+def test_llamagen_loop_top_p():
+    """TopPLogitsWarper3d with top_p < 1 on the HIP path (K2 and the K4 residual)."""
+    s = G.teacher_forced_llamagen_check(latent=8, window=16, seed=5, embed_token_scale=0.25, top_p=0.95, use_graph=True)
+    assert s["tokens"] == 63 and s["nfe"] < 63

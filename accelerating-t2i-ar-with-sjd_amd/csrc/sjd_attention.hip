@@ -156,18 +156,21 @@ __global__ __launch_bounds__(256) void k1_partial(
             vd[i] = *reinterpret_cast<const u32x4 *>(vt + (size_t)(idx / LPR) * D + 8 * (idx % LPR));
         }
     };
-    auto store_v = [&](u32x4 (&vd)[VP]) {
+    // V rows of keys >= total are never visible (p = 0) but 0 * NaN = NaN inside the MFMA: rows beyond the valid cache length
+    // (padding rows of a shape-static window, stale data) are therefore zeroed while staging.
+    auto store_v = [&](int t, u32x4 (&vd)[VP]) {
 #pragma unroll
         for (int i = 0; i < VP; ++i) {
             int idx = i * 64 + lane;
-            *reinterpret_cast<u32x4 *>(vl + (idx / LPR) * VROW + 8 * (idx % LPR)) = vd[i];
+            const bool live = (t * K1_KT + idx / LPR) < total;
+            *reinterpret_cast<u32x4 *>(vl + (idx / LPR) * VROW + 8 * (idx % LPR)) = live ? vd[i] : u32x4{0u, 0u, 0u, 0u};
         }
     };
 
     int t = t_begin + kpart;
     if (t < t_end) {
         load_tile(t, kreg, vstage);
-        store_v(vstage);
+        store_v(t, vstage);
     }
     for (; t < t_end; t += kparts) {
         const int tn = t + kparts;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void k1_partial(
             o_acc[db] = Frag<DT>::mfma(as_frag<vec>(vv), pfrag, acc);
         }
         if (has_next) {
-            store_v(vstage);
+            store_v(tn, vstage);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -283,7 +286,13 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
     constexpr int PER = K1_ROWS * D / 256;          // consecutive d per thread
     const int row = (threadIdx.x * PER) / D, d0 = (threadIdx.x * PER) % D;
     const int grow = chunk * K1_ROWS + row;
-    if (grow >= n_total) return;
+    if (grow >= n_rows) return;
+    if (grow >= n_total) {        // padding rows of a shape-static window: defined (zero) output, never garbage
+        unsigned short *oz = out + (((size_t)b * n_rows + grow) * H + head) * D + d0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) oz[j] = 0;
+        return;
+    }
     const size_t base = (((size_t)b * H + head) * n_chunks + chunk) * n_split;
     float M = -INFINITY;
     for (int s = 0; s < eff_split; ++s) M = fmaxf(M, ws_ml[((base + s) * K1_ROWS + row) * 2]);

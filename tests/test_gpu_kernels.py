@@ -271,3 +271,28 @@ def test_k1_device_side_kv_len(dev):
         torch.cuda.synchronize()
         err = (out[:, :n].float().cpu() - ref).abs()
         assert err.max() < 3e-2 and err.mean() < 3e-3
+
+
+def test_k1_ignores_nan_beyond_the_valid_cache_length(dev):
+    """Cache rows >= kv_len + n (padding rows of a shape-static window, stale data) may hold anything, incl. NaN."""
+    ops, L = _ops()
+    B, H, D, S_max, kv_len, n = 2, 4, 128, 256, 70, 9
+    g = torch.Generator().manual_seed(2)
+    kc = torch.randn(1, B, H, S_max, D, generator=g).to(torch.bfloat16)
+    vc = torch.randn(1, B, H, S_max, D, generator=g).to(torch.bfloat16)
+    q = torch.randn(B, 16, H, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, 16, H, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, 16, H, D, generator=g).to(torch.bfloat16)
+    k[:, n:], v[:, n:] = float("nan"), float("nan")           # what the padding rows of the window may append
+    kc[..., kv_len + 16:, :], vc[..., kv_len + 16:, :] = float("nan"), float("inf")
+    ref_cache = _Cache(kc.clone(), vc.clone())
+    ref = OracleWindowAttention()(0, q[:, :n], k[:, :n], v[:, :n], ref_cache, kv_len, [0, 3]).float()
+    attn = ops.HipWindowAttention(n_split=4)
+    attn.params = ops.DeviceBlob(L.IterParams, dev)
+    attn.params.view.kv_len, attn.params.view.n_rows = kv_len, n
+    attn.params.upload()
+    dcache = _Cache(kc.clone().to(dev), vc.clone().to(dev))
+    out = attn(0, q.to(dev), k.to(dev), v.to(dev), dcache, -1, [0, 3]).float().cpu()
+    assert torch.isfinite(out).all()
+    assert (out[:, n:] == 0).all()
+    assert (out[:, :n] - ref).abs().max() < 3e-2

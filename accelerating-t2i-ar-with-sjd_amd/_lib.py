@@ -8,7 +8,7 @@ import os
 
 MAX_WINDOW = 32
 MAX_RANGES = 4
-DTYPE_BF16, DTYPE_F16 = 0, 1
+DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libsjd_hip.so")

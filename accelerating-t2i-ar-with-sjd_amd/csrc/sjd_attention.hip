@@ -313,6 +313,46 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
     for (int j = 0; j < PER; ++j) o[j] = Frag<DT>::cvt(acc[j] * inv);
 }
 
+// ------------------------------------------------------------------------------------------------ K1 (fp32)
+// Exact-fp32 variant for small parity runs (reproducing the reference's fp32 CPU token sequences on the GPU): one wave64 per
+// (batch, head, query row), two passes over the visible keys, fp32 FMA dot products.  Same visibility rule as k1_partial.
+__global__ __launch_bounds__(64) void k1_f32(const float *__restrict__ q, const float *__restrict__ kc, const float *__restrict__ vc,
+                                             float *__restrict__ out, int n_rows, int H, int H_kv, int D, int S_max,
+                                             const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg)
+{
+    extern __shared__ float sc[];                     // scores of the visible keys
+    const int row = blockIdx.x, head = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int kv_len = params ? params->kv_len : kv_len_arg;
+    const int n_total = params ? params->n_rows : n_rows;
+    float *o = out + (((size_t)b * n_rows + row) * H + head) * D;
+    if (row >= n_total) { for (int d = lane; d < D; d += 64) o[d] = 0.0f; return; }
+    const int hkv = head / (H / H_kv);
+    const int kstart = key_start ? key_start[b] : 0, kend = kv_len + row + 1;       // visible keys [kstart, kend)
+    const float *qr = q + (((size_t)b * n_rows + row) * H + head) * D;
+    const float *kb = kc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
+    const float *vb = vc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
+    const float scale = 1.0f / sqrtf((float)D);
+    float mx = -INFINITY;
+    for (int j = kstart + lane; j < kend; j += 64) {
+        float s = 0.0f;
+        for (int d = 0; d < D; ++d) s = fmaf(qr[d], kb[(size_t)j * D + d], s);
+        s *= scale;
+        sc[j - kstart] = s;
+        mx = fmaxf(mx, s);
+    }
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.0f;
+    for (int j = kstart + lane; j < kend; j += 64) { float e = expf(sc[j - kstart] - mx); sc[j - kstart] = e; sum += e; }
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    __syncthreads();
+    const float inv = (kend > kstart && sum > 0.0f) ? 1.0f / sum : 0.0f;
+    for (int d = lane; d < D; d += 64) {
+        float acc = 0.0f;
+        for (int j = kstart; j < kend; ++j) acc = fmaf(sc[j - kstart], vb[(size_t)j * D + d], acc);
+        o[d] = acc * inv;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K3
 __global__ void k3_kv_append(const u32x4 *__restrict__ k_new, const u32x4 *__restrict__ v_new, u32x4 *__restrict__ k_cache,
                              u32x4 *__restrict__ v_cache, int B, int n_rows, int H_kv, int D8, int S_max,
@@ -336,8 +376,8 @@ __global__ void k3_kv_append(const u32x4 *__restrict__ k_new, const u32x4 *__res
 extern "C" int sjd_kv_append(const void *k_new, const void *v_new, void *k_cache, void *v_cache, int B, int n_rows, int H_kv, int D,
                              int S_max, int dtype, const sjd_iter_params *params, int kv_len, void *stream)
 {
-    (void)dtype;
     if (!k_new || !v_new || !k_cache || !v_cache || B < 1 || n_rows < 1 || H_kv < 1 || (D % 8) != 0 || S_max < 1) return SJD_ERR_BAD_ARG;
+    if (dtype == SJD_DTYPE_F32) D *= 2;              // rows are copied as 16-byte pieces: an fp32 row is 2x as many
     const size_t total = (size_t)B * n_rows * H_kv * (D / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -378,6 +418,12 @@ extern "C" int sjd_draft_window_attention_ex(const void *q, const void *k_cache,
 {
     if (!q || !k_cache || !v_cache || !out || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
     if (H % H_kv != 0 || (S_max % K1_KT) != 0) return SJD_ERR_BAD_ARG;
+    if (dtype == SJD_DTYPE_F32) {
+        if ((size_t)S_max * sizeof(float) > 160 * 1024) return SJD_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(k1_f32, dim3(n_rows, H, B), dim3(64), (size_t)S_max * sizeof(float), (hipStream_t)stream, (const float *)q,
+                           (const float *)k_cache, (const float *)v_cache, (float *)out, n_rows, H, H_kv, D, S_max, key_start, params, kv_len);
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+    }
     const int G = H / H_kv;
     if (!(G == 1 || G == 2 || G == 4)) return SJD_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;

@@ -46,6 +46,8 @@ class SJDConfig:
     img_vocab_n: int = 8192
     max_length: int = 1 << 30
     eos_token_ids: tuple = ()
+    noise_device: Optional[str] = None   # None: the engine's device (what the reference does on a GPU);  "cpu": draw the noise
+    #                                      from a CPU generator and upload it -- replays the reference's CPU run bit-exactly
 
 
 @dataclass
@@ -190,7 +192,8 @@ class SJDEngine:
         gen = None
         if cfg.seed is not None:                                                   # JL:1021-1023
             set_seed(cfg.seed)
-            gen = torch.Generator(dev).manual_seed(cfg.seed)
+            gen = torch.Generator(cfg.noise_device or dev).manual_seed(cfg.seed)
+        host_noise = cfg.noise_device is not None and torch.device(cfg.noise_device).type == "cpu"
         l_abs, r_abs = P + cfg.jacobi_loop_interval_l, P + cfg.jacobi_loop_interval_r   # JL:1025
         W = cfg.max_num_new_tokens
         grammar.start(X)
@@ -237,12 +240,19 @@ class SJDEngine:
             g_state = None
             self.rng_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.rng_stream):
-                e1.exponential_(generator=gen)                                       # == torch.multinomial (JL:118)
-                if n_rows > 1 and scheme == 0:
-                    self.rs[:n_rows].uniform_(0.0, 1.0, generator=gen)               # torch.rand([1,n,V]) (JL:260)
-                    if gen is not None:
+                if host_noise:                                                       # parity mode: CPU stream of the reference
+                    e1.copy_(torch.empty(n_rows, self.V).exponential_(generator=gen))
+                    if n_rows > 1 and scheme == 0:
+                        self.rs[:n_rows].copy_(torch.rand((1, n_rows, self.V), generator=gen)[0])
                         g_state = gen.get_state()
-                    self.noise2.exponential_(generator=gen)                          # residual multinomial (JL:237)
+                        self.noise2.copy_(torch.empty(1, self.V).exponential_(generator=gen))
+                else:
+                    e1.exponential_(generator=gen)                                   # == torch.multinomial (JL:118)
+                    if n_rows > 1 and scheme == 0:
+                        self.rs[:n_rows].uniform_(0.0, 1.0, generator=gen)           # torch.rand([1,n,V]) (JL:260)
+                        if gen is not None:
+                            g_state = gen.get_state()
+                        self.noise2.exponential_(generator=gen)                      # residual multinomial (JL:237)
                 noise_ready = self.rng_stream.record_event()
             # ---------------- device work ----------------
             stats.host_seconds += time.perf_counter() - t_host0

@@ -19,6 +19,8 @@ def _dtype_code(dt):
         return L.DTYPE_BF16
     if dt == torch.float16:
         return L.DTYPE_F16
+    if dt == torch.float32:
+        return L.DTYPE_F32        # K1/K3 only (exact-fp32 parity variant)
     raise L.SjdLibraryError(f"SJD HIP kernels support bf16/fp16 KV and activations, got {dt}")
 
 

@@ -31,6 +31,7 @@ extern "C" {
 
 #define SJD_DTYPE_BF16 0
 #define SJD_DTYPE_F16 1
+#define SJD_DTYPE_F32 2        /* K1/K3 only: exact-fp32 VALU variant for small parity runs (not a performance path) */
 
 /* One row of the "3-dim" logits processors, reduced to what the kernels need.  Built on the host from
  * integer grammar state; replaces MultiTokensVLLogitsProcessor / MultiTokensInterleavedTopKLogitsWarper /

@@ -1,0 +1,116 @@
+"""Mirror of reference lumina_mgpt/inference_solver.py::FlexARInferenceSolver for the SJD hot path.
+
+The reference class is ~90 % tokenizer / VQ-GAN glue (FlexARItemProcessor, decode_image, gradio helpers) around one call:
+`self.model.generate(prompt_ids, generation_config, logits_processor=..., streamer=...)` (IS:347-350).  Those assets
+(./ckpts/chameleon/tokenizer/*, multi-GB checkpoints) do not exist on the GPU box, so this mirror keeps the constructor /
+attribute surface the SJD installers touch (`.model`, `.model.model`, `.item_processor`, `.device`, `.dtype`,
+`create_logits_processor`, `generate`) and works on token ids: `generate_ids(prompt_ids, max_gen_len, logits_processor)`
+is exactly IS:335-354 without the tokenizer, and `generate(images, qas, ...)` delegates to it when an `item_processor`
+with the reference's `process_item` / `decode_image` methods is supplied.
+"""
+from typing import List, Optional
+
+import torch
+
+from . import backbones as BB
+from . import ops
+
+
+class _EosCriteria:
+    def __init__(self, eos_token_id):
+        self.eos_token_id = list(eos_token_id)
+
+
+class FlexARInferenceSolver:
+    """reference IS:273-450.  `model_path` may be a directory with `config.json` + `*.safetensors` / `pytorch_model.bin`
+    holding reference (HF Chameleon) weights, or `model=` may pass a ready `sjd_amd.backbones.ChameleonBackbone`."""
+
+    def __init__(self, model_path=None, precision="bf16", target_size=512, cache_dir=None, device="cpu", tokenizer=None,
+                 model: Optional[BB.ChameleonBackbone] = None, item_processor=None, fused=True, gemm="sjd"):
+        self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[precision]
+        self.device = torch.device(device)
+        self.target_size = target_size
+        if model is None:
+            model = self._load(model_path)
+        self.model = model.to(device=self.device, dtype=self.dtype).eval()
+        if self.model.attn is None and self.device.type == "cuda":
+            self.model.attn = ops.HipWindowAttention()
+        if fused and self.device.type == "cuda" and self.dtype != torch.float32 and getattr(self.model, "_ops", None) is None:
+            self.model.enable_fused(ops, gemm=gemm)
+        self.item_processor = item_processor
+
+    @staticmethod
+    def _load(model_path):
+        import json
+        import os
+        if model_path is None or not os.path.isdir(model_path):
+            raise FileNotFoundError(f"{model_path!r}: no local checkpoint directory (there is no network access here); pass "
+                                    "model=<ChameleonBackbone> or a directory with config.json and the weight files")
+        cfg = json.load(open(os.path.join(model_path, "config.json")))
+        args = BB.ChameleonArgs(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+                                num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+                                num_key_value_heads=cfg.get("num_key_value_heads", cfg["num_attention_heads"]),
+                                rms_norm_eps=cfg.get("rms_norm_eps", 1e-5), rope_theta=cfg.get("rope_theta", 10000.0))
+        model = BB.ChameleonBackbone(args)
+        sd = {}
+        for f in sorted(os.listdir(model_path)):
+            if f.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                sd.update(load_file(os.path.join(model_path, f)))
+            elif f.endswith(".bin"):
+                sd.update(torch.load(os.path.join(model_path, f), map_location="cpu"))
+        own = model.state_dict()
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise KeyError(f"checkpoint lacks {len(missing)} tensors, e.g. {missing[:3]}")
+        model.load_state_dict({k: sd[k] for k in own})      # VQ-VAE / vision keys of the checkpoint are not on the hot path
+        return model
+
+    def create_logits_processor(self, cfg=3.0, image_top_k=2000, text_top_k=10):
+        """The non-SJD processors of IS:402-450 are replaced by the SJD ones when renew_pipeline_sampler is applied (JL:432-468);
+        without it there is no hand-written path, so this raises instead of silently decoding differently."""
+        raise RuntimeError("apply scheduler.jacobi_iteration_lumina_mgpt.renew_pipeline_sampler(solver, ...) first")
+
+    @torch.no_grad()
+    def generate_ids(self, prompt_ids: List[int], max_gen_len: int, logits_processor=None, streamer=None, temperature=1.0):
+        """IS:335-354 on token ids: GenerationConfig(max_new_tokens, do_sample, eos 8710) -> model._sample."""
+        from transformers import GenerationConfig
+        if logits_processor is None:
+            logits_processor = self.create_logits_processor()
+        prompt = torch.tensor([prompt_ids], dtype=torch.int64, device=self.device)
+        max_length = len(prompt_ids) + max_gen_len
+        gc = GenerationConfig(max_new_tokens=max_gen_len, max_length=max_length, temperature=temperature, top_k=None, do_sample=True,
+                              eos_token_id=[8710])
+        if not hasattr(self.model, "_sample"):
+            raise RuntimeError("model has no _sample hook: apply renew_pipeline_sampler / renew_sampler first")
+        out = self.model._sample(prompt, logits_processor, [_EosCriteria(getattr(self, "eos_token_ids", [8710]))], gc, False, streamer,
+                                 attention_mask=torch.ones_like(prompt))
+        ids = out[0, len(prompt_ids):].tolist()
+        if ids and ids[-1] == 8710:
+            ids = ids[:-1]
+        return ids
+
+    def generate(self, images, qas, max_gen_len, temperature, logits_processor=None, streamer=None):
+        """reference IS:299-354 -> (text, [PIL.Image]).  Needs the reference's item processor (tokenizer + VQ decoder)."""
+        if self.item_processor is None:
+            raise NotImplementedError("tokenizer / VQ-GAN assets are not part of the SJD hot path; use generate_ids(prompt_ids, ...) "
+                                      "or construct the solver with item_processor=<reference FlexARItemProcessor>")
+        conversations = [{"from": "human", "value": q} if i % 2 == 0 else {"from": "gpt", "value": a}
+                         for q, a in qas for i in range(2)]
+        prompt = self.item_processor.process_item({"image": images, "conversations": conversations}, training_mode=False)
+        ids = self.generate_ids(list(prompt), max_gen_len, logits_processor, streamer, temperature)
+        return self.decode_ids(ids)
+
+    def decode_ids(self, tokens: List[int]):
+        """reference IS:356-400: split at <racm3:break>(8197) ... <eoss>(8196) spans; images go through item_processor.decode_image."""
+        text_ids, images, i = [], [], 0
+        while i < len(tokens):
+            if tokens[i] == 8197 and 8196 in tokens[i:]:
+                j = tokens.index(8196, i)
+                images.append(self.item_processor.decode_image(tokens[i:j + 1]) if self.item_processor is not None else tokens[i:j + 1])
+                i = j + 1
+            else:
+                text_ids.append(tokens[i])
+                i += 1
+        text = self.item_processor.tokenizer.decode(text_ids) if self.item_processor is not None else text_ids
+        return text, images

@@ -38,8 +38,8 @@ template <> struct G1Mfma<SJD_DTYPE_F16> {
 };
 
 // x: [M, K] row-major (M <= 32; missing rows read as zero).  wp: packed weights.  out: fp32 [n_chunks, 32, N].
-template <int DT, int G1_WAVES>
-__global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
+template <int DT>
+__global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                 float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
                                                                 int rec_stride)
 {
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned s
     const int k0 = chunk * KC;
     const int steps = min(KC, K - k0) / 16;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int t = blockIdx.x * G1_WAVES + w;
+    const int waves = blockDim.x >> 6;
+    const int t = blockIdx.x * waves + w;
     const bool has_tile = t < n_tiles;
     // record (chunk, s, t) in 1-KiB units: all earlier chunks are full (KC/16 steps each).
     //   rec_stride == 1      : tile-major   -- a wave streams one contiguous run of `steps` KiB
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned s
         for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);
     }
     // stage the activation chunk in A-fragment order: piece (s, l) = x[l&31][k0 + 16s + 8(l>>5) .. +7]
-    for (int p = threadIdx.x; p < steps * 64; p += G1_WAVES * 64) {
+    for (int p = threadIdx.x; p < steps * 64; p += blockDim.x) {
         const int s = p >> 6, l = p & 63, m = l & 31;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (m < M) v = *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + 16 * s + 8 * (l >> 5));
@@ -106,14 +107,14 @@ __global__ __launch_bounds__(G1_WAVES * 64) void g1_skinny_gemm(const unsigned s
 extern "C" int sjd_gemm_num_chunks(int K, int KC) { return (K + KC - 1) / KC; }
 
 // out: fp32 [n_chunks, 32, N] partial products; the consumer sums the chunks.
-template <int DT, int WAVES>
-static int g1_launch(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int step_major, hipStream_t s)
+template <int DT>
+static int g1_launch(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major, hipStream_t s)
 {
     const int n_tiles = N / 32, n_chunks = (K + KC - 1) / KC;
-    const dim3 grid((n_tiles + WAVES - 1) / WAVES, n_chunks), block(WAVES * 64);
+    const dim3 grid((n_tiles + waves - 1) / waves, n_chunks), block(waves * 64);
     const size_t lds = (size_t)(KC / 16) * 64 * 16;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((g1_skinny_gemm<DT, WAVES>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles,
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((g1_skinny_gemm<DT>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles,
                        step_major ? n_tiles : 1);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
@@ -122,11 +123,9 @@ extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, 
                                int dtype, void *stream)
 {
     if (!x || !w_packed || !out || M < 1 || M > 32 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
-    if ((size_t)KC * 64 > 160 * 1024) return SJD_ERR_BAD_ARG;       // activation chunk must fit in LDS (KC <= 2560)
+    if ((size_t)KC * 64 > 160 * 1024 || waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;       // activation chunk must fit in LDS (KC <= 2560)
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SJD_DTYPE_BF16 && waves == 4) return g1_launch<SJD_DTYPE_BF16, 4>(x, w_packed, out, M, N, K, KC, step_major, s);
-    if (dtype == SJD_DTYPE_BF16 && waves == 8) return g1_launch<SJD_DTYPE_BF16, 8>(x, w_packed, out, M, N, K, KC, step_major, s);
-    if (dtype == SJD_DTYPE_F16 && waves == 4) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, step_major, s);
-    if (dtype == SJD_DTYPE_F16 && waves == 8) return g1_launch<SJD_DTYPE_F16, 8>(x, w_packed, out, M, N, K, KC, step_major, s);
+    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
     return SJD_ERR_UNSUPPORTED;
 }

@@ -134,6 +134,72 @@ __global__ __launch_bounds__(256) void f1_add_rmsnorm(unsigned short *__restrict
     }
 }
 
+// F1 for a G1 producer: the residual delta arrives as fp32 split-K partials [n_chunks, 32, hidden].  Only `rows` (<= 32)
+// workgroups exist, so the kernel is bound by how many loads ONE CU keeps in flight: 1024 threads, 4 columns each per 4096-column
+// stripe, and all chunk loads of a stripe are issued before the first add.
+template <int DT>
+__global__ __launch_bounds__(1024) void f1p_add_rmsnorm(unsigned short *__restrict__ h, const float *__restrict__ part, int n_chunks,
+                                                        const unsigned short *__restrict__ w, unsigned short *__restrict__ y,
+                                                        int hidden, float eps)
+{
+    __shared__ float red[16];
+    constexpr int MAXS = 4;                        // stripes of 4096 columns (hidden <= 16384)
+    constexpr int MAXC = 16;
+    const int row = blockIdx.x;
+    unsigned short *hr = h + (size_t)row * hidden;
+    const size_t cstride = (size_t)32 * hidden;
+    float x[MAXS][4];
+    float ss = 0.f;
+    int ns = 0;
+    for (int c = threadIdx.x * 4; c < hidden && ns < MAXS; c += 4096, ++ns) {
+        const uint2 hv = *reinterpret_cast<const uint2 *>(hr + c);
+        const float *p0 = part + (size_t)row * hidden + c;
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+        for (int c0 = 0; c0 < n_chunks; c0 += MAXC) {
+            float4 v[MAXC];
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q)
+                if (c0 + q < n_chunks) v[q] = *reinterpret_cast<const float4 *>(p0 + (size_t)(c0 + q) * cstride);
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q)
+                if (c0 + q < n_chunks) { d0 += v[q].x; d1 += v[q].y; d2 += v[q].z; d3 += v[q].w; }
+        }
+        const float hx[4] = {Cvt<DT>::to_f((unsigned short)(hv.x & 0xffffu)), Cvt<DT>::to_f((unsigned short)(hv.x >> 16)),
+                             Cvt<DT>::to_f((unsigned short)(hv.y & 0xffffu)), Cvt<DT>::to_f((unsigned short)(hv.y >> 16))};
+        const float dd[4] = {d0, d1, d2, d3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dj = Cvt<DT>::to_f(Cvt<DT>::from_f(dd[j]));                       // projection output rounds to the activation dtype
+            x[ns][j] = Cvt<DT>::to_f(Cvt<DT>::from_f(hx[j] + dj));                        // residual add rounds too
+            ss += x[ns][j] * x[ns][j];
+        }
+        uint2 ho;
+        ho.x = (unsigned)Cvt<DT>::from_f(x[ns][0]) | ((unsigned)Cvt<DT>::from_f(x[ns][1]) << 16);
+        ho.y = (unsigned)Cvt<DT>::from_f(x[ns][2]) | ((unsigned)Cvt<DT>::from_f(x[ns][3]) << 16);
+        *reinterpret_cast<uint2 *>(hr + c) = ho;
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    const float inv = rsqrtf(tot / (float)hidden + eps);
+    ns = 0;
+    for (int c = threadIdx.x * 4; c < hidden && ns < MAXS; c += 4096, ++ns) {
+        const uint2 wv = *reinterpret_cast<const uint2 *>(w + c);
+        const float ww[4] = {Cvt<DT>::to_f((unsigned short)(wv.x & 0xffffu)), Cvt<DT>::to_f((unsigned short)(wv.x >> 16)),
+                             Cvt<DT>::to_f((unsigned short)(wv.y & 0xffffu)), Cvt<DT>::to_f((unsigned short)(wv.y >> 16))};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = ww[j] * Cvt<DT>::to_f(Cvt<DT>::from_f(x[ns][j] * inv));
+        uint2 yo;
+        yo.x = (unsigned)Cvt<DT>::from_f(o[0]) | ((unsigned)Cvt<DT>::from_f(o[1]) << 16);
+        yo.y = (unsigned)Cvt<DT>::from_f(o[2]) | ((unsigned)Cvt<DT>::from_f(o[3]) << 16);
+        *reinterpret_cast<uint2 *>(y + (size_t)row * hidden + c) = yo;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ F2
 // qkv: [T, (H + 2*Hkv) * D] fused projection output (T = B*n tokens).  One wave64 per (token, head); D in {64,128}.
 // Lane l owns the rotate-half pair (d = l', d + D/2) for l' = l (+64*k).  positions: int64 [T].
@@ -257,6 +323,15 @@ extern "C" int sjd_add_rmsnorm(void *h, const void *delta, const void *weight, v
     if (part && (rows > 32 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
     if (!h || !weight || !y || rows < 1 || hidden < 8 || (hidden % 8) != 0 || hidden > 256 * 8 * 4) return SJD_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (part && (hidden % 4) == 0 && hidden <= 16384 && (dtype == SJD_DTYPE_BF16 || dtype == SJD_DTYPE_F16)) {
+        if (dtype == SJD_DTYPE_BF16)
+            hipLaunchKernelGGL(f1p_add_rmsnorm<SJD_DTYPE_BF16>, dim3(rows), dim3(1024), 0, s, (unsigned short *)h, part, n_chunks,
+                               (const unsigned short *)weight, (unsigned short *)y, hidden, eps);
+        else
+            hipLaunchKernelGGL(f1p_add_rmsnorm<SJD_DTYPE_F16>, dim3(rows), dim3(1024), 0, s, (unsigned short *)h, part, n_chunks,
+                               (const unsigned short *)weight, (unsigned short *)y, hidden, eps);
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+    }
     if (dtype == SJD_DTYPE_BF16)
         hipLaunchKernelGGL(f1_add_rmsnorm<SJD_DTYPE_BF16>, dim3(rows), dim3(256), 0, s, (unsigned short *)h, (const unsigned short *)delta,
                            (const unsigned short *)weight, (unsigned short *)y, hidden, eps, part, n_chunks);

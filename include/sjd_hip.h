@@ -148,7 +148,7 @@ int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, c
  * replaces the nn.Linear calls of the decoder layer (reference modeling_chameleon.py:527-529, 579, 193-195) for the
  * window forward.  w_packed: the [N, K] weight re-ordered by sjd_amd.ops.pack_weight (MFMA 32x32x16 B-fragment order,
  * one contiguous run per (k-chunk, 32-column tile)).  N % 32 == 0, K % 16 == 0, KC % 16 == 0, KC <= 2560;
- * waves (4 or 8) = column tiles per workgroup sharing one staged activation chunk; step_major selects the packed record
+ * waves (1..16) = column tiles per workgroup sharing one staged activation chunk; step_major selects the packed record
  * order (0: one contiguous run per tile, 1: the records of all tiles interleaved per k-step). */
 int sjd_gemm_num_chunks(int K, int KC);
 int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,

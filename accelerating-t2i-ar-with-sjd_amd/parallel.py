@@ -19,7 +19,7 @@ def contiguous_split(n_items: int, world: int, rank: int):
 
 def gather_report(n_tokens, n_steps, seconds, device=None):
     """-> list over ranks of (n_tokens, n_steps, seconds).  One all_gather; no-op without a process group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [(float(n_tokens), float(n_steps), float(seconds))]
     backend = dist.get_backend()
     dev = device if backend == "nccl" else torch.device("cpu")

@@ -167,7 +167,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("SJD_FORCE_DIST") == "1":
         dist.init_process_group(backend="nccl")          # RCCL on ROCm
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -190,7 +190,7 @@ def main():
     eng = SJDEngine(model, margs.vocab_size, device, max_window=args.window, use_graph=not args.no_graph)
 
     def sync_all():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -209,7 +209,7 @@ def main():
     prof_g1 = measure_g1(args, model, device) if (args.gemm == "sjd" and not args.no_fused) else None
     rep = gather_report(stats.tokens, stats.timed_nfe, stats.seconds, device)   # one RCCL all_gather (24 B/rank)
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
     tot_tokens = sum(r[0] for r in rep)
@@ -260,7 +260,7 @@ def main():
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, tok_per_step)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -8,29 +8,32 @@ from .scheduler.logit_processor_3dim import TopKLogitsWarper, TopPLogitsWarper3d
 
 
 def top_k_top_p_filtering(logits, top_k: int = 0, top_p: float = 1.0, filter_value: float = -float("Inf"), min_tokens_to_keep: int = 1):
-    """reference LS:34-72 (one-off per image; plain torch ops)."""
+    """Behaviour of reference LS:34-72 (used once per image, for the first token): keep the k largest logits, then the
+    smallest descending-sorted prefix whose probability mass exceeds top_p (the token that crosses the threshold is kept)."""
+    V = logits.size(-1)
     if top_k > 0:
-        top_k = min(max(top_k, min_tokens_to_keep), logits.size(-1))
-        logits[logits < torch.topk(logits, top_k)[0][..., -1, None]] = filter_value
+        k = min(max(top_k, min_tokens_to_keep), V)
+        kth = logits.topk(k, dim=-1).values[..., -1:]
+        logits.masked_fill_(logits < kth, filter_value)
     if top_p < 1.0:
-        sorted_logits, sorted_indices = torch.sort(logits, descending=True)
-        cumulative_probs = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1)
-        remove = cumulative_probs > top_p
+        order = logits.argsort(dim=-1, descending=True)
+        mass = logits.gather(-1, order).softmax(dim=-1).cumsum(dim=-1)
+        drop_sorted = torch.zeros_like(mass, dtype=torch.bool)
+        drop_sorted[..., 1:] = mass[..., :-1] > top_p          # shifted by one: the crossing token survives
         if min_tokens_to_keep > 1:
-            remove[..., :min_tokens_to_keep] = 0
-        remove[..., 1:] = remove[..., :-1].clone()
-        remove[..., 0] = 0
-        logits[remove.scatter(1, sorted_indices, remove)] = filter_value
+            drop_sorted[..., :min_tokens_to_keep] = False
+        drop = torch.zeros_like(drop_sorted).scatter(-1, order, drop_sorted)
+        logits.masked_fill_(drop, filter_value)
     return logits
 
 
 def sample(logits, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, sample_logits=True):
-    """reference LS:75-84"""
-    logits = logits[:, -1, :] / max(temperature, 1e-5)
+    """Behaviour of reference LS:75-84: last row / temperature -> filtering -> softmax -> one draw from the GLOBAL generator."""
+    last = logits[:, -1, :] / max(temperature, 1e-5)
     if top_k > 0 or top_p < 1.0:
-        logits = top_k_top_p_filtering(logits, top_k=top_k, top_p=top_p)
-    probs = F.softmax(logits, dim=-1)
-    idx = torch.multinomial(probs, num_samples=1) if sample_logits else torch.topk(probs, k=1, dim=-1)[1]
+        last = top_k_top_p_filtering(last, top_k=top_k, top_p=top_p)
+    probs = last.softmax(dim=-1)
+    idx = torch.multinomial(probs, num_samples=1) if sample_logits else probs.argmax(dim=-1, keepdim=True)
     return idx, probs
 
 

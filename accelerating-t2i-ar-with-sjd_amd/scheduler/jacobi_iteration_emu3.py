@@ -37,31 +37,29 @@ def renew_sampler_forward(model_class):
             self._init_doubled_attn_mask_cfg = _init_doubled_attn_mask_cfg
 
         def renew_attn_mask(self, batchsize, prefill_num, not_pad_mask=None, device='cuda'):
-            B_cfg = 2 * batchsize if self.do_cfg else batchsize
-            attention_mask = torch.ones((B_cfg, prefill_num), device=device)
-            attention_mask[~not_pad_mask] = 0
-            return attention_mask
+            """reference JE:177-186: 0/1 mask [B_cfg, prefill_num], zero on pad columns."""
+            rows = batchsize * (2 if self.do_cfg else 1)
+            return not_pad_mask.to(device=device, dtype=torch.float32).reshape(rows, prefill_num).clone()
 
         def prepare_batch_cfg_model_inputs(self, input_ids, neg_input_ids=None, attention_mask=None):
-            """reference JE:234-278"""
+            """reference JE:234-278: stack the positive and negative prompts (left-padded to a common length) on the batch
+            axis and derive the pad mask.  Returns {input_ids, pos_input_ids (when a negative prompt is given), attention_mask}."""
             pad = self.config.pad_token_id if hasattr(self, "config") else self.pad_token_id
-            model_inputs = dict(input_ids=input_ids, attention_mask=attention_mask)
-            batchsize, prefill_num = input_ids.shape
-            neg_prefill_num = neg_input_ids.shape[1] if neg_input_ids is not None else prefill_num
-            batchsize_cfg = 2 * batchsize if self.do_cfg else batchsize
-            max_prefill_num = max(prefill_num, neg_prefill_num)
-            not_pad_mask = torch.zeros((batchsize_cfg, max_prefill_num), dtype=torch.bool, device=input_ids.device)
-            not_pad_mask[:batchsize, -input_ids.shape[1]:] = input_ids != pad
+            B = input_ids.shape[0]
+            out = {"input_ids": input_ids, "attention_mask": attention_mask}
             if neg_input_ids is not None:
-                both = get_double_cfg_input_ids(input_ids, neg_input_ids, pad_category=pad)
-                model_inputs['input_ids'] = both
-                model_inputs['pos_input_ids'] = both[:batchsize, :]
-                not_pad_mask[:, :] = both != pad
+                stacked = get_double_cfg_input_ids(input_ids, neg_input_ids, pad_category=pad)
+                out["input_ids"], out["pos_input_ids"] = stacked, stacked[:B]
+                keep = stacked != pad
+            else:
+                rows = B * (2 if self.do_cfg else 1)
+                keep = torch.zeros((rows, input_ids.shape[1]), dtype=torch.bool, device=input_ids.device)
+                keep[:B] = input_ids != pad
             if attention_mask is None:
-                model_inputs['attention_mask'] = self.renew_attn_mask(batchsize, max_prefill_num, not_pad_mask, input_ids.device)
-            elif attention_mask.shape[0] == batchsize:
+                out["attention_mask"] = self.renew_attn_mask(B, keep.shape[1], keep, input_ids.device)
+            elif attention_mask.shape[0] == B:
                 raise NotImplementedError
-            return model_inputs
+            return out
 
     return JacobiModel
 

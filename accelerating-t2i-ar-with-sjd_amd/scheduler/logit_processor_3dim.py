@@ -13,11 +13,10 @@ from .. import grammar as G
 
 
 def check_eol_in_multitokens(tokenlen, new_pred_tokenlen, line_len):
-    """reference logit_processor_3dim.py:25-29 (pure integer arithmetic)."""
-    L, R = (tokenlen + 1), (tokenlen + new_pred_tokenlen)
-    check_interval_l = L // line_len + 1 if L % line_len != 0 else L // line_len
-    check_interval_r = R // line_len
-    return check_interval_l <= check_interval_r
+    """Behaviour of reference logit_processor_3dim.py:25-29: does any of the next `new_pred_tokenlen` positions
+    (tokenlen+1 .. tokenlen+new_pred_tokenlen) fall on a multiple of `line_len`?"""
+    first_multiple = -(-(tokenlen + 1) // line_len) * line_len
+    return first_multiple <= tokenlen + new_pred_tokenlen
 
 
 def eol_positions_in_multitokens(tokenlen, new_pred_tokenlen, line_len):
@@ -99,13 +98,10 @@ class SuppressTokensLogitsProcessor3d(SuppressTokensInIndexRangeLogitsProcessor3
 
 
 def get_double_cfg_input_ids(input_ids, neg_input_ids, pad_category):
-    """reference :422-440: left-pad positive/negative prompts to a common length, stacked on the batch dim."""
-    batchsize, prefill_num = input_ids.shape
-    max_prefill_num = max(prefill_num, neg_input_ids.shape[1])
-    out = torch.full((2 * batchsize, max_prefill_num), pad_category, dtype=input_ids.dtype, device=input_ids.device)
-    out[:batchsize, -input_ids.shape[1]:] = input_ids
-    out[batchsize:, -neg_input_ids.shape[1]:] = neg_input_ids
-    return out
+    """Behaviour of reference :422-440: [pos; neg] stacked on the batch axis, both right-aligned in a pad-filled frame."""
+    width = max(input_ids.shape[1], neg_input_ids.shape[1])
+    rows = [torch.nn.functional.pad(t, (width - t.shape[1], 0), value=pad_category) for t in (input_ids, neg_input_ids)]
+    return torch.cat(rows, dim=0)
 
 
 def grammar_from_processors(processors, prompt_len=None, max_length=None):

@@ -363,6 +363,9 @@ class ChameleonBackbone(nn.Module):
         into the consuming glue kernel (F2 / F1 / F3 / F1)."""
         ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
         T, eps, cfg = B * n, self.args.rms_norm_eps, self.G1_CFG
+        cap = 2560 if T <= 32 else 1280           # the staged activation chunk (32 or 64 rows) must fit in LDS
+        if any(c[0] > cap for c in cfg.values()):
+            raise ValueError(f"G1_CFG chunk sizes must be <= {cap} for a {T}-row window")
         g1 = lambda x_, name, N_, K_: ops.skinny_gemm(x_, self._packed[li][name], N_, K_, cfg[name][0], cfg[name][1], cfg[name][2])
         H, Hkv, D, hid, inter = self.n_heads, self.n_kv_heads, self.head_dim, self.args.hidden_size, self.args.intermediate_size
         params = getattr(self.attn, "params", None)
@@ -386,7 +389,7 @@ class ChameleonBackbone(nn.Module):
         return self.lm_head(x).float().view(B, n, -1)
 
     def _forward_window_fused(self, tokens, positions, kv_len, key_start):
-        if self._gemm == "sjd" and tokens.shape[0] * tokens.shape[1] <= 32:
+        if self._gemm == "sjd" and tokens.shape[0] * tokens.shape[1] <= 64:
             return self._forward_window_g1(tokens, positions, kv_len, key_start)
         ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
         T, eps = B * n, self.args.rms_norm_eps

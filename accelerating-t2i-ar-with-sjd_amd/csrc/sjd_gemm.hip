@@ -37,8 +37,9 @@ template <> struct G1Mfma<SJD_DTYPE_F16> {
     { return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); }
 };
 
-// x: [M, K] row-major (M <= 32; missing rows read as zero).  wp: packed weights.  out: fp32 [n_chunks, 32, N].
-template <int DT>
+// x: [M, K] row-major (M <= 32*MT; missing rows read as zero).  wp: packed weights.  out: fp32 [n_chunks, 32*MT, N].
+// MT = 2 serves a 64-row window (B_cfg * L with a draft window of 32): every weight record feeds two MFMAs.
+template <int DT, int MT>
 __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                 float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
                                                                 int rec_stride)
@@ -66,18 +67,22 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
 #pragma unroll
         for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);
     }
-    // stage the activation chunk in A-fragment order: piece (s, l) = x[l&31][k0 + 16s + 8(l>>5) .. +7]
-    for (int p = threadIdx.x; p < steps * 64; p += blockDim.x) {
-        const int s = p >> 6, l = p & 63, m = l & 31;
+    // stage the activation chunk in A-fragment order: piece (mt, s, l) = x[32mt + (l&31)][k0 + 16s + 8(l>>5) .. +7]
+    for (int p = threadIdx.x; p < MT * steps * 64; p += blockDim.x) {
+        const int mt = p / (steps * 64), q = p - mt * steps * 64;
+        const int s = q >> 6, l = q & 63, m = 32 * mt + (l & 31);
         u32x4 v = {0u, 0u, 0u, 0u};
         if (m < M) v = *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + 16 * s + 8 * (l >> 5));
         xl[p] = v;
     }
     __syncthreads();
     if (!has_tile) return;
-    f32x16 acc;
+    f32x16 acc[MT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    const int xs = steps * 64;           // records per m-tile in LDS
     for (int g = 0; g < full; ++g) {
         const bool more = g + 1 < full;
         if (more) {
@@ -85,36 +90,45 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
             for (int u = 0; u < G1_UNROLL; ++u) nxt[u] = __builtin_nontemporal_load(wu + (size_t)((g + 1) * G1_UNROLL + u) * rs);
         }
 #pragma unroll
-        for (int u = 0; u < G1_UNROLL; ++u) acc = G1Mfma<DT>::mma(xl[(g * G1_UNROLL + u) * 64 + lane], cur[u], acc);
+        for (int u = 0; u < G1_UNROLL; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = G1Mfma<DT>::mma(xl[mt * xs + (g * G1_UNROLL + u) * 64 + lane], cur[u], acc[mt]);
         if (more) {
 #pragma unroll
             for (int u = 0; u < G1_UNROLL; ++u) cur[u] = nxt[u];
         }
     }
-    for (int s = full * G1_UNROLL; s < steps; ++s)      // ragged tail (K chunk not a multiple of 128)
-        acc = G1Mfma<DT>::mma(xl[s * 64 + lane], __builtin_nontemporal_load(wu + (size_t)s * rs), acc);
+    for (int s = full * G1_UNROLL; s < steps; ++s) {    // ragged tail (K chunk not a multiple of 128)
+        const u32x4 wv = __builtin_nontemporal_load(wu + (size_t)s * rs);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(xl[mt * xs + s * 64 + lane], wv, acc[mt]);
+    }
 
     // D[m][n]: reg r of lane l -> row m = (r&3) + 8*(r>>2) + 4*(l>>5), column n = 32t + (l&31): 128-B coalesced rows
-    float *o = out + ((size_t)chunk * 32) * N + (size_t)t * 32 + (lane & 31);
+    float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        o[(size_t)m * N] = acc[r];
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            o[(size_t)m * N] = acc[mt][r];
+        }
 }
 
 
 extern "C" int sjd_gemm_num_chunks(int K, int KC) { return (K + KC - 1) / KC; }
 
 // out: fp32 [n_chunks, 32, N] partial products; the consumer sums the chunks.
-template <int DT>
+template <int DT, int MT>
 static int g1_launch(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major, hipStream_t s)
 {
     const int n_tiles = N / 32, n_chunks = (K + KC - 1) / KC;
     const dim3 grid((n_tiles + waves - 1) / waves, n_chunks), block(waves * 64);
-    const size_t lds = (size_t)(KC / 16) * 64 * 16;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((g1_skinny_gemm<DT>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles,
+    const size_t lds = (size_t)MT * (KC / 16) * 64 * 16;
+    if (lds > 160 * 1024) return SJD_ERR_BAD_ARG;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((g1_skinny_gemm<DT, MT>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles,
                        step_major ? n_tiles : 1);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
@@ -122,10 +136,12 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
 extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,
                                int dtype, void *stream)
 {
-    if (!x || !w_packed || !out || M < 1 || M > 32 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
+    if (!x || !w_packed || !out || M < 1 || M > 64 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
     if ((size_t)KC * 64 > 160 * 1024 || waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;       // activation chunk must fit in LDS (KC <= 2560)
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
-    if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_BF16 && M <= 32) return g1_launch<SJD_DTYPE_BF16, 1>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_F16 && M <= 32) return g1_launch<SJD_DTYPE_F16, 1>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
     return SJD_ERR_UNSUPPORTED;
 }

@@ -69,7 +69,7 @@ __device__ __forceinline__ float wave_sum(float v)
 template <int DT>
 __global__ __launch_bounds__(256) void f1_add_rmsnorm(unsigned short *__restrict__ h, const unsigned short *__restrict__ delta,
                                                       const unsigned short *__restrict__ w, unsigned short *__restrict__ y,
-                                                      int hidden, float eps, const float *__restrict__ part, int n_chunks)
+                                                      int hidden, float eps, const float *__restrict__ part, int n_chunks, int prows)
 {
     __shared__ float red[4];
     const int row = blockIdx.x;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void f1_add_rmsnorm(unsigned short *__restrict
             if (part) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d[j] = 0.f;
-                const size_t cstride = (size_t)32 * hidden;
+                const size_t cstride = (size_t)prows * hidden;
                 const float *p0 = part + (size_t)row * hidden + c;
                 int cc = 0;
                 for (; cc + 4 <= n_chunks; cc += 4) {       // issue the loads of four chunks before any add (L2 latency overlap)
@@ -140,14 +140,14 @@ __global__ __launch_bounds__(256) void f1_add_rmsnorm(unsigned short *__restrict
 template <int DT>
 __global__ __launch_bounds__(1024) void f1p_add_rmsnorm(unsigned short *__restrict__ h, const float *__restrict__ part, int n_chunks,
                                                         const unsigned short *__restrict__ w, unsigned short *__restrict__ y,
-                                                        int hidden, float eps)
+                                                        int hidden, float eps, int prows)
 {
     __shared__ float red[16];
     constexpr int MAXS = 4;                        // stripes of 4096 columns (hidden <= 16384)
     constexpr int MAXC = 16;
     const int row = blockIdx.x;
     unsigned short *hr = h + (size_t)row * hidden;
-    const size_t cstride = (size_t)32 * hidden;
+    const size_t cstride = (size_t)prows * hidden;
     float x[MAXS][4];
     float ss = 0.f;
     int ns = 0;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     unsigned short *__restrict__ v_cache, const unsigned short *__restrict__ qn_w, const unsigned short *__restrict__ qn_b,
     const unsigned short *__restrict__ kn_w, const unsigned short *__restrict__ kn_b, const float *__restrict__ inv_freq,
     const long *__restrict__ positions, int B, int n, int H, int H_kv, int S_max, const sjd_iter_params *__restrict__ params,
-    int kv_len_arg, const float *__restrict__ part, int n_chunks)
+    int kv_len_arg, const float *__restrict__ part, int n_chunks, int prows)
 {
     constexpr int HALF = D / 2;
     constexpr int PPL = HALF / 64 > 0 ? HALF / 64 : 1;       // pairs per lane (D=128: 1, D=64: lanes 32..63 idle)
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
         if (part) {                                           // fp32 split-K partials of the qkv projection (G1)
             const size_t ncol = (size_t)heads * D, col = (size_t)hh * D + lane;
             for (int cc = 0; cc < n_chunks; ++cc) {
-                const float *pp = part + ((size_t)cc * 32 + tok) * ncol + col;
+                const float *pp = part + ((size_t)cc * prows + tok) * ncol + col;
                 x0 += pp[0];
                 x1 += pp[HALF];
             }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
 // ------------------------------------------------------------------------------------------------ F3
 template <int DT>
 __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restrict__ gu, unsigned short *__restrict__ y, int M, int I,
-                                                   const float *__restrict__ part, int n_chunks)
+                                                   const float *__restrict__ part, int n_chunks, int prows)
 {
     const int per_row = I / 8;
     const size_t total = (size_t)M * per_row;
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
 #pragma unroll
             for (int j = 0; j < 8; ++j) { g[j] = 0.f; u[j] = 0.f; }
             for (int cc = 0; cc < n_chunks; ++cc) {
-                const float4 *pg = reinterpret_cast<const float4 *>(part + ((size_t)cc * 32 + row) * 2 * I + c);
-                const float4 *pu = reinterpret_cast<const float4 *>(part + ((size_t)cc * 32 + row) * 2 * I + I + c);
+                const float4 *pg = reinterpret_cast<const float4 *>(part + ((size_t)cc * prows + row) * 2 * I + c);
+                const float4 *pu = reinterpret_cast<const float4 *>(part + ((size_t)cc * prows + row) * 2 * I + I + c);
                 const float4 a = pg[0], b = pg[1], e = pu[0], f = pu[1];
                 g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; g[4] += b.x; g[5] += b.y; g[6] += b.z; g[7] += b.w;
                 u[0] += e.x; u[1] += e.y; u[2] += e.z; u[3] += e.w; u[4] += f.x; u[5] += f.y; u[6] += f.z; u[7] += f.w;
@@ -320,24 +320,25 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
 extern "C" int sjd_add_rmsnorm(void *h, const void *delta, const void *weight, void *y, int rows, int hidden, float eps, int dtype,
                                const float *part, int n_chunks, void *stream)
 {
-    if (part && (rows > 32 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    if (part && (rows > 64 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    const int prows = rows <= 32 ? 32 : 64;      // row padding of the G1 partials
     if (!h || !weight || !y || rows < 1 || hidden < 8 || (hidden % 8) != 0 || hidden > 256 * 8 * 4) return SJD_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (part && (hidden % 4) == 0 && hidden <= 16384 && (dtype == SJD_DTYPE_BF16 || dtype == SJD_DTYPE_F16)) {
         if (dtype == SJD_DTYPE_BF16)
             hipLaunchKernelGGL(f1p_add_rmsnorm<SJD_DTYPE_BF16>, dim3(rows), dim3(1024), 0, s, (unsigned short *)h, part, n_chunks,
-                               (const unsigned short *)weight, (unsigned short *)y, hidden, eps);
+                               (const unsigned short *)weight, (unsigned short *)y, hidden, eps, prows);
         else
             hipLaunchKernelGGL(f1p_add_rmsnorm<SJD_DTYPE_F16>, dim3(rows), dim3(1024), 0, s, (unsigned short *)h, part, n_chunks,
-                               (const unsigned short *)weight, (unsigned short *)y, hidden, eps);
+                               (const unsigned short *)weight, (unsigned short *)y, hidden, eps, prows);
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
     }
     if (dtype == SJD_DTYPE_BF16)
         hipLaunchKernelGGL(f1_add_rmsnorm<SJD_DTYPE_BF16>, dim3(rows), dim3(256), 0, s, (unsigned short *)h, (const unsigned short *)delta,
-                           (const unsigned short *)weight, (unsigned short *)y, hidden, eps, part, n_chunks);
+                           (const unsigned short *)weight, (unsigned short *)y, hidden, eps, part, n_chunks, prows);
     else if (dtype == SJD_DTYPE_F16)
         hipLaunchKernelGGL(f1_add_rmsnorm<SJD_DTYPE_F16>, dim3(rows), dim3(256), 0, s, (unsigned short *)h, (const unsigned short *)delta,
-                           (const unsigned short *)weight, (unsigned short *)y, hidden, eps, part, n_chunks);
+                           (const unsigned short *)weight, (unsigned short *)y, hidden, eps, part, n_chunks, prows);
     else return SJD_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
@@ -347,7 +348,8 @@ extern "C" int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cach
                                       int H, int H_kv, int D, int S_max, int dtype, const sjd_iter_params *params, int kv_len,
                                       const float *part, int n_chunks, void *stream)
 {
-    if (part && (B * n > 32 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    if (part && (B * n > 64 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    const int prows = B * n <= 32 ? 32 : 64;
     if ((!qkv && !part) || !q_out || !k_cache || !v_cache || !inv_freq || !positions || B < 1 || n < 1 || H < 1 || H_kv < 1) return SJD_ERR_BAD_ARG;
     const int waves = B * n * (H + 2 * H_kv);
     const dim3 grid((waves + 3) / 4), block(256);
@@ -357,7 +359,7 @@ extern "C" int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cach
         hipLaunchKernelGGL((f2_qknorm_rope_append<DT_, D_>), grid, block, 0, s, (const unsigned short *)qkv, (unsigned short *)q_out, \
                            (unsigned short *)k_cache, (unsigned short *)v_cache, (const unsigned short *)qn_w,                        \
                            (const unsigned short *)qn_b, (const unsigned short *)kn_w, (const unsigned short *)kn_b, inv_freq,        \
-                           (const long *)positions, B, n, H, H_kv, S_max, params, kv_len, part, n_chunks);                           \
+                           (const long *)positions, B, n, H, H_kv, S_max, params, kv_len, part, n_chunks, prows);                           \
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;                                                             \
     }
     SJD_F2_CASE(SJD_DTYPE_BF16, 128)
@@ -370,16 +372,17 @@ extern "C" int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cach
 
 extern "C" int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks, void *stream)
 {
-    if (part && (rows > 32 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    if (part && (rows > 64 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    const int prows = rows <= 32 ? 32 : 64;
     if ((!gate_up && !part) || !y || rows < 1 || inter < 8 || (inter % 8) != 0) return SJD_ERR_BAD_ARG;
     const size_t total = (size_t)rows * (inter / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SJD_DTYPE_BF16)
-        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_BF16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter, part, n_chunks);
+        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_BF16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter, part, n_chunks, prows);
     else if (dtype == SJD_DTYPE_F16)
-        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_F16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter, part, n_chunks);
+        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_F16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter, part, n_chunks, prows);
     else return SJD_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }

@@ -143,11 +143,11 @@ def pack_weight(weight, KC, step_major=False):
 
 
 def skinny_gemm(x, w_packed, N, K, KC, waves=4, step_major=False):
-    """x [M<=32, K] bf16/fp16 -> Partials([n_chunks, 32, N] fp32)."""
+    """x [M<=64, K] bf16/fp16 -> Partials([n_chunks, 32 or 64, N] fp32)."""
     M = x.shape[0]
     assert x.is_contiguous() and x.shape[1] == K and w_packed.numel() == N * K
     nc = (K + KC - 1) // KC
-    out = torch.empty(nc, 32, N, dtype=torch.float32, device=x.device)
+    out = torch.empty(nc, 32 if M <= 32 else 64, N, dtype=torch.float32, device=x.device)
     L.check(L.load().sjd_skinny_gemm(_ptr(x), _ptr(w_packed), _ptr(out), M, N, K, KC, waves, int(step_major), _dtype_code(x.dtype), _stream()), "sjd_skinny_gemm")
     return Partials(out, nc, N)
 

@@ -143,8 +143,8 @@ int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cache, void *v_
 /* F3: y[rows, inter] = silu(gate_up[:, :inter]) * gate_up[:, inter:].  replaces ChameleonMLP's act_fn/mul (:193-195). */
 int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks, void *stream);
 
-/* G1 -- weight-streaming projection of the draft window: out[c, m, n] = sum_{k in chunk c} x[m, k] * W[n, k], M <= 32 rows,
- * fp32 split-K partials [n_chunks, 32, N] (n_chunks = ceil(K / KC)); the consumer (F1/F2/F3 `part` argument) sums them.
+/* G1 -- weight-streaming projection of the draft window: out[c, m, n] = sum_{k in chunk c} x[m, k] * W[n, k], M <= 64 rows,
+ * fp32 split-K partials [n_chunks, R, N] with R = 32 (M <= 32) or 64 (n_chunks = ceil(K / KC)); the consumer (F1/F2/F3 `part` argument) sums them.
  * replaces the nn.Linear calls of the decoder layer (reference modeling_chameleon.py:527-529, 579, 193-195) for the
  * window forward.  w_packed: the [N, K] weight re-ordered by sjd_amd.ops.pack_weight (MFMA 32x32x16 B-fragment order,
  * one contiguous run per (k-chunk, 32-column tile)).  N % 32 == 0, K % 16 == 0, KC % 16 == 0, KC <= 2560;

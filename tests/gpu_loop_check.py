@@ -135,7 +135,7 @@ def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, 
 
 @torch.no_grad()
 def teacher_forced_emu3_check(device="cuda:0", H=3, W=5, window=32, seed=5, embed_token_scale=0.4, dtype=torch.float16,
-                              use_graph=True, pos_len=9, neg_len=5):
+                              use_graph=True, pos_len=9, neg_len=5, gemm="torch"):
     """Emu3 flavour (config 3): Llama-style GQA backbone without QK-norm, pos/neg prompts left-padded to a common
     length (pads are hidden keys), EOL/EOF/EOI/EOS grammar, top-k 2048, draft window 32, fp16."""
     import sjd_amd.ops as ops
@@ -150,7 +150,9 @@ def teacher_forced_emu3_check(device="cuda:0", H=3, W=5, window=32, seed=5, embe
                             num_key_value_heads=2, rope_theta=1000000.0, qk_norm=False)
     model = BB.ChameleonBackbone(args, attn=ops.HipWindowAttention(n_split=2)).eval()
     synthetic.fill_state_dict(model, seed=29, embed_token_scale=embed_token_scale)
-    model = model.to(device=device, dtype=dtype).enable_fused(ops)
+    model = model.to(device=device, dtype=dtype)
+    model.G1_CFG = dict(qkv=(256, 8, True), o=(256, 4, False), gate_up=(512, 8, True), down=(256, 4, False))
+    model.enable_fused(ops, gemm=gemm)
     g = torch.Generator().manual_seed(seed)
     pos_ids = torch.randint(300, 2000, (pos_len - 1,), generator=g).tolist() + [tok["img_token"]]
     neg_ids = torch.randint(300, 2000, (neg_len - 1,), generator=g).tolist() + [tok["img_token"]]

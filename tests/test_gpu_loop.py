@@ -35,9 +35,9 @@ def test_lumina_loop(scheme, seed, window, kvh, l, r, use_graph):
         assert s["last"] == 8196 and s["tokens"] == 73
 
 
-@pytest.mark.parametrize("window,use_graph", [(32, True), (16, False)])
-def test_emu3_loop(window, use_graph):
-    s = G.teacher_forced_emu3_check(window=window, use_graph=use_graph)
+@pytest.mark.parametrize("window,use_graph,gemm", [(32, True, "torch"), (16, False, "torch"), (32, True, "sjd"), (16, True, "sjd")])
+def test_emu3_loop(window, use_graph, gemm):
+    s = G.teacher_forced_emu3_check(window=window, use_graph=use_graph, gemm=gemm)
     gen, t, W, H = s["gen"], s["tok"], s["W"], s["H"]
     eols = [i for i, x in enumerate(gen) if x == t["eol_token"]]
     assert eols == [(W + 1) * (r + 1) - 1 for r in range(H)]                        # EOL closes every row

@@ -26,7 +26,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--model", default="lumina7b", choices=["lumina7b", "lumina_tiny"])
+    ap.add_argument("--model", default="lumina7b", choices=["lumina7b", "lumina_tiny", "emu3_8b"],
+                    help="lumina7b = BASELINE.json's metric config; emu3_8b = config 3 (720x720, GQA 32/8, V=184622, fp16)")
+    ap.add_argument("--dtype", default=None, choices=[None, "bf16", "fp16"])
     ap.add_argument("--embed-token-scale", type=float, default=0.7)
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--n-split", type=int, default=8)
@@ -47,12 +49,17 @@ def build_model(args, device):
     import sjd_amd.synthetic as synthetic
     if args.model == "lumina7b":
         margs = BB.LUMINA_7B
+    elif args.model == "emu3_8b":
+        margs = BB.EMU3_8B
     else:
         margs = BB.ChameleonArgs(vocab_size=65536, hidden_size=1024, intermediate_size=2048, num_hidden_layers=4,
                                  num_attention_heads=8, num_key_value_heads=8)
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype or ("fp16" if args.model == "emu3_8b" else "bf16")]
     attn = ops.HipWindowAttention(n_split=args.n_split)
     with torch.device(device):
-        model = BB.ChameleonBackbone(margs, attn=attn).to(torch.bfloat16).eval()
+        model = BB.ChameleonBackbone(margs, attn=attn).to(dt).eval()
+    if args.model == "emu3_8b":      # 64-row windows (draft window 32) need activation chunks <= 1280 columns
+        model.G1_CFG = dict(qkv=(512, 6, True), o=(256, 4, False), gate_up=(1024, 8, True), down=(1024, 4, False))
     synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=args.embed_token_scale)
     if not args.no_fused:
         model.enable_fused(ops, gemm=args.gemm)
@@ -72,7 +79,7 @@ def measure_k1(args, model, attn, device, kv_len):
     kc, vc = model.cache.k, model.cache.v   # a single layer would sit in the 256 MB Infinity Cache
     q = torch.randn(B, n, H, D, device=device).to(kc.dtype)
     out = torch.empty_like(q)
-    ks = torch.tensor([0, 63], dtype=torch.int32, device=device)
+    ks = torch.tensor([0, 0], dtype=torch.int32, device=device) if model.n_kv_heads != model.n_heads else torch.tensor([0, 63], dtype=torch.int32, device=device)
     ws = ops.attention_workspace(B, H, n, D, args.n_split, device)
     evs = [(ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())) for _ in range(args.k1_launches)]
     for i in range(nl):
@@ -87,7 +94,7 @@ def measure_k1(args, model, attn, device, kv_len):
         lib.sjd_event_destroy(e1)
     esz = kc.element_size()
     Hkv = kc.shape[2]
-    rows0, rows1 = kv_len + n, kv_len + n - 63          # visible key rows of the cond / uncond batch row
+    rows0, rows1 = kv_len + n, kv_len + n - int(ks[1])   # visible key rows of the cond / uncond batch row
     alg = 2 * Hkv * (rows0 + rows1) * D * esz + B * n * H * D * esz     # K,V rows once per kv head + q
     avg_ms = sum(ms) / len(ms)
     return dict(launches=len(ms), avg_ms=avg_ms, avg_bytes=alg, avg_kv_rows=kv_len + n, gbps=alg / 1e9 / (avg_ms / 1e3))
@@ -178,15 +185,35 @@ def main():
     from sjd_amd.parallel import gather_report
 
     model, margs, attn = build_model(args, device)
-    P, grid = 64, 48
-    n_img = grid * (grid + 1)
-    s_max = ((P + n_img + 64 + 31) // 32) * 32
+    if args.model == "emu3_8b":
+        from sjd_amd.frontends import emu3_window_spec
+        from sjd_amd.grammar import Emu3Grammar
+        import sjd_amd.synthetic as synthetic
+        tok = dict(img_token=151851, eoi_token=151853, eos_token=151850, eol_token=151846, eof_token=151847, pad_token=151643)
+        Hh = Ww = 90                                        # 720x720 / 8 (reference test_emu3.py:121-122)
+        pos = synthetic.synthetic_prompt(63, 1234 + rank, lo=1000, hi=150000)[0].tolist() + [tok["img_token"]]
+        neg = synthetic.synthetic_prompt(11, 4321 + rank, lo=1000, hi=150000)[0].tolist() + [tok["img_token"]]
+        spec = emu3_window_spec(pos, neg, tok["pad_token"], device)
+        prompt = spec.first_tokens[0].tolist()
+        P, n_img = len(prompt), (Ww + 1) * Hh + 2
+        grammar = Emu3Grammar(Hh, Ww, 151854, 32768, top_k=2048, **tok)
+        cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=Hh * Ww - 1, max_num_new_tokens=args.window,
+                        guidance_scale=3.0, seed=1234 + rank, prefix_token_sampler_scheme="speculative_jacobi",
+                        max_length=P + n_img + 1, eos_token_ids=(tok["eos_token"],))
+        workload = f"Emu3-Gen 8B architecture 720x720 (90x91 visual tokens), pos/neg prompt CFG 3.0, top-k 2048, draft window {args.window}, fp16"
+    else:
+        P, grid = 64, 48
+        n_img = grid * (grid + 1)
+        prompt = lumina_prompt(P, grid, grid, seed=1234 + rank)
+        spec = lumina_window_spec(prompt, device)
+        grammar = LuminaGrammar(2000, 10)
+        cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=grid * grid + grid - 10 - 3,
+                        max_num_new_tokens=args.window, guidance_scale=3.0, seed=1234 + rank,
+                        prefix_token_sampler_scheme="speculative_jacobi", max_length=P + n_img + 1, eos_token_ids=(8196,))
+        workload = (f"{'Lumina-mGPT-7B' if args.model == 'lumina7b' else args.model} 768x768, 1 prompt/GPU, draft window {args.window}, "
+                    f"CFG 3.0 (batch 2), top-k 2000, bf16")
+    s_max = ((P + n_img + 2 * args.window + 64 + 31) // 32) * 32
     model.setup_cache(batch=2, s_max=s_max)
-    prompt = lumina_prompt(P, grid, grid, seed=1234 + rank)
-    spec = lumina_window_spec(prompt, device)
-    cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=grid * grid + grid - 10 - 3,
-                    max_num_new_tokens=args.window, guidance_scale=3.0, seed=1234 + rank,
-                    prefix_token_sampler_scheme="speculative_jacobi", max_length=P + n_img + 1, eos_token_ids=(8196,))
     eng = SJDEngine(model, margs.vocab_size, device, max_window=args.window, use_graph=not args.no_graph)
 
     def sync_all():
@@ -203,7 +230,7 @@ def main():
     def timed_end():
         sync_all()
 
-    seq, stats = eng.decode(prompt, spec, LuminaGrammar(2000, 10), cfg, warmup_iters=args.warmup, timed_iters=args.steps,
+    seq, stats = eng.decode(prompt, spec, grammar, cfg, warmup_iters=args.warmup, timed_iters=args.steps,
                             on_timed_start=timed_start, on_timed_end=timed_end)
     prof = measure_k1(args, model, attn, device, kv_len=(kv_at.get("start", P) + stats.kv_len) // 2)
     prof_g1 = measure_g1(args, model, device) if (args.gemm == "sjd" and not args.no_fused) else None
@@ -218,17 +245,17 @@ def main():
     tps = tot_tokens / t_max
     tok_per_step = tot_tokens / max(tot_steps, 1)
     out = {
-        "metric": "accepted image-tokens/s (SJD, Lumina-mGPT-7B 768px); tokens_per_step = 1/steps-to-converge rate",
+        "metric": ("accepted image-tokens/s (SJD, Lumina-mGPT-7B 768px); tokens_per_step = 1/steps-to-converge rate" if args.model != "emu3_8b"
+                   else "accepted image-tokens/s (SJD, Emu3 720px, BASELINE.json config 3)"),
         "value": round(tps, 2), "unit": "image-tokens/s", "n_gpus": world, "steps": stats.timed_nfe, "warmup": args.warmup,
         "ms_per_step": round(t_max / max(stats.timed_nfe, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "fp16" if str(model.lm_head.weight.dtype).endswith("float16") and "bf" not in str(model.lm_head.weight.dtype) else "bf16",
+        "data": "synthetic",
         "tokens_per_step": round(tok_per_step, 4),
         "host_ms_per_step": round(stats.host_seconds / max(stats.timed_nfe, 1) * 1e3, 4),
         "sync_wait_ms_per_step": round(stats.sync_seconds / max(stats.timed_nfe, 1) * 1e3, 4),
         "nfe_full_image_est": round((n_img + 1) / tok_per_step, 1),
-        "config": {"workload": f"{'Lumina-mGPT-7B' if args.model == 'lumina7b' else args.model} 768x768, 1 prompt/GPU, "
-                               f"draft window {args.window}, CFG 3.0 (batch 2), top-k 2000, bf16, random-init synthetic weights "
-                               f"(embed_token_scale={args.embed_token_scale})",
+        "config": {"workload": workload + f", random-init synthetic weights (embed_token_scale={args.embed_token_scale})",
                    "prompt_len": P, "image_tokens": n_img, "kv_len_end": stats.kv_len, "prompts": world,
                    "parallelism": f"prompt-parallel x{world}"},
     }

@@ -260,6 +260,8 @@ def main():
                    "parallelism": f"prompt-parallel x{world}"},
     }
     def traffic_of(fname):
+        if args.model != "lumina7b":
+            return None                     # the committed PMC traffic files were collected at the Lumina-7B shapes
         tpath = os.path.join(ROOT, "profiles", fname)
         if os.path.exists(tpath):
             try:

@@ -199,9 +199,12 @@ def silu_mul(gate_up, rows=None, dtype=None):
 class HipWindowAttention:
     """Backbone attention backend = K3 append + K1 draft-window attention (the product path)."""
 
-    def __init__(self, n_split=8):
+    def __init__(self, n_split=None):
+        """n_split: static upper bound of key splits per (batch, kv head); None = enough to give the 256 CUs ~512 workgroups
+        (8 for MHA 2x32 heads, 32 for Emu3's 2x8 kv heads).  The kernel opens fewer splits for short contexts on its own."""
         L.load()
         self.n_split = n_split
+        self._auto_split = n_split is None
         self._ws = None
         self._key_start = None
         self.params = None          # DeviceBlob(IterParams) when the engine drives kv_len from the device
@@ -209,10 +212,16 @@ class HipWindowAttention:
         self.profile_records = []   # (ev0, ev1, algorithmic_bytes)
         self._ev_pool = []
 
+    def _resolve_split(self, B, Hkv):
+        if self._auto_split and self.n_split is None:
+            self.n_split = int(min(64, max(8, -(-512 // (B * Hkv)))))
+        return self.n_split
+
     def __call__(self, layer, q, k, v, cache, kv_len, key_start):
         B, n, H, D = q.shape
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         kc, vc = cache.k[layer], cache.v[layer]
+        self._resolve_split(B, kc.shape[1])
         if isinstance(key_start, torch.Tensor) and key_start.is_cuda and key_start.dtype == torch.int32:
             ks = key_start
         else:
@@ -245,6 +254,7 @@ class HipWindowAttention:
         """K1 only: the window's K/V rows were already written into the cache (fused F2 path)."""
         B, n, H, D = q.shape
         kc, vc = cache.k[layer], cache.v[layer]
+        self._resolve_split(B, kc.shape[1])
         need = L.load().sjd_attention_workspace_bytes(B, H, n, D, self.n_split) // 4
         if self._ws is None or self._ws.numel() < need or self._ws.device != q.device:
             self._ws = torch.empty(need, dtype=torch.float32, device=q.device)

@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--dtype", default=None, choices=[None, "bf16", "fp16"])
     ap.add_argument("--embed-token-scale", type=float, default=0.7)
     ap.add_argument("--window", type=int, default=16)
-    ap.add_argument("--n-split", type=int, default=8)
+    ap.add_argument("--n-split", type=int, default=0, help="K1 key splits (0 = auto from batch x kv heads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=12)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -55,7 +55,7 @@ def build_model(args, device):
         margs = BB.ChameleonArgs(vocab_size=65536, hidden_size=1024, intermediate_size=2048, num_hidden_layers=4,
                                  num_attention_heads=8, num_key_value_heads=8)
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype or ("fp16" if args.model == "emu3_8b" else "bf16")]
-    attn = ops.HipWindowAttention(n_split=args.n_split)
+    attn = ops.HipWindowAttention(n_split=args.n_split or None)
     with torch.device(device):
         model = BB.ChameleonBackbone(margs, attn=attn).to(dt).eval()
     if args.model == "emu3_8b":      # 64-row windows (draft window 32) need activation chunks <= 1280 columns
@@ -75,18 +75,19 @@ def measure_k1(args, model, attn, device, kv_len):
     import sjd_amd.ops as ops
     lib = L.load()
     B, n, H, D = 2, args.window, model.n_heads, model.head_dim
+    n_split = attn.n_split or 8
     nl = model.cache.k.shape[0]      # cycle over all layers' caches like a real iteration: ~40 MB/layer x 32 streams from HBM,
     kc, vc = model.cache.k, model.cache.v   # a single layer would sit in the 256 MB Infinity Cache
     q = torch.randn(B, n, H, D, device=device).to(kc.dtype)
     out = torch.empty_like(q)
     ks = torch.tensor([0, 0], dtype=torch.int32, device=device) if model.n_kv_heads != model.n_heads else torch.tensor([0, 63], dtype=torch.int32, device=device)
-    ws = ops.attention_workspace(B, H, n, D, args.n_split, device)
+    ws = ops.attention_workspace(B, H, n, D, n_split, device)
     evs = [(ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())) for _ in range(args.k1_launches)]
     for i in range(nl):
-        ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, kv_len, args.n_split, ws)
+        ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, kv_len, n_split, ws)
     torch.cuda.synchronize()
     for i, (e0, e1) in enumerate(evs):
-        ops.draft_window_attention(q, kc[i % nl], vc[i % nl], out, ks, None, kv_len, args.n_split, ws, e0, e1)
+        ops.draft_window_attention(q, kc[i % nl], vc[i % nl], out, ks, None, kv_len, n_split, ws, e0, e1)
     torch.cuda.synchronize()
     ms = [lib.sjd_event_elapsed_ms(e0, e1) for e0, e1 in evs]
     for e0, e1 in evs:

@@ -89,9 +89,14 @@ __global__ __launch_bounds__(256) void k1_partial(
     constexpr int KS = D / 32;            // k-steps of the QK^T product
     constexpr int DB = D / 16;            // 16-wide d blocks of the output
     constexpr int VROW = D + 8;           // padded LDS row (elements): 16-B aligned rows, breaks the 256-B bank period
-    __shared__ __attribute__((aligned(16))) unsigned short v_lds[K1_WAVES][K1_KT * VROW];
-    __shared__ float red_o[K1_WAVES][K1_ROWS][D];
-    __shared__ float red_ml[K1_WAVES][K1_ROWS][2];
+    // one LDS arena: the per-wave V tiles during the key loop, then (after a barrier) the fp32 merge buffers of the epilogue;
+    // aliasing them keeps the workgroup at ~35 KB so that four workgroups fit on a CU
+    constexpr int V_BYTES = K1_WAVES * K1_KT * VROW * 2;
+    constexpr int R_BYTES = K1_WAVES * K1_ROWS * (D + 2) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char arena[V_BYTES > R_BYTES ? V_BYTES : R_BYTES];
+    unsigned short (*v_lds)[K1_KT * VROW] = reinterpret_cast<unsigned short (*)[K1_KT * VROW]>(arena);
+    float (*red_o)[K1_ROWS][D] = reinterpret_cast<float (*)[K1_ROWS][D]>(arena);
+    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + K1_WAVES * K1_ROWS * D * 4);
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(256) void k1_partial(
     }
 
     // ---- merge the key-parts of each head inside the workgroup, then publish the split partial
+    __syncthreads();            // every wave is done with its V tile: the arena is reused for the merge buffers
     if (g == 0) { red_ml[w][c][0] = m_run; red_ml[w][c][1] = l_run; }
 #pragma unroll
     for (int db = 0; db < DB; ++db)

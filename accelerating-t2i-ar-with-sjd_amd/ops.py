@@ -212,16 +212,19 @@ class HipWindowAttention:
         self.profile_records = []   # (ev0, ev1, algorithmic_bytes)
         self._ev_pool = []
 
-    def _resolve_split(self, B, Hkv):
-        if self._auto_split and self.n_split is None:
-            self.n_split = int(min(64, max(8, -(-512 // (B * Hkv)))))
+    def _resolve_split(self, B, Hkv, n_rows=16):
+        """auto mode: about 512 workgroups per launch = B * H_kv * ceil(n_rows/16) * n_split (two per CU; the kernel is
+        VGPR-limited to two 4-wave workgroups per CU)."""
+        if self._auto_split:
+            chunks = (n_rows + 15) // 16
+            self.n_split = int(min(64, max(1, 512 // (B * Hkv * chunks))))
         return self.n_split
 
     def __call__(self, layer, q, k, v, cache, kv_len, key_start):
         B, n, H, D = q.shape
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         kc, vc = cache.k[layer], cache.v[layer]
-        self._resolve_split(B, kc.shape[1])
+        self._resolve_split(B, kc.shape[1], n)
         if isinstance(key_start, torch.Tensor) and key_start.is_cuda and key_start.dtype == torch.int32:
             ks = key_start
         else:
@@ -254,7 +257,7 @@ class HipWindowAttention:
         """K1 only: the window's K/V rows were already written into the cache (fused F2 path)."""
         B, n, H, D = q.shape
         kc, vc = cache.k[layer], cache.v[layer]
-        self._resolve_split(B, kc.shape[1])
+        self._resolve_split(B, kc.shape[1], n)
         need = L.load().sjd_attention_workspace_bytes(B, H, n, D, self.n_split) // 4
         if self._ws is None or self._ws.numel() < need or self._ws.device != q.device:
             self._ws = torch.empty(need, dtype=torch.float32, device=q.device)

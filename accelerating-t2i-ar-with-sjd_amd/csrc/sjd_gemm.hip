@@ -9,8 +9,9 @@
 //     is `steps` consecutive 1-KiB records, record s = the B operand of k-step s, lane l holding
 //     W[32t + (l&31)][k0 + 16s + 8(l>>5) .. +7].  A wave therefore reads ONE contiguous run of 16..64 KiB with
 //     1-KiB-per-instruction 16-byte loads straight into MFMA operand registers -- no LDS, no transposes, no address math;
-//   * the activation chunk x[:, k0:k0+KC] is staged once per workgroup in LDS in the same fragment-major order (A operand,
-//     conflict-free ds_read_b128), shared by the 8 waves (8 column tiles) of the workgroup;
+//   * the activation chunk x[:, k0:k0+KC] is staged once per workgroup in LDS in the same fragment-major order (A operand;
+//     coalesced global reads, a per-record slot permutation keeps both the ds_write_b128 and the ds_read_b128 side free of
+//     bank conflicts), shared by the 8 waves (8 column tiles) of the workgroup;
 //   * split-K over grid.y gives every CU several waves; the fp32 partials [n_chunks, 32, N] are summed by the CONSUMER
 //     kernel (F1 / F2 / F3 take n_chunks), so no reduction pass and no atomics;
 //   * loads are issued 8 k-steps ahead of their MFMA (register double buffer) and marked non-temporal (read once).
@@ -26,6 +27,14 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 #ifndef G1_UNROLL
 #define G1_UNROLL 8
 #endif
+
+// Slot of an A-fragment piece inside its 1-KiB record (lane l = 32 half + mm of the MFMA operand).  The 64 pieces are permuted
+// so that BOTH sides are bank-conflict free: the MFMA side reads a record with lanes = consecutive mm (fixed s), the staging
+// side writes with lanes = consecutive (s, half) of ONE row (fixed mm).
+__device__ __forceinline__ int g1_slot(int half, int mm, int s)
+{
+    return (half << 5) | (mm & 16) | ((mm & 15) ^ (((s & 7) << 1) | half));
+}
 
 template <int DT> struct G1Mfma;
 template <> struct G1Mfma<SJD_DTYPE_BF16> {
@@ -67,13 +76,14 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
 #pragma unroll
         for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);
     }
-    // stage the activation chunk in A-fragment order: piece (mt, s, l) = x[32mt + (l&31)][k0 + 16s + 8(l>>5) .. +7]
-    for (int p = threadIdx.x; p < MT * steps * 64; p += blockDim.x) {
-        const int mt = p / (steps * 64), q = p - mt * steps * 64;
-        const int s = q >> 6, l = q & 63, m = 32 * mt + (l & 31);
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (m < M) v = *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + 16 * s + 8 * (l >> 5));
-        xl[p] = v;
+    // stage the activation chunk in A-fragment order: the piece of (row m, k-step s, half) = x[m][k0 + 16s + 8 half .. +7] goes
+    // to record (mt, s), slot g1_slot(half, m % 32, s).  Pieces are walked in ROW order (coalesced 16-byte reads along k).
+    const int ppr = 2 * steps;                                    // pieces per row of the chunk
+    for (int v = threadIdx.x; v < MT * 32 * ppr; v += blockDim.x) {
+        const int m = v / ppr, j = v - m * ppr, s = j >> 1;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (m < M) val = *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + 8 * j);
+        xl[((m >> 5) * steps + s) * 64 + g1_slot(j & 1, m & 31, s)] = val;
     }
     __syncthreads();
     if (!has_tile) return;
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
         for (int u = 0; u < G1_UNROLL; ++u)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = G1Mfma<DT>::mma(xl[mt * xs + (g * G1_UNROLL + u) * 64 + lane], cur[u], acc[mt]);
+                acc[mt] = G1Mfma<DT>::mma(xl[mt * xs + (g * G1_UNROLL + u) * 64 + g1_slot(lane >> 5, lane & 31, u)], cur[u], acc[mt]);
         if (more) {
 #pragma unroll
             for (int u = 0; u < G1_UNROLL; ++u) cur[u] = nxt[u];
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
     for (int s = full * G1_UNROLL; s < steps; ++s) {    // ragged tail (K chunk not a multiple of 128)
         const u32x4 wv = __builtin_nontemporal_load(wu + (size_t)s * rs);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(xl[mt * xs + s * 64 + lane], wv, acc[mt]);
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(xl[mt * xs + s * 64 + g1_slot(lane >> 5, lane & 31, s)], wv, acc[mt]);
     }
 
     // D[m][n]: reg r of lane l -> row m = (r&3) + 8*(r>>2) + 4*(l>>5), column n = 32t + (l&31): 128-B coalesced rows

@@ -18,6 +18,45 @@ import sjd_amd.ops as ops  # noqa: E402
 SHAPES = dict(qkv=(12288, 4096, 1024), o=(4096, 4096, 512), gate_up=(22016, 4096, 2048), down=(4096, 11008, 1024))
 
 
+def timed_batched(fn, n, lib):
+    """n back-to-back launches between ONE event pair: the command processor pipelines the dispatches, as inside a hipGraph."""
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    hip = ctypes.CDLL("libamdhip64.so")
+    e0, e1 = ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())
+    res = []
+    for rep in range(3):
+        hip.hipEventRecord(e0, stream)
+        for i in range(n):
+            fn(i)
+        hip.hipEventRecord(e1, stream)
+        torch.cuda.synchronize()
+        res.append(lib.sjd_event_elapsed_ms(e0, e1) / n)
+    return min(res), sorted(res)[1]
+
+
+def timed_graph(fn, n, lib):
+    """n launches captured in one hipGraph and replayed: no host launch cost, the conditions of the engine's forward graph."""
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        fn(0)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(n):
+            fn(i)
+    g.replay()
+    torch.cuda.synchronize()
+    res = []
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / n)
+    return min(res), sorted(res)[1]
+
+
 def timed(fn, n, lib):
     evs = [(ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())) for _ in range(n)]
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -40,6 +79,9 @@ def main():
     ap.add_argument("--waves", type=int, default=4)
     ap.add_argument("--no-blas", action="store_true")
     ap.add_argument("--step-major", type=int, default=0)
+    ap.add_argument("--batched", action="store_true", help="back-to-back eager launches, one event pair (host launch rate bound for short kernels)")
+    ap.add_argument("--per-launch", action="store_true", help="one event pair per launch (includes ~4 us dispatch latency)")
+    ap.add_argument("--product", action="store_true", help="per-shape (KC, waves, layout) of backbones.G1_CFG")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     if os.environ.get("SJD_SO"):
@@ -49,6 +91,10 @@ def main():
         if a.only and name != a.only:
             continue
         KC = a.kc or KC
+        if a.product:
+            import sjd_amd.backbones as BB
+            KC, a.waves, sm = BB.ChameleonBackbone.G1_CFG[name]
+            a.step_major = int(sm)
         x = torch.randn(32, K, device=dev).to(torch.bfloat16)
         ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16) for _ in range(a.copies)]
         wps = [ops.pack_weight(w, KC, bool(a.step_major)) for w in ws]
@@ -71,7 +117,7 @@ def main():
         r = dict(shape=name, N=N, K=K, KC=KC, weight_MB=round(bytes_w / 1e6, 1))
         r["waves"], r["step_major"] = a.waves, a.step_major
         for tag, f in ((("g1", g1),) if a.no_blas else (("g1", g1), ("hipblaslt", blas))):
-            avg, med = timed(f, a.launches, lib)
+            avg, med = (timed if a.per_launch else timed_batched if a.batched else timed_graph)(f, a.launches, lib)
             r[tag + "_us"] = round(avg * 1e3, 2)
             r[tag + "_TBps"] = round(bytes_w / 1e12 / (avg / 1e3), 3)
         print(json.dumps(r), flush=True)

@@ -358,6 +358,20 @@ class ChameleonBackbone(nn.Module):
         self._inv_freq32 = self.inv_freq.float().contiguous()
         return self
 
+    def _f2(self, qkv, li, qn, pos, B, n, params, kv_len):
+        """F2 (QK-norm + RoPE + KV append).  An fp8 cache takes the rows through a bf16 staging block and the quantising K3."""
+        ops, H, Hkv, D = self._ops, self.n_heads, self.n_kv_heads, self.head_dim
+        kc, vc = self.cache.k[li], self.cache.v[li]
+        if kc.dtype != ops.FP8:
+            return ops.qknorm_rope_append(qkv, kc, vc, *qn, self._inv_freq32, pos, B, n, H, Hkv, D, params, kv_len if params is None else 0)
+        dt = self.lm_head.weight.dtype
+        ks = torch.empty(B, Hkv, n, D, dtype=dt, device=kc.device)
+        vs = torch.empty_like(ks)
+        q = ops.qknorm_rope_append(qkv, ks, vs, *qn, self._inv_freq32, pos, B, n, H, Hkv, D, None, 0)
+        sk, sv = getattr(self.attn, "kv_scale", (1.0, 1.0))
+        ops.kv_append_fp8(ks, vs, kc, vc, sk, sv, params, kv_len if params is None else 0, head_major=True)
+        return q
+
     def _forward_window_g1(self, tokens, positions, kv_len, key_start):
         """Window forward (B*n <= 32 rows) with the four per-layer projections on kernel G1; split-K partials flow straight
         into the consuming glue kernel (F2 / F1 / F3 / F1)."""
@@ -377,8 +391,7 @@ class ChameleonBackbone(nn.Module):
             x = ops.add_rmsnorm(h, delta, layer.input_layernorm.weight, eps)
             qkv = g1(x, "qkv", (H + 2 * Hkv) * D, hid)
             qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
-            q = ops.qknorm_rope_append(qkv, self.cache.k[li], self.cache.v[li], *qn, self._inv_freq32, pos, B, n, H, Hkv, D,
-                                       params, kv_len if params is None else 0)
+            q = self._f2(qkv, li, qn, pos, B, n, params, kv_len)
             o = self.attn.attend(li, q, self.cache, kv_len, key_start)
             attn_out = g1(o.view(T, H * D), "o", hid, H * D)
             x = ops.add_rmsnorm(h, attn_out, layer.post_attention_layernorm.weight, eps)
@@ -404,8 +417,7 @@ class ChameleonBackbone(nn.Module):
             x = ops.add_rmsnorm(h, delta, layer.input_layernorm.weight, eps)
             qkv = F.linear(x, qkv_w)
             qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
-            q = ops.qknorm_rope_append(qkv, self.cache.k[li], self.cache.v[li], *qn, self._inv_freq32, pos, B, n, H, Hkv, D,
-                                       params, kv_len if params is None else 0)
+            q = self._f2(qkv, li, qn, pos, B, n, params, kv_len)
             o = self.attn.attend(li, q, self.cache, kv_len, key_start)
             attn_out = F.linear(o.view(T, H * D), a.o_proj.weight)
             x = ops.add_rmsnorm(h, attn_out, layer.post_attention_layernorm.weight, eps)

@@ -319,6 +319,253 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
     for (int j = 0; j < PER; ++j) o[j] = Frag<DT>::cvt(acc[j] * inv);
 }
 
+// ------------------------------------------------------------------------------------------------ K1 (fp8 KV)
+// BASELINE config 5: the KV cache is stored as OCP fp8 e4m3 (value = fp8 * scale, one scale per tensor), which halves the
+// bytes K1 streams, and both contractions run on v_mfma_f32_16x16x32_fp8_fp8:
+//   S^T = K Q^T : K bytes go straight from HBM into the A operand (lane (key c, group g) takes the 16 bytes
+//                 d = 64p + 16g .. +15 of its key row: first half = k-step 2p, second half = k-step 2p+1); q is converted to
+//                 fp8 once, in the matching order;
+//   O^T += V^T P^T : P is scaled by 256 and rounded to fp8 (keeps the softmax tail out of the e4m3 subnormals), V bytes
+//                 pass through a per-wave LDS tile and come back transposed with ds_read_b64_tr_b8 (lane i of a 16-lane
+//                 group points at row i/2, columns 8(i%2).. of an 8-key x 16-d byte block; lane c receives column c).
+// Everything else (tile ranges, online softmax, masks, merge, workspace layout, k1_combine) is shared with k1_partial.
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d)
+{
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+__device__ __forceinline__ long as_long(unsigned lo, unsigned hi) { return (long)(((unsigned long long)hi << 32) | lo); }
+
+template <int DT> __device__ __forceinline__ float k1_to_f32(unsigned short h);
+template <> __device__ __forceinline__ float k1_to_f32<SJD_DTYPE_BF16>(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+template <> __device__ __forceinline__ float k1_to_f32<SJD_DTYPE_F16>(unsigned short h) { return (float)(*reinterpret_cast<_Float16 *>(&h)); }
+
+template <int DT, int D>
+__global__ __launch_bounds__(256) void k1_partial_fp8(
+    const unsigned short *__restrict__ q, const unsigned char *__restrict__ kc, const unsigned char *__restrict__ vc,
+    float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max,
+    const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks,
+    float k_scale, float v_scale)
+{
+    constexpr int KP = D / 64;            // 16-byte K pieces per key row and lane group = pairs of k-steps
+    constexpr int DB = D / 16;            // 16-wide d blocks of the output
+    constexpr int VROW = D + 16;          // padded LDS row in bytes (16-B aligned rows, breaks the 128-B bank period)
+    constexpr float PSCALE = 256.0f;
+    constexpr int V_BYTES = K1_WAVES * K1_KT * VROW;
+    constexpr int R_BYTES = K1_WAVES * K1_ROWS * (D + 2) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char arena[V_BYTES > R_BYTES ? V_BYTES : R_BYTES];
+    float (*red_o)[K1_ROWS][D] = reinterpret_cast<float (*)[K1_ROWS][D]>(arena);
+    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + K1_WAVES * K1_ROWS * D * 4);
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int G = H / H_kv;
+    const int kparts = K1_WAVES / G;
+    const int head_in_group = w % G, kpart = w / G;
+    const int chunk = blockIdx.x / n_split, split = blockIdx.x % n_split;
+    const int hkv = blockIdx.y, b = blockIdx.z;
+    const int head = hkv * G + head_in_group;
+    unsigned char *vl = arena + (size_t)w * K1_KT * VROW;
+
+    const int kv_base = params ? params->kv_len : kv_len_arg;
+    const int n_total = params ? params->n_rows : n_rows;
+    const int row0 = chunk * K1_ROWS;
+    const int n_c = min(K1_ROWS, n_total - row0);
+    const int kv_len = kv_base + row0;
+    const int total = kv_len + max(n_c, 0);
+    const int kstart = key_start ? key_start[b] : 0;
+    const float scale = rsqrtf((float)D) * k_scale;
+
+    int t_lo, t_hi, eff_split, tps;
+    k1_tile_range(kstart, total, n_split, t_lo, t_hi, eff_split, tps);
+    if (split >= eff_split) return;
+    const int t_begin = t_lo + split * tps, t_end = min(t_hi, t_begin + tps);
+
+    // Q (B operand) as fp8: lane (row c, group g), pair p: d = 64p + 16g .. +15 -> two 8-byte k-step operands
+    long qf[KP][2];
+    {
+        const bool rv = (c < n_c);
+        const unsigned short *qp = q + (((size_t)b * n_rows + (row0 + (rv ? c : 0))) * H + head) * D + 16 * g;
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            unsigned wds[4] = {0u, 0u, 0u, 0u};
+            if (rv) {
+                const u32x4 lo = *reinterpret_cast<const u32x4 *>(qp + 64 * p), hi = *reinterpret_cast<const u32x4 *>(qp + 64 * p + 8);
+                float f[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f[2 * i] = k1_to_f32<DT>((unsigned short)(lo[i] & 0xffffu)); f[2 * i + 1] = k1_to_f32<DT>((unsigned short)(lo[i] >> 16));
+                    f[8 + 2 * i] = k1_to_f32<DT>((unsigned short)(hi[i] & 0xffffu)); f[8 + 2 * i + 1] = k1_to_f32<DT>((unsigned short)(hi[i] >> 16));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wds[i] = pack4_fp8(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+            }
+            qf[p][0] = as_long(wds[0], wds[1]);
+            qf[p][1] = as_long(wds[2], wds[3]);
+        }
+    }
+    const unsigned char *kbase = kc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
+    const unsigned char *vbase = vc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x4 o_acc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int VP = K1_KT * D / (64 * 16);     // 16-B pieces per lane for one V tile
+    constexpr int LPR = D / 16;                   // lanes per V row
+    u32x4 kreg[2][KP], kn[2][KP], vstage[VP];
+
+    auto load_tile = [&](int t, u32x4 (&kd)[2][KP], u32x4 (&vd)[VP]) {
+        const unsigned char *kt = kbase + (size_t)(t * K1_KT) * D;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int p = 0; p < KP; ++p)
+                kd[kb][p] = *reinterpret_cast<const u32x4 *>(kt + (size_t)(16 * kb + c) * D + 64 * p + 16 * g);
+        const unsigned char *vt = vbase + (size_t)(t * K1_KT) * D;
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            int idx = i * 64 + lane;
+            vd[i] = *reinterpret_cast<const u32x4 *>(vt + (size_t)(idx / LPR) * D + 16 * (idx % LPR));
+        }
+    };
+    // bytes of keys >= total are never visible (p = 0) but may decode to NaN: zero them while staging
+    auto store_v = [&](int t, u32x4 (&vd)[VP]) {
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            int idx = i * 64 + lane;
+            const bool live = (t * K1_KT + idx / LPR) < total;
+            *reinterpret_cast<u32x4 *>(vl + (idx / LPR) * VROW + 16 * (idx % LPR)) = live ? vd[i] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    // transposed V operand: element j of lane group g is key 16(j/4) + 4g + (j%4) (the order the S^T accumulators hold P in)
+    const int jrow = c >> 1;
+    const unsigned char *vrd = vl + (16 * (jrow >> 2) + 4 * g + (jrow & 3)) * VROW + 8 * (c & 1);
+
+    int t = t_begin + kpart;
+    if (t < t_end) {
+        load_tile(t, kreg, vstage);
+        store_v(t, vstage);
+    }
+    for (; t < t_end; t += kparts) {
+        const int tn = t + kparts;
+        const bool has_next = tn < t_end;
+        if (has_next) load_tile(tn, kn, vstage);
+
+        f32x4 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long(kreg[kb][p][0], kreg[kb][p][1]), qf[p][0], st[kb], 0, 0, 0);
+                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long(kreg[kb][p][2], kreg[kb][p][3]), qf[p][1], st[kb], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = t * K1_KT + 16 * kb + 4 * g + r;
+                bool vis = (key >= kstart) && (key <= kv_len + c) && (key < total);
+                float sv = vis ? st[kb][r] * scale : -INFINITY;
+                st[kb][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+        const float alpha = __expf(m_run - m_safe);
+        float rs = 0.0f, pv[8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(st[kb][r] - m_safe);
+                rs += e;
+                pv[4 * kb + r] = e * PSCALE;
+            }
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        const long pfrag = as_long(pack4_fp8(pv[0], pv[1], pv[2], pv[3]), pack4_fp8(pv[4], pv[5], pv[6], pv[7]));
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const i32x2 vv = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2 *)(vrd + 16 * db));
+            f32x4 acc = o_acc[db];
+            acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+            o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long((unsigned)vv[0], (unsigned)vv[1]), pfrag, acc, 0, 0, 0);
+        }
+        if (has_next) {
+            store_v(tn, vstage);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int p = 0; p < KP; ++p) kreg[kb][p] = kn[kb][p];
+        }
+    }
+
+    __syncthreads();
+    const float oscale = v_scale / PSCALE;
+    if (g == 0) { red_ml[w][c][0] = m_run; red_ml[w][c][1] = l_run; }
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red_o[w][c][16 * db + 4 * g + r] = o_acc[db][r] * oscale;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < G * K1_ROWS * D; idx += 256) {
+        const int hg = idx / (K1_ROWS * D), row = (idx / D) % K1_ROWS, d = idx % D;
+        float M = -INFINITY;
+        for (int kp = 0; kp < kparts; ++kp) M = fmaxf(M, red_ml[kp * G + hg][row][0]);
+        const float Ms = (M == -INFINITY) ? 0.0f : M;
+        float L = 0.f, O = 0.f;
+        for (int kp = 0; kp < kparts; ++kp) {
+            const int ww = kp * G + hg;
+            const float wgt = __expf(red_ml[ww][row][0] - Ms);
+            L += wgt * red_ml[ww][row][1];
+            O += wgt * red_o[ww][row][d];
+        }
+        const size_t slot = ((((size_t)b * H + (hkv * G + hg)) * n_chunks + chunk) * n_split + split) * K1_ROWS + row;
+        ws_o[slot * D + d] = O;
+        if (d == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = L; }
+    }
+}
+
+// K3 for an fp8 cache: rows [kv_len, kv_len + n) <- fp8(x / scale); one thread converts 8 values (16 B in, 8 B out)
+template <int DT>
+__global__ void k3_kv_append_fp8(const u32x4 *__restrict__ k_new, const u32x4 *__restrict__ v_new, u32x2 *__restrict__ k_cache,
+                                 u32x2 *__restrict__ v_cache, int B, int n_rows, int H_kv, int D8, int S_max,
+                                 const sjd_iter_params *__restrict__ params, int kv_len_arg, float k_inv, float v_inv, int head_major)
+{
+    const int kv_len = params ? params->kv_len : kv_len_arg;
+    const size_t total = (size_t)B * n_rows * H_kv * D8;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = i % D8;
+        const int h = (i / D8) % H_kv;
+        const int r = (i / ((size_t)D8 * H_kv)) % n_rows;
+        const int b = i / ((size_t)D8 * H_kv * n_rows);
+        if (kv_len + r >= S_max) continue;
+        const size_t dst = (((size_t)b * H_kv + h) * S_max + (kv_len + r)) * D8 + d;
+        const size_t src = head_major ? (((size_t)b * H_kv + h) * n_rows + r) * D8 + d : i;     // [B, H_kv, n, D] or [B, n, H_kv, D]
+        const u32x4 kv = k_new[src], vv = v_new[src];
+        float kf[8], vf[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kf[2 * j] = k1_to_f32<DT>((unsigned short)(kv[j] & 0xffffu)) * k_inv; kf[2 * j + 1] = k1_to_f32<DT>((unsigned short)(kv[j] >> 16)) * k_inv;
+            vf[2 * j] = k1_to_f32<DT>((unsigned short)(vv[j] & 0xffffu)) * v_inv; vf[2 * j + 1] = k1_to_f32<DT>((unsigned short)(vv[j] >> 16)) * v_inv;
+        }
+        k_cache[dst] = u32x2{pack4_fp8(kf[0], kf[1], kf[2], kf[3]), pack4_fp8(kf[4], kf[5], kf[6], kf[7])};
+        v_cache[dst] = u32x2{pack4_fp8(vf[0], vf[1], vf[2], vf[3]), pack4_fp8(vf[4], vf[5], vf[6], vf[7])};
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K1 (fp32)
 // Exact-fp32 variant for small parity runs (reproducing the reference's fp32 CPU token sequences on the GPU): one wave64 per
 // (batch, head, query row), two passes over the visible keys, fp32 FMA dot products.  Same visibility rule as k1_partial.
@@ -449,6 +696,62 @@ extern "C" int sjd_draft_window_attention(const void *q, const void *k_cache, co
 {
     return sjd_draft_window_attention_ex(q, k_cache, v_cache, out, B, n_rows, H, H_kv, D, S_max, dtype, key_start, params, kv_len,
                                          n_split, workspace, stream, nullptr, nullptr);
+}
+
+extern "C" int sjd_kv_append_fp8(const void *k_new, const void *v_new, void *k_cache, void *v_cache, int B, int n_rows, int H_kv, int D,
+                                 int S_max, int dtype, float k_scale, float v_scale, int head_major, const sjd_iter_params *params, int kv_len,
+                                 void *stream)
+{
+    if (!k_new || !v_new || !k_cache || !v_cache || B < 1 || n_rows < 1 || H_kv < 1 || (D % 8) != 0 || S_max < 1 || !(k_scale > 0.f) || !(v_scale > 0.f))
+        return SJD_ERR_BAD_ARG;
+    const size_t total = (size_t)B * n_rows * H_kv * (D / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SJD_DTYPE_BF16)
+        hipLaunchKernelGGL(k3_kv_append_fp8<SJD_DTYPE_BF16>, dim3(blocks), dim3(256), 0, s, (const u32x4 *)k_new, (const u32x4 *)v_new, (u32x2 *)k_cache,
+                           (u32x2 *)v_cache, B, n_rows, H_kv, D / 8, S_max, params, kv_len, 1.0f / k_scale, 1.0f / v_scale, head_major);
+    else if (dtype == SJD_DTYPE_F16)
+        hipLaunchKernelGGL(k3_kv_append_fp8<SJD_DTYPE_F16>, dim3(blocks), dim3(256), 0, s, (const u32x4 *)k_new, (const u32x4 *)v_new, (u32x2 *)k_cache,
+                           (u32x2 *)v_cache, B, n_rows, H_kv, D / 8, S_max, params, kv_len, 1.0f / k_scale, 1.0f / v_scale, head_major);
+    else return SJD_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+template <int DT, int D>
+static int launch_attention_fp8(const void *q, const void *kc, const void *vc, void *out, int B, int n_rows, int H, int H_kv, int S_max,
+                                float k_scale, float v_scale, const int32_t *key_start, const sjd_iter_params *params, int kv_len, int n_split,
+                                void *workspace, hipStream_t stream)
+{
+    const int n_chunks = (n_rows + K1_ROWS - 1) / K1_ROWS;
+    float *ws_o = (float *)workspace;
+    float *ws_ml = ws_o + (size_t)B * H * n_chunks * n_split * K1_ROWS * D;
+    hipLaunchKernelGGL((k1_partial_fp8<DT, D>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
+                       (const unsigned char *)kc, (const unsigned char *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
+                       kv_len, n_split, n_chunks, k_scale, v_scale);
+    if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
+    hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
+                       n_split, n_chunks, params, key_start, kv_len);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_draft_window_attention_fp8(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
+                                              int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
+                                              const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream)
+{
+    if (!q || !k_cache || !v_cache || !out || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
+    if (H % H_kv != 0 || (S_max % K1_KT) != 0 || !(k_scale > 0.f) || !(v_scale > 0.f)) return SJD_ERR_BAD_ARG;
+    const int G = H / H_kv;
+    if (!(G == 1 || G == 2 || G == 4)) return SJD_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+#define SJD_K1F8_CASE(DT_, D_) \
+    if (dtype == DT_ && D == D_) return launch_attention_fp8<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, k_scale, v_scale, key_start, params, kv_len, n_split, workspace, s);
+    SJD_K1F8_CASE(SJD_DTYPE_BF16, 128)
+    SJD_K1F8_CASE(SJD_DTYPE_BF16, 64)
+    SJD_K1F8_CASE(SJD_DTYPE_F16, 128)
+    SJD_K1F8_CASE(SJD_DTYPE_F16, 64)
+#undef SJD_K1F8_CASE
+    return SJD_ERR_UNSUPPORTED;
 }
 
 extern "C" void *sjd_event_create(void)

@@ -98,6 +98,37 @@ def kv_append(k_new, v_new, k_cache, v_cache, params, kv_len):
                                   int(kv_len), _stream()), "sjd_kv_append")
 
 
+FP8 = torch.float8_e4m3fn      # OCP e4m3: the fp8 KV-cache element type (BASELINE config 5)
+
+
+def kv_append_fp8(k_new, v_new, k_cache, v_cache, k_scale, v_scale, params, kv_len, head_major=False):
+    """k_new/v_new bf16/fp16 [B,n,Hkv,D] (or [B,Hkv,n,D] with head_major) -> fp8(x / scale) rows [kv_len, kv_len+n) of the
+    fp8 caches [B,Hkv,S,D]."""
+    if head_major:
+        B, Hkv, n, D = k_new.shape
+    else:
+        B, n, Hkv, D = k_new.shape
+    assert k_cache.dtype == FP8 and v_cache.dtype == FP8 and k_new.is_contiguous() and v_new.is_contiguous()
+    assert k_cache.is_contiguous() and v_cache.is_contiguous()
+    L.check(L.load().sjd_kv_append_fp8(_ptr(k_new), _ptr(v_new), _ptr(k_cache), _ptr(v_cache), B, n, Hkv, D, k_cache.shape[2],
+                                      _dtype_code(k_new.dtype), float(k_scale), float(v_scale), int(head_major),
+                                      params.ptr if params is not None else None, int(kv_len), _stream()), "sjd_kv_append_fp8")
+
+
+def draft_window_attention_fp8(q, k_cache, v_cache, out, k_scale, v_scale, key_start, params, kv_len, n_split, workspace):
+    """K1 over fp8 caches [B,Hkv,S,D] (value = fp8 * scale); q/out bf16/fp16 [B,n,H,D]."""
+    B, n, H, D = q.shape
+    assert q.is_contiguous() and out.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert k_cache.dtype == FP8 and v_cache.dtype == FP8
+    assert key_start is None or (key_start.dtype == torch.int32 and key_start.is_cuda)
+    need = L.load().sjd_attention_workspace_bytes(B, H, n, D, n_split)
+    assert workspace.numel() * 4 >= need, "attention workspace too small"
+    L.check(L.load().sjd_draft_window_attention_fp8(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), B, n, H, k_cache.shape[1], D,
+                                                   k_cache.shape[2], _dtype_code(q.dtype), float(k_scale), float(v_scale),
+                                                   _ptr(key_start), params.ptr if params is not None else None, int(kv_len),
+                                                   int(n_split), _ptr(workspace), _stream()), "sjd_draft_window_attention_fp8")
+
+
 def attention_workspace(B, H, n_rows, D, n_split, device):
     nbytes = L.load().sjd_attention_workspace_bytes(B, H, n_rows, D, n_split)
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
@@ -211,20 +242,23 @@ class HipWindowAttention:
         self.profile_layer = None   # int: time k1_partial of that layer with HIP events (bench.py roofline leg)
         self.profile_records = []   # (ev0, ev1, algorithmic_bytes)
         self._ev_pool = []
+        self.kv_scale = (1.0, 1.0)  # (k, v) scales of an fp8 cache: stored byte = fp8(x / scale)
 
-    def _resolve_split(self, B, Hkv, n_rows=16):
-        """auto mode: about 512 workgroups per launch = B * H_kv * ceil(n_rows/16) * n_split (two per CU; the kernel is
-        VGPR-limited to two 4-wave workgroups per CU)."""
+    def _resolve_split(self, B, Hkv, n_rows=16, H=None):
+        """auto mode: one workgroup per CU for MHA (256 = B * H_kv * ceil(n_rows/16) * n_split; tools/k1_bench.py --graph: 4 splits
+        22.3 us vs 8 splits 24.7 us per layer at kv_len 1216), two per CU for GQA, whose workgroups share each K/V tile between
+        the q-heads of a group and are VGPR-limited to two per CU."""
         if self._auto_split:
             chunks = (n_rows + 15) // 16
-            self.n_split = int(min(64, max(1, 512 // (B * Hkv * chunks))))
+            target = 256 if (H is None or H == Hkv) else 512
+            self.n_split = int(min(64, max(1, target // (B * Hkv * chunks))))
         return self.n_split
 
     def __call__(self, layer, q, k, v, cache, kv_len, key_start):
         B, n, H, D = q.shape
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         kc, vc = cache.k[layer], cache.v[layer]
-        self._resolve_split(B, kc.shape[1], n)
+        self._resolve_split(B, kc.shape[1], n, H)
         if isinstance(key_start, torch.Tensor) and key_start.is_cuda and key_start.dtype == torch.int32:
             ks = key_start
         else:
@@ -234,6 +268,10 @@ class HipWindowAttention:
             self._ws = torch.empty(need, dtype=torch.float32, device=q.device)
         out = torch.empty_like(q)
         kv_host = 0 if self.params is not None else int(kv_len)
+        if kc.dtype == FP8:
+            kv_append_fp8(k, v, kc, vc, self.kv_scale[0], self.kv_scale[1], self.params, kv_host)
+            draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], ks, self.params, kv_host, self.n_split, self._ws)
+            return out
         kv_append(k, v, kc, vc, self.params, kv_host)
         ev0 = ev1 = None
         if self.profile_layer is not None and layer == self.profile_layer and n <= 32:
@@ -257,13 +295,16 @@ class HipWindowAttention:
         """K1 only: the window's K/V rows were already written into the cache (fused F2 path)."""
         B, n, H, D = q.shape
         kc, vc = cache.k[layer], cache.v[layer]
-        self._resolve_split(B, kc.shape[1], n)
+        self._resolve_split(B, kc.shape[1], n, H)
         need = L.load().sjd_attention_workspace_bytes(B, H, n, D, self.n_split) // 4
         if self._ws is None or self._ws.numel() < need or self._ws.device != q.device:
             self._ws = torch.empty(need, dtype=torch.float32, device=q.device)
         out = torch.empty_like(q)
         kv_host = 0 if self.params is not None else int(kv_len)
-        draft_window_attention(q, kc, vc, out, key_start, self.params, kv_host, self.n_split, self._ws)
+        if kc.dtype == FP8:
+            draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], key_start, self.params, kv_host, self.n_split, self._ws)
+        else:
+            draft_window_attention(q, kc, vc, out, key_start, self.params, kv_host, self.n_split, self._ws)
         return out
 
     def profile_summary(self):

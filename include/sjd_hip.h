@@ -154,6 +154,17 @@ int sjd_gemm_num_chunks(int K, int KC);
 int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,
                     int dtype, void *stream);
 
+/* K1 / K3 over an fp8 KV cache (BASELINE config 5; there is no fp8 in the reference -- the parity target is the bf16 result
+ * within tolerance): the cache holds OCP e4m3 bytes, value = fp8 * scale with one scale per tensor; q / out keep `dtype` (bf16/f16).
+ * Half the KV bytes of sjd_draft_window_attention, both contractions on v_mfma_f32_16x16x32_fp8_fp8.  Other arguments as the
+ * 16-bit entry points (replaces the same reference call sites, modeling_chameleon.py:499-581 / DynamicCache.update). */
+int sjd_kv_append_fp8(const void *k_new, const void *v_new, void *k_cache, void *v_cache, int B, int n_rows, int H_kv, int D, int S_max,
+                      int dtype, float k_scale, float v_scale, int head_major /* new rows [B,H_kv,n,D] instead of [B,n,H_kv,D] */,
+                      const sjd_iter_params *params, int kv_len, void *stream);
+int sjd_draft_window_attention_fp8(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H, int H_kv,
+                                   int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
+                                   const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream);
+
 /* HIP event helpers so that a ctypes host can time kernels on the stream they run on. */
 void *sjd_event_create(void);
 void sjd_event_destroy(void *ev);

@@ -95,7 +95,7 @@ def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7,
 @torch.no_grad()
 def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, scheme="speculative_jacobi", P=12,
                                 embed_token_scale=0.25, kv_heads=4, l=3, r=None, dtype=torch.bfloat16,
-                                use_graph=False, fused=True):
+                                use_graph=False, fused=True, gemm="torch", fp8_kv=False):
     import sjd_amd.ops as ops
     import sjd_amd.synthetic as synthetic
     from sjd_amd.engine import SJDEngine, SJDConfig, WindowSpec
@@ -106,12 +106,12 @@ def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, 
                 num_key_value_heads=kv_heads, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
     model = make_chameleon(conf, 23, embed_token_scale, ops.HipWindowAttention(n_split=2), dtype=dtype, device=device)
     if fused:
-        model.enable_fused(ops)
+        model.enable_fused(ops, gemm=gemm)
     prompt = torch.cat([synthetic.synthetic_prompt(P - 3, seed, lo=8900, hi=9200),
                         torch.tensor([[8197, 8804 + hg, 8804 + wg]])], dim=1)
     n_img = (2 * wg + 1) * 2 * hg
     max_len = P + n_img + 1 + 4
-    model.setup_cache(batch=2, s_max=((max_len + 64 + 31) // 32) * 32)
+    model.setup_cache(batch=2, s_max=((max_len + 64 + 31) // 32) * 32, dtype=ops.FP8 if fp8_kv else None)
     r = r if r is not None else (2 * wg + 1) * 2 * hg - 10
     cfg = SJDConfig(jacobi_loop_interval_l=l, jacobi_loop_interval_r=r, max_num_new_tokens=window, guidance_scale=3.0,
                     seed=seed, prefix_token_sampler_scheme=scheme, max_length=max_len, eos_token_ids=(8196,))

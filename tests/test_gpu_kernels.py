@@ -296,3 +296,75 @@ def test_k1_ignores_nan_beyond_the_valid_cache_length(dev):
     assert torch.isfinite(out).all()
     assert (out[:, n:] == 0).all()
     assert (out[:, :n] - ref).abs().max() < 3e-2
+
+
+FP8_CASES = [
+    # name, B, H, Hkv, D, S_max, kv_len, n, key_start, dtype, (k_scale, v_scale)
+    ("fp8_mha_d128_mid", 2, 4, 4, 128, 1280, 1216, 16, [0, 59], torch.bfloat16, (1.0, 1.0)),
+    ("fp8_mha_d128_empty_cache", 2, 4, 4, 128, 128, 0, 16, [0, 0], torch.bfloat16, (1.0, 1.0)),
+    ("fp8_mha_d128_unaligned_scaled", 2, 2, 2, 128, 256, 77, 16, [0, 33], torch.bfloat16, (0.5, 2.0)),
+    ("fp8_short_window", 2, 2, 2, 128, 256, 100, 5, [0, 10], torch.float16, (1.0, 0.25)),
+    ("fp8_gqa4_d128", 2, 8, 2, 128, 1056, 1000, 16, [3, 0], torch.float16, (1.0, 1.0)),
+    ("fp8_gqa2_window32", 1, 4, 2, 128, 512, 300, 32, [0], torch.bfloat16, (1.0, 1.0)),
+    ("fp8_mha_d64", 2, 12, 12, 64, 288, 200, 16, [0, 0], torch.bfloat16, (1.0, 1.0)),
+]
+
+
+@pytest.mark.parametrize("case", FP8_CASES, ids=[c[0] for c in FP8_CASES])
+@pytest.mark.parametrize("n_split", [1, 8])
+def test_k1_k3_fp8_kv_cache(dev, case, n_split):
+    """BASELINE config 5: K3 quantises the new rows to OCP e4m3 exactly like torch's cast; K1 over the fp8 cache (fp8 MFMA for both
+    contractions, q and P rounded to fp8 in the kernel) stays within fp8 tolerance of exact attention over the SAME dequantised
+    cache -- and therefore of the bf16 result (the reference has no fp8; that is the stated parity target)."""
+    ops, L = _ops()
+    name, B, H, Hkv, D, S_max, kv_len, n, key_start, dtype, (sk, sv) = case
+    g = torch.Generator().manual_seed(len(name))
+    k_all = torch.randn(1, B, Hkv, S_max, D, generator=g) * sk * 1.2
+    v_all = torch.randn(1, B, Hkv, S_max, D, generator=g) * sv * 1.2
+    q = (torch.randn(B, n, H, D, generator=g) * 1.5).to(dtype)
+    k = (torch.randn(B, n, Hkv, D, generator=g) * sk * 1.2).to(dtype)
+    v = (torch.randn(B, n, Hkv, D, generator=g) * sv * 1.2).to(dtype)
+    kc8 = (k_all / sk).to(ops.FP8)
+    vc8 = (v_all / sv).to(ops.FP8)
+    dcache = _Cache(kc8.clone().to(dev), vc8.clone().to(dev))
+    attn = ops.HipWindowAttention(n_split=n_split)
+    attn.kv_scale = (sk, sv)
+    out = attn(0, q.to(dev), k.to(dev), v.to(dev), dcache, kv_len, key_start)
+    torch.cuda.synchronize()
+    # K3: appended rows are torch's round-to-nearest-even e4m3 cast of x / scale, bit for bit; older rows untouched
+    want_k = (k.float() / sk).to(ops.FP8).permute(0, 2, 1, 3).contiguous().view(torch.uint8)
+    want_v = (v.float() / sv).to(ops.FP8).permute(0, 2, 1, 3).contiguous().view(torch.uint8)
+    got_k, got_v = dcache.k.cpu().view(torch.uint8)[0], dcache.v.cpu().view(torch.uint8)[0]
+    assert torch.equal(got_k[:, :, kv_len:kv_len + n], want_k) and torch.equal(got_v[:, :, kv_len:kv_len + n], want_v)
+    assert torch.equal(got_k[:, :, :kv_len], kc8.view(torch.uint8)[0, :, :, :kv_len])
+    # K1: exact attention over the dequantised cache (fp64 oracle on bf16-free operands)
+    ref_cache = _Cache(dcache.k.cpu().float() * sk, dcache.v.cpu().float() * sv)
+    kd, vd = ref_cache.k[0].double(), ref_cache.v[0].double()
+    G = H // Hkv
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    q8 = q.float().to(ops.FP8).double()                   # the kernel's q operand
+    for b in range(B):
+        for i in range(n):
+            lo, hi = key_start[b], kv_len + i + 1
+            if hi <= lo:
+                assert (got[b, i] == 0).all()
+                continue
+            for h in range(H):
+                kk, vv = kd[b, h // G, lo:hi], vd[b, h // G, lo:hi]
+                # (1) the kernel arithmetic restated (fp8 q; P = fp8(256 e), e = exp(s - max); l from the unrounded e) -- the kernel rounds e
+                #     against its running per-tile max, so the two P roundings are independent: tolerance = one fp8 rounding of P
+                sc = (kk @ q8[b, i, h]) / D ** 0.5
+                e = torch.exp(sc - sc.max())
+                p8 = (e * 256).float().to(ops.FP8).double() / 256
+                emu = ((p8[:, None] * vv).sum(0) / e.sum()).float()
+                err = (got[b, i, h] - emu).abs()
+                conc = float((e / e.sum()).pow(2).sum().sqrt())          # fp8 rounding noise on P scales with sqrt(sum p^2) |v|
+                assert err.max() < 0.5 * sv * conc + 5e-3 and err.mean() < 0.1 * sv * conc + 1e-3, \
+                    f"{name} b{b} row{i} head{h}: vs emulation max {err.max():.4f} mean {err.mean():.5f} conc {conc:.3f}"
+                # (2) exact attention over the same cache (what a 16-bit K1 would return up to bf16 rounding): fp8 tolerance
+                p = torch.softmax((kk @ q[b, i, h].double()) / D ** 0.5, dim=0)
+                want = (p[:, None] * vv).sum(0).float()
+                err = (got[b, i, h] - want).abs()
+                assert err.max() < 1.0 * sv * conc + 1e-2 and err.mean() < 0.25 * sv * conc + 2e-3, \
+                    f"{name} b{b} row{i} head{h}: vs exact max {err.max():.4f} mean {err.mean():.5f} conc {conc:.3f}"

@@ -50,3 +50,11 @@ def test_llamagen_loop_top_p():
     """TopPLogitsWarper3d with top_p < 1 on the HIP path (K2 and the K4 residual)."""
     s = G.teacher_forced_llamagen_check(latent=8, window=16, seed=5, embed_token_scale=0.25, top_p=0.95, use_graph=True)
     assert s["tokens"] == 63 and s["nfe"] < 63
+
+
+@pytest.mark.parametrize("fused,gemm,use_graph", [(False, "torch", False), (True, "torch", True), (True, "sjd", True)])
+def test_lumina_loop_fp8_kv_cache(fused, gemm, use_graph):
+    """BASELINE config 5 flavour: the whole loop over an fp8 (e4m3) KV cache -- K3 quantises, K1 runs its fp8-MFMA variant -- still
+    takes exactly the decisions the oracle takes on the engine's logits (eager and hipGraph, fused glue, G1 projections)."""
+    r = G.teacher_forced_lumina_check(seed=4, window=16, fused=fused, gemm=gemm, use_graph=use_graph, fp8_kv=True)
+    assert r["last"] == 8196 and r["tokens"] > 0

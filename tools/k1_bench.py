@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--n-split", type=int, default=8)
     ap.add_argument("--prompt", type=int, default=64)
+    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) KV cache + the fp8-MFMA K1 variant (BASELINE config 5)")
+    ap.add_argument("--graph", action="store_true", help="time k1_partial + k1_combine per layer inside one hipGraph replay")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = L.load()
@@ -38,6 +40,39 @@ def main():
     out = torch.empty_like(q)
     ks = torch.tensor([0, a.prompt - 1], dtype=torch.int32, device=dev)
     ws = ops.attention_workspace(B, H, n, D, a.n_split, dev)
+    if a.fp8:
+        kc, vc = kc.to(ops.FP8), vc.to(ops.FP8)
+    if a.fp8 or a.graph:
+        def one(i):
+            if a.fp8:
+                ops.draft_window_attention_fp8(q, kc[i], vc[i], out, 1.0, 1.0, ks, None, a.kv_len, a.n_split, ws)
+            else:
+                ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, a.kv_len, a.n_split, ws)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            one(0)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(a.layers):
+                one(i)
+        g.replay()
+        torch.cuda.synchronize()
+        reps = max(1, a.launches // a.layers)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        avg = e0.elapsed_time(e1) / (reps * a.layers)
+        esz = kc.element_size()
+        rows0, rows1 = a.kv_len + n, a.kv_len + n - (a.prompt - 1)
+        alg = 2 * Hkv * (rows0 + rows1) * D * esz + B * n * H * D * 2
+        print(json.dumps(dict(kernel="k1_partial+k1_combine (hipGraph replay)", kv=("fp8" if a.fp8 else "bf16"), kv_len=a.kv_len, window=n,
+                              launches=reps * a.layers, avg_us=round(avg * 1e3, 2), algorithmic_bytes=alg,
+                              gbps=round(alg / 1e9 / (avg / 1e3), 1), frac_of_8TBps=round(alg / 1e9 / (avg / 1e3) / 8000, 4))))
+        return
     for i in range(a.layers):
         ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, a.kv_len, a.n_split, ws)
     torch.cuda.synchronize()

@@ -36,7 +36,7 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_kv_append", "sjd_attention_workspace_bytes", "sjd_draft_window_attention", "sjd_draft_window_attention_ex",
            "sjd_event_create", "sjd_event_destroy", "sjd_event_synchronize", "sjd_event_elapsed_ms",
            "sjd_add_rmsnorm", "sjd_qknorm_rope_append", "sjd_silu_mul", "sjd_gemm_num_chunks", "sjd_skinny_gemm",
-           "sjd_kv_append_fp8", "sjd_draft_window_attention_fp8"]
+           "sjd_kv_append_fp8", "sjd_draft_window_attention_fp8", "sjd_qknorm_rope_append_fp8"]
 
 _lib = None
 
@@ -70,6 +70,7 @@ def load():
     lib.sjd_silu_mul.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
     lib.sjd_gemm_num_chunks.argtypes = [i32, i32]
     lib.sjd_skinny_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.sjd_qknorm_rope_append_fp8.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, i32, vp, i32, vp]
     lib.sjd_kv_append_fp8.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, i32, vp, i32, vp]
     lib.sjd_draft_window_attention_fp8.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp, vp]
     lib.sjd_event_create.restype = vp

@@ -359,18 +359,11 @@ class ChameleonBackbone(nn.Module):
         return self
 
     def _f2(self, qkv, li, qn, pos, B, n, params, kv_len):
-        """F2 (QK-norm + RoPE + KV append).  An fp8 cache takes the rows through a bf16 staging block and the quantising K3."""
+        """F2 (QK-norm + RoPE + KV append); an fp8 cache gets its rows quantised in the same launch."""
         ops, H, Hkv, D = self._ops, self.n_heads, self.n_kv_heads, self.head_dim
-        kc, vc = self.cache.k[li], self.cache.v[li]
-        if kc.dtype != ops.FP8:
-            return ops.qknorm_rope_append(qkv, kc, vc, *qn, self._inv_freq32, pos, B, n, H, Hkv, D, params, kv_len if params is None else 0)
-        dt = self.lm_head.weight.dtype
-        ks = torch.empty(B, Hkv, n, D, dtype=dt, device=kc.device)
-        vs = torch.empty_like(ks)
-        q = ops.qknorm_rope_append(qkv, ks, vs, *qn, self._inv_freq32, pos, B, n, H, Hkv, D, None, 0)
-        sk, sv = getattr(self.attn, "kv_scale", (1.0, 1.0))
-        ops.kv_append_fp8(ks, vs, kc, vc, sk, sv, params, kv_len if params is None else 0, head_major=True)
-        return q
+        return ops.qknorm_rope_append(qkv, self.cache.k[li], self.cache.v[li], *qn, self._inv_freq32, pos, B, n, H, Hkv, D, params,
+                                      kv_len if params is None else 0, kv_scale=getattr(self.attn, "kv_scale", (1.0, 1.0)),
+                                      dtype=self.lm_head.weight.dtype)
 
     def _forward_window_g1(self, tokens, positions, kv_len, key_start):
         """Window forward (B*n <= 32 rows) with the four per-layer projections on kernel G1; split-K partials flow straight

@@ -203,13 +203,16 @@ __global__ __launch_bounds__(1024) void f1p_add_rmsnorm(unsigned short *__restri
 // ------------------------------------------------------------------------------------------------ F2
 // qkv: [T, (H + 2*Hkv) * D] fused projection output (T = B*n tokens).  One wave64 per (token, head); D in {64,128}.
 // Lane l owns the rotate-half pair (d = l', d + D/2) for l' = l (+64*k).  positions: int64 [T].
-template <int DT, int D>
+// KV8: the cache holds OCP fp8 e4m3 bytes (value = fp8 * scale); k/v rows are quantised on the way in (q stays 16-bit)
+__device__ __forceinline__ unsigned char f2_to_fp8(float x) { return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff); }
+
+template <int DT, int D, bool KV8>
 __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     const unsigned short *__restrict__ qkv, unsigned short *__restrict__ q_out, unsigned short *__restrict__ k_cache,
     unsigned short *__restrict__ v_cache, const unsigned short *__restrict__ qn_w, const unsigned short *__restrict__ qn_b,
     const unsigned short *__restrict__ kn_w, const unsigned short *__restrict__ kn_b, const float *__restrict__ inv_freq,
     const long *__restrict__ positions, int B, int n, int H, int H_kv, int S_max, const sjd_iter_params *__restrict__ params,
-    int kv_len_arg, const float *__restrict__ part, int n_chunks, int prows)
+    int kv_len_arg, const float *__restrict__ part, int n_chunks, int prows, float k_inv, float v_inv)
 {
     constexpr int HALF = D / 2;
     constexpr int PPL = HALF / 64 > 0 ? HALF / 64 : 1;       // pairs per lane (D=128: 1, D=64: lanes 32..63 idle)
@@ -223,13 +226,17 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     const unsigned short *src = qkv + (size_t)tok * heads * D + (size_t)hh * D;
     const bool is_q = hh < H, is_k = !is_q && hh < H + H_kv;
     const int hl = is_q ? hh : (is_k ? hh - H : hh - H - H_kv);
-    unsigned short *dst;
+    unsigned short *dst = nullptr;
+    unsigned char *dst8 = nullptr;                            // KV8: byte rows of the fp8 cache
     if (is_q) dst = q_out + ((size_t)tok * H + hl) * D;
     else {
         const int r = kv_len + i;
         if (r >= S_max) return;
-        dst = (is_k ? k_cache : v_cache) + (((size_t)b * H_kv + hl) * S_max + r) * D;
+        const size_t off = (((size_t)b * H_kv + hl) * S_max + r) * D;
+        if (KV8) dst8 = reinterpret_cast<unsigned char *>(is_k ? k_cache : v_cache) + off;
+        else dst = (is_k ? k_cache : v_cache) + off;
     }
+    const float q8 = is_k ? k_inv : v_inv;
     const bool active = lane < HALF;
     float x0 = 0.f, x1 = 0.f;
     if (active) {
@@ -248,7 +255,10 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
         }
     }
     if (!is_q && !is_k) {                                     // V: plain copy into the cache
-        if (active) { dst[lane] = Cvt<DT>::from_f(x0); dst[lane + HALF] = Cvt<DT>::from_f(x1); }
+        if (active) {
+            if (KV8) { dst8[lane] = f2_to_fp8(x0 * q8); dst8[lane + HALF] = f2_to_fp8(x1 * q8); }
+            else { dst[lane] = Cvt<DT>::from_f(x0); dst[lane + HALF] = Cvt<DT>::from_f(x1); }
+        }
         return;
     }
     const unsigned short *gw_ = is_q ? qn_w : kn_w, *gb_ = is_q ? qn_b : kn_b;
@@ -275,8 +285,13 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
         // (q*cos) + (rotate_half(q)*sin): each product and the sum round to the activation dtype, as the ATen ops do
         const float a0 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0 * cs)), b0 = Cvt<DT>::to_f(Cvt<DT>::from_f(-x1 * sn));
         const float a1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x1 * cs)), b1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0 * sn));
-        dst[lane] = Cvt<DT>::from_f(a0 + b0);
-        dst[lane + HALF] = Cvt<DT>::from_f(a1 + b1);
+        if (KV8 && !is_q) {                                   // the 16-bit value the reference would cache, then fp8(x / scale)
+            dst8[lane] = f2_to_fp8(Cvt<DT>::to_f(Cvt<DT>::from_f(a0 + b0)) * q8);
+            dst8[lane + HALF] = f2_to_fp8(Cvt<DT>::to_f(Cvt<DT>::from_f(a1 + b1)) * q8);
+        } else {
+            dst[lane] = Cvt<DT>::from_f(a0 + b0);
+            dst[lane + HALF] = Cvt<DT>::from_f(a1 + b1);
+        }
     }
     (void)PPL;
 }
@@ -343,31 +358,55 @@ extern "C" int sjd_add_rmsnorm(void *h, const void *delta, const void *weight, v
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
+static int f2_launch(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b, const void *kn_w,
+                     const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n, int H, int H_kv, int D, int S_max,
+                     int dtype, const sjd_iter_params *params, int kv_len, const float *part, int n_chunks, bool kv8, float k_scale,
+                     float v_scale, void *stream)
+{
+    if (part && (B * n > 64 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    const int prows = B * n <= 32 ? 32 : 64;
+    if ((!qkv && !part) || !q_out || !k_cache || !v_cache || !inv_freq || !positions || B < 1 || n < 1 || H < 1 || H_kv < 1) return SJD_ERR_BAD_ARG;
+    if (kv8 && (!(k_scale > 0.f) || !(v_scale > 0.f))) return SJD_ERR_BAD_ARG;
+    const int waves = B * n * (H + 2 * H_kv);
+    const dim3 grid((waves + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define SJD_F2_CASE(DT_, D_, KV8_)                                                                                                         \
+    if (dtype == DT_ && D == D_ && kv8 == KV8_) {                                                                                          \
+        hipLaunchKernelGGL((f2_qknorm_rope_append<DT_, D_, KV8_>), grid, block, 0, s, (const unsigned short *)qkv, (unsigned short *)q_out, \
+                           (unsigned short *)k_cache, (unsigned short *)v_cache, (const unsigned short *)qn_w,                              \
+                           (const unsigned short *)qn_b, (const unsigned short *)kn_w, (const unsigned short *)kn_b, inv_freq,              \
+                           (const long *)positions, B, n, H, H_kv, S_max, params, kv_len, part, n_chunks, prows,                           \
+                           kv8 ? 1.0f / k_scale : 1.0f, kv8 ? 1.0f / v_scale : 1.0f);                                                      \
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;                                                                   \
+    }
+    SJD_F2_CASE(SJD_DTYPE_BF16, 128, false)
+    SJD_F2_CASE(SJD_DTYPE_F16, 128, false)
+    SJD_F2_CASE(SJD_DTYPE_BF16, 64, false)
+    SJD_F2_CASE(SJD_DTYPE_F16, 64, false)
+    SJD_F2_CASE(SJD_DTYPE_BF16, 128, true)
+    SJD_F2_CASE(SJD_DTYPE_F16, 128, true)
+    SJD_F2_CASE(SJD_DTYPE_BF16, 64, true)
+    SJD_F2_CASE(SJD_DTYPE_F16, 64, true)
+#undef SJD_F2_CASE
+    return SJD_ERR_UNSUPPORTED;
+}
+
 extern "C" int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b,
                                       const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n,
                                       int H, int H_kv, int D, int S_max, int dtype, const sjd_iter_params *params, int kv_len,
                                       const float *part, int n_chunks, void *stream)
 {
-    if (part && (B * n > 64 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
-    const int prows = B * n <= 32 ? 32 : 64;
-    if ((!qkv && !part) || !q_out || !k_cache || !v_cache || !inv_freq || !positions || B < 1 || n < 1 || H < 1 || H_kv < 1) return SJD_ERR_BAD_ARG;
-    const int waves = B * n * (H + 2 * H_kv);
-    const dim3 grid((waves + 3) / 4), block(256);
-    hipStream_t s = (hipStream_t)stream;
-#define SJD_F2_CASE(DT_, D_)                                                                                                         \
-    if (dtype == DT_ && D == D_) {                                                                                                   \
-        hipLaunchKernelGGL((f2_qknorm_rope_append<DT_, D_>), grid, block, 0, s, (const unsigned short *)qkv, (unsigned short *)q_out, \
-                           (unsigned short *)k_cache, (unsigned short *)v_cache, (const unsigned short *)qn_w,                        \
-                           (const unsigned short *)qn_b, (const unsigned short *)kn_w, (const unsigned short *)kn_b, inv_freq,        \
-                           (const long *)positions, B, n, H, H_kv, S_max, params, kv_len, part, n_chunks, prows);                           \
-        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;                                                             \
-    }
-    SJD_F2_CASE(SJD_DTYPE_BF16, 128)
-    SJD_F2_CASE(SJD_DTYPE_F16, 128)
-    SJD_F2_CASE(SJD_DTYPE_BF16, 64)
-    SJD_F2_CASE(SJD_DTYPE_F16, 64)
-#undef SJD_F2_CASE
-    return SJD_ERR_UNSUPPORTED;
+    return f2_launch(qkv, q_out, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, H_kv, D, S_max, dtype, params, kv_len,
+                     part, n_chunks, false, 1.0f, 1.0f, stream);
+}
+
+extern "C" int sjd_qknorm_rope_append_fp8(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b,
+                                          const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n,
+                                          int H, int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale,
+                                          const sjd_iter_params *params, int kv_len, const float *part, int n_chunks, void *stream)
+{
+    return f2_launch(qkv, q_out, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, H_kv, D, S_max, dtype, params, kv_len,
+                     part, n_chunks, true, k_scale, v_scale, stream);
 }
 
 extern "C" int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks, void *stream)

@@ -195,9 +195,6 @@ class AnoleGrammar(_Grammar):
 
     def _allowed(self):
         ctx, cur, L = self.ctx, len(self.ctx), self.L
-        img = set(range(self.img_lo, self.img_hi))
-        masked_special = set()                   # masked ids outside the image range
-        img_masked = False
         offset = L + 1
         at_offset = cur >= offset and ctx[-offset] == self.boi
         window = min(L, cur)

@@ -201,15 +201,29 @@ def add_rmsnorm(h, delta, weight, eps):
     return y
 
 
-def qknorm_rope_append(qkv, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, H_kv, D, params, kv_len):
-    """qkv [B*n, (H+2Hkv)*D] (tensor or G1 Partials) -> q [B,n,H,D]; k/v rows are written into k_cache/v_cache [B,Hkv,S,D]."""
+def qknorm_rope_append(qkv, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, H_kv, D, params, kv_len,
+                       kv_scale=(1.0, 1.0), dtype=None):
+    """qkv [B*n, (H+2Hkv)*D] (tensor or G1 Partials) -> q [B,n,H,D]; k/v rows are written into k_cache/v_cache [B,Hkv,S,D].
+    An fp8 cache (dtype FP8) receives fp8(x / scale) with kv_scale = (k, v); `dtype` = the activation dtype (needed with Partials
+    into an fp8 cache, where no 16-bit tensor is around to tell)."""
     t, part, nc = _part_args(qkv)
     assert (t is None or t.is_contiguous()) and positions.is_contiguous() and positions.dtype == torch.int64
     assert inv_freq.dtype == torch.float32 and inv_freq.is_contiguous()
-    q = torch.empty(B, n, H, D, dtype=k_cache.dtype, device=k_cache.device)
-    L.check(L.load().sjd_qknorm_rope_append(_ptr(t), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(qn_w), _ptr(qn_b), _ptr(kn_w),
+    fp8 = k_cache.dtype == FP8
+    act = dtype or (t.dtype if t is not None else k_cache.dtype)
+    assert act in (torch.bfloat16, torch.float16)
+    q = torch.empty(B, n, H, D, dtype=act, device=k_cache.device)
+    lib = L.load()
+    if fp8:
+        L.check(lib.sjd_qknorm_rope_append_fp8(_ptr(t), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(qn_w), _ptr(qn_b), _ptr(kn_w),
+                                               _ptr(kn_b), _ptr(inv_freq), _ptr(positions), B, n, H, H_kv, D, k_cache.shape[2],
+                                               _dtype_code(act), float(kv_scale[0]), float(kv_scale[1]),
+                                               params.ptr if params is not None else None, int(kv_len), part, nc, _stream()),
+                "sjd_qknorm_rope_append_fp8")
+    else:
+        L.check(lib.sjd_qknorm_rope_append(_ptr(t), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(qn_w), _ptr(qn_b), _ptr(kn_w),
                                            _ptr(kn_b), _ptr(inv_freq), _ptr(positions), B, n, H, H_kv, D, k_cache.shape[2],
-                                           _dtype_code(k_cache.dtype), params.ptr if params is not None else None, int(kv_len),
+                                           _dtype_code(act), params.ptr if params is not None else None, int(kv_len),
                                            part, nc, _stream()), "sjd_qknorm_rope_append")
     return q
 

@@ -26,9 +26,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--model", default="lumina7b", choices=["lumina7b", "lumina_tiny", "emu3_8b"],
+    ap.add_argument("--model", default="lumina7b", choices=["lumina7b", "lumina_tiny", "emu3_8b", "anole7b"],
                     help="lumina7b = BASELINE.json's metric config; emu3_8b = config 3 (720x720, GQA 32/8, V=184622, fp16)")
     ap.add_argument("--dtype", default=None, choices=[None, "bf16", "fp16"])
+    ap.add_argument("--kv", default="auto", choices=["auto", "16bit", "fp8"],
+                    help="KV-cache element type: the activation dtype, or OCP fp8 e4m3 with the fp8-MFMA K1 (auto: fp8 for anole7b = BASELINE config 5)")
     ap.add_argument("--embed-token-scale", type=float, default=0.7)
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--n-split", type=int, default=0, help="K1 key splits (0 = auto from batch x kv heads)")
@@ -47,7 +49,7 @@ def build_model(args, device):
     import sjd_amd.backbones as BB
     import sjd_amd.ops as ops
     import sjd_amd.synthetic as synthetic
-    if args.model == "lumina7b":
+    if args.model in ("lumina7b", "anole7b"):      # Anole-7B is the Chameleon-7B architecture
         margs = BB.LUMINA_7B
     elif args.model == "emu3_8b":
         margs = BB.EMU3_8B
@@ -82,6 +84,23 @@ def measure_k1(args, model, attn, device, kv_len):
     out = torch.empty_like(q)
     ks = torch.tensor([0, 0], dtype=torch.int32, device=device) if model.n_kv_heads != model.n_heads else torch.tensor([0, 63], dtype=torch.int32, device=device)
     ws = ops.attention_workspace(B, H, n, D, n_split, device)
+    if kc.dtype == ops.FP8:        # fp8 cache: k1_partial_fp8 + k1_combine, back-to-back launches between one event pair
+        q = q.to(model.lm_head.weight.dtype)
+        out = torch.empty_like(q)
+        sk, sv = attn.kv_scale
+        for i in range(nl):
+            ops.draft_window_attention_fp8(q, kc[i], vc[i], out, sk, sv, ks, None, kv_len, n_split, ws)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(args.k1_launches):
+            ops.draft_window_attention_fp8(q, kc[i % nl], vc[i % nl], out, sk, sv, ks, None, kv_len, n_split, ws)
+        e1.record()
+        torch.cuda.synchronize()
+        rows0, rows1 = kv_len + n, kv_len + n - int(ks[1])
+        alg = 2 * kc.shape[2] * (rows0 + rows1) * D + B * n * H * D * 2
+        avg_ms = e0.elapsed_time(e1) / args.k1_launches
+        return dict(launches=args.k1_launches, avg_ms=avg_ms, avg_bytes=alg, avg_kv_rows=kv_len + n, gbps=alg / 1e9 / (avg_ms / 1e3))
     evs = [(ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())) for _ in range(args.k1_launches)]
     for i in range(nl):
         ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, kv_len, n_split, ws)
@@ -214,6 +233,18 @@ def main():
                         guidance_scale=3.0, seed=1234 + rank, prefix_token_sampler_scheme="speculative_jacobi",
                         max_length=P + n_img + 1, eos_token_ids=(tok["eos_token"],))
         workload = f"Emu3-Gen 8B architecture 720x720 (90x91 visual tokens), pos/neg prompt CFG 3.0, top-k 2048, draft window {args.window}, fp16"
+    elif args.model == "anole7b":
+        from sjd_amd.grammar import AnoleGrammar
+        import sjd_amd.synthetic as synthetic
+        P, n_img = 64, 1024 + 1                              # 512x512 -> 32x32 VQ tokens + <eoi>; no line tokens (config 5)
+        prompt = synthetic.synthetic_prompt(P - 1, 1234 + rank, lo=9000, hi=60000)[0].tolist() + [8197]
+        spec = lumina_window_spec(prompt, device)
+        grammar = AnoleGrammar(margs.vocab_size, P, P + n_img, 1024)
+        cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=1024 - args.window - 2, max_num_new_tokens=args.window,
+                        guidance_scale=3.0, seed=1234 + rank, prefix_token_sampler_scheme="speculative_jacobi",
+                        max_length=P + n_img, eos_token_ids=(8196,))
+        workload = (f"Anole/Chameleon-7B architecture 512x512 (1024 image tokens, image-only grammar), draft window {args.window}, CFG 3.0, "
+                    f"top-k 2000, bf16")
     else:
         P, grid = 64, 48
         n_img = grid * (grid + 1)
@@ -226,7 +257,11 @@ def main():
         workload = (f"{'Lumina-mGPT-7B' if args.model == 'lumina7b' else args.model} 768x768, 1 prompt/GPU, draft window {args.window}, "
                     f"CFG 3.0 (batch 2), top-k 2000, bf16")
     s_max = ((P + n_img + 2 * args.window + 64 + 31) // 32) * 32
-    model.setup_cache(batch=2, s_max=s_max)
+    fp8_kv = args.kv == "fp8" or (args.kv == "auto" and args.model == "anole7b")
+    if fp8_kv:
+        import sjd_amd.ops as ops_
+        workload += ", fp8 (e4m3) KV cache + fp8-MFMA draft attention"
+    model.setup_cache(batch=2, s_max=s_max, dtype=ops_.FP8 if fp8_kv else None)
     eng = SJDEngine(model, margs.vocab_size, device, max_window=args.window, use_graph=not args.no_graph)
 
     def sync_all():
@@ -258,8 +293,9 @@ def main():
     tps = tot_tokens / t_max
     tok_per_step = tot_tokens / max(tot_steps, 1)
     out = {
-        "metric": ("accepted image-tokens/s (SJD, Lumina-mGPT-7B 768px); tokens_per_step = 1/steps-to-converge rate" if args.model != "emu3_8b"
-                   else "accepted image-tokens/s (SJD, Emu3 720px, BASELINE.json config 3)"),
+        "metric": ("accepted image-tokens/s (SJD, Emu3 720px, BASELINE.json config 3)" if args.model == "emu3_8b"
+                   else "accepted image-tokens/s (SJD, Anole/Chameleon-7B 512px, fp8 draft attention, BASELINE.json config 5)" if args.model == "anole7b"
+                   else "accepted image-tokens/s (SJD, Lumina-mGPT-7B 768px); tokens_per_step = 1/steps-to-converge rate"),
         "value": round(tps, 2), "unit": "image-tokens/s", "n_gpus": world, "steps": stats.timed_nfe, "warmup": args.warmup,
         "ms_per_step": round(t_max / max(stats.timed_nfe, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "fp16" if str(model.lm_head.weight.dtype).endswith("float16") and "bf" not in str(model.lm_head.weight.dtype) else "bf16",

@@ -161,6 +161,11 @@ int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int 
 int sjd_kv_append_fp8(const void *k_new, const void *v_new, void *k_cache, void *v_cache, int B, int n_rows, int H_kv, int D, int S_max,
                       int dtype, float k_scale, float v_scale, int head_major /* new rows [B,H_kv,n,D] instead of [B,n,H_kv,D] */,
                       const sjd_iter_params *params, int kv_len, void *stream);
+/* F2 writing into an fp8 cache: k/v rows are rounded to `dtype` exactly as sjd_qknorm_rope_append does, then stored as fp8(x / scale). */
+int sjd_qknorm_rope_append_fp8(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b,
+                               const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n,
+                               int H, int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale,
+                               const sjd_iter_params *params, int kv_len, const float *part, int n_chunks, void *stream);
 int sjd_draft_window_attention_fp8(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H, int H_kv,
                                    int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
                                    const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream);

@@ -134,6 +134,44 @@ def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, 
 
 
 @torch.no_grad()
+def teacher_forced_anole_check(device="cuda:0", img_len=40, window=16, seed=5, P=10, embed_token_scale=0.25, dtype=torch.bfloat16,
+                               use_graph=True, gemm="torch", fp8_kv=True):
+    """BASELINE config 5 flavour: Chameleon architecture, image-only grammar of the Anole adapter (every window row carries the mask
+    of the accepted prefix, reference logit_processor_3dim.py:242-338), no line tokens, fp8 KV cache + fp8-MFMA K1."""
+    import sjd_amd.ops as ops
+    import sjd_amd.synthetic as synthetic
+    from sjd_amd.engine import SJDEngine, SJDConfig, WindowSpec
+    from sjd_amd.grammar import AnoleGrammar
+    from tests.helpers import make_chameleon
+    V = 9216
+    conf = dict(vocab_size=V, hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=4, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    model = make_chameleon(conf, 29, embed_token_scale, ops.HipWindowAttention(n_split=2), dtype=dtype, device=device)
+    model.enable_fused(ops, gemm=gemm)
+    prompt = torch.cat([synthetic.synthetic_prompt(P - 1, seed, lo=8900, hi=9200), torch.tensor([[8197]])], dim=1)
+    max_len = P + img_len + 1
+    model.setup_cache(batch=2, s_max=((max_len + 64 + 31) // 32) * 32, dtype=ops.FP8 if fp8_kv else None)
+    cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=img_len - window - 2, max_num_new_tokens=window, guidance_scale=3.0,
+                    seed=seed, prefix_token_sampler_scheme="speculative_jacobi", max_length=max_len, eos_token_ids=(8196,))
+    ids = prompt.to(device)
+    spec = WindowSpec(first_tokens=ids.repeat(2, 1),
+                      first_positions=torch.stack([torch.arange(P), torch.tensor([1] * (P - 1) + [0])]).to(device),
+                      key_start=torch.tensor([0, P - 1], dtype=torch.int32),
+                      pos_offset=torch.tensor([0, -(P - 1)], dtype=torch.long), kv_base=0)
+    eng = SJDEngine(model, V, device, max_window=window, use_graph=use_graph)
+    rec = _Recorder()
+    eng.hook = rec
+    seq, stats = eng.decode(prompt[0].tolist(), spec, AnoleGrammar(V, P, max_len, img_len), cfg)
+    seq_ref, tr, checks = _replay(rec, prompt[0].tolist(), lambda c, n: O.anole_rules(c, n, V, P, max_len, img_len), _loop_cfg(cfg), V,
+                                  device=device)
+    assert seq == seq_ref, "token sequences differ"
+    assert stats.matched == tr.matched and stats.nfe == len(tr.matched)
+    gen = seq[P:]
+    return dict(tokens=len(gen), nfe=stats.nfe, last=gen[-1], image_ids=all(4 <= t < 8196 for t in gen[:-1]),
+                accepted_hist=sorted(set(stats.matched[1:])))
+
+
+@torch.no_grad()
 def teacher_forced_emu3_check(device="cuda:0", H=3, W=5, window=32, seed=5, embed_token_scale=0.4, dtype=torch.float16,
                               use_graph=True, pos_len=9, neg_len=5, gemm="torch"):
     """Emu3 flavour (config 3): Llama-style GQA backbone without QK-norm, pos/neg prompts left-padded to a common

@@ -171,3 +171,27 @@ def test_g1_forward_matches_library_gemm_forward(dev):
         toks2 = torch.randint(4, 9000, (2, 16), generator=torch.Generator().manual_seed(2)).to(dev)
         outs.append(m.forward_window(toks2, (40 + torch.arange(16))[None].repeat(2, 1).to(dev), 40, ks))
     assert (outs[0] - outs[1]).abs().mean() < 0.05 and (outs[0] - outs[1]).abs().max() < 0.6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("H,Hkv,D,qk_norm", [(8, 8, 128, True), (8, 2, 128, False), (12, 12, 64, True)])
+def test_f2_into_fp8_cache(dev, dtype, H, Hkv, D, qk_norm):
+    """F2 with an fp8 (e4m3) cache = F2 into a 16-bit cache followed by torch's cast of x / scale, bit for bit; q unchanged."""
+    import sjd_amd.ops as ops
+    B, n, S, kv_len, sk, sv = 2, 16, 96, 37, 0.5, 2.0
+    g = torch.Generator().manual_seed(H + D)
+    qkv = torch.randn(B * n, (H + 2 * Hkv) * D, generator=g).to(dtype).to(dev)
+    qn = [(1 + 0.2 * torch.randn(1, D, generator=g)).to(dtype).to(dev), (0.1 * torch.randn(1, D, generator=g)).to(dtype).to(dev),
+          (1 + 0.2 * torch.randn(1, D, generator=g)).to(dtype).to(dev), (0.1 * torch.randn(1, D, generator=g)).to(dtype).to(dev)]
+    if not qk_norm:
+        qn = [None] * 4
+    inv = (1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))).to(dev)
+    pos = (500 + torch.arange(B * n)).to(dev)
+    kc, vc = torch.zeros(B, Hkv, S, D, dtype=dtype, device=dev), torch.zeros(B, Hkv, S, D, dtype=dtype, device=dev)
+    kc8, vc8 = torch.zeros(B, Hkv, S, D, device=dev).to(ops.FP8), torch.zeros(B, Hkv, S, D, device=dev).to(ops.FP8)
+    q_a = ops.qknorm_rope_append(qkv, kc, vc, *qn, inv, pos, B, n, H, Hkv, D, None, kv_len)
+    q_b = ops.qknorm_rope_append(qkv, kc8, vc8, *qn, inv, pos, B, n, H, Hkv, D, None, kv_len, kv_scale=(sk, sv))
+    assert torch.equal(q_a, q_b)
+    assert torch.equal((kc.float() / sk).to(ops.FP8).view(torch.uint8), kc8.view(torch.uint8))
+    assert torch.equal((vc.float() / sv).to(ops.FP8).view(torch.uint8), vc8.view(torch.uint8))
+    assert kc8.view(torch.uint8)[:, :, kv_len:kv_len + n].float().abs().sum() > 0

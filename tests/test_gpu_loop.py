@@ -58,3 +58,11 @@ def test_lumina_loop_fp8_kv_cache(fused, gemm, use_graph):
     takes exactly the decisions the oracle takes on the engine's logits (eager and hipGraph, fused glue, G1 projections)."""
     r = G.teacher_forced_lumina_check(seed=4, window=16, fused=fused, gemm=gemm, use_graph=use_graph, fp8_kv=True)
     assert r["last"] == 8196 and r["tokens"] > 0
+
+
+@pytest.mark.parametrize("fp8_kv,gemm", [(True, "torch"), (True, "sjd"), (False, "torch")])
+def test_anole_loop(fp8_kv, gemm):
+    """Anole image-only grammar (config 5): image ids only between <boi> and the forced <eoi>, identical decisions in engine and
+    oracle, with the fp8 KV cache and with the 16-bit one."""
+    r = G.teacher_forced_anole_check(fp8_kv=fp8_kv, gemm=gemm)
+    assert r["tokens"] == 41 and r["last"] == 8196 and r["image_ids"] and max(r["accepted_hist"]) > 1

@@ -28,6 +28,17 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _head_logits(linear, x, cols):
+    """fp32 logits of the output head, optionally only for the vocabulary columns [cols[0], cols[1]) -- the rows of the weight the
+    grammar can give probability mass to in this iteration (Lumina image body: 8192 of 65536 ids).  K2 never reads a masked column,
+    so the narrow head is bit-identical downstream and streams 1/8 of the weight."""
+    if cols is None:
+        return linear(x).float()
+    w = linear.weight[cols[0]:cols[1]]
+    b = linear.bias[cols[0]:cols[1]] if linear.bias is not None else None
+    return F.linear(x, w, b).float()
+
+
 class StaticKVCache:
     """[n_layers, B, H_kv, S_max, D]: one contiguous D-row per (layer, batch, head, position)."""
 
@@ -190,7 +201,7 @@ class LlamaGenBackbone(nn.Module):
             return self.cls_embedding.embedding_table(cond).unsqueeze(1)[:, : self.cls_token_num]
         return self.cls_embedding.cap_proj(cond)[:, : self.cls_token_num]
 
-    def forward_embeds(self, h, positions, kv_len, key_start):
+    def forward_embeds(self, h, positions, kv_len, key_start, cols=None):
         B, n, _ = h.shape
         freqs = self.freqs[positions.clamp(max=self.freqs.shape[0] - 1)]   # [B,n,D/2,2]; padded window rows clamp
         for li, layer in enumerate(self.layers):
@@ -203,10 +214,10 @@ class LlamaGenBackbone(nn.Module):
             o = self.attn(li, q, k, v, self.cache, kv_len, key_start)
             h = h + a.wo(o.reshape(B, n, a.dim))
             h = h + layer.feed_forward(layer.ffn_norm(h))
-        return self.output(self.norm(h)).float()
+        return _head_logits(self.output, self.norm(h), cols)
 
-    def forward_window(self, tokens, positions, kv_len, key_start):
-        return self.forward_embeds(self.tok_embeddings(tokens), positions, kv_len, key_start)
+    def forward_window(self, tokens, positions, kv_len, key_start, cols=None):
+        return self.forward_embeds(self.tok_embeddings(tokens), positions, kv_len, key_start, cols=cols)
 
 
 # ------------------------------------------------------------------------------------------ Chameleon / Llama
@@ -365,7 +376,7 @@ class ChameleonBackbone(nn.Module):
                                       kv_len if params is None else 0, kv_scale=getattr(self.attn, "kv_scale", (1.0, 1.0)),
                                       dtype=self.lm_head.weight.dtype)
 
-    def _forward_window_g1(self, tokens, positions, kv_len, key_start):
+    def _forward_window_g1(self, tokens, positions, kv_len, key_start, cols=None):
         """Window forward (B*n <= 32 rows) with the four per-layer projections on kernel G1; split-K partials flow straight
         into the consuming glue kernel (F2 / F1 / F3 / F1)."""
         ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
@@ -392,11 +403,11 @@ class ChameleonBackbone(nn.Module):
             act = ops.silu_mul(gu, rows=T, dtype=h.dtype)
             delta = g1(act, "down", hid, inter)
         x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
-        return self.lm_head(x).float().view(B, n, -1)
+        return _head_logits(self.lm_head, x, cols).view(B, n, -1)
 
-    def _forward_window_fused(self, tokens, positions, kv_len, key_start):
+    def _forward_window_fused(self, tokens, positions, kv_len, key_start, cols=None):
         if self._gemm == "sjd" and tokens.shape[0] * tokens.shape[1] <= 64:
-            return self._forward_window_g1(tokens, positions, kv_len, key_start)
+            return self._forward_window_g1(tokens, positions, kv_len, key_start, cols)
         ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
         T, eps = B * n, self.args.rms_norm_eps
         H, Hkv, D = self.n_heads, self.n_kv_heads, self.head_dim
@@ -416,11 +427,12 @@ class ChameleonBackbone(nn.Module):
             x = ops.add_rmsnorm(h, attn_out, layer.post_attention_layernorm.weight, eps)
             delta = F.linear(ops.silu_mul(F.linear(x, gu_w)), layer.mlp.down_proj.weight)
         x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
-        return self.lm_head(x).float().view(B, n, -1)
+        return _head_logits(self.lm_head, x, cols).view(B, n, -1)
 
-    def forward_window(self, tokens, positions, kv_len, key_start):
+    def forward_window(self, tokens, positions, kv_len, key_start, cols=None):
+        """cols = (lo, hi): compute the logits of vocabulary columns [lo, hi) only (returned compact, [B, n, hi - lo])."""
         if getattr(self, "_ops", None) is not None:
-            return self._forward_window_fused(tokens, positions, kv_len, key_start)
+            return self._forward_window_fused(tokens, positions, kv_len, key_start, cols)
         B, n = tokens.shape
         h = self.model.embed_tokens(tokens)
         cos, sin = self._rope(positions, h.dtype)
@@ -437,7 +449,7 @@ class ChameleonBackbone(nn.Module):
             o = self.attn(li, q, k, v, self.cache, kv_len, key_start)
             h = h + a.o_proj(o.reshape(B, n, -1))
             h = h + layer.mlp(layer.post_attention_layernorm(h))
-        return self.lm_head(self.model.norm(h)).float()   # modeling_chameleon.py:1560-1561
+        return _head_logits(self.lm_head, self.model.norm(h), cols)   # modeling_chameleon.py:1560-1561
 
 
 LUMINA_7B = ChameleonArgs()

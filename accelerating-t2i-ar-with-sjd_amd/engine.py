@@ -83,7 +83,7 @@ def set_seed(seed):
 
 
 class SJDEngine:
-    def __init__(self, backbone, vocab_size, device, max_window=16, n_batch=2, use_graph=False):
+    def __init__(self, backbone, vocab_size, device, max_window=16, n_batch=2, use_graph=False, narrow_head=True):
         L.load()                                   # fail loudly if the HIP extension is missing
         if max_window > L.MAX_WINDOW:
             raise ValueError(f"max_window {max_window} > {L.MAX_WINDOW}")
@@ -105,6 +105,7 @@ class SJDEngine:
         self.kv_len_dev = self.params.dev[off:off + 4].view(torch.int32)      # device view of params->kv_len
         self.hook = None                            # test hook: called with per-iteration device tensors
         self.use_graph = use_graph                  # capture the window step (K5 -> forward -> K2 -> K4) in hipGraphs
+        self.narrow_head = narrow_head              # evaluate the output head only for the columns the grammar allows
         self._guidance = 3.0
         self.rng_stream = torch.cuda.Stream(device=dev)
         self.reset_graphs()
@@ -125,47 +126,72 @@ class SJDEngine:
             p.resid_rules[j] = r
         self.params.upload()
 
-    def _forward_body(self):
-        """Shape-static launch sequence, part 1: K5 + transformer forward (every dynamic scalar is read from device blobs)."""
+    def _forward_body(self, cols=None):
+        """Shape-static launch sequence, part 1: K5 + transformer forward (every dynamic scalar is read from device blobs).
+        cols: vocabulary column window of the output head (None = all columns)."""
         ops.reguess(self.params, self.state, self.input_ids)
         positions = self.kv_len_dev.to(torch.int64) + self.arange[None, :] + self.pos_offset[:, None]
-        return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start)
+        if cols is None:
+            return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start)
+        return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start, cols=cols)
 
-    def _sample_body(self, cur, logits):
+    def _sample_body(self, cur, logits, cols=None):
         """part 2: K2 + K4 (needs the noise tensors, which are drawn on a side stream while part 1 runs)."""
         lu = logits[1] if self.B > 1 else None
-        ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr)
+        ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr,
+                                   col0=cols[0] if cols else 0)
         ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0], self.scratch)
 
-    def _run_window(self, cur, noise_ready):
-        """K5 -> forward -> [wait for the noise] -> K2 -> K4.  With use_graph the two parts are hipGraphs captured once (part 2
-        once per prob-buffer parity) and replayed."""
+    def logit_columns(self, rules):
+        """Vocabulary window [lo, hi) (32-aligned) that holds every id the non-forced rows of this iteration may emit, or None when
+        it is not at most half of the vocabulary (text rows, unrestricted rules).  The output head is then evaluated for these
+        columns only: the ids outside are masked by the grammar before the softmax (reference logit_processor_3dim.py:125-129,
+        jacobi_iteration_emu3.py:44-128), so not computing them changes nothing downstream."""
+        if not self.narrow_head:
+            return None
+        lo, hi = self.V, 0
+        for r in rules:
+            if r.forced >= 0:
+                continue
+            if r.n_ranges == 0:
+                return None
+            lo = min([lo] + [r.lo[i] for i in range(r.n_ranges)])
+            hi = max([hi] + [r.hi[i] for i in range(r.n_ranges)])
+        if hi <= lo:
+            return None
+        lo, hi = (lo // 32) * 32, min(self.V, ((hi + 31) // 32) * 32)
+        return (lo, hi) if 2 * (hi - lo) <= self.V else None
+
+    def _run_window(self, cur, noise_ready, cols=None):
+        """K5 -> forward -> [wait for the noise] -> K2 -> K4.  With use_graph the two parts are hipGraphs captured once per
+        output-head column window (part 2 also once per prob-buffer parity) and replayed."""
         main = torch.cuda.current_stream()
         if not self.use_graph:
-            logits = self._forward_body()
+            logits = self._forward_body(cols)
             main.wait_event(noise_ready)
-            self._sample_body(cur, logits)
+            self._sample_body(cur, logits, cols)
             return logits
-        if "fwd" not in self._graphs:
-            if self._eager_runs.get("fwd", 0) < 1:   # one eager run warms up allocations / hipBLASLt before capture
-                self._eager_runs["fwd"] = 1
-                logits = self._forward_body()
+        fkey = ("fwd", cols)
+        if fkey not in self._graphs:
+            if self._eager_runs.get(fkey, 0) < 1:   # one eager run warms up allocations / hipBLASLt before capture
+                self._eager_runs[fkey] = 1
+                logits = self._forward_body(cols)
                 main.wait_event(noise_ready)
-                self._sample_body(cur, logits)
+                self._sample_body(cur, logits, cols)
                 return logits
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._graph_logits["fwd"] = self._forward_body()
-            self._graphs["fwd"] = g
-        self._graphs["fwd"].replay()
-        logits = self._graph_logits["fwd"]
+                self._graph_logits[fkey] = self._forward_body(cols)
+            self._graphs[fkey] = g
+        self._graphs[fkey].replay()
+        logits = self._graph_logits[fkey]
         main.wait_event(noise_ready)
-        key = (cur, self._guidance)
+        key = (cur, self._guidance, cols)
         if key not in self._graphs:
-            self._sample_body(cur, logits)           # eager warm-up of this parity, captured below for the next use
+            self._sample_body(cur, logits, cols)     # eager warm-up of this parity, captured below for the next use
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._sample_body(cur, logits)
+                self._sample_body(cur, logits, cols)
             self._graphs[key] = g
             return logits
         self._graphs[key].replay()
@@ -271,10 +297,15 @@ class SJDEngine:
                 if attn is not None and hasattr(attn, "params"):
                     attn.params = self.params                                        # windows: kv_len / n_rows from the blob
             else:
-                logits = self._run_window(cur, noise_ready)
+                cols = self.logit_columns(rules)
+                logits = self._run_window(cur, noise_ready, cols)
                 lc = logits[0, :n_rows]
                 lu = logits[1, :n_rows] if B > 1 else None
                 win_len = n_rows
+                if cols is not None and self.hook is not None:       # observers get full-width rows (zeros where nothing was computed)
+                    full = torch.zeros(logits.shape[0], n_rows, self.V, dtype=logits.dtype, device=dev)
+                    full[:, :, cols[0]:cols[1]] = logits[:, :n_rows]
+                    lc, lu = full[0], (full[1] if B > 1 else None)
             if self.hook is not None:
                 self.hook(dict(first=first, n_rows=n_rows, logits_c=lc, logits_u=lu, use_cfg=use_cfg, rules=rules,
                                resid=resid, noise=e1, rs=self.rs[:n_rows], noise2=self.noise2[0], probs=self.probs[cur],

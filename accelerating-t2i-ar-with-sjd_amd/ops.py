@@ -69,14 +69,17 @@ def reguess(params: DeviceBlob, state: DeviceBlob, input_ids_out: torch.Tensor):
     L.check(L.load().sjd_reguess(params.ptr, state.ptr, _ptr(input_ids_out), n_batch, max_rows, _stream()), "sjd_reguess")
 
 
-def logits_to_probs_sample(logits_c, logits_u, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr):
-    """logits_c/u: [rows, V] fp32 views with a common row stride (last dim contiguous)."""
+def logits_to_probs_sample(logits_c, logits_u, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr, col0=0):
+    """logits_c/u: [rows, V] fp32 views with a common row stride (last dim contiguous) -- or, with col0 > 0, compact views holding
+    only the vocabulary columns [col0, col0 + width): every rule in `params` must then keep its allowed ranges inside that window
+    (K2 reads no other column; the pointers handed over are those of the virtual column 0)."""
     max_rows, V = probs_out.shape
     assert logits_c.dtype == torch.float32 and logits_c.stride(-1) == 1 and probs_out.is_contiguous()
     assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V
     if logits_u is not None:
         assert logits_u.stride(-2) == logits_c.stride(-2) and logits_u.stride(-1) == 1
-    L.check(L.load().sjd_logits_to_probs_sample(_ptr(logits_c), _ptr(logits_u), logits_c.stride(-2), float(guidance),
+    shift = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr() - 4 * int(col0))
+    L.check(L.load().sjd_logits_to_probs_sample(shift(logits_c), shift(logits_u), logits_c.stride(-2), float(guidance),
                                                max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out), tokens_out_ptr,
                                                _stream()), "sjd_logits_to_probs_sample")
 

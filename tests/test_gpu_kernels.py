@@ -86,6 +86,44 @@ def test_k2_bit_exact(dev, name, V, n, builder, use_cfg):
         f"max |dp| = {np.abs(probs - probs_ref).max()}"
 
 
+@pytest.mark.parametrize("name,V,n,builder,cols", [
+    ("lumina_image_65536", 65536, 16, K2_CASES[0][3], (0, 8224)),
+    ("lumina_eol_rows", 9216, 16, K2_CASES[1][3], (0, 8224)),
+    ("emu3_odd_vocab", 184622, 8, K2_CASES[5][3], (151840, 184622)),
+    ("lumina_range_top_p", 65536, 4, K2_CASES[9][3], (0, 8224)),
+], ids=lambda v: v if isinstance(v, str) else None)
+def test_k2_column_window_of_the_output_head(dev, name, V, n, builder, cols):
+    """The engine evaluates the output head only for the vocabulary columns the grammar allows (engine.logit_columns) and hands
+    K2 the compact logits with the column offset: bit-identical to the oracle on the full-width logits."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    logits = (torch.randn(2, n, V, generator=g) * 3.0).numpy()
+    noise = torch.empty(n, V).exponential_(generator=g).numpy()
+    rules = builder(n)
+    toks_ref, probs_ref = O.logits_to_probs_sample(logits[0], logits[1], 3.0, rules, noise)
+    params = ops.DeviceBlob(L.IterParams, dev)
+    params.view.n_rows, params.view.use_cfg = n, 1
+    for j, r in enumerate(rules):
+        params.view.rules[j] = to_dev_rule(L, ops, r)
+    params.upload()
+    compact = torch.from_numpy(np.ascontiguousarray(logits[:, :, cols[0]:cols[1]])).to(dev)
+    nz = torch.from_numpy(noise).to(dev)
+    probs = torch.full((n, V), -7.0, device=dev)
+    toks = torch.full((n,), -5, dtype=torch.int64, device=dev)
+    ops.logits_to_probs_sample(compact[0], compact[1], 3.0, params, nz, probs, ctypes.c_void_p(toks.data_ptr()), col0=cols[0])
+    torch.cuda.synchronize()
+    assert toks.cpu().tolist() == toks_ref.tolist()
+    assert np.array_equal(probs.cpu().numpy().view(np.uint32), probs_ref.view(np.uint32))
+
+    class _E:            # the host-side choice of that window
+        V, narrow_head = None, True
+    from sjd_amd.engine import SJDEngine
+    e = _E()
+    e.V = V
+    want = cols if 2 * (cols[1] - cols[0]) <= V else None      # only worth a separate graph when it halves the head
+    assert SJDEngine.logit_columns(e, [to_dev_rule(L, ops, r) for r in rules]) == want
+
+
 def test_k2_matches_torch_softmax(dev):
     """Independent fp32 torch reference of the same op (tolerance, not bit-exact)."""
     V, n = 65536, 16

@@ -32,11 +32,17 @@ class State(ctypes.Structure):
                 ("win_tok", ctypes.c_int64 * MAX_WINDOW), ("q_src", ctypes.c_int32 * MAX_WINDOW)]
 
 
+class RowNorm(ctypes.Structure):
+    """sjd_row_norm: per-slice sums of squares of the residual stream -> the RMSNorm scale of a row (folded-norm path)."""
+    _fields_ = [("sumsq", ctypes.c_void_p), ("slices", ctypes.c_int32), ("hidden", ctypes.c_int32), ("eps", ctypes.c_float)]
+
+
 EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_probs_sample", "sjd_verify_accept",
            "sjd_kv_append", "sjd_attention_workspace_bytes", "sjd_draft_window_attention", "sjd_draft_window_attention_ex",
            "sjd_event_create", "sjd_event_destroy", "sjd_event_synchronize", "sjd_event_elapsed_ms",
            "sjd_add_rmsnorm", "sjd_qknorm_rope_append", "sjd_silu_mul", "sjd_gemm_num_chunks", "sjd_skinny_gemm",
-           "sjd_kv_append_fp8", "sjd_draft_window_attention_fp8", "sjd_qknorm_rope_append_fp8"]
+           "sjd_kv_append_fp8", "sjd_draft_window_attention_fp8", "sjd_qknorm_rope_append_fp8",
+           "sjd_residual_sumsq", "sjd_qknorm_rope_append_ex", "sjd_silu_mul_ex"]
 
 _lib = None
 
@@ -71,6 +77,10 @@ def load():
     lib.sjd_gemm_num_chunks.argtypes = [i32, i32]
     lib.sjd_skinny_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_qknorm_rope_append_fp8.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, i32, vp, i32, vp]
+    lib.sjd_residual_sumsq.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.sjd_qknorm_rope_append_ex.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32,
+                                              ctypes.POINTER(RowNorm), vp, i32, vp, i32, vp]
+    lib.sjd_silu_mul_ex.argtypes = [vp, vp, i32, i32, i32, vp, i32, ctypes.POINTER(RowNorm), vp]
     lib.sjd_kv_append_fp8.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, i32, vp, i32, vp]
     lib.sjd_draft_window_attention_fp8.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp, vp]
     lib.sjd_event_create.restype = vp

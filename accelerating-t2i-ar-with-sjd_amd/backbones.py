@@ -340,7 +340,7 @@ class ChameleonBackbone(nn.Module):
     # tools/g1_bench.py so that every launch gives the 256 CUs ~1000+ balanced waves
     G1_CFG = dict(qkv=(1024, 8, True), o=(256, 4, False), gate_up=(2048, 8, True), down=(1024, 4, False))
 
-    def enable_fused(self, ops, gemm="torch"):
+    def enable_fused(self, ops, gemm="torch", fold_norm=True):
         """Switch to the fused HIP glue path (F1-F3): q|k|v and gate|up projections become single GEMMs whose weights are
         concatenated once; the original parameters are re-pointed at slices of the fused tensors (state-dict unchanged,
         no extra memory).  gemm="sjd": the window forward (<= 32 rows) also runs its four per-layer projections on the
@@ -348,6 +348,7 @@ class ChameleonBackbone(nn.Module):
         weights); other shapes (prefill) keep hipBLASLt.  `ops` is sjd_amd.ops (raises if libsjd_hip.so is missing)."""
         self._ops = ops
         self._gemm = gemm
+        self._fold_norm = bool(fold_norm) and gemm == "sjd"
         self._packed = []
         self._fused = []
         with torch.no_grad():
@@ -362,19 +363,48 @@ class ChameleonBackbone(nn.Module):
                 self._fused.append((qkv, gu))
                 if gemm == "sjd":
                     c = self.G1_CFG
-                    self._packed.append(dict(qkv=ops.pack_weight(qkv, c["qkv"][0], c["qkv"][2]),
+                    if self._fold_norm:       # W' = W diag(gamma): the norm gain of the projection's input lives in the packed copy
+                        fold = lambda w, g: (w.float() * g.float()[None, :]).to(w.dtype)
+                        qkv_p, gu_p = fold(qkv, layer.input_layernorm.weight), fold(gu, layer.post_attention_layernorm.weight)
+                    else:
+                        qkv_p, gu_p = qkv, gu
+                    self._packed.append(dict(qkv=ops.pack_weight(qkv_p, c["qkv"][0], c["qkv"][2]),
                                              o=ops.pack_weight(a.o_proj.weight, c["o"][0], c["o"][2]),
-                                             gate_up=ops.pack_weight(gu, c["gate_up"][0], c["gate_up"][2]),
+                                             gate_up=ops.pack_weight(gu_p, c["gate_up"][0], c["gate_up"][2]),
                                              down=ops.pack_weight(m.down_proj.weight, c["down"][0], c["down"][2])))
         self._inv_freq32 = self.inv_freq.float().contiguous()
         return self
 
-    def _f2(self, qkv, li, qn, pos, B, n, params, kv_len):
+    def _f2(self, qkv, li, qn, pos, B, n, params, kv_len, row_norm=None):
         """F2 (QK-norm + RoPE + KV append); an fp8 cache gets its rows quantised in the same launch."""
         ops, H, Hkv, D = self._ops, self.n_heads, self.n_kv_heads, self.head_dim
         return ops.qknorm_rope_append(qkv, self.cache.k[li], self.cache.v[li], *qn, self._inv_freq32, pos, B, n, H, Hkv, D, params,
                                       kv_len if params is None else 0, kv_scale=getattr(self.attn, "kv_scale", (1.0, 1.0)),
-                                      dtype=self.lm_head.weight.dtype)
+                                      dtype=self.lm_head.weight.dtype, row_norm=row_norm)
+
+    def _forward_window_g1_folded(self, tokens, positions, kv_len, key_start, cols=None):
+        """_forward_window_g1 with the RMSNorm folded away: the projections run on the residual stream h itself (norm gain inside
+        the packed weight), F1r does the residual add and the per-slice sums of h^2, F2 / F3 apply the row scale on the partials:
+          F1r, qkv GEMM, F2, K1 partial, K1 combine, o GEMM, F1r, gate|up GEMM, F3, down GEMM   (F1r 3.5 us against F1's 6.1)."""
+        ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
+        T, eps, cfg = B * n, self.args.rms_norm_eps, self.G1_CFG
+        g1 = lambda x_, name, N_, K_: ops.skinny_gemm(x_, self._packed[li][name], N_, K_, cfg[name][0], cfg[name][1], cfg[name][2])
+        H, Hkv, D, hid, inter = self.n_heads, self.n_kv_heads, self.head_dim, self.args.hidden_size, self.args.intermediate_size
+        params = getattr(self.attn, "params", None)
+        h = self.model.embed_tokens(tokens).view(T, -1).contiguous()
+        pos = positions.reshape(T).contiguous()
+        delta = None
+        for li, layer in enumerate(self.model.layers):
+            a = layer.self_attn
+            rn = (ops.residual_sumsq(h, delta), hid, eps)
+            qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
+            q = self._f2(g1(h, "qkv", (H + 2 * Hkv) * D, hid), li, qn, pos, B, n, params, kv_len, row_norm=rn)
+            o = self.attn.attend(li, q, self.cache, kv_len, key_start)
+            rn = (ops.residual_sumsq(h, g1(o.view(T, H * D), "o", hid, H * D)), hid, eps)
+            act = ops.silu_mul(g1(h, "gate_up", 2 * inter, hid), rows=T, dtype=h.dtype, row_norm=rn)
+            delta = g1(act, "down", hid, inter)
+        x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
+        return _head_logits(self.lm_head, x, cols).view(B, n, -1)
 
     def _forward_window_g1(self, tokens, positions, kv_len, key_start, cols=None):
         """Window forward (B*n <= 32 rows) with the four per-layer projections on kernel G1; split-K partials flow straight
@@ -407,6 +437,8 @@ class ChameleonBackbone(nn.Module):
 
     def _forward_window_fused(self, tokens, positions, kv_len, key_start, cols=None):
         if self._gemm == "sjd" and tokens.shape[0] * tokens.shape[1] <= 64:
+            if self._fold_norm:
+                return self._forward_window_g1_folded(tokens, positions, kv_len, key_start, cols)
             return self._forward_window_g1(tokens, positions, kv_len, key_start, cols)
         ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
         T, eps = B * n, self.args.rms_norm_eps

@@ -200,6 +200,71 @@ __global__ __launch_bounds__(1024) void f1p_add_rmsnorm(unsigned short *__restri
     }
 }
 
+// F1r: only the residual half of F1, spread over (row, 512-column slice) workgroups: h += dtype(sum_c part[c]) (part optional) and
+// the slice's sum of h^2.  With the RMSNorm gain folded into the next projection's packed weight (W' = W diag(gamma)) the norm
+// reduces to one scale per row, which commutes with the projection and is applied by its consumer (F2 / F3 `row_sumsq`):
+//   gamma * (h * r) @ W^T  ==  r * (h @ (W diag(gamma))^T),   r = rsqrt(mean(h^2) + eps)
+template <int DT>
+__global__ __launch_bounds__(128) void f1r_residual_sumsq(unsigned short *__restrict__ h, const float *__restrict__ part, int n_chunks,
+                                                          int hidden, int prows, float *__restrict__ out_sumsq)
+{
+    __shared__ float red[2];
+    const int row = blockIdx.x, c = blockIdx.y * 512 + threadIdx.x * 4;
+    float ss = 0.f;
+    if (c < hidden) {
+        unsigned short *hp = h + (size_t)row * hidden + c;
+        const uint2 hv = *reinterpret_cast<const uint2 *>(hp);
+        float hx[4] = {Cvt<DT>::to_f((unsigned short)(hv.x & 0xffffu)), Cvt<DT>::to_f((unsigned short)(hv.x >> 16)),
+                       Cvt<DT>::to_f((unsigned short)(hv.y & 0xffffu)), Cvt<DT>::to_f((unsigned short)(hv.y >> 16))};
+        if (part) {
+            const size_t cstride = (size_t)prows * hidden;
+            const float *p0 = part + (size_t)row * hidden + c;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+            for (int c0 = 0; c0 < n_chunks; c0 += 8) {           // issue the loads of eight chunks before the first add
+                float4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (c0 + q < n_chunks) v[q] = *reinterpret_cast<const float4 *>(p0 + (size_t)(c0 + q) * cstride);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (c0 + q < n_chunks) { d0 += v[q].x; d1 += v[q].y; d2 += v[q].z; d3 += v[q].w; }
+            }
+            const float dd[4] = {d0, d1, d2, d3};
+            unsigned short o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dj = Cvt<DT>::to_f(Cvt<DT>::from_f(dd[j]));                   // projection output rounds to the activation dtype
+                o[j] = Cvt<DT>::from_f(hx[j] + dj);                                       // residual add rounds too
+                hx[j] = Cvt<DT>::to_f(o[j]);
+            }
+            uint2 ho;
+            ho.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
+            ho.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
+            *reinterpret_cast<uint2 *>(hp) = ho;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ss += hx[j] * hx[j];
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) out_sumsq[(size_t)blockIdx.y * prows + row] = red[0] + red[1];
+}
+
+// 1/rms of a row from the per-slice sums of squares F1r wrote (fixed order)
+__device__ __forceinline__ float row_sumsq_total(const float *__restrict__ row_sumsq, int slices, int prows, int row)
+{
+    float t = 0.f;
+    for (int s0 = 0; s0 < slices; s0 += 8) {          // eight independent loads in flight, then a fixed-order sum
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (s0 + q < slices) ? row_sumsq[(size_t)(s0 + q) * prows + row] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += v[q];
+    }
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------------ F2
 // qkv: [T, (H + 2*Hkv) * D] fused projection output (T = B*n tokens).  One wave64 per (token, head); D in {64,128}.
 // Lane l owns the rotate-half pair (d = l', d + D/2) for l' = l (+64*k).  positions: int64 [T].
@@ -212,7 +277,8 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     unsigned short *__restrict__ v_cache, const unsigned short *__restrict__ qn_w, const unsigned short *__restrict__ qn_b,
     const unsigned short *__restrict__ kn_w, const unsigned short *__restrict__ kn_b, const float *__restrict__ inv_freq,
     const long *__restrict__ positions, int B, int n, int H, int H_kv, int S_max, const sjd_iter_params *__restrict__ params,
-    int kv_len_arg, const float *__restrict__ part, int n_chunks, int prows, float k_inv, float v_inv)
+    int kv_len_arg, const float *__restrict__ part, int n_chunks, int prows, float k_inv, float v_inv,
+    const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden, float rs_eps)
 {
     constexpr int HALF = D / 2;
     constexpr int PPL = HALF / 64 > 0 ? HALF / 64 : 1;       // pairs per lane (D=128: 1, D=64: lanes 32..63 idle)
@@ -239,6 +305,7 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     const float q8 = is_k ? k_inv : v_inv;
     const bool active = lane < HALF;
     float x0 = 0.f, x1 = 0.f;
+    const float ss_tot = row_sumsq ? row_sumsq_total(row_sumsq, rs_slices, prows, tok) : 0.f;   // issued ahead of the partial loads
     if (active) {
         if (part) {                                           // fp32 split-K partials of the qkv projection (G1)
             const size_t ncol = (size_t)heads * D, col = (size_t)hh * D + lane;
@@ -246,6 +313,11 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
                 const float *pp = part + ((size_t)cc * prows + tok) * ncol + col;
                 x0 += pp[0];
                 x1 += pp[HALF];
+            }
+            if (row_sumsq) {                                  // the RMSNorm of the projection's input, applied on its output
+                const float r = rsqrtf(ss_tot * rs_inv_hidden + rs_eps);
+                x0 *= r;
+                x1 *= r;
             }
             x0 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0));
             x1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x1));
@@ -299,7 +371,8 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
 // ------------------------------------------------------------------------------------------------ F3
 template <int DT>
 __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restrict__ gu, unsigned short *__restrict__ y, int M, int I,
-                                                   const float *__restrict__ part, int n_chunks, int prows)
+                                                   const float *__restrict__ part, int n_chunks, int prows,
+                                                   const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden, float rs_eps)
 {
     const int per_row = I / 8;
     const size_t total = (size_t)M * per_row;
@@ -307,6 +380,7 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
         const int row = idx / per_row, c = (idx % per_row) * 8;
         float g[8], u[8], o[8];
         if (part) {
+            const float ss_tot = row_sumsq ? row_sumsq_total(row_sumsq, rs_slices, prows, row) : 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { g[j] = 0.f; u[j] = 0.f; }
             for (int cc = 0; cc < n_chunks; ++cc) {
@@ -316,8 +390,9 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
                 g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; g[4] += b.x; g[5] += b.y; g[6] += b.z; g[7] += b.w;
                 u[0] += e.x; u[1] += e.y; u[2] += e.z; u[3] += e.w; u[4] += f.x; u[5] += f.y; u[6] += f.z; u[7] += f.w;
             }
+            const float r = row_sumsq ? rsqrtf(ss_tot * rs_inv_hidden + rs_eps) : 1.0f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { g[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(g[j])); u[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(u[j])); }
+            for (int j = 0; j < 8; ++j) { g[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(g[j] * r)); u[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(u[j] * r)); }
         } else {
             unpack8<DT>(*reinterpret_cast<const u32x4 *>(gu + (size_t)row * 2 * I + c), g);
             unpack8<DT>(*reinterpret_cast<const u32x4 *>(gu + (size_t)row * 2 * I + I + c), u);
@@ -361,9 +436,10 @@ extern "C" int sjd_add_rmsnorm(void *h, const void *delta, const void *weight, v
 static int f2_launch(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b, const void *kn_w,
                      const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n, int H, int H_kv, int D, int S_max,
                      int dtype, const sjd_iter_params *params, int kv_len, const float *part, int n_chunks, bool kv8, float k_scale,
-                     float v_scale, void *stream)
+                     float v_scale, const sjd_row_norm *rn, void *stream)
 {
     if (part && (B * n > 64 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    if (rn && (!part || !rn->sumsq || rn->slices < 1 || rn->hidden < 1)) return SJD_ERR_BAD_ARG;
     const int prows = B * n <= 32 ? 32 : 64;
     if ((!qkv && !part) || !q_out || !k_cache || !v_cache || !inv_freq || !positions || B < 1 || n < 1 || H < 1 || H_kv < 1) return SJD_ERR_BAD_ARG;
     if (kv8 && (!(k_scale > 0.f) || !(v_scale > 0.f))) return SJD_ERR_BAD_ARG;
@@ -376,7 +452,8 @@ static int f2_launch(const void *qkv, void *q_out, void *k_cache, void *v_cache,
                            (unsigned short *)k_cache, (unsigned short *)v_cache, (const unsigned short *)qn_w,                              \
                            (const unsigned short *)qn_b, (const unsigned short *)kn_w, (const unsigned short *)kn_b, inv_freq,              \
                            (const long *)positions, B, n, H, H_kv, S_max, params, kv_len, part, n_chunks, prows,                           \
-                           kv8 ? 1.0f / k_scale : 1.0f, kv8 ? 1.0f / v_scale : 1.0f);                                                      \
+                           kv8 ? 1.0f / k_scale : 1.0f, kv8 ? 1.0f / v_scale : 1.0f, rn ? rn->sumsq : nullptr, rn ? rn->slices : 0,         \
+                           rn ? 1.0f / (float)rn->hidden : 0.f, rn ? rn->eps : 0.f);                                                       \
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;                                                                   \
     }
     SJD_F2_CASE(SJD_DTYPE_BF16, 128, false)
@@ -397,7 +474,7 @@ extern "C" int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cach
                                       const float *part, int n_chunks, void *stream)
 {
     return f2_launch(qkv, q_out, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, H_kv, D, S_max, dtype, params, kv_len,
-                     part, n_chunks, false, 1.0f, 1.0f, stream);
+                     part, n_chunks, false, 1.0f, 1.0f, nullptr, stream);
 }
 
 extern "C" int sjd_qknorm_rope_append_fp8(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b,
@@ -406,22 +483,62 @@ extern "C" int sjd_qknorm_rope_append_fp8(const void *qkv, void *q_out, void *k_
                                           const sjd_iter_params *params, int kv_len, const float *part, int n_chunks, void *stream)
 {
     return f2_launch(qkv, q_out, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, H_kv, D, S_max, dtype, params, kv_len,
-                     part, n_chunks, true, k_scale, v_scale, stream);
+                     part, n_chunks, true, k_scale, v_scale, nullptr, stream);
 }
 
-extern "C" int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks, void *stream)
+extern "C" int sjd_qknorm_rope_append_ex(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b,
+                                         const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n,
+                                         int H, int H_kv, int D, int S_max, int dtype, int kv_fp8, float k_scale, float v_scale,
+                                         const sjd_row_norm *row_norm, const sjd_iter_params *params, int kv_len, const float *part,
+                                         int n_chunks, void *stream)
+{
+    return f2_launch(qkv, q_out, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, H_kv, D, S_max, dtype, params, kv_len,
+                     part, n_chunks, kv_fp8 != 0, k_scale, v_scale, row_norm, stream);
+}
+
+extern "C" int sjd_residual_sumsq(void *h, const float *part, int n_chunks, int rows, int hidden, int dtype, float *out_sumsq, void *stream)
+{
+    if (!h || !out_sumsq || rows < 1 || rows > 64 || (part && n_chunks < 1) || hidden < 4 || (hidden % 4) != 0) return SJD_ERR_BAD_ARG;
+    const int prows = rows <= 32 ? 32 : 64;
+    const dim3 grid(rows, (hidden + 511) / 512), block(128);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SJD_DTYPE_BF16)
+        hipLaunchKernelGGL(f1r_residual_sumsq<SJD_DTYPE_BF16>, grid, block, 0, s, (unsigned short *)h, part, n_chunks, hidden, prows, out_sumsq);
+    else if (dtype == SJD_DTYPE_F16)
+        hipLaunchKernelGGL(f1r_residual_sumsq<SJD_DTYPE_F16>, grid, block, 0, s, (unsigned short *)h, part, n_chunks, hidden, prows, out_sumsq);
+    else return SJD_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+static int f3_launch(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks, const sjd_row_norm *rn,
+                     void *stream)
 {
     if (part && (rows > 64 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    if (rn && (!part || !rn->sumsq || rn->slices < 1 || rn->hidden < 1)) return SJD_ERR_BAD_ARG;
     const int prows = rows <= 32 ? 32 : 64;
     if ((!gate_up && !part) || !y || rows < 1 || inter < 8 || (inter % 8) != 0) return SJD_ERR_BAD_ARG;
     const size_t total = (size_t)rows * (inter / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipStream_t s = (hipStream_t)stream;
+    const float *ss = rn ? rn->sumsq : nullptr;
+    const int sl = rn ? rn->slices : 0;
+    const float ih = rn ? 1.0f / (float)rn->hidden : 0.f, eps = rn ? rn->eps : 0.f;
     if (dtype == SJD_DTYPE_BF16)
-        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_BF16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter, part, n_chunks, prows);
+        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_BF16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter, part, n_chunks, prows, ss, sl, ih, eps);
     else if (dtype == SJD_DTYPE_F16)
-        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_F16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter, part, n_chunks, prows);
+        hipLaunchKernelGGL(f3_silu_mul<SJD_DTYPE_F16>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)gate_up, (unsigned short *)y, rows, inter, part, n_chunks, prows, ss, sl, ih, eps);
     else return SJD_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks, void *stream)
+{
+    return f3_launch(gate_up, y, rows, inter, dtype, part, n_chunks, nullptr, stream);
+}
+
+extern "C" int sjd_silu_mul_ex(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks,
+                               const sjd_row_norm *row_norm, void *stream)
+{
+    return f3_launch(gate_up, y, rows, inter, dtype, part, n_chunks, row_norm, stream);
 }

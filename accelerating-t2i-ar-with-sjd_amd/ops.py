@@ -204,11 +204,23 @@ def add_rmsnorm(h, delta, weight, eps):
     return y
 
 
+def _row_norm(row_norm):
+    """(sumsq [slices, R] fp32, hidden, eps) -> ctypes pointer to an sjd_row_norm (or None)"""
+    if row_norm is None:
+        return None
+    sumsq, hidden, eps = row_norm
+    assert sumsq.dtype == torch.float32 and sumsq.is_contiguous() and sumsq.dim() == 2
+    rn = L.RowNorm()
+    rn.sumsq, rn.slices, rn.hidden, rn.eps = sumsq.data_ptr(), sumsq.shape[0], int(hidden), float(eps)
+    return ctypes.pointer(rn)
+
+
 def qknorm_rope_append(qkv, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, H_kv, D, params, kv_len,
-                       kv_scale=(1.0, 1.0), dtype=None):
+                       kv_scale=(1.0, 1.0), dtype=None, row_norm=None):
     """qkv [B*n, (H+2Hkv)*D] (tensor or G1 Partials) -> q [B,n,H,D]; k/v rows are written into k_cache/v_cache [B,Hkv,S,D].
     An fp8 cache (dtype FP8) receives fp8(x / scale) with kv_scale = (k, v); `dtype` = the activation dtype (needed with Partials
-    into an fp8 cache, where no 16-bit tensor is around to tell)."""
+    into an fp8 cache, where no 16-bit tensor is around to tell).  row_norm = (sumsq, hidden, eps): the projection ran on the
+    un-normalised residual stream with the norm gain folded into its weight; the row scale is applied here (folded-norm path)."""
     t, part, nc = _part_args(qkv)
     assert (t is None or t.is_contiguous()) and positions.is_contiguous() and positions.dtype == torch.int64
     assert inv_freq.dtype == torch.float32 and inv_freq.is_contiguous()
@@ -216,23 +228,16 @@ def qknorm_rope_append(qkv, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, 
     act = dtype or (t.dtype if t is not None else k_cache.dtype)
     assert act in (torch.bfloat16, torch.float16)
     q = torch.empty(B, n, H, D, dtype=act, device=k_cache.device)
-    lib = L.load()
-    if fp8:
-        L.check(lib.sjd_qknorm_rope_append_fp8(_ptr(t), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(qn_w), _ptr(qn_b), _ptr(kn_w),
-                                               _ptr(kn_b), _ptr(inv_freq), _ptr(positions), B, n, H, H_kv, D, k_cache.shape[2],
-                                               _dtype_code(act), float(kv_scale[0]), float(kv_scale[1]),
-                                               params.ptr if params is not None else None, int(kv_len), part, nc, _stream()),
-                "sjd_qknorm_rope_append_fp8")
-    else:
-        L.check(lib.sjd_qknorm_rope_append(_ptr(t), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(qn_w), _ptr(qn_b), _ptr(kn_w),
-                                           _ptr(kn_b), _ptr(inv_freq), _ptr(positions), B, n, H, H_kv, D, k_cache.shape[2],
-                                           _dtype_code(act), params.ptr if params is not None else None, int(kv_len),
-                                           part, nc, _stream()), "sjd_qknorm_rope_append")
+    L.check(L.load().sjd_qknorm_rope_append_ex(_ptr(t), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(qn_w), _ptr(qn_b), _ptr(kn_w),
+                                              _ptr(kn_b), _ptr(inv_freq), _ptr(positions), B, n, H, H_kv, D, k_cache.shape[2],
+                                              _dtype_code(act), int(fp8), float(kv_scale[0]), float(kv_scale[1]), _row_norm(row_norm),
+                                              params.ptr if params is not None else None, int(kv_len), part, nc, _stream()),
+            "sjd_qknorm_rope_append")
     return q
 
 
-def silu_mul(gate_up, rows=None, dtype=None):
-    """gate|up [T, 2I] (tensor, or G1 Partials with `rows`/`dtype` given) -> silu(gate) * up [T, I]."""
+def silu_mul(gate_up, rows=None, dtype=None, row_norm=None):
+    """gate|up [T, 2I] (tensor, or G1 Partials with `rows`/`dtype` given) -> silu(gate) * up [T, I]; row_norm as in qknorm_rope_append."""
     t, part, nc = _part_args(gate_up)
     if t is not None:
         T, two_i, dtype, dev = t.shape[0], t.shape[1], t.dtype, t.device
@@ -240,8 +245,21 @@ def silu_mul(gate_up, rows=None, dtype=None):
     else:
         T, two_i, dev = rows, gate_up.N, gate_up.data.device
     y = torch.empty(T, two_i // 2, dtype=dtype, device=dev)
-    L.check(L.load().sjd_silu_mul(_ptr(t), _ptr(y), T, two_i // 2, _dtype_code(dtype), part, nc, _stream()), "sjd_silu_mul")
+    L.check(L.load().sjd_silu_mul_ex(_ptr(t), _ptr(y), T, two_i // 2, _dtype_code(dtype), part, nc, _row_norm(row_norm), _stream()),
+            "sjd_silu_mul")
     return y
+
+
+def residual_sumsq(h, part=None):
+    """F1r: h [T, hidden] += dtype(sum of the G1 partials) in place (part None: h unchanged); returns the per-512-column-slice sums
+    of h^2 [slices, R] fp32 -- the `sumsq` of a row_norm."""
+    T, hidden = h.shape
+    assert h.is_contiguous() and (part is None or (isinstance(part, Partials) and part.N == hidden))
+    R = part.data.shape[1] if part is not None else (32 if T <= 32 else 64)
+    out = torch.empty((hidden + 511) // 512, R, dtype=torch.float32, device=h.device)
+    L.check(L.load().sjd_residual_sumsq(_ptr(h), _ptr(part.data) if part is not None else None, part.n_chunks if part is not None else 0,
+                                       T, hidden, _dtype_code(h.dtype), _ptr(out), _stream()), "sjd_residual_sumsq")
+    return out
 
 
 class HipWindowAttention:

@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--gemm", default="sjd", choices=["sjd", "torch"], help="window projections: G1 weight-streaming kernel or hipBLASLt")
     ap.add_argument("--tunableop", action="store_true", help="enable PyTorch TunableOp GEMM selection")
+    ap.add_argument("--no-fold-norm", action="store_true", help="keep F1 (RMSNorm before the projection) instead of the folded-norm forward")
     ap.add_argument("--no-fused", action="store_true", help="plain ATen element-wise glue instead of the fused F1-F3 kernels")
     ap.add_argument("--k1-launches", type=int, default=320, help="launches of the K1 micro-measurement")
     return ap.parse_args()
@@ -62,9 +63,12 @@ def build_model(args, device):
         model = BB.ChameleonBackbone(margs, attn=attn).to(dt).eval()
     if args.model == "emu3_8b":      # 64-row windows (draft window 32) need activation chunks <= 1280 columns
         model.G1_CFG = dict(qkv=(512, 6, True), o=(256, 4, False), gate_up=(1024, 8, True), down=(1024, 4, False))
+    if os.environ.get("SJD_G1_CFG"):       # tuning aid: JSON {"o": [KC, waves, step_major], ...} overriding the per-projection launch shapes
+        over = json.loads(os.environ["SJD_G1_CFG"])
+        model.G1_CFG = dict(model.G1_CFG, **{k: (int(v[0]), int(v[1]), bool(v[2])) for k, v in over.items()})
     synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=args.embed_token_scale)
     if not args.no_fused:
-        model.enable_fused(ops, gemm=args.gemm)
+        model.enable_fused(ops, gemm=args.gemm, fold_norm=not args.no_fold_norm)
     return model, margs, attn
 
 

@@ -143,6 +143,29 @@ int sjd_qknorm_rope_append(const void *qkv, void *q_out, void *k_cache, void *v_
 /* F3: y[rows, inter] = silu(gate_up[:, :inter]) * gate_up[:, inter:].  replaces ChameleonMLP's act_fn/mul (:193-195). */
 int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks, void *stream);
 
+/* Folded RMSNorm (optional, faster form of F1 -> projection -> F2/F3).  With the norm gain folded into the packed weight of the NEXT
+ * projection (W' = W diag(gamma), done once at load time) the RMSNorm is one scale per row and commutes with the projection:
+ *   gamma * (h r) W^T == r (h W'^T),  r = rsqrt(mean(h^2) + eps).
+ * sjd_residual_sumsq (F1r) does only the residual half of F1 -- h[rows, hidden] += dtype(sum_c part[c]) in place (part may be NULL) --
+ * over (row, 512-column slice) workgroups and writes out_sumsq[s, m] = sum of h[m, :]^2 over slice s ([ceil(hidden/512), R] floats,
+ * R = 32 for rows <= 32 else 64); the projection then runs on h itself and its consumer applies r through `row_norm`
+ * (sjd_qknorm_rope_append_ex / sjd_silu_mul_ex, on the summed partials before they are rounded to `dtype`).
+ * replaces ChameleonRMSNorm + the residual adds (reference modeling_chameleon.py:59-73, 637, 643); differs from F1 only in where bf16
+ * rounding happens (x_norm is never rounded; W diag(gamma) is). */
+typedef struct sjd_row_norm {
+    const float *sumsq;       /* [slices, R] */
+    int32_t slices, hidden;   /* hidden = the K of the projection whose input is normalised */
+    float eps;
+} sjd_row_norm;
+int sjd_residual_sumsq(void *h, const float *part, int n_chunks, int rows, int hidden, int dtype, float *out_sumsq, void *stream);
+int sjd_qknorm_rope_append_ex(const void *qkv, void *q_out, void *k_cache, void *v_cache, const void *qn_w, const void *qn_b,
+                              const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n,
+                              int H, int H_kv, int D, int S_max, int dtype, int kv_fp8, float k_scale, float v_scale,
+                              const sjd_row_norm *row_norm, const sjd_iter_params *params, int kv_len, const float *part,
+                              int n_chunks, void *stream);
+int sjd_silu_mul_ex(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks,
+                    const sjd_row_norm *row_norm, void *stream);
+
 /* G1 -- weight-streaming projection of the draft window: out[c, m, n] = sum_{k in chunk c} x[m, k] * W[n, k], M <= 64 rows,
  * fp32 split-K partials [n_chunks, R, N] with R = 32 (M <= 32) or 64 (n_chunks = ceil(K / KC)); the consumer (F1/F2/F3 `part` argument) sums them.
  * replaces the nn.Linear calls of the decoder layer (reference modeling_chameleon.py:527-529, 579, 193-195) for the

@@ -160,17 +160,65 @@ def test_g1_forward_matches_library_gemm_forward(dev):
     conf = dict(vocab_size=9216, hidden_size=512, intermediate_size=1024, num_hidden_layers=3, num_attention_heads=4,
                 num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
     outs = []
-    for gemm in ("torch", "sjd"):
+    for gemm, fold in (("torch", False), ("sjd", False), ("sjd", True)):
         m = make_chameleon(conf, 23, 0.5, ops.HipWindowAttention(n_split=2), dtype=torch.bfloat16, device=dev)
         m.G1_CFG = dict(qkv=(256, 8, True), o=(128, 4, False), gate_up=(512, 8, True), down=(256, 4, False))
-        m.enable_fused(ops, gemm=gemm)
+        for layer in m.model.layers:          # non-trivial norm gains, so that folding them into the packed weights is exercised
+            for nm in (layer.input_layernorm, layer.post_attention_layernorm):
+                nm.weight.data = (1 + 0.2 * torch.randn(nm.weight.shape, generator=torch.Generator().manual_seed(9))).to(nm.weight)
+        m.enable_fused(ops, gemm=gemm, fold_norm=fold)
         m.setup_cache(batch=2, s_max=128)
         toks = torch.randint(4, 9000, (2, 40), generator=torch.Generator().manual_seed(1)).to(dev)
         ks = torch.tensor([0, 7], dtype=torch.int32, device=dev)
         m.forward_window(toks, torch.arange(40)[None].repeat(2, 1).to(dev), 0, ks)
         toks2 = torch.randint(4, 9000, (2, 16), generator=torch.Generator().manual_seed(2)).to(dev)
         outs.append(m.forward_window(toks2, (40 + torch.arange(16))[None].repeat(2, 1).to(dev), 40, ks))
-    assert (outs[0] - outs[1]).abs().mean() < 0.05 and (outs[0] - outs[1]).abs().max() < 0.6
+    for o in outs[1:]:
+        assert (outs[0] - o).abs().mean() < 0.05 and (outs[0] - o).abs().max() < 0.6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [32, 17, 64])
+@pytest.mark.parametrize("N,K,KC", [(4096, 4096, 256), (512, 1376, 256), (1536, 2752, 1024)])
+def test_f1r_residual_sumsq_and_row_norm_consumers(dev, dtype, M, N, K, KC):
+    """F1r: the residual half of F1 (h bit-identical), per-slice sums of h^2; F2 / F3 with `row_norm` on a projection of the RAW
+    residual stream through a gain-folded weight match F1 -> projection -> F2 / F3 (the folded-norm forward)."""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(N + K + M)
+    x = torch.randn(M, K, generator=g).to(dtype).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    h = torch.randn(M, N, generator=g).to(dtype).to(dev)
+    gamma = (1 + 0.2 * torch.randn(N, generator=g)).to(dtype).to(dev)
+    part = ops.skinny_gemm(x, ops.pack_weight(w, KC), N, K, KC)
+    h_a, h_b, h_c = h.clone(), h.clone(), h.clone()
+    y = ops.add_rmsnorm(h_a, part, gamma, 1e-5)
+    sumsq = ops.residual_sumsq(h_b, part)
+    assert torch.equal(h_a, h_b) and sumsq.shape == ((N + 511) // 512, 32 if M <= 32 else 64)
+    torch.testing.assert_close(sumsq.sum(0)[:M], h_b.float().pow(2).sum(-1), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(ops.residual_sumsq(h_c, None).sum(0)[:M], h.float().pow(2).sum(-1), rtol=1e-4, atol=1e-3)
+    assert torch.equal(h_c, h)
+    # second projection [2I, N] consumed by F3, and a qkv-shaped one consumed by F2
+    I = 512
+    w2 = (torch.randn(2 * I, N, generator=g) / N ** 0.5).to(dtype).to(dev)
+    w2f = (w2.float() * gamma.float()[None, :]).to(dtype)
+    kc2 = 256 if N % 256 == 0 else N
+    ref = ops.silu_mul(ops.skinny_gemm(y, ops.pack_weight(w2, kc2), 2 * I, N, kc2), rows=M, dtype=dtype)
+    got = ops.silu_mul(ops.skinny_gemm(h_b, ops.pack_weight(w2f, kc2), 2 * I, N, kc2), rows=M, dtype=dtype, row_norm=(sumsq, N, 1e-5))
+    d = (ref.float() - got.float()).abs()
+    assert d.mean() < 4e-3 and d.max() < 0.15, (d.mean(), d.max())
+    B, n, H, Hkv, D = 1, M, 2, 1, 128
+    wq = (torch.randn((H + 2 * Hkv) * D, N, generator=g) / N ** 0.5).to(dtype).to(dev)
+    wqf = (wq.float() * gamma.float()[None, :]).to(dtype)
+    inv = (1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))).to(dev)
+    pos = torch.arange(M, device=dev)
+    caches = [torch.zeros(B, Hkv, 96, D, dtype=dtype, device=dev) for _ in range(4)]
+    q_ref = ops.qknorm_rope_append(ops.skinny_gemm(y, ops.pack_weight(wq, kc2), wq.shape[0], N, kc2), caches[0], caches[1],
+                                   None, None, None, None, inv, pos, B, n, H, Hkv, D, None, 3, dtype=dtype)
+    q_got = ops.qknorm_rope_append(ops.skinny_gemm(h_b, ops.pack_weight(wqf, kc2), wq.shape[0], N, kc2), caches[2], caches[3],
+                                   None, None, None, None, inv, pos, B, n, H, Hkv, D, None, 3, dtype=dtype, row_norm=(sumsq, N, 1e-5))
+    for a_, b_ in ((q_ref, q_got), (caches[0], caches[2]), (caches[1], caches[3])):
+        d = (a_.float() - b_.float()).abs()
+        assert d.mean() < 4e-3 and d.max() < 0.15, (d.mean(), d.max())
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

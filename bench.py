@@ -210,10 +210,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or os.environ.get("SJD_FORCE_DIST") == "1":
-        dist.init_process_group(backend="nccl")          # RCCL on ROCm
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world > 1 or os.environ.get("SJD_FORCE_DIST") == "1":
+        dist.init_process_group(backend="nccl", device_id=device)          # RCCL on ROCm
 
     from sjd_amd.engine import SJDEngine, SJDConfig
     from sjd_amd.grammar import LuminaGrammar
@@ -341,9 +341,14 @@ def main():
         out["roofline"] = k1_block
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, tok_per_step)
-    print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    try:                                   # RCCL prints its version banner through C stdio: flush it so that the JSON line is the LAST line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

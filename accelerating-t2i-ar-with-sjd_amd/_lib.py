@@ -21,7 +21,7 @@ class RowRule(ctypes.Structure):
 
 class IterParams(ctypes.Structure):
     _fields_ = [("n_rows", ctypes.c_int32), ("kv_len", ctypes.c_int32), ("use_cfg", ctypes.c_int32),
-                ("scheme", ctypes.c_int32), ("n_fresh", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
+                ("scheme", ctypes.c_int32), ("n_fresh", ctypes.c_int32), ("batch_rows", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2),
                 ("fresh_tok", ctypes.c_int64 * MAX_WINDOW), ("rules", RowRule * MAX_WINDOW),
                 ("resid_rules", RowRule * MAX_WINDOW)]
 

@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void k1_partial(
     const int hkv = blockIdx.y, b = blockIdx.z;
     const int head = hkv * G + head_in_group;
 
-    const int kv_base = params ? params->kv_len : kv_len_arg;
-    const int n_total = params ? params->n_rows : n_rows;         // valid rows of this call
+    const int kv_base = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
+    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;         // valid rows of this call
     const int row0 = chunk * K1_ROWS;
     const int n_c = min(K1_ROWS, n_total - row0);                 // may be <= 0 for padding chunks
     const int kv_len = kv_base + row0;                            // keys < kv_len are visible to every row of the chunk
@@ -280,10 +280,10 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
                                                  int kv_len_arg)
 {
     const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-    const int n_total = params ? params->n_rows : n_rows;
+    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;
     int eff_split;
     {
-        const int kv_base = params ? params->kv_len : kv_len_arg;
+        const int kv_base = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
         const int n_c = min(K1_ROWS, n_total - chunk * K1_ROWS);
         const int total = kv_base + chunk * K1_ROWS + max(n_c, 0);
         int t_lo, t_hi, tps;
@@ -370,8 +370,8 @@ __global__ __launch_bounds__(256) void k1_partial_fp8(
     const int head = hkv * G + head_in_group;
     unsigned char *vl = arena + (size_t)w * K1_KT * VROW;
 
-    const int kv_base = params ? params->kv_len : kv_len_arg;
-    const int n_total = params ? params->n_rows : n_rows;
+    const int kv_base = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
+    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;
     const int row0 = chunk * K1_ROWS;
     const int n_c = min(K1_ROWS, n_total - row0);
     const int kv_len = kv_base + row0;
@@ -544,13 +544,13 @@ __global__ void k3_kv_append_fp8(const u32x4 *__restrict__ k_new, const u32x4 *_
                                  u32x2 *__restrict__ v_cache, int B, int n_rows, int H_kv, int D8, int S_max,
                                  const sjd_iter_params *__restrict__ params, int kv_len_arg, float k_inv, float v_inv, int head_major)
 {
-    const int kv_len = params ? params->kv_len : kv_len_arg;
     const size_t total = (size_t)B * n_rows * H_kv * D8;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int d = i % D8;
         const int h = (i / D8) % H_kv;
         const int r = (i / ((size_t)D8 * H_kv)) % n_rows;
         const int b = i / ((size_t)D8 * H_kv * n_rows);
+        const int kv_len = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
         if (kv_len + r >= S_max) continue;
         const size_t dst = (((size_t)b * H_kv + h) * S_max + (kv_len + r)) * D8 + d;
         const size_t src = head_major ? (((size_t)b * H_kv + h) * n_rows + r) * D8 + d : i;     // [B, H_kv, n, D] or [B, n, H_kv, D]
@@ -575,8 +575,8 @@ __global__ __launch_bounds__(64) void k1_f32(const float *__restrict__ q, const 
 {
     extern __shared__ float sc[];                     // scores of the visible keys
     const int row = blockIdx.x, head = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
-    const int kv_len = params ? params->kv_len : kv_len_arg;
-    const int n_total = params ? params->n_rows : n_rows;
+    const int kv_len = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
+    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;
     float *o = out + (((size_t)b * n_rows + row) * H + head) * D;
     if (row >= n_total) { for (int d = lane; d < D; d += 64) o[d] = 0.0f; return; }
     const int hkv = head / (H / H_kv);
@@ -611,13 +611,13 @@ __global__ void k3_kv_append(const u32x4 *__restrict__ k_new, const u32x4 *__res
                              u32x4 *__restrict__ v_cache, int B, int n_rows, int H_kv, int D8, int S_max,
                              const sjd_iter_params *__restrict__ params, int kv_len_arg)
 {
-    const int kv_len = params ? params->kv_len : kv_len_arg;
     const size_t total = (size_t)B * n_rows * H_kv * D8;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int d = i % D8;
         const int h = (i / D8) % H_kv;
         const int r = (i / ((size_t)D8 * H_kv)) % n_rows;
         const int b = i / ((size_t)D8 * H_kv * n_rows);
+        const int kv_len = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
         if (kv_len + r >= S_max) continue;
         const size_t dst = (((size_t)b * H_kv + h) * S_max + (kv_len + r)) * D8 + d;
         k_cache[dst] = k_new[i];

@@ -135,7 +135,7 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
 {
     const int n_tiles = N / 32, n_chunks = (K + KC - 1) / KC;
     const dim3 grid((n_tiles + waves - 1) / waves, n_chunks), block(waves * 64);
-    const size_t lds = (size_t)MT * (KC / 16) * 64 * 16;
+    const size_t lds = (size_t)MT * ((KC < K ? KC : K) / 16) * 64 * 16;       // the staged activation chunk
     if (lds > 160 * 1024) return SJD_ERR_BAD_ARG;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((g1_skinny_gemm<DT, MT>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles,
@@ -147,7 +147,7 @@ extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, 
                                int dtype, void *stream)
 {
     if (!x || !w_packed || !out || M < 1 || M > 64 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
-    if ((size_t)KC * 64 > 160 * 1024 || waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;       // activation chunk must fit in LDS (KC <= 2560)
+    if (waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;       // (the staged activation chunk must fit in LDS: min(KC, K) <= 2560 / 1280)
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SJD_DTYPE_BF16 && M <= 32) return g1_launch<SJD_DTYPE_BF16, 1>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
     if (dtype == SJD_DTYPE_F16 && M <= 32) return g1_launch<SJD_DTYPE_F16, 1>(x, w_packed, out, M, N, K, KC, waves, step_major, s);

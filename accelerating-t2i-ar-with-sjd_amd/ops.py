@@ -41,11 +41,13 @@ def make_rule(ranges=(), forced=-1, top_k=0, top_p=None):
 class DeviceBlob:
     """A ctypes struct mirrored in pinned host memory and in a device buffer (one async H2D per upload)."""
 
-    def __init__(self, ctype, device):
+    def __init__(self, ctype, device, host=None, dev=None):
+        """host / dev: optional pre-allocated uint8 slices (one element of a contiguous array of blobs, see BlobArray)."""
         self.ctype = ctype
         self.nbytes = ctypes.sizeof(ctype)
-        self.host = torch.zeros(self.nbytes, dtype=torch.uint8, pin_memory=True)
-        self.dev = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.host = host if host is not None else torch.zeros(self.nbytes, dtype=torch.uint8, pin_memory=True)
+        self.dev = dev if dev is not None else torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        assert self.host.numel() == self.nbytes and self.dev.numel() == self.nbytes
         self.view = ctype.from_address(self.host.data_ptr())
 
     def upload(self):
@@ -57,6 +59,27 @@ class DeviceBlob:
 
     def field_ptr(self, name):
         return ctypes.c_void_p(self.dev.data_ptr() + getattr(self.ctype, name).offset)
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.dev.data_ptr())
+
+
+class BlobArray:
+    """n blobs of one ctypes struct, contiguous on the host (pinned) and on the device: the kernels that take per-prompt control
+    data index the device array (sjd_iter_params.batch_rows), the host uploads / downloads all of it with one copy."""
+
+    def __init__(self, ctype, n, device):
+        nb = ctypes.sizeof(ctype)
+        self.host = torch.zeros(n * nb, dtype=torch.uint8, pin_memory=True)
+        self.dev = torch.zeros(n * nb, dtype=torch.uint8, device=device)
+        self.blobs = [DeviceBlob(ctype, device, self.host[i * nb:(i + 1) * nb], self.dev[i * nb:(i + 1) * nb]) for i in range(n)]
+
+    def upload(self):
+        self.dev.copy_(self.host, non_blocking=True)
+
+    def download(self):
+        self.host.copy_(self.dev)
 
     @property
     def ptr(self):

@@ -31,6 +31,9 @@ def parse():
     ap.add_argument("--dtype", default=None, choices=[None, "bf16", "fp16"])
     ap.add_argument("--kv", default="auto", choices=["auto", "16bit", "fp8"],
                     help="KV-cache element type: the activation dtype, or OCP fp8 e4m3 with the fp8-MFMA K1 (auto: fp8 for anole7b = BASELINE config 5)")
+    ap.add_argument("--prompts-per-gpu", type=int, default=1,
+                    help="decode this many independent prompts per GPU in ONE window forward (SJDBatchEngine; 1 = the reference's "
+                         "operating point and BASELINE.json's configuration; 2 x B_cfg x window must stay <= 64 rows)")
     ap.add_argument("--embed-token-scale", type=float, default=0.7)
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--n-split", type=int, default=0, help="K1 key splits (0 = auto from batch x kv heads)")
@@ -61,6 +64,8 @@ def build_model(args, device):
     attn = ops.HipWindowAttention(n_split=args.n_split or None)
     with torch.device(device):
         model = BB.ChameleonBackbone(margs, attn=attn).to(dt).eval()
+    if args.prompts_per_gpu > 1 and args.model != "emu3_8b":      # 64-row windows: the staged activation chunk (64 x KC) must fit in LDS
+        model.G1_CFG = dict(model.G1_CFG_64ROW)
     if args.model == "emu3_8b":      # 64-row windows (draft window 32) need activation chunks <= 1280 columns
         model.G1_CFG = dict(qkv=(512, 6, True), o=(256, 4, False), gate_up=(1024, 8, True), down=(1024, 4, False))
     if os.environ.get("SJD_G1_CFG"):       # tuning aid: JSON {"o": [KC, waves, step_major], ...} overriding the per-projection launch shapes
@@ -265,8 +270,18 @@ def main():
     if fp8_kv:
         import sjd_amd.ops as ops_
         workload += ", fp8 (e4m3) KV cache + fp8-MFMA draft attention"
-    model.setup_cache(batch=2, s_max=s_max, dtype=ops_.FP8 if fp8_kv else None)
-    eng = SJDEngine(model, margs.vocab_size, device, max_window=args.window, use_graph=not args.no_graph)
+    PP = args.prompts_per_gpu
+    model.setup_cache(batch=2 * PP, s_max=s_max, dtype=ops_.FP8 if fp8_kv else None)
+    if PP > 1:
+        if args.model != "lumina7b" and args.model != "lumina_tiny":
+            raise SystemExit("--prompts-per-gpu > 1 is wired for the Lumina workload")
+        from sjd_amd.engine_batch import SJDBatchEngine
+        eng = SJDBatchEngine(model, margs.vocab_size, device, PP, max_window=args.window, use_graph=not args.no_graph)
+        prompts = [lumina_prompt(P, grid, grid, seed=1234 + rank * PP + i) for i in range(PP)]
+        specs = [lumina_window_spec(p_, device) for p_ in prompts]
+        workload += f", {PP} prompts per GPU sharing one window forward"
+    else:
+        eng = SJDEngine(model, margs.vocab_size, device, max_window=args.window, use_graph=not args.no_graph)
 
     def sync_all():
         if dist.is_initialized():
@@ -282,8 +297,15 @@ def main():
     def timed_end():
         sync_all()
 
-    seq, stats = eng.decode(prompt, spec, grammar, cfg, warmup_iters=args.warmup, timed_iters=args.steps,
-                            on_timed_start=timed_start, on_timed_end=timed_end)
+    if PP > 1:
+        import copy
+        res = eng.decode_many(prompts, specs, [copy.deepcopy(grammar) for _ in range(PP)], cfg, warmup_iters=args.warmup,
+                              timed_iters=args.steps, on_timed_start=timed_start, on_timed_end=timed_end)
+        stats = res[0][1]
+        stats.tokens = sum(r[1].tokens for r in res)            # all slots of this GPU; steps = shared window forwards
+    else:
+        seq, stats = eng.decode(prompt, spec, grammar, cfg, warmup_iters=args.warmup, timed_iters=args.steps,
+                                on_timed_start=timed_start, on_timed_end=timed_end)
     prof = measure_k1(args, model, attn, device, kv_len=(kv_at.get("start", P) + stats.kv_len) // 2)
     prof_g1 = measure_g1(args, model, device) if (args.gemm == "sjd" and not args.no_fused) else None
     rep = gather_report(stats.tokens, stats.timed_nfe, stats.seconds, device)   # one RCCL all_gather (24 B/rank)
@@ -309,7 +331,7 @@ def main():
         "sync_wait_ms_per_step": round(stats.sync_seconds / max(stats.timed_nfe, 1) * 1e3, 4),
         "nfe_full_image_est": round((n_img + 1) / tok_per_step, 1),
         "config": {"workload": workload + f", random-init synthetic weights (embed_token_scale={args.embed_token_scale})",
-                   "prompt_len": P, "image_tokens": n_img, "kv_len_end": stats.kv_len, "prompts": world,
+                   "prompt_len": P, "image_tokens": n_img, "kv_len_end": stats.kv_len, "prompts": world * args.prompts_per_gpu,
                    "parallelism": f"prompt-parallel x{world}"},
     }
     def traffic_of(fname):

@@ -53,11 +53,22 @@ typedef struct sjd_iter_params {
     int32_t use_cfg;                /* 1: z = g*(c-u)+u ; 0: z = c  (check_is_force_no_cfg, JL:70-80) */
     int32_t scheme;                 /* 0: speculative_jacobi ; 1: jacobi */
     int32_t n_fresh;                /* trailing window rows filled with fresh random ids */
-    int32_t reserved[3];
+    int32_t batch_rows;             /* several prompts per launch: 0 = this blob governs every batch row; > 0 = `params` points at a
+                                       contiguous ARRAY of blobs and blob i governs batch rows [i*batch_rows, (i+1)*batch_rows) of K1 /
+                                       K3 / F2 (each prompt has its own kv_len / n_rows); same value in every blob of the array */
+    int32_t reserved[2];
     int64_t fresh_tok[SJD_MAX_WINDOW];            /* random re-guess ids (host global RNG, JL:505-509), packed */
     sjd_row_rule rules[SJD_MAX_WINDOW];           /* rules of the sampling call, row j */
     sjd_row_rule resid_rules[SJD_MAX_WINDOW];     /* rule of the residual call if rejection happens at i=j+1 */
 } sjd_iter_params;
+
+#if defined(__HIPCC__)
+/* blob that governs batch row b (see batch_rows) */
+static inline __attribute__((device, always_inline)) const sjd_iter_params *sjdi_params_of(const sjd_iter_params *p, int b)
+{
+    return (p && p->batch_rows > 0) ? p + b / p->batch_rows : p;
+}
+#endif
 
 /* Device-resident decode state carried between iterations (written by sjd_verify_accept, read by sjd_reguess). */
 typedef struct sjd_state {

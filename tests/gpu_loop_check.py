@@ -212,3 +212,51 @@ def teacher_forced_emu3_check(device="cuda:0", H=3, W=5, window=32, seed=5, embe
     assert stats.matched == tr.matched and stats.nfe == len(tr.matched)
     gen = seq[P:]
     return dict(tokens=len(gen), nfe=stats.nfe, gen=gen, tok=tok, W=W, H=H)
+
+
+@torch.no_grad()
+def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=16, seed=3, P=(12, 9), embed_token_scale=0.25,
+                               dtype=torch.bfloat16, use_graph=True, gemm="sjd", fp8_kv=False):
+    """Several prompts per window forward (SJDBatchEngine): every slot's recorded logits, replayed into the CPU oracle with the slot's
+    seed, must give that slot's token sequence and accept lengths -- i.e. sharing the forward changes nothing in any prompt's
+    state machine (own window, kv_len, grammar, generators)."""
+    import sjd_amd.ops as ops
+    import sjd_amd.synthetic as synthetic
+    from sjd_amd.engine import SJDConfig, WindowSpec
+    from sjd_amd.engine_batch import SJDBatchEngine
+    from sjd_amd.grammar import LuminaGrammar
+    from tests.helpers import make_chameleon
+    V = 9216
+    conf = dict(vocab_size=V, hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=4, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    model = make_chameleon(conf, 23, embed_token_scale, ops.HipWindowAttention(n_split=2), dtype=dtype, device=device)
+    model.enable_fused(ops, gemm=gemm)
+    n_img = (2 * wg + 1) * 2 * hg
+    prompts, specs = [], []
+    for i in range(n_prompts):
+        Pi = P[i % len(P)]
+        pr = torch.cat([synthetic.synthetic_prompt(Pi - 3, seed + 17 * i, lo=8900, hi=9200), torch.tensor([[8197, 8804 + hg, 8804 + wg]])], dim=1)
+        prompts.append(pr[0].tolist())
+        specs.append(WindowSpec(first_tokens=pr.to(device).repeat(2, 1),
+                                first_positions=torch.stack([torch.arange(Pi), torch.tensor([1] * (Pi - 1) + [0])]).to(device),
+                                key_start=torch.tensor([0, Pi - 1], dtype=torch.int32),
+                                pos_offset=torch.tensor([0, -(Pi - 1)], dtype=torch.long), kv_base=0))
+    max_len = max(P) + n_img + 1 + 4
+    model.setup_cache(batch=2 * n_prompts, s_max=((max_len + 64 + 31) // 32) * 32, dtype=ops.FP8 if fp8_kv else None)
+    cfg = SJDConfig(jacobi_loop_interval_l=3, jacobi_loop_interval_r=n_img - 10, max_num_new_tokens=window, guidance_scale=3.0,
+                    seed=seed, prefix_token_sampler_scheme="speculative_jacobi", max_length=1 << 20, eos_token_ids=(8196,))
+    eng = SJDBatchEngine(model, V, device, n_prompts, max_window=window, use_graph=use_graph)
+    recs = [_Recorder() for _ in range(n_prompts)]
+    eng.hook = lambda i, d: recs[i](d)
+    results = eng.decode_many(prompts, specs, [LuminaGrammar(2000, 10) for _ in range(n_prompts)], cfg)
+    out = []
+    for i, (seq, stats) in enumerate(results):
+        c = _loop_cfg(cfg)
+        c.seed = cfg.seed + i
+        seq_ref, tr, checks = _replay(recs[i], prompts[i], lambda cx, n: O.lumina_rules(cx, n, 2000, 10), c, V,
+                                      no_cfg_fn=O.lumina_force_no_cfg, device=device)
+        assert seq == seq_ref, f"slot {i}: token sequences differ"
+        assert stats.matched == tr.matched, f"slot {i}: accept lengths differ"
+        gen = seq[len(prompts[i]):]
+        out.append(dict(tokens=len(gen), nfe=stats.nfe, last=gen[-1], max_accept=max(stats.matched[1:])))
+    return out

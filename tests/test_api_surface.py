@@ -19,6 +19,7 @@ def test_reference_import_paths_resolve():
     from scheduler.jacobi_iteration_anhole import renew_pipeline_sampler as anole_rps  # noqa
     from llamagen.llamagen_solver import LlamaGenSolver, renew_llamagen  # noqa
     from llamagen.llamagen import GPT_models  # noqa
+    from lumina_mgpt.inference_solver import FlexARInferenceSolver  # noqa  (test_lumina_mgpt.py:94)
     assert set(GPT_models) == {'GPT-B', 'GPT-L', 'GPT-XL', 'GPT-XXL', 'GPT-XXXL', 'GPT-1B', 'GPT-3B', 'GPT-7B'}
 
 

@@ -24,17 +24,28 @@ def _dtype_code(dt):
     raise L.SjdLibraryError(f"SJD HIP kernels support bf16/fp16 KV and activations, got {dt}")
 
 
+_RULE_CACHE = {}
+
+
 def make_rule(ranges=(), forced=-1, top_k=0, top_p=None):
+    """-> sjd_row_rule.  A decode asks for the same handful of rules thirty times per iteration, so the structs are interned
+    (treat them as read-only; assigning one into a params blob copies it)."""
+    key = (tuple((int(lo), int(hi)) for lo, hi in ranges), int(forced), int(top_k or 0), None if top_p is None else float(top_p))
+    r = _RULE_CACHE.get(key)
+    if r is not None:
+        return r
+    rg = key[0]
+    if len(rg) > L.MAX_RANGES:
+        raise ValueError(f"grammar needs {len(rg)} allowed ranges, kernel supports {L.MAX_RANGES}")
     r = L.RowRule()
-    ranges = list(ranges)
-    if len(ranges) > L.MAX_RANGES:
-        raise ValueError(f"grammar needs {len(ranges)} allowed ranges, kernel supports {L.MAX_RANGES}")
-    r.n_ranges = len(ranges)
-    for i, (lo, hi) in enumerate(ranges):
-        r.lo[i], r.hi[i] = int(lo), int(hi)
-    r.forced, r.top_k = int(forced), int(top_k or 0)
+    r.n_ranges = len(rg)
+    for i, (lo, hi) in enumerate(rg):
+        r.lo[i], r.hi[i] = lo, hi
+    r.forced, r.top_k = key[1], key[2]
     import numpy as np
     r.top_p_thr = -1.0 if (top_p is None or top_p >= 1.0) else float(np.float32(1.0 - float(top_p)))
+    if len(_RULE_CACHE) < 4096:
+        _RULE_CACHE[key] = r
     return r
 
 

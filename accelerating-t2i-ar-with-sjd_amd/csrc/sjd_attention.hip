@@ -21,6 +21,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/sjd_hip.h"
 
@@ -52,10 +53,9 @@ template <> struct Frag<SJD_DTYPE_BF16> {
     typedef bf16x8 vec;
     static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ unsigned short cvt(float x)
-    {   // round-to-nearest-even fp32 -> bf16
-        unsigned u = __float_as_uint(x);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (unsigned short)(u >> 16);
+    {   // round-to-nearest-even fp32 -> bf16 (v_cvt_pk_bf16_f32 on gfx950)
+        const __bf16 h = (__bf16)x;
+        return __builtin_bit_cast(unsigned short, h);
     }
 };
 template <> struct Frag<SJD_DTYPE_F16> {
@@ -271,6 +271,185 @@ __global__ __launch_bounds__(256) void k1_partial(
         ws_o[slot * D + d] = O;
         if (d == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = L; }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ K1 (shared tiles)
+// Grouped-query attention and/or several 16-row chunks (Emu3: H/H_kv = 4, draft window 32): in k1_partial every (head, chunk) pair
+// streams the same K/V tiles by itself, 8 times the bytes through L2/L1.  Here ONE workgroup owns a (batch, kv head, key split) and
+// all its (head, chunk) pairs -- one wave each, up to 8 -- and the 32-key K and V tiles are fetched once per workgroup into a
+// double-buffered LDS tile (K rows padded to 272 B: the fragment read "lane = key, 16 B" is conflict free; V as in k1_partial,
+// read back transposed).  The next tile's loads are in flight while the current one is consumed; one barrier per tile.
+// Same split / workspace layout as k1_partial (the waves of a pair cover all tiles of the split, so no LDS merge), k1_combine
+// is unchanged.
+template <int DT, int D>
+__global__ __launch_bounds__(512) void k1_partial_shared(
+    const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
+    float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max,
+    const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks)
+{
+    typedef typename Frag<DT>::vec vec;
+    constexpr int KS = D / 32, DB = D / 16;
+    constexpr int ROW = D + 8;                // padded LDS row (elements) for both tiles
+    constexpr int TILE = K1_KT * ROW;         // elements per K or V tile
+    __shared__ __attribute__((aligned(16))) unsigned short tiles[2][2][TILE];     // [buffer][K, V]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int G = H / H_kv;
+    const int head_in_group = w % G, chunk = w / G;           // wave = (q head of the group, 16-row chunk)
+    const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
+    const int head = hkv * G + head_in_group;
+    const int kv_base = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
+    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;
+    const int kstart = key_start ? key_start[b] : 0;
+    const float scale = rsqrtf((float)D);
+
+    // this wave's rows and tile range (identical to what k1_partial / k1_combine derive for its chunk)
+    const int row0 = chunk * K1_ROWS;
+    const int n_c = min(K1_ROWS, n_total - row0);
+    const int kv_len = kv_base + row0;
+    const int total = kv_len + max(n_c, 0);
+    int t_lo, t_hi, eff_split, tps;
+    k1_tile_range(kstart, total, n_split, t_lo, t_hi, eff_split, tps);
+    const bool wave_on = split < eff_split;
+    const int wt0 = wave_on ? t_lo + split * tps : 0, wt1 = wave_on ? min(t_hi, wt0 + tps) : 0;
+    // the workgroup walks the union of its waves' ranges (they differ by at most a tile between the chunks)
+    int bt0 = 1 << 30, bt1 = 0, total_max = 0;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int nc = min(K1_ROWS, n_total - ch * K1_ROWS), tot = kv_base + ch * K1_ROWS + max(nc, 0);
+        int a, e, es, tp;
+        k1_tile_range(kstart, tot, n_split, a, e, es, tp);
+        if (split < es) { bt0 = min(bt0, a + split * tp); bt1 = max(bt1, min(e, a + split * tp + tp)); }
+        total_max = max(total_max, tot);
+    }
+    if (bt1 <= bt0) {                         // no wave of this workgroup has work in this split
+        return;
+    }
+
+    vec qf[KS];
+    {
+        const bool rv = (c < n_c);
+        const unsigned short *qp = q + (((size_t)b * n_rows + (row0 + (rv ? c : 0))) * H + head) * D + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 x = rv ? *reinterpret_cast<const u32x4 *>(qp + 32 * ks) : u32x4{0, 0, 0, 0};
+            qf[ks] = as_frag<vec>(x);
+        }
+    }
+    const unsigned short *kbase = kc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
+    const unsigned short *vbase = vc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
+
+    // cooperative tile fetch: K1_KT * D / 8 16-byte pieces per tensor, spread over the workgroup
+    constexpr int PIECES = K1_KT * D / 8, LPR = D / 8;
+    constexpr int MAXP = PIECES / 256;        // pieces per thread and tensor with the smallest workgroup (4 waves)
+    u32x4 kst[MAXP], vst[MAXP];
+    const int nth = blockDim.x;
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int idx = i * nth + (int)threadIdx.x;
+            if (idx < PIECES) {
+                const size_t off = (size_t)(t * K1_KT + idx / LPR) * D + 8 * (idx % LPR);
+                kst[i] = *reinterpret_cast<const u32x4 *>(kbase + off);
+                vst[i] = *reinterpret_cast<const u32x4 *>(vbase + off);
+            }
+        }
+    };
+    auto stash = [&](int t, int buf) {        // rows of keys >= total_max are zeroed (0 * NaN inside the MFMA, see k1_partial)
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int idx = i * nth + (int)threadIdx.x;
+            if (idx < PIECES) {
+                const bool live = (t * K1_KT + idx / LPR) < total_max;
+                const int o = (idx / LPR) * ROW + 8 * (idx % LPR);
+                *reinterpret_cast<u32x4 *>(&tiles[buf][0][o]) = live ? kst[i] : u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4 *>(&tiles[buf][1][o]) = live ? vst[i] : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x4 o_acc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(bt0);
+    stash(bt0, 0);
+    __syncthreads();
+    for (int t = bt0; t < bt1; ++t) {
+        const int buf = (t - bt0) & 1;
+        const bool has_next = t + 1 < bt1;
+        if (has_next) fetch(t + 1);
+        if (t >= wt0 && t < wt1) {
+            const unsigned short *kl = tiles[buf][0], *vl = tiles[buf][1];
+            f32x4 st[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const u32x4 kf = *reinterpret_cast<const u32x4 *>(kl + (16 * kb + c) * ROW + 32 * ks + 8 * g);
+                    st[kb] = Frag<DT>::mfma(as_frag<vec>(kf), qf[ks], st[kb]);
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int key = t * K1_KT + 16 * kb + 4 * g + r;
+                    bool vis = (key >= kstart) && (key <= kv_len + c) && (key < total);
+                    float sv = vis ? st[kb][r] * scale : -INFINITY;
+                    st[kb][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float alpha = __expf(m_run - m_safe);
+            float rs = 0.0f;
+            unsigned short pb[8];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = __expf(st[kb][r] - m_safe);
+                    rs += pv;
+                    pb[4 * kb + r] = Frag<DT>::cvt(pv);
+                }
+            rs += __shfl_xor(rs, 16);
+            rs += __shfl_xor(rs, 32);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+            u32x4 pw;
+            pw[0] = pb[0] | ((unsigned)pb[1] << 16);
+            pw[1] = pb[2] | ((unsigned)pb[3] << 16);
+            pw[2] = pb[4] | ((unsigned)pb[5] << 16);
+            pw[3] = pb[6] | ((unsigned)pb[7] << 16);
+            const vec pfrag = as_frag<vec>(pw);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const unsigned short *a0 = vl + (4 * g + (c >> 2)) * ROW + 16 * db + 4 * (c & 3);
+                u32x2 lo = lds_tr_read(a0);
+                u32x2 hi = lds_tr_read(a0 + 16 * ROW);
+                u32x4 vv{lo[0], lo[1], hi[0], hi[1]};
+                f32x4 acc = o_acc[db];
+                acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+                o_acc[db] = Frag<DT>::mfma(as_frag<vec>(vv), pfrag, acc);
+            }
+        }
+        if (has_next) stash(t + 1, buf ^ 1);
+        __syncthreads();
+    }
+    if (!wave_on) return;
+    // the wave covered every tile of its split: its (m, l, O) is the split partial
+    const size_t slot0 = ((((size_t)b * H + head) * n_chunks + chunk) * n_split + split) * K1_ROWS;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws_o[(slot0 + c) * D + 16 * db + 4 * g + r] = o_acc[db][r];
+    if (g == 0) { ws_ml[(slot0 + c) * 2] = m_run; ws_ml[(slot0 + c) * 2 + 1] = l_run; }
+    (void)nw;
 }
 
 template <int DT, int D>
@@ -654,9 +833,15 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     float *ws_o = (float *)workspace;
     float *ws_ml = ws_o + (size_t)B * H * n_chunks * n_split * K1_ROWS * D;
     if (ev0) (void)hipEventRecord(ev0, stream);
-    hipLaunchKernelGGL((k1_partial<DT, D>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
-                       (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
-                       kv_len, n_split, n_chunks);
+    const int pairs = (H / H_kv) * n_chunks;           // (q head of a group, row chunk) pairs that read the same K/V tiles
+    if (D == 128 && (pairs == 4 || pairs == 8) && (H / H_kv > 1 || n_chunks > 1) && !getenv("SJD_K1_NO_SHARED"))
+        hipLaunchKernelGGL((k1_partial_shared<DT, D>), dim3(n_split, H_kv, B), dim3(64 * pairs), 0, stream, (const unsigned short *)q,
+                           (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
+                           kv_len, n_split, n_chunks);
+    else
+        hipLaunchKernelGGL((k1_partial<DT, D>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
+                           (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
+                           kv_len, n_split, n_chunks);
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,

@@ -254,6 +254,11 @@ ATTN_CASES = [
     ("mha_d64_llamagen", 2, 12, 12, 64, 288, 200, 16, [0, 0], torch.bfloat16),
     ("prefill_60_rows", 2, 4, 4, 128, 128, 0, 60, [0, 59], torch.bfloat16),
     ("prefill_17_rows_offset", 1, 2, 2, 128, 128, 9, 17, [2], torch.bfloat16),
+    # shared-tile kernel: (q head of the group, row chunk) pairs of one workgroup read each K/V tile once
+    ("gqa4_window32_emu3", 2, 8, 2, 128, 2112, 2000, 32, [5, 0], torch.float16),
+    ("gqa4_window20_ragged_chunk", 2, 8, 2, 128, 512, 333, 20, [0, 40], torch.bfloat16),
+    ("gqa4_window32_short_cache", 1, 4, 1, 128, 128, 7, 32, [0], torch.bfloat16),
+    ("gqa2_window32", 2, 4, 2, 128, 512, 300, 32, [0, 11], torch.bfloat16),
 ]
 
 

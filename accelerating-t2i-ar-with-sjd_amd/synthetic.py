@@ -61,6 +61,27 @@ def fill_state_dict(module: torch.nn.Module, seed: int = 0, skip_prefixes=(), he
     return module
 
 
+def fill_state_dict_conv(module: torch.nn.Module, seed: int = 0):
+    """Deterministic per-key fill for convolutional nets (the VQ decoders): weights N(0, 1/fan_in) with fan_in = prod(shape[1:]),
+    GroupNorm gains 1 + 0.1 N(0,1), biases 0.02 N(0,1), codebooks N(0,1).  Depends only on (key, shape, seed)."""
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if not torch.is_floating_point(t):
+                continue
+            x = torch.randn(tuple(t.shape), generator=_gen_for(name, seed), dtype=torch.float32)
+            if name.endswith("bias"):
+                x = 0.02 * x
+            elif t.dim() == 1:
+                x = 1.0 + 0.1 * x
+            elif "embedding" not in name:
+                fan_in = 1
+                for d in t.shape[1:]:
+                    fan_in *= int(d)
+                x = x / fan_in ** 0.5
+            t.copy_(x.to(t.dtype))
+    return module
+
+
 def synthetic_prompt(length: int, seed: int, lo: int = 8900, hi: int = 60000) -> torch.Tensor:
     """Prompt token ids uniform in a text-id range (never grammar tokens)."""
     g = torch.Generator(device="cpu")

@@ -18,6 +18,8 @@ Fixtures
   fn_reguess.npz                get_multi_token_for_preparation('random') (JL:470-514)
   loop_llamagen.npz             whole _sample loop, tiny LlamaGen c2i   (JL:912-1249, LS:349-456)
   loop_lumina.npz               whole _sample loop, tiny Chameleon      (JL:912-1249, MC)
+  vq_decoders.npz               image detokenizers: LlamaGen VQModel.decode_code and the Chameleon VQGAN decode of
+                                image_tokenizer.pil_from_img_toks, small widths, per-key synthetic weights
 """
 import json
 import os
@@ -481,8 +483,52 @@ def gen_loop_lumina():
     np.savez_compressed(os.path.join(HERE, "loop_lumina.npz"), **out)
 
 
+def gen_vq_decoders():
+    """Reference decoders at small widths with weights that depend only on (state-dict key, shape): the fixture keeps the key/shape
+    list (the test asserts the rewrite has exactly these), the codes and the decoded images."""
+    import torch.nn as nn
+    from llamagen.tokenizer.tokenizer_image import vq_model as LV
+    out, meta = {}, {}
+
+    class LG(nn.Module):               # the decode side of LV.VQModel with a configurable base width
+        def __init__(self):
+            super().__init__()
+            self.quantize = LV.VectorQuantizer(96, 8, 0.25, 0.0, True, False)
+            self.post_quant_conv = nn.Conv2d(8, 32, 1)
+            self.decoder = LV.Decoder(z_channels=32, ch=32, ch_mult=(1, 2, 2))
+    lg = synthetic.fill_state_dict_conv(LG().eval(), seed=11)
+    codes = torch.randint(0, 96, (2 * 5 * 6,), generator=torch.Generator().manual_seed(1))
+    img = lg.decoder(lg.post_quant_conv(lg.quantize.get_codebook_entry(codes, (2, 8, 5, 6), True)))
+    out["llamagen_codes"], out["llamagen_image"] = codes.numpy(), img.numpy()
+    meta["llamagen"] = dict(keys={k: list(v.shape) for k, v in lg.state_dict().items()}, seed=11, shape=[2, 8, 5, 6],
+                            kwargs=dict(codebook_size=96, codebook_embed_dim=8, z_channels=32, ch=32, ch_mult=[1, 2, 2]))
+
+    sys.path.insert(0, "/root/reference/lumina_mgpt")
+    from model.chameleon_vae_ori import vqgan as CV
+    dd = dict(double_z=False, z_channels=32, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 2], num_res_blocks=2,
+              attn_resolutions=[8], dropout=0.0)
+
+    class CH(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.quantize = CV.VectorQuantizer(80, 16, beta=0.25)
+            self.post_quant_conv = nn.Conv2d(16, 32, 1)
+            self.decoder = CV.Decoder(**dd)
+    ch = synthetic.fill_state_dict_conv(CH().eval(), seed=12)
+    codes = torch.randint(0, 80, (8 * 8,), generator=torch.Generator().manual_seed(2))
+    img = ch.decoder(ch.post_quant_conv(ch.quantize.get_codebook_entry(codes, (1, 8, 8, 16))))
+    out["chameleon_codes"], out["chameleon_image"] = codes.numpy(), img.numpy()
+    meta["chameleon"] = dict(keys={k: list(v.shape) for k, v in ch.state_dict().items()}, seed=12,
+                             kwargs=dict(n_embed=80, embed_dim=16, z_channels=32, ch=32, ch_mult=[1, 2, 2], num_res_blocks=2,
+                                         attn_resolutions=[8], resolution=32))
+    np.savez_compressed(os.path.join(HERE, "vq_decoders.npz"), meta=json.dumps(meta), **out)
+    print("vq_decoders.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fn", "loops"]
+    which = sys.argv[1:] or ["fn", "loops", "vq"]
+    if "vq" in which:
+        gen_vq_decoders()
     if "fn" in which:
         gen_fn_logits2tokens_lumina()
         gen_fn_logits2tokens_llamagen()

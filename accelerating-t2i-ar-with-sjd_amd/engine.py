@@ -126,6 +126,15 @@ class SJDEngine:
             p.resid_rules[j] = r
         self.params.upload()
 
+    def _fill_resid(self, resid):
+        """the residual rules are read by K4 only: they are computed and uploaded (their slice of the blob) while the forward runs"""
+        p = self.params.view
+        for j, r in enumerate(resid):
+            p.resid_rules[j] = r
+        off = L.IterParams.resid_rules.offset
+        with torch.cuda.stream(self.rng_stream):          # part 2 waits for this stream (noise_ready): off the forward's stream
+            self.params.dev[off:].copy_(self.params.host[off:], non_blocking=True)
+
     def _forward_body(self, cols=None):
         """Shape-static launch sequence, part 1: K5 + transformer forward (every dynamic scalar is read from device blobs).
         cols: vocabulary column window of the output head (None = all columns)."""
@@ -162,39 +171,44 @@ class SJDEngine:
         lo, hi = (lo // 32) * 32, min(self.V, ((hi + 31) // 32) * 32)
         return (lo, hi) if 2 * (hi - lo) <= self.V else None
 
-    def _run_window(self, cur, noise_ready, cols=None):
-        """K5 -> forward -> [wait for the noise] -> K2 -> K4.  With use_graph the two parts are hipGraphs captured once per
-        output-head column window (part 2 also once per prob-buffer parity) and replayed."""
-        main = torch.cuda.current_stream()
+    def _launch_forward(self, cols=None):
+        """part 1 (K5 + transformer forward): eager, or a hipGraph captured once per output-head column window.  Returns the logits
+        tensor part 2 will read (static across replays of the same graph)."""
         if not self.use_graph:
-            logits = self._forward_body(cols)
-            main.wait_event(noise_ready)
-            self._sample_body(cur, logits, cols)
-            return logits
+            return self._forward_body(cols)
         fkey = ("fwd", cols)
         if fkey not in self._graphs:
             if self._eager_runs.get(fkey, 0) < 1:   # one eager run warms up allocations / hipBLASLt before capture
                 self._eager_runs[fkey] = 1
-                logits = self._forward_body(cols)
-                main.wait_event(noise_ready)
-                self._sample_body(cur, logits, cols)
-                return logits
+                return self._forward_body(cols)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._graph_logits[fkey] = self._forward_body(cols)
             self._graphs[fkey] = g
         self._graphs[fkey].replay()
-        logits = self._graph_logits[fkey]
-        main.wait_event(noise_ready)
+        return self._graph_logits[fkey]
+
+    def _launch_sample(self, cur, logits, noise_ready, cols=None):
+        """part 2 (K2 + K4) once the noise drawn on the side stream is ready; a hipGraph per (prob-buffer parity, column window),
+        captured the second time that combination runs on graph-owned logits."""
+        torch.cuda.current_stream().wait_event(noise_ready)
         key = (cur, self._guidance, cols)
+        if not self.use_graph or ("fwd", cols) not in self._graphs:
+            self._sample_body(cur, logits, cols)
+            return
         if key not in self._graphs:
             self._sample_body(cur, logits, cols)     # eager warm-up of this parity, captured below for the next use
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._sample_body(cur, logits, cols)
             self._graphs[key] = g
-            return logits
+            return
         self._graphs[key].replay()
+
+    def _run_window(self, cur, noise_ready, cols=None):
+        """K5 -> forward -> [wait for the noise] -> K2 -> K4"""
+        logits = self._launch_forward(cols)
+        self._launch_sample(cur, logits, noise_ready, cols)
         return logits
 
     @torch.no_grad()
@@ -256,15 +270,26 @@ class SJDEngine:
                 fr = torch.randint(0, cfg.img_vocab_n, (1, n - 1 - a))[0].tolist()   # GLOBAL CPU generator (JL:505)
                 fresh = [cfg.img_vocab_lo + t for t in fr]                           # img_vocab[rand] (JL:509)
                 rules = grammar.window_rules(n_rows)
-                # window ids are needed on the host only for the residual grammar; carried ids come from the last read-back
-                resid = grammar.residual_rules([X[-1]] + carried[:a] + fresh) if (scheme == 0 and n_rows > 1) else []
+                resid = []                     # computed below, while the forward runs (K4 is their only reader)
             use_cfg = do_cfg and not grammar.force_no_cfg()                          # JL:1086-1096
             self._fill_params(n_rows, kv_len, use_cfg, scheme, fresh, rules, resid)
+            self.rng_stream.wait_stream(torch.cuda.current_stream())                 # the previous iteration is done with the noise
+            logits = None
+            if not first:
+                # part 1 goes out NOW: everything the forward reads (n_rows, kv_len, fresh ids) is uploaded; the residual grammar,
+                # the noise fills and their launches below overlap it instead of delaying it
+                stats.host_seconds += time.perf_counter() - t_host0
+                cols = self.logit_columns(rules)
+                logits = self._launch_forward(cols)
+                t_host0 = time.perf_counter()
+                if scheme == 0 and n_rows > 1:
+                    # window ids are needed on the host only for the residual grammar; carried ids come from the last read-back
+                    resid = grammar.residual_rules([X[-1]] + carried[:a] + fresh)
+                    self._fill_resid(resid)
             # ---------------- noise, in the reference's order and shapes; drawn on a side stream so that the three fills
             # overlap the transformer forward (they are only needed by K2 / K4) ----------------
             e1 = self.noise[:n_rows]
             g_state = None
-            self.rng_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.rng_stream):
                 if host_noise:                                                       # parity mode: CPU stream of the reference
                     e1.copy_(torch.empty(n_rows, self.V).exponential_(generator=gen))
@@ -281,8 +306,8 @@ class SJDEngine:
                         self.noise2.exponential_(generator=gen)                      # residual multinomial (JL:237)
                 noise_ready = self.rng_stream.record_event()
             # ---------------- device work ----------------
-            stats.host_seconds += time.perf_counter() - t_host0
             if first:
+                stats.host_seconds += time.perf_counter() - t_host0
                 if attn is not None and hasattr(attn, "params"):
                     attn.params = None                                               # prefill: kv_len passed by value
                 tokens, positions = spec.first_tokens.to(dev), spec.first_positions.to(dev)
@@ -297,8 +322,7 @@ class SJDEngine:
                 if attn is not None and hasattr(attn, "params"):
                     attn.params = self.params                                        # windows: kv_len / n_rows from the blob
             else:
-                cols = self.logit_columns(rules)
-                logits = self._run_window(cur, noise_ready, cols)
+                self._launch_sample(cur, logits, noise_ready, cols)
                 lc = logits[0, :n_rows]
                 lu = logits[1, :n_rows] if B > 1 else None
                 win_len = n_rows

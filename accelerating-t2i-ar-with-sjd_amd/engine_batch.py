@@ -120,38 +120,35 @@ class SJDBatchEngine:
             ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, s.noise, s.probs[cur], s.tokens_ptr, col0=cols[0] if cols else 0)
             ops.verify_accept(s.params, s.state, s.probs[cur], s.probs[1 - cur], s.rs, s.noise2[0], s.scratch)
 
-    def _run_window(self, cur, noise_ready, cols):
-        main = torch.cuda.current_stream()
+    def _launch_forward(self, cols):
         if not self.use_graph:
-            logits = self._forward_body(cols)
-            main.wait_event(noise_ready)
-            self._sample_body(cur, logits, cols)
-            return logits
+            return self._forward_body(cols)
         fkey = ("fwd", cols)
         if fkey not in self._graphs:
             if self._eager_runs.get(fkey, 0) < 1:     # one eager run warms up allocations / hipBLASLt before capture
                 self._eager_runs[fkey] = 1
-                logits = self._forward_body(cols)
-                main.wait_event(noise_ready)
-                self._sample_body(cur, logits, cols)
-                return logits
+                return self._forward_body(cols)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._graph_logits[fkey] = self._forward_body(cols)
             self._graphs[fkey] = g
         self._graphs[fkey].replay()
-        logits = self._graph_logits[fkey]
-        main.wait_event(noise_ready)
+        return self._graph_logits[fkey]
+
+    def _launch_sample(self, cur, logits, noise_ready, cols):
+        torch.cuda.current_stream().wait_event(noise_ready)
         key = (cur, self._guidance, cols)
+        if not self.use_graph or ("fwd", cols) not in self._graphs:
+            self._sample_body(cur, logits, cols)
+            return
         if key not in self._graphs:
             self._sample_body(cur, logits, cols)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._sample_body(cur, logits, cols)
             self._graphs[key] = g
-            return logits
+            return
         self._graphs[key].replay()
-        return logits
 
     def _draw_noise(self, s, n_rows, scheme):
         """the slot's three noise tensors, in the reference's order and shapes, from the slot's own device generator"""
@@ -260,28 +257,36 @@ class SJDBatchEngine:
             rule_lists, metas = [], []
             for s in self.slots:
                 if s.finished:                                 # dummy one-row window: a forced row (K2 reads no logits), result ignored
-                    n_rows, fresh = 1, []
-                    rules, resid, use_cfg = [ops.make_rule(forced=0)], [], False
+                    n_rows, fresh, a = 1, [], 0
+                    rules, use_cfg = [ops.make_rule(forced=0)], False
                 else:
                     n_rows = s.n
                     a = max(0, min(s.n_prev - s.m_prev, s.n - 1))
                     fr = torch.randint(0, cfg.img_vocab_n, (1, s.n - 1 - a), generator=s.cpu_gen)[0].tolist()
                     fresh = [cfg.img_vocab_lo + t for t in fr]
                     rules = s.grammar.window_rules(n_rows)
-                    resid = s.grammar.residual_rules([s.X[-1]] + s.carried[:a] + fresh) if (scheme == 0 and n_rows > 1) else []
                     use_cfg = do_cfg and not s.grammar.force_no_cfg()
-                self._fill(s, n_rows, s.kv_len, use_cfg, scheme, fresh, rules, resid)
-                rule_lists.append(rules)
-                metas.append((n_rows, rules, resid, use_cfg))
+                    rule_lists.append(rules)
+                self._fill(s, n_rows, s.kv_len, use_cfg, scheme, fresh, rules, [])
+                metas.append([n_rows, rules, [], use_cfg, a, fresh])
             self.params.upload()
-            self.rng_stream.wait_stream(torch.cuda.current_stream())
+            self.rng_stream.wait_stream(torch.cuda.current_stream())       # the previous iteration is done with the noise buffers
+            cols = self._columns(rule_lists) if rule_lists else None
+            host_s += time.perf_counter() - t_h
+            logits = self._launch_forward(cols)                             # everything below overlaps the forward
+            off = L.IterParams.resid_rules.offset
             with torch.cuda.stream(self.rng_stream):
-                for s, (n_rows, _, _, _) in zip(self.slots, metas):
+                for s, mt in zip(self.slots, metas):
+                    n_rows, a, fresh = mt[0], mt[4], mt[5]
+                    if not s.finished and scheme == 0 and n_rows > 1:
+                        mt[2] = s.grammar.residual_rules([s.X[-1]] + s.carried[:a] + fresh)
+                        for j, r in enumerate(mt[2]):
+                            s.params.view.resid_rules[j] = r
+                        s.params.dev[off:].copy_(s.params.host[off:], non_blocking=True)
                     self._draw_noise(s, n_rows, scheme)
                 noise_ready = self.rng_stream.record_event()
-            cols = self._columns(rule_lists)
-            host_s += time.perf_counter() - t_h
-            logits = self._run_window(cur, noise_ready, cols)
+            self._launch_sample(cur, logits, noise_ready, cols)
+            metas = [tuple(mt[:4]) for mt in metas]
             if self.hook is not None:
                 for i, (s, (n_rows, rules, resid, use_cfg)) in enumerate(zip(self.slots, metas)):
                     if s.finished:

@@ -1,4 +1,4 @@
-"""Image detokenizers: VQ token ids -> pixels, for the two VQGAN families of the reference.
+"""Image detokenizers: VQ token ids -> pixels, for the three VQGAN families of the reference.
 
 Not part of the per-token hot path: one call per finished image, plain PyTorch-ROCm convolutions (MIOpen).  The two decoders
 are the same network family -- 3x3 conv, a middle (res, attention, res), then per resolution level a run of residual blocks
@@ -11,6 +11,9 @@ with `load_state_dict(strict=True)`:
              :258-275 (get_codebook_entry: l2-normalised codebook rows)
   Chameleon  lumina_mgpt/model/chameleon_vae_ori/vqgan.py:410-529 (Decoder), :532-600 (VQModel.decode_code),
              :131-146 (get_codebook_entry) -- used by Lumina-mGPT and Anole through chameleon_vae_ori/image_tokenizer.py
+
+  Emu3       emu3/tokenizer/modeling_emu3visionvq.py:596-721 (decoder), :790-812 (decode): the same decoder with a causal
+             temporal 3-D-conv stack in front and norms modulated by the quantised latent (classes below the Chameleon one)
 
 Parity: tests/test_detokenizers.py loads per-key synthetic weights (the fixture lists the reference's state-dict keys and shapes)
 and compares the decoded image with the one the imported reference produced (tests/golden/make_golden.py::gen_vq_decoders).
@@ -209,6 +212,158 @@ class ChameleonVQ(nn.Module):
             code_b = code_b.reshape(b, h, w)
         z = self.quantize.embedding(code_b).permute(0, 3, 1, 2).contiguous()          # [b, h, w, e] -> [b, e, h, w]
         return self.decoder(self.post_quant_conv(z))
+
+
+# ------------------------------------------------------------------------------------------------ Emu3 VisionVQ (decode side)
+class _CausalConv3d(nn.Module):
+    """3-D conv over [b, c, t, h, w]: "same" padding in h/w, two frames of left padding in t (never looks at later frames)"""
+
+    def __init__(self, c_in, c_out, kernel=(3, 1, 1)):
+        super().__init__()
+        self.conv = nn.Conv3d(c_in, c_out, kernel)
+        ph, pw = kernel[1] - 1, kernel[2] - 1
+        self.pad = (pw // 2 + pw % 2, pw // 2, ph // 2 + ph % 2, ph // 2, 2, 0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, self.pad))
+
+
+class _TemporalRes(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.norm1, self.conv1 = nn.BatchNorm3d(c), _CausalConv3d(c, c, (3, 3, 3))
+        self.norm2, self.conv2 = nn.BatchNorm3d(c), _CausalConv3d(c, c, (3, 3, 3))
+
+    def forward(self, x):
+        return x + self.conv2(F.silu(self.norm2(self.conv1(F.silu(self.norm1(x))))))
+
+
+class _TemporalUp(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = _CausalConv3d(c, c, (3, 3, 3))
+
+    def forward(self, x):
+        return self.conv(x.repeat_interleave(2, dim=2))             # nearest-neighbour x2 along t
+
+
+class _SpatialNorm(nn.Module):
+    """GroupNorm whose scale and shift are 1x1 convs of the (resized) quantised latent"""
+
+    def __init__(self, c, zq_ch):
+        super().__init__()
+        self.norm_layer = _gn(c)
+        self.conv_y, self.conv_b = nn.Conv2d(zq_ch, c, 1), nn.Conv2d(zq_ch, c, 1)
+
+    def forward(self, x, zq):
+        zq = F.interpolate(zq, size=x.shape[-2:], mode="nearest")
+        return self.norm_layer(x) * self.conv_y(zq) + self.conv_b(zq)
+
+
+class _ResZ(nn.Module):
+    def __init__(self, c_in, c_out, zq_ch):
+        super().__init__()
+        self.norm1, self.conv1 = _SpatialNorm(c_in, zq_ch), nn.Conv2d(c_in, c_out, 3, padding=1)
+        self.norm2, self.conv2 = _SpatialNorm(c_out, zq_ch), nn.Conv2d(c_out, c_out, 3, padding=1)
+        if c_in != c_out:
+            self.nin_shortcut = nn.Conv2d(c_in, c_out, 1)
+
+    def forward(self, x, zq):
+        y = self.conv1(F.silu(self.norm1(x, zq)))
+        y = self.conv2(F.silu(self.norm2(y, zq)))
+        return (self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x) + y
+
+
+class _AttnZ(nn.Module):
+    def __init__(self, c, zq_ch):
+        super().__init__()
+        self.norm = _SpatialNorm(c, zq_ch)
+        self.q, self.k, self.v, self.proj_out = (nn.Conv2d(c, c, 1) for _ in range(4))
+
+    def forward(self, x, zq):
+        b, c, h, w = x.shape
+        y = self.norm(x, zq)
+        q, k, v = (m(y).flatten(2).transpose(1, 2) for m in (self.q, self.k, self.v))
+        o = F.scaled_dot_product_attention(q, k, v)
+        return x + self.proj_out(o.transpose(1, 2).reshape(b, c, h, w))
+
+
+class _Emu3Decoder(nn.Module):
+    def __init__(self, z_channels, embed_dim, ch, ch_mult, num_res_blocks, attn_levels, temporal_factor, out_channels):
+        super().__init__()
+        self.time_res_stack = nn.Sequential(*[_TemporalRes(z_channels) for _ in range(num_res_blocks)])
+        n_up, f = 0, temporal_factor
+        while f > 1:
+            n_up, f = n_up + 1, f // 2
+        self.time_conv = nn.ModuleList([_TemporalUp(z_channels) for _ in range(n_up)])
+        c = ch * ch_mult[-1]
+        self.conv_in = nn.Conv2d(z_channels, c, 3, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1, self.mid.attn_1, self.mid.block_2 = _ResZ(c, c, embed_dim), _AttnZ(c, embed_dim), _ResZ(c, c, embed_dim)
+        levels = []
+        for lvl in reversed(range(len(ch_mult))):          # coarse -> fine; stored fine-first as `up`
+            level = nn.Module()
+            level.block, level.attn = nn.ModuleList(), nn.ModuleList()
+            for _ in range(num_res_blocks + 1):
+                level.block.append(_ResZ(c, ch * ch_mult[lvl], embed_dim))
+                c = ch * ch_mult[lvl]
+                if lvl in attn_levels:
+                    level.attn.append(_AttnZ(c, embed_dim))
+            if lvl != 0:
+                level.upsample = _Up(c)
+            levels.append(level)
+        self.up = nn.ModuleList(list(reversed(levels)))
+        self.norm_out = _SpatialNorm(c, embed_dim)
+        self.conv_out = nn.Conv2d(c, out_channels, 3, padding=1)
+
+    def forward(self, z, zq):
+        """z (after post_quant_conv) and zq (raw codebook vectors): [b, t, c, h, w]; both run through the temporal stack together"""
+        x = torch.cat((z, zq), dim=0).permute(0, 2, 1, 3, 4)           # [2b, c, t, h, w]
+        x = self.time_res_stack(x)
+        for up in self.time_conv:
+            x = F.silu(up(x))
+        h, zq = torch.chunk(x.permute(0, 2, 1, 3, 4), 2, dim=0)
+        h, zq = h.reshape(-1, *h.shape[2:]), zq.reshape(-1, *zq.shape[2:])     # frames become batch entries
+        h = self.conv_in(h)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h, zq), zq), zq)
+        for level in reversed(self.up):
+            for i, blk in enumerate(level.block):
+                h = blk(h, zq)
+                if len(level.attn) > 0:
+                    h = level.attn[i](h, zq)
+            if hasattr(level, "upsample"):
+                h = level.upsample(h)
+        return self.conv_out(F.silu(self.norm_out(h, zq)))
+
+
+class Emu3VisionVQ(nn.Module):
+    """Decode side of the Emu3 VisionVQ tokenizer (reference emu3/tokenizer/modeling_emu3visionvq.py:596-721 decoder, :790-812 decode):
+    a causal temporal stack (4 output frames per latent frame) in front of a VQGAN decoder whose norms are modulated by the
+    quantised latent.  ids [b, h, w] -> image [b, 3, 8h, 8w] (frame 0), ids [b, t, h, w] -> video [b, 4t, 3, 8h, 8w]."""
+
+    def __init__(self, codebook_size=32768, embed_dim=4, z_channels=4, out_channels=3, temporal_downsample_factor=4, ch=256,
+                 ch_mult=(1, 2, 2, 4), num_res_blocks=2, attn_resolutions=(3,)):
+        super().__init__()
+        self.t_factor, self.out_channels, self.scale = temporal_downsample_factor, out_channels, 2 ** (len(ch_mult) - 1)
+        self.quantize = _Codebook(codebook_size, embed_dim)
+        self.post_quant_conv = _CausalConv3d(embed_dim, z_channels)
+        self.decoder = _Emu3Decoder(z_channels, embed_dim, ch, tuple(ch_mult), num_res_blocks, tuple(attn_resolutions),
+                                    temporal_downsample_factor, out_channels)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        return super().load_state_dict(_decode_side(state_dict), strict=strict, **kw)
+
+    @torch.no_grad()
+    def decode(self, x):
+        image = x.dim() == 3
+        if image:
+            x = x.unsqueeze(1)
+        b, t, h, w = x.shape
+        zq = self.quantize.embedding(x).permute(0, 4, 1, 2, 3).contiguous()        # [b, c, t, h, w]
+        z = self.post_quant_conv(zq)
+        video = self.decoder(z.permute(0, 2, 1, 3, 4), zq.permute(0, 2, 1, 3, 4))
+        video = video.reshape(b, t * self.t_factor, self.out_channels, h * self.scale, w * self.scale)
+        return video[:, 0] if image else video
 
 
 def to_uint8(img, truncate=False):

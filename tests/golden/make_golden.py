@@ -521,6 +521,17 @@ def gen_vq_decoders():
     meta["chameleon"] = dict(keys={k: list(v.shape) for k, v in ch.state_dict().items()}, seed=12,
                              kwargs=dict(n_embed=80, embed_dim=16, z_channels=32, ch=32, ch_mult=[1, 2, 2], num_res_blocks=2,
                                          attn_resolutions=[8], resolution=32))
+    from emu3.tokenizer.modeling_emu3visionvq import Emu3VisionVQModel
+    from emu3.tokenizer.configuration_emu3visionvq import Emu3VisionVQConfig
+    ekw = dict(codebook_size=64, embed_dim=4, z_channels=4, ch=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[1])
+    em = Emu3VisionVQModel(Emu3VisionVQConfig(**ekw)).eval()
+    synthetic.fill_state_dict_conv(em, seed=13)
+    codes = torch.randint(0, 64, (2, 4, 5), generator=torch.Generator().manual_seed(3))
+    vcodes = torch.randint(0, 64, (1, 2, 3, 4), generator=torch.Generator().manual_seed(4))
+    out["emu3_codes"], out["emu3_image"] = codes.numpy(), em.decode(codes).numpy()
+    out["emu3_video_codes"], out["emu3_video"] = vcodes.numpy(), em.decode(vcodes).numpy()
+    dec_keys = {k: list(v.shape) for k, v in em.state_dict().items() if not k.startswith(("encoder.", "quant_conv."))}
+    meta["emu3"] = dict(keys=dec_keys, seed=13, kwargs=ekw)
     np.savez_compressed(os.path.join(HERE, "vq_decoders.npz"), meta=json.dumps(meta), **out)
     print("vq_decoders.npz", {k: v.shape for k, v in out.items()})
 

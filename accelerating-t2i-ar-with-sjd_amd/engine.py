@@ -2,12 +2,15 @@
 shape-static launch sequence over device-resident state.
 
 Per window iteration (reference line numbers in brackets):
-   host   n, a', fresh random ids (torch.randint on the GLOBAL CPU generator, JL:505), grammar rules -> ONE pinned
-          sjd_iter_params blob, one async H2D;  the three noise tensors are drawn from the device generator
-   ---- captured once per prob-buffer parity in a hipGraph, replayed afterwards ----
+   host   n, a', fresh random ids (torch.randint on the GLOBAL CPU generator, JL:505), window rules -> ONE pinned
+          sjd_iter_params blob, one async H2D
+   ---- graph 1, captured once per output-head column window, launched as soon as the blob is uploaded ----
    K5     window = [last emitted | carried samples | fresh ids]                              [JL:606-701]
-   fwd    backbone.forward_window over the static L rows (PyTorch-ROCm GEMMs; K3 + K1 per layer, kv_len and n_rows
-          read from the device blob)                                                         [JL:1107]
+   fwd    backbone.forward_window over the static L rows (G1 / F1r-F3 / K1 per layer, kv_len and n_rows read from the
+          device blob; output head on the vocabulary columns the rules allow)                [JL:1107]
+   host   (while graph 1 runs) residual rules -> their slice of the blob; the three noise tensors are drawn from the
+          device generator on a side stream
+   ---- graph 2, captured once per prob-buffer parity ----
    K2     CFG + grammar + top-k + softmax + multinomial -> p[L,V], Y[L]                      [JL:82-132]
    K4     accept scan + residual resample -> m, corrected Y                                  [JL:247-376]
    ----

@@ -181,7 +181,8 @@ int sjd_silu_mul_ex(const void *gate_up, void *y, int rows, int inter, int dtype
  * fp32 split-K partials [n_chunks, R, N] with R = 32 (M <= 32) or 64 (n_chunks = ceil(K / KC)); the consumer (F1/F2/F3 `part` argument) sums them.
  * replaces the nn.Linear calls of the decoder layer (reference modeling_chameleon.py:527-529, 579, 193-195) for the
  * window forward.  w_packed: the [N, K] weight re-ordered by sjd_amd.ops.pack_weight (MFMA 32x32x16 B-fragment order,
- * one contiguous run per (k-chunk, 32-column tile)).  N % 32 == 0, K % 16 == 0, KC % 16 == 0, KC <= 2560;
+ * one contiguous run per (k-chunk, 32-column tile)).  N % 32 == 0, K % 16 == 0, KC % 16 == 0, and the staged
+ * activation chunk must fit in LDS: min(KC, K) <= 2560 for M <= 32, <= 1280 for M <= 64;
  * waves (1..16) = column tiles per workgroup sharing one staged activation chunk; step_major selects the packed record
  * order (0: one contiguous run per tile, 1: the records of all tiles interleaved per k-step). */
 int sjd_gemm_num_chunks(int K, int KC);

@@ -87,6 +87,10 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
     }
     __syncthreads();
     if (!has_tile) return;
+    // Nothing may be pending on the vector-memory counter when the main loop is entered: the compiler places ONE s_waitcnt per MFMA
+    // for every path into the loop, and with the prologue's weight loads possibly outstanding it would wait for the group just
+    // issued (vmcnt(7)..vmcnt(0)) instead of letting the MFMAs of this group run under the loads of the next one.
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
     f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)

@@ -27,6 +27,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 #ifndef G1_UNROLL
 #define G1_UNROLL 8
 #endif
+#define G1_STAGE 8          // activation pieces (16 B) a thread keeps in flight while staging
 
 // Slot of an A-fragment piece inside its 1-KiB record (lane l = 32 half + mm of the MFMA operand).  The 64 pieces are permuted
 // so that BOTH sides are bank-conflict free: the MFMA side reads a record with lanes = consecutive mm (fixed s), the staging
@@ -79,11 +80,20 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
     // stage the activation chunk in A-fragment order: the piece of (row m, k-step s, half) = x[m][k0 + 16s + 8 half .. +7] goes
     // to record (mt, s), slot g1_slot(half, m % 32, s).  Pieces are walked in ROW order (coalesced 16-byte reads along k).
     const int ppr = 2 * steps;                                    // pieces per row of the chunk
-    for (int v = threadIdx.x; v < MT * 32 * ppr; v += blockDim.x) {
-        const int m = v / ppr, j = v - m * ppr, s = j >> 1;
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (m < M) val = *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + 8 * j);
-        xl[((m >> 5) * steps + s) * 64 + g1_slot(j & 1, m & 31, s)] = val;
+    const int n_pieces = MT * 32 * ppr, nth = blockDim.x;
+    for (int v0 = threadIdx.x; v0 < n_pieces; v0 += G1_STAGE * nth) {    // all round trips of a thread in flight, not one after another
+        u32x4 val[G1_STAGE];
+#pragma unroll
+        for (int i = 0; i < G1_STAGE; ++i) {
+            const int v = v0 + i * nth, m = v / ppr, j = v - m * ppr;
+            val[i] = u32x4{0u, 0u, 0u, 0u};
+            if (v < n_pieces && m < M) val[i] = *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + 8 * j);
+        }
+#pragma unroll
+        for (int i = 0; i < G1_STAGE; ++i) {
+            const int v = v0 + i * nth, m = v / ppr, j = v - m * ppr, s = j >> 1;
+            if (v < n_pieces) xl[((m >> 5) * steps + s) * 64 + g1_slot(j & 1, m & 31, s)] = val[i];
+        }
     }
     __syncthreads();
     if (!has_tile) return;

@@ -54,6 +54,76 @@ __global__ void probe(const u32x4 *__restrict__ p, size_t n_vec, u32x4 *sink, in
     if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[tid & 63] = acc;
 }
 
+// Build-up towards G1 from the pure read: pattern-2 addressing (one tile per wave, step-major records), 8 records per group with the
+// next group in flight, and per record   mode 1: an MFMA 32x32x16 with a register A operand   mode 2: the A operand read from LDS
+// (ds_read_b128, as G1 does)   mode 3: + the fp32 tile written out at the end.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+template <int MODE>
+__global__ __launch_bounds__(512) void g1like(const u32x4 *__restrict__ p, size_t n_vec, float *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nwaves = nthreads >> 6, wave = tid >> 6, lane = tid & 63;
+    const size_t n_tiles = nwaves / 2, chunk = wave / n_tiles, t = wave % n_tiles;
+    const int steps = (int)(((n_vec / 64) / nwaves) & ~(size_t)7);
+    const u32x4 *q = p + (chunk * n_tiles * steps + t) * 64 + lane;
+    const size_t rs = n_tiles * 64;
+    if (MODE >= 2) {
+        for (int i = threadIdx.x; i < steps * 64; i += blockDim.x) lds[i] = u32x4{(unsigned)i, 1u, 2u, 3u};
+        __syncthreads();
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    u32x4 cur[8], nxt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cur[u] = __builtin_nontemporal_load(q + (size_t)u * rs);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const u32x4 areg = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    for (int g = 0; g < steps / 8; ++g) {
+        const bool more = g + 1 < steps / 8;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) nxt[u] = __builtin_nontemporal_load(q + (size_t)((g + 1) * 8 + u) * rs);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const u32x4 a = MODE >= 2 ? lds[(g * 8 + u) * 64 + lane] : areg;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, cur[u]), acc, 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+        }
+    }
+    if (MODE >= 3) {
+        float *o = sink + ((size_t)chunk * 32) * (n_tiles * 32) + t * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * (n_tiles * 32)] = acc[r];
+    } else if (acc[0] == 1.2345e-30f) sink[tid & 63] = acc[1];
+}
+
+template <int MODE>
+static float run_g1like(const char *base, size_t total, size_t bytes, float *sink, int blocks, int threads, int reps)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const size_t slots = total / bytes, n_vec = bytes / 16, nwaves = (size_t)blocks * threads / 64;
+    const int steps = (int)(((n_vec / 64) / nwaves) & ~(size_t)7);
+    const size_t lds = MODE >= 2 ? (size_t)steps * 1024 : 0;
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)g1like<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((g1like<MODE>), dim3(blocks), dim3(threads), lds, 0, (const u32x4 *)(base + (r % slots) * bytes), n_vec, sink);
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((g1like<MODE>), dim3(blocks), dim3(threads), lds, 0, (const u32x4 *)(base + (r % slots) * bytes), n_vec, sink);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return (float)((size_t)steps * 1024 * nwaves / 1e9 / (ms / reps));
+}
+
 template <int U, bool NT>
 static float run(const char *base, size_t total, size_t bytes, u32x4 *sink, int pattern, int blocks, int threads, int reps)
 {
@@ -96,6 +166,15 @@ int main(int argc, char **argv)
     hipMemset(buf, 1, total);
     hipDeviceSynchronize();
     const int reps = 48;
+    if (argc > 4 && atoi(argv[2]) == 9) {      // G1 build-up: MB 9 blocks threads
+        const int g = atoi(argv[3]), t = atoi(argv[4]);
+        float *fs;
+        hipMalloc(&fs, (size_t)64 << 20);
+        printf("{\"MB\": %zu, \"g1like\": true, \"blocks\": %d, \"threads\": %d, \"TBps_mfma_regA\": %.3f, \"TBps_mfma_ldsA\": %.3f, \"TBps_mfma_ldsA_store\": %.3f}\n",
+               mb, g, t, run_g1like<1>(buf, total, bytes, fs, g, t, reps), run_g1like<2>(buf, total, bytes, fs, g, t, reps),
+               run_g1like<3>(buf, total, bytes, fs, g, t, reps));
+        return 0;
+    }
     if (argc > 4) {      // one configuration: MB pattern blocks threads
         const int pattern = atoi(argv[2]), g = atoi(argv[3]), t = atoi(argv[4]);
         printf("{\"MB\": %zu, \"pattern\": %d, \"blocks\": %d, \"threads\": %d, \"TBps_u4\": %.3f, \"TBps_u8\": %.3f, \"TBps_u16\": %.3f, \"TBps_u8_temporal\": %.3f}\n", mb, pattern, g, t,

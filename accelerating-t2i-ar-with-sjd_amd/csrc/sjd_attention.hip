@@ -479,18 +479,33 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
         return;
     }
     const size_t base = (((size_t)b * H + head) * n_chunks + chunk) * n_split;
-    float M = -INFINITY;
-    for (int s = 0; s < eff_split; ++s) M = fmaxf(M, ws_ml[((base + s) * K1_ROWS + row) * 2]);
-    const float Ms = (M == -INFINITY) ? 0.0f : M;
-    float L = 0.f, acc[PER];
+    // four splits' (m, l, O) in flight at a time (the partials were written by the kernel that has just finished: cold), merged
+    // online in split order
+    float M = -INFINITY, L = 0.f, acc[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) acc[j] = 0.f;
-    for (int s = 0; s < eff_split; ++s) {
-        const size_t slot = (base + s) * K1_ROWS + row;
-        const float wgt = __expf(ws_ml[slot * 2] - Ms);
-        L += wgt * ws_ml[slot * 2 + 1];
+    for (int s0 = 0; s0 < eff_split; s0 += 4) {
+        float ms[4], ls[4], os[4][PER];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) acc[j] += wgt * ws_o[slot * D + d0 + j];
+        for (int q = 0; q < 4; ++q)
+            if (s0 + q < eff_split) {
+                const size_t slot = (base + s0 + q) * K1_ROWS + row;
+                ms[q] = ws_ml[slot * 2];
+                ls[q] = ws_ml[slot * 2 + 1];
+#pragma unroll
+                for (int j = 0; j < PER; ++j) os[q][j] = ws_o[slot * D + d0 + j];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (s0 + q < eff_split) {
+                const float Mn = fmaxf(M, ms[q]);
+                const float Msafe = (Mn == -INFINITY) ? 0.0f : Mn;
+                const float a0 = __expf(M - Msafe), a1 = __expf(ms[q] - Msafe);
+                L = L * a0 + ls[q] * a1;
+#pragma unroll
+                for (int j = 0; j < PER; ++j) acc[j] = acc[j] * a0 + os[q][j] * a1;
+                M = Mn;
+            }
     }
     const float inv = L > 0.f ? 1.0f / L : 0.0f;
     unsigned short *o = out + (((size_t)b * n_rows + grow) * H + head) * D + d0;

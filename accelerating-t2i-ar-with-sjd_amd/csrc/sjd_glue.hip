@@ -309,10 +309,18 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     if (active) {
         if (part) {                                           // fp32 split-K partials of the qkv projection (G1)
             const size_t ncol = (size_t)heads * D, col = (size_t)hh * D + lane;
-            for (int cc = 0; cc < n_chunks; ++cc) {
-                const float *pp = part + ((size_t)cc * prows + tok) * ncol + col;
-                x0 += pp[0];
-                x1 += pp[HALF];
+            for (int c0 = 0; c0 < n_chunks; c0 += 8) {        // the loads of eight chunks in flight (cold data: the producer
+                float v0[8], v1[8];                            // kernel has just finished), then the sum in chunk order
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (c0 + q < n_chunks) {
+                        const float *pp = part + ((size_t)(c0 + q) * prows + tok) * ncol + col;
+                        v0[q] = pp[0];
+                        v1[q] = pp[HALF];
+                    }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (c0 + q < n_chunks) { x0 += v0[q]; x1 += v1[q]; }
             }
             if (row_sumsq) {                                  // the RMSNorm of the projection's input, applied on its output
                 const float r = rsqrtf(ss_tot * rs_inv_hidden + rs_eps);
@@ -383,12 +391,21 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
             const float ss_tot = row_sumsq ? row_sumsq_total(row_sumsq, rs_slices, prows, row) : 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { g[j] = 0.f; u[j] = 0.f; }
-            for (int cc = 0; cc < n_chunks; ++cc) {
-                const float4 *pg = reinterpret_cast<const float4 *>(part + ((size_t)cc * prows + row) * 2 * I + c);
-                const float4 *pu = reinterpret_cast<const float4 *>(part + ((size_t)cc * prows + row) * 2 * I + I + c);
-                const float4 a = pg[0], b = pg[1], e = pu[0], f = pu[1];
-                g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; g[4] += b.x; g[5] += b.y; g[6] += b.z; g[7] += b.w;
-                u[0] += e.x; u[1] += e.y; u[2] += e.z; u[3] += e.w; u[4] += f.x; u[5] += f.y; u[6] += f.z; u[7] += f.w;
+            for (int c0 = 0; c0 < n_chunks; c0 += 4) {        // four chunks (16 loads) in flight, then the sum in chunk order
+                float4 a[4], b[4], e[4], f[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c0 + q < n_chunks) {
+                        const float4 *pg = reinterpret_cast<const float4 *>(part + ((size_t)(c0 + q) * prows + row) * 2 * I + c);
+                        const float4 *pu = reinterpret_cast<const float4 *>(part + ((size_t)(c0 + q) * prows + row) * 2 * I + I + c);
+                        a[q] = pg[0]; b[q] = pg[1]; e[q] = pu[0]; f[q] = pu[1];
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c0 + q < n_chunks) {
+                        g[0] += a[q].x; g[1] += a[q].y; g[2] += a[q].z; g[3] += a[q].w; g[4] += b[q].x; g[5] += b[q].y; g[6] += b[q].z; g[7] += b[q].w;
+                        u[0] += e[q].x; u[1] += e[q].y; u[2] += e[q].z; u[3] += e[q].w; u[4] += f[q].x; u[5] += f[q].y; u[6] += f[q].z; u[7] += f[q].w;
+                    }
             }
             const float r = row_sumsq ? rsqrtf(ss_tot * rs_inv_hidden + rs_eps) : 1.0f;
 #pragma unroll

@@ -73,21 +73,24 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
     const size_t rs = (size_t)rec_stride * 64;
     u32x4 cur[G1_UNROLL], nxt[G1_UNROLL];
     const int full = steps / G1_UNROLL;
-    if (has_tile && full > 0) {          // the weight stream does not depend on x: start it before staging the activations
-#pragma unroll
-        for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);
-    }
     // stage the activation chunk in A-fragment order: the piece of (row m, k-step s, half) = x[m][k0 + 16s + 8 half .. +7] goes
-    // to record (mt, s), slot g1_slot(half, m % 32, s).  Pieces are walked in ROW order (coalesced 16-byte reads along k).
+    // to record (mt, s), slot g1_slot(half, m % 32, s).  Pieces are walked in ROW order (coalesced 16-byte reads along k), eight
+    // round trips in flight per thread.  The first weight group is requested right BEHIND the first batch of x loads: vector loads
+    // retire in order, so the (cached) activation is not held up by the HBM round trip of the weights, and the weight loads
+    // travel while the activation is written to LDS.
     const int ppr = 2 * steps;                                    // pieces per row of the chunk
     const int n_pieces = MT * 32 * ppr, nth = blockDim.x;
-    for (int v0 = threadIdx.x; v0 < n_pieces; v0 += G1_STAGE * nth) {    // all round trips of a thread in flight, not one after another
+    for (int v0 = threadIdx.x, batch = 0; v0 < n_pieces || batch == 0; v0 += G1_STAGE * nth, ++batch) {
         u32x4 val[G1_STAGE];
 #pragma unroll
         for (int i = 0; i < G1_STAGE; ++i) {
             const int v = v0 + i * nth, m = v / ppr, j = v - m * ppr;
             val[i] = u32x4{0u, 0u, 0u, 0u};
             if (v < n_pieces && m < M) val[i] = *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + 8 * j);
+        }
+        if (batch == 0 && has_tile && full > 0) {
+#pragma unroll
+            for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);
         }
 #pragma unroll
         for (int i = 0; i < G1_STAGE; ++i) {

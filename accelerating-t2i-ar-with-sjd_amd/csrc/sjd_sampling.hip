@@ -177,6 +177,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
     __syncthreads();
     const int m = sh.misc[0];
     const bool rejected = (scheme == 0) && (m < n);
+    bool degenerate = false;        // residual distribution empty under the residual rule: the reference's torch.multinomial raises
     if (rejected) {
         // phase 2: residual resample of position m-1 from norm(max(p - q, 0)) (JL:203-241)
         const int row = m - 1;
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                 }
                 float S = block_canonical_sum(a0, a1, a2, a3, sh);
                 if (rule.top_p_thr >= 0.0f) S = block_top_p_apply(scratch, wlo, whi, S, rule.top_p_thr, sh);
+                degenerate = !(S > 0.0f);         // 0/0 below: flagged to the host (state->rejected = 2), never a silent arbitrary id
                 unsigned long long best = 0ull;
                 SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
 #pragma unroll
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
             }
         }
     }
-    if (threadIdx.x == 0) { state->m = m; state->rejected = rejected ? 1 : 0; state->n_prev = n; }
+    if (threadIdx.x == 0) { state->m = m; state->rejected = rejected ? (degenerate ? 2 : 1) : 0; state->n_prev = n; }
 }
 
 // ------------------------------------------------------------------------------------------------ K5

@@ -70,7 +70,10 @@ class DecodeStats:
     seconds: float = 0.0
     wall_seconds: float = 0.0
     timed_nfe: int = 0
-    kv_len: int = 0
+    kv_len: int = 0                # KV length at the end of the timed region (whole decode when none)
+    kv_len_start: int = 0          # ... at its start
+    total_tokens: int = 0          # whole decode (lead-in + warm-up + timed + continuation)
+    total_seconds: float = 0.0
     host_seconds: float = 0.0      # host bookkeeping + RNG launches before the window step is enqueued
     sync_seconds: float = 0.0      # time blocked in the per-iteration state read-back
     matched: List[int] = field(default_factory=list)
@@ -116,6 +119,19 @@ class SJDEngine:
     def reset_graphs(self):
         """Call after the backbone's cache / weights were re-allocated."""
         self._graphs, self._graph_logits, self._eager_runs = {}, {}, {}
+        self._graph_ws_version = getattr(getattr(self.backbone, "attn", None), "ws_version", 0)
+
+    def _check_graph_buffers(self):
+        """The captured graphs hold raw addresses of the K1 workspace and of the KV cache: if either was re-allocated since the
+        capture (HipWindowAttention.ws_version, the cache tensor's data_ptr) the graphs are dropped and captured again instead of
+        replaying into freed memory."""
+        attn = getattr(self.backbone, "attn", None)
+        ver = getattr(attn, "ws_version", 0)
+        cache = getattr(self.backbone, "cache", None)
+        cptr = cache.k.data_ptr() if cache is not None else 0
+        if ver != self._graph_ws_version or cptr != getattr(self, "_graph_cache_ptr", cptr):
+            self.reset_graphs()
+        self._graph_cache_ptr = cptr
 
     # ------------------------------------------------------------------------------------------------
     def _fill_params(self, n, kv_len, use_cfg, scheme, fresh, rules, resid):
@@ -179,6 +195,7 @@ class SJDEngine:
         tensor part 2 will read (static across replays of the same graph)."""
         if not self.use_graph:
             return self._forward_body(cols)
+        self._check_graph_buffers()
         fkey = ("fwd", cols)
         if fkey not in self._graphs:
             if self._eager_runs.get(fkey, 0) < 1:   # one eager run warms up allocations / hipBLASLt before capture
@@ -216,10 +233,14 @@ class SJDEngine:
 
     @torch.no_grad()
     def decode(self, prompt: List[int], spec: WindowSpec, grammar, cfg: SJDConfig, warmup_iters=0, timed_iters=None,
-               on_timed_start=None, on_timed_end=None):
+               on_timed_start=None, on_timed_end=None, lead_in_kv=None, continue_after=False, iter_log=None):
         """prompt: accepted ids handed to `_sample` (the context the grammar sees).  Returns (sequence, DecodeStats).
-        bench mode: iterations [warmup_iters, warmup_iters+timed_iters) are bracketed by on_timed_start/on_timed_end
-        (barrier + synchronize live in the callbacks) and the decode stops after them; stats then cover that region."""
+        bench mode: an untimed lead-in runs until kv_len >= lead_in_kv (None: no lead-in), then `warmup_iters` untimed iterations,
+        then EXACTLY `timed_iters` iterations bracketed by on_timed_start/on_timed_end (barrier + synchronize live in the
+        callbacks); stats.{seconds, tokens, timed_nfe, kv_len, kv_len_start, host_seconds, sync_seconds} cover that region.  The
+        decode stops after it unless continue_after (then it runs on to EOS / max_length and stats.{nfe, total_tokens,
+        total_seconds} describe the whole decode).  iter_log: list receiving (kv_len before the iteration, rows, accepted,
+        host clock after the iteration's sync) per iteration."""
         if cfg.multi_token_init_scheme != "random":
             # the released reference raises IndexError for the horizon schemes (SURVEY.md 8a defect ledger)
             raise NotImplementedError("only multi_token_init_scheme='random' is parity-checkable")
@@ -252,12 +273,18 @@ class SJDEngine:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         timed_tok0, timed_nfe0 = 0, 0
+        warm_nfe0, timing, timed_done = None, False, False
+        t_decode0 = time.perf_counter()
         finished = False
         while not finished:
-            if timed_iters is not None and stats.nfe == warmup_iters:
+            if timed_iters is not None and warm_nfe0 is None and (lead_in_kv is None or (not first and kv_len >= lead_in_kv)):
+                warm_nfe0 = stats.nfe                                            # the lead-in is over: warm-up iterations start here
+            if timed_iters is not None and warm_nfe0 is not None and not timing and not timed_done and stats.nfe == warm_nfe0 + warmup_iters:
                 if on_timed_start is not None:
                     on_timed_start()
+                timing = True
                 timed_tok0, timed_nfe0 = len(X), stats.nfe
+                stats.kv_len_start = kv_len
                 stats.host_seconds = stats.sync_seconds = 0.0
                 t0 = time.perf_counter()
                 ev0.record()
@@ -342,6 +369,9 @@ class SJDEngine:
             self.state.download()
             stats.sync_seconds += time.perf_counter() - t_sync0
             m_dev, rejected = int(st.m), bool(st.rejected)
+            if int(st.rejected) > 1:
+                raise RuntimeError("SJD verify: the residual distribution max(p - q, 0) is empty under the residual grammar rule "
+                                   "(the reference's torch.multinomial raises on the NaN probabilities at JL:237)")
             if g_state is not None and not rejected:
                 gen.set_state(g_state)
             Y = [int(st.tokens[i]) for i in range(n_rows)]
@@ -352,6 +382,8 @@ class SJDEngine:
                 m = m_dev
                 emitted, carried = Y[:m], Y[m:]
             stats.matched.append(m)
+            if iter_log is not None:
+                iter_log.append((kv_len, n_rows, m, time.perf_counter()))
             # ---------------- next window length, append, rollback ----------------
             n = min(W, r_abs - cur_len) if (l_abs <= cur_len < r_abs) else 1       # JL:1142-1144 (old cur_len)
             X.extend(emitted)
@@ -364,15 +396,24 @@ class SJDEngine:
             if X[-1] in cfg.eos_token_ids or len(X) >= cfg.max_length:             # JL:1200-1201
                 finished = True
             cur_len = len(X)
-            if timed_iters is not None and stats.nfe == warmup_iters + timed_iters:
-                break
+            if timing and stats.nfe == timed_nfe0 + timed_iters:
+                self._close_timed(stats, ev0, ev1, t0, on_timed_end, len(X) - timed_tok0, stats.nfe - timed_nfe0, kv_len)
+                timing, timed_done = False, True
+                if not continue_after:
+                    break
+        if not timed_done:          # plain decode, or EOS inside the timed region: the region is what ran since its start
+            self._close_timed(stats, ev0, ev1, t0, on_timed_end, len(X) - (timed_tok0 if timing else P),
+                              stats.nfe - (timed_nfe0 if timing else 0), kv_len)
+        torch.cuda.synchronize()
+        stats.total_tokens, stats.total_seconds = len(X) - P, time.perf_counter() - t_decode0
+        return X, stats
+
+    @staticmethod
+    def _close_timed(stats, ev0, ev1, t0, on_timed_end, tokens, nfe, kv_len):
         ev1.record()
         torch.cuda.synchronize()
         if on_timed_end is not None:
             on_timed_end()
         stats.seconds = ev0.elapsed_time(ev1) / 1000.0
         stats.wall_seconds = time.perf_counter() - t0
-        stats.tokens = len(X) - (timed_tok0 if timed_iters is not None else P)
-        stats.timed_nfe = stats.nfe - timed_nfe0
-        stats.kv_len = kv_len
-        return X, stats
+        stats.tokens, stats.timed_nfe, stats.kv_len = tokens, nfe, kv_len

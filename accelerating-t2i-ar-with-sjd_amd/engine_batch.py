@@ -73,7 +73,21 @@ class SJDBatchEngine:
         self._guidance = 3.0
         self.rng_stream = torch.cuda.Stream(device=dev)
         self.hook = None                       # test hook: called per slot and iteration with that slot's device tensors
+        self.reset_graphs()
+
+    def reset_graphs(self):
+        """Call after the backbone's cache / weights were re-allocated."""
         self._graphs, self._graph_logits, self._eager_runs = {}, {}, {}
+        self._graph_ws_version = getattr(getattr(self.backbone, "attn", None), "ws_version", 0)
+
+    def _check_graph_buffers(self):
+        """see SJDEngine._check_graph_buffers: never replay a graph that holds the address of a re-allocated workspace / cache"""
+        ver = getattr(getattr(self.backbone, "attn", None), "ws_version", 0)
+        cache = getattr(self.backbone, "cache", None)
+        cptr = cache.k.data_ptr() if cache is not None else 0
+        if ver != self._graph_ws_version or cptr != getattr(self, "_graph_cache_ptr", cptr):
+            self.reset_graphs()
+        self._graph_cache_ptr = cptr
 
     # ------------------------------------------------------------------------------------------------
     @staticmethod
@@ -123,6 +137,7 @@ class SJDBatchEngine:
     def _launch_forward(self, cols):
         if not self.use_graph:
             return self._forward_body(cols)
+        self._check_graph_buffers()
         fkey = ("fwd", cols)
         if fkey not in self._graphs:
             if self._eager_runs.get(fkey, 0) < 1:     # one eager run warms up allocations / hipBLASLt before capture
@@ -307,6 +322,8 @@ class SJDBatchEngine:
                     continue
                 st = s.state.view
                 m_dev, rejected = int(st.m), bool(st.rejected)
+                if int(st.rejected) > 1:
+                    raise RuntimeError("SJD verify: the residual distribution max(p - q, 0) is empty under the residual grammar rule")
                 if s.g_state is not None and not rejected:
                     s.gen.set_state(s.g_state)
                 Y = [int(st.tokens[j]) for j in range(n_rows)]

@@ -97,8 +97,11 @@ class FlexARInferenceSolver:
                                       "or construct the solver with item_processor=<reference FlexARItemProcessor>")
         conversations = [{"from": "human", "value": q} if i % 2 == 0 else {"from": "gpt", "value": a}
                          for q, a in qas for i in range(2)]
-        prompt = self.item_processor.process_item({"image": images, "conversations": conversations}, training_mode=False)
-        ids = self.generate_ids(list(prompt), max_gen_len, logits_processor, streamer, temperature)
+        item = {"image": images, "conversations": conversations}
+        prompt = []
+        for value in self.item_processor.process_item(item):          # IS:325-333: ints, or dicts holding an image's ids
+            prompt += [value] if isinstance(value, int) else list(value["input_ids"])
+        ids = self.generate_ids(prompt, max_gen_len, logits_processor, streamer, temperature)
         return self.decode_ids(ids)
 
     def decode_ids(self, tokens: List[int]):

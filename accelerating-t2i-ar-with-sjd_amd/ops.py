@@ -305,7 +305,13 @@ class HipWindowAttention:
         L.load()
         self.n_split = n_split
         self._auto_split = n_split is None
+        # K1 split-partial workspaces.  The window path (<= 64 rows, captured in the engine's hipGraphs) and the prefill path
+        # (a whole prompt, eager) own SEPARATE buffers, so that a long prefill never replaces the buffer whose address the
+        # captured window graphs hold; `ws_version` counts replacements of the window buffer and the engines drop their graphs
+        # when it changes (sjd_amd/engine.py::_graphs_valid).
         self._ws = None
+        self._ws_prefill = None
+        self.ws_version = 0
         self._key_start = None
         self.params = None          # DeviceBlob(IterParams) when the engine drives kv_len from the device
         self.profile_layer = None   # int: time k1_partial of that layer with HIP events (bench.py roofline leg)
@@ -323,6 +329,19 @@ class HipWindowAttention:
             self.n_split = int(min(64, max(1, target // (B * Hkv * chunks))))
         return self.n_split
 
+    def _workspace(self, B, H, n, D, device):
+        need = L.load().sjd_attention_workspace_bytes(B, H, n, D, self.n_split) // 4
+        if n > 64:                                   # prefill rows: never captured, free to grow
+            if self._ws_prefill is None or self._ws_prefill.numel() < need or self._ws_prefill.device != device:
+                self._ws_prefill = torch.empty(need, dtype=torch.float32, device=device)
+            return self._ws_prefill
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            # sized for the largest window (64 rows) of this (B, H, D, n_split) so that it is allocated once per configuration
+            full = L.load().sjd_attention_workspace_bytes(B, H, 64, D, self.n_split) // 4
+            self._ws = torch.empty(max(need, full), dtype=torch.float32, device=device)
+            self.ws_version += 1
+        return self._ws
+
     def __call__(self, layer, q, k, v, cache, kv_len, key_start):
         B, n, H, D = q.shape
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
@@ -332,14 +351,12 @@ class HipWindowAttention:
             ks = key_start
         else:
             ks = torch.as_tensor(key_start, dtype=torch.int32).to(q.device)
-        need = L.load().sjd_attention_workspace_bytes(B, H, n, D, self.n_split) // 4
-        if self._ws is None or self._ws.numel() < need or self._ws.device != q.device:
-            self._ws = torch.empty(need, dtype=torch.float32, device=q.device)
+        ws = self._workspace(B, H, n, D, q.device)
         out = torch.empty_like(q)
         kv_host = 0 if self.params is not None else int(kv_len)
         if kc.dtype == FP8:
             kv_append_fp8(k, v, kc, vc, self.kv_scale[0], self.kv_scale[1], self.params, kv_host)
-            draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], ks, self.params, kv_host, self.n_split, self._ws)
+            draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], ks, self.params, kv_host, self.n_split, ws)
             return out
         kv_append(k, v, kc, vc, self.params, kv_host)
         ev0 = ev1 = None
@@ -357,7 +374,7 @@ class HipWindowAttention:
                 kv_rows = int(kv_len) + n
             alg = 2 * B * Hkv * kv_rows * D * esz + B * n * H * D * esz
             self.profile_records.append((ev0, ev1, alg, kv_rows))
-        draft_window_attention(q, kc, vc, out, ks, self.params, kv_host, self.n_split, self._ws, ev0, ev1)
+        draft_window_attention(q, kc, vc, out, ks, self.params, kv_host, self.n_split, ws, ev0, ev1)
         return out
 
     def attend(self, layer, q, cache, kv_len, key_start):
@@ -365,15 +382,13 @@ class HipWindowAttention:
         B, n, H, D = q.shape
         kc, vc = cache.k[layer], cache.v[layer]
         self._resolve_split(B, kc.shape[1], n, H)
-        need = L.load().sjd_attention_workspace_bytes(B, H, n, D, self.n_split) // 4
-        if self._ws is None or self._ws.numel() < need or self._ws.device != q.device:
-            self._ws = torch.empty(need, dtype=torch.float32, device=q.device)
+        ws = self._workspace(B, H, n, D, q.device)
         out = torch.empty_like(q)
         kv_host = 0 if self.params is not None else int(kv_len)
         if kc.dtype == FP8:
-            draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], key_start, self.params, kv_host, self.n_split, self._ws)
+            draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], key_start, self.params, kv_host, self.n_split, ws)
         else:
-            draft_window_attention(q, kc, vc, out, key_start, self.params, kv_host, self.n_split, self._ws)
+            draft_window_attention(q, kc, vc, out, key_start, self.params, kv_host, self.n_split, ws)
         return out
 
     def profile_summary(self):

@@ -137,6 +137,8 @@ class SpeculativeSampler:
         q = draft_prob[0].float().contiguous()
         ops.verify_accept(blob, state, p, q, rs.contiguous(), noise2, torch.empty(V, dtype=torch.float32, device=dev))
         st = state.download()
+        if int(st.rejected) > 1:
+            raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0")      # torch.multinomial's message (JL:237)
         if g_state is not None and not st.rejected:
             self.generator.set_state(g_state)
         m = int(st.m)
@@ -265,8 +267,21 @@ def renew_sampler(model_class):
                             multi_token_init_scheme=self.multi_token_init_scheme, img_vocab_lo=self.img_vocab_range[0],
                             img_vocab_n=self.img_vocab_range[1] - self.img_vocab_range[0], max_length=max_len, eos_token_ids=eos)
             B = 2 if do_cfg else 1
+            if max_len >= (1 << 30):
+                # no MaxLength criterion: bound the cache by the model's own context instead of asking for ~1e9 rows
+                a_ = getattr(self, "args", None)
+                lim = getattr(a_, "max_position_embeddings", None) or (getattr(a_, "block_size", 0) + getattr(a_, "cls_token_num", 0)) or None
+                if lim is None:
+                    raise ValueError("_sample needs a MaxLengthCriteria / generation_config.max_length (the model states no context limit)")
+                max_len = cfg.max_length = int(lim)
             need = spec.kv_base + max(max_len, input_ids.shape[1]) + self.max_num_new_tokens + 32
             if self.cache is None or self.cache.k.shape[1] != B or self.cache.s_max < need:
+                if spec.kv_base > 0:
+                    # the conditioning rows are already IN the cache (LlamaGen prefill): re-allocating would decode from zeros.  The
+                    # reference fails with a shape error when the CFG batch of `_sample` disagrees with the one `generate` prefilled.
+                    have = None if self.cache is None else (int(self.cache.k.shape[1]), int(self.cache.s_max))
+                    raise ValueError(f"prefilled KV cache (batch, rows) = {have} does not fit `_sample` (batch {B}, rows {need}): "
+                                     "cfg_scale > 1 at prefill must match do_cfg / guidance_scale of the sampler")
                 self.setup_cache(batch=B, s_max=((need + 31) // 32) * 32)
                 for e in self._sjd_engines.values():
                     e.reset_graphs()

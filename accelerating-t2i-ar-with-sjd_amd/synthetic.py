@@ -89,28 +89,42 @@ def synthetic_prompt(length: int, seed: int, lo: int = 8900, hi: int = 60000) ->
     return torch.randint(lo, hi, (1, length), generator=g, dtype=torch.long)
 
 
+def device_tensor_fill(name: str, t: torch.Tensor, seed: int = 0, head_gain: float = 3.0, embed_token_scale: float = 1.0):
+    """In-place fill of ONE state-dict tensor on its own device (the per-tensor rule of fill_state_dict_device; the values depend
+    only on (name, shape, seed, embed_token_scale), so a single tensor -- e.g. the embedding table -- can be re-drawn alone)."""
+    g = torch.Generator(device=t.device)
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2**63 - 1))
+    lname = name.lower()
+    x = torch.randn(t.shape, generator=g, device=t.device, dtype=torch.float32)
+    if lname.endswith("bias"):
+        x = 0.02 * x
+    elif t.dim() == 1 or "norm" in lname:
+        x = 1.0 + 0.1 * x
+    elif "embed" in lname:
+        if embed_token_scale < 1.0:
+            common = torch.randn(t.shape[-1:], generator=g, device=t.device, dtype=torch.float32)
+            x = common + embed_token_scale * x
+    else:
+        gain = head_gain if (lname.startswith("output.") or lname.startswith("lm_head.")) else 1.0
+        x = x * (gain / t.shape[-1] ** 0.5)
+    t.copy_(x.to(t.dtype))
+
+
 def fill_state_dict_device(module: torch.nn.Module, seed: int = 0, head_gain: float = 3.0, embed_token_scale: float = 1.0):
     """Same distribution as fill_state_dict but drawn ON the tensor's device (fast for 7B-parameter benches).
     Values differ from the CPU variant; use fill_state_dict when CPU/GPU weight equality matters."""
     with torch.no_grad():
         for name, t in module.state_dict().items():
-            if not torch.is_floating_point(t):
-                continue
-            g = torch.Generator(device=t.device)
-            g.manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2**63 - 1))
-            lname = name.lower()
-            x = torch.randn(t.shape, generator=g, device=t.device, dtype=torch.float32)
-            if lname.endswith("bias"):
-                x = 0.02 * x
-            elif t.dim() == 1 or "norm" in lname:
-                x = 1.0 + 0.1 * x
-            elif "embed" in lname:
-                if embed_token_scale < 1.0:
-                    common = torch.randn(t.shape[-1:], generator=g, device=t.device, dtype=torch.float32)
-                    x = common + embed_token_scale * x
-            else:
-                gain = head_gain if (lname.startswith("output.") or lname.startswith("lm_head.")) else 1.0
-                x = x * (gain / t.shape[-1] ** 0.5)
-            t.copy_(x.to(t.dtype))
-            del x
+            if torch.is_floating_point(t):
+                device_tensor_fill(name, t, seed, head_gain, embed_token_scale)
+    return module
+
+
+def refill_embeddings_device(module: torch.nn.Module, seed: int = 0, embed_token_scale: float = 1.0):
+    """Re-draw only the token-embedding tables in place (same storage: captured hipGraphs stay valid).  embed_token_scale = 1.0 is
+    the "floor" regime of SURVEY.md 8(d): plain random weights, ~1 accepted token per SJD step."""
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if torch.is_floating_point(t) and "embed" in name.lower() and t.dim() == 2:
+                device_tensor_fill(name, t, seed, 3.0, embed_token_scale)
     return module

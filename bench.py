@@ -5,15 +5,26 @@ Workload (config.workload): Lumina-mGPT-7B architecture (Chameleon-7B dims, bf16
 no checkpoints reach the GPU box), one 768x768 prompt per GPU (P=64 incl. <start> h w, 48x(48+1) image tokens),
 draft window 16, CFG 3.0 (cond||uncond batch of 2), image top-k 2000, speculative_jacobi, seed 1234+rank.
 A "step" is ONE SJD iteration (= one transformer forward over the draft window + the whole hand-written hot path).
-Synthetic weights are generated with embed_token_scale<1 (sjd_amd/synthetic.py) so that the acceptance rate is in the
-regime the reference publishes (~2.1-2.4 tokens/step); tokens_per_step is reported next to the value.
 
-python bench.py [--gpus N] [--steps K] [--warmup W]   (N>1: launched by torch.distributed.run, one rank per GPU)
+Where the K timed steps sit: the cost of a step grows with the KV length, so the decode first runs an UNTIMED lead-in (real SJD
+iterations from the prompt) until the KV length is such that the W warm-up + K timed steps are centred on the mean KV length of
+a whole image (P + image/2 = 1240 for 768x768; `--kv-center 0` times from the prompt as round 1 did).  At N=1 the same decode
+then continues to the end of the image, so the line also carries the MEASURED whole-image NFE / tokens/s (`whole_image`) and
+ms/step at KV lengths {64, 1216, 2368} (`per_kv`), plus three bounded side legs: `floor` (plain random embeddings: ~1 token/step),
+`torch_baseline` (the reference's data flow in PyTorch-ROCm ops on the same weights at the same KV length: `vs_baseline`), and
+`cpu_baseline` (the oracle's scheduler step on the host cores).
+
+python bench.py [--gpus N] [--steps K] [--warmup W]
+   N > 1 without a torch.distributed environment: re-executes itself under `python -m torch.distributed.run --nproc-per-node N`
+   (one rank per GPU, RCCL); under the driver's own torchrun launch it reads RANK / LOCAL_RANK / WORLD_SIZE.  Prompt i -> rank i
+   (weak scaling), no collective inside the decode, ONE all_gather of [tokens, steps, seconds] at the end.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,10 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--model", default="lumina7b", choices=["lumina7b", "lumina_tiny", "emu3_8b", "anole7b"],
                     help="lumina7b = BASELINE.json's metric config; emu3_8b = config 3 (720x720, GQA 32/8, V=184622, fp16)")
@@ -37,15 +48,36 @@ def parse():
     ap.add_argument("--embed-token-scale", type=float, default=0.7)
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--n-split", type=int, default=0, help="K1 key splits (0 = auto from batch x kv heads)")
+    ap.add_argument("--kv-center", type=int, default=-1,
+                    help="KV length the timed region is centred on (-1: the mean over a whole image, P + image/2; 0: no lead-in, time from the prompt)")
+    ap.add_argument("--no-whole-image", action="store_true", help="stop after the timed region (default at N=1: decode on to the end of the image)")
+    ap.add_argument("--no-floor", action="store_true")
+    ap.add_argument("--floor-steps", type=int, default=96)
+    ap.add_argument("--no-torch-baseline", action="store_true")
+    ap.add_argument("--torch-baseline-steps", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-iters", type=int, default=450, help="scheduler steps of the cpu_baseline sample (~22 ms each)")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=0, help="scheduler steps of the cpu_baseline sample (0: sized for ~15 s)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--gemm", default="sjd", choices=["sjd", "torch"], help="window projections: G1 weight-streaming kernel or hipBLASLt")
     ap.add_argument("--tunableop", action="store_true", help="enable PyTorch TunableOp GEMM selection")
     ap.add_argument("--no-fold-norm", action="store_true", help="keep F1 (RMSNorm before the projection) instead of the folded-norm forward")
     ap.add_argument("--no-fused", action="store_true", help="plain ATen element-wise glue instead of the fused F1-F3 kernels")
     ap.add_argument("--k1-launches", type=int, default=320, help="launches of the K1 micro-measurement")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` with no torch.distributed environment: start N ranks ourselves (the reference's fan-out is one
+    process per GPU, dataset_tools/multi_gpu_infer_with_prompt.py:146-172) and hand our stdout through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    return subprocess.call(cmd, env=env)
 
 
 def build_model(args, device):
@@ -78,8 +110,9 @@ def build_model(args, device):
 
 
 def measure_k1(args, model, attn, device, kv_len):
-    """Dominant hand-written kernel, measured live with HIP events on the stream it runs on: k1_partial over layer 0's
-    cache at the mean KV length of the timed region (same B/H/D/window/n_split as the decode), back-to-back launches."""
+    """K1 measured live with HIP events on the stream it runs on: k1_partial over the per-layer caches at KV length `kv_len` (same
+    B/H/D/window/n_split as the decode), cycling over all layers' caches like a real iteration (~40 MB/layer x 32 streams from HBM; a
+    single layer would sit in the 256 MB Infinity Cache)."""
     import ctypes
     import torch
     import sjd_amd._lib as L
@@ -87,15 +120,14 @@ def measure_k1(args, model, attn, device, kv_len):
     lib = L.load()
     B, n, H, D = 2, args.window, model.n_heads, model.head_dim
     n_split = attn.n_split or 8
-    nl = model.cache.k.shape[0]      # cycle over all layers' caches like a real iteration: ~40 MB/layer x 32 streams from HBM,
-    kc, vc = model.cache.k, model.cache.v   # a single layer would sit in the 256 MB Infinity Cache
-    q = torch.randn(B, n, H, D, device=device).to(kc.dtype)
+    nl = model.cache.k.shape[0]
+    kc, vc = model.cache.k, model.cache.v
+    kv_len = min(int(kv_len), model.cache.s_max - n)
+    q = torch.randn(B, n, H, D, device=device).to(kc.dtype if kc.dtype != ops.FP8 else model.lm_head.weight.dtype)
     out = torch.empty_like(q)
     ks = torch.tensor([0, 0], dtype=torch.int32, device=device) if model.n_kv_heads != model.n_heads else torch.tensor([0, 63], dtype=torch.int32, device=device)
     ws = ops.attention_workspace(B, H, n, D, n_split, device)
     if kc.dtype == ops.FP8:        # fp8 cache: k1_partial_fp8 + k1_combine, back-to-back launches between one event pair
-        q = q.to(model.lm_head.weight.dtype)
-        out = torch.empty_like(q)
         sk, sv = attn.kv_scale
         for i in range(nl):
             ops.draft_window_attention_fp8(q, kc[i], vc[i], out, sk, sv, ks, None, kv_len, n_split, ws)
@@ -142,7 +174,7 @@ def measure_g1(args, model, device, rounds=2):
     hip = ctypes.CDLL("libamdhip64.so")
     H, Hkv, D, hid, inter = model.n_heads, model.n_kv_heads, model.head_dim, model.args.hidden_size, model.args.intermediate_size
     shapes = dict(qkv=((H + 2 * Hkv) * D, hid), o=(hid, H * D), gate_up=(2 * inter, hid), down=(hid, inter))
-    xs = {k: torch.randn(32, K, device=device).to(torch.bfloat16) for k, (N, K) in shapes.items()}
+    xs = {k: torch.randn(32, K, device=device).to(model.lm_head.weight.dtype) for k, (N, K) in shapes.items()}
     cfg = model.G1_CFG
 
     def one_pass():
@@ -172,41 +204,94 @@ def measure_g1(args, model, device, rounds=2):
     return dict(launches=n, avg_ms=tot_ms / n, avg_bytes=tot_b / n, gbps=tot_b / 1e9 / (tot_ms / 1e3))
 
 
-def cpu_baseline(args, tokens_per_step):
-    """The reference's scheduler step (logits->probs->sample + verify/accept) as restated by the CPU oracle, timed on
-    this host (1 core, scalar C), on a bounded sample of the same workload: V=65536, L=16, CFG, image top-k 2000."""
-    import numpy as np
+def cpu_baseline(args, gpu_sched_ms=None):
+    """The reference's scheduler step (logits->probs->sample + verify/accept) as restated by the CPU oracle, timed on this host on a
+    bounded sample of the same workload: V=65536, L=16, CFG, image top-k 2000.  The window rows of the K2 restatement are independent
+    and run one per OpenMP thread on all host cores (min(nproc, L) threads do work); the accept scan is sequential, as in the reference."""
     import torch
     from oracle import sjd_oracle as O
     V, L = 65536, args.window
+    nproc = os.cpu_count() or 1
+    threads = O.set_threads(nproc)
     g = torch.Generator().manual_seed(0)
     ctx = [9000] * 61 + [8197, 8828, 8828] + [100] * 40
     rules = O.lumina_rules(ctx, L, 2000, 10)
     resid = [O.lumina_rules(ctx, 1, 2000, 10)[0] for _ in range(L - 1)]
-    t_total, n_it = 0.0, 0
-    prev = None
     ring = []                                   # eight pre-drawn input sets, cycled: the sample times the scheduler step, not the RNG
     for _ in range(8):
         ring.append(((torch.randn(2, L, V, generator=g) * 3.0).numpy(), torch.empty(L, V).exponential_(generator=g).numpy(),
                      torch.rand(L, V, generator=g).numpy(), torch.empty(V).exponential_(generator=g).numpy()))
-    for it in range(args.cpu_baseline_iters):
+
+    def step(it, prev):
         logits, noise, rs, e2 = ring[it % len(ring)]
-        t0 = time.perf_counter()
         toks, probs = O.logits_to_probs_sample(logits[0], logits[1], 3.0, rules, noise)
         q_rows = [None] * L if prev is None else [prev[i] for i in range(L)]
         win = [100] + toks[:-1].tolist()
         O.verify_accept(win, toks, probs, q_rows, rs, resid, e2)
+        return probs
+
+    prev = None
+    t0 = time.perf_counter()
+    for it in range(3):                          # probe: size the sample for ~15 s of CPU work
+        prev = step(it, prev)
+    probe = (time.perf_counter() - t0) / 3
+    n_it = args.cpu_baseline_iters or int(min(2000, max(50, 15.0 / max(probe, 1e-4))))
+    t_total = 0.0
+    for it in range(n_it):
+        t0 = time.perf_counter()
+        prev = step(it, prev)
         t_total += time.perf_counter() - t0
-        n_it += 1
-        prev = probs
-    sec_per_step = t_total / n_it
-    return {"value": round(tokens_per_step / sec_per_step, 2), "unit": "image-tokens/s (scheduler step only, no transformer forward)",
-            "cores": 1, "kind": "port", "ms_per_step": round(sec_per_step * 1e3, 2),
-            "sample": f"{n_it} SJD scheduler steps (logits->probs->sample + verify/accept), V=65536, L={L}, CFG, top-k 2000"}
+    sec = t_total / n_it
+    out = {"value": round(1.0 / sec, 2), "unit": "SJD scheduler steps/s (logits->tokens + verify/accept only; no transformer forward)",
+           "cores": min(threads, L), "host_cores": nproc, "kind": "port", "ms_per_step": round(sec * 1e3, 3),
+           "sample": f"{n_it} SJD scheduler steps, V=65536, L={L}, CFG, top-k 2000 ({t_total:.1f} s of CPU work)"}
+    if gpu_sched_ms:
+        out["gpu_same_work_ms_per_step"] = round(gpu_sched_ms, 4)
+    return out
+
+
+def measure_scheduler_gpu(eng, grammar0, prompt, window, reps=200):
+    """K2 + K4 (the GPU side of what cpu_baseline times) on a full image-body window: HIP-event time per step.  The iteration blob is
+    set to `window` image rows (rules of a context just inside the image); logits are those of the engine's last body forward."""
+    import copy
+    import torch
+    g = copy.deepcopy(grammar0)
+    ctx = list(prompt) + [100] * 5
+    g.start(ctx)
+    rules = g.window_rules(window)
+    cols = eng.logit_columns(rules)
+    logits = eng._graph_logits.get(("fwd", cols))
+    if logits is None:
+        return None
+    resid = g.residual_rules([100] * window)
+    eng._fill_params(window, 100, True, 0, [], rules, resid)
+    ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        eng._sample_body(0, logits, cols)
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(reps):
+        eng._sample_body(0, logits, cols)
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / reps
+
+
+def per_kv_table(iter_log, points, half=48):
+    """median ms/step of the iterations whose KV length lies within +-half of each point (host clock after each iteration's sync)"""
+    out = {}
+    for S in points:
+        d = sorted((iter_log[i][3] - iter_log[i - 1][3]) * 1e3 for i in range(1, len(iter_log))
+                   if abs(iter_log[i][0] - S) <= half and iter_log[i][1] > 1)
+        if d:
+            out[str(S)] = {"ms_per_step": round(d[len(d) // 2], 4), "iterations": len(d)}
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
     if args.tunableop:
         os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
         os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
@@ -216,6 +301,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("SJD_FORCE_DIST") == "1":
@@ -225,12 +312,14 @@ def main():
     from sjd_amd.grammar import LuminaGrammar
     from sjd_amd.frontends import lumina_window_spec, lumina_prompt
     from sjd_amd.parallel import gather_report
+    import sjd_amd.synthetic as synthetic
 
     model, margs, attn = build_model(args, device)
+    grid = 48
+    tau_est = 2.3                                  # accepted tokens / step used only to place the lead-in
     if args.model == "emu3_8b":
         from sjd_amd.frontends import emu3_window_spec
         from sjd_amd.grammar import Emu3Grammar
-        import sjd_amd.synthetic as synthetic
         tok = dict(img_token=151851, eoi_token=151853, eos_token=151850, eol_token=151846, eof_token=151847, pad_token=151643)
         Hh = Ww = 90                                        # 720x720 / 8 (reference test_emu3.py:121-122)
         pos = synthetic.synthetic_prompt(63, 1234 + rank, lo=1000, hi=150000)[0].tolist() + [tok["img_token"]]
@@ -245,7 +334,6 @@ def main():
         workload = f"Emu3-Gen 8B architecture 720x720 (90x91 visual tokens), pos/neg prompt CFG 3.0, top-k 2048, draft window {args.window}, fp16"
     elif args.model == "anole7b":
         from sjd_amd.grammar import AnoleGrammar
-        import sjd_amd.synthetic as synthetic
         P, n_img = 64, 1024 + 1                              # 512x512 -> 32x32 VQ tokens + <eoi>; no line tokens (config 5)
         prompt = synthetic.synthetic_prompt(P - 1, 1234 + rank, lo=9000, hi=60000)[0].tolist() + [8197]
         spec = lumina_window_spec(prompt, device)
@@ -256,7 +344,7 @@ def main():
         workload = (f"Anole/Chameleon-7B architecture 512x512 (1024 image tokens, image-only grammar), draft window {args.window}, CFG 3.0, "
                     f"top-k 2000, bf16")
     else:
-        P, grid = 64, 48
+        P = 64
         n_img = grid * (grid + 1)
         prompt = lumina_prompt(P, grid, grid, seed=1234 + rank)
         spec = lumina_window_spec(prompt, device)
@@ -268,8 +356,8 @@ def main():
                     f"CFG 3.0 (batch 2), top-k 2000, bf16")
     s_max = ((P + n_img + 2 * args.window + 64 + 31) // 32) * 32
     fp8_kv = args.kv == "fp8" or (args.kv == "auto" and args.model == "anole7b")
+    import sjd_amd.ops as ops_
     if fp8_kv:
-        import sjd_amd.ops as ops_
         workload += ", fp8 (e4m3) KV cache + fp8-MFMA draft attention"
     PP = args.prompts_per_gpu
     model.setup_cache(batch=2 * PP, s_max=s_max, dtype=ops_.FP8 if fp8_kv else None)
@@ -289,25 +377,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kv_at = {}
-
-    def timed_start():
-        sync_all()
-        kv_at["start"] = int(eng.params.view.kv_len)
-
-    def timed_end():
-        sync_all()
-
+    # ---- where the timed region sits
+    kv_center = (P + n_img // 2) if args.kv_center < 0 else args.kv_center
+    lead_in_kv = None
+    if kv_center > 0 and PP == 1:
+        lead_in_kv = int(kv_center - tau_est * (args.steps / 2.0 + args.warmup))
+        if lead_in_kv <= P + args.window:
+            lead_in_kv = None
+    whole_image = (world == 1 and PP == 1 and not args.no_whole_image)
+    iter_log = []
+    import copy
+    grammar0 = copy.deepcopy(grammar)              # pristine grammar for the side legs
+    t_wall0 = time.perf_counter()
     if PP > 1:
-        import copy
         res = eng.decode_many(prompts, specs, [copy.deepcopy(grammar) for _ in range(PP)], cfg, warmup_iters=args.warmup,
-                              timed_iters=args.steps, on_timed_start=timed_start, on_timed_end=timed_end)
-        stats = res[0][1]
+                              timed_iters=args.steps, on_timed_start=sync_all, on_timed_end=sync_all)
+        seq, stats = res[0]
         stats.tokens = sum(r[1].tokens for r in res)            # all slots of this GPU; steps = shared window forwards
+        stats.kv_len_start = P
     else:
-        seq, stats = eng.decode(prompt, spec, grammar, cfg, warmup_iters=args.warmup, timed_iters=args.steps,
-                                on_timed_start=timed_start, on_timed_end=timed_end)
-    prof = measure_k1(args, model, attn, device, kv_len=(kv_at.get("start", P) + stats.kv_len) // 2)
+        seq, stats = eng.decode(prompt, spec, grammar, cfg, warmup_iters=args.warmup, timed_iters=args.steps, on_timed_start=sync_all,
+                                on_timed_end=sync_all, lead_in_kv=lead_in_kv, continue_after=whole_image, iter_log=iter_log)
+    decode_wall = time.perf_counter() - t_wall0
+    kv_mid = (stats.kv_len_start + stats.kv_len) // 2
+    prof = measure_k1(args, model, attn, device, kv_len=kv_mid)
     prof_g1 = measure_g1(args, model, device) if (args.gemm == "sjd" and not args.no_fused) else None
     rep = gather_report(stats.tokens, stats.timed_nfe, stats.seconds, device)   # one RCCL all_gather (24 B/rank)
     if rank != 0:
@@ -319,22 +412,41 @@ def main():
     t_max = max(r[2] for r in rep)
     tps = tot_tokens / t_max
     tok_per_step = tot_tokens / max(tot_steps, 1)
+    dt_name = "fp16" if model.lm_head.weight.dtype == torch.float16 else "bf16"
     out = {
         "metric": ("accepted image-tokens/s (SJD, Emu3 720px, BASELINE.json config 3)" if args.model == "emu3_8b"
                    else "accepted image-tokens/s (SJD, Anole/Chameleon-7B 512px, fp8 draft attention, BASELINE.json config 5)" if args.model == "anole7b"
                    else "accepted image-tokens/s (SJD, Lumina-mGPT-7B 768px); tokens_per_step = 1/steps-to-converge rate"),
         "value": round(tps, 2), "unit": "image-tokens/s", "n_gpus": world, "steps": stats.timed_nfe, "warmup": args.warmup,
         "ms_per_step": round(t_max / max(stats.timed_nfe, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "fp16" if str(model.lm_head.weight.dtype).endswith("float16") and "bf" not in str(model.lm_head.weight.dtype) else "bf16",
-        "data": "synthetic",
+        "vs_baseline": None, "dtype": dt_name, "data": "synthetic",
         "tokens_per_step": round(tok_per_step, 4),
         "host_ms_per_step": round(stats.host_seconds / max(stats.timed_nfe, 1) * 1e3, 4),
         "sync_wait_ms_per_step": round(stats.sync_seconds / max(stats.timed_nfe, 1) * 1e3, 4),
-        "nfe_full_image_est": round((n_img + 1) / tok_per_step, 1),
         "config": {"workload": workload + f", random-init synthetic weights (embed_token_scale={args.embed_token_scale})",
-                   "prompt_len": P, "image_tokens": n_img, "kv_len_end": stats.kv_len, "prompts": world * args.prompts_per_gpu,
-                   "parallelism": f"prompt-parallel x{world}"},
+                   "prompt_len": P, "image_tokens": n_img, "kv_len_start": stats.kv_len_start, "kv_len_end": stats.kv_len,
+                   "lead_in_steps": 0,
+                   "prompts": world * args.prompts_per_gpu, "parallelism": f"prompt-parallel x{world}"},
     }
+    if iter_log:       # untimed real SJD iterations before the W warm-up steps (kv_len grows strictly, so the region's first step is unique)
+        i_start = next((i for i, r in enumerate(iter_log) if r[0] == stats.kv_len_start), args.warmup)
+        out["config"]["lead_in_steps"] = max(0, i_start - args.warmup)
+    if whole_image and iter_log:
+        # the SAME decode, continued to the end of the image: measured steps-to-converge and whole-image rate (host wall clock of the
+        # whole decode, which includes the prefill iteration, the hipGraph captures and the two barrier brackets)
+        n_tok, nfe = stats.total_tokens, stats.nfe
+        t_img = iter_log[-1][3] - iter_log[0][3]                   # from the end of the prefill iteration to the last iteration
+        out["whole_image"] = {"tokens": n_tok, "nfe": nfe, "tokens_per_step": round(n_tok / max(nfe, 1), 4),
+                              "seconds": round(t_img, 4), "ms_per_step": round(t_img / max(nfe - 1, 1) * 1e3, 4),
+                              "tokens_per_s": round((n_tok - 1) / t_img, 2), "finished": bool(seq[-1] in cfg.eos_token_ids),
+                              "reference_published_nfe": "1009-1115 (hardware unstated, BASELINE.md)" if args.model == "lumina7b" else None}
+        pts = [P, P + n_img // 2 - 24, P + n_img - 112] if args.model != "lumina7b" else [64, 1216, 2368]
+        out["per_kv"] = per_kv_table(iter_log, pts)
+        for S in pts:
+            if str(S) in out["per_kv"]:
+                k1 = measure_k1(args, model, attn, device, kv_len=S)
+                out["per_kv"][str(S)].update({"k1_partial_us": round(k1["avg_ms"] * 1e3, 2), "k1_GBps": round(k1["gbps"], 1)})
+
     def traffic_of(fname):
         if args.model != "lumina7b":
             return None                     # the committed PMC traffic files were collected at the Lumina-7B shapes
@@ -362,8 +474,41 @@ def main():
             out["roofline_k1"] = k1_block
     elif k1_block is not None:
         out["roofline"] = k1_block
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, tok_per_step)
+    side_legs = (world == 1 and PP == 1)
+    gpu_sched_ms = None
+    if side_legs and not args.no_graph:
+        try:
+            gpu_sched_ms = measure_scheduler_gpu(eng, grammar0, prompt, args.window)
+        except Exception:
+            gpu_sched_ms = None
+    if side_legs and not args.no_floor:
+        # floor regime: plain random embeddings -> the next-token distribution depends almost only on the previous
+        # token -> ~1 accepted token per step.  Same engine, same graphs (the embedding table is re-drawn in place).
+        synthetic.refill_embeddings_device(model, seed=0, embed_token_scale=1.0)
+        cfg_f = copy.copy(cfg)
+        _, st_f = eng.decode(prompt, spec, copy.deepcopy(grammar0), cfg_f, warmup_iters=8, timed_iters=args.floor_steps,
+                             on_timed_start=sync_all, on_timed_end=sync_all)
+        synthetic.refill_embeddings_device(model, seed=0, embed_token_scale=args.embed_token_scale)
+        tpf = st_f.tokens / max(st_f.timed_nfe, 1)
+        out["floor"] = {"embed_token_scale": 1.0, "tokens_per_step": round(tpf, 4), "steps": st_f.timed_nfe,
+                        "ms_per_step": round(st_f.seconds / max(st_f.timed_nfe, 1) * 1e3, 4), "kv_len": [st_f.kv_len_start, st_f.kv_len],
+                        "tokens_per_s_at_headline_ms_per_step": round(tpf / (t_max / max(stats.timed_nfe, 1)), 2)}
+    if side_legs and not args.no_torch_baseline and args.model in ("lumina7b", "lumina_tiny"):
+        # PyTorch-ROCm SJD: the reference's data flow with ATen ops on the SAME weights, prefilled with the engine's
+        # own accepted sequence up to the start of the timed region, so that both run at the same KV length
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import torch_sjd_baseline as TB
+        ctx = seq[:stats.kv_len_start + 1] if stats.kv_len_start >= P else list(prompt)
+        tb = TB.run_on_engine_model(model, ctx, P, grid, args.torch_baseline_steps, 4, seed=1234, window=args.window)
+        tb["what"] = ("reference data flow in PyTorch-ROCm ops (torch.cat KV cache, masked SDPA, torch.topk, torch.multinomial, Python "
+                      "accept loop with a sync per draft), same weights, same KV length; tools/torch_sjd_baseline.py")
+        out["torch_baseline"] = tb
+        out["vs_baseline"] = round(tps / tb["tokens_per_s"], 3) if tb["tokens_per_s"] > 0 else None
+        out["vs_baseline_per_step"] = round(tb["ms_per_step"] / out["ms_per_step"], 3)
+        out["vs_baseline_kind"] = "value / torch_baseline.tokens_per_s (PyTorch-ROCm SJD on this GPU; the reference publishes no number on stated hardware)"
+    if side_legs and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, gpu_sched_ms)
+    out["bench_wall_s"] = {"decode": round(decode_wall, 2)}
     if dist.is_initialized():
         dist.destroy_process_group()
     try:                                   # RCCL prints its version banner through C stdio: flush it so that the JSON line is the LAST line

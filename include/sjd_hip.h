@@ -73,7 +73,9 @@ static inline __attribute__((device, always_inline)) const sjd_iter_params *sjdi
 /* Device-resident decode state carried between iterations (written by sjd_verify_accept, read by sjd_reguess). */
 typedef struct sjd_state {
     int32_t m;                      /* tokens emitted by the last iteration (first_misaligned, 1..n) */
-    int32_t rejected;               /* 1: a residual resample happened (the g-stream consumed noise2) */
+    int32_t rejected;               /* 1: a residual resample happened (the g-stream consumed noise2); 2: ... and the residual
+                                     * distribution was EMPTY under the residual rule (sum 0): the host raises, as the
+                                     * reference's torch.multinomial does on NaN probabilities (JL:237) */
     int32_t n_prev;                 /* window length of the last iteration */
     int32_t prob_buf;               /* which of the two prob buffers holds the last iteration's rows */
     int64_t tokens[SJD_MAX_WINDOW]; /* corrected samples Y of the last iteration: [0,m) emitted, [m,n) carried */

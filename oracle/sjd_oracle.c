@@ -193,10 +193,20 @@ int sjd_o_logits_to_probs_sample(const float *logits_c, const float *logits_u, f
                                  int n_rows, int V, const sjd_row_rule *rules, const float *noise,
                                  float *probs_out, int64_t *tokens_out)
 {
-    float *z = (float *)malloc((size_t)V * sizeof(float));
-    float *scratch = (float *)malloc((size_t)V * sizeof(float));
-    if (!z || !scratch) return -1;
+    /* window rows are independent (the reference's tensor ops broadcast over L): with OpenMP one row per thread, which is what
+     * bench.py's cpu_baseline leg times on all host cores; the result does not depend on the thread count */
+    int err = 0;
+#pragma omp parallel for schedule(dynamic, 1)
     for (int j = 0; j < n_rows; ++j) {
+        float *z = (float *)malloc((size_t)V * sizeof(float));
+        float *scratch = (float *)malloc((size_t)V * sizeof(float));
+        if (!z || !scratch) {
+#pragma omp atomic write
+            err = -1;
+            free(z);
+            free(scratch);
+            continue;
+        }
         const float *c = logits_c + (size_t)j * V;
         if (logits_u) {
             const float *u = logits_u + (size_t)j * V;
@@ -212,11 +222,20 @@ int sjd_o_logits_to_probs_sample(const float *logits_c, const float *logits_u, f
         float *p = probs_out + (size_t)j * V;
         softmax_canonical(z, V, p);                        /* JL:111 */
         tokens_out[j] = argmax_ratio(p, noise + (size_t)j * V, V);   /* JL:118 */
+        free(z);
+        free(scratch);
     }
-    free(z);
-    free(scratch);
-    return 0;
+    return err;
 }
+
+#ifdef _OPENMP
+#include <omp.h>
+int sjd_o_max_threads(void) { return omp_get_max_threads(); }
+void sjd_o_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+int sjd_o_max_threads(void) { return 1; }
+void sjd_o_set_threads(int n) { (void)n; }
+#endif
 
 /* ---------------------------------------------------------------- K4 restatement */
 /* Window of n tokens.  win_tok[n]: window ids (win_tok[0] = last accepted token).

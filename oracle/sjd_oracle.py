@@ -50,7 +50,15 @@ def lib():
         _lib.sjd_o_expf.restype = ctypes.c_float
         _lib.sjd_o_sum.argtypes = [f32p, ctypes.c_int]
         _lib.sjd_o_sum.restype = ctypes.c_float
+        _lib.sjd_o_max_threads.restype = ctypes.c_int
+        _lib.sjd_o_set_threads.argtypes = [ctypes.c_int]
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads of the K2 restatement (rows of a window are independent); returns the count in effect."""
+    lib().sjd_o_set_threads(int(n))
+    return int(lib().sjd_o_max_threads())
 
 
 def top_p_threshold(top_p):

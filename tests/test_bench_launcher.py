@@ -1,0 +1,63 @@
+"""CPU: `python bench.py --gpus N` must itself start N ranks when no torch.distributed environment is present (round-1 defect:
+--gpus was parsed and ignored), with the driver's own torchrun launch left untouched; plus the pure helpers of the bench line."""
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def bench(monkeypatch):
+    monkeypatch.syspath_prepend(ROOT)
+    return importlib.import_module("bench")
+
+
+def test_gpus_n_relaunches_under_torchrun(bench, monkeypatch):
+    calls = {}
+
+    def fake_call(cmd, env=None):
+        calls["cmd"], calls["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                              # the launcher's return code is ours
+    cmd = calls["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]  # every rank sees the same flags
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_no_relaunch_inside_a_torchrun_rank(bench, monkeypatch):
+    """under the driver's `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE is set: no second fan-out"""
+    monkeypatch.setattr(bench.subprocess, "call", lambda *a, **k: pytest.fail("must not relaunch"))
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    with pytest.raises((SystemExit, RuntimeError, AssertionError)):     # no GPU here: it must fail at device selection, not fan out again
+        bench.main()
+
+
+def test_per_kv_table_uses_window_iterations_near_each_point(bench):
+    log, t = [], 0.0
+    for i in range(400):
+        kv = 60 + 6 * i
+        t += 0.004 + 1e-6 * kv
+        log.append((kv, 16, 2, t))
+    tab = bench.per_kv_table(log, [64, 1216, 2368])
+    assert set(tab) == {"64", "1216", "2368"}
+    assert tab["64"]["ms_per_step"] < tab["1216"]["ms_per_step"] < tab["2368"]["ms_per_step"]
+    assert abs(tab["1216"]["ms_per_step"] - (4.0 + 1.216)) < 0.1

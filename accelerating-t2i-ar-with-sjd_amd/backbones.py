@@ -342,6 +342,52 @@ class ChameleonBackbone(nn.Module):
     # the same for 64-row windows (two prompts per forward, or a draft window of 32): the staged chunk is twice as tall, so KC <= 1280;
     # set `model.G1_CFG = model.G1_CFG_64ROW` before enable_fused (the packing depends on KC).  Tuned end to end at Lumina-7B shapes.
     G1_CFG_64ROW = dict(qkv=(1024, 8, True), o=(512, 8, False), gate_up=(1024, 16, True), down=(1024, 8, False))
+    # Emu3-Gen 8B (GQA 32/8: the q|k|v projection has 6144 columns; draft window 32 -> 64 rows), tuned end to end with bench.py --model emu3_8b
+    G1_CFG_EMU3 = dict(G1_CFG_64ROW, qkv=(512, 6, True))
+
+    # Weight prefetch plan of the G1 window forward: projection -> (workgroups of the prefetch kernel, when it is issued).  The packed
+    # weights of projection j+1 are read into the Infinity Cache on a side stream (a parallel branch of the forward hipGraph)
+    # "g1": from the moment G1(j) is launched, "after": from the moment G1(j) has finished (i.e. under the latency-bound kernels that
+    # follow it).  0 workgroups = no prefetch.  Tuned end to end on MI355X ("Idle HBM"); override with
+    # SJD_PREFETCH="o:128:after,gate_up:0,..." or model.PREFETCH = {...} before the first forward.
+    PREFETCH = dict(qkv=(0, "after"), o=(0, "after"), gate_up=(0, "after"), down=(0, "after"))
+    _PF_NEXT = dict(qkv=("o", 0), o=("gate_up", 0), gate_up=("down", 0), down=("qkv", 1))
+
+    def _prefetch_plan(self):
+        plan = getattr(self, "_pf_plan", None)
+        if plan is None:
+            import os
+            plan = dict(self.PREFETCH)
+            for item in filter(None, os.environ.get("SJD_PREFETCH", "").split(",")):
+                f = item.split(":")
+                plan[f[0]] = (int(f[1]), f[2] if len(f) > 2 else "after")
+            self._pf_plan = plan
+            self._pf_on = any(b > 0 for b, _ in plan.values())
+            self._pf_stream = torch.cuda.Stream(device=self.lm_head.weight.device) if self._pf_on else None
+        return plan
+
+    def _prefetch(self, li, name, when):
+        """issue the prefetch of the projection that FOLLOWS (li, name), if the plan asks for it at this point"""
+        if not self._pf_on:
+            return
+        nxt, dl = self._PF_NEXT[name]
+        blocks, w = self._pf_plan[nxt]
+        if blocks <= 0 or w != when or li + dl >= len(self._packed):
+            return
+        self._pf_stream.wait_stream(torch.cuda.current_stream())          # gate: not before the main branch got here
+        with torch.cuda.stream(self._pf_stream):
+            self._ops.weight_prefetch(self._packed[li + dl][nxt], blocks)
+
+    def _g1(self, li, x_, name, N_, K_):
+        cfg = self.G1_CFG[name]
+        self._prefetch(li, name, "g1")
+        out = self._ops.skinny_gemm(x_, self._packed[li][name], N_, K_, cfg[0], cfg[1], cfg[2])
+        self._prefetch(li, name, "after")
+        return out
+
+    def _prefetch_join(self):
+        if self._pf_on:
+            torch.cuda.current_stream().wait_stream(self._pf_stream)       # every forked branch rejoins (hipGraph capture needs it)
 
     def enable_fused(self, ops, gemm="torch", fold_norm=True):
         """Switch to the fused HIP glue path (F1-F3): q|k|v and gate|up projections become single GEMMs whose weights are
@@ -391,7 +437,8 @@ class ChameleonBackbone(nn.Module):
           F1r, qkv GEMM, F2, K1 partial, K1 combine, o GEMM, F1r, gate|up GEMM, F3, down GEMM   (F1r 3.5 us against F1's 6.1)."""
         ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
         T, eps, cfg = B * n, self.args.rms_norm_eps, self.G1_CFG
-        g1 = lambda x_, name, N_, K_: ops.skinny_gemm(x_, self._packed[li][name], N_, K_, cfg[name][0], cfg[name][1], cfg[name][2])
+        self._prefetch_plan()
+        g1 = lambda x_, name, N_, K_: self._g1(li, x_, name, N_, K_)
         H, Hkv, D, hid, inter = self.n_heads, self.n_kv_heads, self.head_dim, self.args.hidden_size, self.args.intermediate_size
         params = getattr(self.attn, "params", None)
         h = self.model.embed_tokens(tokens).view(T, -1).contiguous()
@@ -406,6 +453,7 @@ class ChameleonBackbone(nn.Module):
             rn = (ops.residual_sumsq(h, g1(o.view(T, H * D), "o", hid, H * D)), hid, eps)
             act = ops.silu_mul(g1(h, "gate_up", 2 * inter, hid), rows=T, dtype=h.dtype, row_norm=rn)
             delta = g1(act, "down", hid, inter)
+        self._prefetch_join()
         x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
         return _head_logits(self.lm_head, x, cols).view(B, n, -1)
 

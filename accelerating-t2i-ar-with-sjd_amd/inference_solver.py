@@ -50,7 +50,9 @@ class FlexARInferenceSolver:
         args = BB.ChameleonArgs(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
                                 num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
                                 num_key_value_heads=cfg.get("num_key_value_heads", cfg["num_attention_heads"]),
-                                rms_norm_eps=cfg.get("rms_norm_eps", 1e-5), rope_theta=cfg.get("rope_theta", 10000.0))
+                                rms_norm_eps=cfg.get("rms_norm_eps", 1e-5), rope_theta=cfg.get("rope_theta", 10000.0),
+                                qk_norm=bool(cfg.get("qk_norm", str(cfg.get("model_type", "chameleon")).lower().startswith("chameleon"))),
+                                max_position_embeddings=cfg.get("max_position_embeddings", 4096))
         model = BB.ChameleonBackbone(args)
         sd = {}
         for f in sorted(os.listdir(model_path)):

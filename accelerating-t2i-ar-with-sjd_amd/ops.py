@@ -220,6 +220,20 @@ def skinny_gemm(x, w_packed, N, K, KC, waves=4, step_major=False):
     return Partials(out, nc, N)
 
 
+_PREFETCH_SINK = {}
+
+
+def weight_prefetch(w_packed, blocks=128, nbytes=None):
+    """Read `w_packed` (a G1 packed weight) on the CURRENT stream and discard it: pulls the lines into the Infinity Cache ahead of
+    the G1 launch that streams them (call it on a side stream forked from the forward, see ChameleonBackbone._prefetch)."""
+    dev = w_packed.device
+    sink = _PREFETCH_SINK.get(dev)
+    if sink is None:
+        sink = _PREFETCH_SINK[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
+    nb = int(nbytes) if nbytes is not None else w_packed.numel() * w_packed.element_size()
+    L.check(L.load().sjd_weight_prefetch(_ptr(w_packed), nb, int(blocks), _ptr(sink), _stream()), "sjd_weight_prefetch")
+
+
 def _part_args(delta):
     if isinstance(delta, Partials):
         return None, _ptr(delta.data), delta.n_chunks

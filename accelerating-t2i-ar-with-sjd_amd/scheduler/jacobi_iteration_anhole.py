@@ -1,6 +1,8 @@
 """Mirror of reference scheduler/jacobi_iteration_anhole.py (Anole / HF-Chameleon adapter): builds the image-only
 processor list of JA:194-232 from the 3d descriptor classes and installs the SJD sampler."""
-from .jacobi_iteration_lumina_mgpt import renew_sampler, renew_backbone
+import torch
+
+from .jacobi_iteration_lumina_mgpt import renew_sampler, renew_backbone, hf_generate
 from .logit_processor_3dim import (AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d,
                                    AllowOnlyTokensInRelativeWindowLogitsProcessor3d,
                                    SuppressTokensAtBeginLogitsProcessor3d, SuppressTokensInIndexRangeLogitsProcessor3d,
@@ -30,12 +32,61 @@ def image_only_processors(vocab_size, input_ids_length, max_length, image_seq_le
 
 def renew_pipeline_anole(model_class):
     class JacobiPipeline(model_class):
-        """reference JA:97-288 (parameter plumbing; generate() of the HF pipeline calls `_sample`)."""
+        """reference JA:97-288: `generate(..., multimodal_generation_mode=)` builds the mode's 3d processor list and hands over to HF
+        generate -> `_sample`; `decode_image_tokens` maps the emitted BPE ids to VQ codes and decodes them."""
 
         def _init_new_params(self, guidance_scale=3.0, image_top_k=2000, text_top_k=10, **kwargs):
             self.cfg = guidance_scale
             self.image_top_k = image_top_k
             self.text_top_k = text_top_k
+            # ChameleonImageVocabularyMapping of the reference (JA:56-95): contiguous image ids 4..8195, <racm3:break>, <eoss>
+            if not hasattr(self, "image_token_ids"):
+                self.image_token_ids = list(range(4, 8196))
+            self.boi_token_id = getattr(self, "boi_token_id", 8197)
+            self.eoi_token_id = getattr(self, "eoi_token_id", 8196)
+            self.eos_token_id = getattr(getattr(self, "config", None), "eos_token_id", None) or getattr(self, "eos_token_id", 2)
+
+        @torch.no_grad()
+        def generate(self, inputs=None, generation_config=None, logits_processor=None, multimodal_generation_mode=None, **kwargs):
+            """reference JA:137-272"""
+            ids = inputs if inputs is not None else kwargs.get("input_ids")
+            mode = multimodal_generation_mode or getattr(generation_config, "multimodal_generation_mode", None) or "text-only"
+            L_img = self.model.image_seq_length if hasattr(self.model, "image_seq_length") else self.image_seq_length
+            if mode == "image-only" and kwargs.get("max_length") is None and kwargs.get("max_new_tokens") is None and (
+                    generation_config is None or (generation_config.max_length is None and generation_config.max_new_tokens is None)):
+                kwargs["max_new_tokens"] = L_img + 2                                        # JA:116-126
+            P = ids.shape[-1]
+            mnt = kwargs.get("max_new_tokens", getattr(generation_config, "max_new_tokens", None))
+            max_length = P + int(mnt) if mnt is not None else int(kwargs.get("max_length", getattr(generation_config, "max_length", 0)))
+            if mode == "image-only":
+                if max_length - P < L_img + 2:
+                    import warnings
+                    warnings.warn(f"the VQ decoder expects {L_img} image tokens wrapped in begin/end-of-image: max_new_tokens must be "
+                                  f"at least {L_img + 2}, got {max_length - P}")
+                procs = image_only_processors(self.vocab_size, P, max_length, L_img, self.image_token_ids, self.boi_token_id,
+                                              self.eoi_token_id, self.eos_token_id, device=ids.device)
+                procs = type(procs)(list(logits_processor or []) + list(procs))
+            elif mode == "unrestricted":
+                procs = logits_processor
+            else:
+                raise NotImplementedError(f"multimodal_generation_mode={mode!r}: only the image generation path is an SJD hot path "
+                                          "('image-only', or 'unrestricted' with your own processors)")
+            kwargs.setdefault("do_sample", True)
+            kwargs.pop("input_ids", None)
+            return hf_generate(self, ids, generation_config, logits_processor=procs, **kwargs)
+
+        def decode_image_tokens(self, bpe_tokens):
+            """reference JA:274-316 (+ the truncating variant of renew_backbone_adapt_anole): BPE ids -> VQ codes -> pixels.
+            Needs a VQ decoder on `self.model.vqmodel` (sjd_amd.detokenizers.ChameleonVQ with the checkpoint's weights)."""
+            L_img = self.model.image_seq_length if hasattr(self.model, "image_seq_length") else self.image_seq_length
+            if bpe_tokens.shape[1] != L_img:
+                bpe_tokens = bpe_tokens[:, :L_img]
+            vq = getattr(self.model, "vqmodel", None)
+            if vq is None:
+                raise RuntimeError("no VQ decoder attached: set model.model.vqmodel = sjd_amd.detokenizers.ChameleonVQ(...) with the checkpoint's weights")
+            codes = (bpe_tokens - self.image_token_ids[0]).clamp_(0, len(self.image_token_ids) - 1)
+            side = int(round(L_img ** 0.5))
+            return vq.decode_code(codes, hw=(side, side))
 
     return JacobiPipeline
 

@@ -179,6 +179,60 @@ def _stopping_to_limits(stopping_criteria, generation_config):
     return tuple(eos), max_len
 
 
+class _EosStop:
+    def __init__(self, eos_token_id):
+        self.eos_token_id = [int(t) for t in (eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])]
+
+
+class _MaxLengthStop:
+    def __init__(self, max_length):
+        self.max_length = int(max_length)
+
+
+def hf_generate(model, inputs=None, generation_config=None, logits_processor=None, stopping_criteria=None, streamer=None,
+                attention_mask=None, neg_input_ids=None, input_ids=None, **kwargs):
+    """What the reference drivers get from HF `GenerationMixin.generate` (transformers 4.47.1, third-party -- not in the reference
+    tree) before it reaches the `_sample` hook, reduced to the arguments they use (test_emu3.py:163-169, IS:335-350, JA:137-272,
+    ML:406-411): the generation length (max_new_tokens wins over max_length), EOS / max-length stopping criteria, the user's logits
+    processors followed by a TopKLogitsWarper when `generation_config.top_k` is set, then
+    `model._sample(input_ids, processors, criteria, generation_config, synced_gpus=False, streamer, attention_mask=, neg_input_ids=)`.
+    Anything that changes the distribution and has no kernel rule (temperature != 1, top_p via the config, beams, greedy) raises."""
+    import copy
+    from transformers import GenerationConfig
+    from transformers.generation.logits_process import LogitsProcessorList
+    from .logit_processor_3dim import TopKLogitsWarper
+    ids = inputs if inputs is not None else input_ids
+    if ids is None:
+        raise ValueError("generate() needs input_ids")
+    gc = copy.deepcopy(generation_config) if generation_config is not None else GenerationConfig(do_sample=True)
+    for k in ("max_new_tokens", "max_length", "do_sample", "top_k", "top_p", "temperature", "eos_token_id", "pad_token_id", "num_beams"):
+        if k in kwargs and kwargs[k] is not None:
+            setattr(gc, k, kwargs.pop(k))
+    if not getattr(gc, "do_sample", False) or (getattr(gc, "num_beams", 1) or 1) != 1:
+        raise NotImplementedError("the SJD hot path samples (do_sample=True, num_beams=1)")
+    if (getattr(gc, "temperature", None) or 1.0) != 1.0 or (getattr(gc, "top_p", None) or 1.0) != 1.0:
+        raise NotImplementedError("temperature / top_p through GenerationConfig have no kernel rule (the drivers use 1.0)")
+    P = ids.shape[1]
+    if getattr(gc, "max_new_tokens", None) is not None:
+        gc.max_length = P + int(gc.max_new_tokens)
+    limit = getattr(getattr(model, "args", None), "max_position_embeddings", None)
+    if limit is not None and (gc.max_length is None or gc.max_length > limit):
+        gc.max_length = int(limit)               # HF only warns beyond the context; rows past it could never be positioned
+    procs = LogitsProcessorList(list(logits_processor or []))
+    if getattr(gc, "top_k", None):               # HF appends the warpers after the user's processors
+        procs.append(TopKLogitsWarper(int(gc.top_k)))
+    crit = list(stopping_criteria or [])
+    if getattr(gc, "eos_token_id", None) is not None:
+        crit.append(_EosStop(gc.eos_token_id))
+    crit.append(_MaxLengthStop(gc.max_length))
+    kw = {}
+    if attention_mask is not None:
+        kw["attention_mask"] = attention_mask
+    if neg_input_ids is not None:
+        kw["neg_input_ids"] = neg_input_ids
+    return model._sample(ids, procs, crit, gc, False, streamer, **kw)
+
+
 def renew_sampler(model_class):
     class JacobiSampler(model_class):
         """reference JL:598-1251"""
@@ -265,7 +319,8 @@ def renew_sampler(model_class):
                             max_num_new_tokens=self.max_num_new_tokens, guidance_scale=self.guidance_scale, seed=self.seed,
                             do_cfg=do_cfg, prefix_token_sampler_scheme=self.prefix_token_sampler_scheme,
                             multi_token_init_scheme=self.multi_token_init_scheme, img_vocab_lo=self.img_vocab_range[0],
-                            img_vocab_n=self.img_vocab_range[1] - self.img_vocab_range[0], max_length=max_len, eos_token_ids=eos)
+                            img_vocab_n=self.img_vocab_range[1] - self.img_vocab_range[0], max_length=max_len, eos_token_ids=eos,
+                            noise_device=getattr(self, "sjd_noise_device", None))
             B = 2 if do_cfg else 1
             if max_len >= (1 << 30):
                 # no MaxLength criterion: bound the cache by the model's own context instead of asking for ~1e9 rows
@@ -297,6 +352,10 @@ def renew_sampler(model_class):
             print("tokens length: ", len(seq))
             return torch.tensor([seq], dtype=torch.long, device=dev)
 
+    if not hasattr(model_class, "generate"):
+        # this package's backbones are plain nn.Modules: give them the HF-shaped entry point the drivers call
+        # (`model.generate(input_ids, generation_config, logits_processor=..., attention_mask=..., neg_input_ids=...)`)
+        JacobiSampler.generate = torch.no_grad()(hf_generate)
     return JacobiSampler
 
 

@@ -99,7 +99,7 @@ def build_model(args, device):
     if args.prompts_per_gpu > 1 and args.model != "emu3_8b":      # 64-row windows: the staged activation chunk (64 x KC) must fit in LDS
         model.G1_CFG = dict(model.G1_CFG_64ROW)
     if args.model == "emu3_8b":      # 64-row windows (draft window 32) need activation chunks <= 1280 columns
-        model.G1_CFG = dict(model.G1_CFG_64ROW, qkv=(512, 6, True))
+        model.G1_CFG = dict(model.G1_CFG_EMU3)
     if os.environ.get("SJD_G1_CFG"):       # tuning aid: JSON {"o": [KC, waves, step_major], ...} overriding the per-projection launch shapes
         over = json.loads(os.environ["SJD_G1_CFG"])
         model.G1_CFG = dict(model.G1_CFG, **{k: (int(v[0]), int(v[1]), bool(v[2])) for k, v in over.items()})

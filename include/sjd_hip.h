@@ -191,6 +191,13 @@ int sjd_gemm_num_chunks(int K, int KC);
 int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,
                     int dtype, void *stream);
 
+/* Weight prefetch for G1: reads `nbytes` of packed weights with plain loads and discards them, so that the lines sit in the 256 MiB
+ * Infinity Cache when the next sjd_skinny_gemm streams them.  Meant for a SIDE stream / parallel hipGraph branch while the
+ * latency-bound kernels of the layer (F1r, F2, K1, F3) leave HBM idle.  No reference counterpart (the reference's nn.Linear calls,
+ * modeling_chameleon.py:527-529, are library GEMMs); no effect on results.  sink: any 4-byte device scratch (never written in
+ * practice).  blocks: workgroups of 256 threads (1..4096). */
+int sjd_weight_prefetch(const void *w, int64_t nbytes, int blocks, void *sink, void *stream);
+
 /* K1 / K3 over an fp8 KV cache (BASELINE config 5; there is no fp8 in the reference -- the parity target is the bf16 result
  * within tolerance): the cache holds OCP e4m3 bytes, value = fp8 * scale with one scale per tensor; q / out keep `dtype` (bf16/f16).
  * Half the KV bytes of sjd_draft_window_attention, both contractions on v_mfma_f32_16x16x32_fp8_fp8.  Other arguments as the

@@ -78,7 +78,7 @@ static float sjd_expf(float x)
 
 static float sjd_canonical_sum(const float *v, int V)
 {
-    static float acc[4096];
+    float acc[4096];                     /* on the stack: the row loop of the K2 restatement runs one row per OpenMP thread */
     for (int a = 0; a < 4096; ++a) acc[a] = 0.0f;
     for (int i = 0; i < V; ++i) acc[i & 4095] = acc[i & 4095] + v[i];
     float lane[1024];

@@ -260,3 +260,153 @@ def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=
         gen = seq[len(prompts[i]):]
         out.append(dict(tokens=len(gen), nfe=stats.nfe, last=gen[-1], max_accept=max(stats.matched[1:])))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ through the reference API
+@torch.no_grad()
+def teacher_forced_emu3_api_check(device="cuda:0", H=3, W=5, window=16, seed=5, embed_token_scale=0.4, dtype=torch.float16, pos_len=9,
+                                  neg_len=5, gemm="sjd"):
+    """The Emu3 flow exactly as reference test_emu3.py:145-169 drives it -- Emu3Processor.build_prefix_constrained_fn -> renew_solver ->
+    model.prepare_batch_cfg_model_inputs -> model.generate(pos_ids, GENERATION_CONFIG, logits_processor=, attention_mask=,
+    neg_input_ids=) -- on this package's backbone; the engine's logits are replayed into the CPU oracle loop (teacher forcing)."""
+    from types import SimpleNamespace as NS
+    from transformers import GenerationConfig
+    import sjd_amd.ops as ops
+    import sjd_amd.backbones as BB
+    import sjd_amd.synthetic as synthetic
+    from emu3.mllm.processing_emu3 import Emu3Processor
+    from scheduler.jacobi_iteration_emu3 import renew_solver
+    from tests.helpers import Emu3StubTokenizer
+    V, vis_n = 12288, 8192
+    tk = Emu3StubTokenizer()
+    tok = dict(img_token=200, eoi_token=201, eos_token=202, eol_token=203, eof_token=204, pad_token=205)
+    args = BB.ChameleonArgs(vocab_size=V, hidden_size=1024, intermediate_size=512, num_hidden_layers=2, num_attention_heads=8,
+                            num_key_value_heads=2, rope_theta=1000000.0, qk_norm=False, max_position_embeddings=256)
+    model = BB.ChameleonBackbone(args, attn=ops.HipWindowAttention(n_split=2)).eval()
+    synthetic.fill_state_dict(model, seed=29, embed_token_scale=embed_token_scale)
+    model = model.to(device=device, dtype=dtype)
+    model.G1_CFG = dict(qkv=(256, 8, True), o=(256, 4, False), gate_up=(512, 8, True), down=(256, 4, False))
+    model.enable_fused(ops, gemm=gemm)
+    model.config = NS(pad_token_id=tok["pad_token"], eos_token_id=tok["eos_token"], image_area=(8 * H) * (8 * W))
+    processor = Emu3Processor(None, NS(config=NS(codebook_size=vis_n), spatial_scale_factor=8), tk)
+    g = torch.Generator().manual_seed(seed)
+    pos_ids = torch.tensor([torch.randint(300, 2000, (pos_len - 1,), generator=g).tolist() + [tok["img_token"]]], device=device)
+    neg_ids = torch.tensor([torch.randint(300, 2000, (neg_len - 1,), generator=g).tolist() + [tok["img_token"]]], device=device)
+    jac = dict(jacobi_loop_interval_l=1, jacobi_loop_interval_r=(W + 1) * H - 1, max_num_new_tokens=window, guidance_scale=3.0, seed=seed,
+               multi_token_init_scheme='random', do_cfg=True, image_top_k=2048, text_top_k=10, prefix_token_sampler_scheme='speculative_jacobi',
+               h=H, w=W, neg_inputs=neg_ids, classifier_free_guidance=3.0)
+    model, logits_processor = renew_solver(model, processor, **jac)                       # test_emu3.py:145-146
+    gc = GenerationConfig(use_cache=True, eos_token_id=tok["eos_token"], pad_token_id=tok["pad_token"], max_new_tokens=40960,
+                          do_sample=True, top_k=2048)                                      # test_emu3.py:81-90
+    mi = model.prepare_batch_cfg_model_inputs(pos_ids, neg_input_ids=neg_ids, attention_mask=None)   # test_emu3.py:149-155
+    assert mi["attention_mask"].shape == (2, pos_len) and mi["pos_input_ids"].shape == (1, pos_len)
+    assert mi["attention_mask"][1, :pos_len - neg_len].sum() == 0 and mi["attention_mask"][0].all()
+    eng = model._sjd_engine(2, torch.device(device))
+    rec = _Recorder()
+    eng.hook = rec
+    out = model.generate(mi["pos_input_ids"], gc, logits_processor=logits_processor, attention_mask=mi["attention_mask"],
+                         neg_input_ids=neg_ids)                                            # test_emu3.py:163-169
+    seq = out[0].tolist()
+    prompt = mi["pos_input_ids"][0].tolist()
+    vis_lo = processor.build_prefix_constrained_fn(H, W).visual_tokens[0]
+    cfg = OL.LoopConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=(W + 1) * H - 1, max_num_new_tokens=window, guidance_scale=3.0,
+                        seed=seed, do_cfg=True, prefix_token_sampler_scheme="speculative_jacobi", max_length=256,
+                        eos_token_ids=(tok["eos_token"],))
+    rules_fn = lambda c, n: O.emu3_rules(c, n, H, W, vis_lo, vis_n, top_k=2048, **tok)
+    seq_ref, tr, checks = _replay(rec, prompt, rules_fn, cfg, V, device=device)
+    assert seq == seq_ref, "token sequences differ"
+    assert model.last_sjd_stats.matched == tr.matched
+    return dict(gen=seq[len(prompt):], tok=tok, W=W, H=H, vis=(vis_lo, vis_n), nfe=model.last_sjd_stats.nfe)
+
+
+@torch.no_grad()
+def teacher_forced_anole_api_check(device="cuda:0", img_len=36, window=16, seed=5, P=10, embed_token_scale=0.25, dtype=torch.bfloat16,
+                                   gemm="sjd", fp8_kv=False):
+    """The Anole flow as reference model_loader.py:82-108 / 396-411 drives it: renew_pipeline_sampler(model, processor, **kw) then
+    model.generate(input_ids, multimodal_generation_mode="image-only", max_new_tokens=L+2, do_sample=True); teacher-forced replay."""
+    from types import SimpleNamespace as NS
+    import sjd_amd.ops as ops
+    import sjd_amd.synthetic as synthetic
+    from scheduler.jacobi_iteration_anhole import renew_pipeline_sampler
+    from tests.helpers import make_chameleon
+    V = 9216
+    conf = dict(vocab_size=V, hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=4, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    model = make_chameleon(conf, 29, embed_token_scale, ops.HipWindowAttention(n_split=2), dtype=dtype, device=device)
+    model.G1_CFG = dict(qkv=(256, 8, True), o=(256, 4, False), gate_up=(256, 8, True), down=(256, 4, False))
+    model.enable_fused(ops, gemm=gemm)
+    kw = dict(jacobi_loop_interval_l=1, jacobi_loop_interval_r=img_len - window - 2, max_num_new_tokens=window, guidance_scale=3.0, seed=seed,
+              multi_token_init_scheme='random', do_cfg=True, image_top_k=2000, text_top_k=10, prefix_token_sampler_scheme='speculative_jacobi')
+    model = renew_pipeline_sampler(model, NS(image_seq_length=img_len), **kw)               # ML:89-104
+    assert model.model.image_seq_length == img_len
+    ids = torch.cat([synthetic.synthetic_prompt(P - 1, seed, lo=8900, hi=9200), torch.tensor([[8197]])], dim=1).to(device)
+    eng = model._sjd_engine(2, torch.device(device))
+    rec = _Recorder()
+    eng.hook = rec
+    out = model.generate(ids, multimodal_generation_mode="image-only", max_new_tokens=img_len + 2, do_sample=True)   # ML:406-411
+    seq = out[0].tolist()
+    max_len = P + img_len + 2
+    cfg = OL.LoopConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=img_len - window - 2, max_num_new_tokens=window, guidance_scale=3.0,
+                        seed=seed, do_cfg=True, prefix_token_sampler_scheme="speculative_jacobi", max_length=max_len, eos_token_ids=())
+    seq_ref, tr, checks = _replay(rec, ids[0].tolist(), lambda c, n: O.anole_rules(c, n, V, P, max_len, img_len), cfg, V, device=device)
+    assert seq == seq_ref, "token sequences differ"
+    assert model.last_sjd_stats.matched == tr.matched
+    gen = seq[P:]
+    return dict(gen=gen, img_len=img_len, nfe=model.last_sjd_stats.nfe)
+
+
+@torch.no_grad()
+def teacher_forced_real_shape_check(family="lumina7b", device="cuda:0", prompt_len=700, new_tokens=56, seed=11):
+    """Teacher-forced parity at the REAL architecture shapes and production launch configuration (BASELINE.json configs 2 / 3):
+    Lumina-mGPT-7B (32 layers, hidden 4096, 32 heads, V=65536, window 16, G1_CFG, K1 auto-split 4, output head on the grammar's column
+    window, hipGraph) or Emu3-Gen-8B (GQA 32/8, V=184622, fp16, window 32, G1_CFG_EMU3, k1_partial_shared).  A prompt of `prompt_len`
+    text ids puts the K1 launches into the multi-split regime; ~`new_tokens` tokens are decoded (~25 SJD iterations) and every
+    iteration's logits are replayed into the CPU oracle, which must take identical decisions."""
+    import sjd_amd.ops as ops
+    import sjd_amd.backbones as BB
+    import sjd_amd.synthetic as synthetic
+    from sjd_amd.engine import SJDEngine, SJDConfig
+    from sjd_amd.frontends import lumina_window_spec, lumina_prompt, emu3_window_spec
+    from sjd_amd.grammar import LuminaGrammar, Emu3Grammar
+    dev = torch.device(device)
+    if family == "lumina7b":
+        margs, dt, window = BB.LUMINA_7B, torch.bfloat16, 16
+    else:
+        margs, dt, window = BB.EMU3_8B, torch.float16, 32
+    with torch.device(dev):
+        model = BB.ChameleonBackbone(margs, attn=ops.HipWindowAttention()).to(dt).eval()
+    if family != "lumina7b":
+        model.G1_CFG = dict(model.G1_CFG_EMU3)
+    synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=0.7)
+    model.enable_fused(ops, gemm="sjd")
+    V = margs.vocab_size
+    if family == "lumina7b":
+        grid = 48
+        prompt = lumina_prompt(prompt_len, grid, grid, seed=seed)
+        spec = lumina_window_spec(prompt, dev)
+        grammar, rules_fn, no_cfg = LuminaGrammar(2000, 10), (lambda c, n: O.lumina_rules(c, n, 2000, 10)), O.lumina_force_no_cfg
+        cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=grid * grid + grid - 13, max_num_new_tokens=window, guidance_scale=3.0,
+                        seed=seed, max_length=len(prompt) + new_tokens, eos_token_ids=(8196,))
+    else:
+        tok = dict(img_token=151851, eoi_token=151853, eos_token=151850, eol_token=151846, eof_token=151847, pad_token=151643)
+        Hh = Ww = 90
+        pos = synthetic.synthetic_prompt(prompt_len - 1, seed, lo=1000, hi=150000)[0].tolist() + [tok["img_token"]]
+        neg = synthetic.synthetic_prompt(11, seed + 1, lo=1000, hi=150000)[0].tolist() + [tok["img_token"]]
+        spec = emu3_window_spec(pos, neg, tok["pad_token"], dev)
+        prompt = spec.first_tokens[0].tolist()
+        grammar = Emu3Grammar(Hh, Ww, 151854, 32768, top_k=2048, **tok)
+        rules_fn, no_cfg = (lambda c, n: O.emu3_rules(c, n, Hh, Ww, 151854, 32768, top_k=2048, **tok)), None
+        cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=Hh * Ww - 1, max_num_new_tokens=window, guidance_scale=3.0,
+                        seed=seed, max_length=len(prompt) + new_tokens, eos_token_ids=(tok["eos_token"],))
+    model.setup_cache(batch=2, s_max=((len(prompt) + new_tokens + 2 * window + 64 + 31) // 32) * 32)
+    eng = SJDEngine(model, V, dev, max_window=window, use_graph=True)
+    rec = _Recorder()
+    eng.hook = rec
+    seq, stats = eng.decode(prompt, spec, grammar, cfg)
+    O.set_threads(8)
+    seq_ref, tr, checks = _replay(rec, prompt, rules_fn, _loop_cfg(cfg), V, no_cfg_fn=no_cfg, device=device)
+    assert seq == seq_ref, "token sequences differ"
+    assert stats.matched == tr.matched and stats.nfe == len(tr.matched)
+    graphs = [k for k in eng._graphs if isinstance(k, tuple) and k[0] == "fwd"]
+    return dict(tokens=len(seq) - len(prompt), nfe=stats.nfe, accepted=sorted(set(stats.matched[1:])), n_split=model.attn.n_split,
+                fwd_graphs=len(graphs), head_cols=[k[1] for k in graphs])

@@ -118,3 +118,21 @@ def lumina_forward_fn(model, P, s_max, device="cpu"):
         return lg[0].cpu().numpy(), lg[1].cpu().numpy()
 
     return fwd
+
+
+class Emu3StubTokenizer:
+    """stand-in for the hub tokenizer: only the special-token attributes and `encode` of single tokens are used"""
+    bos_token, boi_token, img_token, eoi_token, eos_token, eol_token, eof_token, pad_token = "<b>", "<boi>", "<img>", "<eoi>", "<eos>", "<eol>", "<eof>", "<pad>"
+    table = {"<b>": 1, "<boi>": 2, "<img>": 200, "<eoi>": 201, "<eos>": 202, "<eol>": 203, "<eof>": 204, "<pad>": 205}
+
+    def encode(self, s):
+        if s in self.table:
+            return [self.table[s]]
+        if s.startswith("<|visual token "):
+            return [3000 + int(s[len("<|visual token "):-2])]
+        out, i = [], 0
+        while i < len(s):                               # greedy special tokens, every other character = one text id
+            hit = next((t for t in self.table if s.startswith(t, i)), None)
+            out.append(self.table[hit] if hit else 300 + (ord(s[i]) % 1000))
+            i += len(hit) if hit else 1
+        return out

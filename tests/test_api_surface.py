@@ -97,3 +97,94 @@ def test_integer_helpers():
     assert check_is_force_no_cfg(torch.tensor([[9, 8197, 5, 8196]]), 8197, 8196) is True
     assert check_is_force_no_cfg(torch.tensor([[9]]), None, None) is False
     assert check_eol_in_multitokens(7, 16, 9) and not check_eol_in_multitokens(0, 3, 9)
+
+
+def test_reference_driver_import_statements_resolve():
+    """The import lines of the reference's three drivers and of its eval wrapper, written out (names only -- nothing of the
+    reference is read at run time): test_lumina_mgpt.py:10,101; test_emu3.py:16,145; test_llamagen.py:17-21; model_loader.py:19-22,
+    126, 225-229, 502."""
+    from lumina_mgpt.inference_solver import FlexARInferenceSolver  # noqa: F401
+    from scheduler.jacobi_iteration_lumina_mgpt import renew_pipeline_sampler  # noqa: F401
+    from emu3.mllm.processing_emu3 import Emu3Processor  # noqa: F401
+    from scheduler.jacobi_iteration_emu3 import renew_solver  # noqa: F401
+    from llamagen.tokenizer.tokenizer_image.vq_model import VQ_models  # noqa: F401
+    from llamagen.language.t5 import T5Embedder  # noqa: F401
+    from llamagen.llamagen import GPT_models  # noqa: F401
+    from llamagen.llamagen_solver import LlamaGenSolver, renew_llamagen, generate  # noqa: F401
+    from scheduler.jacobi_iteration_lumina_mgpt import renew_sampler  # noqa: F401
+    from scheduler.jacobi_iteration_anhole import renew_pipeline_sampler as renew_pipeline_sampler_anhole  # noqa: F401
+    from scheduler.jacobi_iteration_emu3 import renew_solver as renew_solver_emu3  # noqa: F401
+    from model_wrappers.model_loader import load_pretrained_model, get_forward_func  # noqa: F401
+    from llamagen.llamagen_solver import generate as llamagen_original_generate
+    sig = inspect.signature(llamagen_original_generate)                            # LS:145
+    assert list(sig.parameters)[:6] == ["model", "cond", "max_new_tokens", "emb_masks", "cfg_scale", "cfg_interval"]
+    assert set(VQ_models) == {"VQ-16", "VQ-8"}
+
+
+def test_model_loader_dispatch_and_defaults():
+    """reference ML:347-359, 564-574: name-substring dispatch, NotImplementedError otherwise; loader keyword defaults (ML:25-35, 62-77,
+    112-127, 194-224)."""
+    import model_wrappers.model_loader as ML
+    with pytest.raises(NotImplementedError):
+        ML.load_pretrained_model("some-other-model")
+    with pytest.raises(NotImplementedError):
+        ML.get_forward_func("some-other-model", None)
+    d = {k: v.default for k, v in inspect.signature(ML.load_lumina_mgpt).parameters.items()}
+    assert (d["model_name"], d["target_size"], d["max_num_new_tokens"], d["guidance_scale"], d["multi_token_init_scheme"]) == \
+        ("Alpha-VLLM/Lumina-mGPT-7B-768", 768, 16, 7.0, "random")
+    d = {k: v.default for k, v in inspect.signature(ML.load_emu3).parameters.items()}
+    assert (d["model_name"], d["target_size"], d["image_top_k"], d["prefix_token_sampler_scheme"]) == ("BAAI/Emu3-Gen", 720, 2048, "speculative_jacobi")
+    d = {k: v.default for k, v in inspect.signature(ML.load_llamagen).parameters.items()}
+    assert d["guidance_scale"] == 7.5 and d["image_top_k"] == 1000 and d["backbone_params"]["gpt_model"] == "GPT-XL"
+    d = {k: v.default for k, v in inspect.signature(ML.load_anole).parameters.items()}
+    assert d["model_name"] == "leloy/Anole-7b-v0.1-hf" and d["target_size"] == 512
+    with pytest.raises(FileNotFoundError):           # no hub access: a missing local checkpoint is an error, not a download
+        ML.load_pretrained_model("Alpha-VLLM/Lumina-mGPT-7B-768", cache_dir="/nonexistent")
+
+
+def test_emu3_processor_grammar_helper_and_generation_prompt():
+    """reference emu3/mllm/processing_emu3.py:246-290 and the 'G' branch of __call__ (:150-165)"""
+    from types import SimpleNamespace as NS
+    from emu3.mllm.processing_emu3 import Emu3Processor
+    from tests.helpers import Emu3StubTokenizer
+    proc = Emu3Processor(None, NS(config=NS(codebook_size=8192), spatial_scale_factor=8), Emu3StubTokenizer())
+    fn = proc.build_prefix_constrained_fn(3, 5)
+    assert (fn.height, fn.width, fn.img_token, fn.eol_token, fn.eof_token, fn.eoi_token, fn.eos_token, fn.pad_token) == (3, 5, 200, 203, 204, 201, 202, 205)
+    assert fn.visual_tokens == list(range(3000, 3000 + 8192))
+    assert proc.calculate_generate_size("1:1", 720 * 720, 8) == (90, 90) and proc.calculate_generate_size("4:3", 518400, 8) == (78, 104)
+    out = proc(text="ab", mode="G", ratio="1:1", image_area=24 * 40, return_tensors="pt")
+    ids = out.input_ids[0].tolist()
+    assert ids[0] == 1 and ids[-1] == 200 and 2 in ids and out.image_size == [[4, 4]]
+    with pytest.raises(ValueError):
+        proc(text=["a", "b"], mode="G")
+
+
+def test_hf_generate_builds_criteria_and_topk_then_calls_sample():
+    """HF generate's contract as the drivers rely on it (test_emu3.py:81-90, 163-169): max_new_tokens -> max_length, EOS criterion,
+    TopKLogitsWarper(generation_config.top_k) appended AFTER the user's processors, attention_mask / neg_input_ids passed through."""
+    from transformers import GenerationConfig
+    from scheduler.jacobi_iteration_lumina_mgpt import hf_generate
+    seen = {}
+
+    class M:
+        args = type("A", (), {"max_position_embeddings": 64})()
+
+        def _sample(self, ids, procs, crit, gc, synced, streamer, **kw):
+            seen.update(ids=ids, procs=[type(p).__name__ for p in procs], eos=[c.eos_token_id for c in crit if hasattr(c, "eos_token_id")],
+                        max_len=[c.max_length for c in crit if hasattr(c, "max_length")], kw=kw, gc=gc)
+            return ids
+
+    ids = torch.zeros(1, 10, dtype=torch.long)
+    gc = GenerationConfig(use_cache=True, eos_token_id=202, pad_token_id=205, max_new_tokens=40960, do_sample=True, top_k=2048)
+
+    class Proc:
+        pass
+
+    hf_generate(M(), ids, gc, logits_processor=[Proc()], attention_mask=torch.ones(2, 10), neg_input_ids=torch.ones(1, 4, dtype=torch.long))
+    assert seen["procs"] == ["Proc", "TopKLogitsWarper"] and seen["eos"] == [[202]]
+    assert seen["max_len"] == [64]                                   # 10 + 40960, bounded by the model's context
+    assert set(seen["kw"]) == {"attention_mask", "neg_input_ids"} and gc.max_length != 64       # the caller's config is not mutated
+    with pytest.raises(NotImplementedError):
+        hf_generate(M(), ids, GenerationConfig(do_sample=True, temperature=0.7, max_new_tokens=4))
+    with pytest.raises(NotImplementedError):
+        hf_generate(M(), ids, GenerationConfig(do_sample=False, max_new_tokens=4))

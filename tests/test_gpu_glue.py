@@ -243,3 +243,41 @@ def test_f2_into_fp8_cache(dev, dtype, H, Hkv, D, qk_norm):
     assert torch.equal((kc.float() / sk).to(ops.FP8).view(torch.uint8), kc8.view(torch.uint8))
     assert torch.equal((vc.float() / sv).to(ops.FP8).view(torch.uint8), vc8.view(torch.uint8))
     assert kc8.view(torch.uint8)[:, :, kv_len:kv_len + n].float().abs().sum() > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_16bit_window_forward_error_against_fp32_forward(dev, dtype):
+    """Reported and bounded: max |delta logit| of the hand-written 16-bit window forward (G1 + F1r/F2/F3 + K1, folded norm) against an
+    fp32 forward of the SAME weights (hipBLASLt fp32 GEMMs + the exact-fp32 K1), next to the same figure for the plain PyTorch-ROCm
+    16-bit forward (ATen GEMMs / norms / RoPE; attention = K1).  The hand-written path must not be further from fp32 than the
+    library path is (x1.5 + 1e-3 slack): its rounding points are the reference's."""
+    import json
+    import os
+    import sjd_amd.ops as ops
+    from tests.helpers import make_chameleon
+    conf = dict(vocab_size=9216, hidden_size=1024, intermediate_size=2048, num_hidden_layers=4, num_attention_heads=8,
+                num_key_value_heads=8, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    toks = torch.randint(4, 9000, (2, 48), generator=torch.Generator().manual_seed(1)).to(dev)
+    toks2 = torch.randint(4, 9000, (2, 16), generator=torch.Generator().manual_seed(2)).to(dev)
+    ks = torch.tensor([0, 7], dtype=torch.int32, device=dev)
+    outs = {}
+    for tag, dt, fused in (("fp32", torch.float32, None), ("aten16", dtype, None), ("hip16", dtype, "sjd")):
+        m = make_chameleon(conf, 23, 0.5, ops.HipWindowAttention(n_split=2), dtype=torch.float32, device=dev)
+        # the 16-bit models hold the 16-bit ROUNDED weights; the fp32 reference uses exactly those values
+        m = m.to(dtype).to(dt) if dt == torch.float32 else m.to(dt)
+        if fused:
+            m.G1_CFG = dict(qkv=(512, 8, True), o=(256, 8, False), gate_up=(512, 8, True), down=(512, 8, False))
+            m.enable_fused(ops, gemm=fused)
+        m.setup_cache(batch=2, s_max=128)
+        m.forward_window(toks, torch.arange(48)[None].repeat(2, 1).to(dev), 0, ks)
+        outs[tag] = m.forward_window(toks2, (48 + torch.arange(16))[None].repeat(2, 1).to(dev), 48, ks).float()
+    e_aten = (outs["aten16"] - outs["fp32"]).abs()
+    e_hip = (outs["hip16"] - outs["fp32"]).abs()
+    rep = dict(dtype=str(dtype), logit_std=round(float(outs["fp32"].std()), 3), aten16_max=round(float(e_aten.max()), 5),
+               aten16_mean=round(float(e_aten.mean()), 6), hip16_max=round(float(e_hip.max()), 5), hip16_mean=round(float(e_hip.mean()), 6))
+    print("16-bit forward vs fp32:", rep)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, f"logit_error_{str(dtype).split('.')[-1]}.json"), "w") as f:
+            json.dump(rep, f)
+    assert e_hip.max() <= 1.5 * e_aten.max() + 1e-3 and e_hip.mean() <= 1.5 * e_aten.mean() + 1e-4, rep

@@ -13,6 +13,11 @@ def _gpu():
         pytest.skip("no GPU")
 
 
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
 @pytest.mark.parametrize("scheme,seed,window,ets", [("speculative_jacobi", 7, 16, 0.25), ("speculative_jacobi", 11, 8, 0.5),
                                                     ("jacobi", 7, 16, 0.25), ("speculative_jacobi", 13, 16, 1.0)])
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
@@ -74,3 +79,37 @@ def test_two_prompts_share_one_window_forward(gemm, use_graph, fp8_kv):
     rs = G.teacher_forced_batch_check(gemm=gemm, use_graph=use_graph, fp8_kv=fp8_kv)
     assert len(rs) == 2 and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs) and any(r["max_accept"] > 1 for r in rs)
     assert rs[0]["nfe"] != rs[1]["nfe"] or True
+
+
+def test_emu3_reference_api_flow(dev):
+    """A14 / A18: renew_solver + prepare_batch_cfg_model_inputs + HF-shaped generate, executed (reference JE:234-278, 370-411;
+    test_emu3.py:145-169), teacher-forced against the oracle."""
+    from tests.gpu_loop_check import teacher_forced_emu3_api_check
+    r = teacher_forced_emu3_api_check(device=str(dev))
+    gen, tok, W, H = r["gen"], r["tok"], r["W"], r["H"]
+    assert [i for i, t in enumerate(gen) if t == tok["eol_token"]] == [(W + 1) * (k + 1) - 1 for k in range(H)]
+    assert gen[(W + 1) * H:(W + 1) * H + 3] == [tok["eof_token"], tok["eoi_token"], tok["eos_token"]]
+    lo, n = r["vis"]
+    assert all(lo <= t < lo + n for i, t in enumerate(gen[:(W + 1) * H]) if (i + 1) % (W + 1))
+    assert r["nfe"] < len(gen)
+
+
+def test_anole_reference_api_flow(dev):
+    """A14: Anole renew_pipeline_sampler + generate(multimodal_generation_mode='image-only'), executed (reference JA:137-330)."""
+    from tests.gpu_loop_check import teacher_forced_anole_api_check
+    r = teacher_forced_anole_api_check(device=str(dev))
+    gen, L = r["gen"], r["img_len"]
+    assert len(gen) == L + 2 and all(4 <= t < 8196 for t in gen[:L]) and gen[L] == 8196
+    assert r["nfe"] < len(gen)
+
+
+@pytest.mark.parametrize("family", ["lumina7b", "emu3_8b"])
+def test_real_shape_teacher_forced_loop(dev, family):
+    """parity at the production launch configuration of BASELINE.json configs 2 and 3 (real 7B / 8B shapes, ~25 iterations)"""
+    from tests.gpu_loop_check import teacher_forced_real_shape_check
+    if torch.cuda.get_device_properties(dev).total_memory < 60e9:
+        pytest.skip("needs a 7B-class model + its packed copy in HBM")
+    r = teacher_forced_real_shape_check(family=family, device=str(dev))
+    assert r["nfe"] >= 12 and r["tokens"] >= 40 and max(r["accepted"]) >= 2
+    assert r["fwd_graphs"] >= 1 and all(c is not None for c in r["head_cols"])          # the narrow output head was the one that ran
+    torch.cuda.empty_cache()

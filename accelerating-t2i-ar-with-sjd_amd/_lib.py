@@ -37,12 +37,21 @@ class RowNorm(ctypes.Structure):
     _fields_ = [("sumsq", ctypes.c_void_p), ("slices", ctypes.c_int32), ("hidden", ctypes.c_int32), ("eps", ctypes.c_float)]
 
 
+class HeadPartials(ctypes.Structure):
+    """sjd_head_partials: the unmaterialised output head K2 reads (split-K partials of the lm_head projection)"""
+    _fields_ = [("part", ctypes.c_void_p), ("n_chunks", ctypes.c_int32), ("chunk_stride", ctypes.c_int64), ("row_stride", ctypes.c_int64),
+                ("col0", ctypes.c_int32), ("n_cols", ctypes.c_int32), ("urow_off", ctypes.c_int32), ("round_dtype", ctypes.c_int32),
+                ("row_sumsq", ctypes.c_void_p), ("slices", ctypes.c_int32), ("prows", ctypes.c_int32), ("inv_hidden", ctypes.c_float),
+                ("eps", ctypes.c_float), ("dbg_c", ctypes.c_void_p), ("dbg_u", ctypes.c_void_p)]
+
+
 EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_probs_sample", "sjd_verify_accept",
            "sjd_kv_append", "sjd_attention_workspace_bytes", "sjd_draft_window_attention", "sjd_draft_window_attention_ex",
            "sjd_event_create", "sjd_event_destroy", "sjd_event_synchronize", "sjd_event_elapsed_ms",
            "sjd_add_rmsnorm", "sjd_qknorm_rope_append", "sjd_silu_mul", "sjd_gemm_num_chunks", "sjd_skinny_gemm",
            "sjd_kv_append_fp8", "sjd_draft_window_attention_fp8", "sjd_qknorm_rope_append_fp8",
-           "sjd_residual_sumsq", "sjd_qknorm_rope_append_ex", "sjd_silu_mul_ex", "sjd_weight_prefetch"]
+           "sjd_residual_sumsq", "sjd_qknorm_rope_append_ex", "sjd_silu_mul_ex", "sjd_weight_prefetch", "sjd_qkv_attention_fused", "sjd_skinny_gemm_cols",
+           "sjd_logits_to_probs_sample_part"]
 
 _lib = None
 
@@ -84,6 +93,10 @@ def load():
     lib.sjd_kv_append_fp8.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, i32, vp, i32, vp]
     lib.sjd_draft_window_attention_fp8.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp, vp]
     lib.sjd_weight_prefetch.argtypes = [vp, i64, i32, vp, vp]
+    lib.sjd_skinny_gemm_cols.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.sjd_logits_to_probs_sample_part.argtypes = [ctypes.POINTER(HeadPartials), f32, i32, i32, vp, vp, vp, vp, vp]
+    lib.sjd_qkv_attention_fused.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),
+                                            vp, vp, i32, vp]
     lib.sjd_event_create.restype = vp
     lib.sjd_event_destroy.argtypes = [vp]
     lib.sjd_event_synchronize.argtypes = [vp]

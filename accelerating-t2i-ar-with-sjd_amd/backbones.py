@@ -28,6 +28,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+import os as _os
+
+_K1_FUSED_DEFAULT = _os.environ.get("SJD_K1_FUSED", "1") != "0"       # measurement switch: 0 = F2 + K1 + combine (three launches)
+
+
 def _head_logits(linear, x, cols):
     """fp32 logits of the output head, optionally only for the vocabulary columns [cols[0], cols[1]) -- the rows of the weight the
     grammar can give probability mass to in this iteration (Lumina image body: 8192 of 65536 ids).  K2 never reads a masked column,
@@ -421,8 +426,33 @@ class ChameleonBackbone(nn.Module):
                                              o=ops.pack_weight(a.o_proj.weight, c["o"][0], c["o"][2]),
                                              gate_up=ops.pack_weight(gu_p, c["gate_up"][0], c["gate_up"][2]),
                                              down=ops.pack_weight(m.down_proj.weight, c["down"][0], c["down"][2])))
+            self._packed_head = None
+            if gemm == "sjd" and self._fold_norm and self.lm_head.bias is None:
+                # output head on G1: ONE packed copy of lm_head with the final norm gain folded in; a launch covers only
+                # the vocabulary columns the grammar allows and K2 reads its split-K partials directly (no fp32 logits tensor)
+                w = self.lm_head.weight
+                wf = (w.float() * self.model.norm.weight.float()[None, :]).to(w.dtype)
+                V, pad = w.shape[0], (-w.shape[0]) % 32
+                if pad:
+                    wf = torch.cat([wf, torch.zeros(pad, w.shape[1], dtype=w.dtype, device=w.device)], dim=0)
+                self._head_cols = V + pad
+                self._packed_head = ops.pack_weight(wf, self.HEAD_CFG[0], self.HEAD_CFG[2])
+                del wf
         self._inv_freq32 = self.inv_freq.float().contiguous()
         return self
+
+    HEAD_CFG = (512, 8, True)          # G1 launch shape of the output head: (split-K chunk, column tiles per workgroup, step-major)
+    supports_head_partials = True
+
+    def _head_partials(self, h, delta, cols, n):
+        """final residual add + the output head as G1 split-K partials over the column window `cols` -> ops.HeadOut (K2 applies the folded
+        final RMSNorm as a row scale and the 16-bit rounding of the lm_head output while it reads them)"""
+        ops, hid = self._ops, self.args.hidden_size
+        sumsq = ops.residual_sumsq(h, delta)
+        lo, hi = cols if cols is not None else (0, self.vocab_size)
+        lo32, hi32 = (lo // 32) * 32, min(self._head_cols, ((hi + 31) // 32) * 32)
+        part = ops.skinny_gemm_cols(h, self._packed_head, self._head_cols, hid, self.HEAD_CFG[0], lo32, hi32 - lo32, self.HEAD_CFG[1], self.HEAD_CFG[2])
+        return ops.HeadOut(part, lo32, n if h.shape[0] > n else 0, h.dtype, row_norm=(sumsq, hid, self.args.rms_norm_eps))
 
     def _f2(self, qkv, li, qn, pos, B, n, params, kv_len, row_norm=None):
         """F2 (QK-norm + RoPE + KV append); an fp8 cache gets its rows quantised in the same launch."""
@@ -431,7 +461,18 @@ class ChameleonBackbone(nn.Module):
                                       kv_len if params is None else 0, kv_scale=getattr(self.attn, "kv_scale", (1.0, 1.0)),
                                       dtype=self.lm_head.weight.dtype, row_norm=row_norm)
 
-    def _forward_window_g1_folded(self, tokens, positions, kv_len, key_start, cols=None):
+    def _attention_block(self, qkv_part, li, qn, pos, B, n, params, kv_len, key_start, row_norm=None):
+        """QK-norm + RoPE + KV append + draft-window attention of one layer on the G1 partials of the q|k|v projection: kernel K1F (one
+        launch) for the multi-head 16-row window, F2 then K1 (+ combine) otherwise."""
+        ops, H, Hkv, D = self._ops, self.n_heads, self.n_kv_heads, self.head_dim
+        ks_ok = isinstance(key_start, torch.Tensor) and key_start.is_cuda and key_start.dtype == torch.int32
+        if getattr(self, "k1_fused", _K1_FUSED_DEFAULT) and ks_ok and ops.fused_attention_ok(B, n, H, Hkv, D, self.cache.k.dtype):
+            return ops.qkv_attention_fused(qkv_part, self.cache.k[li], self.cache.v[li], *qn, self._inv_freq32, pos, B, n, H, D, params,
+                                           kv_len if params is None else 0, key_start, row_norm=row_norm, dtype=self.lm_head.weight.dtype)
+        q = self._f2(qkv_part, li, qn, pos, B, n, params, kv_len, row_norm=row_norm)
+        return self.attn.attend(li, q, self.cache, kv_len, key_start)
+
+    def _forward_window_g1_folded(self, tokens, positions, kv_len, key_start, cols=None, head_partials=False):
         """_forward_window_g1 with the RMSNorm folded away: the projections run on the residual stream h itself (norm gain inside
         the packed weight), F1r does the residual add and the per-slice sums of h^2, F2 / F3 apply the row scale on the partials:
           F1r, qkv GEMM, F2, K1 partial, K1 combine, o GEMM, F1r, gate|up GEMM, F3, down GEMM   (F1r 3.5 us against F1's 6.1)."""
@@ -448,12 +489,13 @@ class ChameleonBackbone(nn.Module):
             a = layer.self_attn
             rn = (ops.residual_sumsq(h, delta), hid, eps)
             qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
-            q = self._f2(g1(h, "qkv", (H + 2 * Hkv) * D, hid), li, qn, pos, B, n, params, kv_len, row_norm=rn)
-            o = self.attn.attend(li, q, self.cache, kv_len, key_start)
+            o = self._attention_block(g1(h, "qkv", (H + 2 * Hkv) * D, hid), li, qn, pos, B, n, params, kv_len, key_start, row_norm=rn)
             rn = (ops.residual_sumsq(h, g1(o.view(T, H * D), "o", hid, H * D)), hid, eps)
             act = ops.silu_mul(g1(h, "gate_up", 2 * inter, hid), rows=T, dtype=h.dtype, row_norm=rn)
             delta = g1(act, "down", hid, inter)
         self._prefetch_join()
+        if head_partials and self._packed_head is not None:
+            return self._head_partials(h, delta, cols, n)
         x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
         return _head_logits(self.lm_head, x, cols).view(B, n, -1)
 
@@ -476,8 +518,7 @@ class ChameleonBackbone(nn.Module):
             x = ops.add_rmsnorm(h, delta, layer.input_layernorm.weight, eps)
             qkv = g1(x, "qkv", (H + 2 * Hkv) * D, hid)
             qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
-            q = self._f2(qkv, li, qn, pos, B, n, params, kv_len)
-            o = self.attn.attend(li, q, self.cache, kv_len, key_start)
+            o = self._attention_block(qkv, li, qn, pos, B, n, params, kv_len, key_start)
             attn_out = g1(o.view(T, H * D), "o", hid, H * D)
             x = ops.add_rmsnorm(h, attn_out, layer.post_attention_layernorm.weight, eps)
             gu = g1(x, "gate_up", 2 * inter, hid)
@@ -486,10 +527,10 @@ class ChameleonBackbone(nn.Module):
         x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
         return _head_logits(self.lm_head, x, cols).view(B, n, -1)
 
-    def _forward_window_fused(self, tokens, positions, kv_len, key_start, cols=None):
+    def _forward_window_fused(self, tokens, positions, kv_len, key_start, cols=None, head_partials=False):
         if self._gemm == "sjd" and tokens.shape[0] * tokens.shape[1] <= 64:
             if self._fold_norm:
-                return self._forward_window_g1_folded(tokens, positions, kv_len, key_start, cols)
+                return self._forward_window_g1_folded(tokens, positions, kv_len, key_start, cols, head_partials)
             return self._forward_window_g1(tokens, positions, kv_len, key_start, cols)
         ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
         T, eps = B * n, self.args.rms_norm_eps
@@ -512,10 +553,12 @@ class ChameleonBackbone(nn.Module):
         x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
         return _head_logits(self.lm_head, x, cols).view(B, n, -1)
 
-    def forward_window(self, tokens, positions, kv_len, key_start, cols=None):
-        """cols = (lo, hi): compute the logits of vocabulary columns [lo, hi) only (returned compact, [B, n, hi - lo])."""
+    def forward_window(self, tokens, positions, kv_len, key_start, cols=None, head_partials=False):
+        """cols = (lo, hi): compute the logits of vocabulary columns [lo, hi) only (returned compact, [B, n, hi - lo]).
+        head_partials: on the G1 folded-norm path return an ops.HeadOut (split-K partials of the output head for kernel K2) instead of
+        materialised fp32 logits; paths that cannot (library GEMMs, prefill shapes) return logits as usual."""
         if getattr(self, "_ops", None) is not None:
-            return self._forward_window_fused(tokens, positions, kv_len, key_start, cols)
+            return self._forward_window_fused(tokens, positions, kv_len, key_start, cols, head_partials)
         B, n = tokens.shape
         h = self.model.embed_tokens(tokens)
         cos, sin = self._rope(positions, h.dtype)

@@ -513,6 +513,329 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
     for (int j = 0; j < PER; ++j) o[j] = Frag<DT>::cvt(acc[j] * inv);
 }
 
+// ------------------------------------------------------------------------------------------------ K1F (fused F2 + K1 + combine)
+// rocprofv3, round 1: per layer the attention block is THREE dependent launches -- F2 (QK-norm + RoPE + KV append, 5.2 us), k1_partial
+// (11.8 us at kv_len 100 ... 21 us at 1216) and k1_combine (4.6 us) -- each at its launch-latency floor, and the split partials make a
+// round trip through HBM.  K1F does all of it in ONE launch for the multi-head-attention window (H == H_kv, <= 16 rows, D = 128):
+//   grid = (H, B); one 512-thread workgroup = 8 wave64 owns a (batch, head) completely.
+//   phase A  the 48 (row, q|k|v) head slices are spread over the waves (6 each): a wave sums the fp32 split-K partials of its slice
+//            (lane l owns the rotate-half pair d = l, l + 64), applies the folded RMSNorm row scale, per-head LayerNorm, RoPE -- the
+//            arithmetic and rounding points of F2 (sjd_glue.hip), so K/V rows are bit-identical -- and writes q to LDS, k / v into cache
+//            rows [kv_len + row].  Waves whose first key tile lies wholly below kv_len have its K/V loads in flight meanwhile.
+//   phase B  wave w walks key tiles t_lo + w, + 8, ... like k1_partial, two tiles in flight (K rows straight from HBM into MFMA fragments, V via a
+//            per-wave LDS tile and ds_read_b64_tr_b16, online softmax in registers): 8 waves x 32 KB in flight per CU replace the four
+//            4-wave workgroups of the split version, and the window's own K/V rows are read back by the workgroup that wrote them.
+//   phase C  the 8 (m, l, O) states are merged through LDS (the arena of the V tiles, reused) and the normalised output goes straight
+//            to out[B, n, H, D]: no workspace, no second kernel.
+// 64 workgroups instead of 256: each CU has to pull ~0.6 MB at kv_len 1216, which 8 waves with two tiles each in flight have to sustain (~100 GB/s per CU).
+#define K1F_WAVES 8           // 512 threads = 2 waves per SIMD = 256 registers per lane: room for TWO key tiles in flight per wave
+
+template <int DT> __device__ __forceinline__ float k1f_round(float x);
+template <> __device__ __forceinline__ float k1f_round<SJD_DTYPE_BF16>(float x)
+{   // the round-to-nearest-even F2 uses (sjd_glue.hip Cvt<BF16>)
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xffff0000u);
+}
+template <> __device__ __forceinline__ float k1f_round<SJD_DTYPE_F16>(float x) { return (float)((_Float16)x); }
+template <int DT> __device__ __forceinline__ unsigned short k1f_bits(float x);       // x already representable
+template <> __device__ __forceinline__ unsigned short k1f_bits<SJD_DTYPE_BF16>(float x) { return (unsigned short)(__float_as_uint(x) >> 16); }
+template <> __device__ __forceinline__ unsigned short k1f_bits<SJD_DTYPE_F16>(float x) { _Float16 h = (_Float16)x; return *reinterpret_cast<unsigned short *>(&h); }
+template <int DT> __device__ __forceinline__ float k1f_load16(const unsigned short *p);
+template <> __device__ __forceinline__ float k1f_load16<SJD_DTYPE_BF16>(const unsigned short *p) { return __uint_as_float((unsigned)(*p) << 16); }
+template <> __device__ __forceinline__ float k1f_load16<SJD_DTYPE_F16>(const unsigned short *p) { return (float)(*reinterpret_cast<const _Float16 *>(p)); }
+
+__device__ __forceinline__ float k1f_wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <int DT, int D>
+__global__ __launch_bounds__(64 * K1F_WAVES) void k1f_qkv_attention(
+    const float *__restrict__ part, int n_chunks, int prows, const unsigned short *__restrict__ qn_w, const unsigned short *__restrict__ qn_b,
+    const unsigned short *__restrict__ kn_w, const unsigned short *__restrict__ kn_b, const float *__restrict__ inv_freq,
+    const long *__restrict__ positions, const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden, float rs_eps,
+    unsigned short *__restrict__ kc, unsigned short *__restrict__ vc, unsigned short *__restrict__ out, int n_rows, int H, int S_max,
+    const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg)
+{
+    typedef typename Frag<DT>::vec vec;
+    static_assert(D == 128, "K1F is written for head_dim 128");
+    constexpr int HALF = D / 2, KS = D / 32, DB = D / 16, VROW = D + 8;
+    constexpr int V_BYTES = K1F_WAVES * K1_KT * VROW * 2;             // per-wave V tiles of the key loop
+    constexpr int R_BYTES = K1F_WAVES * K1_ROWS * (D + 2) * 4;        // merge buffers of the epilogue (aliased)
+    __shared__ __attribute__((aligned(16))) unsigned char arena[V_BYTES > R_BYTES ? V_BYTES : R_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned short q_lds[K1_ROWS][VROW];
+    unsigned short (*v_lds)[K1_KT * VROW] = reinterpret_cast<unsigned short (*)[K1_KT * VROW]>(arena);
+    float (*red_o)[K1_ROWS][D] = reinterpret_cast<float (*)[K1_ROWS][D]>(arena);
+    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + K1F_WAVES * K1_ROWS * D * 4);
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int kv_len = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
+    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;
+    const int n_c = min(min(K1_ROWS, n_rows), n_total);
+    const int total = kv_len + max(n_c, 0);
+    const int kstart = key_start ? key_start[b] : 0;
+    const float scale = rsqrtf((float)D);
+    const int t_lo = kstart / K1_KT, t_hi = (total + K1_KT - 1) / K1_KT;
+    unsigned short *kbase = kc + ((size_t)b * H + head) * (size_t)S_max * D;
+    unsigned short *vbase = vc + ((size_t)b * H + head) * (size_t)S_max * D;
+
+    // ---------------- phase A loads.  16 rows x {q, k, v} = 48 (row, tensor) tasks, 48 / K1F_WAVES per wave; in a task lane l owns the
+    // rotate-half pair d = l, l + 64 of that row's head slice: fp32 split-K partials of the q|k|v projection, all chunks in flight.
+    constexpr int TPW = 3 * K1_ROWS / K1F_WAVES;                  // tasks per wave
+    static_assert(TPW * K1F_WAVES == 3 * K1_ROWS, "tasks must divide evenly");
+    constexpr int MAXC = 4;                                       // chunks in flight per task and pass
+    const size_t ncol = (size_t)3 * H * D;
+    float acc[TPW][2], ss_tot[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int task = w * TPW + j, row = task / 3, x = task % 3;
+        const int tok = b * n_rows + row;
+        acc[j][0] = acc[j][1] = 0.f;
+        ss_tot[j] = 0.f;
+        if (row < n_rows) {
+            if (row_sumsq)
+                for (int s0 = 0; s0 < rs_slices; s0 += 8) {      // as row_sumsq_total (sjd_glue.hip): eight loads in flight, fixed order
+                    float v8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v8[q] = (s0 + q < rs_slices) ? row_sumsq[(size_t)(s0 + q) * prows + tok] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) ss_tot[j] += v8[q];
+                }
+            const float *p0 = part + (size_t)tok * ncol + ((size_t)x * H + head) * D + lane;
+            for (int c0 = 0; c0 < n_chunks; c0 += MAXC) {        // summed in chunk order, as F2 does
+                float v0[MAXC], v1[MAXC];
+#pragma unroll
+                for (int q = 0; q < MAXC; ++q)
+                    if (c0 + q < n_chunks) {
+                        const float *pp = p0 + (size_t)(c0 + q) * prows * ncol;
+                        v0[q] = pp[0];
+                        v1[q] = pp[HALF];
+                    }
+#pragma unroll
+                for (int q = 0; q < MAXC; ++q)
+                    if (c0 + q < n_chunks) { acc[j][0] += v0[q]; acc[j][1] += v1[q]; }
+            }
+        }
+    }
+
+    // ---------------- key tiles.  A wave owns tiles t_lo + w, + 8, ...; TWO of them are in flight at any time (two register landing
+    // zones of K fragments + V rows, 64 registers each): measured with one tile in flight and 12 waves, a CU pulled only ~40 GB/s -- the
+    // per-wave load -> MFMA -> softmax -> LDS -> MFMA chain is latency bound -- and with 64 workgroups the kernel needs ~100 GB/s per CU
+    // to beat four 4-wave workgroups per head.  Tiles that contain rows this workgroup is about to append are fetched after the barrier.
+    u32x4 kA[2][KS], kB[2][KS];
+    constexpr int VP = K1_KT * D / (64 * 8), LPR = D / 8;
+    u32x4 vA[VP], vB[VP];
+    unsigned short *vl = v_lds[w];
+    auto load_k = [&](int t_, u32x4 (&kd)[2][KS]) {
+        const unsigned short *kt = kbase + (size_t)(t_ * K1_KT) * D;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                kd[kb][ks] = *reinterpret_cast<const u32x4 *>(kt + (size_t)(16 * kb + c) * D + 32 * ks + 8 * g);
+    };
+    auto load_v = [&](int t_, u32x4 (&vd)[VP]) {
+        const unsigned short *vt = vbase + (size_t)(t_ * K1_KT) * D;
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            const int idx = i * 64 + lane;
+            vd[i] = *reinterpret_cast<const u32x4 *>(vt + (size_t)(idx / LPR) * D + 8 * (idx % LPR));
+        }
+    };
+    auto store_v = [&](int t_, u32x4 (&vd)[VP]) {                // rows of keys >= total are zeroed (0 * NaN inside the MFMA)
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            const int idx = i * 64 + lane;
+            const bool live = (t_ * K1_KT + idx / LPR) < total;
+            *reinterpret_cast<u32x4 *>(vl + (idx / LPR) * VROW + 8 * (idx % LPR)) = live ? vd[i] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    const int t0 = t_lo + w, t1 = t0 + K1F_WAVES;
+    const bool early0 = (t0 < t_hi) && ((t0 + 1) * K1_KT <= kv_len);         // no window row inside: safe to fetch before the append
+    const bool early1 = (t1 < t_hi) && ((t1 + 1) * K1_KT <= kv_len);
+    if (early0) { load_k(t0, kA); load_v(t0, vA); }
+    if (early1) { load_k(t1, kB); load_v(t1, vB); }
+
+    // ---------------- phase A math: the arithmetic of f2_qknorm_rope_append, same rounding points
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int task = w * TPW + j, row = task / 3, x = task % 3;
+        if (row >= n_rows) continue;
+        const int tok = b * n_rows + row, rr = kv_len + row;
+        float x0 = acc[j][0], x1 = acc[j][1];
+        if (row_sumsq) {
+            const float r = rsqrtf(ss_tot[j] * rs_inv_hidden + rs_eps);
+            x0 *= r;
+            x1 *= r;
+        }
+        x0 = k1f_round<DT>(x0);
+        x1 = k1f_round<DT>(x1);
+        if (x == 2) {                                                          // V: plain copy into the cache
+            if (rr < S_max) {
+                vbase[(size_t)rr * D + lane] = k1f_bits<DT>(x0);
+                vbase[(size_t)rr * D + lane + HALF] = k1f_bits<DT>(x1);
+            }
+            continue;
+        }
+        const unsigned short *gw_ = x == 0 ? qn_w : kn_w, *gb_ = x == 0 ? qn_b : kn_b;
+        if (gw_ != nullptr) {                                                  // per-head LayerNorm over head_dim (eps 1e-5)
+            const float mean = k1f_wave_sum(x0 + x1) / (float)D;
+            const float d0 = x0 - mean, d1 = x1 - mean;
+            const float var = k1f_wave_sum(d0 * d0 + d1 * d1) / (float)D;
+            const float inv = rsqrtf(var + 1e-5f);
+            const float n0 = k1f_round<DT>(d0 * inv), n1 = k1f_round<DT>(d1 * inv);
+            x0 = k1f_round<DT>(k1f_round<DT>(n0 * k1f_load16<DT>(gw_ + lane)) + k1f_load16<DT>(gb_ + lane));
+            x1 = k1f_round<DT>(k1f_round<DT>(n1 * k1f_load16<DT>(gw_ + lane + HALF)) + k1f_load16<DT>(gb_ + lane + HALF));
+        }
+        float sn, cs;
+        sincosf((float)positions[tok] * inv_freq[lane], &sn, &cs);
+        cs = k1f_round<DT>(cs);
+        sn = k1f_round<DT>(sn);
+        const float a0 = k1f_round<DT>(x0 * cs), b0 = k1f_round<DT>(-x1 * sn);
+        const float a1 = k1f_round<DT>(x1 * cs), b1 = k1f_round<DT>(x0 * sn);
+        const unsigned short o0 = k1f_bits<DT>(k1f_round<DT>(a0 + b0)), o1 = k1f_bits<DT>(k1f_round<DT>(a1 + b1));
+        if (x == 0) { q_lds[row][lane] = o0; q_lds[row][lane + HALF] = o1; }
+        else if (rr < S_max) { kbase[(size_t)rr * D + lane] = o0; kbase[(size_t)rr * D + lane + HALF] = o1; }
+    }
+    __syncthreads();            // q in LDS; this workgroup's K/V rows acknowledged by L2 (it is their only reader in this launch)
+
+    // ---------------- phase B: the key loop of k1_partial with 8 key-parts, two tiles in flight per wave
+    const bool rv = (c < n_c);
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x4 o_acc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t0 < t_hi && !early0) { load_k(t0, kA); load_v(t0, vA); }
+    if (t1 < t_hi && !early1) { load_k(t1, kB); load_v(t1, vB); }
+    // one tile: on entry kc_ / vc_ hold (or are about to receive) tile t_; the other pair holds tile t_ + 8.  As soon as a landing zone
+    // has been consumed it is re-armed with tile t_ + 16.
+    auto step = [&](int t_, u32x4 (&kc_)[2][KS], u32x4 (&vc_)[VP]) {
+        const int t2 = t_ + 2 * K1F_WAVES;
+        const bool more = t2 < t_hi;
+        f32x4 st[2];
+        st[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {                        // Q fragments from LDS (4 ds_read_b128 per tile instead of 16 registers)
+            const u32x4 qx = rv ? *reinterpret_cast<const u32x4 *>(&q_lds[c][32 * ks + 8 * g]) : u32x4{0, 0, 0, 0};
+            st[0] = Frag<DT>::mfma(as_frag<vec>(kc_[0][ks]), as_frag<vec>(qx), st[0]);
+            st[1] = Frag<DT>::mfma(as_frag<vec>(kc_[1][ks]), as_frag<vec>(qx), st[1]);
+        }
+        if (more) load_k(t2, kc_);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t_ * K1_KT + 16 * kb + 4 * g + r;
+                const bool vis = (key >= kstart) && (key <= kv_len + c) && (key < total);
+                const float sv = vis ? st[kb][r] * scale : -INFINITY;
+                st[kb][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+        const float alpha = __expf(m_run - m_safe);
+        float rsum = 0.0f;
+        unsigned short pb[8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __expf(st[kb][r] - m_safe);
+                rsum += pv;
+                pb[4 * kb + r] = Frag<DT>::cvt(pv);
+            }
+        rsum += __shfl_xor(rsum, 16);
+        rsum += __shfl_xor(rsum, 32);
+        l_run = l_run * alpha + rsum;
+        m_run = m_new;
+        u32x4 pw;
+        pw[0] = pb[0] | ((unsigned)pb[1] << 16);
+        pw[1] = pb[2] | ((unsigned)pb[3] << 16);
+        pw[2] = pb[4] | ((unsigned)pb[5] << 16);
+        pw[3] = pb[6] | ((unsigned)pb[7] << 16);
+        const vec pfrag = as_frag<vec>(pw);
+        store_v(t_, vc_);              // in-order LDS queue: the previous tile's transposed reads are done
+        if (more) load_v(t2, vc_);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const unsigned short *a0 = vl + (4 * g + (c >> 2)) * VROW + 16 * db + 4 * (c & 3);
+            const u32x2 lo = lds_tr_read(a0), hi = lds_tr_read(a0 + 16 * VROW);
+            const u32x4 vv{lo[0], lo[1], hi[0], hi[1]};
+            f32x4 a = o_acc[db];
+            a[0] *= alpha; a[1] *= alpha; a[2] *= alpha; a[3] *= alpha;
+            o_acc[db] = Frag<DT>::mfma(as_frag<vec>(vv), pfrag, a);
+        }
+    };
+    for (int t = t0; t < t_hi; t += 2 * K1F_WAVES) {
+        step(t, kA, vA);
+        if (t + K1F_WAVES < t_hi) step(t + K1F_WAVES, kB, vB);
+    }
+
+    // ---------------- phase C: merge the 16 key-parts and write the normalised rows
+    __syncthreads();
+    if (g == 0) { red_ml[w][c][0] = m_run; red_ml[w][c][1] = l_run; }
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red_o[w][c][16 * db + 4 * g + r] = o_acc[db][r];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < K1_ROWS * D; idx += 64 * K1F_WAVES) {
+        const int row = idx / D, d = idx % D;
+        if (row >= n_rows) continue;
+        unsigned short *o = out + (((size_t)b * n_rows + row) * H + head) * D + d;
+        if (row >= n_total) { *o = 0; continue; }              // padding rows of a shape-static window: defined (zero) output
+        float M = -INFINITY;
+#pragma unroll
+        for (int ww = 0; ww < K1F_WAVES; ++ww) M = fmaxf(M, red_ml[ww][row][0]);
+        const float Ms = (M == -INFINITY) ? 0.0f : M;
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < K1F_WAVES; ++ww) {
+            const float wgt = __expf(red_ml[ww][row][0] - Ms);
+            L += wgt * red_ml[ww][row][1];
+            O += wgt * red_o[ww][row][d];
+        }
+        *o = Frag<DT>::cvt(L > 0.f ? O / L : 0.0f);
+    }
+}
+
+extern "C" int sjd_qkv_attention_fused(const float *part, int n_chunks, void *k_cache, void *v_cache, void *out, const void *qn_w,
+                                       const void *qn_b, const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions,
+                                       int B, int n_rows, int H, int D, int S_max, int dtype, const sjd_row_norm *row_norm,
+                                       const int32_t *key_start, const sjd_iter_params *params, int kv_len, void *stream)
+{
+    if (!part || n_chunks < 1 || !k_cache || !v_cache || !out || !inv_freq || !positions || B < 1 || H < 1) return SJD_ERR_BAD_ARG;
+    if (n_rows < 1 || n_rows > K1_ROWS || B * n_rows > 32 || (S_max % K1_KT) != 0) return SJD_ERR_BAD_ARG;
+    if ((qn_w == nullptr) != (qn_b == nullptr) || (kn_w == nullptr) != (kn_b == nullptr)) return SJD_ERR_BAD_ARG;
+    if (row_norm && (!row_norm->sumsq || row_norm->slices < 1 || row_norm->hidden < 1)) return SJD_ERR_BAD_ARG;
+    if (D != 128) return SJD_ERR_UNSUPPORTED;
+    const float *ss = row_norm ? row_norm->sumsq : nullptr;
+    const int sl = row_norm ? row_norm->slices : 0;
+    const float ih = row_norm ? 1.0f / (float)row_norm->hidden : 0.f, eps = row_norm ? row_norm->eps : 0.f;
+    hipStream_t s = (hipStream_t)stream;
+#define SJD_K1F_CASE(DT_)                                                                                                                  \
+    if (dtype == DT_) {                                                                                                                    \
+        hipLaunchKernelGGL((k1f_qkv_attention<DT_, 128>), dim3(H, B), dim3(64 * K1F_WAVES), 0, s, part, n_chunks, 32, (const unsigned short *)qn_w,   \
+                           (const unsigned short *)qn_b, (const unsigned short *)kn_w, (const unsigned short *)kn_b, inv_freq,              \
+                           (const long *)positions, ss, sl, ih, eps, (unsigned short *)k_cache, (unsigned short *)v_cache,                 \
+                           (unsigned short *)out, n_rows, H, S_max, key_start, params, kv_len);                                           \
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;                                                                   \
+    }
+    SJD_K1F_CASE(SJD_DTYPE_BF16)
+    SJD_K1F_CASE(SJD_DTYPE_F16)
+#undef SJD_K1F_CASE
+    return SJD_ERR_UNSUPPORTED;
+}
+
 // ------------------------------------------------------------------------------------------------ K1 (fp8 KV)
 // BASELINE config 5: the KV cache is stored as OCP fp8 e4m3 (value = fp8 * scale, one scale per tensor), which halves the
 // bytes K1 streams, and both contractions run on v_mfma_f32_16x16x32_fp8_fp8:

@@ -49,10 +49,12 @@ template <> struct G1Mfma<SJD_DTYPE_F16> {
 
 // x: [M, K] row-major (M <= 32*MT; missing rows read as zero).  wp: packed weights.  out: fp32 [n_chunks, 32*MT, N].
 // MT = 2 serves a 64-row window (B_cfg * L with a draft window of 32): every weight record feeds two MFMAs.
+// Column window: the launch covers tiles [tile0, tile0 + N/32) of a weight packed with `n_tiles` tiles (N = columns of THIS launch's
+// output): the output head is evaluated only for the vocabulary columns the grammar allows out of one packed copy.
 template <int DT, int MT>
 __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                 float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
-                                                                int rec_stride)
+                                                                int rec_stride, int tile0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *xl = reinterpret_cast<u32x4 *>(smem);
@@ -61,8 +63,9 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
     const int steps = min(KC, K - k0) / 16;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
-    const int t = blockIdx.x * waves + w;
-    const bool has_tile = t < n_tiles;
+    const int t_out = blockIdx.x * waves + w;          // tile of this launch's output
+    const int t = tile0 + t_out;                       // tile of the packed weight
+    const bool has_tile = t_out < N / 32;
     // record (chunk, s, t) in 1-KiB units: all earlier chunks are full (KC/16 steps each).
     //   rec_stride == 1      : tile-major   -- a wave streams one contiguous run of `steps` KiB
     //   rec_stride == n_tiles: step-major   -- at every k-step the whole grid row reads n_tiles contiguous KiB, i.e. the
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
     }
 
     // D[m][n]: reg r of lane l -> row m = (r&3) + 8*(r>>2) + 4*(l>>5), column n = 32t + (l&31): 128-B coalesced rows
-    float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t * 32 + (lane & 31);
+    float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t_out * 32 + (lane & 31);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -175,16 +178,34 @@ extern "C" int sjd_gemm_num_chunks(int K, int KC) { return (K + KC - 1) / KC; }
 
 // out: fp32 [n_chunks, 32, N] partial products; the consumer sums the chunks.
 template <int DT, int MT>
-static int g1_launch(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major, hipStream_t s)
+static int g1_launch(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major, hipStream_t s,
+                     int n_tiles_packed = 0, int tile0 = 0)
 {
-    const int n_tiles = N / 32, n_chunks = (K + KC - 1) / KC;
-    const dim3 grid((n_tiles + waves - 1) / waves, n_chunks), block(waves * 64);
+    const int n_out = N / 32, n_tiles = n_tiles_packed > 0 ? n_tiles_packed : n_out, n_chunks = (K + KC - 1) / KC;
+    if (tile0 < 0 || tile0 + n_out > n_tiles) return SJD_ERR_BAD_ARG;
+    const dim3 grid((n_out + waves - 1) / waves, n_chunks), block(waves * 64);
     const size_t lds = (size_t)MT * ((KC < K ? KC : K) / 16) * 64 * 16;       // the staged activation chunk
     if (lds > 160 * 1024) return SJD_ERR_BAD_ARG;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((g1_skinny_gemm<DT, MT>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles,
-                       step_major ? n_tiles : 1);
+                       step_major ? n_tiles : 1, tile0);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+// Column window of a packed weight: out[c, m, j] for the N = 32 * n columns [32 * tile0, 32 * tile0 + N) of a weight packed with N_packed columns.
+extern "C" int sjd_skinny_gemm_cols(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,
+                                    int dtype, int N_packed, int tile0, void *stream)
+{
+    if (!x || !w_packed || !out || M < 1 || M > 64 || N < 32 || (N % 32) != 0 || (N_packed % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0)
+        return SJD_ERR_BAD_ARG;
+    if (waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int np = N_packed / 32;
+    if (dtype == SJD_DTYPE_BF16 && M <= 32) return g1_launch<SJD_DTYPE_BF16, 1>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_F16 && M <= 32) return g1_launch<SJD_DTYPE_F16, 1>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    return SJD_ERR_UNSUPPORTED;
 }
 
 extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,

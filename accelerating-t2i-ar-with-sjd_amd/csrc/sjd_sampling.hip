@@ -32,10 +32,42 @@ __device__ __forceinline__ bool rule_allows(const sjd_row_rule &r, int c)
 
 // ------------------------------------------------------------------------------------------------ K2
 // replaces sampling_logits2tokens (reference jacobi_iteration_lumina_mgpt.py:82-132)
+// PART: the logits are not materialised -- K2 reads the fp32 split-K partials of the output-head projection (G1 over the packed
+// lm_head, only the vocabulary columns the grammar allows), sums the chunks in order, applies the folded final-RMSNorm row scale and
+// rounds to the activation dtype exactly where nn.Linear would (MC:1560-1561: 16-bit lm_head output, then .float()); the CFG combine,
+// grammar mask, top-k, softmax and draw are the same code as the dense-logits form.
+static_assert(sizeof(sjd_head_partials) == 88, "sjd_head_partials layout is mirrored by ctypes (sjd_amd/_lib.py::HeadPartials)");
+
+__device__ __forceinline__ float k2_round16(float x, int dt)
+{
+    if (dt == SJD_DTYPE_BF16) {
+        unsigned u = __float_as_uint(x);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return __uint_as_float(u & 0xffff0000u);
+    }
+    if (dt == SJD_DTYPE_F16) return (float)((_Float16)x);
+    return x;
+}
+
+__device__ __forceinline__ float k2_row_scale(const sjd_head_partials &hp, int tok)
+{
+    if (!hp.row_sumsq) return 1.0f;
+    float t = 0.f;
+    for (int s0 = 0; s0 < hp.slices; s0 += 8) {          // the fixed order of row_sumsq_total (sjd_glue.hip)
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (s0 + q < hp.slices) ? hp.row_sumsq[(size_t)(s0 + q) * hp.prows + tok] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += v[q];
+    }
+    return rsqrtf(t * hp.inv_hidden + hp.eps);
+}
+
+template <bool PART>
 __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const float *__restrict__ logits_c, const float *__restrict__ logits_u, long row_stride, float guidance, int V,
     const sjd_iter_params *__restrict__ params, const float *__restrict__ noise, float *__restrict__ probs_out,
-    int64_t *__restrict__ tokens_out)
+    int64_t *__restrict__ tokens_out, const sjd_head_partials hp)
 {
     __shared__ SjdShared sh;
     const int row = blockIdx.x;
@@ -52,9 +84,19 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
         return;
     }
 
-    const float *c = logits_c + (size_t)row * row_stride;
-    const float *u = (logits_u != nullptr && params->use_cfg) ? logits_u + (size_t)row * row_stride : nullptr;
-    const bool vec = ((V & 3) == 0) && ((row_stride & 3) == 0);
+    const float *c, *u;
+    float rc = 1.0f, ru = 1.0f;
+    if (PART) {                 // virtual column 0 of this row's first chunk; only columns [col0, col0 + n_cols) exist
+        row_stride = hp.row_stride;
+        c = hp.part + (size_t)row * row_stride - hp.col0;
+        u = (hp.urow_off > 0 && params->use_cfg) ? hp.part + (size_t)(hp.urow_off + row) * row_stride - hp.col0 : nullptr;
+        rc = k2_row_scale(hp, row);
+        if (u) ru = k2_row_scale(hp, hp.urow_off + row);
+    } else {
+        c = logits_c + (size_t)row * row_stride;
+        u = (logits_u != nullptr && params->use_cfg) ? logits_u + (size_t)row * row_stride : nullptr;
+    }
+    const bool vec = ((V & 3) == 0) && ((row_stride & 3) == 0) && (!PART || (hp.col0 & 3) == 0);
     // Only the window [wlo, whi) spanned by the rule's allowed ranges can hold probability mass (Lumina image rows: 8192 of
     // 65536 columns); everything outside is written as 0 once and never read again.
     int wlo, whi;
@@ -69,7 +111,35 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     int cnt = 0;
     SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
         float zc[4], zu[4];
-        if (vec && c0 + 3 < V) {
+        if (PART) {
+            const bool in4 = vec && c0 >= hp.col0 && c0 + 3 < hp.col0 + hp.n_cols && c0 + 3 < V;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { zc[j] = 0.f; zu[j] = 0.f; }
+            for (int ch = 0; ch < hp.n_chunks; ++ch) {           // chunk order = the summation order of every G1 consumer
+                const size_t off = (size_t)ch * hp.chunk_stride + c0;
+                if (in4) {
+                    const float4 a = *reinterpret_cast<const float4 *>(c + off);
+                    zc[0] += a.x; zc[1] += a.y; zc[2] += a.z; zc[3] += a.w;
+                    if (u) { const float4 b = *reinterpret_cast<const float4 *>(u + off); zu[0] += b.x; zu[1] += b.y; zu[2] += b.z; zu[3] += b.w; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = c0 + j;
+                        if (col >= hp.col0 && col < hp.col0 + hp.n_cols && col < V) { zc[j] += c[off + j]; if (u) zu[j] += u[off + j]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                zc[j] = k2_round16(zc[j] * rc, hp.round_dtype);
+                if (u) zu[j] = k2_round16(zu[j] * ru, hp.round_dtype);
+                const int col = c0 + j;
+                if (hp.dbg_c && col >= wlo && col < whi) {       // observers (tests): the logits exactly as this kernel derived them
+                    hp.dbg_c[(size_t)row * V + col] = zc[j];
+                    if (u && hp.dbg_u) hp.dbg_u[(size_t)row * V + col] = zu[j];
+                }
+            }
+        } else if (vec && c0 + 3 < V) {
             float4 a = *reinterpret_cast<const float4 *>(c + c0);
             zc[0] = a.x; zc[1] = a.y; zc[2] = a.z; zc[3] = a.w;
             if (u) { float4 b = *reinterpret_cast<const float4 *>(u + c0); zu[0] = b.x; zu[1] = b.y; zu[2] = b.z; zu[3] = b.w; }
@@ -291,8 +361,21 @@ extern "C" int sjd_logits_to_probs_sample(const float *logits_c, const float *lo
 {
     if (!logits_c || !params || !noise || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
         return SJD_ERR_BAD_ARG;
-    hipLaunchKernelGGL(k2_logits_to_probs_sample, dim3(max_rows), dim3(SJD_TPB), 0, (hipStream_t)stream, logits_c, logits_u,
-                       (long)row_stride, guidance, V, params, noise, probs_out, tokens_out);
+    sjd_head_partials none = {};
+    hipLaunchKernelGGL(k2_logits_to_probs_sample<false>, dim3(max_rows), dim3(SJD_TPB), 0, (hipStream_t)stream, logits_c, logits_u,
+                       (long)row_stride, guidance, V, params, noise, probs_out, tokens_out, none);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_logits_to_probs_sample_part(const sjd_head_partials *head, float guidance, int max_rows, int V,
+                                               const sjd_iter_params *params, const float *noise, float *probs_out, int64_t *tokens_out,
+                                               void *stream)
+{
+    if (!head || !head->part || head->n_chunks < 1 || head->n_cols < 1 || head->col0 < 0 || head->row_stride < head->n_cols) return SJD_ERR_BAD_ARG;
+    if (!params || !noise || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1) return SJD_ERR_BAD_ARG;
+    if (head->row_sumsq && (head->slices < 1 || head->prows < 1)) return SJD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k2_logits_to_probs_sample<true>, dim3(max_rows), dim3(SJD_TPB), 0, (hipStream_t)stream, (const float *)nullptr,
+                       (const float *)nullptr, (long)0, guidance, V, params, noise, probs_out, tokens_out, *head);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 

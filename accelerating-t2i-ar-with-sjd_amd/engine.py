@@ -89,7 +89,7 @@ def set_seed(seed):
 
 
 class SJDEngine:
-    def __init__(self, backbone, vocab_size, device, max_window=16, n_batch=2, use_graph=False, narrow_head=True):
+    def __init__(self, backbone, vocab_size, device, max_window=16, n_batch=2, use_graph=False, narrow_head=True, head_partials=True):
         L.load()                                   # fail loudly if the HIP extension is missing
         if max_window > L.MAX_WINDOW:
             raise ValueError(f"max_window {max_window} > {L.MAX_WINDOW}")
@@ -112,6 +112,9 @@ class SJDEngine:
         self.hook = None                            # test hook: called with per-iteration device tensors
         self.use_graph = use_graph                  # capture the window step (K5 -> forward -> K2 -> K4) in hipGraphs
         self.narrow_head = narrow_head              # evaluate the output head only for the columns the grammar allows
+        # K2 reads the output head's split-K partials (no fp32 logits tensor) when the backbone can produce them
+        self.head_partials = bool(head_partials) and getattr(backbone, "supports_head_partials", False)
+        self._dbg = None                            # [2, L, V] logits as K2 derived them; allocated only for observers (hook)
         self._guidance = 3.0
         self.rng_stream = torch.cuda.Stream(device=dev)
         self.reset_graphs()
@@ -159,15 +162,26 @@ class SJDEngine:
         cols: vocabulary column window of the output head (None = all columns)."""
         ops.reguess(self.params, self.state, self.input_ids)
         positions = self.kv_len_dev.to(torch.int64) + self.arange[None, :] + self.pos_offset[:, None]
+        if self.head_partials:
+            return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start, cols=cols, head_partials=True)
         if cols is None:
             return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start)
         return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start, cols=cols)
 
     def _sample_body(self, cur, logits, cols=None):
         """part 2: K2 + K4 (needs the noise tensors, which are drawn on a side stream while part 1 runs)."""
-        lu = logits[1] if self.B > 1 else None
-        ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr,
-                                   col0=cols[0] if cols else 0)
+        if isinstance(logits, ops.HeadOut):
+            dbg = None
+            if self.hook is not None:
+                if self._dbg is None:
+                    self._dbg = torch.zeros(2, self.Lmax, self.V, dtype=torch.float32, device=self.device)
+                dbg = self._dbg
+                dbg.zero_()
+            ops.logits_to_probs_sample_part(logits, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr, dbg=dbg)
+        else:
+            lu = logits[1] if self.B > 1 else None
+            ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr,
+                                       col0=cols[0] if cols else 0)
         ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0], self.scratch)
 
     def logit_columns(self, rules):
@@ -212,7 +226,7 @@ class SJDEngine:
         """part 2 (K2 + K4) once the noise drawn on the side stream is ready; a hipGraph per (prob-buffer parity, column window),
         captured the second time that combination runs on graph-owned logits."""
         torch.cuda.current_stream().wait_event(noise_ready)
-        key = (cur, self._guidance, cols)
+        key = (cur, self._guidance, cols, self.hook is not None)
         if not self.use_graph or ("fwd", cols) not in self._graphs:
             self._sample_body(cur, logits, cols)
             return
@@ -353,10 +367,13 @@ class SJDEngine:
                     attn.params = self.params                                        # windows: kv_len / n_rows from the blob
             else:
                 self._launch_sample(cur, logits, noise_ready, cols)
-                lc = logits[0, :n_rows]
-                lu = logits[1, :n_rows] if B > 1 else None
                 win_len = n_rows
-                if cols is not None and self.hook is not None:       # observers get full-width rows (zeros where nothing was computed)
+                if isinstance(logits, ops.HeadOut):                  # observers get the logits exactly as K2 derived them
+                    lc, lu = (self._dbg[0, :n_rows], self._dbg[1, :n_rows] if B > 1 else None) if self.hook is not None else (None, None)
+                else:
+                    lc = logits[0, :n_rows]
+                    lu = logits[1, :n_rows] if B > 1 else None
+                if cols is not None and self.hook is not None and not isinstance(logits, ops.HeadOut):       # full-width rows (zeros elsewhere)
                     full = torch.zeros(logits.shape[0], n_rows, self.V, dtype=logits.dtype, device=dev)
                     full[:, :, cols[0]:cols[1]] = logits[:, :n_rows]
                     lc, lu = full[0], (full[1] if B > 1 else None)

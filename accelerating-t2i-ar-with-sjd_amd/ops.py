@@ -234,6 +234,46 @@ def weight_prefetch(w_packed, blocks=128, nbytes=None):
     L.check(L.load().sjd_weight_prefetch(_ptr(w_packed), nb, int(blocks), _ptr(sink), _stream()), "sjd_weight_prefetch")
 
 
+def skinny_gemm_cols(x, w_packed, N_packed, K, KC, col0, n_cols, waves=8, step_major=True):
+    """G1 over the vocabulary columns [col0, col0 + n_cols) (32-aligned) of a weight packed with N_packed columns -> Partials [n_chunks, R, n_cols]."""
+    M = x.shape[0]
+    assert x.is_contiguous() and x.shape[1] == K and w_packed.numel() == N_packed * K and col0 % 32 == 0 and n_cols % 32 == 0
+    nc = (K + KC - 1) // KC
+    out = torch.empty(nc, 32 if M <= 32 else 64, n_cols, dtype=torch.float32, device=x.device)
+    L.check(L.load().sjd_skinny_gemm_cols(_ptr(x), _ptr(w_packed), _ptr(out), M, n_cols, K, KC, waves, int(step_major), _dtype_code(x.dtype),
+                                         N_packed, col0 // 32, _stream()), "sjd_skinny_gemm_cols")
+    return Partials(out, nc, n_cols)
+
+
+class HeadOut:
+    """What a backbone hands to K2 instead of logits: the lm_head split-K partials of the window (cond rows [0, n), uncond rows
+    [urow_off, urow_off + n)), their vocabulary column window and the folded final-norm row statistics."""
+
+    def __init__(self, part: Partials, col0, urow_off, dtype, row_norm=None):
+        self.part, self.col0, self.urow_off, self.dtype, self.row_norm = part, int(col0), int(urow_off), dtype, row_norm
+
+
+def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr, dbg=None):
+    """K2 reading the unmaterialised output head (see sjd_head_partials in include/sjd_hip.h).  dbg: optional fp32 [2, rows, V] that
+    receives the logits K2 derived (cond, uncond) -- observers only."""
+    max_rows, V = probs_out.shape
+    p = head.part
+    hp = L.HeadPartials()
+    hp.part, hp.n_chunks = p.data.data_ptr(), p.n_chunks
+    hp.row_stride, hp.chunk_stride = p.N, p.data.shape[1] * p.N
+    hp.col0, hp.n_cols, hp.urow_off = head.col0, p.N, head.urow_off
+    hp.round_dtype = _dtype_code(head.dtype)
+    if head.row_norm is not None:
+        sumsq, hidden, eps = head.row_norm
+        hp.row_sumsq, hp.slices, hp.prows, hp.inv_hidden, hp.eps = sumsq.data_ptr(), sumsq.shape[0], sumsq.shape[1], 1.0 / float(hidden), float(eps)
+    if dbg is not None:
+        assert dbg.dtype == torch.float32 and dbg.is_contiguous() and dbg.shape[0] == 2 and dbg.shape[2] == V and dbg.shape[1] >= max_rows
+        hp.dbg_c, hp.dbg_u = dbg[0].data_ptr(), dbg[1].data_ptr()
+    assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V and probs_out.is_contiguous()
+    L.check(L.load().sjd_logits_to_probs_sample_part(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out),
+                                                    tokens_out_ptr, _stream()), "sjd_logits_to_probs_sample_part")
+
+
 def _part_args(delta):
     if isinstance(delta, Partials):
         return None, _ptr(delta.data), delta.n_chunks
@@ -282,6 +322,28 @@ def qknorm_rope_append(qkv, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, 
                                               params.ptr if params is not None else None, int(kv_len), part, nc, _stream()),
             "sjd_qknorm_rope_append")
     return q
+
+
+def fused_attention_ok(B, n, H, H_kv, D, cache_dtype):
+    """shapes kernel K1F serves (everything else: F2 + K1 + combine)"""
+    return H == H_kv and D == 128 and n <= 16 and B * n <= 32 and cache_dtype in (torch.bfloat16, torch.float16)
+
+
+def qkv_attention_fused(qkv_part, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, D, params, kv_len, key_start,
+                        row_norm=None, dtype=None):
+    """K1F: G1 Partials of the q|k|v projection -> attention output [B, n, H, D]; the window's k / v rows are appended to
+    k_cache / v_cache [B, H, S, D] on the way (QK-norm + RoPE as in qknorm_rope_append)."""
+    assert isinstance(qkv_part, Partials) and qkv_part.N == 3 * H * D and qkv_part.data.shape[1] == 32
+    assert positions.is_contiguous() and positions.dtype == torch.int64 and inv_freq.dtype == torch.float32
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape[1] == H
+    assert key_start is None or (key_start.dtype == torch.int32 and key_start.is_cuda)
+    act = dtype or k_cache.dtype
+    out = torch.empty(B, n, H, D, dtype=act, device=k_cache.device)
+    L.check(L.load().sjd_qkv_attention_fused(_ptr(qkv_part.data), qkv_part.n_chunks, _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(qn_w),
+                                            _ptr(qn_b), _ptr(kn_w), _ptr(kn_b), _ptr(inv_freq), _ptr(positions), B, n, H, D, k_cache.shape[2],
+                                            _dtype_code(act), _row_norm(row_norm), _ptr(key_start), params.ptr if params is not None else None,
+                                            int(kv_len), _stream()), "sjd_qkv_attention_fused")
+    return out
 
 
 def silu_mul(gate_up, rows=None, dtype=None, row_norm=None):

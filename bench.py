@@ -110,55 +110,81 @@ def build_model(args, device):
 
 
 def measure_k1(args, model, attn, device, kv_len):
-    """K1 measured live with HIP events on the stream it runs on: k1_partial over the per-layer caches at KV length `kv_len` (same
-    B/H/D/window/n_split as the decode), cycling over all layers' caches like a real iteration (~40 MB/layer x 32 streams from HBM; a
-    single layer would sit in the 256 MB Infinity Cache)."""
+    """The attention kernel the engine runs, measured live with HIP events on the stream it runs on, at KV length `kv_len` (same
+    B/H/D/window as the decode), cycling over all layers' caches like a real iteration (~40 MB/layer x 32 streams from HBM; a single layer
+    would sit in the 256 MB Infinity Cache).  MHA 16-row window: K1F (QK-norm + RoPE + append + attention + merge, one launch, fed with
+    q|k|v split-K partials); otherwise k1_partial (the split combine is a separate launch and not included)."""
     import ctypes
     import torch
     import sjd_amd._lib as L
     import sjd_amd.ops as ops
     lib = L.load()
     B, n, H, D = 2, args.window, model.n_heads, model.head_dim
-    n_split = attn.n_split or 8
     nl = model.cache.k.shape[0]
     kc, vc = model.cache.k, model.cache.v
     kv_len = min(int(kv_len), model.cache.s_max - n)
-    q = torch.randn(B, n, H, D, device=device).to(kc.dtype if kc.dtype != ops.FP8 else model.lm_head.weight.dtype)
-    out = torch.empty_like(q)
+    adt = model.lm_head.weight.dtype
     ks = torch.tensor([0, 0], dtype=torch.int32, device=device) if model.n_kv_heads != model.n_heads else torch.tensor([0, 63], dtype=torch.int32, device=device)
+    esz, Hkv = kc.element_size(), kc.shape[2]
+    rows0, rows1 = kv_len + n, kv_len + n - int(ks[1])   # visible key rows of the cond / uncond batch row
+    kv_bytes = 2 * Hkv * (rows0 + rows1) * D * esz
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    import sjd_amd.backbones as BB_
+    if getattr(model, "k1_fused", BB_._K1_FUSED_DEFAULT) and getattr(model, "_gemm", None) == "sjd" and ops.fused_attention_ok(B, n, H, Hkv, D, kc.dtype):
+        n_chunks = (model.args.hidden_size + model.G1_CFG["qkv"][0] - 1) // model.G1_CFG["qkv"][0]
+        parts = [ops.Partials(torch.randn(n_chunks, 32, 3 * H * D, device=device), n_chunks, 3 * H * D) for _ in range(4)]
+        a0 = model.model.layers[0].self_attn
+        qn = (a0.q_norm.weight, a0.q_norm.bias, a0.k_norm.weight, a0.k_norm.bias) if model.args.qk_norm else (None,) * 4
+        pos = (kv_len + torch.arange(n, device=device)[None] - ks[:, None].long()).reshape(-1).contiguous()
+        sumsq = torch.full((model.args.hidden_size // 512, 32), 512.0, device=device)
+        rn = (sumsq, model.args.hidden_size, model.args.rms_norm_eps) if getattr(model, "_fold_norm", False) else None
+        run = lambda i: ops.qkv_attention_fused(parts[i % 4], kc[i % nl], vc[i % nl], *qn, model._inv_freq32, pos, B, n, H, D, None, kv_len, ks,
+                                                row_norm=rn, dtype=adt)
+        for i in range(nl):
+            run(i)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(args.k1_launches):
+            run(i)
+        e1.record()
+        torch.cuda.synchronize()
+        alg = kv_bytes + n_chunks * B * n * 3 * H * D * 4 + 2 * B * n * Hkv * D * esz + B * n * H * D * esz     # + partials in, K/V rows + out written
+        avg_ms = e0.elapsed_time(e1) / args.k1_launches
+        return dict(kernel="k1f_qkv_attention (QK-norm + RoPE + KV append + draft-window attention, one launch)", launches=args.k1_launches,
+                    avg_ms=avg_ms, avg_bytes=alg, avg_kv_rows=kv_len + n, gbps=alg / 1e9 / (avg_ms / 1e3))
+    n_split = attn.n_split or 8
+    q = torch.randn(B, n, H, D, device=device).to(adt)
+    out = torch.empty_like(q)
     ws = ops.attention_workspace(B, H, n, D, n_split, device)
     if kc.dtype == ops.FP8:        # fp8 cache: k1_partial_fp8 + k1_combine, back-to-back launches between one event pair
         sk, sv = attn.kv_scale
         for i in range(nl):
             ops.draft_window_attention_fp8(q, kc[i], vc[i], out, sk, sv, ks, None, kv_len, n_split, ws)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(args.k1_launches):
             ops.draft_window_attention_fp8(q, kc[i % nl], vc[i % nl], out, sk, sv, ks, None, kv_len, n_split, ws)
         e1.record()
         torch.cuda.synchronize()
-        rows0, rows1 = kv_len + n, kv_len + n - int(ks[1])
-        alg = 2 * kc.shape[2] * (rows0 + rows1) * D + B * n * H * D * 2
+        alg = kv_bytes + B * n * H * D * 2
         avg_ms = e0.elapsed_time(e1) / args.k1_launches
-        return dict(launches=args.k1_launches, avg_ms=avg_ms, avg_bytes=alg, avg_kv_rows=kv_len + n, gbps=alg / 1e9 / (avg_ms / 1e3))
+        return dict(kernel="k1_partial_fp8 + k1_combine", launches=args.k1_launches, avg_ms=avg_ms, avg_bytes=alg, avg_kv_rows=kv_len + n,
+                    gbps=alg / 1e9 / (avg_ms / 1e3))
     evs = [(ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())) for _ in range(args.k1_launches)]
     for i in range(nl):
         ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, kv_len, n_split, ws)
     torch.cuda.synchronize()
-    for i, (e0, e1) in enumerate(evs):
-        ops.draft_window_attention(q, kc[i % nl], vc[i % nl], out, ks, None, kv_len, n_split, ws, e0, e1)
+    for i, (ev0, ev1) in enumerate(evs):
+        ops.draft_window_attention(q, kc[i % nl], vc[i % nl], out, ks, None, kv_len, n_split, ws, ev0, ev1)
     torch.cuda.synchronize()
-    ms = [lib.sjd_event_elapsed_ms(e0, e1) for e0, e1 in evs]
-    for e0, e1 in evs:
-        lib.sjd_event_destroy(e0)
-        lib.sjd_event_destroy(e1)
-    esz = kc.element_size()
-    Hkv = kc.shape[2]
-    rows0, rows1 = kv_len + n, kv_len + n - int(ks[1])   # visible key rows of the cond / uncond batch row
-    alg = 2 * Hkv * (rows0 + rows1) * D * esz + B * n * H * D * esz     # K,V rows once per kv head + q
+    ms = [lib.sjd_event_elapsed_ms(ev0, ev1) for ev0, ev1 in evs]
+    for ev0, ev1 in evs:
+        lib.sjd_event_destroy(ev0)
+        lib.sjd_event_destroy(ev1)
+    alg = kv_bytes + B * n * H * D * esz     # K,V rows once per kv head + q
     avg_ms = sum(ms) / len(ms)
-    return dict(launches=len(ms), avg_ms=avg_ms, avg_bytes=alg, avg_kv_rows=kv_len + n, gbps=alg / 1e9 / (avg_ms / 1e3))
+    return dict(kernel="k1_partial (draft-window attention)", launches=len(ms), avg_ms=avg_ms, avg_bytes=alg, avg_kv_rows=kv_len + n,
+                gbps=alg / 1e9 / (avg_ms / 1e3))
 
 
 def measure_g1(args, model, device, rounds=2):
@@ -445,7 +471,7 @@ def main():
         for S in pts:
             if str(S) in out["per_kv"]:
                 k1 = measure_k1(args, model, attn, device, kv_len=S)
-                out["per_kv"][str(S)].update({"k1_partial_us": round(k1["avg_ms"] * 1e3, 2), "k1_GBps": round(k1["gbps"], 1)})
+                out["per_kv"][str(S)].update({"k1_us": round(k1["avg_ms"] * 1e3, 2), "k1_GBps": round(k1["gbps"], 1)})
 
     def traffic_of(fname):
         if args.model != "lumina7b":
@@ -461,7 +487,7 @@ def main():
     peak = 8000.0
     k1_block = None
     if prof is not None:
-        k1_block = {"kernel": "k1_partial (draft-window attention)", "bound": "hbm", "achieved": round(prof["gbps"], 1),
+        k1_block = {"kernel": prof.get("kernel", "k1_partial (draft-window attention)"), "bound": "hbm", "achieved": round(prof["gbps"], 1),
                     "peak": peak, "unit": "GB/s", "frac": round(prof["gbps"] / peak, 4), "traffic": traffic_of("k1_traffic.json"),
                     "avg_us": round(prof["avg_ms"] * 1e3, 2), "avg_bytes": int(prof["avg_bytes"]),
                     "avg_kv_rows": round(prof["avg_kv_rows"], 1), "launches": prof["launches"]}

@@ -105,6 +105,31 @@ int sjd_logits_to_probs_sample(const float *logits_c, const float *logits_u, int
                                int max_rows, int V, const sjd_iter_params *params, const float *noise,
                                float *probs_out, int64_t *tokens_out, void *stream);
 
+/* K2 on an UNMATERIALISED output head: the logits of window row r are
+ *     z[r, col] = dtype( row_scale[r] * sum_c part[c][r][col - col0] ),   col in [col0, col0 + n_cols),
+ * i.e. the fp32 split-K partials of the lm_head projection (sjd_skinny_gemm_cols over the packed head, only the vocabulary columns the
+ * rules allow), the folded final-RMSNorm row scale (row_sumsq from sjd_residual_sumsq; NULL = none) and the rounding nn.Linear applies
+ * (reference modeling_chameleon.py:1560-1561 computes 16-bit logits, then .float()).  Cond rows are part rows [0, max_rows), uncond
+ * rows [urow_off, urow_off + max_rows) (urow_off <= 0: never CFG).  Everything after the load -- CFG combine, grammar, top-k / top-p,
+ * softmax, draw -- is sjd_logits_to_probs_sample's code, so results are bit-identical to feeding it those logits.
+ * dbg_c / dbg_u (optional, [max_rows, V] fp32): receive the derived logits of the columns inside each row's rule window (tests). */
+typedef struct sjd_head_partials {
+    const float *part;              /* [n_chunks][prows][n_cols] fp32 */
+    int32_t n_chunks;
+    int64_t chunk_stride;           /* elements between chunks (= prows * row_stride) */
+    int64_t row_stride;             /* elements between rows (>= n_cols) */
+    int32_t col0, n_cols;           /* vocabulary columns covered by `part` */
+    int32_t urow_off;               /* part row of uncond row 0 */
+    int32_t round_dtype;            /* SJD_DTYPE_BF16 / SJD_DTYPE_F16: round like the 16-bit lm_head output; SJD_DTYPE_F32: none */
+    const float *row_sumsq;         /* [slices][prows] per-slice sums of h^2 (folded final norm) or NULL */
+    int32_t slices, prows;
+    float inv_hidden, eps;
+    float *dbg_c, *dbg_u;
+} sjd_head_partials;
+int sjd_logits_to_probs_sample_part(const sjd_head_partials *head /* host struct, passed by value to the kernel */, float guidance,
+                                    int max_rows, int V, const sjd_iter_params *params, const float *noise, float *probs_out,
+                                    int64_t *tokens_out, void *stream);
+
 /* K4 -- probabilistic verify-and-accept (longest accepted prefix) + residual resample of the first reject.
  * replaces SpeculativeSampler.__call__ / find_first_misaligned_token_inds / prefix_matching_next_tokens
  * (reference jacobi_iteration_lumina_mgpt.py:203-376).
@@ -139,6 +164,19 @@ int sjd_draft_window_attention_ex(const void *q, const void *k_cache, const void
                                   int H, int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
                                   const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream,
                                   void *ev_start, void *ev_stop);
+
+/* K1F -- F2 + K1 + the split combine in ONE launch, for the multi-head-attention draft window (H == H_kv, n_rows <= 16,
+ * B * n_rows <= 32, D == 128, 16-bit cache): per (batch, head) one 512-thread workgroup sums the fp32 split-K partials `part`
+ * [n_chunks, 32, 3 * H * D] of the q|k|v projection (G1), applies the folded-RMSNorm row scale (`row_norm`, may be NULL), the per-head
+ * LayerNorm (qn_w/qn_b, kn_w/kn_b: NULL = none) and RoPE with the arithmetic of sjd_qknorm_rope_append, appends the k / v rows at cache
+ * rows [kv_len, kv_len + n_rows), attends over [key_start[b], kv_len + i] and writes out [B, n_rows, H, D].  No workspace.
+ * replaces, like F2 + K1: ChameleonLayerNorm, apply_rotary_pos_emb, DynamicCache.update, _update_causal_mask and
+ * scaled_dot_product_attention (reference modeling_chameleon.py:198-219, 144-178, 547, 549-576; jacobi_iteration_lumina_mgpt.py:1256-1336). */
+typedef struct sjd_row_norm sjd_row_norm;
+int sjd_qkv_attention_fused(const float *part, int n_chunks, void *k_cache, void *v_cache, void *out, const void *qn_w, const void *qn_b,
+                            const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n_rows, int H,
+                            int D, int S_max, int dtype, const sjd_row_norm *row_norm, const int32_t *key_start,
+                            const sjd_iter_params *params, int kv_len, void *stream);
 
 /* F1-F3 -- fused element-wise glue of the draft-window forward (the "next" row of SURVEY.md 8f.1).
  * F1: h += delta (delta may be NULL; or delta = dtype(sum of the fp32 split-K partials `part`)); y = weight * dtype(h * rsqrt(mean(h^2) + eps)).  replaces ChameleonRMSNorm +
@@ -188,6 +226,10 @@ int sjd_silu_mul_ex(const void *gate_up, void *y, int rows, int inter, int dtype
  * waves (1..16) = column tiles per workgroup sharing one staged activation chunk; step_major selects the packed record
  * order (0: one contiguous run per tile, 1: the records of all tiles interleaved per k-step). */
 int sjd_gemm_num_chunks(int K, int KC);
+/* the same over the N = 32 n columns [32 * tile0, 32 * tile0 + N) of a weight packed with N_packed columns (the output head evaluated on
+ * the grammar's column window out of ONE packed copy of lm_head): out [n_chunks, R, N] */
+int sjd_skinny_gemm_cols(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,
+                         int dtype, int N_packed, int tile0, void *stream);
 int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,
                     int dtype, void *stream);
 

@@ -348,7 +348,7 @@ def teacher_forced_anole_api_check(device="cuda:0", img_len=36, window=16, seed=
     max_len = P + img_len + 2
     cfg = OL.LoopConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=img_len - window - 2, max_num_new_tokens=window, guidance_scale=3.0,
                         seed=seed, do_cfg=True, prefix_token_sampler_scheme="speculative_jacobi", max_length=max_len, eos_token_ids=())
-    seq_ref, tr, checks = _replay(rec, ids[0].tolist(), lambda c, n: O.anole_rules(c, n, V, P, max_len, img_len), cfg, V, device=device)
+    seq_ref, tr, checks = _replay(rec, ids[0].tolist(), lambda c, n: O.anole_rules(c, n, V, P, max_len, img_len, top_k=0), cfg, V, device=device)   # no TopK warper in JA:183-232
     assert seq == seq_ref, "token sequences differ"
     assert model.last_sjd_stats.matched == tr.matched
     gen = seq[P:]

@@ -411,3 +411,169 @@ def test_k1_k3_fp8_kv_cache(dev, case, n_split):
                 err = (got[b, i, h] - want).abs()
                 assert err.max() < 1.0 * sv * conc + 1e-2 and err.mean() < 0.25 * sv * conc + 2e-3, \
                     f"{name} b{b} row{i} head{h}: vs exact max {err.max():.4f} mean {err.mean():.5f} conc {conc:.3f}"
+
+
+K1F_CASES = [
+    # kv_len, key_start, valid rows (None: all 16, host kv_len; int: through a device params blob), S_max
+    (0, (0, 0), None, 128), (5, (0, 3), None, 128), (37, (0, 36), 9, 128), (64, (0, 63), None, 160), (100, (0, 63), None, 192),
+    (448, (0, 17), 16, 512), (1216, (0, 63), None, 1280), (2368, (0, 63), 5, 2432), (31, (0, 0), 1, 128),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("qk_norm,fold", [(True, True), (False, False), (True, False)])
+@pytest.mark.parametrize("kv_len,key_start,n_valid,S_max", K1F_CASES)
+def test_k1f_fused_attention_matches_f2_then_k1(dev, dtype, qk_norm, fold, kv_len, key_start, n_valid, S_max):
+    """K1F (F2 + K1 + combine in one launch) against the three-launch path on the same G1 partials: identical K/V cache rows (same
+    arithmetic and rounding points as F2), attention output within the K1 tolerance of an fp32 softmax over the appended cache."""
+    ops, L = _ops()
+    B, n, H, D, hid = 2, 16, 6, 128, 512
+    g = torch.Generator().manual_seed(kv_len + 7 * H)
+    x = torch.randn(B * n, hid, generator=g).to(dtype).to(dev)
+    w = (torch.randn(3 * H * D, hid, generator=g) / hid ** 0.5 * 2.0).to(dtype).to(dev)
+    part = ops.skinny_gemm(x, ops.pack_weight(w, 128), 3 * H * D, hid, 128)
+    assert part.n_chunks == 4
+    rn = (ops.residual_sumsq(x.clone(), None), hid, 1e-5) if fold else None
+    mk = lambda a, b_: (a + b_ * torch.randn(1, D, generator=g)).to(dtype).to(dev)
+    qn = (mk(1.0, 0.2), mk(0.0, 0.1), mk(1.0, 0.2), mk(0.0, 0.1)) if qk_norm else (None,) * 4
+    inv = (1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))).to(dev)
+    ks = torch.tensor(key_start, dtype=torch.int32, device=dev)
+    pos = (kv_len + torch.arange(n)[None] - torch.tensor(key_start)[:, None]).reshape(-1).to(dev)
+    base_k = torch.randn(1, B, H, S_max, D, generator=g).to(dtype).to(dev)
+    base_v = torch.randn(1, B, H, S_max, D, generator=g).to(dtype).to(dev)
+    params = None
+    if n_valid is not None:
+        params = ops.DeviceBlob(L.IterParams, dev)
+        params.view.n_rows, params.view.kv_len = n_valid, kv_len
+        params.upload()
+    nv = n if n_valid is None else n_valid
+    c1, c2 = _Cache(base_k.clone(), base_v.clone()), _Cache(base_k.clone(), base_v.clone())
+    q = ops.qknorm_rope_append(part, c1.k[0], c1.v[0], *qn, inv, pos, B, n, H, H, D, params, 0 if params else kv_len, dtype=dtype, row_norm=rn)
+    attn = ops.HipWindowAttention(n_split=4)
+    attn.params = params
+    ref3 = attn.attend(0, q, c1, kv_len, ks)
+    out = ops.qkv_attention_fused(part, c2.k[0], c2.v[0], *qn, inv, pos, B, n, H, D, params, 0 if params else kv_len, ks, row_norm=rn, dtype=dtype)
+    torch.cuda.synchronize()
+    assert torch.equal(c1.k, c2.k) and torch.equal(c1.v, c2.v)                      # appended rows bit-identical, nothing else touched
+    assert not torch.equal(c2.k[0, :, :, kv_len:kv_len + n], base_k[0, :, :, kv_len:kv_len + n])
+    # fp32 softmax over the appended cache with the 16-bit q of F2
+    K, V = c1.k[0].float(), c1.v[0].float()
+    S = torch.einsum("bihd,bhjd->bhij", q.float(), K) / D ** 0.5
+    j = torch.arange(S_max, device=dev)[None, None, None, :]
+    i = torch.arange(n, device=dev)[None, None, :, None]
+    vis = (j >= ks.view(B, 1, 1, 1)) & (j <= kv_len + i) & (j < kv_len + nv)
+    P = torch.softmax(S.masked_fill(~vis, float("-inf")), dim=-1)
+    ref = torch.einsum("bhij,bhjd->bihd", torch.nan_to_num(P), V)
+    got = out.float()
+    assert torch.isfinite(got).all()
+    live = torch.zeros(B, n, dtype=torch.bool, device=dev)
+    live[:, :nv] = True
+    for b in range(B):
+        live[b] &= (kv_len + torch.arange(n, device=dev)) >= int(ks[b])
+    err = (got - ref).abs()[live]
+    assert err.max() < 3e-2 and err.mean() < 3e-3, (float(err.max()), float(err.mean()))
+    assert (got[:, nv:] == 0).all()                                                 # padding rows of a shape-static window
+    d3 = (got - ref3.float()).abs()[live]
+    assert d3.max() < 4e-2 and d3.mean() < 2e-3, (float(d3.max()), float(d3.mean()))
+
+
+def test_backbone_window_forward_fused_attention_equals_unfused(dev):
+    """the G1 window forward with K1F against the same forward with F2 + K1 + combine (model.k1_fused = False): same cache, close logits"""
+    ops, L = _ops()
+    from tests.helpers import make_chameleon
+    conf = dict(vocab_size=9216, hidden_size=1024, intermediate_size=1024, num_hidden_layers=3, num_attention_heads=8,
+                num_key_value_heads=8, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    outs, caches = [], []
+    for fused in (False, True):
+        m = make_chameleon(conf, 23, 0.5, ops.HipWindowAttention(n_split=2), dtype=torch.bfloat16, device=dev)
+        m.G1_CFG = dict(qkv=(256, 8, True), o=(256, 8, False), gate_up=(512, 8, True), down=(256, 8, False))
+        m.enable_fused(ops, gemm="sjd")
+        m.k1_fused = fused
+        m.setup_cache(batch=2, s_max=128)
+        toks = torch.randint(4, 9000, (2, 40), generator=torch.Generator().manual_seed(1)).to(dev)
+        ks = torch.tensor([0, 7], dtype=torch.int32, device=dev)
+        m.forward_window(toks, torch.arange(40)[None].repeat(2, 1).to(dev), 0, ks)
+        toks2 = torch.randint(4, 9000, (2, 16), generator=torch.Generator().manual_seed(2)).to(dev)
+        outs.append(m.forward_window(toks2, (40 + torch.arange(16))[None].repeat(2, 1).to(dev), 40, ks))
+        caches.append((m.cache.k.clone(), m.cache.v.clone()))
+    assert torch.equal(caches[0][0][0], caches[1][0][0]) and torch.equal(caches[0][1][0], caches[1][1][0])     # layer 0: identical inputs
+    assert (outs[0] - outs[1]).abs().mean() < 0.03 and (outs[0] - outs[1]).abs().max() < 0.5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N_packed,col0,n_cols,K,KC", [(9216, 0, 8224, 512, 128), (12320, 3008, 8224, 1024, 512), (65536, 0, 8224, 4096, 512),
+                                                      (2048, 1024, 1024, 256, 256)])
+def test_g1_column_window_of_a_packed_weight(dev, dtype, N_packed, col0, n_cols, K, KC):
+    """sjd_skinny_gemm_cols: the launch over a tile window of ONE packed weight equals the same columns of the full launch, bit for bit"""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(N_packed + col0)
+    x = torch.randn(32, K, generator=g).to(dtype).to(dev)
+    w = (torch.randn(N_packed, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    for sm in (True, False):
+        wp = ops.pack_weight(w, KC, sm)
+        full = ops.skinny_gemm(x, wp, N_packed, K, KC, waves=8, step_major=sm)
+        win = ops.skinny_gemm_cols(x, wp, N_packed, K, KC, col0, n_cols, waves=8, step_major=sm)
+        assert win.n_chunks == full.n_chunks and win.data.shape == (full.n_chunks, 32, n_cols)
+        assert torch.equal(win.data, full.data[:, :, col0:col0 + n_cols])
+
+
+@pytest.mark.parametrize("dtype,fold", [(torch.bfloat16, True), (torch.float16, True), (torch.bfloat16, False)])
+@pytest.mark.parametrize("name,V,n,builder,cols", [
+    ("lumina_image_window", 65536, 16, lambda O: O.lumina_rules([9000] * 61 + [8197, 8828, 8828] + [100] * 40, 16, 2000, 10), (0, 8224)),
+    ("emu3_visual_window_odd_vocab", 184622, 8, lambda O: O.emu3_rules([1000] * 20 + [151851] + [151860] * 7, 8, 90, 90, 151854, 32768, top_k=2048,
+                                                                         img_token=151851, eoi_token=151853, eos_token=151850, eol_token=151846,
+                                                                         eof_token=151847, pad_token=151643), (151840, 184640)),
+    ("text_rows_full_vocab", 9216, 4, lambda O: O.lumina_rules([9000] * 12, 4, 2000, 10), (0, 9216)),
+])
+def test_k2_on_the_unmaterialised_output_head(dev, dtype, fold, name, V, n, builder, cols):
+    """K2 reading the lm_head split-K partials (chunk sum, folded-norm row scale, 16-bit rounding inside the kernel) gives
+    bit-identical probabilities and tokens to the dense-logits K2 fed with the logits it derived, and those logits equal the
+    torch restatement dtype(r * sum_c part_c) (within one 16-bit rounding where rsqrt differs in the last bit)."""
+    ops, L = _ops()
+    from oracle import sjd_oracle as O
+    rules = builder(O)
+    g = torch.Generator().manual_seed(V + n)
+    Lmax, n_chunks, hidden = 16, 4, 2048
+    n_cols = cols[1] - cols[0]
+    part = ops.Partials((torch.randn(n_chunks, 32, n_cols, generator=g) * 1.5).to(dev), n_chunks, n_cols)
+    sumsq = (hidden / 4 * (0.5 + torch.rand(4, 32, generator=g))).to(dev)
+    head = ops.HeadOut(part, cols[0], Lmax, dtype, row_norm=(sumsq, hidden, 1e-5) if fold else None)
+    params = ops.DeviceBlob(L.IterParams, dev)
+    params.view.n_rows, params.view.use_cfg = n, 1
+    for j, r in enumerate(rules):
+        params.view.rules[j] = to_dev_rule(L, ops, r)
+    params.upload()
+    noise = torch.empty(Lmax, V).exponential_(generator=g).to(dev)
+    probs_a, probs_b = torch.zeros(Lmax, V, device=dev), torch.zeros(Lmax, V, device=dev)
+    toks_a, toks_b = torch.zeros(Lmax, dtype=torch.int64, device=dev), torch.zeros(Lmax, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(2, Lmax, V, device=dev)
+    ops.logits_to_probs_sample_part(head, 3.0, params, noise, probs_a, ctypes_ptr(toks_a), dbg=dbg)
+    # the same K2 on materialised logits = what the partial path derived
+    ops.logits_to_probs_sample(dbg[0], dbg[1], 3.0, params, noise, probs_b, ctypes_ptr(toks_b))
+    torch.cuda.synchronize()
+    assert torch.equal(toks_a[:n], toks_b[:n])
+    assert torch.equal(probs_a[:n].view(torch.int32), probs_b[:n].view(torch.int32))
+    # torch restatement of the derived logits
+    s = part.data[0].clone()
+    for c in range(1, n_chunks):
+        s = s + part.data[c]
+    if fold:
+        s = s * torch.rsqrt(sumsq.sum(0) / hidden + 1e-5)[:, None]
+    ref = s.to(dtype).float()
+    for b in range(2):
+        for row in range(n):
+            r = rules[row]
+            if r.forced >= 0:
+                continue
+            lo = min(r.lo[i] for i in range(r.n_ranges)) if r.n_ranges else 0
+            hi = max(r.hi[i] for i in range(r.n_ranges)) if r.n_ranges else V
+            got = dbg[b, row, lo:hi]
+            want = ref[b * Lmax + row, lo - cols[0]:hi - cols[0]]
+            ulp = want.abs() * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) + 1e-6
+            assert ((got - want).abs() <= ulp).all(), (name, b, row)
+            assert (got == want).float().mean() > 0.99
+
+
+def ctypes_ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())

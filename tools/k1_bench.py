@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--prompt", type=int, default=64)
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) KV cache + the fp8-MFMA K1 variant (BASELINE config 5)")
     ap.add_argument("--graph", action="store_true", help="time k1_partial + k1_combine per layer inside one hipGraph replay")
+    ap.add_argument("--block", choices=["fused", "unfused"], default=None,
+                    help="time the whole attention block of a layer on q|k|v split-K partials inside a hipGraph: fused = kernel K1F (one "
+                         "launch), unfused = F2 + k1_partial + k1_combine (three launches)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = L.load()
@@ -42,6 +45,51 @@ def main():
     ws = ops.attention_workspace(B, H, n, D, a.n_split, dev)
     if a.fp8:
         kc, vc = kc.to(ops.FP8), vc.to(ops.FP8)
+    if a.block:
+        n_chunks = 4
+        parts = [ops.Partials(torch.randn(n_chunks, 32, (H + 2 * Hkv) * D, device=dev), n_chunks, (H + 2 * Hkv) * D) for _ in range(4)]
+        mk = lambda m_, s_: (m_ + s_ * torch.randn(1, D, device=dev)).to(torch.bfloat16)
+        qn = (mk(1, .1), mk(0, .1), mk(1, .1), mk(0, .1))
+        inv = (1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))).to(dev)
+        pos = (a.kv_len + torch.arange(n, device=dev)[None] - ks[:, None].long()).reshape(-1).contiguous()
+        rn = (torch.full((8, 32), 512.0, device=dev), 4096, 1e-5)
+        attn = ops.HipWindowAttention(n_split=a.n_split)
+
+        class C:
+            pass
+        cache = C()
+        cache.k, cache.v = kc, vc
+
+        def one(i):
+            if a.block == "fused":
+                ops.qkv_attention_fused(parts[i % 4], kc[i], vc[i], *qn, inv, pos, B, n, H, D, None, a.kv_len, ks, row_norm=rn, dtype=torch.bfloat16)
+            else:
+                q_ = ops.qknorm_rope_append(parts[i % 4], kc[i], vc[i], *qn, inv, pos, B, n, H, Hkv, D, None, a.kv_len, dtype=torch.bfloat16, row_norm=rn)
+                attn.attend(i, q_, cache, a.kv_len, ks)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            one(0)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(a.layers):
+                one(i)
+        g.replay()
+        torch.cuda.synchronize()
+        reps = max(1, a.launches // a.layers)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        avg = e0.elapsed_time(e1) / (reps * a.layers)
+        rows0, rows1 = a.kv_len + n, a.kv_len + n - (a.prompt - 1)
+        alg = 2 * Hkv * (rows0 + rows1) * D * 2 + n_chunks * B * n * (H + 2 * Hkv) * D * 4 + 2 * B * n * Hkv * D * 2 + B * n * H * D * 2
+        print(json.dumps(dict(kernel=f"attention block, {a.block} (hipGraph replay)", kv_len=a.kv_len, window=n, n_split=a.n_split,
+                              launches=reps * a.layers, avg_us=round(avg * 1e3, 2), algorithmic_bytes=alg,
+                              gbps=round(alg / 1e9 / (avg / 1e3), 1), frac_of_8TBps=round(alg / 1e9 / (avg / 1e3) / 8000, 4))))
+        return
     if a.fp8 or a.graph:
         def one(i):
             if a.fp8:

@@ -29,7 +29,7 @@ class IterParams(ctypes.Structure):
 class State(ctypes.Structure):
     _fields_ = [("m", ctypes.c_int32), ("rejected", ctypes.c_int32), ("n_prev", ctypes.c_int32),
                 ("prob_buf", ctypes.c_int32), ("tokens", ctypes.c_int64 * MAX_WINDOW),
-                ("win_tok", ctypes.c_int64 * MAX_WINDOW), ("q_src", ctypes.c_int32 * MAX_WINDOW)]
+                ("win_tok", ctypes.c_int64 * MAX_WINDOW), ("q_src", ctypes.c_int32 * MAX_WINDOW), ("amax", ctypes.c_int64 * MAX_WINDOW)]
 
 
 class RowNorm(ctypes.Structure):
@@ -51,7 +51,7 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_add_rmsnorm", "sjd_qknorm_rope_append", "sjd_silu_mul", "sjd_gemm_num_chunks", "sjd_skinny_gemm",
            "sjd_kv_append_fp8", "sjd_draft_window_attention_fp8", "sjd_qknorm_rope_append_fp8",
            "sjd_residual_sumsq", "sjd_qknorm_rope_append_ex", "sjd_silu_mul_ex", "sjd_weight_prefetch", "sjd_qkv_attention_fused", "sjd_skinny_gemm_cols",
-           "sjd_logits_to_probs_sample_part"]
+           "sjd_logits_to_probs_sample_part", "sjd_logits_to_probs_sample_ex"]
 
 _lib = None
 
@@ -94,7 +94,8 @@ def load():
     lib.sjd_draft_window_attention_fp8.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp, vp]
     lib.sjd_weight_prefetch.argtypes = [vp, i64, i32, vp, vp]
     lib.sjd_skinny_gemm_cols.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
-    lib.sjd_logits_to_probs_sample_part.argtypes = [ctypes.POINTER(HeadPartials), f32, i32, i32, vp, vp, vp, vp, vp]
+    lib.sjd_logits_to_probs_sample_part.argtypes = [ctypes.POINTER(HeadPartials), f32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.sjd_logits_to_probs_sample_ex.argtypes = [vp, vp, i64, f32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.sjd_qkv_attention_fused.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),
                                             vp, vp, i32, vp]
     lib.sjd_event_create.restype = vp

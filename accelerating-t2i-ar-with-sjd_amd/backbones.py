@@ -30,7 +30,11 @@ import torch.nn.functional as F
 
 import os as _os
 
-_K1_FUSED_DEFAULT = _os.environ.get("SJD_K1_FUSED", "1") != "0"       # measurement switch: 0 = F2 + K1 + combine (three launches)
+# K1F (F2 + K1 + combine in one launch, 64 workgroups) is correct and tested but NOT faster on MI355X: a CU streams ~30 GB/s at most, so
+# 64 workgroups cap at ~1.9 TB/s where the 256-workgroup split kernel reaches 2.8 TB/s, and the dependent round trips (partials -> q/K/V
+# -> tiles -> merge) remain inside the fused kernel (profiles/r2_attention_block.jsonl: 17.3 / 23.2 / 32.5 / 47.6 us against 17.7 / 21.6 /
+# 27.0 / 33.7 us at kv_len 64 / 448 / 1216 / 2368).  Default off; SJD_K1_FUSED=1 or model.k1_fused = True selects it.
+_K1_FUSED_DEFAULT = _os.environ.get("SJD_K1_FUSED", "0") == "1"
 
 
 def _head_logits(linear, x, cols):

@@ -67,7 +67,7 @@ template <bool PART>
 __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const float *__restrict__ logits_c, const float *__restrict__ logits_u, long row_stride, float guidance, int V,
     const sjd_iter_params *__restrict__ params, const float *__restrict__ noise, float *__restrict__ probs_out,
-    int64_t *__restrict__ tokens_out, const sjd_head_partials hp)
+    int64_t *__restrict__ tokens_out, const sjd_head_partials hp, int64_t *__restrict__ amax_out)
 {
     __shared__ SjdShared sh;
     const int row = blockIdx.x;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
         SJD_FOR_OWNED_COLS(V, c0)
             for (int j = 0; j < 4; ++j)
                 if (c0 + j < V) p[c0 + j] = (c0 + j == rule.forced) ? 1.0f : 0.0f;
-        if (threadIdx.x == 0) tokens_out[row] = rule.forced;
+        if (threadIdx.x == 0) { tokens_out[row] = rule.forced; if (amax_out) amax_out[row] = rule.forced; }
         return;
     }
 
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     if (rule.top_p_thr >= 0.0f) S = block_top_p_apply(p, wlo, whi, S, rule.top_p_thr, sh);     // TopPLogitsWarper3d (LP:406-419)
 
     // pass B: p = e / S ; multinomial == lowest-index argmax of p / Exp(1)   (JL:111-118)
-    unsigned long long best = 0ull;
+    unsigned long long best = 0ull, best_p = 0ull;
     SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -198,11 +198,17 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
                 float r = pv / e[col];
                 unsigned long long cand = pack_vi(r, col);
                 best = cand > best ? cand : best;
+                cand = pack_vi(pv, col);
+                best_p = cand > best_p ? cand : best_p;
             }
         }
     }
     const int tok = block_argmax(best, sh);
     if (threadIdx.x == 0) tokens_out[row] = tok;
+    if (amax_out) {                                  // by-product: the row's mode (lowest index among equal maxima)
+        const int am = block_argmax(best_p, sh);
+        if (threadIdx.x == 0) amax_out[row] = am;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K4
@@ -355,27 +361,38 @@ extern "C" int sjd_reguess(const sjd_iter_params *params, sjd_state *state, int6
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
+extern "C" int sjd_logits_to_probs_sample_ex(const float *logits_c, const float *logits_u, int64_t row_stride, float guidance,
+                                             int max_rows, int V, const sjd_iter_params *params, const float *noise,
+                                             float *probs_out, int64_t *tokens_out, int64_t *amax_out, void *stream);
+
 extern "C" int sjd_logits_to_probs_sample(const float *logits_c, const float *logits_u, int64_t row_stride, float guidance,
                                           int max_rows, int V, const sjd_iter_params *params, const float *noise,
                                           float *probs_out, int64_t *tokens_out, void *stream)
+{
+    return sjd_logits_to_probs_sample_ex(logits_c, logits_u, row_stride, guidance, max_rows, V, params, noise, probs_out, tokens_out, nullptr, stream);
+}
+
+extern "C" int sjd_logits_to_probs_sample_ex(const float *logits_c, const float *logits_u, int64_t row_stride, float guidance,
+                                             int max_rows, int V, const sjd_iter_params *params, const float *noise,
+                                             float *probs_out, int64_t *tokens_out, int64_t *amax_out, void *stream)
 {
     if (!logits_c || !params || !noise || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
         return SJD_ERR_BAD_ARG;
     sjd_head_partials none = {};
     hipLaunchKernelGGL(k2_logits_to_probs_sample<false>, dim3(max_rows), dim3(SJD_TPB), 0, (hipStream_t)stream, logits_c, logits_u,
-                       (long)row_stride, guidance, V, params, noise, probs_out, tokens_out, none);
+                       (long)row_stride, guidance, V, params, noise, probs_out, tokens_out, none, amax_out);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
 extern "C" int sjd_logits_to_probs_sample_part(const sjd_head_partials *head, float guidance, int max_rows, int V,
                                                const sjd_iter_params *params, const float *noise, float *probs_out, int64_t *tokens_out,
-                                               void *stream)
+                                               int64_t *amax_out, void *stream)
 {
     if (!head || !head->part || head->n_chunks < 1 || head->n_cols < 1 || head->col0 < 0 || head->row_stride < head->n_cols) return SJD_ERR_BAD_ARG;
     if (!params || !noise || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1) return SJD_ERR_BAD_ARG;
     if (head->row_sumsq && (head->slices < 1 || head->prows < 1)) return SJD_ERR_BAD_ARG;
     hipLaunchKernelGGL(k2_logits_to_probs_sample<true>, dim3(max_rows), dim3(SJD_TPB), 0, (hipStream_t)stream, (const float *)nullptr,
-                       (const float *)nullptr, (long)0, guidance, V, params, noise, probs_out, tokens_out, *head);
+                       (const float *)nullptr, (long)0, guidance, V, params, noise, probs_out, tokens_out, *head, amax_out);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 

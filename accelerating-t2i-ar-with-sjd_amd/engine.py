@@ -33,6 +33,7 @@ import torch
 
 from . import _lib as L
 from . import ops
+from .grammar import spatial_fresh_tokens
 
 
 @dataclass
@@ -105,6 +106,7 @@ class SJDEngine:
         self.input_ids = torch.zeros(self.B, self.Lmax, dtype=torch.int64, device=dev)
         self.arange = torch.arange(self.Lmax, device=dev)
         self.tokens_ptr = self.state.field_ptr("tokens")
+        self.amax_ptr = self.state.field_ptr("amax")
         self.key_start = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.pos_offset = torch.zeros(self.B, dtype=torch.int64, device=dev)
         off = L.IterParams.kv_len.offset
@@ -177,11 +179,12 @@ class SJDEngine:
                     self._dbg = torch.zeros(2, self.Lmax, self.V, dtype=torch.float32, device=self.device)
                 dbg = self._dbg
                 dbg.zero_()
-            ops.logits_to_probs_sample_part(logits, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr, dbg=dbg)
+            ops.logits_to_probs_sample_part(logits, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr, dbg=dbg,
+                                            amax_out_ptr=self.amax_ptr)
         else:
             lu = logits[1] if self.B > 1 else None
             ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr,
-                                       col0=cols[0] if cols else 0)
+                                       col0=cols[0] if cols else 0, amax_out_ptr=self.amax_ptr)
         ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0], self.scratch)
 
     def logit_columns(self, rules):
@@ -255,9 +258,9 @@ class SJDEngine:
         decode stops after it unless continue_after (then it runs on to EOS / max_length and stats.{nfe, total_tokens,
         total_seconds} describe the whole decode).  iter_log: list receiving (kv_len before the iteration, rows, accepted,
         host clock after the iteration's sync) per iteration."""
-        if cfg.multi_token_init_scheme != "random":
-            # the released reference raises IndexError for the horizon schemes (SURVEY.md 8a defect ledger)
-            raise NotImplementedError("only multi_token_init_scheme='random' is parity-checkable")
+        if cfg.multi_token_init_scheme not in ("random", "repeat_horizon", "sample_horizon"):
+            # JL:554-560, 592: anything else (incl. the 'vertical' variants) asserts in the reference
+            raise ValueError(f"multi_token_init_scheme should be 'random', 'repeat_horizon' or 'sample_horizon', but got {cfg.multi_token_init_scheme}")
         if cfg.prefix_token_sampler_scheme not in ("speculative_jacobi", "jacobi"):
             raise ValueError(f"prefix_token_sampler_scheme: {cfg.prefix_token_sampler_scheme}")   # JL:1048
         if cfg.max_num_new_tokens > self.Lmax:
@@ -283,6 +286,8 @@ class SJDEngine:
         stats = DecodeStats()
         n, kv_len, first, cur_len, cur, n_prev, m_prev = 1, spec.kv_base, True, P, 0, 1, 1
         carried: List[int] = []
+        carried_amax: List[int] = []
+        last_amax = None
         t0 = time.perf_counter()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -313,6 +318,9 @@ class SJDEngine:
                 a = max(0, min(n_prev - m_prev, n - 1))                              # JL:633-639, 657-662
                 fr = torch.randint(0, cfg.img_vocab_n, (1, n - 1 - a))[0].tolist()   # GLOBAL CPU generator (JL:505)
                 fresh = [cfg.img_vocab_lo + t for t in fr]                           # img_vocab[rand] (JL:509)
+                if cfg.multi_token_init_scheme != "random":                          # spatial init (JL:516-594): copy / re-draw from the left
+                    fresh = spatial_fresh_tokens(cfg.multi_token_init_scheme, fresh, len(X) + a, carried[a - 1] if a else X[-1],
+                                                 carried_amax[a - 1] if a else last_amax, grammar.grid())
                 rules = grammar.window_rules(n_rows)
                 resid = []                     # computed below, while the forward runs (K4 is their only reader)
             use_cfg = do_cfg and not grammar.force_no_cfg()                          # JL:1086-1096
@@ -360,7 +368,8 @@ class SJDEngine:
                 lu = logits[1, -1:, :] if B > 1 else None
                 win_len = tokens.shape[1]
                 torch.cuda.current_stream().wait_event(noise_ready)
-                ops.logits_to_probs_sample(lc, lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr)
+                ops.logits_to_probs_sample(lc, lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr,
+                                           amax_out_ptr=self.amax_ptr)
                 ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0],
                                   self.scratch)
                 if attn is not None and hasattr(attn, "params"):
@@ -392,12 +401,13 @@ class SJDEngine:
             if g_state is not None and not rejected:
                 gen.set_state(g_state)
             Y = [int(st.tokens[i]) for i in range(n_rows)]
+            A = [int(st.amax[i]) for i in range(n_rows)]       # modes of this iteration's target rows (K2 by-product)
             if n_rows <= 1:
                 m = win_len                      # is_prefilling_phase short-circuit (JL:344-350)
-                emitted, carried = [Y[0]], []
+                emitted, carried, carried_amax, last_amax = [Y[0]], [], [], A[0]
             else:
                 m = m_dev
-                emitted, carried = Y[:m], Y[m:]
+                emitted, carried, carried_amax, last_amax = Y[:m], Y[m:], A[m:], A[m - 1]
             stats.matched.append(m)
             if iter_log is not None:
                 iter_log.append((kv_len, n_rows, m, time.perf_counter()))

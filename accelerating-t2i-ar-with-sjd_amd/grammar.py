@@ -50,6 +50,37 @@ class _Grammar:
     def force_no_cfg(self):
         return False
 
+    def grid(self):
+        """(absolute index of the image's first token, tokens per image row excluding the line token, image-id range lo, hi) while an
+        image with line tokens is open, else None.  Drives the spatial draft initialisation (multi_token_init_scheme 'repeat_horizon' / 'sample_horizon',
+        reference JL:516-594: `img_width` = logits_processor[0].w_latent_dim, one pad token per row)."""
+        return None
+
+
+def spatial_fresh_tokens(scheme, fresh, n_known, left_tok, left_amax, grid):
+    """Draft initialisation from the left neighbour (the paper's spatial-locality-aware token initialisation; reference JL:516-594,
+    which is broken at JL:577 in the released tree -- SURVEY.md 8a defect ledger -- so this follows the code's evident intent):
+    the fresh draft at absolute index s = n_known + j sits in image column (s - img_start) % (w + 1); if it has a left neighbour in the
+    same image row (column >= 1) it takes that neighbour's token ('repeat_horizon') or the mode of the distribution that neighbour was
+    drawn from ('sample_horizon': the reference's top-1 re-draw), chaining through the fresh drafts; first-column drafts and drafts whose
+    source is not an image token keep the uniformly random id of the 'random' scheme.  The draft distribution stays a one-hot.
+      fresh: the random ids already drawn (the global-RNG draw happens for every scheme, JL:519-522);  n_known: tokens before the first
+      fresh draft (accepted + last emitted + carried);  left_tok / left_amax: token (and its distribution's mode) just left of it."""
+    if scheme not in ("random", "repeat_horizon", "sample_horizon"):
+        raise ValueError(f"multi_token_init_scheme should be 'random', 'repeat_horizon' or 'sample_horizon', but got {scheme}")   # JL:560, 592
+    if scheme == "random" or grid is None or not fresh:
+        return list(fresh)
+    img_start, w, img_lo, img_hi = grid
+    out = []
+    for j, rnd in enumerate(fresh):
+        s = n_known + j
+        col = (s - img_start) % (w + 1)
+        src = left_tok if scheme == "repeat_horizon" else left_amax
+        tok = src if (s > img_start and col >= 1 and src is not None and img_lo <= src < img_hi) else rnd
+        out.append(int(tok))
+        left_tok = left_amax = int(tok)             # a fresh draft's distribution is the one-hot of its token
+    return out
+
 
 class LuminaGrammar(_Grammar):
     def __init__(self, image_top_k=2000, text_top_k=10, image_start_token_id=8197, image_end_token_id=8196,
@@ -85,6 +116,13 @@ class LuminaGrammar(_Grammar):
 
     def force_no_cfg(self):                        # check_is_force_no_cfg (JL:70-80)
         return self.s[1] == self.s[2]
+
+    def grid(self):
+        n, ns, ne, since, g1, g2 = self.s
+        if not (ns == ne + 1 and since >= 2):
+            return None
+        w = (g2 - 8804) * 2
+        return (n - (since - 2), w, self.img_lo, self.img_hi) if w > 0 else None
 
     def window_rules(self, n):
         _, ns, ne, since, g1, g2 = self.s
@@ -136,18 +174,25 @@ class Emu3Grammar(_Grammar):
 
     def reset(self):
         self.since = -1          # tokens after the FIRST img token (offset_cache, JE:50-52)
+        self.n = 0
 
     def _snapshot(self):
-        return self.since
+        return (self.since, self.n)
 
     def _restore(self, s):
-        self.since = s
+        self.since, self.n = s
 
     def _advance(self, t):
+        self.n += 1
         if self.since >= 0:
             self.since += 1
         elif t == self.img:
             self.since = 0
+
+    def grid(self):
+        if self.since < 0 or self.since >= (self.W + 1) * self.H:
+            return None
+        return (self.n - self.since, self.W, self.vis[0], self.vis[1])
 
     def window_rules(self, n):
         T = self.since

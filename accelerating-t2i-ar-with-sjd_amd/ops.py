@@ -103,7 +103,7 @@ def reguess(params: DeviceBlob, state: DeviceBlob, input_ids_out: torch.Tensor):
     L.check(L.load().sjd_reguess(params.ptr, state.ptr, _ptr(input_ids_out), n_batch, max_rows, _stream()), "sjd_reguess")
 
 
-def logits_to_probs_sample(logits_c, logits_u, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr, col0=0):
+def logits_to_probs_sample(logits_c, logits_u, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr, col0=0, amax_out_ptr=None):
     """logits_c/u: [rows, V] fp32 views with a common row stride (last dim contiguous) -- or, with col0 > 0, compact views holding
     only the vocabulary columns [col0, col0 + width): every rule in `params` must then keep its allowed ranges inside that window
     (K2 reads no other column; the pointers handed over are those of the virtual column 0)."""
@@ -113,9 +113,9 @@ def logits_to_probs_sample(logits_c, logits_u, guidance, params: DeviceBlob, noi
     if logits_u is not None:
         assert logits_u.stride(-2) == logits_c.stride(-2) and logits_u.stride(-1) == 1
     shift = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr() - 4 * int(col0))
-    L.check(L.load().sjd_logits_to_probs_sample(shift(logits_c), shift(logits_u), logits_c.stride(-2), float(guidance),
-                                               max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out), tokens_out_ptr,
-                                               _stream()), "sjd_logits_to_probs_sample")
+    L.check(L.load().sjd_logits_to_probs_sample_ex(shift(logits_c), shift(logits_u), logits_c.stride(-2), float(guidance),
+                                                  max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out), tokens_out_ptr, amax_out_ptr,
+                                                  _stream()), "sjd_logits_to_probs_sample")
 
 
 def verify_accept(params: DeviceBlob, state: DeviceBlob, probs, prev_probs, rs, noise2, scratch):
@@ -253,7 +253,7 @@ class HeadOut:
         self.part, self.col0, self.urow_off, self.dtype, self.row_norm = part, int(col0), int(urow_off), dtype, row_norm
 
 
-def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr, dbg=None):
+def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr, dbg=None, amax_out_ptr=None):
     """K2 reading the unmaterialised output head (see sjd_head_partials in include/sjd_hip.h).  dbg: optional fp32 [2, rows, V] that
     receives the logits K2 derived (cond, uncond) -- observers only."""
     max_rows, V = probs_out.shape
@@ -271,7 +271,7 @@ def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noi
         hp.dbg_c, hp.dbg_u = dbg[0].data_ptr(), dbg[1].data_ptr()
     assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V and probs_out.is_contiguous()
     L.check(L.load().sjd_logits_to_probs_sample_part(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out),
-                                                    tokens_out_ptr, _stream()), "sjd_logits_to_probs_sample_part")
+                                                    tokens_out_ptr, amax_out_ptr, _stream()), "sjd_logits_to_probs_sample_part")
 
 
 def _part_args(delta):

@@ -81,6 +81,9 @@ typedef struct sjd_state {
     int64_t tokens[SJD_MAX_WINDOW]; /* corrected samples Y of the last iteration: [0,m) emitted, [m,n) carried */
     int64_t win_tok[SJD_MAX_WINDOW];/* current window ids */
     int32_t q_src[SJD_MAX_WINDOW];  /* row of the previous prob buffer holding the draft distribution, -1: one-hot */
+    int64_t amax[SJD_MAX_WINDOW];   /* K2 by-product: lowest-index argmax of each row's distribution p (the 'sample_horizon' draft
+                                     * initialisation of JL:540-586 re-draws a draft from its left neighbour's distribution, which the
+                                     * reference reduces to its top-1 entry) */
 } sjd_state;
 
 int sjd_version(void);
@@ -104,6 +107,10 @@ int sjd_reguess(const sjd_iter_params *params, sjd_state *state, int64_t *input_
 int sjd_logits_to_probs_sample(const float *logits_c, const float *logits_u, int64_t row_stride, float guidance,
                                int max_rows, int V, const sjd_iter_params *params, const float *noise,
                                float *probs_out, int64_t *tokens_out, void *stream);
+/* same; amax_out (int64 [max_rows], may be NULL; state->amax works) also receives the lowest-index argmax of every row of p */
+int sjd_logits_to_probs_sample_ex(const float *logits_c, const float *logits_u, int64_t row_stride, float guidance,
+                                  int max_rows, int V, const sjd_iter_params *params, const float *noise,
+                                  float *probs_out, int64_t *tokens_out, int64_t *amax_out, void *stream);
 
 /* K2 on an UNMATERIALISED output head: the logits of window row r are
  *     z[r, col] = dtype( row_scale[r] * sum_c part[c][r][col - col0] ),   col in [col0, col0 + n_cols),
@@ -128,7 +135,7 @@ typedef struct sjd_head_partials {
 } sjd_head_partials;
 int sjd_logits_to_probs_sample_part(const sjd_head_partials *head /* host struct, passed by value to the kernel */, float guidance,
                                     int max_rows, int V, const sjd_iter_params *params, const float *noise, float *probs_out,
-                                    int64_t *tokens_out, void *stream);
+                                    int64_t *tokens_out, int64_t *amax_out /* may be NULL */, void *stream);
 
 /* K4 -- probabilistic verify-and-accept (longest accepted prefix) + residual resample of the first reject.
  * replaces SpeculativeSampler.__call__ / find_first_misaligned_token_inds / prefix_matching_next_tokens

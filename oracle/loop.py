@@ -34,6 +34,7 @@ class LoopConfig:
     img_vocab_n: int = 8192
     max_length: int = 1 << 30      # MaxLengthCriteria / MaxlenCriteria
     eos_token_ids: tuple = ()      # EosTokenCriteria looks at the LAST appended token only
+    multi_token_init_scheme: str = "random"    # 'repeat_horizon' / 'sample_horizon': spatial draft initialisation (JL:516-594)
 
 
 @dataclass
@@ -52,14 +53,35 @@ def set_seed(seed):
     torch.manual_seed(seed)
 
 
+def spatial_init(scheme, fresh, n_known, left_tok, left_mode, grid):
+    """Restatement of the spatial draft initialisation of JL:516-594 as intended (the released code raises IndexError at JL:577, so
+    there is no reference run to pin this against: PARITY UNPINNED).  The fresh draft at absolute index s = n_known + j lies in image
+    column (s - img_start) % (w + 1); with a left neighbour in the same row (column >= 1) that is an image token it repeats that token
+    ('repeat_horizon', JL:586-590) or takes the top-1 entry of the distribution the neighbour was drawn from ('sample_horizon',
+    JL:485-498, 579-585); the draft distribution is a one-hot either way (JL:583-590), so later fresh drafts chain through it."""
+    if scheme == "random" or grid is None:
+        return list(fresh)
+    img_start, w, lo, hi = grid
+    out = []
+    for j, rnd in enumerate(fresh):
+        s = n_known + j
+        src = left_tok if scheme == "repeat_horizon" else left_mode
+        ok = s > img_start and (s - img_start) % (w + 1) >= 1 and src is not None and lo <= src < hi
+        tok = int(src) if ok else int(rnd)
+        out.append(tok)
+        left_tok = left_mode = tok
+    return out
+
+
 def run(prompt, forward_fn, rules_fn, cfg: LoopConfig, vocab_size, no_cfg_fn=None, resid_rules_fn=None,
-        noise_device="cpu", hook=None):
+        noise_device="cpu", hook=None, grid_fn=None):
     """prompt: list[int] accepted ids handed to _sample.
     forward_fn(window_ids list[int], kv_len int) -> (logits_c [n,V], logits_u [n,V] or None) float32 numpy; the
         callee owns the KV cache: it must write the n window rows at [kv_len, kv_len+n) and attend causally.
     rules_fn(ctx list[int], n) -> n RowRules for the sampling call (JL:106);
     resid_rules_fn(ctx, 1) -> rule of the residual call (JL:297-306); defaults to rules_fn.
     no_cfg_fn(ctx) -> bool (check_is_force_no_cfg, JL:70-80).
+    grid_fn(ctx) -> (img_start, w, img_lo, img_hi) or None: image geometry for the spatial init schemes.
     Returns (sequence list[int], Trace)."""
     resid_rules_fn = resid_rules_fn or rules_fn
     X = [int(t) for t in prompt]
@@ -96,6 +118,11 @@ def run(prompt, forward_fn, rules_fn, cfg: LoopConfig, vocab_size, no_cfg_fn=Non
             n_fresh = n - 1 - a
             fresh = torch.randint(0, cfg.img_vocab_n, (1, n_fresh))[0].tolist()   # GLOBAL generator (JL:505)
             fresh = [cfg.img_vocab_lo + t for t in fresh]                          # img_vocab[rand] (JL:509)
+            if cfg.multi_token_init_scheme != "random":
+                left_tok = carried_tok[a - 1] if a else X[-1]
+                left_row = carried_rows[a - 1] if a else p_last
+                fresh = spatial_init(cfg.multi_token_init_scheme, fresh, len(X) + a, left_tok, int(np.argmax(left_row)),
+                                     grid_fn(list(X)) if grid_fn is not None else None)
             win = [X[-1]] + carried_tok[:a] + fresh
             q_rows = [p_last] + carried_rows[:a] + [None] * n_fresh              # JL:688-701 (None = one-hot)
         ctx = list(X)

@@ -252,3 +252,26 @@ def anole_rules(ctx, n, V, prompt_len, max_length, image_seq_length, boi=8197, e
         masked[eos] = True
     ranges = _mask_to_ranges(~masked)
     return [rule(ranges, -1, top_k) for _ in range(n)]
+
+
+def lumina_grid(ctx, start=8197, end=8196, img_lo=4, img_hi=8196):
+    """(index of the first image token, w_latent, img_lo, img_hi) while an image is open (#start == #end + 1 and the two grid tokens are
+    known), else None -- the geometry the spatial init schemes use (reference JL:531-537: img_width = w_latent_dim, one pad per row)."""
+    ctx = list(ctx)
+    if ctx.count(start) != ctx.count(end) + 1:
+        return None
+    i = len(ctx) - 1 - ctx[::-1].index(start)
+    if len(ctx) - i < 3:
+        return None
+    w = (ctx[i + 2] - 8804) * 2
+    return (i + 3, w, img_lo, img_hi) if w > 0 else None
+
+
+def emu3_grid(ctx, H, W, vis_lo, vis_n, img_token):
+    ctx = list(ctx)
+    if img_token not in ctx:
+        return None
+    i = ctx.index(img_token)
+    if len(ctx) - 1 - i >= (W + 1) * H:
+        return None
+    return (i + 1, W, vis_lo, vis_lo + vis_n)

@@ -23,7 +23,7 @@ class _Recorder:
             noise2=d["noise2"].cpu().numpy().copy(), use_cfg=bool(d["use_cfg"])))
 
 
-def _replay(rec, prompt, rules_fn, cfg, V, no_cfg_fn=None, device="cuda"):
+def _replay(rec, prompt, rules_fn, cfg, V, no_cfg_fn=None, device="cuda", grid_fn=None):
     it = iter(rec.items)
     state = {"i": -1}
 
@@ -45,7 +45,7 @@ def _replay(rec, prompt, rules_fn, cfg, V, no_cfg_fn=None, device="cuda"):
             assert (d["rs"].cpu().numpy() == r["rs"]).all(), "uniform stream diverged"
             assert (d["noise2"].cpu().numpy() == r["noise2"]).all(), "residual noise stream diverged"
 
-    seq, tr = OL.run(prompt, fwd, rules_fn, cfg, V, no_cfg_fn=no_cfg_fn, noise_device=device, hook=hook)
+    seq, tr = OL.run(prompt, fwd, rules_fn, cfg, V, no_cfg_fn=no_cfg_fn, noise_device=device, hook=hook, grid_fn=grid_fn)
     return seq, tr, checks
 
 
@@ -53,7 +53,7 @@ def _loop_cfg(c):
     return OL.LoopConfig(jacobi_loop_interval_l=c.jacobi_loop_interval_l, jacobi_loop_interval_r=c.jacobi_loop_interval_r,
                          max_num_new_tokens=c.max_num_new_tokens, guidance_scale=c.guidance_scale, seed=c.seed,
                          do_cfg=c.do_cfg, prefix_token_sampler_scheme=c.prefix_token_sampler_scheme,
-                         max_length=c.max_length, eos_token_ids=c.eos_token_ids)
+                         max_length=c.max_length, eos_token_ids=c.eos_token_ids, multi_token_init_scheme=c.multi_token_init_scheme)
 
 
 @torch.no_grad()
@@ -95,7 +95,7 @@ def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7,
 @torch.no_grad()
 def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, scheme="speculative_jacobi", P=12,
                                 embed_token_scale=0.25, kv_heads=4, l=3, r=None, dtype=torch.bfloat16,
-                                use_graph=False, fused=True, gemm="torch", fp8_kv=False):
+                                use_graph=False, fused=True, gemm="torch", fp8_kv=False, init_scheme="random"):
     import sjd_amd.ops as ops
     import sjd_amd.synthetic as synthetic
     from sjd_amd.engine import SJDEngine, SJDConfig, WindowSpec
@@ -114,7 +114,8 @@ def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, 
     model.setup_cache(batch=2, s_max=((max_len + 64 + 31) // 32) * 32, dtype=ops.FP8 if fp8_kv else None)
     r = r if r is not None else (2 * wg + 1) * 2 * hg - 10
     cfg = SJDConfig(jacobi_loop_interval_l=l, jacobi_loop_interval_r=r, max_num_new_tokens=window, guidance_scale=3.0,
-                    seed=seed, prefix_token_sampler_scheme=scheme, max_length=max_len, eos_token_ids=(8196,))
+                    seed=seed, prefix_token_sampler_scheme=scheme, max_length=max_len, eos_token_ids=(8196,),
+                    multi_token_init_scheme=init_scheme)
     ids = prompt.to(device)
     spec = WindowSpec(first_tokens=ids.repeat(2, 1),
                       first_positions=torch.stack([torch.arange(P), torch.tensor([1] * (P - 1) + [0])]).to(device),
@@ -125,12 +126,13 @@ def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, 
     eng.hook = rec
     seq, stats = eng.decode(prompt[0].tolist(), spec, LuminaGrammar(2000, 10), cfg)
     seq_ref, tr, checks = _replay(rec, prompt[0].tolist(), lambda c, n: O.lumina_rules(c, n, 2000, 10), _loop_cfg(cfg), V,
-                                  no_cfg_fn=O.lumina_force_no_cfg, device=device)
+                                  no_cfg_fn=O.lumina_force_no_cfg, device=device, grid_fn=O.lumina_grid)
     assert seq == seq_ref, "token sequences differ"
     assert stats.matched == tr.matched and stats.nfe == len(tr.matched)
     gen = seq[P:]
+    windows = tr.windows
     return dict(tokens=len(gen), nfe=stats.nfe, eol=[i for i, t in enumerate(gen) if t == 8803][:3], last=gen[-1],
-                accepted_hist=sorted(set(stats.matched[1:])), noise_checks=checks["noise"])
+                accepted_hist=sorted(set(stats.matched[1:])), noise_checks=checks["noise"], windows=windows)
 
 
 @torch.no_grad()
@@ -173,7 +175,7 @@ def teacher_forced_anole_check(device="cuda:0", img_len=40, window=16, seed=5, P
 
 @torch.no_grad()
 def teacher_forced_emu3_check(device="cuda:0", H=3, W=5, window=32, seed=5, embed_token_scale=0.4, dtype=torch.float16,
-                              use_graph=True, pos_len=9, neg_len=5, gemm="torch"):
+                              use_graph=True, pos_len=9, neg_len=5, gemm="torch", init_scheme="random"):
     """Emu3 flavour (config 3): Llama-style GQA backbone without QK-norm, pos/neg prompts left-padded to a common
     length (pads are hidden keys), EOL/EOF/EOI/EOS grammar, top-k 2048, draft window 32, fp16."""
     import sjd_amd.ops as ops
@@ -201,13 +203,15 @@ def teacher_forced_emu3_check(device="cuda:0", H=3, W=5, window=32, seed=5, embe
     max_len = P + n_gen + 2
     model.setup_cache(batch=2, s_max=((max_len + 64 + 31) // 32) * 32)
     cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=(W + 1) * H - 1, max_num_new_tokens=window, guidance_scale=3.0,
-                    seed=seed, prefix_token_sampler_scheme="speculative_jacobi", max_length=max_len, eos_token_ids=(tok["eos_token"],))
+                    seed=seed, prefix_token_sampler_scheme="speculative_jacobi", max_length=max_len, eos_token_ids=(tok["eos_token"],),
+                    multi_token_init_scheme=init_scheme)
     eng = SJDEngine(model, V, device, max_window=window, use_graph=use_graph)
     rec = _Recorder()
     eng.hook = rec
     seq, stats = eng.decode(prompt, spec, Emu3Grammar(H, W, vis_lo, vis_n, **tok, top_k=2048), cfg)
     rules_fn = lambda c, n: O.emu3_rules(c, n, H, W, vis_lo, vis_n, top_k=2048, **tok)
-    seq_ref, tr, checks = _replay(rec, prompt, rules_fn, _loop_cfg(cfg), V, device=device)
+    seq_ref, tr, checks = _replay(rec, prompt, rules_fn, _loop_cfg(cfg), V, device=device,
+                                  grid_fn=lambda c: O.emu3_grid(c, H, W, vis_lo, vis_n, tok["img_token"]))
     assert seq == seq_ref, "token sequences differ"
     assert stats.matched == tr.matched and stats.nfe == len(tr.matched)
     gen = seq[P:]

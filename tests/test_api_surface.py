@@ -44,14 +44,14 @@ def test_init_new_params_defaults_match_reference():
 
 
 def test_engine_rejects_unknown_scheme_and_broken_init_schemes():
-    """ValueError at reference JL:1048; the horizon init schemes crash in the released reference."""
+    """ValueError at reference JL:1048; unknown init schemes assert at JL:560 / 592."""
     from sjd_amd.engine import SJDConfig, SJDEngine
     eng = SJDEngine.__new__(SJDEngine)
     eng.Lmax = 16
     with pytest.raises(ValueError):
         SJDEngine.decode.__wrapped__(eng, [1], None, None, SJDConfig(prefix_token_sampler_scheme="bogus"))
-    with pytest.raises(NotImplementedError):
-        SJDEngine.decode.__wrapped__(eng, [1], None, None, SJDConfig(multi_token_init_scheme="repeat_horizon"))
+    with pytest.raises(ValueError):                  # only the horizon variants exist (the 'vertical' ones assert at JL:554-560)
+        SJDEngine.decode.__wrapped__(eng, [1], None, None, SJDConfig(multi_token_init_scheme="repeat_vertical"))
 
 
 def test_processor_descriptors_and_grammar_mapping():

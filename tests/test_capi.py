@@ -31,8 +31,11 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(L.RowRule) == 48
     assert ctypes.sizeof(L.IterParams) == 32 + 8 * 32 + 2 * 48 * 32
     assert L.IterParams.fresh_tok.offset == 32 and L.IterParams.rules.offset == 32 + 256
-    assert ctypes.sizeof(L.State) == 16 + 8 * 32 * 2 + 4 * 32
+    assert ctypes.sizeof(L.State) == 16 + 8 * 32 * 2 + 4 * 32 + 8 * 32
     assert L.State.tokens.offset == 16 and L.State.win_tok.offset == 16 + 256 and L.State.q_src.offset == 16 + 512
+    assert L.State.amax.offset == 16 + 512 + 128
+    assert ctypes.sizeof(L.HeadPartials) == 88 and L.HeadPartials.row_sumsq.offset == 48          # static_assert'ed in sjd_sampling.hip
+    assert ctypes.sizeof(L.RowNorm) == 24
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

@@ -113,3 +113,19 @@ def test_real_shape_teacher_forced_loop(dev, family):
     assert r["nfe"] >= 12 and r["tokens"] >= 40 and max(r["accepted"]) >= 2
     assert r["fwd_graphs"] >= 1 and all(c is not None for c in r["head_cols"])          # the narrow output head was the one that ran
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("init_scheme", ["repeat_horizon", "sample_horizon"])
+@pytest.mark.parametrize("use_graph,gemm", [(False, "torch"), (True, "sjd")])
+def test_lumina_loop_spatial_init(init_scheme, use_graph, gemm):
+    """spatial draft initialisation (reference JL:516-594, broken upstream: parity is pinned by the oracle restatement
+    only).  Engine and oracle must build identical windows, and fresh drafts inside a row must repeat their left neighbour."""
+    s = G.teacher_forced_lumina_check(hg=5, wg=5, window=16, seed=6, l=3, use_graph=use_graph, gemm=gemm, init_scheme=init_scheme)
+    assert s["tokens"] == 11 * 10 + 1 and s["last"] == 8196
+    copies = sum(1 for w_ in s["windows"][1:] for i in range(1, len(w_)) if w_[i] == w_[i - 1])
+    assert copies > 20                               # with 'random' two equal neighbours are a 1/8192 event
+
+
+def test_emu3_loop_spatial_init():
+    r = G.teacher_forced_emu3_check(H=4, W=6, window=16, seed=8, init_scheme="repeat_horizon", gemm="sjd")
+    assert r["gen"][(r["W"] + 1) * r["H"]:(r["W"] + 1) * r["H"] + 3] == [r["tok"]["eof_token"], r["tok"]["eoi_token"], r["tok"]["eos_token"]]

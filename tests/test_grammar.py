@@ -5,6 +5,8 @@ import json
 import os
 import random
 
+import pytest
+
 import numpy as np
 
 from oracle import sjd_oracle as O
@@ -102,3 +104,32 @@ def test_grammars_on_golden_contexts(golden_dir):
     for m in json.loads(str(d["meta"])):
         ctx = d[f"{m['name']}.ctx"][0].tolist()
         check(G.LuminaGrammar(2000, 10), lambda c, k: O.lumina_rules(c, k, 2000, 10), ctx, m["nrows"])
+
+
+def test_spatial_init_schemes_copy_the_left_neighbour_inside_an_image_row():
+    """multi_token_init_scheme 'repeat_horizon' / 'sample_horizon' (reference JL:516-594): product function and oracle
+    restatement agree, first-column drafts and control-token sources stay random, fresh drafts chain."""
+    from oracle import sjd_oracle as O
+    from oracle.loop import spatial_init
+    from sjd_amd.grammar import LuminaGrammar, Emu3Grammar, TopKTopPGrammar, spatial_fresh_tokens
+    g = LuminaGrammar(2000, 10)
+    ctx = [9000] * 5 + [8197, 8808, 8808] + [100, 101, 102]            # 8 x 8 latent grid, three image tokens so far
+    g.start(ctx)
+    assert g.grid() == O.lumina_grid(ctx) == (8, 8, 4, 8196)
+    fresh = [10, 11, 12, 13, 14, 15, 16, 17]
+    # absolute indices 11.. -> columns 3,4,5,6,7,8(EOL slot),0,1
+    assert spatial_fresh_tokens("repeat_horizon", fresh, len(ctx), 102, 555, g.grid()) == [102] * 6 + [16, 16]
+    assert spatial_fresh_tokens("sample_horizon", fresh, len(ctx), 102, 555, g.grid()) == [555] * 6 + [16, 16]
+    assert spatial_fresh_tokens("random", fresh, len(ctx), 102, 555, g.grid()) == fresh
+    assert spatial_fresh_tokens("repeat_horizon", fresh, len(ctx), 8803, 8803, g.grid())[:2] == [10, 10]     # a line token is never repeated
+    for sch in ("repeat_horizon", "sample_horizon"):
+        assert spatial_fresh_tokens(sch, fresh, len(ctx) + 2, 102, 555, g.grid()) == spatial_init(sch, fresh, len(ctx) + 2, 102, 555, O.lumina_grid(ctx))
+    g.start(ctx[:6])                                                   # grid tokens not yet known -> plain random init
+    assert g.grid() is None and O.lumina_grid(ctx[:6]) is None
+    assert TopKTopPGrammar(100, 1.0).grid() is None                    # LlamaGen: no img_width -> the reference silently degrades to random
+    e = Emu3Grammar(3, 5, 3000, 8192, 200, 201, 202, 203, 204, 205)
+    ectx = [300, 301, 200, 3001, 3002]
+    e.start(ectx)
+    assert e.grid() == O.emu3_grid(ectx, 3, 5, 3000, 8192, 200) == (3, 5, 3000, 11192)
+    with pytest.raises(ValueError):
+        spatial_fresh_tokens("repeat_vertical", fresh, len(ctx), 102, 555, g.grid())

@@ -82,11 +82,43 @@ def main():
     ap.add_argument("--batched", action="store_true", help="back-to-back eager launches, one event pair (host launch rate bound for short kernels)")
     ap.add_argument("--per-launch", action="store_true", help="one event pair per launch (includes ~4 us dispatch latency)")
     ap.add_argument("--product", action="store_true", help="per-shape (KC, waves, layout) of backbones.G1_CFG")
+    ap.add_argument("--sweep", action="store_true", help="grid over KC x waves x layout per shape (one JSON line per point, best first at the end)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     if os.environ.get("SJD_SO"):
         L.SO_PATH = os.environ["SJD_SO"]
     lib = L.load()
+    if a.sweep:
+        for name, (N, K, _) in SHAPES.items():
+            if a.only and name != a.only:
+                continue
+            x = torch.randn(32, K, device=dev).to(torch.bfloat16)
+            ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16) for _ in range(a.copies)]
+            rows = []
+            for sm in (1, 0):
+                for KC in (256, 512, 688, 1024, 1376, 2048):
+                    if KC > K or (name == "down" and KC == 2048):
+                        continue
+                    wps = [ops.pack_weight(w, KC, bool(sm)) for w in ws]
+                    nc = (K + KC - 1) // KC
+                    out = torch.empty(nc, 32, N, dtype=torch.float32, device=dev)
+                    for waves in (4, 6, 8, 11, 12, 16):
+                        n_wg = ((N // 32 + waves - 1) // waves) * nc
+
+                        def g1(i, wps=wps, KC=KC, waves=waves, sm=sm, out=out):
+                            L.check(lib.sjd_skinny_gemm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % a.copies].data_ptr()),
+                                                        ctypes.c_void_p(out.data_ptr()), 32, N, K, KC, waves, sm, 0,
+                                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "g1")
+                        avg, _ = timed_graph(g1, a.launches, lib)
+                        r = dict(shape=name, KC=KC, waves=waves, step_major=sm, workgroups=n_wg, us=round(avg * 1e3, 2),
+                                 TBps=round(N * K * 2 / 1e12 / (avg / 1e3), 3))
+                        rows.append(r)
+                        print(json.dumps(r), flush=True)
+                    del wps, out
+                    torch.cuda.empty_cache()
+            best = sorted(rows, key=lambda r: r["us"])[:5]
+            print(json.dumps(dict(shape=name, best=best)), flush=True)
+        return
     for name, (N, K, KC) in SHAPES.items():
         if a.only and name != a.only:
             continue

@@ -347,7 +347,7 @@ class ChameleonBackbone(nn.Module):
 
     # G1 launch shape per projection: (split-K chunk, column tiles per workgroup, step-major packing) -- tuned on MI355X with
     # tools/g1_bench.py so that every launch gives the 256 CUs ~1000+ balanced waves
-    G1_CFG = dict(qkv=(1024, 8, True), o=(256, 8, False), gate_up=(2048, 8, True), down=(1024, 8, False))
+    G1_CFG = dict(qkv=(1024, 8, True), o=(512, 6, False), gate_up=(2048, 8, True), down=(1024, 8, False))
     # the same for 64-row windows (two prompts per forward, or a draft window of 32): the staged chunk is twice as tall, so KC <= 1280;
     # set `model.G1_CFG = model.G1_CFG_64ROW` before enable_fused (the packing depends on KC).  Tuned end to end at Lumina-7B shapes.
     G1_CFG_64ROW = dict(qkv=(1024, 8, True), o=(512, 8, False), gate_up=(1024, 16, True), down=(1024, 8, False))

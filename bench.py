@@ -462,9 +462,14 @@ def main():
         # whole decode, which includes the prefill iteration, the hipGraph captures and the two barrier brackets)
         n_tok, nfe = stats.total_tokens, stats.nfe
         t_img = iter_log[-1][3] - iter_log[0][3]                   # from the end of the prefill iteration to the last iteration
+        durs = sorted(iter_log[i][3] - iter_log[i - 1][3] for i in range(1, len(iter_log)))
+        cut = durs[:max(1, len(durs) - max(8, len(durs) // 100))]  # steady state: without the ~1 % slowest iterations, i.e. the one-off
+        steady = sum(cut) / len(cut)                               # hipGraph captures and the two barrier brackets of the timed region
         out["whole_image"] = {"tokens": n_tok, "nfe": nfe, "tokens_per_step": round(n_tok / max(nfe, 1), 4),
                               "seconds": round(t_img, 4), "ms_per_step": round(t_img / max(nfe - 1, 1) * 1e3, 4),
-                              "tokens_per_s": round((n_tok - 1) / t_img, 2), "finished": bool(seq[-1] in cfg.eos_token_ids),
+                              "tokens_per_s": round((n_tok - 1) / t_img, 2),
+                              "steady_ms_per_step": round(steady * 1e3, 4), "steady_tokens_per_s": round((n_tok - 1) / (steady * (nfe - 1)), 2),
+                              "finished": bool(seq[-1] in cfg.eos_token_ids),
                               "reference_published_nfe": "1009-1115 (hardware unstated, BASELINE.md)" if args.model == "lumina7b" else None}
         pts = [P, P + n_img // 2 - 24, P + n_img - 112] if args.model != "lumina7b" else [64, 1216, 2368]
         out["per_kv"] = per_kv_table(iter_log, pts)
@@ -510,13 +515,15 @@ def main():
     if side_legs and not args.no_floor:
         # floor regime: plain random embeddings -> the next-token distribution depends almost only on the previous
         # token -> ~1 accepted token per step.  Same engine, same graphs (the embedding table is re-drawn in place).
+        e_before = model.model.embed_tokens.weight[:8, :8].float().clone()
         synthetic.refill_embeddings_device(model, seed=0, embed_token_scale=1.0)
+        redrawn = not torch.equal(e_before, model.model.embed_tokens.weight[:8, :8].float())
         cfg_f = copy.copy(cfg)
         _, st_f = eng.decode(prompt, spec, copy.deepcopy(grammar0), cfg_f, warmup_iters=8, timed_iters=args.floor_steps,
                              on_timed_start=sync_all, on_timed_end=sync_all)
         synthetic.refill_embeddings_device(model, seed=0, embed_token_scale=args.embed_token_scale)
         tpf = st_f.tokens / max(st_f.timed_nfe, 1)
-        out["floor"] = {"embed_token_scale": 1.0, "tokens_per_step": round(tpf, 4), "steps": st_f.timed_nfe,
+        out["floor"] = {"embed_token_scale": 1.0, "embeddings_redrawn": redrawn, "tokens_per_step": round(tpf, 4), "steps": st_f.timed_nfe,
                         "ms_per_step": round(st_f.seconds / max(st_f.timed_nfe, 1) * 1e3, 4), "kv_len": [st_f.kv_len_start, st_f.kv_len],
                         "tokens_per_s_at_headline_ms_per_step": round(tpf / (t_max / max(stats.timed_nfe, 1)), 2)}
     if side_legs and not args.no_torch_baseline and args.model in ("lumina7b", "lumina_tiny"):

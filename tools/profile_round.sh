@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round profile set (run on the GPU box through gpurun; outputs under gpurun_out/prof_*; copy the summaries into profiles/):
+#   1. rocprofv3 --kernel-trace --stats of a short bench run -> per-kernel time, split by launch shape
+#   2. PMC passes (counters only, no trace domains besides kernel-trace): MFMA busy for K1 and G1, HBM traffic for K1 / G1 / K2+head
+cd ${GRAFT_REPO_ROOT:-.}
+export TMPDIR=/tmp
+TAG=${1:-r2}
+O=gpurun_out
+mkdir -p $O
+B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-cpu-baseline --no-whole-image"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_trace -- $B > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof_bench.err
+python tools/trace_by_grid.py $O/prof_${TAG}_trace 200 > $O/${TAG}_bench_by_shape.txt
+find $O/prof_${TAG}_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_bench_kernel_stats.csv
+K1="python tools/k1_bench.py --kv-len 1216 --n-split 4 --launches 96 --graph"
+G1="python tools/g1_bench.py --product --no-blas --launches 48"
+for C in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE"; do
+  T=$(echo $C | tr ' ' '_')
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/prof_${TAG}_k1_$T -- $K1 > /dev/null 2>> $O/${TAG}_pmc.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/prof_${TAG}_g1_$T -- $G1 > /dev/null 2>> $O/${TAG}_pmc.err
+done
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/prof_${TAG}_k1_$C -- $K1 > /dev/null 2>> $O/${TAG}_pmc.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/prof_${TAG}_g1_$C -- $G1 > /dev/null 2>> $O/${TAG}_pmc.err
+done
+: > $O/${TAG}_pmc_summary.jsonl
+for d in $O/prof_${TAG}_k1_* $O/prof_${TAG}_g1_*; do
+  echo "# $d" >> $O/${TAG}_pmc_summary.jsonl
+  python tools/pmc_summary.py $d k1_ g1_ >> $O/${TAG}_pmc_summary.jsonl
+done
+cat $O/${TAG}_pmc_summary.jsonl
+head -30 $O/${TAG}_bench_by_shape.txt
+# keep the merged output small: the raw trace directories stay on the box
+rm -rf $O/prof_${TAG}_*

@@ -445,7 +445,7 @@ class ChameleonBackbone(nn.Module):
         self._inv_freq32 = self.inv_freq.float().contiguous()
         return self
 
-    HEAD_CFG = (512, 8, True)          # G1 launch shape of the output head: (split-K chunk, column tiles per workgroup, step-major)
+    HEAD_CFG = (1024, 4, True)         # G1 launch shape of the output head: (split-K chunk, column tiles per workgroup, step-major)
     supports_head_partials = True
 
     def _head_partials(self, h, delta, cols, n):

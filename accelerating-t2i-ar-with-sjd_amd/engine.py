@@ -75,6 +75,8 @@ class DecodeStats:
     kv_len_start: int = 0          # ... at its start
     total_tokens: int = 0          # whole decode (lead-in + warm-up + timed + continuation)
     total_seconds: float = 0.0
+    timed_host_seconds: float = 0.0    # host_seconds / sync_seconds at the end of the timed region
+    timed_sync_seconds: float = 0.0
     host_seconds: float = 0.0      # host bookkeeping + RNG launches before the window step is enqueued
     sync_seconds: float = 0.0      # time blocked in the per-iteration state read-back
     matched: List[int] = field(default_factory=list)
@@ -444,3 +446,4 @@ class SJDEngine:
         stats.seconds = ev0.elapsed_time(ev1) / 1000.0
         stats.wall_seconds = time.perf_counter() - t0
         stats.tokens, stats.timed_nfe, stats.kv_len = tokens, nfe, kv_len
+        stats.timed_host_seconds, stats.timed_sync_seconds = stats.host_seconds, stats.sync_seconds      # frozen: the decode may continue

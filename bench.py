@@ -238,7 +238,7 @@ def cpu_baseline(args, gpu_sched_ms=None):
     from oracle import sjd_oracle as O
     V, L = 65536, args.window
     nproc = os.cpu_count() or 1
-    threads = O.set_threads(nproc)
+    threads = O.set_threads(min(nproc, L))          # one window row per thread: more threads than rows only spin
     g = torch.Generator().manual_seed(0)
     ctx = [9000] * 61 + [8197, 8828, 8828] + [100] * 40
     rules = O.lumina_rules(ctx, L, 2000, 10)
@@ -447,8 +447,8 @@ def main():
         "ms_per_step": round(t_max / max(stats.timed_nfe, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dt_name, "data": "synthetic",
         "tokens_per_step": round(tok_per_step, 4),
-        "host_ms_per_step": round(stats.host_seconds / max(stats.timed_nfe, 1) * 1e3, 4),
-        "sync_wait_ms_per_step": round(stats.sync_seconds / max(stats.timed_nfe, 1) * 1e3, 4),
+        "host_ms_per_step": round(getattr(stats, "timed_host_seconds", stats.host_seconds) / max(stats.timed_nfe, 1) * 1e3, 4),
+        "sync_wait_ms_per_step": round(getattr(stats, "timed_sync_seconds", stats.sync_seconds) / max(stats.timed_nfe, 1) * 1e3, 4),
         "config": {"workload": workload + f", random-init synthetic weights (embed_token_scale={args.embed_token_scale})",
                    "prompt_len": P, "image_tokens": n_img, "kv_len_start": stats.kv_len_start, "kv_len_end": stats.kv_len,
                    "lead_in_steps": 0,
@@ -535,10 +535,14 @@ def main():
         tb = TB.run_on_engine_model(model, ctx, P, grid, args.torch_baseline_steps, 4, seed=1234, window=args.window)
         tb["what"] = ("reference data flow in PyTorch-ROCm ops (torch.cat KV cache, masked SDPA, torch.topk, torch.multinomial, Python "
                       "accept loop with a sync per draft), same weights, same KV length; tools/torch_sjd_baseline.py")
+        # Both run the same algorithm on the same weights, so their expected accepted tokens/step are equal; the baseline's own 24-step
+        # sample of it is noisy, so the ratio is taken at the engine's measured acceptance: value / (tokens_per_step / baseline s/step)
+        tb["tokens_per_s_at_engine_acceptance"] = round(tok_per_step / (tb["ms_per_step"] / 1e3), 2)
         out["torch_baseline"] = tb
-        out["vs_baseline"] = round(tps / tb["tokens_per_s"], 3) if tb["tokens_per_s"] > 0 else None
-        out["vs_baseline_per_step"] = round(tb["ms_per_step"] / out["ms_per_step"], 3)
-        out["vs_baseline_kind"] = "value / torch_baseline.tokens_per_s (PyTorch-ROCm SJD on this GPU; the reference publishes no number on stated hardware)"
+        out["vs_baseline"] = round(tps / tb["tokens_per_s_at_engine_acceptance"], 3)
+        out["vs_baseline_raw_tokens_per_s"] = round(tps / tb["tokens_per_s"], 3) if tb["tokens_per_s"] > 0 else None
+        out["vs_baseline_kind"] = ("value / torch_baseline.tokens_per_s_at_engine_acceptance = PyTorch-ROCm SJD ms/step over engine ms/step "
+                                   "(same GPU, weights, KV length; the reference publishes no number on stated hardware)")
     if side_legs and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, gpu_sched_ms)
     out["bench_wall_s"] = {"decode": round(decode_wall, 2)}

@@ -165,7 +165,7 @@ def test_golden_loop_logits_within_1e3_of_cpu_oracle_forward(dev, golden_dir):
         eng.hook = rec_hook(gpu_rec)
         seq_gpu, _ = eng.decode(prompt, lumina_window_spec(prompt, dev), LuminaGrammar(2000, 10), cfg)
         assert seq_gpu == seq_cpu
-        report[name] = _max_logit_gap(gpu_rec, cpu_rec)
+        report["lumina/" + name] = _max_logit_gap(gpu_rec, cpu_rec)
     d, meta = _load(golden_dir, "loop_llamagen.npz")
     for m in meta[:2]:
         name, jac, N = m["name"], m["jacobi"], m["latent"] ** 2
@@ -189,6 +189,10 @@ def test_golden_loop_logits_within_1e3_of_cpu_oracle_forward(dev, golden_dir):
         eng.hook = rec_hook(gpu_rec)
         seq_gpu, _ = eng.decode([first], llamagen_window_spec(first, 1, dev), TopKTopPGrammar(m["top_k"], m["top_p"]), cfg)
         assert seq_gpu == seq_cpu
-        report[name] = _max_logit_gap(gpu_rec, cpu_rec)
+        report["llamagen/" + name] = _max_logit_gap(gpu_rec, cpu_rec)
     print("max |logit_gpu - logit_cpu_oracle| per golden run:", report)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "golden_logit_gap.json"), "w") as f:
+            json.dump(dict(tolerance=TOL, max_abs_gap_per_golden_run=report), f)
     assert max(report.values()) <= TOL, report

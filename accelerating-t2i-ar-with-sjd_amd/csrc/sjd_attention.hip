@@ -79,8 +79,9 @@ __device__ __forceinline__ u32x2 lds_tr_read(const unsigned short *p)
     return __builtin_bit_cast(u32x2, r);
 }
 
-template <int DT, int D>
-__global__ __launch_bounds__(256) void k1_partial(
+// NW wave64 per workgroup (4, or 8 for two waves per SIMD: twice the key tiles in flight per CU; the key-parts are merged in LDS)
+template <int DT, int D, int NW>
+__global__ __launch_bounds__(64 * NW) void k1_partial(
     const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
     float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max,
     const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks)
@@ -91,17 +92,17 @@ __global__ __launch_bounds__(256) void k1_partial(
     constexpr int VROW = D + 8;           // padded LDS row (elements): 16-B aligned rows, breaks the 256-B bank period
     // one LDS arena: the per-wave V tiles during the key loop, then (after a barrier) the fp32 merge buffers of the epilogue;
     // aliasing them keeps the workgroup at ~35 KB so that four workgroups fit on a CU
-    constexpr int V_BYTES = K1_WAVES * K1_KT * VROW * 2;
-    constexpr int R_BYTES = K1_WAVES * K1_ROWS * (D + 2) * 4;
+    constexpr int V_BYTES = NW * K1_KT * VROW * 2;
+    constexpr int R_BYTES = NW * K1_ROWS * (D + 2) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char arena[V_BYTES > R_BYTES ? V_BYTES : R_BYTES];
     unsigned short (*v_lds)[K1_KT * VROW] = reinterpret_cast<unsigned short (*)[K1_KT * VROW]>(arena);
     float (*red_o)[K1_ROWS][D] = reinterpret_cast<float (*)[K1_ROWS][D]>(arena);
-    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + K1_WAVES * K1_ROWS * D * 4);
+    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + NW * K1_ROWS * D * 4);
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int G = H / H_kv;
-    const int kparts = K1_WAVES / G;
+    const int kparts = NW / G;
     const int head_in_group = w % G, kpart = w / G;
     const int chunk = blockIdx.x / n_split, split = blockIdx.x % n_split;
     const int hkv = blockIdx.y, b = blockIdx.z;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void k1_partial(
 #pragma unroll
         for (int r = 0; r < 4; ++r) red_o[w][c][16 * db + 4 * g + r] = o_acc[db][r];
     __syncthreads();
-    for (int idx = threadIdx.x; idx < G * K1_ROWS * D; idx += 256) {
+    for (int idx = threadIdx.x; idx < G * K1_ROWS * D; idx += 64 * NW) {
         const int hg = idx / (K1_ROWS * D), row = (idx / D) % K1_ROWS, d = idx % D;
         float M = -INFINITY;
         for (int kp = 0; kp < kparts; ++kp) M = fmaxf(M, red_ml[kp * G + hg][row][0]);
@@ -1162,6 +1163,15 @@ extern "C" int64_t sjd_attention_workspace_bytes(int B, int H, int n_rows, int D
     return (int64_t)B * H * n_chunks * n_split * K1_ROWS * (D + 2) * (int64_t)sizeof(float);
 }
 
+// waves per k1_partial workgroup (SJD_K1_WAVES=4|8, read once).  8 = two waves per SIMD, twice the key tiles in flight per CU, the eight
+// key-parts merged in LDS: k1_partial + k1_combine per layer 12.5 / 16.0 / 19.7 / 26.2 us at kv_len 64 / 448 / 1216 / 2368 against
+// 13.2 / 16.4 / 21.7 / 28.4 us with 4 waves (profiles/r2_k1_waves_splits.jsonl; more splits lose either way).
+static int k1_waves()
+{
+    static const int w = [] { const char *e = getenv("SJD_K1_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    return w;
+}
+
 template <int DT, int D>
 static int launch_attention(const void *q, const void *kc, const void *vc, void *out, int B, int n_rows, int H, int H_kv, int S_max,
                             const int32_t *key_start, const sjd_iter_params *params, int kv_len, int n_split, void *workspace,
@@ -1176,8 +1186,12 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
         hipLaunchKernelGGL((k1_partial_shared<DT, D>), dim3(n_split, H_kv, B), dim3(64 * pairs), 0, stream, (const unsigned short *)q,
                            (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
                            kv_len, n_split, n_chunks);
+    else if (k1_waves() == 8)
+        hipLaunchKernelGGL((k1_partial<DT, D, 8>), dim3(n_chunks * n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
+                           (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
+                           kv_len, n_split, n_chunks);
     else
-        hipLaunchKernelGGL((k1_partial<DT, D>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
+        hipLaunchKernelGGL((k1_partial<DT, D, 4>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
                            (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
                            kv_len, n_split, n_chunks);
     if (ev1) (void)hipEventRecord(ev1, stream);

@@ -261,7 +261,7 @@ def cpu_baseline(args, gpu_sched_ms=None):
     for it in range(3):                          # probe: size the sample for ~15 s of CPU work
         prev = step(it, prev)
     probe = (time.perf_counter() - t0) / 3
-    n_it = args.cpu_baseline_iters or int(min(2000, max(50, 15.0 / max(probe, 1e-4))))
+    n_it = args.cpu_baseline_iters or int(min(20000, max(50, 15.0 / max(probe, 1e-4))))
     t_total = 0.0
     for it in range(n_it):
         t0 = time.perf_counter()

@@ -33,13 +33,16 @@ def main():
                           kv_heads=rnd.choice([4, 2, 1]), l=rnd.choice([0, 1, 3]), embed_token_scale=rnd.choice([0.1, 0.25, 0.6]),
                           scheme=rnd.choice(["speculative_jacobi", "speculative_jacobi", "jacobi"]), use_graph=rnd.random() < 0.6,
                           fused=True, gemm=rnd.choice(["torch", "sjd"]), fp8_kv=rnd.random() < 0.3,
-                          dtype=rnd.choice([torch.bfloat16, torch.float16]))
+                          dtype=rnd.choice([torch.bfloat16, torch.float16]),
+                          init_scheme=rnd.choice(["random", "random", "repeat_horizon", "sample_horizon"]))
                 r = G.teacher_forced_lumina_check(**kw)
+                r.pop("windows", None)
             elif kind == "emu3":
                 kw = dict(seed=seed, H=rnd.choice([2, 3, 4]), W=rnd.choice([3, 5, 6]), window=rnd.choice([8, 16, 32]),
                           pos_len=rnd.choice([5, 9, 12]), neg_len=rnd.choice([3, 5, 12]), gemm=rnd.choice(["torch", "sjd"]),
-                          use_graph=rnd.random() < 0.6)
+                          use_graph=rnd.random() < 0.6, init_scheme=rnd.choice(["random", "repeat_horizon", "sample_horizon"]))
                 r = G.teacher_forced_emu3_check(**kw)
+                r = {k: v for k, v in r.items() if k != "gen"}
             elif kind == "anole":
                 kw = dict(seed=seed, img_len=rnd.choice([24, 40, 57]), window=rnd.choice([4, 16]), fp8_kv=rnd.random() < 0.5,
                           gemm=rnd.choice(["torch", "sjd"]), use_graph=rnd.random() < 0.6)

@@ -861,8 +861,8 @@ template <int DT> __device__ __forceinline__ float k1_to_f32(unsigned short h);
 template <> __device__ __forceinline__ float k1_to_f32<SJD_DTYPE_BF16>(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 template <> __device__ __forceinline__ float k1_to_f32<SJD_DTYPE_F16>(unsigned short h) { return (float)(*reinterpret_cast<_Float16 *>(&h)); }
 
-template <int DT, int D>
-__global__ __launch_bounds__(256) void k1_partial_fp8(
+template <int DT, int D, int NW>
+__global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
     const unsigned short *__restrict__ q, const unsigned char *__restrict__ kc, const unsigned char *__restrict__ vc,
     float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max,
     const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks,
@@ -872,16 +872,16 @@ __global__ __launch_bounds__(256) void k1_partial_fp8(
     constexpr int DB = D / 16;            // 16-wide d blocks of the output
     constexpr int VROW = D + 16;          // padded LDS row in bytes (16-B aligned rows, breaks the 128-B bank period)
     constexpr float PSCALE = 256.0f;
-    constexpr int V_BYTES = K1_WAVES * K1_KT * VROW;
-    constexpr int R_BYTES = K1_WAVES * K1_ROWS * (D + 2) * 4;
+    constexpr int V_BYTES = NW * K1_KT * VROW;
+    constexpr int R_BYTES = NW * K1_ROWS * (D + 2) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char arena[V_BYTES > R_BYTES ? V_BYTES : R_BYTES];
     float (*red_o)[K1_ROWS][D] = reinterpret_cast<float (*)[K1_ROWS][D]>(arena);
-    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + K1_WAVES * K1_ROWS * D * 4);
+    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + NW * K1_ROWS * D * 4);
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int G = H / H_kv;
-    const int kparts = K1_WAVES / G;
+    const int kparts = NW / G;
     const int head_in_group = w % G, kpart = w / G;
     const int chunk = blockIdx.x / n_split, split = blockIdx.x % n_split;
     const int hkv = blockIdx.y, b = blockIdx.z;
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(256) void k1_partial_fp8(
 #pragma unroll
         for (int r = 0; r < 4; ++r) red_o[w][c][16 * db + 4 * g + r] = o_acc[db][r] * oscale;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < G * K1_ROWS * D; idx += 256) {
+    for (int idx = threadIdx.x; idx < G * K1_ROWS * D; idx += 64 * NW) {
         const int hg = idx / (K1_ROWS * D), row = (idx / D) % K1_ROWS, d = idx % D;
         float M = -INFINITY;
         for (int kp = 0; kp < kparts; ++kp) M = fmaxf(M, red_ml[kp * G + hg][row][0]);
@@ -1263,9 +1263,14 @@ static int launch_attention_fp8(const void *q, const void *kc, const void *vc, v
     const int n_chunks = (n_rows + K1_ROWS - 1) / K1_ROWS;
     float *ws_o = (float *)workspace;
     float *ws_ml = ws_o + (size_t)B * H * n_chunks * n_split * K1_ROWS * D;
-    hipLaunchKernelGGL((k1_partial_fp8<DT, D>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
-                       (const unsigned char *)kc, (const unsigned char *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
-                       kv_len, n_split, n_chunks, k_scale, v_scale);
+    if (k1_waves() == 8)
+        hipLaunchKernelGGL((k1_partial_fp8<DT, D, 8>), dim3(n_chunks * n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
+                           (const unsigned char *)kc, (const unsigned char *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
+                           kv_len, n_split, n_chunks, k_scale, v_scale);
+    else
+        hipLaunchKernelGGL((k1_partial_fp8<DT, D, 4>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
+                           (const unsigned char *)kc, (const unsigned char *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
+                           kv_len, n_split, n_chunks, k_scale, v_scale);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
                        n_split, n_chunks, params, key_start, kv_len);

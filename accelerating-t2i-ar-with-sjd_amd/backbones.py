@@ -347,12 +347,12 @@ class ChameleonBackbone(nn.Module):
 
     # G1 launch shape per projection: (split-K chunk, column tiles per workgroup, step-major packing) -- tuned on MI355X with
     # tools/g1_bench.py so that every launch gives the 256 CUs ~1000+ balanced waves
-    G1_CFG = dict(qkv=(1024, 8, True), o=(512, 6, False), gate_up=(2048, 8, True), down=(1024, 8, False))
+    G1_CFG = dict(qkv=(896, 8, True), o=(512, 6, False), gate_up=(2048, 8, True), down=(896, 8, False))
     # the same for 64-row windows (two prompts per forward, or a draft window of 32): the staged chunk is twice as tall, so KC <= 1280;
     # set `model.G1_CFG = model.G1_CFG_64ROW` before enable_fused (the packing depends on KC).  Tuned end to end at Lumina-7B shapes.
-    G1_CFG_64ROW = dict(qkv=(1024, 8, True), o=(512, 8, False), gate_up=(1024, 16, True), down=(1024, 8, False))
+    G1_CFG_64ROW = dict(qkv=(896, 8, True), o=(512, 8, False), gate_up=(1024, 12, True), down=(896, 8, False))      # profiles/r2_g1_launch_shape_sweep_64rows.jsonl
     # Emu3-Gen 8B (GQA 32/8: the q|k|v projection has 6144 columns; draft window 32 -> 64 rows), tuned end to end with bench.py --model emu3_8b
-    G1_CFG_EMU3 = dict(G1_CFG_64ROW, qkv=(512, 6, True))
+    G1_CFG_EMU3 = dict(qkv=(512, 8, False), o=(512, 8, False), gate_up=(1024, 16, True), down=(896, 8, False))       # profiles/r2_g1_launch_shape_sweep_emu3_64rows.jsonl
 
     # Weight prefetch plan of the G1 window forward: projection -> (workgroups of the prefetch kernel, when it is issued).  The packed
     # weights of projection j+1 are read into the Infinity Cache on a side stream (a parallel branch of the forward hipGraph)

@@ -83,31 +83,35 @@ def main():
     ap.add_argument("--per-launch", action="store_true", help="one event pair per launch (includes ~4 us dispatch latency)")
     ap.add_argument("--product", action="store_true", help="per-shape (KC, waves, layout) of backbones.G1_CFG")
     ap.add_argument("--sweep", action="store_true", help="grid over KC x waves x layout per shape (one JSON line per point, best first at the end)")
+    ap.add_argument("--rows", type=int, default=32, help="window rows (64: draft window 32 or two prompts; the staged chunk must then be <= 1280 columns)")
+    ap.add_argument("--emu3", action="store_true", help="Emu3-Gen 8B projection shapes (GQA 32/8, intermediate 14336) instead of Lumina-7B")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     if os.environ.get("SJD_SO"):
         L.SO_PATH = os.environ["SJD_SO"]
     lib = L.load()
+    if a.emu3:
+        SHAPES.update(qkv=(6144, 4096, 512), o=(4096, 4096, 512), gate_up=(28672, 4096, 1024), down=(4096, 14336, 1024))
     if a.sweep:
         for name, (N, K, _) in SHAPES.items():
             if a.only and name != a.only:
                 continue
-            x = torch.randn(32, K, device=dev).to(torch.bfloat16)
+            x = torch.randn(a.rows, K, device=dev).to(torch.bfloat16)
             ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16) for _ in range(a.copies)]
             rows = []
             for sm in (1, 0):
-                for KC in (256, 512, 688, 1024, 1376, 2048):
-                    if KC > K or (name == "down" and KC == 2048):
+                for KC in (256, 512, 688, 896, 1024, 1280, 1376, 1536, 2048):
+                    if KC > K or (name == "down" and KC == 2048) or (a.rows > 32 and KC > 1280) or K % 16:
                         continue
                     wps = [ops.pack_weight(w, KC, bool(sm)) for w in ws]
                     nc = (K + KC - 1) // KC
-                    out = torch.empty(nc, 32, N, dtype=torch.float32, device=dev)
+                    out = torch.empty(nc, 32 if a.rows <= 32 else 64, N, dtype=torch.float32, device=dev)
                     for waves in (4, 6, 8, 11, 12, 16):
                         n_wg = ((N // 32 + waves - 1) // waves) * nc
 
                         def g1(i, wps=wps, KC=KC, waves=waves, sm=sm, out=out):
                             L.check(lib.sjd_skinny_gemm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % a.copies].data_ptr()),
-                                                        ctypes.c_void_p(out.data_ptr()), 32, N, K, KC, waves, sm, 0,
+                                                        ctypes.c_void_p(out.data_ptr()), a.rows, N, K, KC, waves, sm, 0,
                                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "g1")
                         avg, _ = timed_graph(g1, a.launches, lib)
                         r = dict(shape=name, KC=KC, waves=waves, step_major=sm, workgroups=n_wg, us=round(avg * 1e3, 2),

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--per-launch", action="store_true", help="one event pair per launch (includes ~4 us dispatch latency)")
     ap.add_argument("--product", action="store_true", help="per-shape (KC, waves, layout) of backbones.G1_CFG")
     ap.add_argument("--sweep", action="store_true", help="grid over KC x waves x layout per shape (one JSON line per point, best first at the end)")
+    ap.add_argument("--fine", action="store_true", help="with --sweep: KC in steps of 64 and waves 6..12, one layout per shape")
     ap.add_argument("--rows", type=int, default=32, help="window rows (64: draft window 32 or two prompts; the staged chunk must then be <= 1280 columns)")
     ap.add_argument("--emu3", action="store_true", help="Emu3-Gen 8B projection shapes (GQA 32/8, intermediate 14336) instead of Lumina-7B")
     a = ap.parse_args()
@@ -99,14 +100,14 @@ def main():
             x = torch.randn(a.rows, K, device=dev).to(torch.bfloat16)
             ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16) for _ in range(a.copies)]
             rows = []
-            for sm in (1, 0):
-                for KC in (256, 512, 688, 896, 1024, 1280, 1376, 1536, 2048):
+            for sm in ((1,) if name in ("qkv", "gate_up") else (0,)) if a.fine else (1, 0):
+                for KC in (range(512, 2049, 64) if a.fine else (256, 512, 688, 896, 1024, 1280, 1376, 1536, 2048)):
                     if KC > K or (name == "down" and KC == 2048) or (a.rows > 32 and KC > 1280) or K % 16:
                         continue
                     wps = [ops.pack_weight(w, KC, bool(sm)) for w in ws]
                     nc = (K + KC - 1) // KC
                     out = torch.empty(nc, 32 if a.rows <= 32 else 64, N, dtype=torch.float32, device=dev)
-                    for waves in (4, 6, 8, 11, 12, 16):
+                    for waves in ((6, 7, 8, 9, 10, 12) if a.fine else (4, 6, 8, 11, 12, 16)):
                         n_wg = ((N // 32 + waves - 1) // waves) * nc
 
                         def g1(i, wps=wps, KC=KC, waves=waves, sm=sm, out=out):

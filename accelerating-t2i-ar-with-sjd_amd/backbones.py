@@ -508,7 +508,7 @@ class ChameleonBackbone(nn.Module):
         into the consuming glue kernel (F2 / F1 / F3 / F1)."""
         ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
         T, eps, cfg = B * n, self.args.rms_norm_eps, self.G1_CFG
-        cap = 2560 if T <= 32 else 1280           # the staged activation chunk (32 or 64 rows) must fit in LDS
+        cap = 2560 if T <= 32 else 1280 if T <= 64 else 1 << 30     # the staged activation chunk (32 / 64 rows) must fit in LDS; 65..128 rows are sub-tiled
         if any(c[0] > cap for c in cfg.values()):
             raise ValueError(f"G1_CFG chunk sizes must be <= {cap} for a {T}-row window")
         g1 = lambda x_, name, N_, K_: ops.skinny_gemm(x_, self._packed[li][name], N_, K_, cfg[name][0], cfg[name][1], cfg[name][2])
@@ -532,7 +532,9 @@ class ChameleonBackbone(nn.Module):
         return _head_logits(self.lm_head, x, cols).view(B, n, -1)
 
     def _forward_window_fused(self, tokens, positions, kv_len, key_start, cols=None, head_partials=False):
-        if self._gemm == "sjd" and tokens.shape[0] * tokens.shape[1] <= 64:
+        T_ = tokens.shape[0] * tokens.shape[1]
+        # G1 serves windows: <= 64 rows, or <= 128 rows of up to four prompts' draft windows (n <= 32 rows per batch row); longer inputs are prefill
+        if self._gemm == "sjd" and (T_ <= 64 or (T_ <= 128 and tokens.shape[1] <= 32)):
             if self._fold_norm:
                 return self._forward_window_g1_folded(tokens, positions, kv_len, key_start, cols, head_partials)
             return self._forward_window_g1(tokens, positions, kv_len, key_start, cols)

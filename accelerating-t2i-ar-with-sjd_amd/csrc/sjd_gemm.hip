@@ -147,6 +147,118 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
 }
 
 
+// ---- windows of 65..128 rows (three / four prompts per forward): MT = 3, 4.
+// The whole activation chunk no longer fits in LDS (128 rows x 896 columns = 224 KiB), so it is staged in SUB-TILES of G1_SUB k-steps
+// (256 columns: MT x 16 KiB), double-buffered: the global loads of sub-tile i+1 are issued before the MFMAs of sub-tile i and land in
+// the other LDS buffer behind them.  The weight pipeline (8 records in flight behind the 8 being multiplied) runs through unchanged, so
+// KC -- and with it the number of fp32 partial planes the consumer sums -- stays what it is for 32 rows.  <= 8 waves (256 VGPRs).
+#define G1_SUB 16
+template <int DT, int MT>
+__global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
+                                                                     float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
+                                                                     int rec_stride, int tile0)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *xl = reinterpret_cast<u32x4 *>(smem);                 // two buffers of MT * G1_SUB records
+    const int chunk = blockIdx.y;
+    const int k0 = chunk * KC;
+    const int steps = min(KC, K - k0) / 16;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int t_out = blockIdx.x * waves + w;
+    const int t = tile0 + t_out;
+    const bool has_tile = t_out < N / 32;                        // (a wave without a tile still stages x and keeps the barriers)
+    const size_t chunk_base = (size_t)chunk * n_tiles * (KC / 16);
+    const size_t tile_off = (rec_stride == 1) ? (size_t)(has_tile ? t : 0) * steps : (size_t)(has_tile ? t : 0);
+    const u32x4 *wu = wp + (chunk_base + tile_off) * 64 + lane;
+    const size_t rs = (size_t)rec_stride * 64;
+    const int n_sub = (steps + G1_SUB - 1) / G1_SUB, nth = blockDim.x;
+    constexpr int BUF = MT * G1_SUB * 64;                         // u32x4 per LDS buffer
+    constexpr int PPR = 2 * G1_SUB;                               // 16-byte pieces per row of a full sub-tile
+    u32x4 cur[G1_UNROLL], nxt[G1_UNROLL];
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    // piece v of a sub-tile: row m = v / PPR, piece j = v % PPR (k-step s = j / 2 of the sub-tile, half j & 1)
+    auto x_load = [&](int st, int v) -> u32x4 {
+        const int m = v / PPR, j = v - m * PPR, sub_steps = min(G1_SUB, steps - st * G1_SUB);
+        if (v < MT * 32 * PPR && m < M && j < 2 * sub_steps) return *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + st * (16 * G1_SUB) + 8 * j);
+        return u32x4{0u, 0u, 0u, 0u};
+    };
+    auto x_store = [&](int buf, int v, u32x4 val) {
+        const int m = v / PPR, j = v - m * PPR, sl = j >> 1;
+        if (v < MT * 32 * PPR) xl[buf * BUF + ((m >> 5) * G1_SUB + sl) * 64 + g1_slot(j & 1, m & 31, sl)] = val;
+    };
+    constexpr int NV = (MT * 32 * PPR + 511) / 512;               // pieces per thread and sub-tile at 512 threads (MT = 4: 8)
+    {
+        u32x4 val[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) val[i] = x_load(0, threadIdx.x + i * nth);
+        if (has_tile && steps >= G1_UNROLL) {
+#pragma unroll
+            for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) x_store(0, threadIdx.x + i * nth, val[i]);
+        if (nth < 512)                                             // fewer than 8 waves: the remaining pieces, plainly
+            for (int v = threadIdx.x + NV * nth; v < MT * 32 * PPR; v += nth) x_store(0, v, x_load(0, v));
+    }
+    __syncthreads();
+    const int full = steps / G1_UNROLL;                           // whole groups of the chunk; group g lives in sub-tile g / (G1_SUB / G1_UNROLL)
+    for (int st = 0; st < n_sub; ++st) {
+        const bool more_x = st + 1 < n_sub;
+        const u32x4 *xb = xl + (st & 1) * BUF;
+        u32x4 val[NV];
+        if (more_x) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) val[i] = x_load(st + 1, threadIdx.x + i * nth);
+        }
+        if (has_tile) {
+            const int s0 = st * G1_SUB, s1 = min(steps, s0 + G1_SUB);
+            int sl = 0;
+            for (int g = s0 / G1_UNROLL; (g + 1) * G1_UNROLL <= s1; ++g, sl += G1_UNROLL) {
+                const bool more = g + 1 < full;
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < G1_UNROLL; ++u) nxt[u] = __builtin_nontemporal_load(wu + (size_t)((g + 1) * G1_UNROLL + u) * rs);
+                }
+#pragma unroll
+                for (int u = 0; u < G1_UNROLL; ++u)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = G1Mfma<DT>::mma(xb[(mt * G1_SUB + sl + u) * 64 + g1_slot(lane >> 5, lane & 31, u)], cur[u], acc[mt]);
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < G1_UNROLL; ++u) cur[u] = nxt[u];
+                }
+            }
+            for (int sg = s0 + sl; sg < s1; ++sg, ++sl) {            // ragged tail of the chunk (steps not a multiple of 8)
+                const u32x4 wv = __builtin_nontemporal_load(wu + (size_t)sg * rs);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(xb[(mt * G1_SUB + sl) * 64 + g1_slot(lane >> 5, lane & 31, sl)], wv, acc[mt]);
+            }
+        }
+        if (more_x) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) x_store((st + 1) & 1, threadIdx.x + i * nth, val[i]);
+            if (nth < 512)
+                for (int v = threadIdx.x + NV * nth; v < MT * 32 * PPR; v += nth) x_store((st + 1) & 1, v, x_load(st + 1, v));
+        }
+        __syncthreads();
+    }
+    if (!has_tile) return;
+    float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t_out * 32 + (lane & 31);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            o[(size_t)m * N] = acc[mt][r];
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ weight prefetch
 // While the latency-bound kernels of a layer run (F1r / F2 / K1 / combine / F3: ~1.15 ms of a 3.9 ms step, rocprofv3 round 1) HBM is
 // idle although the step as a whole is bound by the 13 GB weight stream.  This kernel, launched on a SIDE stream (a parallel branch of
@@ -184,39 +296,56 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
     const int n_out = N / 32, n_tiles = n_tiles_packed > 0 ? n_tiles_packed : n_out, n_chunks = (K + KC - 1) / KC;
     if (tile0 < 0 || tile0 + n_out > n_tiles) return SJD_ERR_BAD_ARG;
     const dim3 grid((n_out + waves - 1) / waves, n_chunks), block(waves * 64);
-    const size_t lds = (size_t)MT * ((KC < K ? KC : K) / 16) * 64 * 16;       // the staged activation chunk
-    if (lds > 160 * 1024) return SJD_ERR_BAD_ARG;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((g1_skinny_gemm<DT, MT>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles,
-                       step_major ? n_tiles : 1, tile0);
-    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+    if constexpr (MT > 2) {                                    // sub-tiled activation (g1_skinny_gemm_tiled)
+        if (waves > 8) return SJD_ERR_BAD_ARG;
+        const size_t lds_t = (size_t)2 * MT * G1_SUB * 1024;
+        (void)hipFuncSetAttribute((const void *)g1_skinny_gemm_tiled<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+        hipLaunchKernelGGL((g1_skinny_gemm_tiled<DT, MT>), grid, block, lds_t, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC,
+                           n_tiles, step_major ? n_tiles : 1, tile0);
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+    } else {
+        const size_t lds = (size_t)MT * ((KC < K ? KC : K) / 16) * 64 * 16;       // the staged activation chunk
+        if (lds > 160 * 1024) return SJD_ERR_BAD_ARG;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((g1_skinny_gemm<DT, MT>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles,
+                           step_major ? n_tiles : 1, tile0);
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+    }
 }
 
 // Column window of a packed weight: out[c, m, j] for the N = 32 * n columns [32 * tile0, 32 * tile0 + N) of a weight packed with N_packed columns.
 extern "C" int sjd_skinny_gemm_cols(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,
                                     int dtype, int N_packed, int tile0, void *stream)
 {
-    if (!x || !w_packed || !out || M < 1 || M > 64 || N < 32 || (N % 32) != 0 || (N_packed % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0)
+    if (!x || !w_packed || !out || M < 1 || M > 128 || N < 32 || (N % 32) != 0 || (N_packed % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0)
         return SJD_ERR_BAD_ARG;
     if (waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int np = N_packed / 32;
     if (dtype == SJD_DTYPE_BF16 && M <= 32) return g1_launch<SJD_DTYPE_BF16, 1>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
     if (dtype == SJD_DTYPE_F16 && M <= 32) return g1_launch<SJD_DTYPE_F16, 1>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
-    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
-    if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_BF16 && M <= 64) return g1_launch<SJD_DTYPE_BF16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_F16 && M <= 64) return g1_launch<SJD_DTYPE_F16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_BF16 && M <= 96) return g1_launch<SJD_DTYPE_BF16, 3>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_F16 && M <= 96) return g1_launch<SJD_DTYPE_F16, 3>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
     return SJD_ERR_UNSUPPORTED;
 }
 
 extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,
                                int dtype, void *stream)
 {
-    if (!x || !w_packed || !out || M < 1 || M > 64 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
+    if (!x || !w_packed || !out || M < 1 || M > 128 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
     if (waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;       // (the staged activation chunk must fit in LDS: min(KC, K) <= 2560 / 1280)
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SJD_DTYPE_BF16 && M <= 32) return g1_launch<SJD_DTYPE_BF16, 1>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
     if (dtype == SJD_DTYPE_F16 && M <= 32) return g1_launch<SJD_DTYPE_F16, 1>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
-    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
-    if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_BF16 && M <= 64) return g1_launch<SJD_DTYPE_BF16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_F16 && M <= 64) return g1_launch<SJD_DTYPE_F16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_BF16 && M <= 96) return g1_launch<SJD_DTYPE_BF16, 3>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_F16 && M <= 96) return g1_launch<SJD_DTYPE_F16, 3>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
     return SJD_ERR_UNSUPPORTED;
 }

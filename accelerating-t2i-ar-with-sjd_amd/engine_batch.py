@@ -40,8 +40,8 @@ class SJDBatchEngine:
         L.load()                                   # fail loudly if the HIP extension is missing
         if max_window > L.MAX_WINDOW:
             raise ValueError(f"max_window {max_window} > {L.MAX_WINDOW}")
-        if n_prompts * n_batch * max_window > 64:
-            raise ValueError("the window forward (G1, F1-F3) serves at most 64 rows: n_prompts * n_batch * max_window <= 64")
+        if n_prompts * n_batch * max_window > 128:
+            raise ValueError("the window forward (G1, F1-F3) serves at most 128 rows: n_prompts * n_batch * max_window <= 128")
         self.backbone, self.V, self.device = backbone, int(vocab_size), torch.device(device)
         self.P, self.nb, self.Lmax, self.B = n_prompts, n_batch, max_window, n_prompts * n_batch
         self.use_graph, self.narrow_head = use_graph, narrow_head

@@ -210,12 +210,17 @@ def pack_weight(weight, KC, step_major=False):
     return torch.cat(out).contiguous()
 
 
+def _prows(M):
+    """row padding of the G1 partial planes: whole 32-row MFMA tiles (M <= 128: up to four prompts per forward)"""
+    return ((int(M) + 31) // 32) * 32
+
+
 def skinny_gemm(x, w_packed, N, K, KC, waves=4, step_major=False):
-    """x [M<=64, K] bf16/fp16 -> Partials([n_chunks, 32 or 64, N] fp32)."""
+    """x [M<=128, K] bf16/fp16 -> Partials([n_chunks, 32 * ceil(M / 32), N] fp32)."""
     M = x.shape[0]
     assert x.is_contiguous() and x.shape[1] == K and w_packed.numel() == N * K
     nc = (K + KC - 1) // KC
-    out = torch.empty(nc, 32 if M <= 32 else 64, N, dtype=torch.float32, device=x.device)
+    out = torch.empty(nc, _prows(M), N, dtype=torch.float32, device=x.device)
     L.check(L.load().sjd_skinny_gemm(_ptr(x), _ptr(w_packed), _ptr(out), M, N, K, KC, waves, int(step_major), _dtype_code(x.dtype), _stream()), "sjd_skinny_gemm")
     return Partials(out, nc, N)
 
@@ -239,7 +244,7 @@ def skinny_gemm_cols(x, w_packed, N_packed, K, KC, col0, n_cols, waves=8, step_m
     M = x.shape[0]
     assert x.is_contiguous() and x.shape[1] == K and w_packed.numel() == N_packed * K and col0 % 32 == 0 and n_cols % 32 == 0
     nc = (K + KC - 1) // KC
-    out = torch.empty(nc, 32 if M <= 32 else 64, n_cols, dtype=torch.float32, device=x.device)
+    out = torch.empty(nc, _prows(M), n_cols, dtype=torch.float32, device=x.device)
     L.check(L.load().sjd_skinny_gemm_cols(_ptr(x), _ptr(w_packed), _ptr(out), M, n_cols, K, KC, waves, int(step_major), _dtype_code(x.dtype),
                                          N_packed, col0 // 32, _stream()), "sjd_skinny_gemm_cols")
     return Partials(out, nc, n_cols)
@@ -365,7 +370,7 @@ def residual_sumsq(h, part=None):
     of h^2 [slices, R] fp32 -- the `sumsq` of a row_norm."""
     T, hidden = h.shape
     assert h.is_contiguous() and (part is None or (isinstance(part, Partials) and part.N == hidden))
-    R = part.data.shape[1] if part is not None else (32 if T <= 32 else 64)
+    R = part.data.shape[1] if part is not None else _prows(T)
     out = torch.empty((hidden + 511) // 512, R, dtype=torch.float32, device=h.device)
     L.check(L.load().sjd_residual_sumsq(_ptr(h), _ptr(part.data) if part is not None else None, part.n_chunks if part is not None else 0,
                                        T, hidden, _dtype_code(h.dtype), _ptr(out), _stream()), "sjd_residual_sumsq")

@@ -119,9 +119,34 @@ def test_g1_skinny_gemm(dev, dtype, M, N, K, KC, waves, step_major):
     got = part.data.sum(0)[:M]
     ref = x.float() @ w.float().t()
     torch.testing.assert_close(got, ref, atol=2e-3, rtol=2e-3)
-    assert part.data.shape[1] == (32 if M <= 32 else 64)
+    assert part.data.shape[1] == ((M + 31) // 32) * 32
     if M < part.data.shape[1]:
         assert part.data[:, M:].abs().max() == 0        # missing rows are zero, not garbage
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,KC", [(128, 4096, 11008, 896), (96, 12288, 4096, 896), (128, 22016, 4096, 2048), (100, 512, 1376, 256),
+                                        (128, 64, 96, 32), (128, 4096, 4096, 1040), (65, 256, 176, 64), (128, 6144, 4096, 512)])
+@pytest.mark.parametrize("waves,step_major", [(8, True), (8, False), (6, False), (3, True)])
+def test_g1_skinny_gemm_three_and_four_row_tiles(dev, dtype, M, N, K, KC, waves, step_major):
+    """65..128-row windows (three / four prompts per forward): the sub-tiled G1 (activation double-buffered through LDS 256 columns at a
+    time) against an fp32 matmul; chunk lengths that are not whole sub-tiles / whole 8-step groups included."""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(N + K + M)
+    x = torch.randn(M, K, generator=g).to(dtype).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    part = ops.skinny_gemm(x, ops.pack_weight(w, KC, step_major), N, K, KC, waves=waves, step_major=step_major)
+    assert part.n_chunks == (K + KC - 1) // KC and part.data.shape[1] == ((M + 31) // 32) * 32
+    torch.testing.assert_close(part.data.sum(0)[:M], x.float() @ w.float().t(), atol=2e-3, rtol=2e-3)
+    if M < part.data.shape[1]:
+        assert part.data[:, M:].abs().max() == 0
+    # the same rows through the 32-row kernel, 32 at a time: identical partial planes (same chunking, same accumulation order)
+    for r0 in range(0, M, 32):
+        p32 = ops.skinny_gemm(x[r0:r0 + 32].contiguous(), ops.pack_weight(w, KC, step_major), N, K, KC, waves=waves, step_major=step_major)
+        rows = min(32, M - r0)
+        assert torch.equal(p32.data[:, :rows], part.data[:, r0:r0 + rows])
+    with pytest.raises(RuntimeError):
+        ops.skinny_gemm(x, ops.pack_weight(w, KC, step_major), N, K, KC, waves=11, step_major=step_major)      # > 8 waves: 256 VGPRs needed
 
 
 def test_partials_feed_glue_kernels(dev):
@@ -178,7 +203,7 @@ def test_g1_forward_matches_library_gemm_forward(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M", [32, 17, 64])
+@pytest.mark.parametrize("M", [32, 17, 64, 96, 128])
 @pytest.mark.parametrize("N,K,KC", [(4096, 4096, 256), (512, 1376, 256), (1536, 2752, 1024)])
 def test_f1r_residual_sumsq_and_row_norm_consumers(dev, dtype, M, N, K, KC):
     """F1r: the residual half of F1 (h bit-identical), per-slice sums of h^2; F2 / F3 with `row_norm` on a projection of the RAW
@@ -193,7 +218,7 @@ def test_f1r_residual_sumsq_and_row_norm_consumers(dev, dtype, M, N, K, KC):
     h_a, h_b, h_c = h.clone(), h.clone(), h.clone()
     y = ops.add_rmsnorm(h_a, part, gamma, 1e-5)
     sumsq = ops.residual_sumsq(h_b, part)
-    assert torch.equal(h_a, h_b) and sumsq.shape == ((N + 511) // 512, 32 if M <= 32 else 64)
+    assert torch.equal(h_a, h_b) and sumsq.shape == ((N + 511) // 512, ((M + 31) // 32) * 32)
     torch.testing.assert_close(sumsq.sum(0)[:M], h_b.float().pow(2).sum(-1), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(ops.residual_sumsq(h_c, None).sum(0)[:M], h.float().pow(2).sum(-1), rtol=1e-4, atol=1e-3)
     assert torch.equal(h_c, h)
@@ -211,7 +236,7 @@ def test_f1r_residual_sumsq_and_row_norm_consumers(dev, dtype, M, N, K, KC):
     wqf = (wq.float() * gamma.float()[None, :]).to(dtype)
     inv = (1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))).to(dev)
     pos = torch.arange(M, device=dev)
-    caches = [torch.zeros(B, Hkv, 96, D, dtype=dtype, device=dev) for _ in range(4)]
+    caches = [torch.zeros(B, Hkv, 192, D, dtype=dtype, device=dev) for _ in range(4)]
     q_ref = ops.qknorm_rope_append(ops.skinny_gemm(y, ops.pack_weight(wq, kc2), wq.shape[0], N, kc2), caches[0], caches[1],
                                    None, None, None, None, inv, pos, B, n, H, Hkv, D, None, 3, dtype=dtype)
     q_got = ops.qknorm_rope_append(ops.skinny_gemm(h_b, ops.pack_weight(wqf, kc2), wq.shape[0], N, kc2), caches[2], caches[3],

@@ -81,6 +81,14 @@ def test_two_prompts_share_one_window_forward(gemm, use_graph, fp8_kv):
     assert rs[0]["nfe"] != rs[1]["nfe"] or True
 
 
+@pytest.mark.parametrize("n_prompts,fp8_kv", [(3, False), (4, False), (4, True)])
+def test_three_and_four_prompts_share_one_window_forward(n_prompts, fp8_kv):
+    """96 / 128 window rows per forward (G1's sub-tiled three- and four-tile kernel, F1r / F2 / F3 over 128 rows, K1 over 8 batch rows):
+    every slot still takes exactly the decisions of its own oracle replay."""
+    rs = G.teacher_forced_batch_check(n_prompts=n_prompts, P=(12, 9, 14, 7), fp8_kv=fp8_kv)
+    assert len(rs) == n_prompts and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs) and any(r["max_accept"] > 1 for r in rs)
+
+
 def test_emu3_reference_api_flow(dev):
     """A14 / A18: renew_solver + prepare_batch_cfg_model_inputs + HF-shaped generate, executed (reference JE:234-278, 370-411;
     test_emu3.py:145-169), teacher-forced against the oracle."""

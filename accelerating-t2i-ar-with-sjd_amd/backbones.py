@@ -351,6 +351,8 @@ class ChameleonBackbone(nn.Module):
     # the same for 64-row windows (two prompts per forward, or a draft window of 32): the staged chunk is twice as tall, so KC <= 1280;
     # set `model.G1_CFG = model.G1_CFG_64ROW` before enable_fused (the packing depends on KC).  Tuned end to end at Lumina-7B shapes.
     G1_CFG_64ROW = dict(qkv=(896, 8, True), o=(512, 8, False), gate_up=(1024, 12, True), down=(896, 8, False))      # profiles/r2_g1_launch_shape_sweep_64rows.jsonl
+    # 65..128-row windows (three / four prompts per forward): the activation is sub-tiled, so KC is free again, but <= 8 waves
+    G1_CFG_128ROW = dict(qkv=(896, 8, True), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))
     # Emu3-Gen 8B (GQA 32/8: the q|k|v projection has 6144 columns; draft window 32 -> 64 rows), tuned end to end with bench.py --model emu3_8b
     G1_CFG_EMU3 = dict(qkv=(512, 8, False), o=(512, 8, False), gate_up=(1024, 16, True), down=(896, 8, False))       # profiles/r2_g1_launch_shape_sweep_emu3_64rows.jsonl
 

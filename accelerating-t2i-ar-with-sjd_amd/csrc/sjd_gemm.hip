@@ -148,11 +148,35 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
 
 
 // ---- windows of 65..128 rows (three / four prompts per forward): MT = 3, 4.
-// The whole activation chunk no longer fits in LDS (128 rows x 896 columns = 224 KiB), so it is staged in SUB-TILES of G1_SUB k-steps
-// (256 columns: MT x 16 KiB), double-buffered: the global loads of sub-tile i+1 are issued before the MFMAs of sub-tile i and land in
-// the other LDS buffer behind them.  The weight pipeline (8 records in flight behind the 8 being multiplied) runs through unchanged, so
-// KC -- and with it the number of fp32 partial planes the consumer sums -- stays what it is for 32 rows.  <= 8 waves (256 VGPRs).
+// The whole activation chunk no longer fits in LDS (128 rows x 896 columns = 224 KiB), so it is staged in SUB-TILES of G1_SUB = 16 k-steps
+// (256 columns: MT x 16 KiB), double-buffered: the global loads of sub-tile i+1 are issued before the MFMAs of sub-tile i and written to
+// the other LDS buffer behind them.  KC -- and with it the number of fp32 partial planes the consumer sums -- stays what it is for 32 rows.
+// With four MFMAs per weight record the wave is no longer idle between memory round trips, so the loop is written for the scheduler:
+//   * a sub-tile is exactly two weight groups held in two register sets A and B that alternate WITHOUT copies; the group after next is
+//     requested before the MFMAs of the current one, so 8 KiB per wave stay in flight through the MFMAs AND through the barrier;
+//   * every load is unconditional (row / column / group indices are clamped, invalid pieces are zeroed after the load, a wave without a
+//     column tile multiplies tile 0 and skips the store): straight-line code, for which the compiler's s_waitcnt counts are exact
+//     (vmcnt(N) leaves the younger loads in flight; a conditional load forces vmcnt(0));
+//   * the A operands of k-step u+1 are read from LDS while the MFMAs of k-step u issue.
+// <= 8 waves (up to 256 VGPRs).
 #define G1_SUB 16
+template <int DT, int MT>
+__device__ __forceinline__ void g1_group(const u32x4 *__restrict__ xb, int sl0, const u32x4 (&W)[G1_UNROLL], f32x16 (&acc)[MT], int lane)
+{
+    u32x4 a[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[0][mt] = xb[(mt * G1_SUB + sl0) * 64 + g1_slot(lane >> 5, lane & 31, 0)];
+#pragma unroll
+    for (int u = 0; u < G1_UNROLL; ++u) {
+        if (u + 1 < G1_UNROLL) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[(u + 1) & 1][mt] = xb[(mt * G1_SUB + sl0 + u + 1) * 64 + g1_slot(lane >> 5, lane & 31, u + 1)];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(a[u & 1][mt], W[u], acc[mt]);
+    }
+}
+
 template <int DT, int MT>
 __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                      float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
@@ -166,87 +190,97 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const int t_out = blockIdx.x * waves + w;
-    const int t = tile0 + t_out;
-    const bool has_tile = t_out < N / 32;                        // (a wave without a tile still stages x and keeps the barriers)
+    const bool has_tile = t_out < N / 32;                        // a wave without a tile multiplies tile 0 and stores nothing
+    const int t = tile0 + (has_tile ? t_out : 0);
     const size_t chunk_base = (size_t)chunk * n_tiles * (KC / 16);
-    const size_t tile_off = (rec_stride == 1) ? (size_t)(has_tile ? t : 0) * steps : (size_t)(has_tile ? t : 0);
+    const size_t tile_off = (rec_stride == 1) ? (size_t)t * steps : (size_t)t;
     const u32x4 *wu = wp + (chunk_base + tile_off) * 64 + lane;
     const size_t rs = (size_t)rec_stride * 64;
-    const int n_sub = (steps + G1_SUB - 1) / G1_SUB, nth = blockDim.x;
+    const int nth = blockDim.x;
     constexpr int BUF = MT * G1_SUB * 64;                         // u32x4 per LDS buffer
-    constexpr int PPR = 2 * G1_SUB;                               // 16-byte pieces per row of a full sub-tile
-    u32x4 cur[G1_UNROLL], nxt[G1_UNROLL];
+    constexpr int PPR = 2 * G1_SUB;                               // 16-byte pieces per row of a sub-tile
+    constexpr int NP = MT * 32 * PPR;                             // pieces per sub-tile
+    constexpr int NV = NP / 512;                                  // pieces per thread at 512 threads (2 MT)
+    const int full = steps / G1_UNROLL;                           // whole weight groups of the chunk
+    const int n_sub_full = steps / G1_SUB, rem = steps - n_sub_full * G1_SUB;
+    const int k_end = k0 + steps * 16;
+    u32x4 A[G1_UNROLL], B[G1_UNROLL];
     f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-    // piece v of a sub-tile: row m = v / PPR, piece j = v % PPR (k-step s = j / 2 of the sub-tile, half j & 1)
+    // piece v of sub-tile st: row m = v / PPR, 8 columns from k0 + 256 st + 8 (v % PPR); always a legal address, zero if outside the chunk
     auto x_load = [&](int st, int v) -> u32x4 {
-        const int m = v / PPR, j = v - m * PPR, sub_steps = min(G1_SUB, steps - st * G1_SUB);
-        if (v < MT * 32 * PPR && m < M && j < 2 * sub_steps) return *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + st * (16 * G1_SUB) + 8 * j);
-        return u32x4{0u, 0u, 0u, 0u};
+        const int m = v / PPR, j = v - m * PPR, col = k0 + st * (16 * G1_SUB) + 8 * j;
+        const u32x4 val = *reinterpret_cast<const u32x4 *>(x + (size_t)min(m, M - 1) * K + min(col, K - 8));
+        return (m < M && col < k_end) ? val : u32x4{0u, 0u, 0u, 0u};
     };
     auto x_store = [&](int buf, int v, u32x4 val) {
         const int m = v / PPR, j = v - m * PPR, sl = j >> 1;
-        if (v < MT * 32 * PPR) xl[buf * BUF + ((m >> 5) * G1_SUB + sl) * 64 + g1_slot(j & 1, m & 31, sl)] = val;
+        xl[buf * BUF + ((m >> 5) * G1_SUB + sl) * 64 + g1_slot(j & 1, m & 31, sl)] = val;
     };
-    constexpr int NV = (MT * 32 * PPR + 511) / 512;               // pieces per thread and sub-tile at 512 threads (MT = 4: 8)
+    auto w_load = [&](u32x4 (&W)[G1_UNROLL], int g) {
+        const int gc = max(0, min(g, full - 1));                  // clamped: a group past the end re-reads the last one and is not used
+#pragma unroll
+        for (int u = 0; u < G1_UNROLL; ++u) W[u] = __builtin_nontemporal_load(wu + (size_t)(gc * G1_UNROLL + u) * rs);
+    };
+    auto stage = [&](int st_next, int buf, u32x4 (&val)[NV], bool load) {      // (load / store halves of staging sub-tile st_next)
+        if (load) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) val[i] = x_load(st_next, min(threadIdx.x + i * nth, NP - 1));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (threadIdx.x + i * nth < NP) x_store(buf, threadIdx.x + i * nth, val[i]);
+            for (int v = threadIdx.x + NV * nth; v < NP; v += nth) x_store(buf, v, x_load(st_next, v));      // fewer than 8 waves
+        }
+    };
     {
         u32x4 val[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) val[i] = x_load(0, threadIdx.x + i * nth);
-        if (has_tile && steps >= G1_UNROLL) {
-#pragma unroll
-            for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);
-        }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) x_store(0, threadIdx.x + i * nth, val[i]);
-        if (nth < 512)                                             // fewer than 8 waves: the remaining pieces, plainly
-            for (int v = threadIdx.x + NV * nth; v < MT * 32 * PPR; v += nth) x_store(0, v, x_load(0, v));
+        stage(0, 0, val, true);
+        if (steps >= G1_UNROLL) w_load(A, 0);
+        stage(0, 0, val, false);
     }
     __syncthreads();
-    const int full = steps / G1_UNROLL;                           // whole groups of the chunk; group g lives in sub-tile g / (G1_SUB / G1_UNROLL)
-    for (int st = 0; st < n_sub; ++st) {
-        const bool more_x = st + 1 < n_sub;
+    // all full sub-tiles but the last: the next sub-tile and the group after next always exist -> unconditional, straight-line
+    for (int st = 0; st + 1 < n_sub_full; ++st) {
         const u32x4 *xb = xl + (st & 1) * BUF;
         u32x4 val[NV];
-        if (more_x) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) val[i] = x_load(st + 1, threadIdx.x + i * nth);
-        }
-        if (has_tile) {
-            const int s0 = st * G1_SUB, s1 = min(steps, s0 + G1_SUB);
-            int sl = 0;
-            for (int g = s0 / G1_UNROLL; (g + 1) * G1_UNROLL <= s1; ++g, sl += G1_UNROLL) {
-                const bool more = g + 1 < full;
-                if (more) {
-#pragma unroll
-                    for (int u = 0; u < G1_UNROLL; ++u) nxt[u] = __builtin_nontemporal_load(wu + (size_t)((g + 1) * G1_UNROLL + u) * rs);
-                }
-#pragma unroll
-                for (int u = 0; u < G1_UNROLL; ++u)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = G1Mfma<DT>::mma(xb[(mt * G1_SUB + sl + u) * 64 + g1_slot(lane >> 5, lane & 31, u)], cur[u], acc[mt]);
-                if (more) {
-#pragma unroll
-                    for (int u = 0; u < G1_UNROLL; ++u) cur[u] = nxt[u];
-                }
-            }
-            for (int sg = s0 + sl; sg < s1; ++sg, ++sl) {            // ragged tail of the chunk (steps not a multiple of 8)
-                const u32x4 wv = __builtin_nontemporal_load(wu + (size_t)sg * rs);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(xb[(mt * G1_SUB + sl) * 64 + g1_slot(lane >> 5, lane & 31, sl)], wv, acc[mt]);
-            }
-        }
-        if (more_x) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) x_store((st + 1) & 1, threadIdx.x + i * nth, val[i]);
-            if (nth < 512)
-                for (int v = threadIdx.x + NV * nth; v < MT * 32 * PPR; v += nth) x_store((st + 1) & 1, v, x_load(st + 1, v));
-        }
+        // (sched_barrier: the machine scheduler otherwise sinks the loads into the MFMA sequence to save registers, i.e. issues them late)
+        stage(st + 1, (st + 1) & 1, val, true);
+        w_load(B, 2 * st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        g1_group<DT, MT>(xb, 0, A, acc, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        w_load(A, 2 * st + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        g1_group<DT, MT>(xb, G1_UNROLL, B, acc, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(st + 1, (st + 1) & 1, val, false);
         __syncthreads();
+    }
+    if (n_sub_full > 0) {                                           // last full sub-tile: what follows it may not exist (uniform branches)
+        const int st = n_sub_full - 1;
+        const u32x4 *xb = xl + (st & 1) * BUF;
+        u32x4 val[NV];
+        if (rem > 0) stage(st + 1, (st + 1) & 1, val, true);
+        w_load(B, 2 * st + 1);
+        g1_group<DT, MT>(xb, 0, A, acc, lane);
+        if (rem >= G1_UNROLL) w_load(A, 2 * st + 2);
+        g1_group<DT, MT>(xb, G1_UNROLL, B, acc, lane);
+        if (rem > 0) stage(st + 1, (st + 1) & 1, val, false);
+        __syncthreads();
+    }
+    if (rem > 0) {                                                  // last, partial sub-tile: one whole group (in A) and / or single k-steps
+        const u32x4 *xb = xl + (n_sub_full & 1) * BUF;
+        int sl = 0;
+        if (rem >= G1_UNROLL) { g1_group<DT, MT>(xb, 0, A, acc, lane); sl = G1_UNROLL; }
+        for (; sl < rem; ++sl) {
+            const u32x4 wv = __builtin_nontemporal_load(wu + (size_t)(n_sub_full * G1_SUB + sl) * rs);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(xb[(mt * G1_SUB + sl) * 64 + g1_slot(lane >> 5, lane & 31, sl)], wv, acc[mt]);
+        }
     }
     if (!has_tile) return;
     float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t_out * 32 + (lane & 31);

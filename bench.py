@@ -97,7 +97,7 @@ def build_model(args, device):
     with torch.device(device):
         model = BB.ChameleonBackbone(margs, attn=attn).to(dt).eval()
     if args.prompts_per_gpu > 1 and args.model != "emu3_8b":      # 64-row windows: the staged activation chunk (64 x KC) must fit in LDS
-        model.G1_CFG = dict(model.G1_CFG_64ROW)
+        model.G1_CFG = dict(model.G1_CFG_64ROW if args.prompts_per_gpu == 2 else model.G1_CFG_128ROW)
     if args.model == "emu3_8b":      # 64-row windows (draft window 32) need activation chunks <= 1280 columns
         model.G1_CFG = dict(model.G1_CFG_EMU3)
     if os.environ.get("SJD_G1_CFG"):       # tuning aid: JSON {"o": [KC, waves, step_major], ...} overriding the per-projection launch shapes

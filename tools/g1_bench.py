@@ -102,12 +102,14 @@ def main():
             rows = []
             for sm in ((1,) if name in ("qkv", "gate_up") else (0,)) if a.fine else (1, 0):
                 for KC in (range(512, 2049, 64) if a.fine else (256, 512, 688, 896, 1024, 1280, 1376, 1536, 2048)):
-                    if KC > K or (name == "down" and KC == 2048) or (a.rows > 32 and KC > 1280) or K % 16:
+                    if KC > K or (name == "down" and KC == 2048) or (32 < a.rows <= 64 and KC > 1280) or K % 16:
                         continue
                     wps = [ops.pack_weight(w, KC, bool(sm)) for w in ws]
                     nc = (K + KC - 1) // KC
-                    out = torch.empty(nc, 32 if a.rows <= 32 else 64, N, dtype=torch.float32, device=dev)
+                    out = torch.empty(nc, ((a.rows + 31) // 32) * 32, N, dtype=torch.float32, device=dev)
                     for waves in ((6, 7, 8, 9, 10, 12) if a.fine else (4, 6, 8, 11, 12, 16)):
+                        if a.rows > 64 and waves > 8:
+                            continue
                         n_wg = ((N // 32 + waves - 1) // waves) * nc
 
                         def g1(i, wps=wps, KC=KC, waves=waves, sm=sm, out=out):
@@ -130,17 +132,18 @@ def main():
         KC = a.kc or KC
         if a.product:
             import sjd_amd.backbones as BB
-            KC, a.waves, sm = BB.ChameleonBackbone.G1_CFG[name]
+            cfg = BB.ChameleonBackbone.G1_CFG if a.rows <= 32 else BB.ChameleonBackbone.G1_CFG_64ROW if a.rows <= 64 else BB.ChameleonBackbone.G1_CFG_128ROW
+            KC, a.waves, sm = cfg[name]
             a.step_major = int(sm)
-        x = torch.randn(32, K, device=dev).to(torch.bfloat16)
+        x = torch.randn(a.rows, K, device=dev).to(torch.bfloat16)
         ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16) for _ in range(a.copies)]
         wps = [ops.pack_weight(w, KC, bool(a.step_major)) for w in ws]
         nc = (K + KC - 1) // KC
-        out = torch.empty(nc, 32, N, dtype=torch.float32, device=dev)
+        out = torch.empty(nc, ((a.rows + 31) // 32) * 32, N, dtype=torch.float32, device=dev)
 
         def g1(i):
             L.check(lib.sjd_skinny_gemm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % a.copies].data_ptr()),
-                                        ctypes.c_void_p(out.data_ptr()), 32, N, K, KC, a.waves, a.step_major, 0,
+                                        ctypes.c_void_p(out.data_ptr()), a.rows, N, K, KC, a.waves, a.step_major, 0,
                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "g1")
 
         def blas(i):

@@ -16,6 +16,7 @@
 //     kernel (F1 / F2 / F3 take n_chunks), so no reduction pass and no atomics;
 //   * loads are issued 8 k-steps ahead of their MFMA (register double buffer) and marked non-temporal (read once).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/sjd_hip.h"
 
@@ -330,21 +331,25 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
     const int n_out = N / 32, n_tiles = n_tiles_packed > 0 ? n_tiles_packed : n_out, n_chunks = (K + KC - 1) / KC;
     if (tile0 < 0 || tile0 + n_out > n_tiles) return SJD_ERR_BAD_ARG;
     const dim3 grid((n_out + waves - 1) / waves, n_chunks), block(waves * 64);
-    if constexpr (MT > 2) {                                    // sub-tiled activation (g1_skinny_gemm_tiled)
+    const size_t lds_whole = (size_t)MT * ((KC < K ? KC : K) / 16) * 64 * 16;       // the whole activation chunk staged at once
+    static const bool force_tiled = [] { const char *e = getenv("SJD_G1_TILED"); return e && e[0] == '1'; }();      // tuning aid (64-row windows)
+    if constexpr (MT >= 2) if (MT > 2 || lds_whole > 160 * 1024 || (force_tiled && waves <= 8)) {     // sub-tiled activation: no limit on KC
         if (waves > 8) return SJD_ERR_BAD_ARG;
         const size_t lds_t = (size_t)2 * MT * G1_SUB * 1024;
         (void)hipFuncSetAttribute((const void *)g1_skinny_gemm_tiled<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
         hipLaunchKernelGGL((g1_skinny_gemm_tiled<DT, MT>), grid, block, lds_t, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC,
                            n_tiles, step_major ? n_tiles : 1, tile0);
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
-    } else {
-        const size_t lds = (size_t)MT * ((KC < K ? KC : K) / 16) * 64 * 16;       // the staged activation chunk
+    }
+    if constexpr (MT <= 2) {
+        const size_t lds = lds_whole;
         if (lds > 160 * 1024) return SJD_ERR_BAD_ARG;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((g1_skinny_gemm<DT, MT>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles,
                            step_major ? n_tiles : 1, tile0);
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
     }
+    return SJD_ERR_UNSUPPORTED;
 }
 
 // Column window of a packed weight: out[c, m, j] for the N = 32 * n columns [32 * tile0, 32 * tile0 + N) of a weight packed with N_packed columns.

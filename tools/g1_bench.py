@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--product", action="store_true", help="per-shape (KC, waves, layout) of backbones.G1_CFG")
     ap.add_argument("--sweep", action="store_true", help="grid over KC x waves x layout per shape (one JSON line per point, best first at the end)")
     ap.add_argument("--fine", action="store_true", help="with --sweep: KC in steps of 64 and waves 6..12, one layout per shape")
+    ap.add_argument("--tiled64", action="store_true", help="with --sweep --rows 64: include KC > 1280 (served by the sub-tiled kernel, <= 8 waves)")
     ap.add_argument("--rows", type=int, default=32, help="window rows (64: draft window 32 or two prompts; the staged chunk must then be <= 1280 columns)")
     ap.add_argument("--emu3", action="store_true", help="Emu3-Gen 8B projection shapes (GQA 32/8, intermediate 14336) instead of Lumina-7B")
     a = ap.parse_args()
@@ -102,13 +103,13 @@ def main():
             rows = []
             for sm in ((1,) if name in ("qkv", "gate_up") else (0,)) if a.fine else (1, 0):
                 for KC in (range(512, 2049, 64) if a.fine else (256, 512, 688, 896, 1024, 1280, 1376, 1536, 2048)):
-                    if KC > K or (name == "down" and KC == 2048) or (32 < a.rows <= 64 and KC > 1280) or K % 16:
+                    if KC > K or (name == "down" and KC == 2048) or (32 < a.rows <= 64 and KC > 1280 and not a.tiled64) or K % 16:
                         continue
                     wps = [ops.pack_weight(w, KC, bool(sm)) for w in ws]
                     nc = (K + KC - 1) // KC
                     out = torch.empty(nc, ((a.rows + 31) // 32) * 32, N, dtype=torch.float32, device=dev)
                     for waves in ((6, 7, 8, 9, 10, 12) if a.fine else (4, 6, 8, 11, 12, 16)):
-                        if a.rows > 64 and waves > 8:
+                        if (a.rows > 64 or (a.tiled64 and KC > 1280)) and waves > 8:
                             continue
                         n_wg = ((N // 32 + waves - 1) // waves) * nc
 

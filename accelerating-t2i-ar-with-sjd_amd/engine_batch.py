@@ -1,7 +1,8 @@
 """Several prompts per GPU in ONE window forward (the reference decodes one prompt per process).
 
 A draft-window forward is a pure weight stream: 13 GB of weights for 32 activation rows.  Two prompts (2 x B_cfg x L = 64 rows)
-cost the same stream, so decoding them together almost doubles the accepted tokens per second of a GPU.  Every prompt ("slot")
+cost the same stream, so decoding them together almost doubles the accepted tokens per second of a GPU; up to four prompts (128 rows,
+G1's sub-tiled kernel) fit in one forward: 963 / 1292 tokens/s per MI355X for two / four Lumina 768px prompts against 561 for one.  Every prompt ("slot")
 keeps exactly the state machine of `SJDEngine.decode` -- its own window, accept length, KV length, grammar, device generator
 and CPU generator for the fresh ids -- so each slot takes the decisions its solo run would take on the same logits; only the
 transformer forward is shared:

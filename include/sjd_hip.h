@@ -206,7 +206,7 @@ int sjd_silu_mul(const void *gate_up, void *y, int rows, int inter, int dtype, c
  *   gamma * (h r) W^T == r (h W'^T),  r = rsqrt(mean(h^2) + eps).
  * sjd_residual_sumsq (F1r) does only the residual half of F1 -- h[rows, hidden] += dtype(sum_c part[c]) in place (part may be NULL) --
  * over (row, 512-column slice) workgroups and writes out_sumsq[s, m] = sum of h[m, :]^2 over slice s ([ceil(hidden/512), R] floats,
- * R = 32 for rows <= 32 else 64); the projection then runs on h itself and its consumer applies r through `row_norm`
+ * R = rows rounded up to a multiple of 32, rows <= 128); the projection then runs on h itself and its consumer applies r through `row_norm`
  * (sjd_qknorm_rope_append_ex / sjd_silu_mul_ex, on the summed partials before they are rounded to `dtype`).
  * replaces ChameleonRMSNorm + the residual adds (reference modeling_chameleon.py:59-73, 637, 643); differs from F1 only in where bf16
  * rounding happens (x_norm is never rounded; W diag(gamma) is). */
@@ -224,12 +224,14 @@ int sjd_qknorm_rope_append_ex(const void *qkv, void *q_out, void *k_cache, void 
 int sjd_silu_mul_ex(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks,
                     const sjd_row_norm *row_norm, void *stream);
 
-/* G1 -- weight-streaming projection of the draft window: out[c, m, n] = sum_{k in chunk c} x[m, k] * W[n, k], M <= 64 rows,
- * fp32 split-K partials [n_chunks, R, N] with R = 32 (M <= 32) or 64 (n_chunks = ceil(K / KC)); the consumer (F1/F2/F3 `part` argument) sums them.
+/* G1 -- weight-streaming projection of the draft window: out[c, m, n] = sum_{k in chunk c} x[m, k] * W[n, k], M <= 128 rows
+ * (one to four 32-row MFMA tiles: up to four prompts' draft windows per forward), fp32 split-K partials [n_chunks, R, N] with R = M rounded up to
+ * a multiple of 32 and n_chunks = ceil(K / KC); the consumer (F1/F2/F3 `part` argument) sums them.
  * replaces the nn.Linear calls of the decoder layer (reference modeling_chameleon.py:527-529, 579, 193-195) for the
  * window forward.  w_packed: the [N, K] weight re-ordered by sjd_amd.ops.pack_weight (MFMA 32x32x16 B-fragment order,
- * one contiguous run per (k-chunk, 32-column tile)).  N % 32 == 0, K % 16 == 0, KC % 16 == 0, and the staged
- * activation chunk must fit in LDS: min(KC, K) <= 2560 for M <= 32, <= 1280 for M <= 64;
+ * one contiguous run per (k-chunk, 32-column tile)).  N % 32 == 0, K % 16 == 0, KC % 16 == 0.  M <= 32: the activation chunk is staged
+ * whole in LDS, min(KC, K) <= 2560.  M <= 64: whole while min(KC, K) <= 1280, otherwise -- and always for M > 64 -- in 256-column sub-tiles
+ * double-buffered through LDS (no limit on KC; waves <= 8).  The partial planes do not depend on which of the two kernels ran;
  * waves (1..16) = column tiles per workgroup sharing one staged activation chunk; step_major selects the packed record
  * order (0: one contiguous run per tile, 1: the records of all tiles interleaved per k-step). */
 int sjd_gemm_num_chunks(int K, int KC);

@@ -84,7 +84,8 @@ template <int DT, int D, int NW>
 __global__ __launch_bounds__(64 * NW) void k1_partial(
     const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
     float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max,
-    const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks)
+    const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks,
+    unsigned short *__restrict__ out_direct)
 {
     typedef typename Frag<DT>::vec vec;
     constexpr int KS = D / 32;            // k-steps of the QK^T product
@@ -267,6 +268,15 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
             const float wgt = __expf(red_ml[ww][row][0] - Ms);
             L += wgt * red_ml[ww][row][1];
             O += wgt * red_o[ww][row][d];
+        }
+        if (out_direct) {
+            // one key split (n_split == 1): this IS the attention output -- exactly what k1_combine makes of a single partial
+            // (acc = 0 * exp(-inf) + O * exp(0), L likewise), written without the workspace round trip and the second launch
+            const int grow = row0 + row;
+            if (grow < n_rows)
+                out_direct[(((size_t)b * n_rows + grow) * H + (hkv * G + hg)) * D + d] =
+                    grow < n_total ? Frag<DT>::cvt(O * (L > 0.f ? 1.0f / L : 0.0f)) : (unsigned short)0;
+            continue;
         }
         const size_t slot = ((((size_t)b * H + (hkv * G + hg)) * n_chunks + chunk) * n_split + split) * K1_ROWS + row;
         ws_o[slot * D + d] = O;
@@ -866,7 +876,7 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
     const unsigned short *__restrict__ q, const unsigned char *__restrict__ kc, const unsigned char *__restrict__ vc,
     float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max,
     const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks,
-    float k_scale, float v_scale)
+    float k_scale, float v_scale, unsigned short *__restrict__ out_direct)
 {
     constexpr int KP = D / 64;            // 16-byte K pieces per key row and lane group = pairs of k-steps
     constexpr int DB = D / 16;            // 16-wide d blocks of the output
@@ -1050,6 +1060,15 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
             L += wgt * red_ml[ww][row][1];
             O += wgt * red_o[ww][row][d];
         }
+        if (out_direct) {
+            // one key split (n_split == 1): this IS the attention output -- exactly what k1_combine makes of a single partial
+            // (acc = 0 * exp(-inf) + O * exp(0), L likewise), written without the workspace round trip and the second launch
+            const int grow = row0 + row;
+            if (grow < n_rows)
+                out_direct[(((size_t)b * n_rows + grow) * H + (hkv * G + hg)) * D + d] =
+                    grow < n_total ? Frag<DT>::cvt(O * (L > 0.f ? 1.0f / L : 0.0f)) : (unsigned short)0;
+            continue;
+        }
         const size_t slot = ((((size_t)b * H + (hkv * G + hg)) * n_chunks + chunk) * n_split + split) * K1_ROWS + row;
         ws_o[slot * D + d] = O;
         if (d == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = L; }
@@ -1182,20 +1201,25 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     float *ws_ml = ws_o + (size_t)B * H * n_chunks * n_split * K1_ROWS * D;
     if (ev0) (void)hipEventRecord(ev0, stream);
     const int pairs = (H / H_kv) * n_chunks;           // (q head of a group, row chunk) pairs that read the same K/V tiles
-    if (D == 128 && (pairs == 4 || pairs == 8) && (H / H_kv > 1 || n_chunks > 1) && !getenv("SJD_K1_NO_SHARED"))
+    const bool shared = D == 128 && (pairs == 4 || pairs == 8) && (H / H_kv > 1 || n_chunks > 1) && !getenv("SJD_K1_NO_SHARED");
+    // a single key split needs no combine: k1_partial normalises and writes the 16-bit output directly (SJD_K1_NO_DIRECT=1: tuning aid)
+    static const bool no_direct = getenv("SJD_K1_NO_DIRECT") != nullptr;
+    unsigned short *direct = (!shared && n_split == 1 && !no_direct) ? (unsigned short *)out : nullptr;
+    if (shared)
         hipLaunchKernelGGL((k1_partial_shared<DT, D>), dim3(n_split, H_kv, B), dim3(64 * pairs), 0, stream, (const unsigned short *)q,
                            (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
                            kv_len, n_split, n_chunks);
     else if (k1_waves() == 8)
         hipLaunchKernelGGL((k1_partial<DT, D, 8>), dim3(n_chunks * n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
                            (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
-                           kv_len, n_split, n_chunks);
+                           kv_len, n_split, n_chunks, direct);
     else
         hipLaunchKernelGGL((k1_partial<DT, D, 4>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
                            (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
-                           kv_len, n_split, n_chunks);
+                           kv_len, n_split, n_chunks, direct);
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
+    if (direct) return SJD_OK;                          // one key split: k1_partial wrote the output itself
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
                        n_split, n_chunks, params, key_start, kv_len);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
@@ -1263,15 +1287,18 @@ static int launch_attention_fp8(const void *q, const void *kc, const void *vc, v
     const int n_chunks = (n_rows + K1_ROWS - 1) / K1_ROWS;
     float *ws_o = (float *)workspace;
     float *ws_ml = ws_o + (size_t)B * H * n_chunks * n_split * K1_ROWS * D;
+    static const bool no_direct = getenv("SJD_K1_NO_DIRECT") != nullptr;
+    unsigned short *direct = (n_split == 1 && !no_direct) ? (unsigned short *)out : nullptr;      // one key split: no combine launch
     if (k1_waves() == 8)
         hipLaunchKernelGGL((k1_partial_fp8<DT, D, 8>), dim3(n_chunks * n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
                            (const unsigned char *)kc, (const unsigned char *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
-                           kv_len, n_split, n_chunks, k_scale, v_scale);
+                           kv_len, n_split, n_chunks, k_scale, v_scale, direct);
     else
         hipLaunchKernelGGL((k1_partial_fp8<DT, D, 4>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
                            (const unsigned char *)kc, (const unsigned char *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
-                           kv_len, n_split, n_chunks, k_scale, v_scale);
+                           kv_len, n_split, n_chunks, k_scale, v_scale, direct);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
+    if (direct) return SJD_OK;
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
                        n_split, n_chunks, params, key_start, kv_len);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;

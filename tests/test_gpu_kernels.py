@@ -7,6 +7,8 @@ import ctypes
 import zlib
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -290,6 +292,46 @@ def test_k1_k3_attention(dev, case, n_split):
     assert err[vis].max() < 3e-2, f"max err {err[vis].max()}"
     assert err[vis].mean() < 3e-3, f"mean err {err[vis].mean()}"
     assert (got[~vis] == 0).all()
+
+
+_DIRECT_SCRIPT = r"""
+import hashlib, sys, torch
+sys.path.insert(0, ".")
+import sjd_amd.ops as ops
+from tests.test_gpu_kernels import _Cache
+dev = torch.device("cuda:0")
+h = hashlib.sha256()
+for fp8 in (False, True):
+    for (B, H, n, kv_len, ks, n_valid) in ((8, 32, 16, 700, [0, 3, 0, 650, 0, 0, 9, 0], 16), (2, 4, 16, 37, [0, 30], 5), (1, 2, 7, 0, [0], 7)):
+        g = torch.Generator().manual_seed(B * 1000 + n)
+        S = 1024
+        kc, vc = torch.randn(1, B, H, S, 128, generator=g).bfloat16().to(dev), torch.randn(1, B, H, S, 128, generator=g).bfloat16().to(dev)
+        q = (torch.randn(B, n, H, 128, generator=g) * 1.5).bfloat16().to(dev)
+        k, v = torch.randn(B, n, H, 128, generator=g).bfloat16().to(dev), torch.randn(B, n, H, 128, generator=g).bfloat16().to(dev)
+        attn = ops.HipWindowAttention(n_split=1)
+        if fp8:
+            kc, vc = kc.float().to(ops.FP8), vc.float().to(ops.FP8)
+        out = attn(0, q, k, v, _Cache(kc, vc), kv_len, ks)
+        torch.cuda.synchronize()
+        h.update(out.cpu().view(torch.int16).numpy().tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_k1_single_split_direct_output_is_what_combine_would_write(dev):
+    """n_split == 1: k1_partial normalises and writes the 16-bit output itself (no workspace round trip, no k1_combine launch); the bytes
+    are those of partial + combine (SJD_K1_NO_DIRECT=1, read once per process -> two subprocesses), 16-bit and fp8 caches."""
+    import subprocess
+    import sys
+    outs = []
+    for env_extra in ({}, {"SJD_K1_NO_DIRECT": "1"}):
+        env = dict(os.environ, **env_extra)
+        env.pop("SJD_K1_NO_DIRECT", None) if not env_extra else None
+        r = subprocess.run([sys.executable, "-c", _DIRECT_SCRIPT], capture_output=True, text=True, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert len(outs[0]) == 64 and outs[0] == outs[1]
 
 
 def test_k1_device_side_kv_len(dev):

@@ -20,7 +20,7 @@ def main():
     rnd = random.Random(a.seed)
     ok = 0
     for i in range(a.n):
-        kind = rnd.choice(["llamagen", "lumina", "lumina", "emu3", "anole", "batch"])
+        kind = rnd.choice(["llamagen", "lumina", "lumina", "emu3", "anole", "batch", "batch"])
         seed = rnd.randrange(1, 10000)
         try:
             if kind == "llamagen":
@@ -48,7 +48,9 @@ def main():
                           gemm=rnd.choice(["torch", "sjd"]), use_graph=rnd.random() < 0.6)
                 r = G.teacher_forced_anole_check(**kw)
             else:
-                kw = dict(seed=seed, window=rnd.choice([8, 16]), P=rnd.choice([(12, 9), (7, 7), (10, 15)]), gemm=rnd.choice(["torch", "sjd"]),
+                n_prompts = rnd.choice([2, 2, 3, 4])
+                kw = dict(seed=seed, n_prompts=n_prompts, window=rnd.choice([8, 16] if n_prompts < 4 else [4, 8, 16]),
+                          P=rnd.choice([(12, 9, 14, 7), (7, 7, 7, 7), (10, 15, 5, 11)]), gemm=rnd.choice(["torch", "sjd"]),
                           use_graph=rnd.random() < 0.6, fp8_kv=rnd.random() < 0.3)
                 r = G.teacher_forced_batch_check(**kw)
             ok += 1

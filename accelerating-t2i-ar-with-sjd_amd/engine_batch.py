@@ -180,9 +180,15 @@ class SJDBatchEngine:
     @torch.no_grad()
     def decode_many(self, prompts: List[List[int]], specs: List[WindowSpec], grammars, cfg: SJDConfig, seeds=None,
                     warmup_iters=0, timed_iters=None, on_timed_start=None, on_timed_end=None):
-        """One SJDConfig for all slots (seed = cfg.seed + slot unless `seeds` is given).  Returns [(sequence, DecodeStats)] per slot;
-        with timed_iters the stats cover window iterations [warmup_iters, warmup_iters + timed_iters)."""
-        assert len(prompts) == len(specs) == len(grammars) == self.P
+        """One SJDConfig for all prompts (seed = cfg.seed + prompt index unless `seeds` is given).  Returns [(sequence, DecodeStats)] in
+        prompt order; with timed_iters the stats cover window iterations [warmup_iters, warmup_iters + timed_iters).
+
+        len(prompts) may exceed the number of slots (continuous batching): a slot whose prompt reached its end token is handed the next
+        prompt of the list -- state machine, grammar and generators re-created, its KV rows reused from 0, its prompt prefilled eagerly
+        over its own batch rows -- while the other slots keep their windows; the captured window graphs are unaffected.  Only when the
+        list is exhausted does a finished slot ride along with a one-row dummy window."""
+        N = len(prompts)
+        assert len(specs) == len(grammars) == N and N >= self.P
         if cfg.multi_token_init_scheme != "random":
             raise NotImplementedError("only multi_token_init_scheme='random' is parity-checkable")
         if cfg.prefix_token_sampler_scheme not in ("speculative_jacobi", "jacobi"):
@@ -196,25 +202,31 @@ class SJDBatchEngine:
         self._guidance = float(cfg.guidance_scale)
         attn = getattr(self.backbone, "attn", None)
         full_cache = self.backbone.cache
-        for i, s in enumerate(self.slots):
-            s.X = [int(t) for t in prompts[i]]
-            s.P = len(s.X)
-            seed = (seeds[i] if seeds is not None else (None if cfg.seed is None else cfg.seed + i))
-            s.gen = None if seed is None else torch.Generator(dev).manual_seed(seed)
-            s.cpu_gen = None if seed is None else torch.Generator().manual_seed(seed)     # the slot's "global CPU generator" (JL:505)
-            s.grammar = grammars[i]
-            s.grammar.start(s.X)
-            s.l_abs, s.r_abs = s.P + cfg.jacobi_loop_interval_l, s.P + cfg.jacobi_loop_interval_r
-            s.n, s.kv_len, s.cur_len, s.n_prev, s.m_prev = 1, specs[i].kv_base, s.P, 1, 1
-            s.carried, s.finished, s.stats = [], False, DecodeStats()
-            self.key_start[i * nb:(i + 1) * nb].copy_(specs[i].key_start.to(device=dev, dtype=torch.int32))
-            self.pos_offset[i * nb:(i + 1) * nb].copy_(specs[i].pos_offset.to(device=dev, dtype=torch.int64))
+        results = [None] * N
+        next_prompt = 0
+        emitted_total = 0                 # tokens appended to any prompt's sequence so far (the timed region counts its increase)
         cur = 0
 
-        # ---------------- iteration 0 of every slot: prefill over the slot's own batch rows (JL:344-350 short-circuit) ----------------
-        if attn is not None and hasattr(attn, "params"):
-            attn.params = None
-        for i, s in enumerate(self.slots):
+        def admit(i, buf):
+            """prompt `next_prompt` -> slot i: iteration 0 (JL:344-350 short-circuit), a prefill over the slot's own batch rows whose
+            distribution lands in probs[buf]"""
+            nonlocal next_prompt
+            j, s = next_prompt, self.slots[i]
+            next_prompt += 1
+            s.prompt_index = j
+            s.X = [int(t) for t in prompts[j]]
+            s.P = len(s.X)
+            seed = (seeds[j] if seeds is not None else (None if cfg.seed is None else cfg.seed + j))
+            s.gen = None if seed is None else torch.Generator(dev).manual_seed(seed)
+            s.cpu_gen = None if seed is None else torch.Generator().manual_seed(seed)     # the prompt's "global CPU generator" (JL:505)
+            s.grammar = grammars[j]
+            s.grammar.start(s.X)
+            s.l_abs, s.r_abs = s.P + cfg.jacobi_loop_interval_l, s.P + cfg.jacobi_loop_interval_r
+            s.n, s.kv_len, s.cur_len, s.n_prev, s.m_prev = 1, specs[j].kv_base, s.P, 1, 1
+            s.carried, s.finished, s.harvested, s.stats = [], False, False, DecodeStats()
+            s.t_admit = time.perf_counter()
+            self.key_start[i * nb:(i + 1) * nb].copy_(specs[j].key_start.to(device=dev, dtype=torch.int32))
+            self.pos_offset[i * nb:(i + 1) * nb].copy_(specs[j].pos_offset.to(device=dev, dtype=torch.int64))
             if s.cpu_gen is not None:
                 torch.randint(0, cfg.img_vocab_n, (1, 0), generator=s.cpu_gen)
             rules = s.grammar.window_rules(1)
@@ -222,7 +234,7 @@ class SJDBatchEngine:
             self._fill(s, 1, s.kv_len, use_cfg, scheme, [], rules, [])
             s.params.upload()
             self._draw_noise(s, 1, scheme)
-            tokens, positions = specs[i].first_tokens.to(dev), specs[i].first_positions.to(dev)
+            tokens, positions = specs[j].first_tokens.to(dev), specs[j].first_positions.to(dev)
             self.backbone.cache = _CacheView(full_cache, i * nb, (i + 1) * nb)
             try:
                 logits = self.backbone.forward_window(tokens, positions, s.kv_len, self.key_start[i * nb:(i + 1) * nb])
@@ -230,26 +242,43 @@ class SJDBatchEngine:
                 self.backbone.cache = full_cache
             lc = logits[0, -1:, :]
             lu = logits[1, -1:, :] if nb > 1 else None
-            ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, s.noise, s.probs[cur], s.tokens_ptr)
-            ops.verify_accept(s.params, s.state, s.probs[cur], s.probs[1 - cur], s.rs, s.noise2[0], s.scratch)
+            ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, s.noise, s.probs[buf], s.tokens_ptr)
+            ops.verify_accept(s.params, s.state, s.probs[buf], s.probs[1 - buf], s.rs, s.noise2[0], s.scratch)
             if self.hook is not None:
-                self.hook(i, dict(first=True, n_rows=1, logits_c=lc, logits_u=lu, use_cfg=use_cfg, rules=rules, resid=[],
-                                  noise=s.noise[:1], rs=s.rs[:1], noise2=s.noise2[0], probs=s.probs[cur], prev_probs=s.probs[1 - cur],
+                self.hook(j, dict(first=True, n_rows=1, logits_c=lc, logits_u=lu, use_cfg=use_cfg, rules=rules, resid=[],
+                                  noise=s.noise[:1], rs=s.rs[:1], noise2=s.noise2[0], probs=s.probs[buf], prev_probs=s.probs[1 - buf],
                                   ctx=list(s.X), scheme=scheme))
             s.win_len = tokens.shape[1]
-        self.state.download()
-        for s in self.slots:
-            st = s.state.view
-            y0 = int(st.tokens[0])
+
+        def after_prefill(s):
+            """host bookkeeping of iteration 0 (after the state download)"""
+            nonlocal emitted_total
+            y0 = int(s.state.view.tokens[0])
             s.stats.matched.append(s.win_len)
             s.n = min(W, s.r_abs - s.cur_len) if (s.l_abs <= s.cur_len < s.r_abs) else 1
             s.X.append(y0)
+            emitted_total += 1
             s.grammar.push([y0])
             s.kv_len += s.win_len
             s.n_prev, s.m_prev, s.carried = 1, 1, []
             s.stats.nfe += 1
             s.finished = s.X[-1] in cfg.eos_token_ids or len(s.X) >= cfg.max_length
             s.cur_len = len(s.X)
+
+        def harvest(s):
+            s.harvested = True
+            s.stats.wall_seconds = time.perf_counter() - s.t_admit
+            s.stats.tokens, s.stats.timed_nfe, s.stats.kv_len = len(s.X) - s.P, s.stats.nfe, s.kv_len
+            results[s.prompt_index] = (s.X, s.stats)
+
+        # ---------------- iteration 0 of the first P prompts ----------------
+        if attn is not None and hasattr(attn, "params"):
+            attn.params = None
+        for i in range(self.P):
+            admit(i, cur)
+        self.state.download()
+        for s in self.slots:
+            after_prefill(s)
         cur = 1 - cur
         if attn is not None and hasattr(attn, "params"):
             attn.params = self.params                          # windows: kv_len / n_rows of every prompt from its blob
@@ -259,13 +288,29 @@ class SJDBatchEngine:
         t0 = time.perf_counter()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        tok0 = [len(s.X) for s in self.slots]
+        tok0 = emitted_total
         host_s = sync_s = 0.0
-        while not all(s.finished for s in self.slots):
+        while True:
+            # finished prompts leave, queued prompts enter (eager prefill; the window graphs hold none of the buffers it allocates)
+            for i, s in enumerate(self.slots):
+                if s.finished and not s.harvested:
+                    harvest(s)
+                    if next_prompt < N:
+                        if attn is not None and hasattr(attn, "params"):
+                            attn.params = None
+                        admit(i, 1 - cur)
+                        self.state.download()
+                        after_prefill(s)
+                        if attn is not None and hasattr(attn, "params"):
+                            attn.params = self.params
+            if all(s.finished for s in self.slots):
+                if any(not s.harvested for s in self.slots):
+                    continue                                    # (a prompt that ended in its prefill iteration)
+                break
             if timed_iters is not None and it == warmup_iters:
                 if on_timed_start is not None:
                     on_timed_start()
-                tok0 = [len(s.X) for s in self.slots]
+                tok0 = emitted_total
                 host_s = sync_s = 0.0
                 t0 = time.perf_counter()
                 ev0.record()
@@ -312,9 +357,10 @@ class SJDBatchEngine:
                         full = torch.zeros(nb, n_rows, self.V, dtype=logits.dtype, device=dev)
                         full[:, :, cols[0]:cols[1]] = lg
                         lg = full
-                    self.hook(i, dict(first=False, n_rows=n_rows, logits_c=lg[0], logits_u=lg[1] if nb > 1 else None, use_cfg=use_cfg,
-                                      rules=rules, resid=resid, noise=s.noise[:n_rows], rs=s.rs[:n_rows], noise2=s.noise2[0],
-                                      probs=s.probs[cur], prev_probs=s.probs[1 - cur], ctx=list(s.X), scheme=scheme))
+                    self.hook(s.prompt_index, dict(first=False, n_rows=n_rows, logits_c=lg[0], logits_u=lg[1] if nb > 1 else None,
+                                                   use_cfg=use_cfg, rules=rules, resid=resid, noise=s.noise[:n_rows], rs=s.rs[:n_rows],
+                                                   noise2=s.noise2[0], probs=s.probs[cur], prev_probs=s.probs[1 - cur], ctx=list(s.X),
+                                                   scheme=scheme))
             t_s = time.perf_counter()
             self.state.download()                              # the single sync of the iteration
             sync_s += time.perf_counter() - t_s
@@ -335,6 +381,7 @@ class SJDBatchEngine:
                 s.stats.matched.append(m)
                 s.n = min(W, s.r_abs - s.cur_len) if (s.l_abs <= s.cur_len < s.r_abs) else 1      # JL:1142-1144 (old cur_len)
                 s.X.extend(emitted)
+                emitted_total += len(emitted)
                 s.grammar.push(emitted)
                 s.kv_len += m
                 s.n_prev, s.m_prev = n_rows, (1 if n_rows <= 1 else m)
@@ -351,11 +398,18 @@ class SJDBatchEngine:
         if on_timed_end is not None:
             on_timed_end()
         seconds = ev0.elapsed_time(ev1) / 1000.0
+        for s in self.slots:                                   # prompts still in flight when a timed run stops
+            if not s.harvested:
+                harvest(s)
+        self.run_stats = dict(seconds=seconds, wall_seconds=time.perf_counter() - t0, iterations=it,
+                              timed_iterations=(it - warmup_iters) if timed_iters is not None else it,
+                              tokens=emitted_total - tok0, host_seconds=host_s, sync_seconds=sync_s, prompts_started=next_prompt)
         out = []
-        for i, s in enumerate(self.slots):
-            s.stats.seconds, s.stats.wall_seconds = seconds, time.perf_counter() - t0
-            s.stats.tokens = len(s.X) - (tok0[i] if timed_iters is not None else s.P)
-            s.stats.timed_nfe = (it - warmup_iters) if timed_iters is not None else s.stats.nfe
-            s.stats.kv_len, s.stats.host_seconds, s.stats.sync_seconds = s.kv_len, host_s, sync_s
-            out.append((s.X, s.stats))
+        for r in results:
+            if r is None:                                      # never admitted (a timed run that stopped early)
+                out.append(None)
+                continue
+            X, st = r
+            st.seconds, st.host_seconds, st.sync_seconds = seconds, host_s, sync_s
+            out.append((X, st))
         return out

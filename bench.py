@@ -44,7 +44,10 @@ def parse(argv=None):
                     help="KV-cache element type: the activation dtype, or OCP fp8 e4m3 with the fp8-MFMA K1 (auto: fp8 for anole7b = BASELINE config 5)")
     ap.add_argument("--prompts-per-gpu", type=int, default=1,
                     help="decode this many independent prompts per GPU in ONE window forward (SJDBatchEngine; 1 = the reference's "
-                         "operating point and BASELINE.json's configuration; 2 x B_cfg x window must stay <= 64 rows)")
+                         "operating point and BASELINE.json's configuration; prompts x B_cfg x window must stay <= 128 rows)")
+    ap.add_argument("--queue-prompts", type=int, default=0,
+                    help="with --prompts-per-gpu > 1: total prompts per GPU (>= --prompts-per-gpu); a slot whose image is complete takes the "
+                         "next prompt of the queue (continuous batching).  0 = one prompt per slot")
     ap.add_argument("--embed-token-scale", type=float, default=0.7)
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--n-split", type=int, default=0, help="K1 key splits (0 = auto from batch x kv heads)")
@@ -392,9 +395,12 @@ def main():
             raise SystemExit("--prompts-per-gpu > 1 is wired for the Lumina workload")
         from sjd_amd.engine_batch import SJDBatchEngine
         eng = SJDBatchEngine(model, margs.vocab_size, device, PP, max_window=args.window, use_graph=not args.no_graph)
-        prompts = [lumina_prompt(P, grid, grid, seed=1234 + rank * PP + i) for i in range(PP)]
+        NQ = max(PP, args.queue_prompts)
+        prompts = [lumina_prompt(P, grid, grid, seed=1234 + rank * NQ + i) for i in range(NQ)]
         specs = [lumina_window_spec(p_, device) for p_ in prompts]
         workload += f", {PP} prompts per GPU sharing one window forward"
+        if NQ > PP:
+            workload += f" (continuous batching over a queue of {NQ} prompts)"
     else:
         eng = SJDEngine(model, margs.vocab_size, device, max_window=args.window, use_graph=not args.no_graph)
 
@@ -416,10 +422,12 @@ def main():
     grammar0 = copy.deepcopy(grammar)              # pristine grammar for the side legs
     t_wall0 = time.perf_counter()
     if PP > 1:
-        res = eng.decode_many(prompts, specs, [copy.deepcopy(grammar) for _ in range(PP)], cfg, warmup_iters=args.warmup,
+        res = eng.decode_many(prompts, specs, [copy.deepcopy(grammar) for _ in range(len(prompts))], cfg, warmup_iters=args.warmup,
                               timed_iters=args.steps, on_timed_start=sync_all, on_timed_end=sync_all)
         seq, stats = res[0]
-        stats.tokens = sum(r[1].tokens for r in res)            # all slots of this GPU; steps = shared window forwards
+        rs = eng.run_stats                                       # all slots of this GPU; steps = shared window forwards
+        stats.tokens, stats.timed_nfe, stats.seconds = rs["tokens"], rs["timed_iterations"], rs["seconds"]
+        stats.host_seconds, stats.sync_seconds = rs["host_seconds"], rs["sync_seconds"]
         stats.kv_len_start = P
     else:
         seq, stats = eng.decode(prompt, spec, grammar, cfg, warmup_iters=args.warmup, timed_iters=args.steps, on_timed_start=sync_all,

@@ -220,10 +220,11 @@ def teacher_forced_emu3_check(device="cuda:0", H=3, W=5, window=32, seed=5, embe
 
 @torch.no_grad()
 def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=16, seed=3, P=(12, 9), embed_token_scale=0.25,
-                               dtype=torch.bfloat16, use_graph=True, gemm="sjd", fp8_kv=False):
+                               dtype=torch.bfloat16, use_graph=True, gemm="sjd", fp8_kv=False, n_slots=None):
     """Several prompts per window forward (SJDBatchEngine): every slot's recorded logits, replayed into the CPU oracle with the slot's
     seed, must give that slot's token sequence and accept lengths -- i.e. sharing the forward changes nothing in any prompt's
-    state machine (own window, kv_len, grammar, generators)."""
+    state machine (own window, kv_len, grammar, generators).  n_slots < n_prompts: continuous batching -- a slot that finished its
+    image takes the next prompt of the list; every prompt must still decode exactly as its own oracle replay says."""
     import sjd_amd.ops as ops
     import sjd_amd.synthetic as synthetic
     from sjd_amd.engine import SJDConfig, WindowSpec
@@ -246,10 +247,11 @@ def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=
                                 key_start=torch.tensor([0, Pi - 1], dtype=torch.int32),
                                 pos_offset=torch.tensor([0, -(Pi - 1)], dtype=torch.long), kv_base=0))
     max_len = max(P) + n_img + 1 + 4
-    model.setup_cache(batch=2 * n_prompts, s_max=((max_len + 64 + 31) // 32) * 32, dtype=ops.FP8 if fp8_kv else None)
+    n_slots = n_slots or n_prompts
+    model.setup_cache(batch=2 * n_slots, s_max=((max_len + 64 + 31) // 32) * 32, dtype=ops.FP8 if fp8_kv else None)
     cfg = SJDConfig(jacobi_loop_interval_l=3, jacobi_loop_interval_r=n_img - 10, max_num_new_tokens=window, guidance_scale=3.0,
                     seed=seed, prefix_token_sampler_scheme="speculative_jacobi", max_length=1 << 20, eos_token_ids=(8196,))
-    eng = SJDBatchEngine(model, V, device, n_prompts, max_window=window, use_graph=use_graph)
+    eng = SJDBatchEngine(model, V, device, n_slots, max_window=window, use_graph=use_graph)
     recs = [_Recorder() for _ in range(n_prompts)]
     eng.hook = lambda i, d: recs[i](d)
     results = eng.decode_many(prompts, specs, [LuminaGrammar(2000, 10) for _ in range(n_prompts)], cfg)

@@ -89,6 +89,14 @@ def test_three_and_four_prompts_share_one_window_forward(n_prompts, fp8_kv):
     assert len(rs) == n_prompts and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs) and any(r["max_accept"] > 1 for r in rs)
 
 
+@pytest.mark.parametrize("n_prompts,n_slots,use_graph", [(5, 2, True), (7, 3, True), (6, 4, False)])
+def test_continuous_batching_refills_finished_slots(n_prompts, n_slots, use_graph):
+    """more prompts than slots: a slot whose image is complete is handed the next prompt (fresh state machine, KV rows reused from 0,
+    eager prefill between two replays of the window graphs); every prompt's tokens and accept lengths equal its own oracle replay."""
+    rs = G.teacher_forced_batch_check(n_prompts=n_prompts, n_slots=n_slots, P=(12, 9, 14, 7, 10), use_graph=use_graph)
+    assert len(rs) == n_prompts and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs) and any(r["max_accept"] > 1 for r in rs)
+
+
 def test_emu3_reference_api_flow(dev):
     """A14 / A18: renew_solver + prepare_batch_cfg_model_inputs + HF-shaped generate, executed (reference JE:234-278, 370-411;
     test_emu3.py:145-169), teacher-forced against the oracle."""

@@ -23,6 +23,65 @@ class _Recorder:
             noise2=d["noise2"].cpu().numpy().copy(), use_cfg=bool(d["use_cfg"])))
 
 
+class _StreamRecorder:
+    """_Recorder for long decodes: a bounded queue between the engine (producer, through its hook) and the oracle loop running in a
+    second thread, so that a whole 768px image at the 7B shapes (~1000 iterations x 17 MB of logits and noise) never sits in host memory."""
+
+    def __init__(self, depth=4):
+        import queue
+        self.q = queue.Queue(maxsize=depth)
+        self.items = self
+
+    def __call__(self, d):
+        self.q.put(dict(
+            first=d["first"], n_rows=d["n_rows"], logits_c=d["logits_c"].float().cpu().numpy().copy(),
+            logits_u=None if d["logits_u"] is None else d["logits_u"].float().cpu().numpy().copy(),
+            noise=d["noise"].cpu().numpy().copy(), rs=d["rs"].cpu().numpy().copy(),
+            noise2=d["noise2"].cpu().numpy().copy(), use_cfg=bool(d["use_cfg"])))
+
+    def close(self):
+        self.q.put(None)
+
+    def __iter__(self):
+        while True:
+            r = self.q.get()
+            if r is None:
+                return
+            yield r
+
+    def drain(self):
+        for _ in self:
+            pass
+
+
+def _replay_while_decoding(rec, decode_fn, prompt, rules_fn, cfg, V, no_cfg_fn=None, device="cuda"):
+    """run `decode_fn()` (the engine, feeding `rec`) and the oracle replay concurrently; returns (engine result, oracle result)"""
+    import threading
+    out = {}
+
+    def oracle():
+        try:
+            O.set_threads(8)          # omp_set_num_threads is per calling thread: without it this thread's regions open one thread per host core
+            out["ref"] = _replay(rec, prompt, rules_fn, cfg, V, no_cfg_fn=no_cfg_fn, device=device)
+            leftover = sum(1 for _ in rec)
+            if leftover:
+                out["err"] = AssertionError(f"the engine ran {leftover} more iterations than the oracle")
+        except BaseException as e:          # keep consuming: the engine must not block on a full queue
+            out["err"] = e
+            rec.drain()
+
+    th = threading.Thread(target=oracle)
+    th.start()
+    try:
+        out["eng"] = decode_fn()
+    finally:
+        rec.close()
+        th.join()
+    if "err" in out:
+        raise out["err"]
+    return out["eng"], out["ref"]
+
+
 def _replay(rec, prompt, rules_fn, cfg, V, no_cfg_fn=None, device="cuda", grid_fn=None):
     it = iter(rec.items)
     state = {"i": -1}
@@ -362,7 +421,7 @@ def teacher_forced_anole_api_check(device="cuda:0", img_len=36, window=16, seed=
 
 
 @torch.no_grad()
-def teacher_forced_real_shape_check(family="lumina7b", device="cuda:0", prompt_len=700, new_tokens=56, seed=11):
+def teacher_forced_real_shape_check(family="lumina7b", device="cuda:0", prompt_len=700, new_tokens=56, seed=11, stream=False):
     """Teacher-forced parity at the REAL architecture shapes and production launch configuration (BASELINE.json configs 2 / 3):
     Lumina-mGPT-7B (32 layers, hidden 4096, 32 heads, V=65536, window 16, G1_CFG, K1 auto-split 4, output head on the grammar's column
     window, hipGraph) or Emu3-Gen-8B (GQA 32/8, V=184622, fp16, window 32, G1_CFG_EMU3, k1_partial_shared).  A prompt of `prompt_len`
@@ -375,13 +434,13 @@ def teacher_forced_real_shape_check(family="lumina7b", device="cuda:0", prompt_l
     from sjd_amd.frontends import lumina_window_spec, lumina_prompt, emu3_window_spec
     from sjd_amd.grammar import LuminaGrammar, Emu3Grammar
     dev = torch.device(device)
-    if family == "lumina7b":
+    if family in ("lumina7b", "anole7b"):          # Anole-7B is the Chameleon-7B architecture; config 5 runs it on an fp8 KV cache
         margs, dt, window = BB.LUMINA_7B, torch.bfloat16, 16
     else:
         margs, dt, window = BB.EMU3_8B, torch.float16, 32
     with torch.device(dev):
         model = BB.ChameleonBackbone(margs, attn=ops.HipWindowAttention()).to(dt).eval()
-    if family != "lumina7b":
+    if family == "emu3_8b":
         model.G1_CFG = dict(model.G1_CFG_EMU3)
     synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=0.7)
     model.enable_fused(ops, gemm="sjd")
@@ -393,6 +452,16 @@ def teacher_forced_real_shape_check(family="lumina7b", device="cuda:0", prompt_l
         grammar, rules_fn, no_cfg = LuminaGrammar(2000, 10), (lambda c, n: O.lumina_rules(c, n, 2000, 10)), O.lumina_force_no_cfg
         cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=grid * grid + grid - 13, max_num_new_tokens=window, guidance_scale=3.0,
                         seed=seed, max_length=len(prompt) + new_tokens, eos_token_ids=(8196,))
+    elif family == "anole7b":
+        from sjd_amd.grammar import AnoleGrammar
+        n_img = min(1024, max(new_tokens - 1, window + 8))           # 512x512 -> 1024 image tokens + <eoi>, no line tokens
+        prompt = synthetic.synthetic_prompt(prompt_len - 1, seed, lo=9000, hi=60000)[0].tolist() + [8197]
+        spec = lumina_window_spec(prompt, dev)
+        max_len = len(prompt) + n_img + 1
+        grammar, no_cfg = AnoleGrammar(V, len(prompt), max_len, n_img), None
+        rules_fn = lambda c, n: O.anole_rules(c, n, V, len(prompt), max_len, n_img, top_k=2000)
+        cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=n_img - window - 2, max_num_new_tokens=window, guidance_scale=3.0,
+                        seed=seed, max_length=max_len, eos_token_ids=(8196,))
     else:
         tok = dict(img_token=151851, eoi_token=151853, eos_token=151850, eol_token=151846, eof_token=151847, pad_token=151643)
         Hh = Ww = 90
@@ -404,13 +473,19 @@ def teacher_forced_real_shape_check(family="lumina7b", device="cuda:0", prompt_l
         rules_fn, no_cfg = (lambda c, n: O.emu3_rules(c, n, Hh, Ww, 151854, 32768, top_k=2048, **tok)), None
         cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=Hh * Ww - 1, max_num_new_tokens=window, guidance_scale=3.0,
                         seed=seed, max_length=len(prompt) + new_tokens, eos_token_ids=(tok["eos_token"],))
-    model.setup_cache(batch=2, s_max=((len(prompt) + new_tokens + 2 * window + 64 + 31) // 32) * 32)
+    model.setup_cache(batch=2, s_max=((len(prompt) + new_tokens + 2 * window + 64 + 31) // 32) * 32, dtype=ops.FP8 if family == "anole7b" else None)
     eng = SJDEngine(model, V, dev, max_window=window, use_graph=True)
-    rec = _Recorder()
-    eng.hook = rec
-    seq, stats = eng.decode(prompt, spec, grammar, cfg)
     O.set_threads(8)
-    seq_ref, tr, checks = _replay(rec, prompt, rules_fn, _loop_cfg(cfg), V, no_cfg_fn=no_cfg, device=device)
+    if stream:       # long decodes (a whole image): the oracle consumes every iteration while the engine produces the next
+        rec = _StreamRecorder()
+        eng.hook = rec
+        (seq, stats), (seq_ref, tr, checks) = _replay_while_decoding(rec, lambda: eng.decode(prompt, spec, grammar, cfg), prompt, rules_fn,
+                                                                      _loop_cfg(cfg), V, no_cfg_fn=no_cfg, device=device)
+    else:
+        rec = _Recorder()
+        eng.hook = rec
+        seq, stats = eng.decode(prompt, spec, grammar, cfg)
+        seq_ref, tr, checks = _replay(rec, prompt, rules_fn, _loop_cfg(cfg), V, no_cfg_fn=no_cfg, device=device)
     assert seq == seq_ref, "token sequences differ"
     assert stats.matched == tr.matched and stats.nfe == len(tr.matched)
     graphs = [k for k in eng._graphs if isinstance(k, tuple) and k[0] == "fwd"]

@@ -131,6 +131,21 @@ def test_real_shape_teacher_forced_loop(dev, family):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("family,prompt_len,n_tokens", [("lumina7b", 64, 48 * 49 + 1), ("anole7b", 64, 1025), ("emu3_8b", 64, 91 * 90 + 3)])
+def test_whole_image_at_the_real_shapes(dev, family, prompt_len, n_tokens):
+    """BASELINE.json configs 2, 5 and 3 at FULL size: the whole image -- Lumina-7B 768px (48 x 48 tokens + line ends, ~1000 SJD
+    iterations, KV 64 -> 2416), Anole-7B 512px on the fp8 KV cache (1024 tokens + <eoi>), Emu3-8B 720px (90 x 91 tokens + the three
+    closing tokens, ~3800 iterations, KV -> 8.3k, V = 184 622) -- on the production launch configuration, every iteration's logits
+    replayed into the CPU oracle while the engine computes the next one: identical tokens, accept lengths and noise streams from the
+    first draft to the end token."""
+    from tests.gpu_loop_check import teacher_forced_real_shape_check
+    if torch.cuda.get_device_properties(dev).total_memory < 60e9:
+        pytest.skip("needs a 7B-class model + its packed copy in HBM")
+    r = teacher_forced_real_shape_check(family=family, device=str(dev), prompt_len=prompt_len, new_tokens=n_tokens + 7, stream=True)
+    assert r["tokens"] == n_tokens and r["nfe"] < 0.6 * n_tokens and max(r["accepted"]) >= 8
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("init_scheme", ["repeat_horizon", "sample_horizon"])
 @pytest.mark.parametrize("use_graph,gemm", [(False, "torch"), (True, "sjd")])
 def test_lumina_loop_spatial_init(init_scheme, use_graph, gemm):

@@ -491,3 +491,50 @@ def teacher_forced_real_shape_check(family="lumina7b", device="cuda:0", prompt_l
     graphs = [k for k in eng._graphs if isinstance(k, tuple) and k[0] == "fwd"]
     return dict(tokens=len(seq) - len(prompt), nfe=stats.nfe, accepted=sorted(set(stats.matched[1:])), n_split=model.attn.n_split,
                 fwd_graphs=len(graphs), head_cols=[k[1] for k in graphs])
+
+
+@torch.no_grad()
+def teacher_forced_real_shape_batch_check(device="cuda:0", n_prompts=4, prompt_lens=(652, 700, 671, 689), new_tokens=56, seed=21):
+    """SJDBatchEngine at the REAL Lumina-mGPT-7B shapes and its production launch configuration: 128 window rows per forward on the
+    sub-tiled G1 (G1_CFG_128ROW / G1_CFG_64ROW for two prompts), K1 over 2 x n_prompts batch rows (single key split: direct output),
+    hipGraph; prompts of different length (different kv_len per slot; max_length is per engine, so the shorter prompts decode up to 48
+    tokens more), 25..50 iterations, every slot replayed against the oracle."""
+    import sjd_amd.ops as ops
+    import sjd_amd.backbones as BB
+    import sjd_amd.synthetic as synthetic
+    from sjd_amd.engine import SJDConfig
+    from sjd_amd.engine_batch import SJDBatchEngine
+    from sjd_amd.frontends import lumina_window_spec, lumina_prompt
+    from sjd_amd.grammar import LuminaGrammar
+    dev = torch.device(device)
+    margs, window, grid = BB.LUMINA_7B, 16, 48
+    with torch.device(dev):
+        model = BB.ChameleonBackbone(margs, attn=ops.HipWindowAttention()).to(torch.bfloat16).eval()
+    model.G1_CFG = dict(model.G1_CFG_64ROW if n_prompts == 2 else model.G1_CFG_128ROW)
+    synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=0.7)
+    model.enable_fused(ops, gemm="sjd")
+    V = margs.vocab_size
+    prompts = [lumina_prompt(prompt_lens[i % len(prompt_lens)], grid, grid, seed=seed + i) for i in range(n_prompts)]
+    specs = [lumina_window_spec(p_, dev) for p_ in prompts]
+    max_len = max(len(p_) for p_ in prompts) + new_tokens
+    model.setup_cache(batch=2 * n_prompts, s_max=((max_len + 2 * window + 64 + 31) // 32) * 32)
+    # every prompt stops after new_tokens tokens of ITS OWN sequence: max_length is per engine, so the longest prompt decides and the
+    # shorter ones decode a little further -- each replay below uses the same limit
+    cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=grid * grid + grid - 13, max_num_new_tokens=window, guidance_scale=3.0,
+                    seed=seed, max_length=max_len, eos_token_ids=(8196,))
+    eng = SJDBatchEngine(model, V, dev, n_prompts, max_window=window, use_graph=True)
+    recs = [_Recorder() for _ in range(n_prompts)]
+    eng.hook = lambda i, d: recs[i](d)
+    results = eng.decode_many(prompts, specs, [LuminaGrammar(2000, 10) for _ in range(n_prompts)], cfg)
+    O.set_threads(8)
+    out = []
+    for i, (seq, stats) in enumerate(results):
+        c = _loop_cfg(cfg)
+        c.seed = cfg.seed + i
+        seq_ref, tr, _ = _replay(recs[i], prompts[i], lambda cx, n: O.lumina_rules(cx, n, 2000, 10), c, V, no_cfg_fn=O.lumina_force_no_cfg,
+                                 device=device)
+        assert seq == seq_ref, f"slot {i}: token sequences differ"
+        assert stats.matched == tr.matched, f"slot {i}: accept lengths differ"
+        out.append(dict(tokens=len(seq) - len(prompts[i]), nfe=stats.nfe, max_accept=max(stats.matched[1:])))
+        recs[i].items.clear()
+    return dict(slots=out, n_split=model.attn.n_split, fwd_graphs=len([k for k in eng._graphs if isinstance(k, tuple) and k[0] == "fwd"]))

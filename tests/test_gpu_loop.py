@@ -131,6 +131,19 @@ def test_real_shape_teacher_forced_loop(dev, family):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("n_prompts", [2, 4])
+def test_real_shape_batch_engine_teacher_forced(dev, n_prompts):
+    """the two / four-prompt engine at the real Lumina-7B shapes (64 / 128 window rows: whole-chunk and sub-tiled G1, K1 over 4 / 8 batch
+    rows, prompts of 652..700 tokens so every slot has its own KV length), every slot against its oracle replay"""
+    from tests.gpu_loop_check import teacher_forced_real_shape_batch_check
+    if torch.cuda.get_device_properties(dev).total_memory < 60e9:
+        pytest.skip("needs a 7B-class model + its packed copy in HBM")
+    r = teacher_forced_real_shape_batch_check(device=str(dev), n_prompts=n_prompts)
+    assert len(r["slots"]) == n_prompts and all(s_["tokens"] >= 56 and s_["nfe"] >= 12 for s_ in r["slots"])
+    assert r["n_split"] == (2 if n_prompts == 2 else 1) and r["fwd_graphs"] >= 1
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("family,prompt_len,n_tokens", [("lumina7b", 64, 48 * 49 + 1), ("anole7b", 64, 1025), ("emu3_8b", 64, 91 * 90 + 3)])
 def test_whole_image_at_the_real_shapes(dev, family, prompt_len, n_tokens):
     """BASELINE.json configs 2, 5 and 3 at FULL size: the whole image -- Lumina-7B 768px (48 x 48 tokens + line ends, ~1000 SJD

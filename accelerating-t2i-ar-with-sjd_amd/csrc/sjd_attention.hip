@@ -34,6 +34,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define K1_WAVES 4
 #define K1_KT 32          // keys per wave tile
 #define K1_ROWS 16        // query rows per chunk
+#define K1_RPAD 4          // fp32 padding of a merge-buffer row: rows 16 banks apart instead of on the same bank
 #define K1_MIN_TILES_PER_SPLIT 4   // a key split is only opened when it gets at least one tile per wave
 
 // Key-tile range [t_lo, t_hi) of a (batch row, chunk) and the number of splits actually used for it.  The launch grid
@@ -79,6 +80,65 @@ __device__ __forceinline__ u32x2 lds_tr_read(const unsigned short *p)
     return __builtin_bit_cast(u32x2, r);
 }
 
+// Epilogue of k1_partial / k1_partial_fp8: merge the key-part states (m, l, O) of every head of the workgroup, which the waves have
+// written to LDS, and publish the result -- the split partial (fp32 workspace) or, with ONE key split, the normalised 16-bit output.
+// One thread per four output columns; its 8 (m, l) pairs and 8 O quads are read from LDS up front (16 independent reads, one round
+// trip), then max / exp / weighted sums in key-part order.  In-kernel timestamps (round 2): the earlier form -- one element per thread,
+// ~50 DEPENDENT LDS reads, rows of the buffer all on one bank -- took 5.3 us of a 14.6 us launch (3.6 us of them bank-conflicted writes
+// and the dependent chain); this one 0.5 us + 0.5 us for the writes.
+template <int DT, int D, int NW>
+__device__ __forceinline__ void k1_merge_publish(float (*red_o)[K1_ROWS][D + K1_RPAD], float (*red_ml)[K1_ROWS][2], int G, int kparts,
+                                                 int b, int H, int head0, int n_chunks, int chunk, int n_split, int split, int row0, int n_rows,
+                                                 int n_total, float *__restrict__ ws_o, float *__restrict__ ws_ml,
+                                                 unsigned short *__restrict__ out_direct)
+{
+    constexpr int D4 = D / 4;
+    for (int u = threadIdx.x; u < G * K1_ROWS * D4; u += 64 * NW) {
+        const int hg = u / (K1_ROWS * D4), row = (u / D4) % K1_ROWS, d = (u % D4) * 4;
+        float mk[NW], lk[NW];
+        float4 ok[NW];
+#pragma unroll
+        for (int kp = 0; kp < NW; ++kp) {                      // every LDS read of this thread is issued before the first use
+            const bool on = kp < kparts;
+            const int ww = on ? kp * G + hg : hg;
+            const float2 v = *reinterpret_cast<const float2 *>(&red_ml[ww][row][0]);
+            ok[kp] = *reinterpret_cast<const float4 *>(&red_o[ww][row][d]);
+            mk[kp] = on ? v.x : -INFINITY;
+            lk[kp] = v.y;
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int kp = 0; kp < NW; ++kp) M = fmaxf(M, mk[kp]);
+        const float Ms = (M == -INFINITY) ? 0.0f : M;
+        float L = 0.f, O0 = 0.f, O1 = 0.f, O2 = 0.f, O3 = 0.f;
+#pragma unroll
+        for (int kp = 0; kp < NW; ++kp)
+            if (kp < kparts) {
+                const float wgt = __expf(mk[kp] - Ms);
+                L += wgt * lk[kp];
+                O0 += wgt * ok[kp].x; O1 += wgt * ok[kp].y; O2 += wgt * ok[kp].z; O3 += wgt * ok[kp].w;
+            }
+        if (out_direct) {
+            // one key split (n_split == 1): this IS the attention output -- exactly what k1_combine makes of a single partial
+            // (acc = 0 * exp(-inf) + O * exp(0), L likewise), written without the workspace round trip and the second launch
+            const int grow = row0 + row;
+            if (grow < n_rows) {
+                const float inv = L > 0.f ? 1.0f / L : 0.0f;
+                uint2 pk{0u, 0u};
+                if (grow < n_total) {
+                    pk.x = (unsigned)Frag<DT>::cvt(O0 * inv) | ((unsigned)Frag<DT>::cvt(O1 * inv) << 16);
+                    pk.y = (unsigned)Frag<DT>::cvt(O2 * inv) | ((unsigned)Frag<DT>::cvt(O3 * inv) << 16);
+                }
+                *reinterpret_cast<uint2 *>(out_direct + (((size_t)b * n_rows + grow) * H + (head0 + hg)) * D + d) = pk;
+            }
+            continue;
+        }
+        const size_t slot = ((((size_t)b * H + (head0 + hg)) * n_chunks + chunk) * n_split + split) * K1_ROWS + row;
+        *reinterpret_cast<float4 *>(ws_o + slot * D + d) = float4{O0, O1, O2, O3};
+        if (d == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = L; }
+    }
+}
+
 // NW wave64 per workgroup (4, or 8 for two waves per SIMD: twice the key tiles in flight per CU; the key-parts are merged in LDS)
 template <int DT, int D, int NW>
 __global__ __launch_bounds__(64 * NW) void k1_partial(
@@ -94,11 +154,11 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
     // one LDS arena: the per-wave V tiles during the key loop, then (after a barrier) the fp32 merge buffers of the epilogue;
     // aliasing them keeps the workgroup at ~35 KB so that four workgroups fit on a CU
     constexpr int V_BYTES = NW * K1_KT * VROW * 2;
-    constexpr int R_BYTES = NW * K1_ROWS * (D + 2) * 4;
+    constexpr int R_BYTES = NW * K1_ROWS * (D + K1_RPAD + 2) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char arena[V_BYTES > R_BYTES ? V_BYTES : R_BYTES];
     unsigned short (*v_lds)[K1_KT * VROW] = reinterpret_cast<unsigned short (*)[K1_KT * VROW]>(arena);
-    float (*red_o)[K1_ROWS][D] = reinterpret_cast<float (*)[K1_ROWS][D]>(arena);
-    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + NW * K1_ROWS * D * 4);
+    float (*red_o)[K1_ROWS][D + K1_RPAD] = reinterpret_cast<float (*)[K1_ROWS][D + K1_RPAD]>(arena);
+    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + NW * K1_ROWS * (D + K1_RPAD) * 4);
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -174,15 +234,10 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
         }
     };
 
-    int t = t_begin + kpart;
-    if (t < t_end) {
-        load_tile(t, kreg, vstage);
-        store_v(t, vstage);
-    }
-    for (; t < t_end; t += kparts) {
-        const int tn = t + kparts;
-        const bool has_next = tn < t_end;
-        if (has_next) load_tile(tn, kn, vstage);
+    // Two tiles of a wave are in flight before the first one is waited for (in-kernel timestamps, round 2: with one tile in flight a
+    // wave that owns two or three tiles pays 3.4 us of HBM latency for each of them).
+    u32x4 vstage2[VP];
+    auto compute_tile = [&](int t) {
 
         // ---- S^T = K Q^T for the two 16-key blocks
         f32x4 st[2];
@@ -240,48 +295,43 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
             acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
             o_acc[db] = Frag<DT>::mfma(as_frag<vec>(vv), pfrag, acc);
         }
-        if (has_next) {
-            store_v(tn, vstage);
+    };
+    auto adopt_next = [&](int tn, u32x4 (&vd)[VP]) {
+        store_v(tn, vd);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) kreg[kb][ks] = kn[kb][ks];
+            for (int ks = 0; ks < KS; ++ks) kreg[kb][ks] = kn[kb][ks];
+    };
+    int t = t_begin + kpart;
+    if (t < t_end) {
+        load_tile(t, kreg, vstage);
+        if (t + kparts < t_end) {
+            load_tile(t + kparts, kn, vstage2);
+            store_v(t, vstage);
+            compute_tile(t);
+            adopt_next(t + kparts, vstage2);
+            t += kparts;
+        } else {
+            store_v(t, vstage);
         }
+    }
+    for (; t < t_end; t += kparts) {
+        const int tn = t + kparts;
+        const bool has_next = tn < t_end;
+        if (has_next) load_tile(tn, kn, vstage);
+        compute_tile(t);
+        if (has_next) adopt_next(tn, vstage);
     }
 
     // ---- merge the key-parts of each head inside the workgroup, then publish the split partial
     __syncthreads();            // every wave is done with its V tile: the arena is reused for the merge buffers
     if (g == 0) { red_ml[w][c][0] = m_run; red_ml[w][c][1] = l_run; }
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red_o[w][c][16 * db + 4 * g + r] = o_acc[db][r];
+    for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(&red_o[w][c][16 * db + 4 * g]) = o_acc[db];
     __syncthreads();
-    for (int idx = threadIdx.x; idx < G * K1_ROWS * D; idx += 64 * NW) {
-        const int hg = idx / (K1_ROWS * D), row = (idx / D) % K1_ROWS, d = idx % D;
-        float M = -INFINITY;
-        for (int kp = 0; kp < kparts; ++kp) M = fmaxf(M, red_ml[kp * G + hg][row][0]);
-        const float Ms = (M == -INFINITY) ? 0.0f : M;
-        float L = 0.f, O = 0.f;
-        for (int kp = 0; kp < kparts; ++kp) {
-            const int ww = kp * G + hg;
-            const float wgt = __expf(red_ml[ww][row][0] - Ms);
-            L += wgt * red_ml[ww][row][1];
-            O += wgt * red_o[ww][row][d];
-        }
-        if (out_direct) {
-            // one key split (n_split == 1): this IS the attention output -- exactly what k1_combine makes of a single partial
-            // (acc = 0 * exp(-inf) + O * exp(0), L likewise), written without the workspace round trip and the second launch
-            const int grow = row0 + row;
-            if (grow < n_rows)
-                out_direct[(((size_t)b * n_rows + grow) * H + (hkv * G + hg)) * D + d] =
-                    grow < n_total ? Frag<DT>::cvt(O * (L > 0.f ? 1.0f / L : 0.0f)) : (unsigned short)0;
-            continue;
-        }
-        const size_t slot = ((((size_t)b * H + (hkv * G + hg)) * n_chunks + chunk) * n_split + split) * K1_ROWS + row;
-        ws_o[slot * D + d] = O;
-        if (d == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = L; }
-    }
+    k1_merge_publish<DT, D, NW>(red_o, red_ml, G, kparts, b, H, hkv * G, n_chunks, chunk, n_split, split, row0, n_rows, n_total, ws_o, ws_ml,
+                                out_direct);
 }
 
 // ------------------------------------------------------------------------------------------------ K1 (shared tiles)
@@ -883,10 +933,10 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
     constexpr int VROW = D + 16;          // padded LDS row in bytes (16-B aligned rows, breaks the 128-B bank period)
     constexpr float PSCALE = 256.0f;
     constexpr int V_BYTES = NW * K1_KT * VROW;
-    constexpr int R_BYTES = NW * K1_ROWS * (D + 2) * 4;
+    constexpr int R_BYTES = NW * K1_ROWS * (D + K1_RPAD + 2) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char arena[V_BYTES > R_BYTES ? V_BYTES : R_BYTES];
-    float (*red_o)[K1_ROWS][D] = reinterpret_cast<float (*)[K1_ROWS][D]>(arena);
-    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + NW * K1_ROWS * D * 4);
+    float (*red_o)[K1_ROWS][D + K1_RPAD] = reinterpret_cast<float (*)[K1_ROWS][D + K1_RPAD]>(arena);
+    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + NW * K1_ROWS * (D + K1_RPAD) * 4);
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -974,15 +1024,9 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
     const int jrow = c >> 1;
     const unsigned char *vrd = vl + (16 * (jrow >> 2) + 4 * g + (jrow & 3)) * VROW + 8 * (c & 1);
 
-    int t = t_begin + kpart;
-    if (t < t_end) {
-        load_tile(t, kreg, vstage);
-        store_v(t, vstage);
-    }
-    for (; t < t_end; t += kparts) {
-        const int tn = t + kparts;
-        const bool has_next = tn < t_end;
-        if (has_next) load_tile(tn, kn, vstage);
+    // two tiles of a wave in flight before the first one is waited for (see k1_partial)
+    u32x4 vstage2[VP];
+    auto compute_tile = [&](int t) {
 
         f32x4 st[2];
 #pragma unroll
@@ -1031,48 +1075,43 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
             acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
             o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long((unsigned)vv[0], (unsigned)vv[1]), pfrag, acc, 0, 0, 0);
         }
-        if (has_next) {
-            store_v(tn, vstage);
+    };
+    auto adopt_next = [&](int tn, u32x4 (&vd)[VP]) {
+        store_v(tn, vd);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int p = 0; p < KP; ++p) kreg[kb][p] = kn[kb][p];
+            for (int p = 0; p < KP; ++p) kreg[kb][p] = kn[kb][p];
+    };
+    int t = t_begin + kpart;
+    if (t < t_end) {
+        load_tile(t, kreg, vstage);
+        if (t + kparts < t_end) {
+            load_tile(t + kparts, kn, vstage2);
+            store_v(t, vstage);
+            compute_tile(t);
+            adopt_next(t + kparts, vstage2);
+            t += kparts;
+        } else {
+            store_v(t, vstage);
         }
+    }
+    for (; t < t_end; t += kparts) {
+        const int tn = t + kparts;
+        const bool has_next = tn < t_end;
+        if (has_next) load_tile(tn, kn, vstage);
+        compute_tile(t);
+        if (has_next) adopt_next(tn, vstage);
     }
 
     __syncthreads();
     const float oscale = v_scale / PSCALE;
     if (g == 0) { red_ml[w][c][0] = m_run; red_ml[w][c][1] = l_run; }
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red_o[w][c][16 * db + 4 * g + r] = o_acc[db][r] * oscale;
+    for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(&red_o[w][c][16 * db + 4 * g]) = o_acc[db] * oscale;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < G * K1_ROWS * D; idx += 64 * NW) {
-        const int hg = idx / (K1_ROWS * D), row = (idx / D) % K1_ROWS, d = idx % D;
-        float M = -INFINITY;
-        for (int kp = 0; kp < kparts; ++kp) M = fmaxf(M, red_ml[kp * G + hg][row][0]);
-        const float Ms = (M == -INFINITY) ? 0.0f : M;
-        float L = 0.f, O = 0.f;
-        for (int kp = 0; kp < kparts; ++kp) {
-            const int ww = kp * G + hg;
-            const float wgt = __expf(red_ml[ww][row][0] - Ms);
-            L += wgt * red_ml[ww][row][1];
-            O += wgt * red_o[ww][row][d];
-        }
-        if (out_direct) {
-            // one key split (n_split == 1): this IS the attention output -- exactly what k1_combine makes of a single partial
-            // (acc = 0 * exp(-inf) + O * exp(0), L likewise), written without the workspace round trip and the second launch
-            const int grow = row0 + row;
-            if (grow < n_rows)
-                out_direct[(((size_t)b * n_rows + grow) * H + (hkv * G + hg)) * D + d] =
-                    grow < n_total ? Frag<DT>::cvt(O * (L > 0.f ? 1.0f / L : 0.0f)) : (unsigned short)0;
-            continue;
-        }
-        const size_t slot = ((((size_t)b * H + (hkv * G + hg)) * n_chunks + chunk) * n_split + split) * K1_ROWS + row;
-        ws_o[slot * D + d] = O;
-        if (d == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = L; }
-    }
+    k1_merge_publish<DT, D, NW>(red_o, red_ml, G, kparts, b, H, hkv * G, n_chunks, chunk, n_split, split, row0, n_rows, n_total, ws_o, ws_ml,
+                                out_direct);
 }
 
 // K3 for an fp8 cache: rows [kv_len, kv_len + n) <- fp8(x / scale); one thread converts 8 values (16 B in, 8 B out)

@@ -11,7 +11,7 @@ MAX_RANGES = 4
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libsjd_hip.so")
+SO_PATH = os.environ.get("SJD_HIP_LIB") or os.path.join(_HERE, "libsjd_hip.so")      # SJD_HIP_LIB: an instrumented build (tools/phase_trace.py)
 
 
 class RowRule(ctypes.Structure):

@@ -32,6 +32,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 #define K1_WAVES 4
+// Phase timestamps (tools/phase_trace.py builds with -DSJD_TRACE; compiled out otherwise): thread 0 of every workgroup records the
+// 100 MHz wall clock at the phase boundaries of k1_partial.  This is how the 5.3 us merge epilogue and the serialised second key tile
+// were found in round 2.
+#ifdef SJD_TRACE
+__device__ unsigned long long g_k1_trace[4096][8];
+#define SJD_TR(i) do { if (threadIdx.x == 0) g_k1_trace[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 4095][i] = wall_clock64(); } while (0)
+#else
+#define SJD_TR(i) do { } while (0)
+#endif
 #define K1_KT 32          // keys per wave tile
 #define K1_ROWS 16        // query rows per chunk
 #define K1_RPAD 4          // fp32 padding of a merge-buffer row: rows 16 banks apart instead of on the same bank
@@ -160,6 +169,7 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
     float (*red_o)[K1_ROWS][D + K1_RPAD] = reinterpret_cast<float (*)[K1_ROWS][D + K1_RPAD]>(arena);
     float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + NW * K1_ROWS * (D + K1_RPAD) * 4);
 
+    SJD_TR(0);                    // entry
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int G = H / H_kv;
@@ -183,6 +193,7 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
     k1_tile_range(kstart, total, n_split, t_lo, t_hi, eff_split, tps);
     if (split >= eff_split) return;
     const int t_begin = t_lo + split * tps, t_end = min(t_hi, t_begin + tps);
+    SJD_TR(1);                    // kv_len / key_start known
 
     // Q fragments (B operand): lane (row c, group g) holds Q[row0+c][head][32*ks + 8g .. +7]
     vec qf[KS];
@@ -309,11 +320,13 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
         if (t + kparts < t_end) {
             load_tile(t + kparts, kn, vstage2);
             store_v(t, vstage);
+            SJD_TR(2);            // first tile arrived
             compute_tile(t);
             adopt_next(t + kparts, vstage2);
             t += kparts;
         } else {
             store_v(t, vstage);
+            SJD_TR(2);
         }
     }
     for (; t < t_end; t += kparts) {
@@ -324,14 +337,22 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
         if (has_next) adopt_next(tn, vstage);
     }
 
+    SJD_TR(3);                    // key loop done
     // ---- merge the key-parts of each head inside the workgroup, then publish the split partial
-    __syncthreads();            // every wave is done with its V tile: the arena is reused for the merge buffers
+    __syncthreads();
+    SJD_TR(4);                    // all waves done            // every wave is done with its V tile: the arena is reused for the merge buffers
     if (g == 0) { red_ml[w][c][0] = m_run; red_ml[w][c][1] = l_run; }
 #pragma unroll
     for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(&red_o[w][c][16 * db + 4 * g]) = o_acc[db];
     __syncthreads();
+    SJD_TR(5);                    // merge buffers written
     k1_merge_publish<DT, D, NW>(red_o, red_ml, G, kparts, b, H, hkv * G, n_chunks, chunk, n_split, split, row0, n_rows, n_total, ws_o, ws_ml,
                                 out_direct);
+#ifdef SJD_TRACE
+    SJD_TR(6);                    // merged, stores issued
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    SJD_TR(7);                    // stores acknowledged
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ K1 (shared tiles)
@@ -1375,3 +1396,10 @@ extern "C" float sjd_event_elapsed_ms(void *ev_start, void *ev_stop)
     if (hipEventElapsedTime(&ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop) != hipSuccess) return -1.0f;
     return ms;
 }
+
+#ifdef SJD_TRACE
+extern "C" int sjd_debug_trace_k1(unsigned long long *host_out, int n_wg)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k1_trace), (size_t)n_wg * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif

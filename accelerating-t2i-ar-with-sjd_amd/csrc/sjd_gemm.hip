@@ -21,6 +21,14 @@
 #include "../../include/sjd_hip.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// phase timestamps of g1_skinny_gemm (tools/phase_trace.py, -DSJD_TRACE; compiled out otherwise), see sjd_attention.hip
+#ifdef SJD_TRACE
+__device__ unsigned long long g_g1_trace[4096][8];
+#define SJD_TR(i) do { if (threadIdx.x == 0) g_g1_trace[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][i] = wall_clock64(); } while (0)
+#else
+#define SJD_TR(i) do { } while (0)
+#endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -52,11 +60,14 @@ template <> struct G1Mfma<SJD_DTYPE_F16> {
 // MT = 2 serves a 64-row window (B_cfg * L with a draft window of 32): every weight record feeds two MFMAs.
 // Column window: the launch covers tiles [tile0, tile0 + N/32) of a weight packed with `n_tiles` tiles (N = columns of THIS launch's
 // output): the output head is evaluated only for the vocabulary columns the grammar allows out of one packed copy.
-template <int DT, int MT>
-__global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
+// MAXT: 512 (<= 8 waves: 256 VGPRs, sixteen activation pieces per thread in flight -> a 2048-column chunk is staged in ONE round trip)
+// or 1024 (9..16 waves, eight pieces).
+template <int DT, int MT, int MAXT>
+__global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                 float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
                                                                 int rec_stride, int tile0)
 {
+    SJD_TR(0);                    // entry
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *xl = reinterpret_cast<u32x4 *>(smem);
     const int chunk = blockIdx.y;
@@ -84,30 +95,52 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
     // travel while the activation is written to LDS.
     const int ppr = 2 * steps;                                    // pieces per row of the chunk
     const int n_pieces = MT * 32 * ppr, nth = blockDim.x;
-    for (int v0 = threadIdx.x, batch = 0; v0 < n_pieces || batch == 0; v0 += G1_STAGE * nth, ++batch) {
-        u32x4 val[G1_STAGE];
+    constexpr int STAGE = MAXT <= 512 ? 2 * G1_STAGE : G1_STAGE;
+    // piece v = (row m, 16-byte piece j of the row); a thread's pieces are nth apart: (m, j) advance without a division per piece
+    const int dm = nth / ppr, dj = nth - dm * ppr;
+    int pm = threadIdx.x / ppr, pj = threadIdx.x - pm * ppr;
+    auto advance = [&](int &m, int &j) { m += dm; j += dj; if (j >= ppr) { j -= ppr; ++m; } };
+    auto x_load = [&](int m, int j) -> u32x4 {
+        return (m < M) ? *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + 8 * j) : u32x4{0u, 0u, 0u, 0u};      // (M <= 32 MT)
+    };
+    auto x_store = [&](int m, int j, u32x4 val) {
+        const int s = j >> 1;
+        if (m < 32 * MT) xl[((m >> 5) * steps + s) * 64 + g1_slot(j & 1, m & 31, s)] = val;
+    };
+    {   // first batch, then the first weight group right behind it.  The weight loads are UNCONDITIONAL (a wave without a tile reads
+        // tile 0, a chunk shorter than a group re-reads its last record): the compiler can then count them and wait for the activation
+        // with vmcnt(8) -- with a conditional block it waits with vmcnt(0), i.e. the LDS writes and the barrier below sat behind the
+        // whole HBM round trip of the weights (in-kernel timestamps, round 2: 1.7 us).
+        u32x4 val[STAGE];
+        int m = pm, j = pj;
 #pragma unroll
-        for (int i = 0; i < G1_STAGE; ++i) {
-            const int v = v0 + i * nth, m = v / ppr, j = v - m * ppr;
-            val[i] = u32x4{0u, 0u, 0u, 0u};
-            if (v < n_pieces && m < M) val[i] = *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + 8 * j);
-        }
-        if (batch == 0 && has_tile && full > 0) {
+        for (int i = 0; i < STAGE; ++i) { val[i] = x_load(m, j); advance(m, j); }
 #pragma unroll
-            for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);
-        }
+        for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)min(u, steps - 1) * rs);
+        m = pm; j = pj;
 #pragma unroll
-        for (int i = 0; i < G1_STAGE; ++i) {
-            const int v = v0 + i * nth, m = v / ppr, j = v - m * ppr, s = j >> 1;
-            if (v < n_pieces) xl[((m >> 5) * steps + s) * 64 + g1_slot(j & 1, m & 31, s)] = val[i];
-        }
+        for (int i = 0; i < STAGE; ++i) { x_store(m, j, val[i]); advance(m, j); }
+        pm = m; pj = j;
     }
+    while (pm < 32 * MT) {                                         // what is left of a tall / long chunk
+        u32x4 val[G1_STAGE];
+        int m = pm, j = pj;
+#pragma unroll
+        for (int i = 0; i < G1_STAGE; ++i) { val[i] = x_load(m, j); advance(m, j); }
+        m = pm; j = pj;
+#pragma unroll
+        for (int i = 0; i < G1_STAGE; ++i) { x_store(m, j, val[i]); advance(m, j); }
+        pm = m; pj = j;
+    }
+    SJD_TR(1);                    // this wave's share of the activation chunk is in LDS
     __syncthreads();
+    SJD_TR(2);                    // all of it is
     if (!has_tile) return;
     // Nothing may be pending on the vector-memory counter when the main loop is entered: the compiler places ONE s_waitcnt per MFMA
     // for every path into the loop, and with the prologue's weight loads possibly outstanding it would wait for the group just
     // issued (vmcnt(7)..vmcnt(0)) instead of letting the MFMAs of this group run under the loads of the next one.
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+    SJD_TR(3);                    // first weight group arrived
     f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -136,6 +169,7 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
         for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(xl[mt * xs + s * 64 + g1_slot(lane >> 5, lane & 31, s)], wv, acc[mt]);
     }
 
+    SJD_TR(4);                    // main loop done
     // D[m][n]: reg r of lane l -> row m = (r&3) + 8*(r>>2) + 4*(l>>5), column n = 32t + (l&31): 128-B coalesced rows
     float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t_out * 32 + (lane & 31);
 #pragma unroll
@@ -145,6 +179,11 @@ __global__ __launch_bounds__(1024) void g1_skinny_gemm(const unsigned short *__r
             const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             o[(size_t)m * N] = acc[mt][r];
         }
+#ifdef SJD_TRACE
+    SJD_TR(5);                    // partial stores issued
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    SJD_TR(6);                    // acknowledged
+#endif
 }
 
 
@@ -344,9 +383,15 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
     if constexpr (MT <= 2) {
         const size_t lds = lds_whole;
         if (lds > 160 * 1024) return SJD_ERR_BAD_ARG;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((g1_skinny_gemm<DT, MT>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles,
-                           step_major ? n_tiles : 1, tile0);
+        if (waves <= 8) {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, MT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((g1_skinny_gemm<DT, MT, 512>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC,
+                               n_tiles, step_major ? n_tiles : 1, tile0);
+        } else {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, MT, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((g1_skinny_gemm<DT, MT, 1024>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC,
+                               n_tiles, step_major ? n_tiles : 1, tile0);
+        }
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
     }
     return SJD_ERR_UNSUPPORTED;
@@ -388,3 +433,10 @@ extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, 
     if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
     return SJD_ERR_UNSUPPORTED;
 }
+
+#ifdef SJD_TRACE
+extern "C" int sjd_debug_trace_g1(unsigned long long *host_out, int n_wg)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_g1_trace), (size_t)n_wg * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Where the time of ONE launch goes: in-kernel phase timestamps of k1_partial and g1_skinny_gemm.
+
+Builds csrc/sjd_attention.hip and csrc/sjd_gemm.hip with -DSJD_TRACE (thread 0 of every workgroup records the 100 MHz wall clock at the
+phase boundaries marked SJD_TR(i) in the sources) into accelerating-t2i-ar-with-sjd_amd/libsjd_hip_trace.so, re-executes itself with
+SJD_HIP_LIB pointing at it, replays the kernels in a hipGraph and prints per-phase means over the workgroups of the LAST launch.
+  python tools/phase_trace.py            (on the MI355X box through gpurun; the instrumented build is made on the fly, hipcc is in the image)
+This is the tool that found K1's 5.3 us merge epilogue and the serialised second key tile (round 2)."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "accelerating-t2i-ar-with-sjd_amd")
+TRACE_SO = os.path.join(PKG, "libsjd_hip_trace.so")
+
+
+def build():
+    csrc = os.path.join(PKG, "csrc")
+    subprocess.check_call(["make", "-C", csrc], stdout=subprocess.DEVNULL)
+    objs = []
+    for f in ("sjd_attention", "sjd_gemm"):
+        o = os.path.join("/tmp", f + "_trace.o")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DSJD_TRACE", "-Wno-unused-value",
+                               "-c", os.path.join(csrc, f + ".hip"), "-o", o])
+        objs.append(o)
+    rest = [os.path.join(csrc, f + ".o") for f in ("sjd_sampling", "sjd_glue", "sjd_capi")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TRACE_SO] + objs + rest)
+
+
+def us(x):
+    return round(float(x) * 10e-3, 2)          # 100 MHz ticks -> us
+
+
+def trace_k1(lib, torch, ops, np):
+    dev = torch.device("cuda:0")
+    B, n, H, D, layers = 2, 16, 32, 128, 32
+    lib.sjd_debug_trace_k1.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    for kv in (64, 448, 1216, 2368):
+        s_max = ((kv + n + 64 + 31) // 32) * 32
+        kc = torch.randn(layers, B, H, s_max, D, device=dev).to(torch.bfloat16)
+        vc = torch.randn(layers, B, H, s_max, D, device=dev).to(torch.bfloat16)
+        q = torch.randn(B, n, H, D, device=dev).to(torch.bfloat16)
+        out = torch.empty_like(q)
+        ks = torch.tensor([0, 63], dtype=torch.int32, device=dev)
+        ws = ops.attention_workspace(B, H, n, D, 4, dev)
+        one = lambda i: ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, kv, 4, ws)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            one(0)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(layers):
+                one(i)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        nwg = 4 * H * B
+        buf = np.zeros((nwg, 8), dtype=np.uint64)
+        assert lib.sjd_debug_trace_k1(buf.ctypes.data, nwg) == 0
+        t = buf.astype(np.int64)
+        t = t[t[:, 7] > 0]                      # splits beyond the effective count exit before the first stamp that matters
+        t0 = t[:, 0].min()
+        d = lambda a, b: us((t[:, b] - t[:, a]).mean())
+        print(json.dumps(dict(kernel="k1_partial<bf16,128,8>", kv_len=kv, n_split=4, workgroups=int(len(t)),
+                              start_skew_us=us((t[:, 0] - t0).max()),
+                              phase_us=dict(kv_len_key_start=d(0, 1), first_tile=d(1, 2), key_loop=d(2, 3), wait_for_waves=d(3, 4),
+                                            merge_buffers=d(4, 5), merge_publish=d(5, 6), store_ack=d(6, 7)),
+                              end_us=dict(mean=us((t[:, 7] - t0).mean()), max=us((t[:, 7] - t0).max())))), flush=True)
+
+
+def trace_g1(lib, torch, ops, np):
+    import sjd_amd._lib as L
+    import sjd_amd.backbones as BB
+    dev = torch.device("cuda:0")
+    lib.sjd_debug_trace_g1.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    for name, (N, K) in dict(qkv=(12288, 4096), o=(4096, 4096), gate_up=(22016, 4096), down=(4096, 11008)).items():
+        KC, waves, sm = BB.ChameleonBackbone.G1_CFG[name]
+        x = torch.randn(32, K, device=dev).to(torch.bfloat16)
+        wps = [ops.pack_weight((torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16), KC, sm) for _ in range(6)]
+        nc = (K + KC - 1) // KC
+        out = torch.empty(nc, 32, N, dtype=torch.float32, device=dev)
+
+        def g1(i):
+            L.check(lib.sjd_skinny_gemm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % 6].data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                        32, N, K, KC, waves, int(sm), 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "g1")
+        with torch.cuda.stream(torch.cuda.Stream()):
+            g1(0)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(12):
+                g1(i)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        nwg = ((N // 32 + waves - 1) // waves) * nc
+        buf = np.zeros((nwg, 8), dtype=np.uint64)
+        assert lib.sjd_debug_trace_g1(buf.ctypes.data, nwg) == 0
+        t = buf.astype(np.int64)
+        t0 = t[:, 0].min()
+        d = lambda a, b: us((t[:, b] - t[:, a]).mean())
+        loop = t[:, 4] - t[:, 3]
+        print(json.dumps(dict(kernel="g1_skinny_gemm<bf16, 32 rows>", shape=name, KC=KC, waves=waves, workgroups=nwg,
+                              start_skew_us=us((t[:, 0] - t0).max()),
+                              phase_us=dict(stage_activation=d(0, 1), wait_for_waves=d(1, 2), first_weight_group=d(2, 3), main_loop=d(3, 4),
+                                            store_issue=d(4, 5), store_ack=d(5, 6)),
+                              main_loop_min_max_us=[us(loop.min()), us(loop.max())],
+                              end_us=dict(mean=us((t[:, 6] - t0).mean()), max=us((t[:, 6] - t0).max())))), flush=True)
+
+
+def main():
+    if os.environ.get("SJD_HIP_LIB") != TRACE_SO:
+        build()
+        os.execve(sys.executable, [sys.executable] + sys.argv, dict(os.environ, SJD_HIP_LIB=TRACE_SO))
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import sjd_amd._lib as L
+    import sjd_amd.ops as ops
+    lib = L.load()
+    trace_k1(lib, torch, ops, np)
+    trace_g1(lib, torch, ops, np)
+
+
+if __name__ == "__main__":
+    main()

@@ -37,9 +37,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 // were found in round 2.
 #ifdef SJD_TRACE
 __device__ unsigned long long g_k1_trace[4096][8];
+__device__ unsigned long long g_k1c_trace[4096][4];
+#define SJD_TRC(i) do { if (threadIdx.x == 0) g_k1c_trace[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 4095][i] = wall_clock64(); } while (0)
 #define SJD_TR(i) do { if (threadIdx.x == 0) g_k1_trace[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 4095][i] = wall_clock64(); } while (0)
 #else
 #define SJD_TR(i) do { } while (0)
+#define SJD_TRC(i) do { } while (0)
 #endif
 #define K1_KT 32          // keys per wave tile
 #define K1_ROWS 16        // query rows per chunk
@@ -540,6 +543,7 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
                                                  const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,
                                                  int kv_len_arg)
 {
+    SJD_TRC(0);
     const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
     const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;
     int eff_split;
@@ -590,9 +594,11 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
             }
     }
     const float inv = L > 0.f ? 1.0f / L : 0.0f;
+    if (inv != 12345.678f) SJD_TRC(1);          // (partials arrived)
     unsigned short *o = out + (((size_t)b * n_rows + grow) * H + head) * D + d0;
 #pragma unroll
     for (int j = 0; j < PER; ++j) o[j] = Frag<DT>::cvt(acc[j] * inv);
+    SJD_TRC(2);
 }
 
 // ------------------------------------------------------------------------------------------------ K1F (fused F2 + K1 + combine)
@@ -1398,6 +1404,10 @@ extern "C" float sjd_event_elapsed_ms(void *ev_start, void *ev_stop)
 }
 
 #ifdef SJD_TRACE
+extern "C" int sjd_debug_trace_k1c(unsigned long long *host_out, int n_wg)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k1c_trace), (size_t)n_wg * 4 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
 extern "C" int sjd_debug_trace_k1(unsigned long long *host_out, int n_wg)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k1_trace), (size_t)n_wg * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;

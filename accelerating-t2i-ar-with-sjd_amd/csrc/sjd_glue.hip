@@ -19,6 +19,19 @@
 
 #include "../../include/sjd_hip.h"
 
+// phase timestamps of the glue kernels (tools/phase_trace.py, -DSJD_TRACE; compiled out otherwise): slot 0 F1r, 1 F2, 2 F3
+#ifdef SJD_TRACE
+__device__ unsigned long long g_glue_trace[3][4096][4];
+#define SJD_TRG(k, i) do { if (threadIdx.x == 0) g_glue_trace[k][((blockIdx.y * gridDim.x) + blockIdx.x) & 4095][i] = wall_clock64(); } while (0)
+extern "C" int sjd_debug_trace_glue(int kind, unsigned long long *host_out, int n_wg)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_glue_trace), (size_t)n_wg * 4 * sizeof(unsigned long long),
+                               (size_t)kind * 4096 * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#else
+#define SJD_TRG(k, i) do { } while (0)
+#endif
+
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int DT> struct Cvt;
@@ -208,6 +221,7 @@ template <int DT>
 __global__ __launch_bounds__(128) void f1r_residual_sumsq(unsigned short *__restrict__ h, const float *__restrict__ part, int n_chunks,
                                                           int hidden, int prows, float *__restrict__ out_sumsq)
 {
+    SJD_TRG(0, 0);
     __shared__ float red[2];
     const int row = blockIdx.x, c = blockIdx.y * 512 + threadIdx.x * 4;
     float ss = 0.f;
@@ -230,6 +244,7 @@ __global__ __launch_bounds__(128) void f1r_residual_sumsq(unsigned short *__rest
                     if (c0 + q < n_chunks) { d0 += v[q].x; d1 += v[q].y; d2 += v[q].z; d3 += v[q].w; }
             }
             const float dd[4] = {d0, d1, d2, d3};
+            if (dd[0] != 12345.678f) SJD_TRG(0, 1);          // (partials arrived)
             unsigned short o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -249,6 +264,7 @@ __global__ __launch_bounds__(128) void f1r_residual_sumsq(unsigned short *__rest
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
     if (threadIdx.x == 0) out_sumsq[(size_t)blockIdx.y * prows + row] = red[0] + red[1];
+    SJD_TRG(0, 2);
 }
 
 // 1/rms of a row from the per-slice sums of squares F1r wrote (fixed order)
@@ -280,6 +296,7 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     int kv_len_arg, const float *__restrict__ part, int n_chunks, int prows, float k_inv, float v_inv,
     const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden, float rs_eps)
 {
+    SJD_TRG(1, 0);
     constexpr int HALF = D / 2;
     constexpr int PPL = HALF / 64 > 0 ? HALF / 64 : 1;       // pairs per lane (D=128: 1, D=64: lanes 32..63 idle)
     const int lane = threadIdx.x & 63;
@@ -329,6 +346,7 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
             }
             x0 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0));
             x1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x1));
+            if (x0 != 12345.678f) SJD_TRG(1, 1);              // (partials + row statistics arrived)
         } else {
             x0 = Cvt<DT>::to_f(src[lane]);
             x1 = Cvt<DT>::to_f(src[lane + HALF]);
@@ -373,6 +391,7 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
             dst[lane + HALF] = Cvt<DT>::from_f(a1 + b1);
         }
     }
+    SJD_TRG(1, 2);
     (void)PPL;
 }
 
@@ -382,6 +401,7 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
                                                    const float *__restrict__ part, int n_chunks, int prows,
                                                    const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden, float rs_eps)
 {
+    SJD_TRG(2, 0);
     const int per_row = I / 8;
     const size_t total = (size_t)M * per_row;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -408,6 +428,7 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
                     }
             }
             const float r = row_sumsq ? rsqrtf(ss_tot * rs_inv_hidden + rs_eps) : 1.0f;
+            if (g[0] + r != 12345.678f) SJD_TRG(2, 1);       // (partials + row statistics arrived)
 #pragma unroll
             for (int j = 0; j < 8; ++j) { g[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(g[j] * r)); u[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(u[j] * r)); }
         } else {
@@ -421,6 +442,7 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
         }
         *reinterpret_cast<u32x4 *>(y + (size_t)row * I + c) = pack8<DT>(o);
     }
+    SJD_TRG(2, 2);
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI

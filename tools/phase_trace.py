@@ -21,12 +21,12 @@ def build():
     csrc = os.path.join(PKG, "csrc")
     subprocess.check_call(["make", "-C", csrc], stdout=subprocess.DEVNULL)
     objs = []
-    for f in ("sjd_attention", "sjd_gemm"):
+    for f in ("sjd_attention", "sjd_gemm", "sjd_glue"):
         o = os.path.join("/tmp", f + "_trace.o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DSJD_TRACE", "-Wno-unused-value",
                                "-c", os.path.join(csrc, f + ".hip"), "-o", o])
         objs.append(o)
-    rest = [os.path.join(csrc, f + ".o") for f in ("sjd_sampling", "sjd_glue", "sjd_capi")]
+    rest = [os.path.join(csrc, f + ".o") for f in ("sjd_sampling", "sjd_capi")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TRACE_SO] + objs + rest)
 
 
@@ -111,6 +111,54 @@ def trace_g1(lib, torch, ops, np):
                               end_us=dict(mean=us((t[:, 6] - t0).mean()), max=us((t[:, 6] - t0).max())))), flush=True)
 
 
+def trace_in_situ(lib, torch, ops, np, kv_target=1216):
+    """the LAST launch of every instrumented kernel inside a real decode (Lumina-7B shapes, hipGraph): layer 31 of the last iteration --
+    inputs just written by the previous kernel on other XCDs, i.e. what the stage costs where it runs"""
+    import sjd_amd.backbones as BB
+    import sjd_amd.synthetic as synthetic
+    from sjd_amd.engine import SJDEngine, SJDConfig
+    from sjd_amd.frontends import lumina_window_spec, lumina_prompt
+    from sjd_amd.grammar import LuminaGrammar
+    dev = torch.device("cuda:0")
+    margs, window, grid = BB.LUMINA_7B, 16, 48
+    with torch.device(dev):
+        model = BB.ChameleonBackbone(margs, attn=ops.HipWindowAttention()).to(torch.bfloat16).eval()
+    synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=0.7)
+    model.enable_fused(ops, gemm="sjd")
+    prompt = lumina_prompt(kv_target - 60, grid, grid, seed=5)
+    spec = lumina_window_spec(prompt, dev)
+    cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=grid * grid + grid - 13, max_num_new_tokens=window, guidance_scale=3.0,
+                    seed=5, max_length=len(prompt) + 60, eos_token_ids=(8196,))
+    model.setup_cache(batch=2, s_max=((len(prompt) + 60 + 2 * window + 64 + 31) // 32) * 32)
+    eng = SJDEngine(model, margs.vocab_size, dev, max_window=window, use_graph=True)
+    seq, stats = eng.decode(prompt, spec, LuminaGrammar(2000, 10), cfg)
+    torch.cuda.synchronize()
+    for f in ("sjd_debug_trace_k1", "sjd_debug_trace_k1c"):
+        getattr(lib, f).argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sjd_debug_trace_glue.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+
+    def table(name, buf, cols, labels):
+        t = buf[:, :cols].astype(np.int64)
+        t = t[(t[:, 0] > 0) & np.all(np.diff(t, axis=1) >= 0, axis=1)]      # workgroups that stamped every phase in THIS launch
+        t = t[t[:, 0] >= t[:, 0].max() - 2000]                               # (rows left over from an earlier launch with a bigger grid)
+        t0 = t[:, 0].min()
+        ph = {labels[i]: us((t[:, i + 1] - t[:, i]).mean()) for i in range(cols - 1)}
+        print(json.dumps(dict(kernel=name, in_situ_kv_len=int(stats.kv_len), workgroups=int(len(t)), start_skew_us=us((t[:, 0] - t0).max()),
+                              phase_us=ph, end_us=dict(mean=us((t[:, cols - 1] - t0).mean()), max=us((t[:, cols - 1] - t0).max())))), flush=True)
+
+    b = np.zeros((256, 8), dtype=np.uint64)
+    assert lib.sjd_debug_trace_k1(b.ctypes.data, 256) == 0
+    table("k1_partial (layer 31, in situ)", b, 8, ["kv_len_key_start", "first_tile", "key_loop", "wait_for_waves", "merge_buffers", "merge_publish", "store_ack"])
+    b = np.zeros((64, 4), dtype=np.uint64)
+    assert lib.sjd_debug_trace_k1c(b.ctypes.data, 64) == 0
+    table("k1_combine (layer 31, in situ)", b, 3, ["partials_arrive", "normalise_store"])
+    for kind, name, nwg in ((0, "f1r_residual_sumsq (last launch: after down of layer 31, 13 partial planes)", 256),
+                            (1, "f2_qknorm_rope_append (layer 31)", 768), (2, "f3_silu_mul (layer 31)", 172)):
+        b = np.zeros((nwg, 4), dtype=np.uint64)
+        assert lib.sjd_debug_trace_glue(kind, b.ctypes.data, nwg) == 0
+        table(name + ", in situ", b, 3, ["inputs_arrive", "compute_store"])
+
+
 def main():
     if os.environ.get("SJD_HIP_LIB") != TRACE_SO:
         build()
@@ -123,6 +171,7 @@ def main():
     lib = L.load()
     trace_k1(lib, torch, ops, np)
     trace_g1(lib, torch, ops, np)
+    trace_in_situ(lib, torch, ops, np)
 
 
 if __name__ == "__main__":

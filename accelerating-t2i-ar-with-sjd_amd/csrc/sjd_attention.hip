@@ -18,6 +18,7 @@
 //   Next tile's K and V loads are issued before the current tile's math (register double buffer).
 //   Split partials (m, l, O) go to an fp32 workspace; k1_combine merges them and writes bf16/f16.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <math.h>
@@ -366,8 +367,8 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
 // read back transposed).  The next tile's loads are in flight while the current one is consumed; one barrier per tile.
 // Same split / workspace layout as k1_partial (the waves of a pair cover all tiles of the split, so no LDS merge), k1_combine
 // is unchanged.
-template <int DT, int D>
-__global__ __launch_bounds__(512) void k1_partial_shared(
+template <int DT, int D, int NWV>          // NWV = waves per workgroup = (q head of the group, row chunk) pairs: 4 or 8
+__global__ __launch_bounds__(64 * NWV) void k1_partial_shared(
     const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
     float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max,
     const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks)
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(512) void k1_partial_shared(
     typedef typename Frag<DT>::vec vec;
     constexpr int KS = D / 32, DB = D / 16;
     constexpr int ROW = D + 8;                // padded LDS row (elements) for both tiles
+    SJD_TR(0);
     constexpr int TILE = K1_KT * ROW;         // elements per K or V tile
     __shared__ __attribute__((aligned(16))) unsigned short tiles[2][2][TILE];     // [buffer][K, V]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -409,6 +411,7 @@ __global__ __launch_bounds__(512) void k1_partial_shared(
     if (bt1 <= bt0) {                         // no wave of this workgroup has work in this split
         return;
     }
+    SJD_TR(1);                    // tile ranges known
 
     vec qf[KS];
     {
@@ -423,32 +426,34 @@ __global__ __launch_bounds__(512) void k1_partial_shared(
     const unsigned short *kbase = kc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
     const unsigned short *vbase = vc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
 
-    // cooperative tile fetch: K1_KT * D / 8 16-byte pieces per tensor, spread over the workgroup
+    // cooperative tile fetch: K1_KT * D / 8 16-byte pieces per tensor, spread over the workgroup.  THREE tiles travel at a time, in three
+    // register sets that rotate without copies (tile r of the workgroup's range lives in set r % 3); every load is unconditional (the
+    // tile index is clamped), so the compiler's vmcnt at a stash leaves the two younger tiles in flight.  With one tile ahead a
+    // workgroup moved 16 KB per HBM round trip: 1.1 TB/s at kv_len 4096 (round 2, 31 us per layer).
     constexpr int PIECES = K1_KT * D / 8, LPR = D / 8;
-    constexpr int MAXP = PIECES / 256;        // pieces per thread and tensor with the smallest workgroup (4 waves)
-    u32x4 kst[MAXP], vst[MAXP];
-    const int nth = blockDim.x;
-    auto fetch = [&](int t) {
+    constexpr int MAXP = PIECES / (64 * NWV);  // pieces per thread and tensor
+    static_assert(MAXP * 64 * NWV == PIECES, "the workgroup covers a tile exactly");
+    u32x4 kst[3][MAXP], vst[3][MAXP];
+    auto fetch = [&](int t, auto set) {
+        constexpr int S = decltype(set)::value;
+        const int tc = min(t, bt1 - 1);
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
-            const int idx = i * nth + (int)threadIdx.x;
-            if (idx < PIECES) {
-                const size_t off = (size_t)(t * K1_KT + idx / LPR) * D + 8 * (idx % LPR);
-                kst[i] = *reinterpret_cast<const u32x4 *>(kbase + off);
-                vst[i] = *reinterpret_cast<const u32x4 *>(vbase + off);
-            }
+            const int idx = i * (64 * NWV) + (int)threadIdx.x;
+            const size_t off = (size_t)(tc * K1_KT + idx / LPR) * D + 8 * (idx % LPR);
+            kst[S][i] = *reinterpret_cast<const u32x4 *>(kbase + off);
+            vst[S][i] = *reinterpret_cast<const u32x4 *>(vbase + off);
         }
     };
-    auto stash = [&](int t, int buf) {        // rows of keys >= total_max are zeroed (0 * NaN inside the MFMA, see k1_partial)
+    auto stash = [&](int t, int buf, auto set) {        // rows of keys >= total_max are zeroed (0 * NaN inside the MFMA, see k1_partial)
+        constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
-            const int idx = i * nth + (int)threadIdx.x;
-            if (idx < PIECES) {
-                const bool live = (t * K1_KT + idx / LPR) < total_max;
-                const int o = (idx / LPR) * ROW + 8 * (idx % LPR);
-                *reinterpret_cast<u32x4 *>(&tiles[buf][0][o]) = live ? kst[i] : u32x4{0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x4 *>(&tiles[buf][1][o]) = live ? vst[i] : u32x4{0u, 0u, 0u, 0u};
-            }
+            const int idx = i * (64 * NWV) + (int)threadIdx.x;
+            const bool live = (t * K1_KT + idx / LPR) < total_max;
+            const int o = (idx / LPR) * ROW + 8 * (idx % LPR);
+            *reinterpret_cast<u32x4 *>(&tiles[buf][0][o]) = live ? kst[S][i] : u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4 *>(&tiles[buf][1][o]) = live ? vst[S][i] : u32x4{0u, 0u, 0u, 0u};
         }
     };
 
@@ -457,13 +462,7 @@ __global__ __launch_bounds__(512) void k1_partial_shared(
 #pragma unroll
     for (int db = 0; db < DB; ++db) o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    fetch(bt0);
-    stash(bt0, 0);
-    __syncthreads();
-    for (int t = bt0; t < bt1; ++t) {
-        const int buf = (t - bt0) & 1;
-        const bool has_next = t + 1 < bt1;
-        if (has_next) fetch(t + 1);
+    auto compute_tile = [&](int t, int buf) {
         if (t >= wt0 && t < wt1) {
             const unsigned short *kl = tiles[buf][0], *vl = tiles[buf][1];
             f32x4 st[2];
@@ -523,17 +522,48 @@ __global__ __launch_bounds__(512) void k1_partial_shared(
                 o_acc[db] = Frag<DT>::mfma(as_frag<vec>(vv), pfrag, acc);
             }
         }
-        if (has_next) stash(t + 1, buf ^ 1);
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, 2> S2;
+    fetch(bt0, S0{});
+    fetch(bt0 + 1, S1{});
+    fetch(bt0 + 2, S2{});
+    stash(bt0, 0, S0{});
+    __syncthreads();
+    SJD_TR(2);                    // first tile in LDS
+    // iteration of tile t (relative index r = t - bt0, r % 3 == k): request tile r + 3 into set k (tile r left it one iteration ago),
+    // multiply tile r out of LDS buffer r & 1, move tile r + 1 from set (k + 1) % 3 into the other buffer
+    for (int t = bt0; t < bt1;) {
+        fetch(t + 3, S0{});
+        compute_tile(t, (t - bt0) & 1);
+        if (t + 1 < bt1) stash(t + 1, ((t - bt0) & 1) ^ 1, S1{});
         __syncthreads();
+        if (++t >= bt1) break;
+        fetch(t + 3, S1{});
+        compute_tile(t, (t - bt0) & 1);
+        if (t + 1 < bt1) stash(t + 1, ((t - bt0) & 1) ^ 1, S2{});
+        __syncthreads();
+        if (++t >= bt1) break;
+        fetch(t + 3, S2{});
+        compute_tile(t, (t - bt0) & 1);
+        if (t + 1 < bt1) stash(t + 1, ((t - bt0) & 1) ^ 1, S0{});
+        __syncthreads();
+        ++t;
     }
+    SJD_TR(3);                    // key loop done
     if (!wave_on) return;
     // the wave covered every tile of its split: its (m, l, O) is the split partial
     const size_t slot0 = ((((size_t)b * H + head) * n_chunks + chunk) * n_split + split) * K1_ROWS;
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ws_o[(slot0 + c) * D + 16 * db + 4 * g + r] = o_acc[db][r];
+    for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(ws_o + (slot0 + c) * D + 16 * db + 4 * g) = o_acc[db];
     if (g == 0) { ws_ml[(slot0 + c) * 2] = m_run; ws_ml[(slot0 + c) * 2 + 1] = l_run; }
+#ifdef SJD_TRACE
+    SJD_TR(4);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    SJD_TR(5);                    // partial stored
+    SJD_TR(6); SJD_TR(7);
+#endif
     (void)nw;
 }
 
@@ -565,15 +595,16 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
         return;
     }
     const size_t base = (((size_t)b * H + head) * n_chunks + chunk) * n_split;
-    // four splits' (m, l, O) in flight at a time (the partials were written by the kernel that has just finished: cold), merged
-    // online in split order
+    // sixteen splits' (m, l, O) in flight at a time (the partials were written by the kernel that has just finished: cold -- every batch is
+    // a full round trip; with batches of four, Emu3's 16 splits took four of them, 7.6 us), merged online in split order
+    constexpr int CB = 16;
     float M = -INFINITY, L = 0.f, acc[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) acc[j] = 0.f;
-    for (int s0 = 0; s0 < eff_split; s0 += 4) {
-        float ms[4], ls[4], os[4][PER];
+    for (int s0 = 0; s0 < eff_split; s0 += CB) {
+        float ms[CB], ls[CB], os[CB][PER];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < CB; ++q)
             if (s0 + q < eff_split) {
                 const size_t slot = (base + s0 + q) * K1_ROWS + row;
                 ms[q] = ws_ml[slot * 2];
@@ -582,7 +613,7 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
                 for (int j = 0; j < PER; ++j) os[q][j] = ws_o[slot * D + d0 + j];
             }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < CB; ++q)
             if (s0 + q < eff_split) {
                 const float Mn = fmaxf(M, ms[q]);
                 const float Msafe = (Mn == -INFINITY) ? 0.0f : Mn;
@@ -1271,11 +1302,18 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     // a single key split needs no combine: k1_partial normalises and writes the 16-bit output directly (SJD_K1_NO_DIRECT=1: tuning aid)
     static const bool no_direct = getenv("SJD_K1_NO_DIRECT") != nullptr;
     unsigned short *direct = (!shared && n_split == 1 && !no_direct) ? (unsigned short *)out : nullptr;
-    if (shared)
-        hipLaunchKernelGGL((k1_partial_shared<DT, D>), dim3(n_split, H_kv, B), dim3(64 * pairs), 0, stream, (const unsigned short *)q,
-                           (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
-                           kv_len, n_split, n_chunks);
-    else if (k1_waves() == 8)
+    if (shared) {
+        if constexpr (D == 128) {
+            if (pairs == 8)
+                hipLaunchKernelGGL((k1_partial_shared<DT, D, 8>), dim3(n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
+                                   (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
+                                   kv_len, n_split, n_chunks);
+            else
+                hipLaunchKernelGGL((k1_partial_shared<DT, D, 4>), dim3(n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
+                                   (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
+                                   kv_len, n_split, n_chunks);
+        }
+    } else if (k1_waves() == 8)
         hipLaunchKernelGGL((k1_partial<DT, D, 8>), dim3(n_chunks * n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
                            (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
                            kv_len, n_split, n_chunks, direct);

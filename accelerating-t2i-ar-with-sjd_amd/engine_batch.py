@@ -145,7 +145,7 @@ class SJDBatchEngine:
                 self._eager_runs[fkey] = 1
                 return self._forward_body(cols)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other host threads may use the GPU (servers; the streaming parity tests)
                 self._graph_logits[fkey] = self._forward_body(cols)
             self._graphs[fkey] = g
         self._graphs[fkey].replay()
@@ -160,7 +160,7 @@ class SJDBatchEngine:
         if key not in self._graphs:
             self._sample_body(cur, logits, cols)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other host threads may use the GPU (servers; the streaming parity tests)
                 self._sample_body(cur, logits, cols)
             self._graphs[key] = g
             return

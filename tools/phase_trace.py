@@ -71,6 +71,43 @@ def trace_k1(lib, torch, ops, np):
                               end_us=dict(mean=us((t[:, 7] - t0).mean()), max=us((t[:, 7] - t0).max())))), flush=True)
 
 
+def trace_k1_shared(lib, torch, ops, np):
+    """Emu3's shape: GQA 32 / 8, draft window 32 (two 16-row chunks), 16 key splits: k1_partial_shared"""
+    dev = torch.device("cuda:0")
+    B, n, H, Hkv, D, layers, ns = 2, 32, 32, 8, 128, 32, 16
+    for kv in (1024, 4096, 8192):
+        s_max = ((kv + n + 64 + 31) // 32) * 32
+        kc = torch.randn(layers, B, Hkv, s_max, D, device=dev).to(torch.float16)
+        vc = torch.randn(layers, B, Hkv, s_max, D, device=dev).to(torch.float16)
+        q = torch.randn(B, n, H, D, device=dev).to(torch.float16)
+        out = torch.empty_like(q)
+        ks = torch.tensor([0, 0], dtype=torch.int32, device=dev)
+        ws = ops.attention_workspace(B, H, n, D, ns, dev)
+        one = lambda i: ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, kv, ns, ws)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            one(0)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(layers):
+                one(i)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        nwg = ns * Hkv * B
+        buf = np.zeros((nwg, 8), dtype=np.uint64)
+        assert lib.sjd_debug_trace_k1(buf.ctypes.data, nwg) == 0
+        t = buf.astype(np.int64)
+        t = t[t[:, 5] > 0]
+        t0 = t[:, 0].min()
+        d = lambda a, b: us((t[:, b] - t[:, a]).mean())
+        tiles = (kv + n + 31) // 32 / ns
+        print(json.dumps(dict(kernel="k1_partial_shared<f16,128,8 waves>", kv_len=kv, n_split=ns, workgroups=int(len(t)), tiles_per_workgroup=round(tiles, 1),
+                              phase_us=dict(tile_ranges=d(0, 1), first_tile=d(1, 2), key_loop=d(2, 3), publish=d(3, 5)),
+                              key_loop_us_per_tile=round(d(2, 3) / max(tiles - 1, 1), 2),
+                              end_us=dict(mean=us((t[:, 5] - t0).mean()), max=us((t[:, 5] - t0).max())))), flush=True)
+
+
 def trace_g1(lib, torch, ops, np):
     import sjd_amd._lib as L
     import sjd_amd.backbones as BB
@@ -170,6 +207,7 @@ def main():
     import sjd_amd.ops as ops
     lib = L.load()
     trace_k1(lib, torch, ops, np)
+    trace_k1_shared(lib, torch, ops, np)
     trace_g1(lib, torch, ops, np)
     trace_in_situ(lib, torch, ops, np)
 

@@ -163,10 +163,19 @@ __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__r
             for (int u = 0; u < G1_UNROLL; ++u) cur[u] = nxt[u];
         }
     }
-    for (int s = full * G1_UNROLL; s < steps; ++s) {    // ragged tail (K chunk not a multiple of 128)
-        const u32x4 wv = __builtin_nontemporal_load(wu + (size_t)s * rs);
+    {   // ragged tail (K chunk not a multiple of 128): its up to seven records in ONE round trip (they used to be seven)
+        const int s0 = full * G1_UNROLL, rem = steps - s0;
+        u32x4 tl[G1_UNROLL - 1];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(xl[mt * xs + s * 64 + g1_slot(lane >> 5, lane & 31, s)], wv, acc[mt]);
+        for (int u = 0; u < G1_UNROLL - 1; ++u)
+            if (u < rem) tl[u] = __builtin_nontemporal_load(wu + (size_t)(s0 + u) * rs);
+#pragma unroll
+        for (int u = 0; u < G1_UNROLL - 1; ++u)
+            if (u < rem) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = G1Mfma<DT>::mma(xl[mt * xs + (s0 + u) * 64 + g1_slot(lane >> 5, lane & 31, s0 + u)], tl[u], acc[mt]);
+            }
     }
 
     SJD_TR(4);                    // main loop done

@@ -231,6 +231,7 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
                                                                      float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
                                                                      int rec_stride, int tile0)
 {
+    SJD_TR(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *xl = reinterpret_cast<u32x4 *>(smem);                 // two buffers of MT * G1_SUB records
     const int chunk = blockIdx.y;
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
         stage(0, 0, val, false);
     }
     __syncthreads();
+    SJD_TR(1);                    // first sub-tile staged
     // all full sub-tiles but the last: the next sub-tile and the group after next always exist -> unconditional, straight-line
     for (int st = 0; st + 1 < n_sub_full; ++st) {
         const u32x4 *xb = xl + (st & 1) * BUF;
@@ -302,13 +304,18 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
         __builtin_amdgcn_sched_barrier(0);
         g1_group<DT, MT>(xb, 0, A, acc, lane);
         __builtin_amdgcn_sched_barrier(0);
+        if (st == 1) SJD_TR(5);       // (second sub-tile: group A multiplied)
         w_load(A, 2 * st + 2);
         __builtin_amdgcn_sched_barrier(0);
         g1_group<DT, MT>(xb, G1_UNROLL, B, acc, lane);
         __builtin_amdgcn_sched_barrier(0);
+        if (st == 1) SJD_TR(6);       // (group B multiplied)
         stage(st + 1, (st + 1) & 1, val, false);
+        if (st == 1) SJD_TR(7);       // (next sub-tile written to LDS)
         __syncthreads();
+        if (st == 0) SJD_TR(4);       // (first sub-tile done, barrier passed)
     }
+    SJD_TR(2);                    // all but the last full sub-tile done
     if (n_sub_full > 0) {                                           // last full sub-tile: what follows it may not exist (uniform branches)
         const int st = n_sub_full - 1;
         const u32x4 *xb = xl + (st & 1) * BUF;
@@ -331,6 +338,7 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
             for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(xb[(mt * G1_SUB + sl) * 64 + g1_slot(lane >> 5, lane & 31, sl)], wv, acc[mt]);
         }
     }
+    SJD_TR(3);                    // main loop done
     if (!has_tile) return;
     float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t_out * 32 + (lane & 31);
 #pragma unroll

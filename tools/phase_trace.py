@@ -148,6 +148,45 @@ def trace_g1(lib, torch, ops, np):
                               end_us=dict(mean=us((t[:, 6] - t0).mean()), max=us((t[:, 6] - t0).max())))), flush=True)
 
 
+def trace_g1_tiled(lib, torch, ops, np):
+    """128 window rows (four prompts per forward): g1_skinny_gemm_tiled"""
+    import sjd_amd._lib as L
+    import sjd_amd.backbones as BB
+    dev = torch.device("cuda:0")
+    for name, (N, K) in dict(qkv=(12288, 4096), gate_up=(22016, 4096), down=(4096, 11008)).items():
+        KC, waves, sm = BB.ChameleonBackbone.G1_CFG_128ROW[name]
+        x = torch.randn(128, K, device=dev).to(torch.bfloat16)
+        wps = [ops.pack_weight((torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16), KC, sm) for _ in range(6)]
+        nc = (K + KC - 1) // KC
+        out = torch.empty(nc, 128, N, dtype=torch.float32, device=dev)
+
+        def g1(i):
+            L.check(lib.sjd_skinny_gemm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % 6].data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                        128, N, K, KC, waves, int(sm), 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "g1")
+        with torch.cuda.stream(torch.cuda.Stream()):
+            g1(0)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(12):
+                g1(i)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        nwg = ((N // 32 + waves - 1) // waves) * nc
+        buf = np.zeros((nwg, 8), dtype=np.uint64)
+        assert lib.sjd_debug_trace_g1(buf.ctypes.data, nwg) == 0
+        t = buf.astype(np.int64)
+        t = t[(t[:, 7] > 0) & (t[:, 3] > t[:, 0])]            # workgroups with at least two full sub-tiles
+        t0 = t[:, 0].min()
+        d = lambda a, b: us((t[:, b] - t[:, a]).mean())
+        n_sub = min(KC, K) // 256
+        print(json.dumps(dict(kernel="g1_skinny_gemm_tiled<bf16, 128 rows>", shape=name, KC=KC, waves=waves, workgroups=int(len(t)), sub_tiles=n_sub,
+                              phase_us=dict(first_sub_tile_staged=d(0, 1), first_sub_tile=d(1, 4), loop_total=d(1, 3)),
+                              second_sub_tile_us=dict(group_A=d(4, 5), group_B=d(5, 6), stage_next=d(6, 7)),
+                              per_sub_tile_us=round(d(1, 3) / max(n_sub, 1), 2), end_us=us((t[:, 3] - t0).max()))), flush=True)
+
+
 def trace_in_situ(lib, torch, ops, np, kv_target=1216):
     """the LAST launch of every instrumented kernel inside a real decode (Lumina-7B shapes, hipGraph): layer 31 of the last iteration --
     inputs just written by the previous kernel on other XCDs, i.e. what the stage costs where it runs"""
@@ -209,6 +248,7 @@ def main():
     trace_k1(lib, torch, ops, np)
     trace_k1_shared(lib, torch, ops, np)
     trace_g1(lib, torch, ops, np)
+    trace_g1_tiled(lib, torch, ops, np)
     trace_in_situ(lib, torch, ops, np)
 
 

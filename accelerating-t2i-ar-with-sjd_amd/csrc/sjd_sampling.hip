@@ -328,8 +328,11 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
 // ------------------------------------------------------------------------------------------------ K5
 // replaces prepare_inputs_for_generation_jacobi / get_multi_token_for_preparation('random') (reference JL:470-514,
 // 606-701): window = [last emitted | carried unverified samples | fresh random ids]
+// positions_out (optional): the position ids of the window rows, kv_len + i + pos_offset[b] (reference JL:1062-1073 builds them on the
+// host from cache_position; three ATen element-wise launches per iteration before round 2's end)
 __global__ void k5_reguess(const sjd_iter_params *__restrict__ params, sjd_state *__restrict__ state,
-                           int64_t *__restrict__ input_ids_out, int n_batch, int max_rows)
+                           int64_t *__restrict__ input_ids_out, int n_batch, int max_rows, const int64_t *__restrict__ pos_offset,
+                           int64_t *__restrict__ positions_out)
 {
     const int i = threadIdx.x;
     const int n = params->n_rows;
@@ -349,16 +352,27 @@ __global__ void k5_reguess(const sjd_iter_params *__restrict__ params, sjd_state
         state->win_tok[i] = tok;
         state->q_src[i] = qs;
         for (int b = 0; b < n_batch; ++b) input_ids_out[(size_t)b * max_rows + i] = tok;
+        if (positions_out) {
+            const int64_t base = (int64_t)params->kv_len + i;
+            for (int b = 0; b < n_batch; ++b) positions_out[(size_t)b * max_rows + i] = base + (pos_offset ? pos_offset[b] : 0);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI
+extern "C" int sjd_reguess_ex(const sjd_iter_params *params, sjd_state *state, int64_t *input_ids_out, int n_batch, int max_rows,
+                              const int64_t *pos_offset, int64_t *positions_out, void *stream)
+{
+    if (!params || !state || !input_ids_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || n_batch < 1) return SJD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k5_reguess, dim3(1), dim3(64), 0, (hipStream_t)stream, params, state, input_ids_out, n_batch, max_rows, pos_offset,
+                       positions_out);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
 extern "C" int sjd_reguess(const sjd_iter_params *params, sjd_state *state, int64_t *input_ids_out, int n_batch,
                            int max_rows, void *stream)
 {
-    if (!params || !state || !input_ids_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || n_batch < 1) return SJD_ERR_BAD_ARG;
-    hipLaunchKernelGGL(k5_reguess, dim3(1), dim3(64), 0, (hipStream_t)stream, params, state, input_ids_out, n_batch, max_rows);
-    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+    return sjd_reguess_ex(params, state, input_ids_out, n_batch, max_rows, nullptr, nullptr, stream);
 }
 
 extern "C" int sjd_logits_to_probs_sample_ex(const float *logits_c, const float *logits_u, int64_t row_stride, float guidance,

@@ -107,6 +107,7 @@ class SJDEngine:
         self.scratch = torch.empty(self.V, dtype=torch.float32, device=dev)
         self.input_ids = torch.zeros(self.B, self.Lmax, dtype=torch.int64, device=dev)
         self.arange = torch.arange(self.Lmax, device=dev)
+        self.positions = torch.zeros(self.B, self.Lmax, dtype=torch.int64, device=dev)      # window position ids, written by K5
         self.tokens_ptr = self.state.field_ptr("tokens")
         self.amax_ptr = self.state.field_ptr("amax")
         self.key_start = torch.zeros(self.B, dtype=torch.int32, device=dev)
@@ -164,8 +165,8 @@ class SJDEngine:
     def _forward_body(self, cols=None):
         """Shape-static launch sequence, part 1: K5 + transformer forward (every dynamic scalar is read from device blobs).
         cols: vocabulary column window of the output head (None = all columns)."""
-        ops.reguess(self.params, self.state, self.input_ids)
-        positions = self.kv_len_dev.to(torch.int64) + self.arange[None, :] + self.pos_offset[:, None]
+        ops.reguess(self.params, self.state, self.input_ids, pos_offset=self.pos_offset, positions_out=self.positions)      # ids + position ids
+        positions = self.positions
         if self.head_partials:
             return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start, cols=cols, head_partials=True)
         if cols is None:

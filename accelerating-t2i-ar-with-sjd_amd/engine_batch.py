@@ -64,6 +64,7 @@ class SJDBatchEngine:
             self.slots.append(s)
         self.input_ids = torch.zeros(self.B, self.Lmax, dtype=torch.int64, device=dev)
         self.arange = torch.arange(self.Lmax, device=dev)
+        self.positions = torch.zeros(self.B, self.Lmax, dtype=torch.int64, device=dev)      # window position ids, written by K5
         self.key_start = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.pos_offset = torch.zeros(self.B, dtype=torch.int64, device=dev)
         nb_params, off = L.ctypes.sizeof(L.IterParams), L.IterParams.kv_len.offset
@@ -122,8 +123,9 @@ class SJDBatchEngine:
 
     def _forward_body(self, cols):
         for i, s in enumerate(self.slots):
-            ops.reguess(s.params, s.state, self.input_ids[i * self.nb:(i + 1) * self.nb])
-        positions = self.kv_len_dev[self.row_slot].to(torch.int64)[:, None] + self.arange[None, :] + self.pos_offset[:, None]
+            lo, hi = i * self.nb, (i + 1) * self.nb
+            ops.reguess(s.params, s.state, self.input_ids[lo:hi], pos_offset=self.pos_offset[lo:hi], positions_out=self.positions[lo:hi])
+        positions = self.positions
         if cols is None:
             return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start)
         return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start, cols=cols)

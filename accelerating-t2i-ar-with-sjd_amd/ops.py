@@ -97,10 +97,17 @@ class BlobArray:
         return ctypes.c_void_p(self.dev.data_ptr())
 
 
-def reguess(params: DeviceBlob, state: DeviceBlob, input_ids_out: torch.Tensor):
+def reguess(params: DeviceBlob, state: DeviceBlob, input_ids_out: torch.Tensor, pos_offset=None, positions_out=None):
+    """K5: window ids; with positions_out ([n_batch, max_rows] int64) also the window's position ids kv_len + i + pos_offset[b]"""
     n_batch, max_rows = input_ids_out.shape
     assert input_ids_out.dtype == torch.int64 and input_ids_out.is_contiguous()
-    L.check(L.load().sjd_reguess(params.ptr, state.ptr, _ptr(input_ids_out), n_batch, max_rows, _stream()), "sjd_reguess")
+    if positions_out is None:
+        L.check(L.load().sjd_reguess(params.ptr, state.ptr, _ptr(input_ids_out), n_batch, max_rows, _stream()), "sjd_reguess")
+        return
+    assert positions_out.dtype == torch.int64 and positions_out.is_contiguous() and tuple(positions_out.shape) == (n_batch, max_rows)
+    assert pos_offset is None or (pos_offset.dtype == torch.int64 and pos_offset.is_contiguous() and pos_offset.numel() == n_batch)
+    L.check(L.load().sjd_reguess_ex(params.ptr, state.ptr, _ptr(input_ids_out), n_batch, max_rows, _ptr(pos_offset) if pos_offset is not None else None,
+                                   _ptr(positions_out), _stream()), "sjd_reguess_ex")
 
 
 def logits_to_probs_sample(logits_c, logits_u, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr, col0=0, amax_out_ptr=None):

@@ -97,6 +97,10 @@ const char *sjd_error_string(int code);
  * the `n_batch` CFG rows, to `input_ids_out` [n_batch, max_rows] (feeds the embedding lookup). */
 int sjd_reguess(const sjd_iter_params *params, sjd_state *state, int64_t *input_ids_out, int n_batch, int max_rows,
                 void *stream);
+/* same, and also writes the window's position ids positions_out[b][i] = params->kv_len + i + pos_offset[b] (int64 [n_batch, max_rows];
+ * pos_offset int64 [n_batch] or NULL) -- what the reference derives from cache_position on the host (JL:1062-1073) */
+int sjd_reguess_ex(const sjd_iter_params *params, sjd_state *state, int64_t *input_ids_out, int n_batch, int max_rows,
+                   const int64_t *pos_offset, int64_t *positions_out, void *stream);
 
 /* K2 -- logits -> CFG -> grammar -> top-k/top-p -> softmax -> multinomial.
  * replaces sampling_logits2tokens + the 3-dim processors (reference jacobi_iteration_lumina_mgpt.py:82-132).

@@ -238,6 +238,15 @@ def test_k5_window_assembly(dev):
         assert [st.win_tok[i] for i in range(n)] == want
         assert [st.q_src[i] for i in range(n)] == [m - 1 + i for i in range(a + 1)] + [-1] * (n - 1 - a)
         assert ids[0, :n].tolist() == want and ids[1, :n].tolist() == want
+        # the same launch with the position ids: kv_len + i + pos_offset[b]
+        params.view.kv_len = 700 + n
+        params.upload()
+        off, pos = torch.tensor([0, -37], dtype=torch.int64, device=dev), torch.full((2, 16), -1, dtype=torch.int64, device=dev)
+        ids.zero_()
+        ops.reguess(params, state, ids, pos_offset=off, positions_out=pos)
+        torch.cuda.synchronize()
+        assert ids[0, :n].tolist() == want and ids[1, :n].tolist() == want
+        assert pos[0].tolist() == [700 + n + i for i in range(16)] and pos[1].tolist() == [700 + n - 37 + i for i in range(16)]
 
 
 class _Cache:

@@ -9,6 +9,18 @@
 #include "../../include/sjd_hip.h"
 #include "sjd_device.cuh"
 
+// phase timestamps of K2 / K4 (tools/phase_trace.py, -DSJD_TRACE; compiled out otherwise): slot = row (K2) / 32 (K4)
+#ifdef SJD_TRACE
+__device__ unsigned long long g_k2_trace[64][8];
+#define SJD_TRS(slot, i) do { if (threadIdx.x == 0) g_k2_trace[(slot) & 63][i] = wall_clock64(); } while (0)
+extern "C" int sjd_debug_trace_k2(unsigned long long *host_out, int n)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k2_trace), (size_t)n * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#else
+#define SJD_TRS(slot, i) do { } while (0)
+#endif
+
 // smallest column window [lo, hi) containing every allowed column of the rule
 __device__ __forceinline__ void rule_window(const sjd_row_rule &r, int V, int &lo, int &hi)
 {
@@ -71,6 +83,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
 {
     __shared__ SjdShared sh;
     const int row = blockIdx.x;
+    SJD_TRS(row, 0);
     if (row >= params->n_rows) return;
     const sjd_row_rule rule = params->rules[row];
     float *p = probs_out + (size_t)row * V;
@@ -102,10 +115,15 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     int wlo, whi;
     rule_window(rule, V, wlo, whi);
     if (wlo > 0 || whi < V) {
-        SJD_FOR_OWNED_COLS(V, c0)
-            for (int j = 0; j < 4; ++j) { int col = c0 + j; if (col < V && (col < wlo || col >= whi)) p[col] = 0.0f; }
+        const bool v4 = (V & 3) == 0;              // (rows of probs_out are then 16-byte aligned)
+        SJD_FOR_OWNED_COLS(V, c0) {
+            if (v4 && (c0 + 3 < wlo || c0 >= whi)) *reinterpret_cast<float4 *>(p + c0) = float4{0.f, 0.f, 0.f, 0.f};
+            else if (c0 < wlo || c0 + 3 >= whi)
+                for (int j = 0; j < 4; ++j) { int col = c0 + j; if (col < V && (col < wlo || col >= whi)) p[col] = 0.0f; }
+        }
     }
 
+    SJD_TRS(row, 1);              // outside of the window zeroed
     // pass 1: CFG combine (JL:104) + grammar mask (LP:125-129); stage z; row max; finite count
     float tmax = -INFINITY;
     int cnt = 0;
@@ -115,6 +133,24 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
             const bool in4 = vec && c0 >= hp.col0 && c0 + 3 < hp.col0 + hp.n_cols && c0 + 3 < V;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { zc[j] = 0.f; zu[j] = 0.f; }
+            if (in4 && hp.n_chunks <= 8) {
+                // all chunk planes of this thread's four columns are requested before the first add (in-kernel timestamps, round 2: one
+                // plane at a time made this pass 8 dependent round trips to cold partials, 17 of K2's 44 us); summed in chunk order
+                float4 a[8], b[8];
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch)
+                    if (ch < hp.n_chunks) {
+                        const size_t off = (size_t)ch * hp.chunk_stride + c0;
+                        a[ch] = *reinterpret_cast<const float4 *>(c + off);
+                        if (u) b[ch] = *reinterpret_cast<const float4 *>(u + off);
+                    }
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch)
+                    if (ch < hp.n_chunks) {
+                        zc[0] += a[ch].x; zc[1] += a[ch].y; zc[2] += a[ch].z; zc[3] += a[ch].w;
+                        if (u) { zu[0] += b[ch].x; zu[1] += b[ch].y; zu[2] += b[ch].z; zu[3] += b[ch].w; }
+                    }
+            } else
             for (int ch = 0; ch < hp.n_chunks; ++ch) {           // chunk order = the summation order of every G1 consumer
                 const size_t off = (size_t)ch * hp.chunk_stride + c0;
                 if (in4) {
@@ -162,11 +198,13 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const float zmax = block_max(tmax, sh);
     const int n_finite = block_sum_int(cnt, sh);
     __syncthreads();   // staged z visible to the whole block (global memory, same CU)
+    SJD_TRS(row, 2);              // logits staged, max known
 
     // top-k (LP:196-204): keep z >= k-th largest; k-th is -inf when fewer than k finite entries exist
     float kth = -INFINITY;
     if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_finite) kth = block_kth_largest(p, wlo, whi, rule.top_k, -INFINITY, sh);
 
+    SJD_TRS(row, 3);              // top-k threshold known
     // pass A: e = exp(z - max) for kept entries, canonical sum
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
@@ -186,6 +224,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     float S = block_canonical_sum(a0, a1, a2, a3, sh);
     if (rule.top_p_thr >= 0.0f) S = block_top_p_apply(p, wlo, whi, S, rule.top_p_thr, sh);     // TopPLogitsWarper3d (LP:406-419)
 
+    SJD_TRS(row, 4);              // sum known
     // pass B: p = e / S ; multinomial == lowest-index argmax of p / Exp(1)   (JL:111-118)
     unsigned long long best = 0ull, best_p = 0ull;
     SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
@@ -203,12 +242,14 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
             }
         }
     }
+    SJD_TRS(row, 5);              // probabilities written
     const int tok = block_argmax(best, sh);
     if (threadIdx.x == 0) tokens_out[row] = tok;
     if (amax_out) {                                  // by-product: the row's mode (lowest index among equal maxima)
         const int am = block_argmax(best_p, sh);
         if (threadIdx.x == 0) amax_out[row] = am;
     }
+    SJD_TRS(row, 6);
 }
 
 // ------------------------------------------------------------------------------------------------ K4

@@ -21,12 +21,12 @@ def build():
     csrc = os.path.join(PKG, "csrc")
     subprocess.check_call(["make", "-C", csrc], stdout=subprocess.DEVNULL)
     objs = []
-    for f in ("sjd_attention", "sjd_gemm", "sjd_glue"):
+    for f in ("sjd_attention", "sjd_gemm", "sjd_glue", "sjd_sampling"):
         o = os.path.join("/tmp", f + "_trace.o")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DSJD_TRACE", "-Wno-unused-value",
-                               "-c", os.path.join(csrc, f + ".hip"), "-o", o])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DSJD_TRACE", "-Wno-unused-value"]
+                              + (["-ffp-contract=off"] if f == "sjd_sampling" else []) + ["-c", os.path.join(csrc, f + ".hip"), "-o", o])
         objs.append(o)
-    rest = [os.path.join(csrc, f + ".o") for f in ("sjd_sampling", "sjd_capi")]
+    rest = [os.path.join(csrc, f + ".o") for f in ("sjd_capi",)]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TRACE_SO] + objs + rest)
 
 
@@ -228,6 +228,11 @@ def trace_in_situ(lib, torch, ops, np, kv_target=1216):
     b = np.zeros((64, 4), dtype=np.uint64)
     assert lib.sjd_debug_trace_k1c(b.ctypes.data, 64) == 0
     table("k1_combine (layer 31, in situ)", b, 3, ["partials_arrive", "normalise_store"])
+    lib.sjd_debug_trace_k2.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    b = np.zeros((16, 8), dtype=np.uint64)
+    assert lib.sjd_debug_trace_k2(b.ctypes.data, 16) == 0
+    table("k2_logits_to_probs_sample (one workgroup per window row, last iteration), in situ", b, 7,
+          ["zero_outside_window", "head_partials_cfg_mask_max", "top_k_radix_select", "exp_and_sum", "normalise_and_draw", "argmax"])
     for kind, name, nwg in ((0, "f1r_residual_sumsq (last launch: after down of layer 31, 13 partial planes)", 256),
                             (1, "f2_qknorm_rope_append (layer 31)", 768), (2, "f3_silu_mul (layer 31)", 172)):
         b = np.zeros((nwg, 4), dtype=np.uint64)

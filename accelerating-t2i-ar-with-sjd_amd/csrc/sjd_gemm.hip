@@ -26,8 +26,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #ifdef SJD_TRACE
 __device__ unsigned long long g_g1_trace[4096][8];
 #define SJD_TR(i) do { if (threadIdx.x == 0) g_g1_trace[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][i] = wall_clock64(); } while (0)
+// slot 7: where the workgroup ran -- XCC_ID (hwreg 20) in the high word, HW_ID (hwreg 4: wave / SIMD / CU / SH / SE) in the low word
+#define SJD_TR_HW() do { if (threadIdx.x == 0) g_g1_trace[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][7] = \
+    ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); } while (0)
 #else
 #define SJD_TR(i) do { } while (0)
+#define SJD_TR_HW() do { } while (0)
 #endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -68,6 +72,7 @@ __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__r
                                                                 int rec_stride, int tile0)
 {
     SJD_TR(0);                    // entry
+    SJD_TR_HW();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *xl = reinterpret_cast<u32x4 *>(smem);
     const int chunk = blockIdx.y;

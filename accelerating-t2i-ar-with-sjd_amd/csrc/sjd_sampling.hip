@@ -253,16 +253,36 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
 }
 
 // ------------------------------------------------------------------------------------------------ K4
+// The per-iteration read-back without a copy engine: the last kernel of an iteration writes the 912-byte state into HOST memory the
+// device can address (pinned, fine-grained), so the host's single sync of the iteration is a stream synchronize and nothing else.
+// rocprofv3 kernel trace, round 2 (tools/step_gaps.py): the D2H copy that used to follow K4 started ~10 us after it (hand-over from
+// the compute queue to the SDMA engine) on top of the copy itself.  All threads of the block call this (barrier inside); the words
+// are read back with device-scope loads: every store of this block has reached L2 at the barrier, K2's came with the previous kernel.
+__device__ __forceinline__ void k4_mirror_state(const sjd_state *state, sjd_state *host_mirror)
+{
+    if (!host_mirror) return;
+    __syncthreads();
+    constexpr int WORDS = (int)(sizeof(sjd_state) / sizeof(unsigned long long));
+    static_assert(sizeof(sjd_state) % sizeof(unsigned long long) == 0, "sjd_state is copied in 8-byte words");
+    if (threadIdx.x < WORDS) {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(state) + threadIdx.x, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        reinterpret_cast<unsigned long long *>(host_mirror)[threadIdx.x] = v;
+    }
+    __threadfence_system();
+}
+
 // replaces SpeculativeSampler.__call__ / find_first_misaligned_token_inds (reference JL:247-333)
 __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
     const sjd_iter_params *__restrict__ params, sjd_state *__restrict__ state, const float *__restrict__ probs,
     const float *__restrict__ prev_probs, const float *__restrict__ rs, const float *__restrict__ noise2,
-    float *__restrict__ scratch, int V)
+    float *__restrict__ scratch, int V, sjd_state *__restrict__ host_mirror)
 {
     __shared__ SjdShared sh;
     const int n = params->n_rows;
     if (n <= 1) {   // prefill / single-token phase short-circuit (JL:344-350)
         if (threadIdx.x == 0) { state->m = 1; state->rejected = 0; state->n_prev = n; }
+        k4_mirror_state(state, host_mirror);
         return;
     }
     const int scheme = params->scheme;
@@ -364,6 +384,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
         }
     }
     if (threadIdx.x == 0) { state->m = m; state->rejected = rejected ? (degenerate ? 2 : 1) : 0; state->n_prev = n; }
+    k4_mirror_state(state, host_mirror);
 }
 
 // ------------------------------------------------------------------------------------------------ K5
@@ -451,12 +472,19 @@ extern "C" int sjd_logits_to_probs_sample_part(const sjd_head_partials *head, fl
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
-extern "C" int sjd_verify_accept(const sjd_iter_params *params, sjd_state *state, const float *probs, const float *prev_probs,
-                                 const float *rs, const float *noise2, float *scratch, int max_rows, int V, void *stream)
+extern "C" int sjd_verify_accept_ex(const sjd_iter_params *params, sjd_state *state, const float *probs, const float *prev_probs,
+                                    const float *rs, const float *noise2, float *scratch, int max_rows, int V, sjd_state *host_mirror,
+                                    void *stream)
 {
     if (!params || !state || !probs || !prev_probs || !rs || !noise2 || !scratch || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
         return SJD_ERR_BAD_ARG;
     hipLaunchKernelGGL(k4_verify_accept, dim3(1), dim3(SJD_TPB), 0, (hipStream_t)stream, params, state, probs, prev_probs, rs,
-                       noise2, scratch, V);
+                       noise2, scratch, V, host_mirror);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_verify_accept(const sjd_iter_params *params, sjd_state *state, const float *probs, const float *prev_probs,
+                                 const float *rs, const float *noise2, float *scratch, int max_rows, int V, void *stream)
+{
+    return sjd_verify_accept_ex(params, state, probs, prev_probs, rs, noise2, scratch, max_rows, V, nullptr, stream);
 }

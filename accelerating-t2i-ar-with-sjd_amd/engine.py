@@ -23,6 +23,7 @@ RNG streams mirror the reference: device generator g for 
 same order and shapes), global CPU generator for the fresh ids.  The residual draw is made from g speculatively
 and the generator state is rewound when no rejection happened.
 """
+import ctypes
 import random
 import time
 from dataclasses import dataclass, field
@@ -122,6 +123,7 @@ class SJDEngine:
         self._dbg = None                            # [2, L, V] logits as K2 derived them; allocated only for observers (hook)
         self._guidance = 3.0
         self.rng_stream = torch.cuda.Stream(device=dev)
+        self._rule_bytes, self._rule_keep, self._cols_cache = {}, [], {}
         self.reset_graphs()
 
     def reset_graphs(self):
@@ -145,19 +147,28 @@ class SJDEngine:
     def _fill_params(self, n, kv_len, use_cfg, scheme, fresh, rules, resid):
         p = self.params.view
         p.n_rows, p.kv_len, p.use_cfg, p.scheme, p.n_fresh = n, kv_len, int(use_cfg), scheme, len(fresh)
-        for i, t in enumerate(fresh):
-            p.fresh_tok[i] = t
-        for j, r in enumerate(rules):
-            p.rules[j] = r
-        for j, r in enumerate(resid):
-            p.resid_rules[j] = r
+        if fresh:
+            p.fresh_tok[:len(fresh)] = fresh
+        self._write_rules(L.IterParams.rules.offset, rules)
+        if resid:
+            self._write_rules(L.IterParams.resid_rules.offset, resid)
         self.params.upload()
+
+    def _write_rules(self, offset, rules):
+        """rules (interned sjd_row_rule structs, ops.make_rule) -> the blob, as ONE block copy: the packed bytes of a rule sequence are
+        cached by the structs' identities (an image body asks for the same two or three sequences over and over)."""
+        key = tuple(map(id, rules))
+        blk = self._rule_bytes.get(key)
+        if blk is None:
+            blk = b"".join(bytes(r) for r in rules)
+            if len(self._rule_bytes) < 4096:
+                self._rule_bytes[key] = blk
+                self._rule_keep.append(list(rules))            # the ids stay valid while the structs are alive
+        ctypes.memmove(self.params.host.data_ptr() + offset, blk, len(blk))
 
     def _fill_resid(self, resid):
         """the residual rules are read by K4 only: they are computed and uploaded (their slice of the blob) while the forward runs"""
-        p = self.params.view
-        for j, r in enumerate(resid):
-            p.resid_rules[j] = r
+        self._write_rules(L.IterParams.resid_rules.offset, resid)
         off = L.IterParams.resid_rules.offset
         with torch.cuda.stream(self.rng_stream):          # part 2 waits for this stream (noise_ready): off the forward's stream
             self.params.dev[off:].copy_(self.params.host[off:], non_blocking=True)
@@ -188,7 +199,7 @@ class SJDEngine:
             lu = logits[1] if self.B > 1 else None
             ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr,
                                        col0=cols[0] if cols else 0, amax_out_ptr=self.amax_ptr)
-        ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0], self.scratch)
+        ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0], self.scratch, mirror=True)
 
     def logit_columns(self, rules):
         """Vocabulary window [lo, hi) (32-aligned) that holds every id the non-forced rows of this iteration may emit, or None when
@@ -197,6 +208,16 @@ class SJDEngine:
         jacobi_iteration_emu3.py:44-128), so not computing them changes nothing downstream."""
         if not self.narrow_head:
             return None
+        key = tuple(map(id, rules))
+        if key in self._cols_cache:
+            return self._cols_cache[key]
+        cols = self._logit_columns(rules)
+        if len(self._cols_cache) < 4096:
+            self._cols_cache[key] = cols
+            self._rule_keep.append(list(rules))
+        return cols
+
+    def _logit_columns(self, rules):
         lo, hi = self.V, 0
         for r in rules:
             if r.forced >= 0:
@@ -319,7 +340,7 @@ class SJDEngine:
             else:
                 n_rows = n
                 a = max(0, min(n_prev - m_prev, n - 1))                              # JL:633-639, 657-662
-                fr = torch.randint(0, cfg.img_vocab_n, (1, n - 1 - a))[0].tolist()   # GLOBAL CPU generator (JL:505)
+                fr = torch.randint(0, cfg.img_vocab_n, (1, n - 1 - a)).tolist()[0]   # GLOBAL CPU generator (JL:505)
                 fresh = [cfg.img_vocab_lo + t for t in fr]                           # img_vocab[rand] (JL:509)
                 if cfg.multi_token_init_scheme != "random":                          # spatial init (JL:516-594): copy / re-draw from the left
                     fresh = spatial_fresh_tokens(cfg.multi_token_init_scheme, fresh, len(X) + a, carried[a - 1] if a else X[-1],
@@ -328,7 +349,9 @@ class SJDEngine:
                 resid = []                     # computed below, while the forward runs (K4 is their only reader)
             use_cfg = do_cfg and not grammar.force_no_cfg()                          # JL:1086-1096
             self._fill_params(n_rows, kv_len, use_cfg, scheme, fresh, rules, resid)
-            self.rng_stream.wait_stream(torch.cuda.current_stream())                 # the previous iteration is done with the noise
+            if first:
+                self.rng_stream.wait_stream(torch.cuda.current_stream())             # earlier work on this stream is done with the noise buffers
+            # (later iterations: the host has just waited for K4, the last reader of the noise, so the side stream may start at once)
             logits = None
             if not first:
                 # part 1 goes out NOW: everything the forward reads (n_rows, kv_len, fresh ids) is uploaded; the residual grammar,
@@ -374,7 +397,7 @@ class SJDEngine:
                 ops.logits_to_probs_sample(lc, lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr,
                                            amax_out_ptr=self.amax_ptr)
                 ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0],
-                                  self.scratch)
+                                  self.scratch, mirror=True)
                 if attn is not None and hasattr(attn, "params"):
                     attn.params = self.params                                        # windows: kv_len / n_rows from the blob
             else:
@@ -395,7 +418,7 @@ class SJDEngine:
                                prev_probs=self.probs[1 - cur], ctx=list(X), scheme=scheme))
             # ---------------- the single sync of the iteration ----------------
             t_sync0 = time.perf_counter()
-            self.state.download()
+            self.state.wait_mirror()          # K4 ended by writing the state into the pinned host copy: no D2H copy, one stream wait
             stats.sync_seconds += time.perf_counter() - t_sync0
             m_dev, rejected = int(st.m), bool(st.rejected)
             if int(st.rejected) > 1:
@@ -403,8 +426,8 @@ class SJDEngine:
                                    "(the reference's torch.multinomial raises on the NaN probabilities at JL:237)")
             if g_state is not None and not rejected:
                 gen.set_state(g_state)
-            Y = [int(st.tokens[i]) for i in range(n_rows)]
-            A = [int(st.amax[i]) for i in range(n_rows)]       # modes of this iteration's target rows (K2 by-product)
+            Y = st.tokens[:n_rows]
+            A = st.amax[:n_rows]                               # modes of this iteration's target rows (K2 by-product)
             if n_rows <= 1:
                 m = win_len                      # is_prefilling_phase short-circuit (JL:344-350)
                 emitted, carried, carried_amax, last_amax = [Y[0]], [], [], A[0]

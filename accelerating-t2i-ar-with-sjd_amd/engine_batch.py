@@ -135,7 +135,7 @@ class SJDBatchEngine:
             lc = logits[i * self.nb]
             lu = logits[i * self.nb + 1] if self.nb > 1 else None
             ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, s.noise, s.probs[cur], s.tokens_ptr, col0=cols[0] if cols else 0)
-            ops.verify_accept(s.params, s.state, s.probs[cur], s.probs[1 - cur], s.rs, s.noise2[0], s.scratch)
+            ops.verify_accept(s.params, s.state, s.probs[cur], s.probs[1 - cur], s.rs, s.noise2[0], s.scratch, mirror=True)
 
     def _launch_forward(self, cols):
         if not self.use_graph:
@@ -245,7 +245,7 @@ class SJDBatchEngine:
             lc = logits[0, -1:, :]
             lu = logits[1, -1:, :] if nb > 1 else None
             ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, s.noise, s.probs[buf], s.tokens_ptr)
-            ops.verify_accept(s.params, s.state, s.probs[buf], s.probs[1 - buf], s.rs, s.noise2[0], s.scratch)
+            ops.verify_accept(s.params, s.state, s.probs[buf], s.probs[1 - buf], s.rs, s.noise2[0], s.scratch, mirror=True)
             if self.hook is not None:
                 self.hook(j, dict(first=True, n_rows=1, logits_c=lc, logits_u=lu, use_cfg=use_cfg, rules=rules, resid=[],
                                   noise=s.noise[:1], rs=s.rs[:1], noise2=s.noise2[0], probs=s.probs[buf], prev_probs=s.probs[1 - buf],
@@ -278,7 +278,7 @@ class SJDBatchEngine:
             attn.params = None
         for i in range(self.P):
             admit(i, cur)
-        self.state.download()
+        self.state.wait_mirror()
         for s in self.slots:
             after_prefill(s)
         cur = 1 - cur
@@ -301,7 +301,7 @@ class SJDBatchEngine:
                         if attn is not None and hasattr(attn, "params"):
                             attn.params = None
                         admit(i, 1 - cur)
-                        self.state.download()
+                        self.state.wait_mirror()
                         after_prefill(s)
                         if attn is not None and hasattr(attn, "params"):
                             attn.params = self.params
@@ -364,7 +364,7 @@ class SJDBatchEngine:
                                                    noise2=s.noise2[0], probs=s.probs[cur], prev_probs=s.probs[1 - cur], ctx=list(s.X),
                                                    scheme=scheme))
             t_s = time.perf_counter()
-            self.state.download()                              # the single sync of the iteration
+            self.state.wait_mirror()                              # the single sync of the iteration
             sync_s += time.perf_counter() - t_s
             for s, (n_rows, _, _, _) in zip(self.slots, metas):
                 if s.finished:

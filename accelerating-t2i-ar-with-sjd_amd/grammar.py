@@ -88,6 +88,7 @@ class LuminaGrammar(_Grammar):
         self.image_top_k, self.text_top_k = image_top_k, text_top_k
         self.start_id, self.end_id, self.eol_id = image_start_token_id, image_end_token_id, image_next_line_token_id
         self.img_lo, self.img_hi = img_lo, img_hi
+        self._body_rules = {}
         self.reset()
 
     def reset(self):
@@ -132,14 +133,17 @@ class LuminaGrammar(_Grammar):
         h, w = (g1 - 8804) * 2, (g2 - 8804) * 2                         # LP:107-111
         T = since - 2                                                   # tokens after <start> h w
         l1, l2 = w + 1, (w + 1) * h + 1
-        rules = []
-        for j in range(n):
-            forced = -1
-            if l1 > 0 and (T + 1 + j) % l1 == 0:
-                forced = self.eol_id                                    # LP:132-137
-            if l2 > 0 and (T + 1 + j) % l2 == 0:
-                forced = self.end_id                                    # LP:140-145
-            rules.append(ops.make_rule(((self.img_lo, self.img_hi),), forced, k))
+        trio = self._body_rules.get(k)
+        if trio is None:                                                # the three rules of an image body, made once per top-k
+            rng = ((self.img_lo, self.img_hi),)
+            trio = self._body_rules[k] = (ops.make_rule(rng, -1, k), ops.make_rule(rng, self.eol_id, k), ops.make_rule(rng, self.end_id, k))
+        rules = [trio[0]] * n
+        if l1 > 0:
+            for j in range((-(T + 1)) % l1, n, l1):                     # rows with (T + 1 + j) % l1 == 0
+                rules[j] = trio[1]                                      # LP:132-137
+        if l2 > 0:
+            for j in range((-(T + 1)) % l2, n, l2):
+                rules[j] = trio[2]                                      # LP:140-145 (evaluated after the line rule: it wins)
         return rules
 
 

@@ -62,11 +62,22 @@ class DeviceBlob:
         self.view = ctype.from_address(self.host.data_ptr())
 
     def upload(self):
-        self.dev.copy_(self.host, non_blocking=True)
+        """pinned host -> device on the current stream (hipMemcpyAsync through the C-ABI: a torch copy_ costs the host 6-8 us per call)"""
+        L.check(L.load().sjd_upload_async(self.dev.data_ptr(), self.host.data_ptr(), self.nbytes, _stream()), "sjd_upload_async")
 
     def download(self):
         self.host.copy_(self.dev)
         return self.view
+
+    def wait_mirror(self):
+        """The kernel that ends the iteration wrote this blob into the pinned host copy itself (sjd_verify_accept_ex, host_mirror):
+        the read-back is a stream synchronize, no D2H copy is enqueued."""
+        L.check(L.load().sjd_stream_synchronize(_stream()), "sjd_stream_synchronize")
+        return self.view
+
+    @property
+    def host_ptr(self):
+        return ctypes.c_void_p(self.host.data_ptr())
 
     def field_ptr(self, name):
         return ctypes.c_void_p(self.dev.data_ptr() + getattr(self.ctype, name).offset)
@@ -87,10 +98,14 @@ class BlobArray:
         self.blobs = [DeviceBlob(ctype, device, self.host[i * nb:(i + 1) * nb], self.dev[i * nb:(i + 1) * nb]) for i in range(n)]
 
     def upload(self):
-        self.dev.copy_(self.host, non_blocking=True)
+        L.check(L.load().sjd_upload_async(self.dev.data_ptr(), self.host.data_ptr(), self.host.numel(), _stream()), "sjd_upload_async")
 
     def download(self):
         self.host.copy_(self.dev)
+
+    def wait_mirror(self):
+        """every blob's last writer (sjd_verify_accept_ex with host_mirror) wrote its pinned host copy itself: one stream wait"""
+        L.check(L.load().sjd_stream_synchronize(_stream()), "sjd_stream_synchronize")
 
     @property
     def ptr(self):
@@ -125,12 +140,13 @@ def logits_to_probs_sample(logits_c, logits_u, guidance, params: DeviceBlob, noi
                                                   _stream()), "sjd_logits_to_probs_sample")
 
 
-def verify_accept(params: DeviceBlob, state: DeviceBlob, probs, prev_probs, rs, noise2, scratch):
+def verify_accept(params: DeviceBlob, state: DeviceBlob, probs, prev_probs, rs, noise2, scratch, mirror=False):
+    """mirror: K4 also writes the state into the blob's pinned host copy (read it with state.wait_mirror(), not download())"""
     max_rows, V = probs.shape
     for t in (probs, prev_probs, rs, noise2, scratch):
         assert t.dtype == torch.float32 and t.is_contiguous()
-    L.check(L.load().sjd_verify_accept(params.ptr, state.ptr, _ptr(probs), _ptr(prev_probs), _ptr(rs), _ptr(noise2),
-                                      _ptr(scratch), max_rows, V, _stream()), "sjd_verify_accept")
+    L.check(L.load().sjd_verify_accept_ex(params.ptr, state.ptr, _ptr(probs), _ptr(prev_probs), _ptr(rs), _ptr(noise2),
+                                         _ptr(scratch), max_rows, V, state.host_ptr if mirror else None, _stream()), "sjd_verify_accept")
 
 
 def kv_append(k_new, v_new, k_cache, v_cache, params, kv_len):

@@ -269,6 +269,15 @@ int sjd_draft_window_attention_fp8(const void *q, const void *k_cache, const voi
                                    int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
                                    const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream);
 
+/* K4 with the read-back folded in: when host_mirror != NULL (HOST memory the device can address: hipHostMalloc / a pinned torch tensor)
+ * the kernel ends by copying *state into it, so the host's one sync per iteration (reference: the ~25-40 implicit syncs of
+ * jacobi_iteration_lumina_mgpt.py:1107-1208) is sjd_stream_synchronize and no D2H copy is enqueued. */
+int sjd_verify_accept_ex(const sjd_iter_params *params, sjd_state *state, const float *probs, const float *prev_probs,
+                         const float *rs, const float *noise2, float *scratch, int max_rows, int V, sjd_state *host_mirror, void *stream);
+/* the iteration's parameter blob: pinned host -> device, asynchronous on `stream`; and the wait that closes an iteration */
+int sjd_upload_async(void *dst_device, const void *src_pinned_host, int64_t bytes, void *stream);
+int sjd_stream_synchronize(void *stream);
+
 /* HIP event helpers so that a ctypes host can time kernels on the stream they run on. */
 void *sjd_event_create(void);
 void sjd_event_destroy(void *ev);

@@ -164,9 +164,14 @@ def run_k4(dev, win, Y, p, q_rows, rs, resid, e2, scheme=0, max_rows=16):
     probs[:n] = torch.from_numpy(p).to(dev)
     rsd = torch.zeros(max_rows, V, device=dev)
     rsd[:n] = torch.from_numpy(rs).to(dev)
-    ops.verify_accept(params, state, probs, prev, rsd, torch.from_numpy(e2).to(dev), torch.empty(V, device=dev))
-    torch.cuda.synchronize()
+    # K4 writes the state into the blob's pinned host copy itself (host_mirror): what the host reads after ONE stream wait must be
+    # byte for byte what a D2H copy of the device state gives
+    state.host.fill_(0xA5)
+    ops.verify_accept(params, state, probs, prev, rsd, torch.from_numpy(e2).to(dev), torch.empty(V, device=dev), mirror=True)
+    state.wait_mirror()
+    mirrored = bytes(state.host.numpy().tobytes())
     st = state.download()
+    assert mirrored == state.host.numpy().tobytes(), "K4's host mirror differs from the device state"
     return st.m, [st.tokens[i] for i in range(n)], bool(st.rejected)
 
 

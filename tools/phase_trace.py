@@ -15,6 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "accelerating-t2i-ar-with-sjd_amd")
 TRACE_SO = os.path.join(PKG, "libsjd_hip_trace.so")
+PER_WG = None
 
 
 def build():
@@ -140,6 +141,12 @@ def trace_g1(lib, torch, ops, np):
         t0 = t[:, 0].min()
         d = lambda a, b: us((t[:, b] - t[:, a]).mean())
         loop = t[:, 4] - t[:, 3]
+        if PER_WG is not None:        # --per-wg FILE: every workgroup's stamps and where it ran (slot 7: XCC_ID << 32 | HW_ID), us from the first entry
+            gx = (N // 32 + waves - 1) // waves
+            PER_WG.write(json.dumps(dict(shape=name, KC=KC, waves=waves, grid=[gx, nc], wg=[
+                dict(x=i % gx, y=i // gx, xcc=int(t[i, 7] >> 32) & 15, cu=int(t[i, 7] >> 8) & 15, sh=int(t[i, 7] >> 12) & 1, se=int(t[i, 7] >> 13) & 7,
+                     t=[us(t[i, k] - t0) for k in range(7)]) for i in range(nwg)])) + "\n")
+            PER_WG.flush()
         print(json.dumps(dict(kernel="g1_skinny_gemm<bf16, 32 rows>", shape=name, KC=KC, waves=waves, workgroups=nwg,
                               start_skew_us=us((t[:, 0] - t0).max()),
                               phase_us=dict(stage_activation=d(0, 1), wait_for_waves=d(1, 2), first_weight_group=d(2, 3), main_loop=d(3, 4),
@@ -250,6 +257,11 @@ def main():
     import sjd_amd._lib as L
     import sjd_amd.ops as ops
     lib = L.load()
+    global PER_WG
+    if "--per-wg" in sys.argv:
+        PER_WG = open(sys.argv[sys.argv.index("--per-wg") + 1], "w")
+        trace_g1(lib, torch, ops, np)
+        return
     trace_k1(lib, torch, ops, np)
     trace_k1_shared(lib, torch, ops, np)
     trace_g1(lib, torch, ops, np)

@@ -50,19 +50,6 @@ __device__ __forceinline__ int g1_slot(int half, int mm, int s)
     return (half << 5) | (mm & 16) | ((mm & 15) ^ (((s & 7) << 1) | half));
 }
 
-// Split-K chunks are BALANCED: the K / 16 k-steps are dealt to the n_chunks = ceil(K / KC) chunks as evenly as integers allow (chunk c =
-// steps [c S / n, (c + 1) S / n)), KC only fixes their number and bounds their size.  Per-workgroup timestamps (tools/phase_trace.py
-// --per-wg, round 2) showed what the earlier "full chunks + one ragged chunk" split cost: q|k|v (K = 4096, KC = 896) ran as 4 x 56 + 32
-// steps and down (K = 11008) as 12 x 56 + 16, the workgroups of the short chunk finished at 11 / 6 us of a 16 us kernel and their CUs (48
-// of 240, 16 of 208) idled while every other workgroup still had its 56 steps to pull at the ~40 GB/s one CU sustains.
-__device__ __forceinline__ void g1_chunk_range(int chunk, int n_chunks, int K, int &k0, int &steps, int &step0)
-{
-    const int S = K / 16;
-    step0 = (int)(((long)chunk * S) / n_chunks);
-    steps = (int)(((long)(chunk + 1) * S) / n_chunks) - step0;
-    k0 = step0 * 16;
-}
-
 template <int DT> struct G1Mfma;
 template <> struct G1Mfma<SJD_DTYPE_BF16> {
     static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c)
@@ -89,18 +76,18 @@ __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *xl = reinterpret_cast<u32x4 *>(smem);
     const int chunk = blockIdx.y;
-    int k0, steps, step0;
-    g1_chunk_range(chunk, gridDim.y, K, k0, steps, step0);
+    const int k0 = chunk * KC;
+    const int steps = min(KC, K - k0) / 16;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const int t_out = blockIdx.x * waves + w;          // tile of this launch's output
     const int t = tile0 + t_out;                       // tile of the packed weight
     const bool has_tile = t_out < N / 32;
-    // record (chunk, s, t) in 1-KiB units: the earlier chunks hold n_tiles * step0 records.
+    // record (chunk, s, t) in 1-KiB units: all earlier chunks are full (KC/16 steps each).
     //   rec_stride == 1      : tile-major   -- a wave streams one contiguous run of `steps` KiB
     //   rec_stride == n_tiles: step-major   -- at every k-step the whole grid row reads n_tiles contiguous KiB, i.e. the
     //                                           chip sweeps the weight matrix like a linear copy (DRAM row locality)
-    const size_t chunk_base = (size_t)n_tiles * step0;
+    const size_t chunk_base = (size_t)chunk * n_tiles * (KC / 16);
     const size_t tile_off = (rec_stride == 1) ? (size_t)(has_tile ? t : 0) * steps : (size_t)(has_tile ? t : 0);
     const u32x4 *wu = wp + (chunk_base + tile_off) * 64 + lane;
     const size_t rs = (size_t)rec_stride * 64;
@@ -253,14 +240,14 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *xl = reinterpret_cast<u32x4 *>(smem);                 // two buffers of MT * G1_SUB records
     const int chunk = blockIdx.y;
-    int k0, steps, step0;
-    g1_chunk_range(chunk, gridDim.y, K, k0, steps, step0);
+    const int k0 = chunk * KC;
+    const int steps = min(KC, K - k0) / 16;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const int t_out = blockIdx.x * waves + w;
     const bool has_tile = t_out < N / 32;                        // a wave without a tile multiplies tile 0 and stores nothing
     const int t = tile0 + (has_tile ? t_out : 0);
-    const size_t chunk_base = (size_t)n_tiles * step0;
+    const size_t chunk_base = (size_t)chunk * n_tiles * (KC / 16);
     const size_t tile_off = (rec_stride == 1) ? (size_t)t * steps : (size_t)t;
     const u32x4 *wu = wp + (chunk_base + tile_off) * 64 + lane;
     const size_t rs = (size_t)rec_stride * 64;

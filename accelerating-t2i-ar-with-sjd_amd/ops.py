@@ -223,10 +223,8 @@ def pack_weight(weight, KC, step_major=False):
     N, K = weight.shape
     assert N % 32 == 0 and K % 16 == 0 and KC % 16 == 0
     out = []
-    S, nc = K // 16, (K + KC - 1) // KC
-    for c in range(nc):             # balanced split-K chunks: k-steps [c S / nc, (c + 1) S / nc), see g1_chunk_range (csrc/sjd_gemm.hip)
-        k0, k1 = 16 * (c * S // nc), 16 * ((c + 1) * S // nc)
-        kc = k1 - k0
+    for k0 in range(0, K, KC):
+        kc = min(KC, K - k0)
         w = weight[:, k0:k0 + kc].reshape(N // 32, 32, kc // 16, 2, 8)      # [t, r, s, h, j]
         if step_major:
             out.append(w.permute(2, 0, 3, 1, 4).reshape(-1))                # [s, t, h, r, j] : records of all tiles per k-step

@@ -52,7 +52,7 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_kv_append_fp8", "sjd_draft_window_attention_fp8", "sjd_qknorm_rope_append_fp8",
            "sjd_residual_sumsq", "sjd_qknorm_rope_append_ex", "sjd_silu_mul_ex", "sjd_weight_prefetch", "sjd_qkv_attention_fused", "sjd_skinny_gemm_cols",
            "sjd_logits_to_probs_sample_part", "sjd_logits_to_probs_sample_ex", "sjd_reguess_ex",
-           "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize"]
+           "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu"]
 
 _lib = None
 
@@ -79,6 +79,7 @@ def load():
     lib.sjd_verify_accept.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.sjd_verify_accept_ex.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.sjd_upload_async.argtypes = [vp, vp, i64, vp]
+    lib.sjd_gateup_silu.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp]
     lib.sjd_stream_synchronize.argtypes = [vp]
     lib.sjd_kv_append.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]
     lib.sjd_attention_workspace_bytes.restype = i64

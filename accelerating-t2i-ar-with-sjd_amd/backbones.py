@@ -35,6 +35,7 @@ import os as _os
 # -> tiles -> merge) remain inside the fused kernel (profiles/r2_attention_block.jsonl: 17.3 / 23.2 / 32.5 / 47.6 us against 17.7 / 21.6 /
 # 27.0 / 33.7 us at kv_len 64 / 448 / 1216 / 2368).  Default off; SJD_K1_FUSED=1 or model.k1_fused = True selects it.
 _K1_FUSED_DEFAULT = _os.environ.get("SJD_K1_FUSED", "0") == "1"
+_GATEUP_FUSED_DEFAULT = _os.environ.get("SJD_GATEUP_FUSED", "1") != "0"     # kernel G1s (gate|up + F3 in one launch); 0: G1 then F3
 
 
 def _head_logits(linear, x, cols):
@@ -488,6 +489,7 @@ class ChameleonBackbone(nn.Module):
         g1 = lambda x_, name, N_, K_: self._g1(li, x_, name, N_, K_)
         H, Hkv, D, hid, inter = self.n_heads, self.n_kv_heads, self.head_dim, self.args.hidden_size, self.args.intermediate_size
         params = getattr(self.attn, "params", None)
+        fuse_mlp = getattr(self, "gateup_fused", _GATEUP_FUSED_DEFAULT) and not self._pf_on and ops.gateup_silu_ok(T, inter, hid, cfg["gate_up"][0])
         h = self.model.embed_tokens(tokens).view(T, -1).contiguous()
         pos = positions.reshape(T).contiguous()
         delta = None
@@ -497,7 +499,10 @@ class ChameleonBackbone(nn.Module):
             qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
             o = self._attention_block(g1(h, "qkv", (H + 2 * Hkv) * D, hid), li, qn, pos, B, n, params, kv_len, key_start, row_norm=rn)
             rn = (ops.residual_sumsq(h, g1(o.view(T, H * D), "o", hid, H * D)), hid, eps)
-            act = ops.silu_mul(g1(h, "gate_up", 2 * inter, hid), rows=T, dtype=h.dtype, row_norm=rn)
+            if fuse_mlp:       # G1s: gate|up with SiLU * up as its epilogue (one launch, no partial planes, bit-identical to G1 + F3)
+                act = ops.gateup_silu(h, self._packed[li]["gate_up"], inter, hid, cfg["gate_up"][2], row_norm=rn)
+            else:
+                act = ops.silu_mul(g1(h, "gate_up", 2 * inter, hid), rows=T, dtype=h.dtype, row_norm=rn)
             delta = g1(act, "down", hid, inter)
         self._prefetch_join()
         if head_partials and self._packed_head is not None:

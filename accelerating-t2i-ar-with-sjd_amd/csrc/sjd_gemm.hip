@@ -382,6 +382,207 @@ extern "C" int sjd_weight_prefetch(const void *w, int64_t nbytes, int blocks, vo
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
+// ------------------------------------------------------------------------------------------------ G1s (gate|up + SiLU * up in one launch)
+// Per layer the MLP was gate|up G1 (split-K over two workgroup rows) -> F3 (sums the two fp32 partial planes, row scale, SiLU, product) ->
+// down G1.  F3 is a dependent stage at its latency floor (4.8 us in situ: a graph-node boundary plus one cold round trip for 5.6 MB of
+// partials another XCD has just written) and the per-workgroup timestamps of this round show the projections themselves streaming at
+// 6.7 TB/s between their first load and their last: what is left to take out of a layer is STAGES, not bytes per second.
+// Here the K split moves INSIDE the workgroup: 8 waves = 4 column tiles (gate tiles 2j, 2j+1 and the up tiles of the same columns) x the
+// two K halves, i.e. every wave still streams exactly the run of records it streamed before (one tile, one half of K, same order, same
+// accumulator), from the SAME packed weight (pack_weight(W, K/2)), and the grid is still I/64 = 172 workgroups.  The activation no longer
+// fits in LDS at once (32 x 4096 bf16 = 256 KiB): it is staged in two PHASES of 2 x (K/4) columns -- the first quarter of each K half,
+// then the second -- with one restaging between them whose global loads are issued a whole weight group ahead of the barrier.
+// Epilogue: the plane of K half 1 and the up planes go through LDS (reusing the activation arena) to the two gate waves of K half 0, which
+// apply F3's arithmetic -- (0 + p0 + p1), row scale, rounding to the activation dtype where nn.Linear / SiLU would round -- and write
+// the 16-bit activation of the down projection.  Same operations in the same order as G1 + F3: the result is BIT-IDENTICAL
+// (tests/test_gpu_glue.py::test_g1_gateup_silu_matches_g1_then_f3), so nothing downstream changes.
+// replaces, like G1 + F3: gate_proj / up_proj / act_fn / the product of ChameleonMLP.forward (reference modeling_chameleon.py:193-195).
+// SP = k-steps per phase per K half = K / 64 (K = 4096: 64).
+__device__ __forceinline__ float g1s_row_sumsq_total(const float *__restrict__ row_sumsq, int slices, int prows, int row)
+{
+    float t = 0.f;                                  // sjd_glue.hip row_sumsq_total: batches of eight, fixed order
+    for (int s0 = 0; s0 < slices; s0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (s0 + q < slices) ? row_sumsq[(size_t)(s0 + q) * prows + row] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += v[q];
+    }
+    return t;
+}
+
+template <int DT> struct G1Cvt;
+template <> struct G1Cvt<SJD_DTYPE_BF16> {
+    static __device__ __forceinline__ unsigned short from_f(float x) { unsigned u = __float_as_uint(x); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
+    static __device__ __forceinline__ float to_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+};
+template <> struct G1Cvt<SJD_DTYPE_F16> {
+    static __device__ __forceinline__ unsigned short from_f(float x) { _Float16 h = (_Float16)x; return *reinterpret_cast<unsigned short *>(&h); }
+    static __device__ __forceinline__ float to_f(unsigned short h) { return (float)(*reinterpret_cast<_Float16 *>(&h)); }
+};
+
+template <int DT, int SP>
+__global__ __launch_bounds__(512) void g1_gateup_silu(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
+                                                      unsigned short *__restrict__ y, int M, int I, int K, int rec_stride,
+                                                      const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden, float rs_eps)
+{
+    SJD_TR(0);
+    SJD_TR_HW();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *xl = reinterpret_cast<u32x4 *>(smem);                  // [2 K halves][SP records][64 slots] of 16 B
+    __shared__ float rsc[32];
+    constexpr int GP = SP / 8;                                    // weight groups per phase
+    constexpr int PPS = 2 * SP;                                   // 16-byte pieces per (row, K half) of a phase
+    constexpr int NPT = (32 * 2 * PPS) / 512;                     // pieces per thread and phase (K = 4096: 16)
+    static_assert(SP % 8 == 0 && NPT >= 1, "phase = whole weight groups, at least one piece per thread");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int kh = w >> 2, q = w & 3;                             // K half; 0, 1 = gate tiles, 2, 3 = the up tiles of the same columns
+    const int n_gate = I / 32, n_tiles = 2 * n_gate;
+    const int t_act = 2 * blockIdx.x + (q & 1);                   // 32-column tile of the activation
+    const int t = (q < 2 ? 0 : n_gate) + t_act;                   // tile of the packed gate|up weight
+    const int steps = 2 * SP;                                     // k-steps of a K half (= of a chunk of the packed weight)
+    const size_t chunk_base = (size_t)kh * n_tiles * steps;
+    const size_t tile_off = (rec_stride == 1) ? (size_t)t * steps : (size_t)t;
+    const u32x4 *wu = wp + (chunk_base + tile_off) * 64 + lane;
+    const size_t rs = (size_t)rec_stride * 64;
+    // the row scales r = rsqrt(mean(h^2) + eps) of the folded RMSNorm (F1r wrote the per-slice sums): off the critical path
+    if (threadIdx.x < 32) {
+        const float ss = row_sumsq ? g1s_row_sumsq_total(row_sumsq, rs_slices, 32, threadIdx.x) : 0.f;
+        rsc[threadIdx.x] = row_sumsq ? rsqrtf(__builtin_fmaf(ss, rs_inv_hidden, rs_eps)) : 1.0f;
+    }
+    // piece v of a phase: row m = v / (2 PPS), K half hh = (v / PPS) & 1, piece j of that (row, half): 8 columns from
+    // hh * K/2 + ph * K/4 + 8 j -> record hh * SP + j / 2, slot g1_slot(j & 1, m, j / 2)
+    auto x_load = [&](int ph, int i) -> u32x4 {
+        const int v = i * 512 + threadIdx.x;
+        const int m = v / (2 * PPS), hh = (v / PPS) & 1, j = v % PPS;
+        return (m < M) ? *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + hh * (K / 2) + ph * (K / 4) + 8 * j) : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto x_store = [&](int i, u32x4 val) {
+        const int v = i * 512 + threadIdx.x;
+        const int m = v / (2 * PPS), hh = (v / PPS) & 1, j = v % PPS;
+        xl[(hh * SP + (j >> 1)) * 64 + g1_slot(j & 1, m, j >> 1)] = val;
+    };
+    u32x4 cur[G1_UNROLL], nxt[G1_UNROLL], val[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) val[i] = x_load(0, i);
+#pragma unroll
+    for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);      // first weight group right behind
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) x_store(i, val[i]);
+    SJD_TR(1);
+    __syncthreads();
+    SJD_TR(2);
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): nothing pending when the loop is entered (see g1_skinny_gemm)
+    SJD_TR(3);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const u32x4 *xa = xl + (size_t)kh * SP * 64;
+    auto mfma_group = [&](int g) {
+#pragma unroll
+        for (int u = 0; u < G1_UNROLL; ++u)
+            acc = G1Mfma<DT>::mma(xa[(g * G1_UNROLL + u) * 64 + g1_slot(lane >> 5, lane & 31, u)], cur[u], acc);
+    };
+    auto load_group = [&](int gi) {               // group gi of the K half (0 .. 2 GP - 1)
+#pragma unroll
+        for (int u = 0; u < G1_UNROLL; ++u) nxt[u] = __builtin_nontemporal_load(wu + (size_t)(gi * G1_UNROLL + u) * rs);
+    };
+    auto adopt = [&]() {
+#pragma unroll
+        for (int u = 0; u < G1_UNROLL; ++u) cur[u] = nxt[u];
+    };
+    // ---- phase 0, all but its last group
+    for (int g = 0; g + 1 < GP; ++g) {
+        load_group(g + 1);
+        mfma_group(g);
+        adopt();
+    }
+    // ---- last group of phase 0 (straight-line: the waits are exact): first weight group of phase 1 and the activation of phase 1 are
+    // requested, in this order, before its MFMAs; then every wave is done with the staged columns and they are replaced
+    load_group(GP);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) val[i] = x_load(1, i);
+    mfma_group(GP - 1);
+    adopt();
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) x_store(i, val[i]);
+    __syncthreads();
+    SJD_TR(4);                    // (trace: restaged)
+    // ---- phase 1
+    for (int g = 0; g < GP; ++g) {
+        const bool more = g + 1 < GP;
+        if (more) load_group(GP + g + 1);
+        mfma_group(g);
+        if (more) adopt();
+    }
+    SJD_TR(5);                    // main loop done
+    // ---- epilogue: six waves hand their plane to the gate wave of K half 0 that owns the same activation tile
+    __syncthreads();                                              // the activation arena is free
+    float *red = reinterpret_cast<float *>(smem);                 // [6][16][64]
+    const bool owner = (kh == 0 && q < 2);
+    if (!owner) {
+        const int slot = (kh == 1) ? q : 4 + (q - 2);              // 0,1: gate half 1; 2,3: up half 1; 4,5: up half 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(slot * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (owner) {
+        const int col = 32 * t_act + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float gsum = 0.f, usum = 0.f;                          // F3: planes summed in chunk order, starting from zero
+            gsum += acc[r];
+            gsum += red[((q) * 16 + r) * 64 + lane];
+            usum += red[((4 + q) * 16 + r) * 64 + lane];
+            usum += red[((2 + q) * 16 + r) * 64 + lane];
+            const float rr = rsc[m];
+            const float gv = G1Cvt<DT>::to_f(G1Cvt<DT>::from_f(gsum * rr));
+            const float uv = G1Cvt<DT>::to_f(G1Cvt<DT>::from_f(usum * rr));
+            const float sv = G1Cvt<DT>::to_f(G1Cvt<DT>::from_f(gv / (1.0f + __expf(-gv))));      // silu rounds to the activation dtype
+            if (m < M) y[(size_t)m * I + col] = G1Cvt<DT>::from_f(sv * uv);
+        }
+    }
+    SJD_TR(6);
+}
+
+template <int DT>
+static int g1s_launch(const void *x, const void *w_packed, void *y, int M, int I, int K, int step_major, const sjd_row_norm *rn, hipStream_t s)
+{
+    const int SP = K / 64;
+    const dim3 grid(I / 64), block(512);
+    const size_t lds_x = (size_t)2 * SP * 1024, lds_red = (size_t)6 * 16 * 64 * sizeof(float);
+    const size_t lds = lds_x > lds_red ? lds_x : lds_red;        // the epilogue's six planes reuse the activation arena
+    const int rec_stride = step_major ? 2 * (I / 32) : 1;
+    const float *ss = rn ? rn->sumsq : nullptr;
+    const int sl = rn ? rn->slices : 0;
+    const float ih = rn ? 1.0f / (float)rn->hidden : 0.f, eps = rn ? rn->eps : 0.f;
+#define SJD_G1S_CASE(SP_) \
+    if (SP == SP_) { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_gateup_silu<DT, SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((g1_gateup_silu<DT, SP_>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, (unsigned short *)y, \
+                           M, I, K, rec_stride, ss, sl, ih, eps); \
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH; \
+    }
+    SJD_G1S_CASE(8) SJD_G1S_CASE(16) SJD_G1S_CASE(32) SJD_G1S_CASE(64)
+#undef SJD_G1S_CASE
+    return SJD_ERR_UNSUPPORTED;
+}
+
+// y [M, I] = silu(r * (x Wg^T)) * (r * (x Wu^T)) with F3's rounding points; w_packed = pack_weight([Wg; Wu] ([2 I, K]), KC = K / 2, step_major).
+// M <= 32 rows, K in {512, 1024, 2048, 4096}, I % 64 == 0.  SJD_ERR_UNSUPPORTED otherwise: the caller keeps G1 + F3.
+extern "C" int sjd_gateup_silu(const void *x, const void *w_packed, void *y, int M, int I, int K, int step_major, int dtype,
+                               const sjd_row_norm *row_norm, void *stream)
+{
+    if (!x || !w_packed || !y || M < 1 || I < 64 || K < 512) return SJD_ERR_BAD_ARG;
+    if (row_norm && (!row_norm->sumsq || row_norm->slices < 1 || row_norm->hidden < 1)) return SJD_ERR_BAD_ARG;
+    if (M > 32 || (I % 64) != 0 || !(K == 512 || K == 1024 || K == 2048 || K == 4096)) return SJD_ERR_UNSUPPORTED;
+    if (dtype == SJD_DTYPE_BF16) return g1s_launch<SJD_DTYPE_BF16>(x, w_packed, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
+    if (dtype == SJD_DTYPE_F16) return g1s_launch<SJD_DTYPE_F16>(x, w_packed, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
+    return SJD_ERR_UNSUPPORTED;
+}
+
 extern "C" int sjd_gemm_num_chunks(int K, int KC) { return (K + KC - 1) / KC; }
 
 // out: fp32 [n_chunks, 32, N] partial products; the consumer sums the chunks.

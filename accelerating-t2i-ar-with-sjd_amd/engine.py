@@ -211,7 +211,7 @@ class SJDEngine:
         key = tuple(map(id, rules))
         if key in self._cols_cache:
             return self._cols_cache[key]
-        cols = self._logit_columns(rules)
+        cols = SJDEngine._logit_columns(self, rules)
         if len(self._cols_cache) < 4096:
             self._cols_cache[key] = cols
             self._rule_keep.append(list(rules))

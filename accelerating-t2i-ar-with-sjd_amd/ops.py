@@ -388,6 +388,22 @@ def silu_mul(gate_up, rows=None, dtype=None, row_norm=None):
     return y
 
 
+def gateup_silu_ok(T, inter, hidden, KC):
+    """shapes kernel G1s serves (see sjd_gateup_silu): a <= 32-row window, the gate|up weight packed in two K halves"""
+    return T <= 32 and hidden in (512, 1024, 2048, 4096) and 2 * KC == hidden and inter % 64 == 0
+
+
+def gateup_silu(x, w_packed, inter, hidden, step_major=False, row_norm=None):
+    """G1s: silu(r * gate(x)) * (r * up(x)) [T, inter] in ONE launch -- the gate|up projection (w_packed = pack_weight([Wg; Wu], hidden / 2,
+    step_major)) with F3 as its epilogue; bit-identical to silu_mul(skinny_gemm(x, w_packed, 2 * inter, hidden, hidden / 2), row_norm=...)."""
+    T = x.shape[0]
+    assert x.is_contiguous() and x.shape[1] == hidden and w_packed.numel() == 2 * inter * hidden
+    y = torch.empty(T, inter, dtype=x.dtype, device=x.device)
+    L.check(L.load().sjd_gateup_silu(_ptr(x), _ptr(w_packed), _ptr(y), T, inter, hidden, int(step_major), _dtype_code(x.dtype),
+                                    _row_norm(row_norm), _stream()), "sjd_gateup_silu")
+    return y
+
+
 def residual_sumsq(h, part=None):
     """F1r: h [T, hidden] += dtype(sum of the G1 partials) in place (part None: h unchanged); returns the per-512-column-slice sums
     of h^2 [slices, R] fp32 -- the `sumsq` of a row_norm."""

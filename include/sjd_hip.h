@@ -228,6 +228,16 @@ int sjd_qknorm_rope_append_ex(const void *qkv, void *q_out, void *k_cache, void 
 int sjd_silu_mul_ex(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks,
                     const sjd_row_norm *row_norm, void *stream);
 
+/* G1s -- the gate|up projection of the window with F3 as its epilogue, ONE launch: y [M, I] = silu(r (x Wg^T)) * (r (x Wu^T)), r = the
+ * row scale of the folded RMSNorm (row_norm; NULL = 1), rounded to `dtype` where nn.Linear and the activation would round.
+ * replaces gate_proj / up_proj / act_fn / the product of ChameleonMLP.forward (reference modeling_chameleon.py:193-195) for a window of
+ * M <= 32 rows.  w_packed = the [2 I, K] weight [Wg; Wu] packed by sjd_amd.ops.pack_weight with KC = K / 2 (the copy sjd_skinny_gemm
+ * streams).  The K split of G1 moves inside the workgroup (8 waves = 4 column tiles x 2 K halves, activation staged in two phases), so
+ * the result is bit-identical to sjd_skinny_gemm(KC = K / 2) followed by sjd_silu_mul_ex on its two partial planes.
+ * K in {512, 1024, 2048, 4096}, I % 64 == 0; SJD_ERR_UNSUPPORTED otherwise (the caller keeps G1 + F3). */
+int sjd_gateup_silu(const void *x, const void *w_packed, void *y, int M, int I, int K, int step_major, int dtype,
+                    const sjd_row_norm *row_norm, void *stream);
+
 /* G1 -- weight-streaming projection of the draft window: out[c, m, n] = sum_{k in chunk c} x[m, k] * W[n, k], M <= 128 rows
  * (one to four 32-row MFMA tiles: up to four prompts' draft windows per forward), fp32 split-K partials [n_chunks, R, N] with R = M rounded up to
  * a multiple of 32 and n_chunks = ceil(K / KC); the consumer (F1/F2/F3 `part` argument) sums them.

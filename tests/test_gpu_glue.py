@@ -204,6 +204,42 @@ def test_g1_forward_matches_library_gemm_forward(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("step_major", [False, True])
+@pytest.mark.parametrize("M,I,K", [(32, 11008, 4096), (17, 11008, 4096), (32, 14336, 4096), (32, 1408, 512), (5, 128, 1024), (32, 2752, 2048)])
+@pytest.mark.parametrize("with_norm", [True, False])
+def test_g1_gateup_silu_matches_g1_then_f3(dev, dtype, step_major, M, I, K, with_norm):
+    """G1s (the gate|up projection with SiLU * up as its epilogue, one launch) is BIT-IDENTICAL to G1 (two K halves) followed by F3 on the
+    two partial planes -- same MFMA sequence per (tile, K half), same summation order and rounding points -- from the same packed weight."""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(I + K + M)
+    x = torch.randn(M, K, generator=g).to(dtype).to(dev)
+    w = (torch.randn(2 * I, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    wp = ops.pack_weight(w, K // 2, step_major)
+    assert ops.gateup_silu_ok(M, I, K, K // 2)
+    rn = (ops.residual_sumsq(x.clone(), None), K, 1e-5) if with_norm else None
+    ref = ops.silu_mul(ops.skinny_gemm(x, wp, 2 * I, K, K // 2, waves=8, step_major=step_major), rows=M, dtype=dtype, row_norm=rn)
+    got = ops.gateup_silu(x, wp, I, K, step_major, row_norm=rn)
+    torch.cuda.synchronize()
+    assert got.shape == (M, I) and torch.equal(got.view(torch.int16), ref.view(torch.int16)), (got.float() - ref.float()).abs().max()
+    # and it is the MLP's first half: silu(x Wg^T) * (x Wu^T) against fp32 math on the same operands
+    if not with_norm:
+        gf, uf = x.float() @ w[:I].float().t(), x.float() @ w[I:].float().t()
+        want = torch.nn.functional.silu(gf) * uf
+        d = (got.float() - want).abs()
+        assert d.mean() < 6e-3 and d.max() < 0.2, (d.mean(), d.max())
+
+
+def test_g1_gateup_silu_refuses_what_it_does_not_serve(dev):
+    import sjd_amd.ops as ops
+    import sjd_amd._lib as L
+    assert not ops.gateup_silu_ok(33, 11008, 4096, 2048) and not ops.gateup_silu_ok(32, 11008, 4096, 1024) and not ops.gateup_silu_ok(32, 100, 4096, 2048)
+    x = torch.zeros(40, 4096, dtype=torch.bfloat16, device=dev)
+    wp = torch.zeros(2 * 128 * 4096, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(L.SjdLibraryError):
+        ops.gateup_silu(x, wp, 128, 4096)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [32, 17, 64, 96, 128])
 @pytest.mark.parametrize("N,K,KC", [(4096, 4096, 256), (512, 1376, 256), (1536, 2752, 1024)])
 def test_f1r_residual_sumsq_and_row_norm_consumers(dev, dtype, M, N, K, KC):

@@ -119,6 +119,7 @@ def test_k2_column_window_of_the_output_head(dev, name, V, n, builder, cols):
 
     class _E:            # the host-side choice of that window
         V, narrow_head = None, True
+        _cols_cache, _rule_keep = {}, []
     from sjd_amd.engine import SJDEngine
     e = _E()
     e.V = V

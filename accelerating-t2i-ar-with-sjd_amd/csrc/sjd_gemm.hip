@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "../../include/sjd_hip.h"
+#include "sjd_mlp_epilogue.cuh"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -398,29 +399,6 @@ extern "C" int sjd_weight_prefetch(const void *w, int64_t nbytes, int blocks, vo
 // (tests/test_gpu_glue.py::test_g1_gateup_silu_matches_g1_then_f3), so nothing downstream changes.
 // replaces, like G1 + F3: gate_proj / up_proj / act_fn / the product of ChameleonMLP.forward (reference modeling_chameleon.py:193-195).
 // SP = k-steps per phase per K half = K / 64 (K = 4096: 64).
-__device__ __forceinline__ float g1s_row_sumsq_total(const float *__restrict__ row_sumsq, int slices, int prows, int row)
-{
-    float t = 0.f;                                  // sjd_glue.hip row_sumsq_total: batches of eight, fixed order
-    for (int s0 = 0; s0 < slices; s0 += 8) {
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (s0 + q < slices) ? row_sumsq[(size_t)(s0 + q) * prows + row] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t += v[q];
-    }
-    return t;
-}
-
-template <int DT> struct G1Cvt;
-template <> struct G1Cvt<SJD_DTYPE_BF16> {
-    static __device__ __forceinline__ unsigned short from_f(float x) { unsigned u = __float_as_uint(x); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
-    static __device__ __forceinline__ float to_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-};
-template <> struct G1Cvt<SJD_DTYPE_F16> {
-    static __device__ __forceinline__ unsigned short from_f(float x) { _Float16 h = (_Float16)x; return *reinterpret_cast<unsigned short *>(&h); }
-    static __device__ __forceinline__ float to_f(unsigned short h) { return (float)(*reinterpret_cast<_Float16 *>(&h)); }
-};
-
 template <int DT, int SP>
 __global__ __launch_bounds__(512) void g1_gateup_silu(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                       unsigned short *__restrict__ y, int M, int I, int K, int rec_stride,
@@ -445,11 +423,6 @@ __global__ __launch_bounds__(512) void g1_gateup_silu(const unsigned short *__re
     const size_t tile_off = (rec_stride == 1) ? (size_t)t * steps : (size_t)t;
     const u32x4 *wu = wp + (chunk_base + tile_off) * 64 + lane;
     const size_t rs = (size_t)rec_stride * 64;
-    // the row scales r = rsqrt(mean(h^2) + eps) of the folded RMSNorm (F1r wrote the per-slice sums): off the critical path
-    if (threadIdx.x < 32) {
-        const float ss = row_sumsq ? g1s_row_sumsq_total(row_sumsq, rs_slices, 32, threadIdx.x) : 0.f;
-        rsc[threadIdx.x] = row_sumsq ? rsqrtf(__builtin_fmaf(ss, rs_inv_hidden, rs_eps)) : 1.0f;
-    }
     // piece v of a phase: row m = v / (2 PPS), K half hh = (v / PPS) & 1, piece j of that (row, half): 8 columns from
     // hh * K/2 + ph * K/4 + 8 j -> record hh * SP + j / 2, slot g1_slot(j & 1, m, j / 2)
     auto x_load = [&](int ph, int i) -> u32x4 {
@@ -465,6 +438,15 @@ __global__ __launch_bounds__(512) void g1_gateup_silu(const unsigned short *__re
     u32x4 cur[G1_UNROLL], nxt[G1_UNROLL], val[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) val[i] = x_load(0, i);
+    // the per-slice sums of h^2 behind the row scale r = rsqrt(mean(h^2) + eps) of the folded RMSNorm (F1r wrote them; K <= 4096: at most
+    // eight slices).  Every thread issues the eight loads -- unconditional, so the waits around them stay exact -- BEHIND the activation
+    // and ahead of the weights: they are cache hits and cost the staging nothing (first version: threads 0..31 did this first, +0.7 us).
+    float ssv[8];
+    {
+        const float *ssp = row_sumsq ? row_sumsq : reinterpret_cast<const float *>(x);
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) ssv[qq] = ssp[(size_t)(row_sumsq ? min(qq, rs_slices - 1) : 0) * 32 + (threadIdx.x & 31)];
+    }
 #pragma unroll
     for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);      // first weight group right behind
 #pragma unroll
@@ -472,6 +454,16 @@ __global__ __launch_bounds__(512) void g1_gateup_silu(const unsigned short *__re
     SJD_TR(1);
     __syncthreads();
     SJD_TR(2);
+    // the activation of phase 1 is requested NOW and travels under the whole of phase 0 (first version: requested one weight group ahead
+    // of the restaging barrier, which then took ~4 us with one weight group per wave in flight)
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) val[i] = x_load(1, i);
+    if (threadIdx.x < 32) {
+        float tsum = 0.f;                          // sjd_glue.hip row_sumsq_total: one batch of eight in slice order, missing slices add zero
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) tsum += (qq < rs_slices) ? ssv[qq] : 0.f;
+        rsc[threadIdx.x] = row_sumsq ? rsqrtf(__builtin_fmaf(tsum, rs_inv_hidden, rs_eps)) : 1.0f;
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): nothing pending when the loop is entered (see g1_skinny_gemm)
     SJD_TR(3);
     f32x16 acc;
@@ -497,11 +489,9 @@ __global__ __launch_bounds__(512) void g1_gateup_silu(const unsigned short *__re
         mfma_group(g);
         adopt();
     }
-    // ---- last group of phase 0 (straight-line: the waits are exact): first weight group of phase 1 and the activation of phase 1 are
-    // requested, in this order, before its MFMAs; then every wave is done with the staged columns and they are replaced
+    // ---- last group of phase 0: the first weight group of phase 1 is requested before its MFMAs and stays in flight through the
+    // restaging; then every wave is done with the staged columns and they are replaced (the new ones have been in registers for long)
     load_group(GP);
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) val[i] = x_load(1, i);
     mfma_group(GP - 1);
     adopt();
     __syncthreads();
@@ -517,31 +507,36 @@ __global__ __launch_bounds__(512) void g1_gateup_silu(const unsigned short *__re
         if (more) adopt();
     }
     SJD_TR(5);                    // main loop done
-    // ---- epilogue: six waves hand their plane to the gate wave of K half 0 that owns the same activation tile
+    // ---- epilogue: the eight planes (tile q x K half) go through LDS (row-major, rows padded to 36 floats: conflict-free both ways), then
+    // every thread finishes FOUR outputs: one (activation tile, row, four columns) each -- first version: the two gate waves of K half 0 did
+    // all sixteen IEEE divisions per lane and 2-byte stores, 3.6 us.
     __syncthreads();                                              // the activation arena is free
-    float *red = reinterpret_cast<float *>(smem);                 // [6][16][64]
-    const bool owner = (kh == 0 && q < 2);
-    if (!owner) {
-        const int slot = (kh == 1) ? q : 4 + (q - 2);              // 0,1: gate half 1; 2,3: up half 1; 4,5: up half 0
+    constexpr int RP = 36;
+    float *red = reinterpret_cast<float *>(smem);                 // [8 planes][32 rows][RP]
+    {
+        float *mine = red + (size_t)(kh * 4 + q) * 32 * RP + (lane & 31);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(slot * 16 + r) * 64 + lane] = acc[r];
+        for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * RP] = acc[r];
     }
     __syncthreads();
-    if (owner) {
-        const int col = 32 * t_act + (lane & 31);
+    {
+        const int a = threadIdx.x >> 8, m = (threadIdx.x >> 3) & 31, c4 = (threadIdx.x & 7) * 4;
+        auto plane = [&](int kh_, int q_) { return *reinterpret_cast<const float4 *>(red + ((size_t)(kh_ * 4 + q_) * 32 + m) * RP + c4); };
+        const float4 g0 = plane(0, a), g1 = plane(1, a), u0 = plane(0, 2 + a), u1 = plane(1, 2 + a);
+        const float gs[4] = {g0.x, g0.y, g0.z, g0.w}, gt[4] = {g1.x, g1.y, g1.z, g1.w};
+        const float us_[4] = {u0.x, u0.y, u0.z, u0.w}, ut[4] = {u1.x, u1.y, u1.z, u1.w};
+        const float rr = rsc[m];
+        unsigned short o16[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        for (int j = 0; j < 4; ++j) {
             float gsum = 0.f, usum = 0.f;                          // F3: planes summed in chunk order, starting from zero
-            gsum += acc[r];
-            gsum += red[((q) * 16 + r) * 64 + lane];
-            usum += red[((4 + q) * 16 + r) * 64 + lane];
-            usum += red[((2 + q) * 16 + r) * 64 + lane];
-            const float rr = rsc[m];
-            const float gv = G1Cvt<DT>::to_f(G1Cvt<DT>::from_f(gsum * rr));
-            const float uv = G1Cvt<DT>::to_f(G1Cvt<DT>::from_f(usum * rr));
-            const float sv = G1Cvt<DT>::to_f(G1Cvt<DT>::from_f(gv / (1.0f + __expf(-gv))));      // silu rounds to the activation dtype
-            if (m < M) y[(size_t)m * I + col] = G1Cvt<DT>::from_f(sv * uv);
+            gsum += gs[j]; gsum += gt[j];
+            usum += us_[j]; usum += ut[j];
+            o16[j] = sjd_silu_mul_elem<DT>(gsum, usum, rr);         // sjd_mlp_epilogue.cuh: the element arithmetic F3 uses, same bits
+        }
+        if (m < M) {
+            uint2 pk{(unsigned)o16[0] | ((unsigned)o16[1] << 16), (unsigned)o16[2] | ((unsigned)o16[3] << 16)};
+            *reinterpret_cast<uint2 *>(y + (size_t)m * I + 32 * (2 * blockIdx.x + a) + c4) = pk;
         }
     }
     SJD_TR(6);
@@ -552,7 +547,7 @@ static int g1s_launch(const void *x, const void *w_packed, void *y, int M, int I
 {
     const int SP = K / 64;
     const dim3 grid(I / 64), block(512);
-    const size_t lds_x = (size_t)2 * SP * 1024, lds_red = (size_t)6 * 16 * 64 * sizeof(float);
+    const size_t lds_x = (size_t)2 * SP * 1024, lds_red = (size_t)8 * 32 * 36 * sizeof(float);
     const size_t lds = lds_x > lds_red ? lds_x : lds_red;        // the epilogue's six planes reuse the activation arena
     const int rec_stride = step_major ? 2 * (I / 32) : 1;
     const float *ss = rn ? rn->sumsq : nullptr;
@@ -577,6 +572,7 @@ extern "C" int sjd_gateup_silu(const void *x, const void *w_packed, void *y, int
 {
     if (!x || !w_packed || !y || M < 1 || I < 64 || K < 512) return SJD_ERR_BAD_ARG;
     if (row_norm && (!row_norm->sumsq || row_norm->slices < 1 || row_norm->hidden < 1)) return SJD_ERR_BAD_ARG;
+    if (row_norm && row_norm->slices > 8) return SJD_ERR_UNSUPPORTED;      // the kernel sums one batch of eight 512-column slices
     if (M > 32 || (I % 64) != 0 || !(K == 512 || K == 1024 || K == 2048 || K == 4096)) return SJD_ERR_UNSUPPORTED;
     if (dtype == SJD_DTYPE_BF16) return g1s_launch<SJD_DTYPE_BF16>(x, w_packed, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
     if (dtype == SJD_DTYPE_F16) return g1s_launch<SJD_DTYPE_F16>(x, w_packed, y, M, I, K, step_major, row_norm, (hipStream_t)stream);

@@ -34,6 +34,8 @@ extern "C" int sjd_debug_trace_glue(int kind, unsigned long long *host_out, int 
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+#include "sjd_mlp_epilogue.cuh"
+
 template <int DT> struct Cvt;
 template <> struct Cvt<SJD_DTYPE_BF16> {
     static __device__ __forceinline__ float to_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
@@ -429,18 +431,22 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
             }
             const float r = row_sumsq ? rsqrtf(ss_tot * rs_inv_hidden + rs_eps) : 1.0f;
             if (g[0] + r != 12345.678f) SJD_TRG(2, 1);       // (partials + row statistics arrived)
+            unsigned short ob[8];                // element arithmetic shared with g1_gateup_silu (sjd_mlp_epilogue.cuh): same bits
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { g[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(g[j] * r)); u[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(u[j] * r)); }
+            for (int j = 0; j < 8; ++j) ob[j] = sjd_silu_mul_elem<DT>(g[j], u[j], r);
+            *reinterpret_cast<u32x4 *>(y + (size_t)row * I + c) = u32x4{(unsigned)ob[0] | ((unsigned)ob[1] << 16), (unsigned)ob[2] | ((unsigned)ob[3] << 16),
+                                                                      (unsigned)ob[4] | ((unsigned)ob[5] << 16), (unsigned)ob[6] | ((unsigned)ob[7] << 16)};
+            continue;
         } else {
             unpack8<DT>(*reinterpret_cast<const u32x4 *>(gu + (size_t)row * 2 * I + c), g);
             unpack8<DT>(*reinterpret_cast<const u32x4 *>(gu + (size_t)row * 2 * I + I + c), u);
         }
+        unsigned short ob[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float s = Cvt<DT>::to_f(Cvt<DT>::from_f(g[j] / (1.0f + __expf(-g[j]))));   // silu rounds to the activation dtype
-            o[j] = s * u[j];
-        }
-        *reinterpret_cast<u32x4 *>(y + (size_t)row * I + c) = pack8<DT>(o);
+        for (int j = 0; j < 8; ++j) ob[j] = sjd_silu_mul_elem_rounded<DT>(g[j], u[j]);     // silu rounds to the activation dtype
+        (void)o;
+        *reinterpret_cast<u32x4 *>(y + (size_t)row * I + c) = u32x4{(unsigned)ob[0] | ((unsigned)ob[1] << 16), (unsigned)ob[2] | ((unsigned)ob[3] << 16),
+                                                                  (unsigned)ob[4] | ((unsigned)ob[5] << 16), (unsigned)ob[6] | ((unsigned)ob[7] << 16)};
     }
     SJD_TRG(2, 2);
 }

@@ -155,6 +155,42 @@ def trace_g1(lib, torch, ops, np):
                               end_us=dict(mean=us((t[:, 6] - t0).mean()), max=us((t[:, 6] - t0).max())))), flush=True)
 
 
+def trace_g1s(lib, torch, ops, np):
+    """G1s: gate|up + SiLU * up in one launch (two staging phases)"""
+    dev = torch.device("cuda:0")
+    lib.sjd_debug_trace_g1.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    I, K = 11008, 4096
+    x = torch.randn(32, K, device=dev).to(torch.bfloat16)
+    wps = [ops.pack_weight((torch.randn(2 * I, K, device=dev) / K ** 0.5).to(torch.bfloat16), K // 2, True) for _ in range(6)]
+    rn = (ops.residual_sumsq(x.clone(), None), K, 1e-5)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        ops.gateup_silu(x, wps[0], I, K, True, row_norm=rn)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(12):
+            ops.gateup_silu(x, wps[i % 6], I, K, True, row_norm=rn)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    nwg = I // 64
+    buf = np.zeros((nwg, 8), dtype=np.uint64)
+    assert lib.sjd_debug_trace_g1(buf.ctypes.data, nwg) == 0
+    t = buf.astype(np.int64)
+    t0 = t[:, 0].min()
+    d = lambda a, b: us((t[:, b] - t[:, a]).mean())
+    print(json.dumps(dict(kernel="g1_gateup_silu<bf16, 64>", workgroups=nwg, us_per_launch_in_graph=round(e0.elapsed_time(e1) * 1000 / 60, 2),
+                          phase_us=dict(stage_phase0=d(0, 1), wait_for_waves=d(1, 2), first_weight_group=d(2, 3), phase0_and_restage=d(3, 4),
+                                        phase1=d(4, 5), epilogue=d(5, 6)),
+                          end_us=dict(mean=us((t[:, 6] - t0).mean()), max=us((t[:, 6] - t0).max())))), flush=True)
+
+
 def trace_g1_tiled(lib, torch, ops, np):
     """128 window rows (four prompts per forward): g1_skinny_gemm_tiled"""
     import sjd_amd._lib as L
@@ -262,9 +298,13 @@ def main():
         PER_WG = open(sys.argv[sys.argv.index("--per-wg") + 1], "w")
         trace_g1(lib, torch, ops, np)
         return
+    if "--g1s" in sys.argv:
+        trace_g1s(lib, torch, ops, np)
+        return
     trace_k1(lib, torch, ops, np)
     trace_k1_shared(lib, torch, ops, np)
     trace_g1(lib, torch, ops, np)
+    trace_g1s(lib, torch, ops, np)
     trace_g1_tiled(lib, torch, ops, np)
     trace_in_situ(lib, torch, ops, np)
 

@@ -206,10 +206,18 @@ def measure_g1(args, model, device, rounds=2):
     xs = {k: torch.randn(32, K, device=device).to(model.lm_head.weight.dtype) for k, (N, K) in shapes.items()}
     cfg = model.G1_CFG
 
+    import sjd_amd.backbones as BB
+    # the product runs gate|up as kernel G1s (the projection with SiLU * up as its epilogue) when the shape allows: measure what it runs
+    fused_mlp = getattr(model, "gateup_fused", BB._GATEUP_FUSED_DEFAULT) and ops.gateup_silu_ok(32, inter, hid, cfg["gate_up"][0])
+    rn = (ops.residual_sumsq(xs["gate_up"].clone(), None), hid, 1e-5)
+
     def one_pass():
         for li in range(len(model._packed)):
             for name, (N, K) in shapes.items():
-                ops.skinny_gemm(xs[name], model._packed[li][name], N, K, cfg[name][0], cfg[name][1], cfg[name][2])
+                if name == "gate_up" and fused_mlp:
+                    ops.gateup_silu(xs[name], model._packed[li][name], inter, hid, cfg[name][2], row_norm=rn)
+                else:
+                    ops.skinny_gemm(xs[name], model._packed[li][name], N, K, cfg[name][0], cfg[name][1], cfg[name][2])
 
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
@@ -230,7 +238,7 @@ def measure_g1(args, model, device, rounds=2):
     n = rounds * len(model._packed) * len(shapes)
     tot_ms = lib.sjd_event_elapsed_ms(e0, e1)
     tot_b = rounds * len(model._packed) * sum(N * K * 2 + 32 * K * 2 for N, K in shapes.values())
-    return dict(launches=n, avg_ms=tot_ms / n, avg_bytes=tot_b / n, gbps=tot_b / 1e9 / (tot_ms / 1e3))
+    return dict(launches=n, avg_ms=tot_ms / n, avg_bytes=tot_b / n, gbps=tot_b / 1e9 / (tot_ms / 1e3), fused_mlp=bool(fused_mlp))
 
 
 def cpu_baseline(args, gpu_sched_ms=None):
@@ -505,7 +513,9 @@ def main():
                     "avg_us": round(prof["avg_ms"] * 1e3, 2), "avg_bytes": int(prof["avg_bytes"]),
                     "avg_kv_rows": round(prof["avg_kv_rows"], 1), "launches": prof["launches"]}
     if prof_g1 is not None:       # the dominant kernel by time (~60 % of an iteration)
-        out["roofline"] = {"kernel": "g1_skinny_gemm (weight-streaming window projections, 128 launches / iteration)", "bound": "hbm",
+        g1_name = ("g1_skinny_gemm x3 + g1_gateup_silu (weight-streaming window projections, gate|up with SiLU*up as its epilogue; 128 launches / iteration)"
+                   if prof_g1.get("fused_mlp") else "g1_skinny_gemm (weight-streaming window projections, 128 launches / iteration)")
+        out["roofline"] = {"kernel": g1_name, "bound": "hbm",
                            "achieved": round(prof_g1["gbps"], 1), "peak": peak, "unit": "GB/s", "frac": round(prof_g1["gbps"] / peak, 4),
                            "traffic": traffic_of("g1_traffic.json"), "avg_us": round(prof_g1["avg_ms"] * 1e3, 2),
                            "avg_bytes": int(prof_g1["avg_bytes"]), "launches": prof_g1["launches"]}

@@ -24,6 +24,7 @@ same order and shapes), global CPU generator for the fresh ids.  The residual dr
 and the generator state is rewound when no rejection happened.
 """
 import ctypes
+import os
 import random
 import time
 from dataclasses import dataclass, field
@@ -35,6 +36,9 @@ import torch
 from . import _lib as L
 from . import ops
 from .grammar import spatial_fresh_tokens
+
+
+_SAMPLE_EAGER = os.environ.get("SJD_SAMPLE_EAGER", "0") == "1"      # experiment: K2 / K4 as two plain launches behind the forward graph
 
 
 @dataclass
@@ -254,7 +258,7 @@ class SJDEngine:
         captured the second time that combination runs on graph-owned logits."""
         torch.cuda.current_stream().wait_event(noise_ready)
         key = (cur, self._guidance, cols, self.hook is not None)
-        if not self.use_graph or ("fwd", cols) not in self._graphs:
+        if not self.use_graph or ("fwd", cols) not in self._graphs or _SAMPLE_EAGER:
             self._sample_body(cur, logits, cols)
             return
         if key not in self._graphs:

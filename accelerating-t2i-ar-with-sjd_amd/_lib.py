@@ -21,7 +21,7 @@ class RowRule(ctypes.Structure):
 
 class IterParams(ctypes.Structure):
     _fields_ = [("n_rows", ctypes.c_int32), ("kv_len", ctypes.c_int32), ("use_cfg", ctypes.c_int32),
-                ("scheme", ctypes.c_int32), ("n_fresh", ctypes.c_int32), ("batch_rows", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2),
+                ("scheme", ctypes.c_int32), ("n_fresh", ctypes.c_int32), ("batch_rows", ctypes.c_int32), ("iter_seq", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("fresh_tok", ctypes.c_int64 * MAX_WINDOW), ("rules", RowRule * MAX_WINDOW),
                 ("resid_rules", RowRule * MAX_WINDOW)]
 
@@ -52,7 +52,7 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_kv_append_fp8", "sjd_draft_window_attention_fp8", "sjd_qknorm_rope_append_fp8",
            "sjd_residual_sumsq", "sjd_qknorm_rope_append_ex", "sjd_silu_mul_ex", "sjd_weight_prefetch", "sjd_qkv_attention_fused", "sjd_skinny_gemm_cols",
            "sjd_logits_to_probs_sample_part", "sjd_logits_to_probs_sample_ex", "sjd_reguess_ex",
-           "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu"]
+           "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu", "sjd_host_wait_u64"]
 
 _lib = None
 
@@ -81,6 +81,7 @@ def load():
     lib.sjd_upload_async.argtypes = [vp, vp, i64, vp]
     lib.sjd_gateup_silu.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp]
     lib.sjd_stream_synchronize.argtypes = [vp]
+    lib.sjd_host_wait_u64.argtypes = [vp, ctypes.c_uint64, i64]
     lib.sjd_kv_append.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]
     lib.sjd_attention_workspace_bytes.restype = i64
     lib.sjd_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]

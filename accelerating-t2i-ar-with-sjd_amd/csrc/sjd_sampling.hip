@@ -258,7 +258,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
 // rocprofv3 kernel trace, round 2 (tools/step_gaps.py): the D2H copy that used to follow K4 started ~10 us after it (hand-over from
 // the compute queue to the SDMA engine) on top of the copy itself.  All threads of the block call this (barrier inside); the words
 // are read back with device-scope loads: every store of this block has reached L2 at the barrier, K2's came with the previous kernel.
-__device__ __forceinline__ void k4_mirror_state(const sjd_state *state, sjd_state *host_mirror)
+__device__ __forceinline__ void k4_mirror_state(const sjd_state *state, sjd_state *host_mirror, int iter_seq)
 {
     if (!host_mirror) return;
     __syncthreads();
@@ -270,6 +270,10 @@ __device__ __forceinline__ void k4_mirror_state(const sjd_state *state, sjd_stat
         reinterpret_cast<unsigned long long *>(host_mirror)[threadIdx.x] = v;
     }
     __threadfence_system();
+    __syncthreads();                      // every word is out and fenced: publish the sequence number the host polls (sjd_host_wait_u64)
+    if (threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(host_mirror) + WORDS, (unsigned long long)(unsigned)iter_seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // replaces SpeculativeSampler.__call__ / find_first_misaligned_token_inds (reference JL:247-333)
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
     const int n = params->n_rows;
     if (n <= 1) {   // prefill / single-token phase short-circuit (JL:344-350)
         if (threadIdx.x == 0) { state->m = 1; state->rejected = 0; state->n_prev = n; }
-        k4_mirror_state(state, host_mirror);
+        k4_mirror_state(state, host_mirror, params->iter_seq);
         return;
     }
     const int scheme = params->scheme;
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
         }
     }
     if (threadIdx.x == 0) { state->m = m; state->rejected = rejected ? (degenerate ? 2 : 1) : 0; state->n_prev = n; }
-    k4_mirror_state(state, host_mirror);
+    k4_mirror_state(state, host_mirror, params->iter_seq);
 }
 
 // ------------------------------------------------------------------------------------------------ K5

@@ -60,6 +60,7 @@ class DeviceBlob:
         self.dev = dev if dev is not None else torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         assert self.host.numel() == self.nbytes and self.dev.numel() == self.nbytes
         self.view = ctype.from_address(self.host.data_ptr())
+        self._mirror = None
 
     def upload(self):
         """pinned host -> device on the current stream (hipMemcpyAsync through the C-ABI: a torch copy_ costs the host 6-8 us per call)"""
@@ -69,15 +70,28 @@ class DeviceBlob:
         self.host.copy_(self.dev)
         return self.view
 
-    def wait_mirror(self):
-        """The kernel that ends the iteration wrote this blob into the pinned host copy itself (sjd_verify_accept_ex, host_mirror):
-        the read-back is a stream synchronize, no D2H copy is enqueued."""
-        L.check(L.load().sjd_stream_synchronize(_stream()), "sjd_stream_synchronize")
+    # ---- read-back without a copy: the kernel that ends the iteration (sjd_verify_accept_ex) writes this blob into a pinned HOST mirror
+    # itself and publishes params->iter_seq in the 8 bytes behind it
+    @property
+    def mirror_ptr(self):
+        if self._mirror is None:
+            self._mirror = torch.zeros(self.nbytes + 8, dtype=torch.uint8, pin_memory=True)
+        return ctypes.c_void_p(self._mirror.data_ptr())
+
+    def collect_mirror(self):
+        ctypes.memmove(self.host.data_ptr(), self._mirror.data_ptr(), self.nbytes)
         return self.view
 
-    @property
-    def host_ptr(self):
-        return ctypes.c_void_p(self.host.data_ptr())
+    def wait_mirror(self, seq=None, timeout_s=300.0):
+        """seq: the iter_seq the iteration's params carried -> the host spins on the mirror's sequence word (sjd_host_wait_u64: no HIP
+        call, the GIL is released) and has the result a microsecond after K4 wrote it; None -> a stream synchronize."""
+        assert self._mirror is not None, "no kernel was given this blob's mirror (verify_accept(..., mirror=True))"
+        if seq is None:
+            L.check(L.load().sjd_stream_synchronize(_stream()), "sjd_stream_synchronize")
+        else:
+            L.check(L.load().sjd_host_wait_u64(self._mirror.data_ptr() + self.nbytes, int(seq) & 0xFFFFFFFF, int(timeout_s * 1e6)),
+                    "sjd_host_wait_u64 (the iteration's last kernel did not report within the timeout)")
+        return self.collect_mirror()
 
     def field_ptr(self, name):
         return ctypes.c_void_p(self.dev.data_ptr() + getattr(self.ctype, name).offset)
@@ -104,8 +118,11 @@ class BlobArray:
         self.host.copy_(self.dev)
 
     def wait_mirror(self):
-        """every blob's last writer (sjd_verify_accept_ex with host_mirror) wrote its pinned host copy itself: one stream wait"""
+        """every blob's last writer (sjd_verify_accept_ex with host_mirror) wrote the blob's pinned host mirror itself: one stream wait"""
         L.check(L.load().sjd_stream_synchronize(_stream()), "sjd_stream_synchronize")
+        for b in self.blobs:
+            if b._mirror is not None:
+                b.collect_mirror()
 
     @property
     def ptr(self):
@@ -146,7 +163,7 @@ def verify_accept(params: DeviceBlob, state: DeviceBlob, probs, prev_probs, rs, 
     for t in (probs, prev_probs, rs, noise2, scratch):
         assert t.dtype == torch.float32 and t.is_contiguous()
     L.check(L.load().sjd_verify_accept_ex(params.ptr, state.ptr, _ptr(probs), _ptr(prev_probs), _ptr(rs), _ptr(noise2),
-                                         _ptr(scratch), max_rows, V, state.host_ptr if mirror else None, _stream()), "sjd_verify_accept")
+                                         _ptr(scratch), max_rows, V, state.mirror_ptr if mirror else None, _stream()), "sjd_verify_accept")
 
 
 def kv_append(k_new, v_new, k_cache, v_cache, params, kv_len):

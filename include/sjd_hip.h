@@ -56,7 +56,8 @@ typedef struct sjd_iter_params {
     int32_t batch_rows;             /* several prompts per launch: 0 = this blob governs every batch row; > 0 = `params` points at a
                                        contiguous ARRAY of blobs and blob i governs batch rows [i*batch_rows, (i+1)*batch_rows) of K1 /
                                        K3 / F2 (each prompt has its own kv_len / n_rows); same value in every blob of the array */
-    int32_t reserved[2];
+    int32_t iter_seq;                             /* host's iteration counter: sjd_verify_accept_ex publishes it behind the mirrored state */
+    int32_t reserved;
     int64_t fresh_tok[SJD_MAX_WINDOW];            /* random re-guess ids (host global RNG, JL:505-509), packed */
     sjd_row_rule rules[SJD_MAX_WINDOW];           /* rules of the sampling call, row j */
     sjd_row_rule resid_rules[SJD_MAX_WINDOW];     /* rule of the residual call if rejection happens at i=j+1 */
@@ -279,14 +280,19 @@ int sjd_draft_window_attention_fp8(const void *q, const void *k_cache, const voi
                                    int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
                                    const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream);
 
-/* K4 with the read-back folded in: when host_mirror != NULL (HOST memory the device can address: hipHostMalloc / a pinned torch tensor)
- * the kernel ends by copying *state into it, so the host's one sync per iteration (reference: the ~25-40 implicit syncs of
+/* K4 with the read-back folded in: when host_mirror != NULL (SJD_STATE_MIRROR_BYTES of HOST memory the device can address: hipHostMalloc /
+ * a pinned torch tensor) the kernel ends by copying *state into it and publishing params->iter_seq behind it, so the host's one sync per iteration (reference: the ~25-40 implicit syncs of
  * jacobi_iteration_lumina_mgpt.py:1107-1208) is sjd_stream_synchronize and no D2H copy is enqueued. */
 int sjd_verify_accept_ex(const sjd_iter_params *params, sjd_state *state, const float *probs, const float *prev_probs,
                          const float *rs, const float *noise2, float *scratch, int max_rows, int V, sjd_state *host_mirror, void *stream);
 /* the iteration's parameter blob: pinned host -> device, asynchronous on `stream`; and the wait that closes an iteration */
 int sjd_upload_async(void *dst_device, const void *src_pinned_host, int64_t bytes, void *stream);
 int sjd_stream_synchronize(void *stream);
+/* The mirror is sizeof(sjd_state) + 8 bytes: behind the state K4 stores (uint64) params->iter_seq, after a system-scope fence, as its very
+ * last action.  A host that polls that word (sjd_host_wait_u64: a spin in C, no HIP call, returns SJD_ERR_LAUNCH after timeout_us) sees
+ * the iteration's result a microsecond after the kernel wrote it instead of after the runtime's interrupt-driven stream wait. */
+#define SJD_STATE_MIRROR_BYTES (sizeof(sjd_state) + 8)
+int sjd_host_wait_u64(const volatile uint64_t *flag, uint64_t value, int64_t timeout_us);
 
 /* HIP event helpers so that a ctypes host can time kernels on the stream they run on. */
 void *sjd_event_create(void);

@@ -148,6 +148,7 @@ def run_k4(dev, win, Y, p, q_rows, rs, resid, e2, scheme=0, max_rows=16):
     params = ops.DeviceBlob(L.IterParams, dev)
     state = ops.DeviceBlob(L.State, dev)
     params.view.n_rows, params.view.scheme = n, scheme
+    params.view.iter_seq = 1000 + n + scheme
     for j, r in enumerate(resid):
         params.view.resid_rules[j] = to_dev_rule(L, ops, r)
     prev = torch.zeros(max_rows, V, device=dev)
@@ -169,7 +170,7 @@ def run_k4(dev, win, Y, p, q_rows, rs, resid, e2, scheme=0, max_rows=16):
     # byte for byte what a D2H copy of the device state gives
     state.host.fill_(0xA5)
     ops.verify_accept(params, state, probs, prev, rsd, torch.from_numpy(e2).to(dev), torch.empty(V, device=dev), mirror=True)
-    state.wait_mirror()
+    state.wait_mirror(seq=params.view.iter_seq)          # host spin on the sequence word K4 publishes behind the state (no HIP call)
     mirrored = bytes(state.host.numpy().tobytes())
     st = state.download()
     assert mirrored == state.host.numpy().tobytes(), "K4's host mirror differs from the device state"

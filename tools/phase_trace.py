@@ -24,7 +24,7 @@ def build():
     objs = []
     for f in ("sjd_attention", "sjd_gemm", "sjd_glue", "sjd_sampling"):
         o = os.path.join("/tmp", f + "_trace.o")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DSJD_TRACE", "-Wno-unused-value"]
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DSJD_TRACE", "-Wno-unused-value", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
                               + (["-ffp-contract=off"] if f == "sjd_sampling" else []) + ["-c", os.path.join(csrc, f + ".hip"), "-o", o])
         objs.append(o)
     rest = [os.path.join(csrc, f + ".o") for f in ("sjd_capi",)]

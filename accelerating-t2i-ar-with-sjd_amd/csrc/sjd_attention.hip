@@ -183,8 +183,8 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
     const int hkv = blockIdx.y, b = blockIdx.z;
     const int head = hkv * G + head_in_group;
 
-    const int kv_base = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
-    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;         // valid rows of this call
+    int kv_base = kv_len_arg, n_total = n_rows;         // valid rows of this call
+    if (params) sjdi_kv_rows(params, b, &kv_base, &n_total);
     const int row0 = chunk * K1_ROWS;
     const int n_c = min(K1_ROWS, n_total - row0);                 // may be <= 0 for padding chunks
     const int kv_len = kv_base + row0;                            // keys < kv_len are visible to every row of the chunk
@@ -385,8 +385,8 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_shared(
     const int head_in_group = w % G, chunk = w / G;           // wave = (q head of the group, 16-row chunk)
     const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
     const int head = hkv * G + head_in_group;
-    const int kv_base = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
-    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;
+    int kv_base = kv_len_arg, n_total = n_rows;
+    if (params) sjdi_kv_rows(params, b, &kv_base, &n_total);
     const int kstart = key_start ? key_start[b] : 0;
     const float scale = rsqrtf((float)D);
 
@@ -575,10 +575,10 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
 {
     SJD_TRC(0);
     const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;
+    int kv_base = kv_len_arg, n_total = n_rows;
+    if (params) sjdi_kv_rows(params, b, &kv_base, &n_total);
     int eff_split;
     {
-        const int kv_base = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
         const int n_c = min(K1_ROWS, n_total - chunk * K1_ROWS);
         const int total = kv_base + chunk * K1_ROWS + max(n_c, 0);
         int t_lo, t_hi, tps;
@@ -693,8 +693,8 @@ __global__ __launch_bounds__(64 * K1F_WAVES) void k1f_qkv_attention(
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int head = blockIdx.x, b = blockIdx.y;
-    const int kv_len = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
-    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;
+    int kv_len = kv_len_arg, n_total = n_rows;
+    if (params) sjdi_kv_rows(params, b, &kv_len, &n_total);
     const int n_c = min(min(K1_ROWS, n_rows), n_total);
     const int total = kv_len + max(n_c, 0);
     const int kstart = key_start ? key_start[b] : 0;
@@ -1006,8 +1006,8 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
     const int head = hkv * G + head_in_group;
     unsigned char *vl = arena + (size_t)w * K1_KT * VROW;
 
-    const int kv_base = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
-    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;
+    int kv_base = kv_len_arg, n_total = n_rows;
+    if (params) sjdi_kv_rows(params, b, &kv_base, &n_total);
     const int row0 = chunk * K1_ROWS;
     const int n_c = min(K1_ROWS, n_total - row0);
     const int kv_len = kv_base + row0;
@@ -1184,7 +1184,8 @@ __global__ void k3_kv_append_fp8(const u32x4 *__restrict__ k_new, const u32x4 *_
         const int h = (i / D8) % H_kv;
         const int r = (i / ((size_t)D8 * H_kv)) % n_rows;
         const int b = i / ((size_t)D8 * H_kv * n_rows);
-        const int kv_len = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
+        int kv_len = kv_len_arg, n_unused_ = 0;
+        if (params) sjdi_kv_rows(params, b, &kv_len, &n_unused_);
         if (kv_len + r >= S_max) continue;
         const size_t dst = (((size_t)b * H_kv + h) * S_max + (kv_len + r)) * D8 + d;
         const size_t src = head_major ? (((size_t)b * H_kv + h) * n_rows + r) * D8 + d : i;     // [B, H_kv, n, D] or [B, n, H_kv, D]
@@ -1209,8 +1210,8 @@ __global__ __launch_bounds__(64) void k1_f32(const float *__restrict__ q, const 
 {
     extern __shared__ float sc[];                     // scores of the visible keys
     const int row = blockIdx.x, head = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
-    const int kv_len = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
-    const int n_total = params ? sjdi_params_of(params, b)->n_rows : n_rows;
+    int kv_len = kv_len_arg, n_total = n_rows;
+    if (params) sjdi_kv_rows(params, b, &kv_len, &n_total);
     float *o = out + (((size_t)b * n_rows + row) * H + head) * D;
     if (row >= n_total) { for (int d = lane; d < D; d += 64) o[d] = 0.0f; return; }
     const int hkv = head / (H / H_kv);
@@ -1251,7 +1252,8 @@ __global__ void k3_kv_append(const u32x4 *__restrict__ k_new, const u32x4 *__res
         const int h = (i / D8) % H_kv;
         const int r = (i / ((size_t)D8 * H_kv)) % n_rows;
         const int b = i / ((size_t)D8 * H_kv * n_rows);
-        const int kv_len = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
+        int kv_len = kv_len_arg, n_unused_ = 0;
+        if (params) sjdi_kv_rows(params, b, &kv_len, &n_unused_);
         if (kv_len + r >= S_max) continue;
         const size_t dst = (((size_t)b * H_kv + h) * S_max + (kv_len + r)) * D8 + d;
         k_cache[dst] = k_new[i];

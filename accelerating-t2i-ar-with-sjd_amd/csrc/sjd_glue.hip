@@ -307,7 +307,8 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     if (gw >= B * n * heads) return;
     const int tok = gw / heads, hh = gw % heads;
     const int b = tok / n, i = tok % n;
-    const int kv_len = params ? sjdi_params_of(params, b)->kv_len : kv_len_arg;
+    int kv_len = kv_len_arg, n_unused_ = 0;
+    if (params) sjdi_kv_rows(params, b, &kv_len, &n_unused_);
     const unsigned short *src = qkv + (size_t)tok * heads * D + (size_t)hh * D;
     const bool is_q = hh < H, is_k = !is_q && hh < H + H_kv;
     const int hl = is_q ? hh : (is_k ? hh - H : hh - H - H_kv);

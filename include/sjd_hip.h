@@ -69,6 +69,16 @@ static inline __attribute__((device, always_inline)) const sjd_iter_params *sjdi
 {
     return (p && p->batch_rows > 0) ? p + b / p->batch_rows : p;
 }
+/* kv_len and n_rows of batch row b in ONE scalar round trip when the launch carries one blob (or b belongs to the first of an array): the
+ * three words are requested together instead of batch_rows first and the field behind it -- a kernel of the window forward opens with this
+ * load, and there are ~130 such kernels per iteration.  A second, dependent load only for the later blobs of an array. */
+static inline __attribute__((device, always_inline)) void sjdi_kv_rows(const sjd_iter_params *p, int b, int *kv_len, int *n_rows)
+{
+    const int br = p->batch_rows, kv0 = p->kv_len, n0 = p->n_rows;
+    const int blob = br > 0 ? b / br : 0;
+    if (blob == 0) { *kv_len = kv0; *n_rows = n0; }
+    else { *kv_len = p[blob].kv_len; *n_rows = p[blob].n_rows; }
+}
 #endif
 
 /* Device-resident decode state carried between iterations (written by sjd_verify_accept, read by sjd_reguess). */

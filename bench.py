@@ -30,6 +30,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# kernel arguments in device memory instead of host-coherent memory (the HIP runtime reads this when it is loaded, i.e. before torch is
+# imported): 3.507 against 3.522 ms/step on one box; a deployment sets it the same way (conventions)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 
 def parse(argv=None):

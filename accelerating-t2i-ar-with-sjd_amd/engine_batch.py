@@ -75,6 +75,7 @@ class SJDBatchEngine:
         self._guidance = 3.0
         self.rng_stream = torch.cuda.Stream(device=dev)
         self.hook = None                       # test hook: called per slot and iteration with that slot's device tensors
+        self._rule_bytes, self._rule_keep, self._cols_cache = {}, [], {}
         self.reset_graphs()
 
     def reset_graphs(self):
@@ -92,21 +93,41 @@ class SJDBatchEngine:
         self._graph_cache_ptr = cptr
 
     # ------------------------------------------------------------------------------------------------
-    @staticmethod
-    def _fill(slot, n, kv_len, use_cfg, scheme, fresh, rules, resid):
+    def _fill(self, slot, n, kv_len, use_cfg, scheme, fresh, rules, resid):
         p = slot.params.view
         p.n_rows, p.kv_len, p.use_cfg, p.scheme, p.n_fresh = n, kv_len, int(use_cfg), scheme, len(fresh)
-        for i, t in enumerate(fresh):
-            p.fresh_tok[i] = t
-        for j, r in enumerate(rules):
-            p.rules[j] = r
-        for j, r in enumerate(resid):
-            p.resid_rules[j] = r
+        if fresh:
+            p.fresh_tok[:len(fresh)] = fresh
+        self._write_rules(slot, L.IterParams.rules.offset, rules)
+        if resid:
+            self._write_rules(slot, L.IterParams.resid_rules.offset, resid)
+
+    def _write_rules(self, slot, offset, rules):
+        """a rule sequence goes into the slot's blob as ONE block copy, its packed bytes cached by the interned structs' identities
+        (SJDEngine._write_rules: with four slots the per-element ctypes writes were ~0.1 ms of host time per forward)"""
+        key = tuple(map(id, rules))
+        blk = self._rule_bytes.get(key)
+        if blk is None:
+            blk = b"".join(bytes(r) for r in rules)
+            if len(self._rule_bytes) < 4096:
+                self._rule_bytes[key] = blk
+                self._rule_keep.append(list(rules))
+        L.ctypes.memmove(slot.params.host.data_ptr() + offset, blk, len(blk))
 
     def _columns(self, rule_lists):
         """union of the slots' output-head column windows (SJDEngine.logit_columns), None = all columns"""
         if not self.narrow_head:
             return None
+        key = tuple(id(r) for rules in rule_lists for r in rules)
+        if key in self._cols_cache:
+            return self._cols_cache[key]
+        cols = self._columns_uncached(rule_lists)
+        if len(self._cols_cache) < 4096:
+            self._cols_cache[key] = cols
+            self._rule_keep.append([r for rules in rule_lists for r in rules])
+        return cols
+
+    def _columns_uncached(self, rule_lists):
         lo, hi = self.V, 0
         for rules in rule_lists:
             for r in rules:
@@ -343,8 +364,7 @@ class SJDBatchEngine:
                     n_rows, a, fresh = mt[0], mt[4], mt[5]
                     if not s.finished and scheme == 0 and n_rows > 1:
                         mt[2] = s.grammar.residual_rules([s.X[-1]] + s.carried[:a] + fresh)
-                        for j, r in enumerate(mt[2]):
-                            s.params.view.resid_rules[j] = r
+                        self._write_rules(s, off, mt[2])
                         s.params.dev[off:].copy_(s.params.host[off:], non_blocking=True)
                     self._draw_noise(s, n_rows, scheme)
                 noise_ready = self.rng_stream.record_event()

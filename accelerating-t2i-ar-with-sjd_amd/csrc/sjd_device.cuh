@@ -195,6 +195,10 @@ __device__ float block_kth_largest(const float *row, int lo, int V, int k, float
 // ---- top-p cut (order-independent restatement of TopPLogitsWarper3d, see oracle/sjd_oracle.c header) ---------------------
 // w[lo..hi): non-negative weights staged in global memory (e = exp(z - max) or the residual d); p_i = w_i / S.
 // Returns K* = the largest uint32 key with canonical_sum{ p_i : w_i > 0, key(w_i) <= K* } <= thr (32 canonical sums).
+// Ties at the cut: every entry whose weight EQUALS the threshold weight is removed or kept together (the set is a function of the values
+// only), whereas the reference's sorted cumulative sum (logit_processor_3dim.py:406-419) splits a run of equal values by sort order --
+// which torch.sort does not define for equal keys.  With fp32 softmax outputs a tie exactly at the cut is a measure-zero event; the oracle
+// restates THIS rule (oracle/sjd_oracle.c) and is pinned against the reference's golden vectors, none of which hits one.
 __device__ unsigned block_top_p_cut_key(const float *w, int lo, int hi, float S, float thr, SjdShared &sh)
 {
     unsigned K = 0;

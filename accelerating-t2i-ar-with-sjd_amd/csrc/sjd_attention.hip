@@ -50,6 +50,28 @@ __device__ unsigned long long g_k1c_trace[4096][4];
 #define K1_RPAD 4          // fp32 padding of a merge-buffer row: rows 16 banks apart instead of on the same bank
 #define K1_MIN_TILES_PER_SPLIT 4   // a key split is only opened when it gets at least one tile per wave
 
+// What an attention kernel of the window forward needs before it can compute a single address: kv_len / n_rows of its batch row (device
+// blob) and the row's first visible key.  ONE scalar round trip: the three loads are issued together, as instructions (sjdi_kv_rows in
+// the header explains why), at the top of the kernel next to the loads of the kernel arguments that did not fit the SGPR preload.
+// Before: arguments -> batch_rows -> kv_len -> key_start, each waiting for the one before (ISA, late round 2).
+__device__ __forceinline__ void k1_entry(const sjd_iter_params *params, const int *key_start, int b, int kv_len_arg, int n_rows_arg,
+                                         int &kv_base, int &n_total, int &kstart)
+{
+    if (!params) {
+        kv_base = kv_len_arg; n_total = n_rows_arg; kstart = key_start ? key_start[b] : 0;
+        return;
+    }
+    const int *ksp = key_start ? key_start + b : reinterpret_cast<const int *>(params);        // (always a readable address)
+    unsigned long long nk;
+    int br, ks;
+    __asm__ volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dword %1, %3, 0x14\n\ts_load_dword %2, %4, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(nk), "=&s"(br), "=&s"(ks) : "s"(params), "s"(ksp) : "memory");
+    kstart = key_start ? ks : 0;
+    const int blob = br > 0 ? b / br : 0;
+    if (blob == 0) { n_total = (int)(unsigned)(nk & 0xffffffffull); kv_base = (int)(unsigned)(nk >> 32); }
+    else { kv_base = params[blob].kv_len; n_total = params[blob].n_rows; }
+}
+
 // Key-tile range [t_lo, t_hi) of a (batch row, chunk) and the number of splits actually used for it.  The launch grid
 // is sized for n_split (static, hipGraph friendly); splits >= the effective count exit immediately and are skipped by
 // the combine kernel, so short contexts do not pay for empty partials.
@@ -156,9 +178,9 @@ __device__ __forceinline__ void k1_merge_publish(float (*red_o)[K1_ROWS][D + K1_
 template <int DT, int D, int NW>
 __global__ __launch_bounds__(64 * NW) void k1_partial(
     const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
-    float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max,
-    const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks,
-    unsigned short *__restrict__ out_direct)
+    const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,        // (among the first 16 dwords: preloaded into SGPRs)
+    float *__restrict__ ws_o, float *__restrict__ ws_ml, unsigned short *__restrict__ out_direct,   // (the pointer before the ints: no padding
+    int n_rows, int H, int H_kv, int S_max, int kv_len_arg, int n_split, int n_chunks)              //  dword in the scalar load of the rest)
 {
     typedef typename Frag<DT>::vec vec;
     constexpr int KS = D / 32;            // k-steps of the QK^T product
@@ -174,6 +196,8 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
     float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + NW * K1_ROWS * (D + K1_RPAD) * 4);
 
     SJD_TR(0);                    // entry
+    int kv_base, n_total, kstart;                                 // valid rows of this call, first visible key: one scalar round trip
+    k1_entry(params, key_start, blockIdx.z, kv_len_arg, n_rows, kv_base, n_total, kstart);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int G = H / H_kv;
@@ -183,13 +207,10 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
     const int hkv = blockIdx.y, b = blockIdx.z;
     const int head = hkv * G + head_in_group;
 
-    int kv_base = kv_len_arg, n_total = n_rows;         // valid rows of this call
-    if (params) sjdi_kv_rows(params, b, &kv_base, &n_total);
     const int row0 = chunk * K1_ROWS;
     const int n_c = min(K1_ROWS, n_total - row0);                 // may be <= 0 for padding chunks
     const int kv_len = kv_base + row0;                            // keys < kv_len are visible to every row of the chunk
     const int total = kv_len + max(n_c, 0);                       // keys >= total are not visible to any row
-    const int kstart = key_start ? key_start[b] : 0;
     const float scale = rsqrtf((float)D);
 
     // tile range of this workgroup / wave
@@ -370,8 +391,8 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
 template <int DT, int D, int NWV>          // NWV = waves per workgroup = (q head of the group, row chunk) pairs: 4 or 8
 __global__ __launch_bounds__(64 * NWV) void k1_partial_shared(
     const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
-    float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max,
-    const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks)
+    const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,        // (among the first 16 dwords: preloaded into SGPRs)
+    float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max, int kv_len_arg, int n_split, int n_chunks)
 {
     typedef typename Frag<DT>::vec vec;
     constexpr int KS = D / 32, DB = D / 16;
@@ -385,9 +406,8 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_shared(
     const int head_in_group = w % G, chunk = w / G;           // wave = (q head of the group, 16-row chunk)
     const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
     const int head = hkv * G + head_in_group;
-    int kv_base = kv_len_arg, n_total = n_rows;
-    if (params) sjdi_kv_rows(params, b, &kv_base, &n_total);
-    const int kstart = key_start ? key_start[b] : 0;
+    int kv_base, n_total, kstart;
+    k1_entry(params, key_start, b, kv_len_arg, n_rows, kv_base, n_total, kstart);
     const float scale = rsqrtf((float)D);
 
     // this wave's rows and tile range (identical to what k1_partial / k1_combine derive for its chunk)
@@ -575,14 +595,14 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
 {
     SJD_TRC(0);
     const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-    int kv_base = kv_len_arg, n_total = n_rows;
-    if (params) sjdi_kv_rows(params, b, &kv_base, &n_total);
+    int kv_base, n_total, kstart;
+    k1_entry(params, key_start, b, kv_len_arg, n_rows, kv_base, n_total, kstart);
     int eff_split;
     {
         const int n_c = min(K1_ROWS, n_total - chunk * K1_ROWS);
         const int total = kv_base + chunk * K1_ROWS + max(n_c, 0);
         int t_lo, t_hi, tps;
-        k1_tile_range(key_start ? key_start[b] : 0, total, n_split, t_lo, t_hi, eff_split, tps);
+        k1_tile_range(kstart, total, n_split, t_lo, t_hi, eff_split, tps);
     }
     constexpr int PER = K1_ROWS * D / 256;          // consecutive d per thread
     const int row = (threadIdx.x * PER) / D, d0 = (threadIdx.x * PER) % D;
@@ -982,9 +1002,9 @@ template <> __device__ __forceinline__ float k1_to_f32<SJD_DTYPE_F16>(unsigned s
 template <int DT, int D, int NW>
 __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
     const unsigned short *__restrict__ q, const unsigned char *__restrict__ kc, const unsigned char *__restrict__ vc,
-    float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max,
-    const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg, int n_split, int n_chunks,
-    float k_scale, float v_scale, unsigned short *__restrict__ out_direct)
+    const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,        // (among the first 16 dwords: preloaded into SGPRs)
+    float *__restrict__ ws_o, float *__restrict__ ws_ml, unsigned short *__restrict__ out_direct,
+    int n_rows, int H, int H_kv, int S_max, int kv_len_arg, int n_split, int n_chunks, float k_scale, float v_scale)
 {
     constexpr int KP = D / 64;            // 16-byte K pieces per key row and lane group = pairs of k-steps
     constexpr int DB = D / 16;            // 16-wide d blocks of the output
@@ -1006,13 +1026,12 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
     const int head = hkv * G + head_in_group;
     unsigned char *vl = arena + (size_t)w * K1_KT * VROW;
 
-    int kv_base = kv_len_arg, n_total = n_rows;
-    if (params) sjdi_kv_rows(params, b, &kv_base, &n_total);
+    int kv_base, n_total, kstart;
+    k1_entry(params, key_start, b, kv_len_arg, n_rows, kv_base, n_total, kstart);
     const int row0 = chunk * K1_ROWS;
     const int n_c = min(K1_ROWS, n_total - row0);
     const int kv_len = kv_base + row0;
     const int total = kv_len + max(n_c, 0);
-    const int kstart = key_start ? key_start[b] : 0;
     const float scale = rsqrtf((float)D) * k_scale;
 
     int t_lo, t_hi, eff_split, tps;
@@ -1308,21 +1327,21 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
         if constexpr (D == 128) {
             if (pairs == 8)
                 hipLaunchKernelGGL((k1_partial_shared<DT, D, 8>), dim3(n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
-                                   (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
+                                   (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,
                                    kv_len, n_split, n_chunks);
             else
                 hipLaunchKernelGGL((k1_partial_shared<DT, D, 4>), dim3(n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
-                                   (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
+                                   (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,
                                    kv_len, n_split, n_chunks);
         }
     } else if (k1_waves() == 8)
         hipLaunchKernelGGL((k1_partial<DT, D, 8>), dim3(n_chunks * n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
-                           (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
-                           kv_len, n_split, n_chunks, direct);
+                           (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, direct, n_rows, H, H_kv, S_max,
+                           kv_len, n_split, n_chunks);
     else
         hipLaunchKernelGGL((k1_partial<DT, D, 4>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
-                           (const unsigned short *)kc, (const unsigned short *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
-                           kv_len, n_split, n_chunks, direct);
+                           (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, direct, n_rows, H, H_kv, S_max,
+                           kv_len, n_split, n_chunks);
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
     if (direct) return SJD_OK;                          // one key split: k1_partial wrote the output itself
@@ -1397,12 +1416,12 @@ static int launch_attention_fp8(const void *q, const void *kc, const void *vc, v
     unsigned short *direct = (n_split == 1 && !no_direct) ? (unsigned short *)out : nullptr;      // one key split: no combine launch
     if (k1_waves() == 8)
         hipLaunchKernelGGL((k1_partial_fp8<DT, D, 8>), dim3(n_chunks * n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
-                           (const unsigned char *)kc, (const unsigned char *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
-                           kv_len, n_split, n_chunks, k_scale, v_scale, direct);
+                           (const unsigned char *)kc, (const unsigned char *)vc, params, key_start, ws_o, ws_ml, direct, n_rows, H, H_kv, S_max,
+                           kv_len, n_split, n_chunks, k_scale, v_scale);
     else
         hipLaunchKernelGGL((k1_partial_fp8<DT, D, 4>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
-                           (const unsigned char *)kc, (const unsigned char *)vc, ws_o, ws_ml, n_rows, H, H_kv, S_max, key_start, params,
-                           kv_len, n_split, n_chunks, k_scale, v_scale, direct);
+                           (const unsigned char *)kc, (const unsigned char *)vc, params, key_start, ws_o, ws_ml, direct, n_rows, H, H_kv, S_max,
+                           kv_len, n_split, n_chunks, k_scale, v_scale);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
     if (direct) return SJD_OK;
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,

@@ -70,8 +70,10 @@ template <> struct G1Mfma<SJD_DTYPE_F16> {
 template <int DT, int MT, int MAXT>
 __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                 float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
-                                                                int rec_stride, int tile0)
+                                                                int rec_stride, int tile0, int n_waves)
 {
+    // n_waves = blockDim.x / 64 as an ARGUMENT: blockDim lives in the implicit kernel arguments, which are not preloaded into SGPRs -- the
+    // kernel opened with an s_load round trip for it in front of every address it computes (ISA, late round 2)
     SJD_TR(0);                    // entry
     SJD_TR_HW();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__r
     const int k0 = chunk * KC;
     const int steps = min(KC, K - k0) / 16;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int waves = blockDim.x >> 6;
+    const int waves = n_waves;
     const int t_out = blockIdx.x * waves + w;          // tile of this launch's output
     const int t = tile0 + t_out;                       // tile of the packed weight
     const bool has_tile = t_out < N / 32;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__r
     // retire in order, so the (cached) activation is not held up by the HBM round trip of the weights, and the weight loads
     // travel while the activation is written to LDS.
     const int ppr = 2 * steps;                                    // pieces per row of the chunk
-    const int n_pieces = MT * 32 * ppr, nth = blockDim.x;
+    const int nth = n_waves * 64;
     constexpr int STAGE = MAXT <= 512 ? 2 * G1_STAGE : G1_STAGE;
     // piece v = (row m, 16-byte piece j of the row); a thread's pieces are nth apart: (m, j) advance without a division per piece
     const int dm = nth / ppr, dj = nth - dm * ppr;
@@ -235,7 +237,7 @@ __device__ __forceinline__ void g1_group(const u32x4 *__restrict__ xb, int sl0, 
 template <int DT, int MT>
 __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                      float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
-                                                                     int rec_stride, int tile0)
+                                                                     int rec_stride, int tile0, int n_waves)
 {
     SJD_TR(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
     const int k0 = chunk * KC;
     const int steps = min(KC, K - k0) / 16;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int waves = blockDim.x >> 6;
+    const int waves = n_waves;
     const int t_out = blockIdx.x * waves + w;
     const bool has_tile = t_out < N / 32;                        // a wave without a tile multiplies tile 0 and stores nothing
     const int t = tile0 + (has_tile ? t_out : 0);
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
     const size_t tile_off = (rec_stride == 1) ? (size_t)t * steps : (size_t)t;
     const u32x4 *wu = wp + (chunk_base + tile_off) * 64 + lane;
     const size_t rs = (size_t)rec_stride * 64;
-    const int nth = blockDim.x;
+    const int nth = n_waves * 64;
     constexpr int BUF = MT * G1_SUB * 64;                         // u32x4 per LDS buffer
     constexpr int PPR = 2 * G1_SUB;                               // 16-byte pieces per row of a sub-tile
     constexpr int NP = MT * 32 * PPR;                             // pieces per sub-tile
@@ -596,7 +598,7 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
         const size_t lds_t = (size_t)2 * MT * G1_SUB * 1024;
         (void)hipFuncSetAttribute((const void *)g1_skinny_gemm_tiled<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
         hipLaunchKernelGGL((g1_skinny_gemm_tiled<DT, MT>), grid, block, lds_t, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC,
-                           n_tiles, step_major ? n_tiles : 1, tile0);
+                           n_tiles, step_major ? n_tiles : 1, tile0, waves);
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
     }
     if constexpr (MT <= 2) {
@@ -605,11 +607,11 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
         if (waves <= 8) {
             if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, MT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((g1_skinny_gemm<DT, MT, 512>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC,
-                               n_tiles, step_major ? n_tiles : 1, tile0);
+                               n_tiles, step_major ? n_tiles : 1, tile0, waves);
         } else {
             if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<DT, MT, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((g1_skinny_gemm<DT, MT, 1024>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC,
-                               n_tiles, step_major ? n_tiles : 1, tile0);
+                               n_tiles, step_major ? n_tiles : 1, tile0, waves);
         }
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
     }

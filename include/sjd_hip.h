@@ -74,7 +74,14 @@ static inline __attribute__((device, always_inline)) const sjd_iter_params *sjdi
  * load, and there are ~130 such kernels per iteration.  A second, dependent load only for the later blobs of an array. */
 static inline __attribute__((device, always_inline)) void sjdi_kv_rows(const sjd_iter_params *p, int b, int *kv_len, int *n_rows)
 {
-    const int br = p->batch_rows, kv0 = p->kv_len, n0 = p->n_rows;
+    /* {n_rows, kv_len} and batch_rows of the first blob, requested TOGETHER.  Written as instructions because the optimiser otherwise
+     * re-creates the dependent form (it folds the two cases into one load from `p + blob`, behind the load of batch_rows): three scalar
+     * round trips in a row opened k1_partial before this (kernel arguments, batch_rows, kv_len). */
+    unsigned long long nk;
+    int br;
+    __asm__ volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x14\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(nk), "=&s"(br) : "s"(p) : "memory");
+    const int n0 = (int)(unsigned)(nk & 0xffffffffull), kv0 = (int)(unsigned)(nk >> 32);
     const int blob = br > 0 ? b / br : 0;
     if (blob == 0) { *kv_len = kv0; *n_rows = n0; }
     else { *kv_len = p[blob].kv_len; *n_rows = p[blob].n_rows; }

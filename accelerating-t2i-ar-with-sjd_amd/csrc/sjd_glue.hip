@@ -302,16 +302,82 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     constexpr int HALF = D / 2;
     constexpr int PPL = HALF / 64 > 0 ? HALF / 64 : 1;       // pairs per lane (D=128: 1, D=64: lanes 32..63 idle)
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);      // global wave id
+    // the wave index as a SCALAR: everything derived from it (token, head, batch row) is uniform, so kv_len and the position come through
+    // the scalar cache instead of as 64-lane vector loads the partial loads would queue behind
+    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // global wave id
     const int heads = H + 2 * H_kv;
     if (gw >= B * n * heads) return;
     const int tok = gw / heads, hh = gw % heads;
     const int b = tok / n, i = tok % n;
-    int kv_len = kv_len_arg, n_unused_ = 0;
-    if (params) sjdi_kv_rows(params, b, &kv_len, &n_unused_);
     const unsigned short *src = qkv + (size_t)tok * heads * D + (size_t)hh * D;
     const bool is_q = hh < H, is_k = !is_q && hh < H + H_kv;
     const int hl = is_q ? hh : (is_k ? hh - H : hh - H - H_kv);
+    const float q8 = is_k ? k_inv : v_inv;
+    const bool active = lane < HALF;
+    float x0 = 0.f, x1 = 0.f;
+    int kv_len = kv_len_arg;
+    if (part) {                                               // fp32 split-K partials of the qkv projection (G1)
+        // Entry sequence written for the memory system (ISA, late round 2: the kernel used to run through five dependent round trips --
+        // two batches of kernel arguments, batch_rows, kv_len as a vector load with a full wait, the row statistics -- before the partial
+        // loads went out).  Now: the row statistics and the first eight partial planes are requested back to back with unconditional
+        // (clamped) loads, THEN kv_len is fetched (one scalar round trip, under the vector one), then the sums in the usual order.
+        const size_t ncol = (size_t)heads * D, col = (size_t)hh * D + (active ? lane : 0);
+        float ssv[8], v0[8], v1[8];
+        const float *ssp = row_sumsq ? row_sumsq : part;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ssv[q] = ssp[(size_t)(row_sumsq ? min(q, rs_slices - 1) : 0) * prows + tok];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float *pp = part + ((size_t)min(q, n_chunks - 1) * prows + tok) * ncol + col;
+            v0[q] = pp[0];
+            v1[q] = pp[HALF];
+        }
+        int n_unused_ = 0;
+        if (params) sjdi_kv_rows(params, b, &kv_len, &n_unused_);
+        float ss_tot = 0.f;                                   // row_sumsq_total: batches of eight slices in order, missing slices add zero
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ss_tot += (q < rs_slices) ? ssv[q] : 0.f;
+        for (int s0 = 8; s0 < rs_slices; s0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (s0 + q < rs_slices) ? row_sumsq[(size_t)(s0 + q) * prows + tok] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ss_tot += v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < n_chunks) { x0 += v0[q]; x1 += v1[q]; }
+        for (int c0 = 8; c0 < n_chunks; c0 += 8) {            // (more than eight planes: the old batched loop)
+            float w0[8], w1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (c0 + q < n_chunks) {
+                    const float *pp = part + ((size_t)(c0 + q) * prows + tok) * ncol + col;
+                    w0[q] = pp[0];
+                    w1[q] = pp[HALF];
+                }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (c0 + q < n_chunks) { x0 += w0[q]; x1 += w1[q]; }
+        }
+        if (row_sumsq) {                                      // the RMSNorm of the projection's input, applied on its output
+            const float r = rsqrtf(ss_tot * rs_inv_hidden + rs_eps);
+            x0 *= r;
+            x1 *= r;
+        }
+        x0 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0));
+        x1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x1));
+        if (!active) { x0 = 0.f; x1 = 0.f; }
+        if (x0 != 12345.678f) SJD_TRG(1, 1);                  // (partials + row statistics arrived)
+    } else {
+        if (params) kv_len = sjdi_params_of(params, b)->kv_len;
+        if (active) {
+            x0 = Cvt<DT>::to_f(src[lane]);
+            x1 = Cvt<DT>::to_f(src[lane + HALF]);
+        }
+    }
+    // Where the row goes.  This used to sit -- with its early return for rows beyond the cache -- in front of the partial loads above,
+    // which therefore could not be issued before kv_len had arrived.
     unsigned short *dst = nullptr;
     unsigned char *dst8 = nullptr;                            // KV8: byte rows of the fp8 cache
     if (is_q) dst = q_out + ((size_t)tok * H + hl) * D;
@@ -321,39 +387,6 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
         const size_t off = (((size_t)b * H_kv + hl) * S_max + r) * D;
         if (KV8) dst8 = reinterpret_cast<unsigned char *>(is_k ? k_cache : v_cache) + off;
         else dst = (is_k ? k_cache : v_cache) + off;
-    }
-    const float q8 = is_k ? k_inv : v_inv;
-    const bool active = lane < HALF;
-    float x0 = 0.f, x1 = 0.f;
-    const float ss_tot = row_sumsq ? row_sumsq_total(row_sumsq, rs_slices, prows, tok) : 0.f;   // issued ahead of the partial loads
-    if (active) {
-        if (part) {                                           // fp32 split-K partials of the qkv projection (G1)
-            const size_t ncol = (size_t)heads * D, col = (size_t)hh * D + lane;
-            for (int c0 = 0; c0 < n_chunks; c0 += 8) {        // the loads of eight chunks in flight (cold data: the producer
-                float v0[8], v1[8];                            // kernel has just finished), then the sum in chunk order
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (c0 + q < n_chunks) {
-                        const float *pp = part + ((size_t)(c0 + q) * prows + tok) * ncol + col;
-                        v0[q] = pp[0];
-                        v1[q] = pp[HALF];
-                    }
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (c0 + q < n_chunks) { x0 += v0[q]; x1 += v1[q]; }
-            }
-            if (row_sumsq) {                                  // the RMSNorm of the projection's input, applied on its output
-                const float r = rsqrtf(ss_tot * rs_inv_hidden + rs_eps);
-                x0 *= r;
-                x1 *= r;
-            }
-            x0 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0));
-            x1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x1));
-            if (x0 != 12345.678f) SJD_TRG(1, 1);              // (partials + row statistics arrived)
-        } else {
-            x0 = Cvt<DT>::to_f(src[lane]);
-            x1 = Cvt<DT>::to_f(src[lane + HALF]);
-        }
     }
     if (!is_q && !is_k) {                                     // V: plain copy into the cache
         if (active) {

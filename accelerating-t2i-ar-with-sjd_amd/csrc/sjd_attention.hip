@@ -595,6 +595,25 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
 {
     SJD_TRC(0);
     const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    constexpr int PER = K1_ROWS * D / 256;          // consecutive d per thread
+    const int row = (threadIdx.x * PER) / D, d0 = (threadIdx.x * PER) % D;
+    const int grow = chunk * K1_ROWS + row;
+    const size_t base = (((size_t)b * H + head) * n_chunks + chunk) * n_split;
+    // sixteen splits' (m, l, O) in flight at a time (the partials were written by the kernel that has just finished: cold -- every batch is
+    // a full round trip; with batches of four, Emu3's 16 splits took four of them, 7.6 us), merged online in split order.
+    // The first batch is requested for ALL n_split slots BEFORE the effective split count is known (it needs kv_len from the device blob:
+    // a scalar round trip that used to sit in front of these loads); slots beyond the effective count hold stale partials and are not merged.
+    constexpr int CB = 16;
+    float ms[CB], ls[CB], os[CB][PER];
+#pragma unroll
+    for (int q = 0; q < CB; ++q)
+        if (q < n_split) {
+            const size_t slot = (base + q) * K1_ROWS + row;
+            ms[q] = ws_ml[slot * 2];
+            ls[q] = ws_ml[slot * 2 + 1];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) os[q][j] = ws_o[slot * D + d0 + j];
+        }
     int kv_base, n_total, kstart;
     k1_entry(params, key_start, b, kv_len_arg, n_rows, kv_base, n_total, kstart);
     int eff_split;
@@ -604,9 +623,6 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
         int t_lo, t_hi, tps;
         k1_tile_range(kstart, total, n_split, t_lo, t_hi, eff_split, tps);
     }
-    constexpr int PER = K1_ROWS * D / 256;          // consecutive d per thread
-    const int row = (threadIdx.x * PER) / D, d0 = (threadIdx.x * PER) % D;
-    const int grow = chunk * K1_ROWS + row;
     if (grow >= n_rows) return;
     if (grow >= n_total) {        // padding rows of a shape-static window: defined (zero) output, never garbage
         unsigned short *oz = out + (((size_t)b * n_rows + grow) * H + head) * D + d0;
@@ -614,24 +630,21 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
         for (int j = 0; j < PER; ++j) oz[j] = 0;
         return;
     }
-    const size_t base = (((size_t)b * H + head) * n_chunks + chunk) * n_split;
-    // sixteen splits' (m, l, O) in flight at a time (the partials were written by the kernel that has just finished: cold -- every batch is
-    // a full round trip; with batches of four, Emu3's 16 splits took four of them, 7.6 us), merged online in split order
-    constexpr int CB = 16;
     float M = -INFINITY, L = 0.f, acc[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) acc[j] = 0.f;
     for (int s0 = 0; s0 < eff_split; s0 += CB) {
-        float ms[CB], ls[CB], os[CB][PER];
+        if (s0 > 0) {                               // (more than sixteen splits: further batches, now that the count is known)
 #pragma unroll
-        for (int q = 0; q < CB; ++q)
-            if (s0 + q < eff_split) {
-                const size_t slot = (base + s0 + q) * K1_ROWS + row;
-                ms[q] = ws_ml[slot * 2];
-                ls[q] = ws_ml[slot * 2 + 1];
+            for (int q = 0; q < CB; ++q)
+                if (s0 + q < eff_split) {
+                    const size_t slot = (base + s0 + q) * K1_ROWS + row;
+                    ms[q] = ws_ml[slot * 2];
+                    ls[q] = ws_ml[slot * 2 + 1];
 #pragma unroll
-                for (int j = 0; j < PER; ++j) os[q][j] = ws_o[slot * D + d0 + j];
-            }
+                    for (int j = 0; j < PER; ++j) os[q][j] = ws_o[slot * D + d0 + j];
+                }
+        }
 #pragma unroll
         for (int q = 0; q < CB; ++q)
             if (s0 + q < eff_split) {

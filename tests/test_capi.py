@@ -47,6 +47,26 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.sjd_attention_workspace_bytes(2, 32, 16, 128, 8) == 2 * 32 * 1 * 8 * 16 * 130 * 4
 
 
+def test_host_wait_on_the_mirror_sequence_word():
+    """sjd_host_wait_u64 is plain host code (the spin on the word K4 publishes behind the mirrored state): it returns at once when the word
+    already matches, when another thread stores the value, and reports a timeout otherwise; bad arguments are rejected."""
+    import threading
+    import time
+    L = _ensure_built()
+    lib = L.load()
+    word = ctypes.c_uint64(41)
+    addr = ctypes.addressof(word)
+    assert lib.sjd_host_wait_u64(addr, 41, 1000) == 0
+    t0 = time.perf_counter()
+    assert lib.sjd_host_wait_u64(addr, 42, 20000) == -3          # SJD_ERR_LAUNCH after ~20 ms
+    assert 0.015 < time.perf_counter() - t0 < 2.0
+    threading.Timer(0.05, lambda: setattr(word, "value", 42)).start()
+    assert lib.sjd_host_wait_u64(addr, 42, 5_000_000) == 0       # ctypes released the GIL: the timer thread could run
+    assert lib.sjd_host_wait_u64(None, 1, 10) == -1
+    assert lib.sjd_gateup_silu(None, None, None, 32, 11008, 4096, 0, 0, None, None) == -1
+    assert lib.sjd_upload_async(None, None, 16, None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import sjd_amd._lib as L
     monkeypatch.setattr(L, "_lib", None)

@@ -62,10 +62,14 @@ __device__ __forceinline__ void k1_entry(const sjd_iter_params *params, const in
         return;
     }
     const int *ksp = key_start ? key_start + b : reinterpret_cast<const int *>(params);        // (always a readable address)
+    // both addresses are wave-uniform (kernel arguments and blockIdx); readfirstlane states it, so that the "s" operands below never
+    // depend on what the uniformity analysis makes of the surrounding code (the -DSJD_TRACE build had the pointer in VGPRs)
+    const unsigned long long pa = sjdi_uniform_u64(reinterpret_cast<unsigned long long>(params));
+    const unsigned long long ka = sjdi_uniform_u64(reinterpret_cast<unsigned long long>(ksp));
     unsigned long long nk;
     int br, ks;
     __asm__ volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dword %1, %3, 0x14\n\ts_load_dword %2, %4, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(nk), "=&s"(br), "=&s"(ks) : "s"(params), "s"(ksp) : "memory");
+                     : "=&s"(nk), "=&s"(br), "=&s"(ks) : "s"(pa), "s"(ka) : "memory");
     kstart = key_start ? ks : 0;
     const int blob = br > 0 ? b / br : 0;
     if (blob == 0) { n_total = (int)(unsigned)(nk & 0xffffffffull); kv_base = (int)(unsigned)(nk >> 32); }

@@ -72,6 +72,12 @@ static inline __attribute__((device, always_inline)) const sjd_iter_params *sjdi
 /* kv_len and n_rows of batch row b in ONE scalar round trip when the launch carries one blob (or b belongs to the first of an array): the
  * three words are requested together instead of batch_rows first and the field behind it -- a kernel of the window forward opens with this
  * load, and there are ~130 such kernels per iteration.  A second, dependent load only for the later blobs of an array. */
+static inline __attribute__((device, always_inline)) unsigned long long sjdi_uniform_u64(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffull));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 static inline __attribute__((device, always_inline)) void sjdi_kv_rows(const sjd_iter_params *p, int b, int *kv_len, int *n_rows)
 {
     /* {n_rows, kv_len} and batch_rows of the first blob, requested TOGETHER.  Written as instructions because the optimiser otherwise
@@ -80,7 +86,7 @@ static inline __attribute__((device, always_inline)) void sjdi_kv_rows(const sjd
     unsigned long long nk;
     int br;
     __asm__ volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x14\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(nk), "=&s"(br) : "s"(p) : "memory");
+                     : "=&s"(nk), "=&s"(br) : "s"(sjdi_uniform_u64((unsigned long long)p)) : "memory");
     const int n0 = (int)(unsigned)(nk & 0xffffffffull), kv0 = (int)(unsigned)(nk >> 32);
     const int blob = br > 0 ? b / br : 0;
     if (blob == 0) { *kv_len = kv0; *n_rows = n0; }

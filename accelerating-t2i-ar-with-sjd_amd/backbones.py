@@ -202,6 +202,7 @@ class LlamaGenBackbone(nn.Module):
         p = self.tok_embeddings.weight
         self.cache = StaticKVCache(self.n_layers, batch, self.n_kv_heads, s_max, self.head_dim, dtype or p.dtype,
                                    device or p.device)
+        self.buffers_version = getattr(self, "buffers_version", 0) + 1
         self.freqs = self.freqs.to(p.device)
         return self.cache
 
@@ -339,6 +340,7 @@ class ChameleonBackbone(nn.Module):
         p = self.lm_head.weight
         self.cache = StaticKVCache(self.n_layers, batch, self.n_kv_heads, s_max, self.head_dim, dtype or p.dtype,
                                    device or p.device)
+        self.buffers_version = getattr(self, "buffers_version", 0) + 1      # captured hipGraphs hold the old cache's addresses
         return self.cache
 
     def _rope(self, positions, dtype):   # modeling_chameleon.py:97-110: fp32 angles, cast to activation dtype
@@ -446,6 +448,7 @@ class ChameleonBackbone(nn.Module):
                 self._packed_head = ops.pack_weight(wf, self.HEAD_CFG[0], self.HEAD_CFG[2])
                 del wf
         self._inv_freq32 = self.inv_freq.float().contiguous()
+        self.buffers_version = getattr(self, "buffers_version", 0) + 1          # ... and the packed weights' (engine._check_graph_buffers)
         return self
 
     HEAD_CFG = (1024, 4, True)         # G1 launch shape of the output head: (split-K chunk, column tiles per workgroup, step-major)

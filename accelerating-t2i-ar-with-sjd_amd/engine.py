@@ -27,6 +27,7 @@ import ctypes
 import os
 import random
 import time
+import warnings
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -54,7 +55,13 @@ class SJDConfig:
     seed: Optional[int] = 42
     do_cfg: bool = True
     prefix_token_sampler_scheme: str = "speculative_jacobi"
-    multi_token_init_scheme: str = "random"
+    multi_token_init_scheme: str = "random"   # 'repeat_horizon' / 'sample_horizon': PARITY UNPINNED -- the reference raises IndexError at
+    #                                           JL:577 for both, so no reference run exists; implemented from the evident intent
+    #                                           (spatial init).  Differences a fixed upstream might show: 'sample_horizon' draws its
+    #                                           top-1 re-sample with torch.multinomial(generator=g) (JL:495), advancing the device generator --
+    #                                           here the mode is a K2 by-product and nothing is drawn; the reference clamps the left-neighbour
+    #                                           index to the last KNOWN token (JL:574) -- here drafts chain through the fresh ones.  Grammars
+    #                                           without grid() (LlamaGen, the 3d-processor Anole path) fall back to 'random' with a warning.
     img_vocab_lo: int = 4
     img_vocab_n: int = 8192
     max_length: int = 1 << 30
@@ -80,6 +87,7 @@ class DecodeStats:
     seconds: float = 0.0
     wall_seconds: float = 0.0
     timed_nfe: int = 0
+    timed_region_reached: bool = True   # False: bench mode, but the decode ended before the timed region opened (stats cover the whole decode)
     kv_len: int = 0                # KV length at the end of the timed region (whole decode when none)
     kv_len_start: int = 0          # ... at its start
     total_tokens: int = 0          # whole decode (lead-in + warm-up + timed + continuation)
@@ -98,6 +106,14 @@ def set_seed(seed):
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
+
+
+def warn_no_grid(cfg, grammar):
+    """a spatial init scheme on a grammar that has no image geometry (LlamaGen, the 3d-processor Anole path) degrades to 'random'"""
+    from .grammar import _Grammar
+    if cfg.multi_token_init_scheme != "random" and type(grammar).grid is _Grammar.grid:
+        warnings.warn(f"multi_token_init_scheme={cfg.multi_token_init_scheme!r}: {type(grammar).__name__} has no image grid (img_width); "
+                      "the fresh drafts stay uniformly random", stacklevel=3)
 
 
 class SJDEngine:
@@ -138,22 +154,28 @@ class SJDEngine:
     def reset_graphs(self):
         """Call after the backbone's cache / weights were re-allocated."""
         self._graphs, self._graph_logits, self._eager_runs = {}, {}, {}
-        self._graph_ws_version = getattr(getattr(self.backbone, "attn", None), "ws_version", 0)
+        self.__dict__.pop("_graph_sig", None)
 
     def _check_graph_buffers(self):
-        """The captured graphs hold raw addresses of the K1 workspace and of the KV cache: if either was re-allocated since the
-        capture (HipWindowAttention.ws_version, the cache tensor's data_ptr) the graphs are dropped and captured again instead of
-        replaying into freed memory."""
+        """The captured graphs hold raw addresses of the K1 workspace, of the KV cache (K and V) and of the packed weights: if any was
+        re-allocated since the capture (HipWindowAttention.ws_version; the backbone's buffers_version, bumped by setup_cache /
+        enable_fused; the cache tensors' data_ptr as a belt for backbones without the counter) the graphs are dropped and captured again
+        instead of replaying into freed memory.  The G1 launch shapes are baked into the packed weights, so changing G1_CFG means
+        calling enable_fused again -- which bumps the counter."""
         attn = getattr(self.backbone, "attn", None)
-        ver = getattr(attn, "ws_version", 0)
         cache = getattr(self.backbone, "cache", None)
-        cptr = cache.k.data_ptr() if cache is not None else 0
-        if ver != self._graph_ws_version or cptr != getattr(self, "_graph_cache_ptr", cptr):
+        sig = (getattr(attn, "ws_version", 0), getattr(self.backbone, "buffers_version", 0),
+               cache.k.data_ptr() if cache is not None else 0, cache.v.data_ptr() if cache is not None else 0)
+        if sig != getattr(self, "_graph_sig", sig):
             self.reset_graphs()
-        self._graph_cache_ptr = cptr
+        self._graph_sig = sig
 
     # ------------------------------------------------------------------------------------------------
-    def _fill_params(self, n, kv_len, use_cfg, scheme, fresh, rules, resid):
+    def _fill_params(self, n, kv_len, use_cfg, scheme, fresh, rules, resid, head_only=False):
+        """head_only: upload everything in FRONT of resid_rules only.  The residual rules of a window iteration go up on the noise
+        stream while the forward runs (_fill_resid); the two copies then write disjoint byte ranges of the device blob and read
+        disjoint ranges of the pinned one, so no ordering between the two streams is needed (a whole-blob upload here
+        raced the partial one)."""
         p = self.params.view
         p.n_rows, p.kv_len, p.use_cfg, p.scheme, p.n_fresh = n, kv_len, int(use_cfg), scheme, len(fresh)
         self._seq = (self._seq % 0x7FFFFFF0) + 1          # K4 publishes it behind the mirrored state: what the host's spin waits for
@@ -163,7 +185,7 @@ class SJDEngine:
         self._write_rules(L.IterParams.rules.offset, rules)
         if resid:
             self._write_rules(L.IterParams.resid_rules.offset, resid)
-        self.params.upload()
+        self.params.upload(L.IterParams.resid_rules.offset if head_only else None)
 
     def _write_rules(self, offset, rules):
         """rules (interned sjd_row_rule structs, ops.make_rule) -> the blob, as ONE block copy: the packed bytes of a rule sequence are
@@ -300,6 +322,7 @@ class SJDEngine:
             raise ValueError(f"prefix_token_sampler_scheme: {cfg.prefix_token_sampler_scheme}")   # JL:1048
         if cfg.max_num_new_tokens > self.Lmax:
             raise ValueError("max_num_new_tokens exceeds the engine's max_window")
+        warn_no_grid(cfg, grammar)
         dev, B = self.device, self.B
         scheme = 0 if cfg.prefix_token_sampler_scheme == "speculative_jacobi" else 1
         do_cfg = cfg.do_cfg and (cfg.guidance_scale != 1)                          # JL:1005
@@ -359,7 +382,7 @@ class SJDEngine:
                 rules = grammar.window_rules(n_rows)
                 resid = []                     # computed below, while the forward runs (K4 is their only reader)
             use_cfg = do_cfg and not grammar.force_no_cfg()                          # JL:1086-1096
-            self._fill_params(n_rows, kv_len, use_cfg, scheme, fresh, rules, resid)
+            self._fill_params(n_rows, kv_len, use_cfg, scheme, fresh, rules, resid, head_only=not first)
             if first:
                 self.rng_stream.wait_stream(torch.cuda.current_stream())             # earlier work on this stream is done with the noise buffers
             # (later iterations: the host has just waited for K4, the last reader of the noise, so the side stream may start at once)
@@ -466,8 +489,11 @@ class SJDEngine:
                 if not continue_after:
                     break
         if not timed_done:          # plain decode, or EOS inside the timed region: the region is what ran since its start
-            self._close_timed(stats, ev0, ev1, t0, on_timed_end, len(X) - (timed_tok0 if timing else P),
-                              stats.nfe - (timed_nfe0 if timing else 0), kv_len)
+            # a bench-mode decode that ended (EOS / max_length) before its timed region OPENED never called on_timed_start: do not call
+            # its partner either (both are barriers in bench.py -- an unmatched one hangs the other ranks), and say so in the stats
+            stats.timed_region_reached = timing or timed_iters is None
+            self._close_timed(stats, ev0, ev1, t0, on_timed_end if timing else None,
+                              len(X) - (timed_tok0 if timing else P), stats.nfe - (timed_nfe0 if timing else 0), kv_len)
         torch.cuda.synchronize()
         stats.total_tokens, stats.total_seconds = len(X) - P, time.perf_counter() - t_decode0
         return X, stats

@@ -81,16 +81,12 @@ class SJDBatchEngine:
     def reset_graphs(self):
         """Call after the backbone's cache / weights were re-allocated."""
         self._graphs, self._graph_logits, self._eager_runs = {}, {}, {}
-        self._graph_ws_version = getattr(getattr(self.backbone, "attn", None), "ws_version", 0)
+        self.__dict__.pop("_graph_sig", None)
 
     def _check_graph_buffers(self):
         """see SJDEngine._check_graph_buffers: never replay a graph that holds the address of a re-allocated workspace / cache"""
-        ver = getattr(getattr(self.backbone, "attn", None), "ws_version", 0)
-        cache = getattr(self.backbone, "cache", None)
-        cptr = cache.k.data_ptr() if cache is not None else 0
-        if ver != self._graph_ws_version or cptr != getattr(self, "_graph_cache_ptr", cptr):
-            self.reset_graphs()
-        self._graph_cache_ptr = cptr
+        from .engine import SJDEngine
+        SJDEngine._check_graph_buffers(self)
 
     # ------------------------------------------------------------------------------------------------
     def _fill(self, slot, n, kv_len, use_cfg, scheme, fresh, rules, resid):

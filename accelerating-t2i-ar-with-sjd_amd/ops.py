@@ -62,9 +62,11 @@ class DeviceBlob:
         self.view = ctype.from_address(self.host.data_ptr())
         self._mirror = None
 
-    def upload(self):
-        """pinned host -> device on the current stream (hipMemcpyAsync through the C-ABI: a torch copy_ costs the host 6-8 us per call)"""
-        L.check(L.load().sjd_upload_async(self.dev.data_ptr(), self.host.data_ptr(), self.nbytes, _stream()), "sjd_upload_async")
+    def upload(self, nbytes=None):
+        """pinned host -> device on the current stream (hipMemcpyAsync through the C-ABI: a torch copy_ costs the host 6-8 us per call);
+        nbytes: only the leading bytes of the blob (the rest is uploaded by someone else, see SJDEngine._fill_resid)"""
+        L.check(L.load().sjd_upload_async(self.dev.data_ptr(), self.host.data_ptr(), self.nbytes if nbytes is None else int(nbytes), _stream()),
+                "sjd_upload_async")
 
     def download(self):
         self.host.copy_(self.dev)

@@ -217,7 +217,10 @@ def hf_generate(model, inputs=None, generation_config=None, logits_processor=Non
         gc.max_length = P + int(gc.max_new_tokens)
     limit = getattr(getattr(model, "args", None), "max_position_embeddings", None)
     if limit is not None and (gc.max_length is None or gc.max_length > limit):
-        gc.max_length = int(limit)               # HF only warns beyond the context; rows past it could never be positioned
+        import warnings
+        warnings.warn(f"generate(): max_length {gc.max_length} exceeds the model's max_position_embeddings {limit}; the generation is cut "
+                      f"at {limit} tokens (HF warns and goes on; rows past the context could never be positioned here)", stacklevel=2)
+        gc.max_length = int(limit)
     procs = LogitsProcessorList(list(logits_processor or []))
     if getattr(gc, "top_k", None):               # HF appends the warpers after the user's processors
         procs.append(TopKLogitsWarper(int(gc.top_k)))

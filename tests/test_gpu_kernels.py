@@ -308,6 +308,29 @@ def test_k1_k3_attention(dev, case, n_split):
     assert err[vis].max() < 3e-2, f"max err {err[vis].max()}"
     assert err[vis].mean() < 3e-3, f"mean err {err[vis].mean()}"
     assert (got[~vis] == 0).all()
+    # The kernel's rounding points restated (the fp8 test does the same for its P): scores and the softmax sum are
+    # fp32, each probability is rounded ONCE to the 16-bit MFMA operand type before P.V (relative error <= u = 2^-9 bf16 / 2^-11 fp16,
+    # whatever running maximum it was taken against), the output is rounded once more.  So element by element
+    #     |out - exact| <= u * (sum_j p_j |v_jd|  +  |exact_d|)            (+ fp16: N * 2^-25 max|v| for subnormal probabilities)
+    # with exact = fp64 attention over the same 16-bit operands -- about two output ulps; a wrong tile edge, mask bit or split merge
+    # is orders of magnitude above it, where the 3e-2 above would hide it.
+    u = 2.0 ** -9 if dtype == torch.bfloat16 else 2.0 ** -11
+    G = H // Hkv
+    Kd, Vd = ref_cache.k[0].double(), ref_cache.v[0].double()
+    for b in range(B):
+        for i in range(n):
+            lo, hi = key_start[b], kv_len + i + 1
+            if hi <= lo:
+                continue
+            for h in range(H):
+                kk, vv = Kd[b, h // G, lo:hi], Vd[b, h // G, lo:hi]
+                p = torch.softmax((kk @ q[b, i, h].double()) / D ** 0.5, dim=0)
+                exact = (p[:, None] * vv).sum(0)
+                bound = u * 1.05 * ((p[:, None] * vv.abs()).sum(0) + exact.abs()) + 2e-6
+                if dtype == torch.float16:
+                    bound = bound + (hi - lo) * 2.0 ** -25 * float(vv.abs().max())
+                e = (got[b, i, h].double() - exact).abs()
+                assert (e <= bound).all(), f"{name} b{b} row{i} head{h}: err {float(e.max()):.3e} over the rounding bound {float(bound[e.argmax()]):.3e}"
 
 
 _DIRECT_SCRIPT = r"""

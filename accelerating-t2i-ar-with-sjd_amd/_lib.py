@@ -21,7 +21,8 @@ class RowRule(ctypes.Structure):
 
 class IterParams(ctypes.Structure):
     _fields_ = [("n_rows", ctypes.c_int32), ("kv_len", ctypes.c_int32), ("use_cfg", ctypes.c_int32),
-                ("scheme", ctypes.c_int32), ("n_fresh", ctypes.c_int32), ("batch_rows", ctypes.c_int32), ("iter_seq", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("scheme", ctypes.c_int32), ("n_fresh", ctypes.c_int32), ("batch_rows", ctypes.c_int32), ("iter_seq", ctypes.c_int32), ("philox_blocks", ctypes.c_int32),
+                ("philox_seed", ctypes.c_uint64), ("philox_offset", ctypes.c_uint64 * 3),
                 ("fresh_tok", ctypes.c_int64 * MAX_WINDOW), ("rules", RowRule * MAX_WINDOW),
                 ("resid_rules", RowRule * MAX_WINDOW)]
 
@@ -52,7 +53,8 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_kv_append_fp8", "sjd_draft_window_attention_fp8", "sjd_qknorm_rope_append_fp8",
            "sjd_residual_sumsq", "sjd_qknorm_rope_append_ex", "sjd_silu_mul_ex", "sjd_weight_prefetch", "sjd_qkv_attention_fused", "sjd_skinny_gemm_cols",
            "sjd_logits_to_probs_sample_part", "sjd_logits_to_probs_sample_ex", "sjd_reguess_ex",
-           "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu", "sjd_host_wait_u64"]
+           "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu", "sjd_host_wait_u64",
+           "sjd_philox_fill", "sjd_philox_offset_increment"]
 
 _lib = None
 
@@ -105,6 +107,9 @@ def load():
     lib.sjd_logits_to_probs_sample_ex.argtypes = [vp, vp, i64, f32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.sjd_qkv_attention_fused.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),
                                             vp, vp, i32, vp]
+    lib.sjd_philox_fill.argtypes = [vp, i64, ctypes.c_uint64, ctypes.c_uint64, i32, i32, vp]
+    lib.sjd_philox_offset_increment.restype = ctypes.c_uint64
+    lib.sjd_philox_offset_increment.argtypes = [i64, i32]
     lib.sjd_event_create.restype = vp
     lib.sjd_event_destroy.argtypes = [vp]
     lib.sjd_event_synchronize.argtypes = [vp]
@@ -112,7 +117,7 @@ def load():
     lib.sjd_event_elapsed_ms.argtypes = [vp, vp]
     for name in EXPORTS:
         getattr(lib, name)
-    assert ctypes.sizeof(RowRule) == 48 and ctypes.sizeof(IterParams) == 32 + 8 * MAX_WINDOW + 2 * 48 * MAX_WINDOW
+    assert ctypes.sizeof(RowRule) == 48 and ctypes.sizeof(IterParams) == 64 + 8 * MAX_WINDOW + 2 * 48 * MAX_WINDOW
     _lib = lib
     return lib
 

@@ -1,4 +1,4 @@
-// sjd_device.cuh -- device helpers shared by the sampling kernels (K2 / K4).
+// sjd_device.h -- device helpers shared by the sampling kernels (K2 / K4).
 //
 // Canonical fp32 numerics (specification; the CPU oracle restates the same arithmetic independently):
 //   * no FMA contraction except the explicit __builtin_fmaf below  (file is built with -ffp-contract=off)

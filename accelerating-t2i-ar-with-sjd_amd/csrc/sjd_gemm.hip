@@ -19,7 +19,7 @@
 #include <stdlib.h>
 
 #include "../../include/sjd_hip.h"
-#include "sjd_mlp_epilogue.cuh"
+#include "sjd_mlp_epilogue.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512) void g1_gateup_silu(const unsigned short *__re
             float gsum = 0.f, usum = 0.f;                          // F3: planes summed in chunk order, starting from zero
             gsum += gs[j]; gsum += gt[j];
             usum += us_[j]; usum += ut[j];
-            o16[j] = sjd_silu_mul_elem<DT>(gsum, usum, rr);         // sjd_mlp_epilogue.cuh: the element arithmetic F3 uses, same bits
+            o16[j] = sjd_silu_mul_elem<DT>(gsum, usum, rr);         // sjd_mlp_epilogue.h: the element arithmetic F3 uses, same bits
         }
         if (m < M) {
             uint2 pk{(unsigned)o16[0] | ((unsigned)o16[1] << 16), (unsigned)o16[2] | ((unsigned)o16[3] << 16)};

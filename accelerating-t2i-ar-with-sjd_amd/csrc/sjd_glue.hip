@@ -34,7 +34,7 @@ extern "C" int sjd_debug_trace_glue(int kind, unsigned long long *host_out, int 
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-#include "sjd_mlp_epilogue.cuh"
+#include "sjd_mlp_epilogue.h"
 
 template <int DT> struct Cvt;
 template <> struct Cvt<SJD_DTYPE_BF16> {
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
             }
             const float r = row_sumsq ? rsqrtf(ss_tot * rs_inv_hidden + rs_eps) : 1.0f;
             if (g[0] + r != 12345.678f) SJD_TRG(2, 1);       // (partials + row statistics arrived)
-            unsigned short ob[8];                // element arithmetic shared with g1_gateup_silu (sjd_mlp_epilogue.cuh): same bits
+            unsigned short ob[8];                // element arithmetic shared with g1_gateup_silu (sjd_mlp_epilogue.h): same bits
 #pragma unroll
             for (int j = 0; j < 8; ++j) ob[j] = sjd_silu_mul_elem<DT>(g[j], u[j], r);
             *reinterpret_cast<u32x4 *>(y + (size_t)row * I + c) = u32x4{(unsigned)ob[0] | ((unsigned)ob[1] << 16), (unsigned)ob[2] | ((unsigned)ob[3] << 16),

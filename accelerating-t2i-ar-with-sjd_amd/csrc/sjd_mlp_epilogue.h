@@ -1,4 +1,4 @@
-// sjd_mlp_epilogue.cuh -- the element arithmetic of F3 (SiLU(gate) * up on a gate|up projection), shared by the two kernels that apply it:
+// sjd_mlp_epilogue.h -- the element arithmetic of F3 (SiLU(gate) * up on a gate|up projection), shared by the two kernels that apply it:
 // f3_silu_mul (sjd_glue.hip, on the split-K partial planes of G1) and g1_gateup_silu (sjd_gemm.hip, as the epilogue of the projection).
 // Both must give the SAME bits (tests/test_gpu_glue.py::test_g1_gateup_silu_matches_g1_then_f3), so nothing here is left to the
 // instruction selector: no contraction inside these functions, and the fp16 conversion is an explicit v_cvt_f16_f32 -- fp32 product, then

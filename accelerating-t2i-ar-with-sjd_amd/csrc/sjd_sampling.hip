@@ -1,5 +1,5 @@
 // sjd_sampling.hip -- kernels K2 (logits -> probs -> sample), K4 (verify/accept + residual resample),
-// K5 (window assembly / re-guess) for gfx950.  Built with -ffp-contract=off (canonical numerics, see sjd_device.cuh).
+// K5 (window assembly / re-guess) for gfx950.  Built with -ffp-contract=off (canonical numerics, see sjd_device.h).
 //
 // One 1024-thread workgroup (16 wave64) owns one row.  The row is staged in the caller's probs_out / scratch buffer
 // (L2-resident between passes); all cross-lane reductions use wave64 shuffles + a 16-entry LDS exchange.
@@ -7,7 +7,8 @@
 #include <math.h>
 
 #include "../../include/sjd_hip.h"
-#include "sjd_device.cuh"
+#include "sjd_device.h"
+#include "sjd_philox.h"
 
 // phase timestamps of K2 / K4 (tools/phase_trace.py, -DSJD_TRACE; compiled out otherwise): slot = row (K2) / 32 (K4)
 #ifdef SJD_TRACE
@@ -48,6 +49,7 @@ __device__ __forceinline__ bool rule_allows(const sjd_row_rule &r, int c)
 // lm_head, only the vocabulary columns the grammar allows), sums the chunks in order, applies the folded final-RMSNorm row scale and
 // rounds to the activation dtype exactly where nn.Linear would (MC:1560-1561: 16-bit lm_head output, then .float()); the CFG combine,
 // grammar mask, top-k, softmax and draw are the same code as the dense-logits form.
+static_assert(sizeof(sjd_iter_params) == 64 + 8 * SJD_MAX_WINDOW + 2 * 48 * SJD_MAX_WINDOW, "sjd_iter_params layout is mirrored by ctypes (sjd_amd/_lib.py::IterParams)");
 static_assert(sizeof(sjd_head_partials) == 88, "sjd_head_partials layout is mirrored by ctypes (sjd_amd/_lib.py::HeadPartials)");
 
 __device__ __forceinline__ float k2_round16(float x, int dt)
@@ -88,6 +90,11 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const sjd_row_rule rule = params->rules[row];
     float *p = probs_out + (size_t)row * V;
     const float *e = noise + (size_t)row * V;
+    // the Exp(1) noise of the draw: read from `noise`, or (params->philox_blocks > 0) generated here -- the elements torch's
+    // empty(n_rows, V).exponential_(generator=g) would hold, for the columns that carry probability mass only (sjd_philox.h)
+    const uint32_t ph_blocks = (uint32_t)params->philox_blocks;
+    const uint64_t ph_seed = params->philox_seed, ph_off = params->philox_offset[0];
+    const uint32_t ph_T = ph_blocks ? sjd_philox_threads((uint64_t)params->n_rows * (uint64_t)V, ph_blocks) : 0u;
 
     if (rule.forced >= 0) {   // forced EOL / end-of-image row: softmax of (-inf,...,0,...,-inf) (LP:39-41)
         SJD_FOR_OWNED_COLS(V, c0)
@@ -234,7 +241,9 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
             if (col >= wlo && col < whi) {
                 float pv = p[col] / S;
                 p[col] = pv;
-                float r = pv / e[col];
+                float r;
+                if (ph_blocks) r = pv > 0.0f ? pv / sjd_philox_exponential(ph_seed, ph_off, ph_T, (uint64_t)row * (uint64_t)V + (uint64_t)col) : 0.0f;   // (0 / e == 0: e is finite and > 0)
+                else r = pv / e[col];
                 unsigned long long cand = pack_vi(r, col);
                 best = cand > best ? cand : best;
                 cand = pack_vi(pv, col);
@@ -302,7 +311,11 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                 int qs = state->q_src[i];
                 float qd = (qs >= 0) ? prev_probs[(size_t)qs * V + x] : 1.0f;
                 float ratio = pa / qd;                       // JL:286 (NaN compares false => reject)
-                float uu = rs[(size_t)i * V + x];            // JL:282
+                float uu;                                    // JL:282: rs[b, i, x] of torch.rand((1, n, V)); generated in place when
+                if (params->philox_blocks > 0)               // the noise is not handed over as tensors (15 uniforms instead of n * V)
+                    uu = sjd_philox_rand(params->philox_seed, params->philox_offset[1],
+                                         sjd_philox_threads((uint64_t)n * (uint64_t)V, (uint32_t)params->philox_blocks), (uint64_t)i * (uint64_t)V + (uint64_t)x);
+                else uu = rs[(size_t)i * V + x];
                 acc = uu < (ratio > 1.0f ? 1.0f : ratio);
             } else {
                 acc = (x == state->tokens[i - 1]);           // JL:325
@@ -318,6 +331,9 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
     __syncthreads();
     const int m = sh.misc[0];
     const bool rejected = (scheme == 0) && (m < n);
+    const uint32_t ph_blocks = (uint32_t)params->philox_blocks;
+    const uint64_t ph_seed = params->philox_seed, ph_off2 = params->philox_offset[2];
+    const uint32_t ph_T2 = ph_blocks ? sjd_philox_threads((uint64_t)V, ph_blocks) : 0u;
     bool degenerate = false;        // residual distribution empty under the residual rule: the reference's torch.multinomial raises
     if (rejected) {
         // phase 2: residual resample of position m-1 from norm(max(p - q, 0)) (JL:203-241)
@@ -376,7 +392,10 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                     for (int j = 0; j < 4; ++j) {
                         int col = c0 + j;
                         if (col >= wlo && col < whi) {
-                            float r = (scratch[col] / S) / noise2[col];
+                            const float dv = scratch[col] / S;
+                            float r;
+                            if (ph_blocks) r = dv > 0.0f ? dv / sjd_philox_exponential(ph_seed, ph_off2, ph_T2, (uint64_t)col) : dv;    // (dv is 0 or NaN here)
+                            else r = dv / noise2[col];
                             unsigned long long cand = pack_vi(r, col);
                             best = cand > best ? cand : best;
                         }
@@ -456,8 +475,8 @@ extern "C" int sjd_logits_to_probs_sample_ex(const float *logits_c, const float 
                                              int max_rows, int V, const sjd_iter_params *params, const float *noise,
                                              float *probs_out, int64_t *tokens_out, int64_t *amax_out, void *stream)
 {
-    if (!logits_c || !params || !noise || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
-        return SJD_ERR_BAD_ARG;
+    if (!logits_c || !params || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
+        return SJD_ERR_BAD_ARG;                    /* noise may be NULL when params->philox_blocks > 0 (the kernel generates it) */
     sjd_head_partials none = {};
     hipLaunchKernelGGL(k2_logits_to_probs_sample<false>, dim3(max_rows), dim3(SJD_TPB), 0, (hipStream_t)stream, logits_c, logits_u,
                        (long)row_stride, guidance, V, params, noise, probs_out, tokens_out, none, amax_out);
@@ -469,7 +488,7 @@ extern "C" int sjd_logits_to_probs_sample_part(const sjd_head_partials *head, fl
                                                int64_t *amax_out, void *stream)
 {
     if (!head || !head->part || head->n_chunks < 1 || head->n_cols < 1 || head->col0 < 0 || head->row_stride < head->n_cols) return SJD_ERR_BAD_ARG;
-    if (!params || !noise || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1) return SJD_ERR_BAD_ARG;
+    if (!params || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1) return SJD_ERR_BAD_ARG;
     if (head->row_sumsq && (head->slices < 1 || head->prows < 1)) return SJD_ERR_BAD_ARG;
     hipLaunchKernelGGL(k2_logits_to_probs_sample<true>, dim3(max_rows), dim3(SJD_TPB), 0, (hipStream_t)stream, (const float *)nullptr,
                        (const float *)nullptr, (long)0, guidance, V, params, noise, probs_out, tokens_out, *head, amax_out);
@@ -480,8 +499,8 @@ extern "C" int sjd_verify_accept_ex(const sjd_iter_params *params, sjd_state *st
                                     const float *rs, const float *noise2, float *scratch, int max_rows, int V, sjd_state *host_mirror,
                                     void *stream)
 {
-    if (!params || !state || !probs || !prev_probs || !rs || !noise2 || !scratch || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
-        return SJD_ERR_BAD_ARG;
+    if (!params || !state || !probs || !prev_probs || !scratch || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
+        return SJD_ERR_BAD_ARG;                    /* rs / noise2 may be NULL when params->philox_blocks > 0 */
     hipLaunchKernelGGL(k4_verify_accept, dim3(1), dim3(SJD_TPB), 0, (hipStream_t)stream, params, state, probs, prev_probs, rs,
                        noise2, scratch, V, host_mirror);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
@@ -491,4 +510,27 @@ extern "C" int sjd_verify_accept(const sjd_iter_params *params, sjd_state *state
                                  const float *rs, const float *noise2, float *scratch, int max_rows, int V, void *stream)
 {
     return sjd_verify_accept_ex(params, state, probs, prev_probs, rs, noise2, scratch, max_rows, V, nullptr, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ noise, as a tensor (tests)
+// What K2 / K4 generate in place, written out: element e of the tensor torch would have filled from a device generator at (seed, offset).
+// kind 0: uniform_(0, 1) / torch.rand;  1: exponential_(1).  tests/test_gpu_philox.py compares it with torch bit for bit.
+__global__ void philox_fill(float *__restrict__ out, uint64_t numel, uint64_t seed, uint64_t offset, uint32_t max_blocks, int kind)
+{
+    const uint32_t T = sjd_philox_threads(numel, max_blocks);
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < numel; e += (uint64_t)gridDim.x * blockDim.x)
+        out[e] = kind == 0 ? sjd_philox_rand(seed, offset, T, e) : sjd_philox_exponential(seed, offset, T, e);
+}
+
+extern "C" int sjd_philox_fill(float *out, int64_t numel, uint64_t seed, uint64_t offset, int max_blocks, int kind, void *stream)
+{
+    if (!out || numel < 0 || max_blocks < 1 || kind < 0 || kind > 1) return SJD_ERR_BAD_ARG;
+    if (numel == 0) return SJD_OK;
+    hipLaunchKernelGGL(philox_fill, dim3(1024), dim3(256), 0, (hipStream_t)stream, out, (uint64_t)numel, seed, offset, (uint32_t)max_blocks, kind);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" uint64_t sjd_philox_offset_increment(int64_t numel, int max_blocks)
+{
+    return (numel <= 0 || max_blocks < 1) ? 0 : sjd_philox_offset_step((uint64_t)numel, (uint32_t)max_blocks);
 }

@@ -24,6 +24,28 @@ def _dtype_code(dt):
     raise L.SjdLibraryError(f"SJD HIP kernels support bf16/fp16 KV and activations, got {dt}")
 
 
+_PHILOX_BLOCKS = {}
+
+
+def philox_max_blocks(device):
+    """grid cap of ATen's distribution kernels on this device (sjd_iter_params.philox_blocks): multiProcessorCount *
+    (maxThreadsPerMultiProcessor / 256) -- calc_execution_policy in ATen/native/cuda/DistributionTemplates.h"""
+    device = torch.device(device)
+    mb = _PHILOX_BLOCKS.get(device)
+    if mb is None:
+        p = torch.cuda.get_device_properties(device)
+        mb = _PHILOX_BLOCKS[device] = int(p.multi_processor_count) * (int(p.max_threads_per_multi_processor) // 256)
+    return mb
+
+
+def philox_step(numel, max_blocks):
+    """what a device generator's offset advances by when ATen fills `numel` elements (== sjd_philox_offset_increment)"""
+    if numel <= 0:
+        return 0
+    T = min((numel + 255) // 256, max_blocks) * 256
+    return ((numel - 1) // (T * 4) + 1) * 4
+
+
 _RULE_CACHE = {}
 
 

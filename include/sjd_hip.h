@@ -57,7 +57,14 @@ typedef struct sjd_iter_params {
                                        contiguous ARRAY of blobs and blob i governs batch rows [i*batch_rows, (i+1)*batch_rows) of K1 /
                                        K3 / F2 (each prompt has its own kv_len / n_rows); same value in every blob of the array */
     int32_t iter_seq;                             /* host's iteration counter: sjd_verify_accept_ex publishes it behind the mirrored state */
-    int32_t reserved;
+    int32_t philox_blocks;                        /* 0: K2 / K4 read the noise tensors they are handed.  > 0: they GENERATE the noise: the
+                                                     elements torch's exponential_ / uniform_ would have written for a device generator
+                                                     with the seed / offsets below (Philox4x32-10, csrc/sjd_philox.h); the value is the
+                                                     grid cap of ATen's launch, multiProcessorCount * (maxThreadsPerMultiProcessor / 256) */
+    uint64_t philox_seed;                         /* torch.Generator.initial_seed() */
+    uint64_t philox_offset[3];                    /* the generator's offset before (0) the [n_rows, V] exponential_ of the multinomial
+                                                     (JL:118), (1) the [1, n_rows, V] rand of the accept test (JL:260), (2) the [1, V]
+                                                     exponential_ of the residual multinomial (JL:237) */
     int64_t fresh_tok[SJD_MAX_WINDOW];            /* random re-guess ids (host global RNG, JL:505-509), packed */
     sjd_row_rule rules[SJD_MAX_WINDOW];           /* rules of the sampling call, row j */
     sjd_row_rule resid_rules[SJD_MAX_WINDOW];     /* rule of the residual call if rejection happens at i=j+1 */
@@ -316,6 +323,16 @@ int sjd_stream_synchronize(void *stream);
  * the iteration's result a microsecond after the kernel wrote it instead of after the runtime's interrupt-driven stream wait. */
 #define SJD_STATE_MIRROR_BYTES (sizeof(sjd_state) + 8)
 int sjd_host_wait_u64(const volatile uint64_t *flag, uint64_t value, int64_t timeout_us);
+
+/* In-kernel noise (SURVEY.md section 7 "reproduce torch's Philox offsets", 8-K4 "K4 needs L-1 uniforms").  The reference draws
+ * torch.multinomial / torch.rand / torch.multinomial from a device torch.Generator (jacobi_iteration_lumina_mgpt.py:118, 260, 237).  With
+ * params->philox_blocks > 0, K2 and K4 compute the very elements those ATen launches would have written (Philox4x32-10 at the generator's
+ * seed and offsets, ATen's thread -> element layout; csrc/sjd_philox.h) and their noise / rs / noise2 arguments may be NULL; the host
+ * advances the generator's offset by sjd_philox_offset_increment(numel, philox_blocks) per tensor the reference would have drawn.
+ * sjd_philox_fill writes such a tensor out (kind 0: uniform_(0, 1) == torch.rand; 1: exponential_(1)) -- the handle of the parity test
+ * against torch itself (tests/test_gpu_philox.py). */
+int sjd_philox_fill(float *out, int64_t numel, uint64_t seed, uint64_t offset, int max_blocks, int kind, void *stream);
+uint64_t sjd_philox_offset_increment(int64_t numel, int max_blocks);
 
 /* HIP event helpers so that a ctypes host can time kernels on the stream they run on. */
 void *sjd_event_create(void);

@@ -309,12 +309,12 @@ def test_k1_k3_attention(dev, case, n_split):
     assert err[vis].mean() < 3e-3, f"mean err {err[vis].mean()}"
     assert (got[~vis] == 0).all()
     # The kernel's rounding points restated (the fp8 test does the same for its P): scores and the softmax sum are
-    # fp32, each probability is rounded ONCE to the 16-bit MFMA operand type before P.V (relative error <= u = 2^-9 bf16 / 2^-11 fp16,
+    # fp32, each probability is rounded ONCE to the 16-bit MFMA operand type before P.V (relative error <= u = 2^-8 bf16 / 2^-11 fp16: half an ulp,
     # whatever running maximum it was taken against), the output is rounded once more.  So element by element
     #     |out - exact| <= u * (sum_j p_j |v_jd|  +  |exact_d|)            (+ fp16: N * 2^-25 max|v| for subnormal probabilities)
     # with exact = fp64 attention over the same 16-bit operands -- about two output ulps; a wrong tile edge, mask bit or split merge
     # is orders of magnitude above it, where the 3e-2 above would hide it.
-    u = 2.0 ** -9 if dtype == torch.bfloat16 else 2.0 ** -11
+    u = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     G = H // Hkv
     Kd, Vd = ref_cache.k[0].double(), ref_cache.v[0].double()
     for b in range(B):

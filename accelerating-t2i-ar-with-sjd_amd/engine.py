@@ -2,26 +2,31 @@
 shape-static launch sequence over device-resident state.
 
 Per window iteration (reference line numbers in brackets):
-   host   n, a', fresh random ids (torch.randint on the GLOBAL CPU generator, JL:505), window rules -> ONE pinned
-          sjd_iter_params blob, one async H2D
-   ---- graph 1, captured once per output-head column window, launched as soon as the blob is uploaded ----
+   host   n, a', fresh random ids (torch.randint on the GLOBAL CPU generator, JL:505), window rules, residual rules, the device
+          generator's seed / offsets -> ONE pinned sjd_iter_params blob, one async H2D
+   ---- ONE hipGraph, captured once per (output-head column window, prob-buffer parity) ----
    K5     window = [last emitted | carried samples | fresh ids]                              [JL:606-701]
    fwd    backbone.forward_window over the static L rows (G1 / F1r-F3 / K1 per layer, kv_len and n_rows read from the
           device blob; output head on the vocabulary columns the rules allow)                [JL:1107]
-   host   (while graph 1 runs) residual rules -> their slice of the blob; the three noise tensors are drawn from the
-          device generator on a side stream
-   ---- graph 2, captured once per prob-buffer parity ----
    K2     CFG + grammar + top-k + softmax + multinomial -> p[L,V], Y[L]                      [JL:82-132]
-   K4     accept scan + residual resample -> m, corrected Y                                  [JL:247-376]
+   K4     accept scan + residual resample -> m, corrected Y, written to pinned host memory   [JL:247-376]
    ----
-   host   reads back {m, rejected, Y} (ONE sync), appends Y[:m], kv_len += m                 [JL:378-430]
+   host   ONE sync, reads {m, rejected, Y}, appends Y[:m], kv_len += m                       [JL:378-430]
 The draft distributions of the next window are rows (m-1 ...) of this iteration's p buffer, so nothing is copied
 (two p buffers alternate); fresh random drafts are implicit one-hots; KV rollback is the kv_len update (rows of
 rejected drafts are overwritten by the next window).
 
-RNG streams mirror the reference: device generator g for exponential_/rand (consumed in the
-same order and shapes), global CPU generator for the fresh ids.  The residual draw is made from g speculatively
-and the generator state is rewound when no rejection happened.
+RNG streams mirror the reference: device generator g for the multinomial / rand / residual multinomial, global CPU
+generator for the fresh ids.  Round 3: the device noise is no longer materialised -- K2 / K4 compute the elements torch's exponential_ /
+rand WOULD have written for g's seed and offset (Philox4x32-10 in ATen's layout, csrc/sjd_philox.h; bit-identical to torch,
+tests/test_gpu_philox.py) and the host advances g's offset by what torch would have consumed; the residual draw consumes its part of the
+stream only when a rejection happened, as in the reference.  Observers (the parity tests' hook) still get the three tensors, drawn by
+torch from the same generator state -- that is what the teacher-forced oracle replays consume.  `noise_device="cpu"` (replay of the
+reference's CPU runs) keeps the tensor path: the noise is drawn on the host and uploaded.
+
+When the grammar cannot name the residual rules before the launch (fast_residual_rules -> None: Anole's context-dependent processors, the
+first rows after <start>, windows that hold an end token) the iteration is launched in two stages instead -- {K5, forward}, residual
+rules computed on the host meanwhile and uploaded behind it on the same stream, {K2, K4}.
 """
 import ctypes
 import os
@@ -43,7 +48,7 @@ from .grammar import spatial_fresh_tokens
 # mirrored state (sjd_host_wait_u64, no HIP call).  Measured equal within the box noise (3.584 / 3.569 against 3.586 ms/step): the runtime's
 # stream wait already polls.  The synchronize also surfaces a GPU fault as an error instead of a timeout, so it stays the default.
 _MIRROR_STREAM_WAIT = os.environ.get("SJD_MIRROR_SPIN", "0") != "1"
-_SAMPLE_EAGER = os.environ.get("SJD_SAMPLE_EAGER", "0") == "1"      # experiment: K2 / K4 as two plain launches behind the forward graph
+_TWO_STAGE = os.environ.get("SJD_TWO_STAGE", "0") == "1"            # A/B: always launch {K5, forward} and {K2, K4} as two graphs (round 2's shape)
 
 
 @dataclass
@@ -126,9 +131,8 @@ class SJDEngine:
         self.params = ops.DeviceBlob(L.IterParams, dev)
         self.state = ops.DeviceBlob(L.State, dev)
         self.probs = torch.zeros(2, self.Lmax, self.V, dtype=torch.float32, device=dev)
-        self.noise = torch.ones(self.Lmax, self.V, dtype=torch.float32, device=dev)
-        self.rs = torch.zeros(self.Lmax, self.V, dtype=torch.float32, device=dev)
-        self.noise2 = torch.ones(1, self.V, dtype=torch.float32, device=dev)
+        self.noise = self.rs = self.noise2 = None   # [L,V], [L,V], [1,V] fp32: allocated only for observers / host-drawn noise (_noise_tensors)
+        self._philox = True                         # this decode's K2 / K4 generate their noise (False: they read the tensors)
         self.scratch = torch.empty(self.V, dtype=torch.float32, device=dev)
         self.input_ids = torch.zeros(self.B, self.Lmax, dtype=torch.int64, device=dev)
         self.arange = torch.arange(self.Lmax, device=dev)
@@ -146,7 +150,6 @@ class SJDEngine:
         self.head_partials = bool(head_partials) and getattr(backbone, "supports_head_partials", False)
         self._dbg = None                            # [2, L, V] logits as K2 derived them; allocated only for observers (hook)
         self._guidance = 3.0
-        self.rng_stream = torch.cuda.Stream(device=dev)
         self._rule_bytes, self._rule_keep, self._cols_cache = {}, [], {}
         self._seq = 0
         self.reset_graphs()
@@ -171,15 +174,27 @@ class SJDEngine:
         self._graph_sig = sig
 
     # ------------------------------------------------------------------------------------------------
-    def _fill_params(self, n, kv_len, use_cfg, scheme, fresh, rules, resid, head_only=False):
-        """head_only: upload everything in FRONT of resid_rules only.  The residual rules of a window iteration go up on the noise
-        stream while the forward runs (_fill_resid); the two copies then write disjoint byte ranges of the device blob and read
-        disjoint ranges of the pinned one, so no ordering between the two streams is needed (a whole-blob upload here
-        raced the partial one)."""
+    def _noise_tensors(self):
+        if self.noise is None:
+            dev = self.device
+            self.noise = torch.ones(self.Lmax, self.V, dtype=torch.float32, device=dev)
+            self.rs = torch.zeros(self.Lmax, self.V, dtype=torch.float32, device=dev)
+            self.noise2 = torch.ones(1, self.V, dtype=torch.float32, device=dev)
+        return self.noise, self.rs, self.noise2
+
+    def _fill_params(self, n, kv_len, use_cfg, scheme, fresh, rules, resid, head_only=False, philox=None):
+        """philox = (blocks, seed, off0, off1, off2): K2 / K4 generate the noise of a device generator at that state (None: tensors).
+        head_only: upload everything in FRONT of resid_rules only -- the residual rules follow on the same stream once the host has
+        computed them (_upload_resid), as a disjoint byte range of the blob."""
         p = self.params.view
         p.n_rows, p.kv_len, p.use_cfg, p.scheme, p.n_fresh = n, kv_len, int(use_cfg), scheme, len(fresh)
         self._seq = (self._seq % 0x7FFFFFF0) + 1          # K4 publishes it behind the mirrored state: what the host's spin waits for
         p.iter_seq = self._seq
+        if philox is None:
+            p.philox_blocks = 0
+        else:
+            p.philox_blocks, p.philox_seed = philox[0], philox[1]
+            p.philox_offset[0], p.philox_offset[1], p.philox_offset[2] = philox[2], philox[3], philox[4]
         if fresh:
             p.fresh_tok[:len(fresh)] = fresh
         self._write_rules(L.IterParams.rules.offset, rules)
@@ -199,12 +214,13 @@ class SJDEngine:
                 self._rule_keep.append(list(rules))            # the ids stay valid while the structs are alive
         ctypes.memmove(self.params.host.data_ptr() + offset, blk, len(blk))
 
-    def _fill_resid(self, resid):
-        """the residual rules are read by K4 only: they are computed and uploaded (their slice of the blob) while the forward runs"""
-        self._write_rules(L.IterParams.resid_rules.offset, resid)
+    def _upload_resid(self, resid):
+        """two-stage iterations: the residual rules (read by K4 only) were computed while the forward runs; their slice of the blob goes
+        up on the SAME stream, behind the forward and in front of K2 / K4"""
         off = L.IterParams.resid_rules.offset
-        with torch.cuda.stream(self.rng_stream):          # part 2 waits for this stream (noise_ready): off the forward's stream
-            self.params.dev[off:].copy_(self.params.host[off:], non_blocking=True)
+        self._write_rules(off, resid)
+        L.check(L.load().sjd_upload_async(self.params.dev.data_ptr() + off, self.params.host.data_ptr() + off, self.params.nbytes - off,
+                                          ops._stream()), "sjd_upload_async")
 
     def _forward_body(self, cols=None):
         """Shape-static launch sequence, part 1: K5 + transformer forward (every dynamic scalar is read from device blobs).
@@ -218,7 +234,8 @@ class SJDEngine:
         return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start, cols=cols)
 
     def _sample_body(self, cur, logits, cols=None):
-        """part 2: K2 + K4 (needs the noise tensors, which are drawn on a side stream while part 1 runs)."""
+        """part 2: K2 + K4.  In-kernel noise (self._philox): the kernels are handed NULL instead of the noise tensors."""
+        noise, rs, noise2 = (None, None, None) if self._philox else (self.noise, self.rs, self.noise2[0])
         if isinstance(logits, ops.HeadOut):
             dbg = None
             if self.hook is not None:
@@ -226,13 +243,13 @@ class SJDEngine:
                     self._dbg = torch.zeros(2, self.Lmax, self.V, dtype=torch.float32, device=self.device)
                 dbg = self._dbg
                 dbg.zero_()
-            ops.logits_to_probs_sample_part(logits, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr, dbg=dbg,
+            ops.logits_to_probs_sample_part(logits, self._guidance, self.params, noise, self.probs[cur], self.tokens_ptr, dbg=dbg,
                                             amax_out_ptr=self.amax_ptr)
         else:
             lu = logits[1] if self.B > 1 else None
-            ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr,
+            ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, noise, self.probs[cur], self.tokens_ptr,
                                        col0=cols[0] if cols else 0, amax_out_ptr=self.amax_ptr)
-        ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0], self.scratch, mirror=True)
+        ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], rs, noise2, self.scratch, mirror=True)
 
     def logit_columns(self, rules):
         """Vocabulary window [lo, hi) (32-aligned) that holds every id the non-forced rows of this iteration may emit, or None when
@@ -282,12 +299,11 @@ class SJDEngine:
         self._graphs[fkey].replay()
         return self._graph_logits[fkey]
 
-    def _launch_sample(self, cur, logits, noise_ready, cols=None):
-        """part 2 (K2 + K4) once the noise drawn on the side stream is ready; a hipGraph per (prob-buffer parity, column window),
-        captured the second time that combination runs on graph-owned logits."""
-        torch.cuda.current_stream().wait_event(noise_ready)
-        key = (cur, self._guidance, cols, self.hook is not None)
-        if not self.use_graph or ("fwd", cols) not in self._graphs or _SAMPLE_EAGER:
+    def _launch_sample(self, cur, logits, cols=None):
+        """part 2 (K2 + K4) of a two-stage iteration; a hipGraph per (prob-buffer parity, column window), captured the second time that
+        combination runs on graph-owned logits."""
+        key = (cur, self._guidance, cols, self.hook is not None, self._philox)
+        if not self.use_graph or ("fwd", cols) not in self._graphs:
             self._sample_body(cur, logits, cols)
             return
         if key not in self._graphs:
@@ -299,11 +315,40 @@ class SJDEngine:
             return
         self._graphs[key].replay()
 
-    def _run_window(self, cur, noise_ready, cols=None):
-        """K5 -> forward -> [wait for the noise] -> K2 -> K4"""
-        logits = self._launch_forward(cols)
-        self._launch_sample(cur, logits, noise_ready, cols)
-        return logits
+    def _launch_window(self, cur, cols=None):
+        """the whole iteration -- K5, forward, K2, K4 -- as ONE hipGraph per (column window, prob-buffer parity): everything it reads
+        is in the blob that was uploaded in front of it.  Returns the logits / head partials K2 read (graph-owned, static)."""
+        if not self.use_graph:
+            logits = self._forward_body(cols)
+            self._sample_body(cur, logits, cols)
+            return logits
+        self._check_graph_buffers()
+        key = ("win", cols, cur, self._guidance, self.hook is not None, self._philox)
+        if key not in self._graphs:
+            if self._eager_runs.get(key, 0) < 1:      # one eager run warms up allocations / hipBLASLt before capture
+                self._eager_runs[key] = 1
+                logits = self._forward_body(cols)
+                self._sample_body(cur, logits, cols)
+                return logits
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                logits = self._forward_body(cols)
+                self._sample_body(cur, logits, cols)
+            self._graph_logits[key] = logits
+            self._graphs[key] = g
+        self._graphs[key].replay()
+        return self._graph_logits[key]
+
+    def captured_column_windows(self):
+        """output-head column windows for which a window graph (one- or two-stage) has been captured"""
+        return sorted({k[1] for k in self._graphs if isinstance(k, tuple) and k[0] in ("fwd", "win")}, key=lambda c: (c is None, c))
+
+    def last_head_output(self, cols):
+        """the logits / head partials the most recently captured window graph of `cols` hands to K2 (bench.py's scheduler leg)"""
+        for k in reversed(list(self._graph_logits)):
+            if k[0] in ("fwd", "win") and k[1] == cols:
+                return self._graph_logits[k]
+        return None
 
     @torch.no_grad()
     def decode(self, prompt: List[int], spec: WindowSpec, grammar, cfg: SJDConfig, warmup_iters=0, timed_iters=None,
@@ -333,6 +378,12 @@ class SJDEngine:
             set_seed(cfg.seed)
             gen = torch.Generator(cfg.noise_device or dev).manual_seed(cfg.seed)
         host_noise = cfg.noise_device is not None and torch.device(cfg.noise_device).type == "cpu"
+        philox = self._philox = not host_noise
+        if philox:
+            if gen is None:                        # no seed: the device's default generator, which exponential_(generator=None) consumes
+                gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+            ph_blocks, ph_seed, ph_off = ops.philox_max_blocks(gen.device), int(gen.initial_seed()), int(gen.get_offset())
+            ph_row = ops.philox_step(self.V, ph_blocks)                            # offset step of a [1, V] draw
         l_abs, r_abs = P + cfg.jacobi_loop_interval_l, P + cfg.jacobi_loop_interval_r   # JL:1025
         W = cfg.max_num_new_tokens
         grammar.start(X)
@@ -367,10 +418,11 @@ class SJDEngine:
                 ev0.record()
             # ---------------- host: integer bookkeeping only ----------------
             t_host0 = time.perf_counter()
+            win, resid = None, []
             if first:
                 n_rows = 1
                 torch.randint(0, cfg.img_vocab_n, (1, 0))
-                rules, resid, fresh = grammar.window_rules(1), [], []
+                rules, fresh = grammar.window_rules(1), []
             else:
                 n_rows = n
                 a = max(0, min(n_prev - m_prev, n - 1))                              # JL:633-639, 657-662
@@ -380,46 +432,41 @@ class SJDEngine:
                     fresh = spatial_fresh_tokens(cfg.multi_token_init_scheme, fresh, len(X) + a, carried[a - 1] if a else X[-1],
                                                  carried_amax[a - 1] if a else last_amax, grammar.grid())
                 rules = grammar.window_rules(n_rows)
-                resid = []                     # computed below, while the forward runs (K4 is their only reader)
-            use_cfg = do_cfg and not grammar.force_no_cfg()                          # JL:1086-1096
-            self._fill_params(n_rows, kv_len, use_cfg, scheme, fresh, rules, resid, head_only=not first)
-            if first:
-                self.rng_stream.wait_stream(torch.cuda.current_stream())             # earlier work on this stream is done with the noise buffers
-            # (later iterations: the host has just waited for K4, the last reader of the noise, so the side stream may start at once)
-            logits = None
-            if not first:
-                # part 1 goes out NOW: everything the forward reads (n_rows, kv_len, fresh ids) is uploaded; the residual grammar,
-                # the noise fills and their launches below overlap it instead of delaying it
-                stats.host_seconds += time.perf_counter() - t_host0
-                cols = self.logit_columns(rules)
-                logits = self._launch_forward(cols)
-                t_host0 = time.perf_counter()
                 if scheme == 0 and n_rows > 1:
-                    # window ids are needed on the host only for the residual grammar; carried ids come from the last read-back
-                    resid = grammar.residual_rules([X[-1]] + carried[:a] + fresh)
-                    self._fill_resid(resid)
-            # ---------------- noise, in the reference's order and shapes; drawn on a side stream so that the three fills
-            # overlap the transformer forward (they are only needed by K2 / K4) ----------------
-            e1 = self.noise[:n_rows]
-            g_state = None
-            with torch.cuda.stream(self.rng_stream):
+                    # the window's ids are all known here (carried ones came with the last read-back): if the grammar can name the
+                    # residual rules without a replay, the whole iteration goes out as one graph; otherwise they are computed below,
+                    # while the forward runs (K4 is their only reader)
+                    win = [X[-1]] + carried[:a] + fresh
+                    resid = None if _TWO_STAGE else grammar.fast_residual_rules(win, rules)
+            two_stage = resid is None
+            use_cfg = do_cfg and not grammar.force_no_cfg()                          # JL:1086-1096
+            draws_rs = n_rows > 1 and scheme == 0
+            ph = None
+            if philox:                                  # offsets of g before the multinomial, the rand and the residual multinomial
+                ph_step = ops.philox_step(n_rows * self.V, ph_blocks)
+                ph = (ph_blocks, ph_seed, ph_off, ph_off + ph_step, ph_off + 2 * ph_step)
+            self._fill_params(n_rows, kv_len, use_cfg, scheme, fresh, rules, resid or [], head_only=two_stage, philox=ph)
+            # ---------------- noise tensors: only for host-drawn noise (the reference's CPU runs) and for observers ----------------
+            e1, g_state = None, None
+            if host_noise or self.hook is not None:
+                self._noise_tensors()
+                e1 = self.noise[:n_rows]
                 if host_noise:                                                       # parity mode: CPU stream of the reference
                     e1.copy_(torch.empty(n_rows, self.V).exponential_(generator=gen))
-                    if n_rows > 1 and scheme == 0:
+                    if draws_rs:
                         self.rs[:n_rows].copy_(torch.rand((1, n_rows, self.V), generator=gen)[0])
                         g_state = gen.get_state()
                         self.noise2.copy_(torch.empty(1, self.V).exponential_(generator=gen))
-                else:
+                else:                           # what the kernels generate, drawn by torch from the same generator state (observers)
+                    gen.set_offset(ph_off)
                     e1.exponential_(generator=gen)                                   # == torch.multinomial (JL:118)
-                    if n_rows > 1 and scheme == 0:
+                    if draws_rs:
                         self.rs[:n_rows].uniform_(0.0, 1.0, generator=gen)           # torch.rand([1,n,V]) (JL:260)
-                        if gen is not None:
-                            g_state = gen.get_state()
                         self.noise2.exponential_(generator=gen)                      # residual multinomial (JL:237)
-                noise_ready = self.rng_stream.record_event()
+            stats.host_seconds += time.perf_counter() - t_host0
             # ---------------- device work ----------------
+            cols = None
             if first:
-                stats.host_seconds += time.perf_counter() - t_host0
                 if attn is not None and hasattr(attn, "params"):
                     attn.params = None                                               # prefill: kv_len passed by value
                 tokens, positions = spec.first_tokens.to(dev), spec.first_positions.to(dev)
@@ -427,15 +474,23 @@ class SJDEngine:
                 lc = logits[0, -1:, :]
                 lu = logits[1, -1:, :] if B > 1 else None
                 win_len = tokens.shape[1]
-                torch.cuda.current_stream().wait_event(noise_ready)
-                ops.logits_to_probs_sample(lc, lu, self._guidance, self.params, self.noise, self.probs[cur], self.tokens_ptr,
+                ops.logits_to_probs_sample(lc, lu, self._guidance, self.params, None if philox else self.noise, self.probs[cur], self.tokens_ptr,
                                            amax_out_ptr=self.amax_ptr)
-                ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], self.rs, self.noise2[0],
-                                  self.scratch, mirror=True)
+                ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], None if philox else self.rs,
+                                  None if philox else self.noise2[0], self.scratch, mirror=True)
                 if attn is not None and hasattr(attn, "params"):
                     attn.params = self.params                                        # windows: kv_len / n_rows from the blob
             else:
-                self._launch_sample(cur, logits, noise_ready, cols)
+                cols = self.logit_columns(rules)
+                if two_stage:
+                    logits = self._launch_forward(cols)
+                    t_host0 = time.perf_counter()
+                    resid = grammar.residual_rules(win)
+                    self._upload_resid(resid)
+                    stats.host_seconds += time.perf_counter() - t_host0
+                    self._launch_sample(cur, logits, cols)
+                else:
+                    logits = self._launch_window(cur, cols)
                 win_len = n_rows
                 if isinstance(logits, ops.HeadOut):                  # observers get the logits exactly as K2 derived them
                     lc, lu = (self._dbg[0, :n_rows], self._dbg[1, :n_rows] if B > 1 else None) if self.hook is not None else (None, None)
@@ -449,7 +504,7 @@ class SJDEngine:
             if self.hook is not None:
                 self.hook(dict(first=first, n_rows=n_rows, logits_c=lc, logits_u=lu, use_cfg=use_cfg, rules=rules,
                                resid=resid, noise=e1, rs=self.rs[:n_rows], noise2=self.noise2[0], probs=self.probs[cur],
-                               prev_probs=self.probs[1 - cur], ctx=list(X), scheme=scheme))
+                               prev_probs=self.probs[1 - cur], ctx=list(X), scheme=scheme, two_stage=two_stage))
             # ---------------- the single sync of the iteration ----------------
             t_sync0 = time.perf_counter()
             self.state.wait_mirror(None if _MIRROR_STREAM_WAIT else self._seq)     # K4 wrote the state into pinned host memory and published iter_seq: no D2H copy, no HIP call
@@ -459,7 +514,11 @@ class SJDEngine:
                 raise RuntimeError("SJD verify: the residual distribution max(p - q, 0) is empty under the residual grammar rule "
                                    "(the reference's torch.multinomial raises on the NaN probabilities at JL:237)")
             if g_state is not None and not rejected:
-                gen.set_state(g_state)
+                gen.set_state(g_state)                 # host-drawn noise: the residual draw was speculative, rewind it
+            if philox:                                 # what torch would have consumed: multinomial [+ rand [+ residual multinomial]]
+                ph_off += ph_step * (2 if draws_rs else 1) + (ph_row if (draws_rs and rejected) else 0)
+                if self.hook is not None:
+                    gen.set_offset(ph_off)
             Y = st.tokens[:n_rows]
             A = st.amax[:n_rows]                               # modes of this iteration's target rows (K2 by-product)
             if n_rows <= 1:
@@ -495,6 +554,8 @@ class SJDEngine:
             self._close_timed(stats, ev0, ev1, t0, on_timed_end if timing else None,
                               len(X) - (timed_tok0 if timing else P), stats.nfe - (timed_nfe0 if timing else 0), kv_len)
         torch.cuda.synchronize()
+        if philox:
+            gen.set_offset(ph_off)                     # leave the generator where the reference's draws would have left it
         stats.total_tokens, stats.total_seconds = len(X) - P, time.perf_counter() - t_decode0
         return X, stats
 

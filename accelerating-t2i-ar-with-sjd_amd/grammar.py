@@ -47,6 +47,15 @@ class _Grammar:
         self._restore(snap)
         return out
 
+    def fast_residual_rules(self, win, rules):
+        """residual_rules(win) WITHOUT replaying the grammar, or None when that is not provably the same.  `rules` = window_rules(len(win))
+        at the current state.  The reference evaluates the residual processors on ctx + win[1:i] (JL:297-306) and the window processors
+        row by row on ctx (LP:84-155): whenever the window tokens move the grammar only by their COUNT, the residual rule of a rejection
+        at position i is the window rule of row i - 1.  The engine then has every input of an iteration before it launches anything and
+        runs it as ONE hipGraph (K5 -> forward -> K2 -> K4); grammars / states that return None keep the two-stage launch with the
+        residual rules computed under the forward."""
+        return None
+
     def force_no_cfg(self):
         return False
 
@@ -118,6 +127,17 @@ class LuminaGrammar(_Grammar):
     def force_no_cfg(self):                        # check_is_force_no_cfg (JL:70-80)
         return self.s[1] == self.s[2]
 
+    def fast_residual_rules(self, win, rules):
+        _, ns, ne, since, _, _ = self.s
+        # inside an image body (grid known) a token only advances the position counter; outside any image it does nothing -- unless it is
+        # the start / end token itself.  The two tokens after <start> (since < 2) switch the rule set mid-window: replay those.
+        if not ((ns == ne + 1 and since >= 2) or ns == ne):
+            return None
+        for t in win[1:-1]:
+            if t == self.start_id or t == self.end_id:
+                return None
+        return list(rules[:len(win) - 1])
+
     def grid(self):
         n, ns, ne, since, g1, g2 = self.s
         if not (ns == ne + 1 and since >= 2):
@@ -166,6 +186,9 @@ class TopKTopPGrammar(_Grammar):
     def window_rules(self, n):
         return [ops.make_rule((), -1, self.top_k, self.top_p) for _ in range(n)]
 
+    def fast_residual_rules(self, win, rules):          # stateless
+        return list(rules[:len(win) - 1])
+
 
 class Emu3Grammar(_Grammar):
     def __init__(self, height, width, visual_lo, visual_n, img_token, eoi_token, eos_token, eol_token, eof_token,
@@ -192,6 +215,13 @@ class Emu3Grammar(_Grammar):
             self.since += 1
         elif t == self.img:
             self.since = 0
+
+    def fast_residual_rules(self, win, rules):
+        # tokens after the first image token only count; the padding clause (JE:118-123) keeps python's slice semantics, which differ
+        # between a window and a single row once T + n passes the end of the image: replay there
+        if self.since < 0 or self.since + len(win) > (self.W + 1) * self.H + 3:
+            return None
+        return list(rules[:len(win) - 1])
 
     def grid(self):
         if self.since < 0 or self.since >= (self.W + 1) * self.H:
@@ -232,14 +262,19 @@ class AnoleGrammar(_Grammar):
 
     def reset(self):
         self.ctx = []
+        self.boi_at = []            # indices of the <boi> tokens in ctx, ascending: "is there one in the last L tokens" without a scan
 
     def _snapshot(self):
         return len(self.ctx)
 
     def _restore(self, s):
         del self.ctx[s:]
+        while self.boi_at and self.boi_at[-1] >= s:
+            self.boi_at.pop()
 
     def _advance(self, t):
+        if t == self.boi:
+            self.boi_at.append(len(self.ctx))
         self.ctx.append(t)
 
     def _allowed(self):
@@ -247,7 +282,7 @@ class AnoleGrammar(_Grammar):
         offset = L + 1
         at_offset = cur >= offset and ctx[-offset] == self.boi
         window = min(L, cur)
-        in_window = self.boi in ctx[cur - window:] if window > 0 else False
+        in_window = bool(self.boi_at) and self.boi_at[-1] >= cur - window and window > 0
         specials = {self.eos, self.boi, self.eoi}
         allowed = set()
         for t in specials:

@@ -86,7 +86,7 @@ class DeviceBlob:
 
     def upload(self, nbytes=None):
         """pinned host -> device on the current stream (hipMemcpyAsync through the C-ABI: a torch copy_ costs the host 6-8 us per call);
-        nbytes: only the leading bytes of the blob (the rest is uploaded by someone else, see SJDEngine._fill_resid)"""
+        nbytes: only the leading bytes of the blob (the rest is uploaded by someone else, see SJDEngine._upload_resid)"""
         L.check(L.load().sjd_upload_async(self.dev.data_ptr(), self.host.data_ptr(), self.nbytes if nbytes is None else int(nbytes), _stream()),
                 "sjd_upload_async")
 
@@ -172,7 +172,7 @@ def logits_to_probs_sample(logits_c, logits_u, guidance, params: DeviceBlob, noi
     (K2 reads no other column; the pointers handed over are those of the virtual column 0)."""
     max_rows, V = probs_out.shape
     assert logits_c.dtype == torch.float32 and logits_c.stride(-1) == 1 and probs_out.is_contiguous()
-    assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V
+    assert noise is None or (noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V)      # None: params->philox_blocks > 0
     if logits_u is not None:
         assert logits_u.stride(-2) == logits_c.stride(-2) and logits_u.stride(-1) == 1
     shift = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr() - 4 * int(col0))
@@ -184,8 +184,8 @@ def logits_to_probs_sample(logits_c, logits_u, guidance, params: DeviceBlob, noi
 def verify_accept(params: DeviceBlob, state: DeviceBlob, probs, prev_probs, rs, noise2, scratch, mirror=False):
     """mirror: K4 also writes the state into the blob's pinned host copy (read it with state.wait_mirror(), not download())"""
     max_rows, V = probs.shape
-    for t in (probs, prev_probs, rs, noise2, scratch):
-        assert t.dtype == torch.float32 and t.is_contiguous()
+    for t in (probs, prev_probs, rs, noise2, scratch):          # rs / noise2 None: the kernel generates them (params->philox_blocks > 0)
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
     L.check(L.load().sjd_verify_accept_ex(params.ptr, state.ptr, _ptr(probs), _ptr(prev_probs), _ptr(rs), _ptr(noise2),
                                          _ptr(scratch), max_rows, V, state.mirror_ptr if mirror else None, _stream()), "sjd_verify_accept")
 
@@ -338,7 +338,8 @@ def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noi
     if dbg is not None:
         assert dbg.dtype == torch.float32 and dbg.is_contiguous() and dbg.shape[0] == 2 and dbg.shape[2] == V and dbg.shape[1] >= max_rows
         hp.dbg_c, hp.dbg_u = dbg[0].data_ptr(), dbg[1].data_ptr()
-    assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V and probs_out.is_contiguous()
+    assert noise is None or (noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V)
+    assert probs_out.is_contiguous()
     L.check(L.load().sjd_logits_to_probs_sample_part(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out),
                                                     tokens_out_ptr, amax_out_ptr, _stream()), "sjd_logits_to_probs_sample_part")
 

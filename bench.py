@@ -69,6 +69,11 @@ def parse(argv=None):
     ap.add_argument("--no-fold-norm", action="store_true", help="keep F1 (RMSNorm before the projection) instead of the folded-norm forward")
     ap.add_argument("--no-fused", action="store_true", help="plain ATen element-wise glue instead of the fused F1-F3 kernels")
     ap.add_argument("--k1-launches", type=int, default=320, help="launches of the K1 micro-measurement")
+    ap.add_argument("--total-prompts", type=int, default=0,
+                    help="config 4's shape: decode a queue of this many prompts (whole images), split contiguously over the --gpus ranks "
+                         "(prompt i keeps seed 1234 + i whatever N is; one all_gather at the end).  0 = the default per-rank K-step bench")
+    ap.add_argument("--no-pin", action="store_true", help="multi-rank runs: do not pin each rank to its GPU's NUMA node")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the compact emu3_8b / anole7b records (BASELINE configs 3 and 5)")
     return ap.parse_args(argv)
 
 
@@ -283,7 +288,10 @@ def cpu_baseline(args, gpu_sched_ms=None):
         t_total += time.perf_counter() - t0
     sec = t_total / n_it
     out = {"value": round(1.0 / sec, 2), "unit": "SJD scheduler steps/s (logits->tokens + verify/accept only; no transformer forward)",
-           "cores": min(threads, L), "host_cores": nproc, "kind": "port", "ms_per_step": round(sec * 1e3, 3),
+           "cores": min(threads, L), "host_cores": nproc, "kind": "port",
+           "kind_detail": ("C/OpenMP restatement of the reference's scheduler step (oracle/sjd_oracle.c), NOT the reference's Python/ATen CPU "
+                           "path: that one measured 46.7 + 14.1 = 60.8 ms per step at 8 cores in the build container (SURVEY.md 8d)"),
+           "ms_per_step": round(sec * 1e3, 3),
            "sample": f"{n_it} SJD scheduler steps, V=65536, L={L}, CFG, top-k 2000 ({t_total:.1f} s of CPU work)"}
     if gpu_sched_ms:
         out["gpu_same_work_ms_per_step"] = round(gpu_sched_ms, 4)
@@ -300,11 +308,13 @@ def measure_scheduler_gpu(eng, grammar0, prompt, window, reps=200):
     g.start(ctx)
     rules = g.window_rules(window)
     cols = eng.logit_columns(rules)
-    logits = eng._graph_logits.get(("fwd", cols))
+    logits = eng.last_head_output(cols)
     if logits is None:
         return None
     resid = g.residual_rules([100] * window)
-    eng._fill_params(window, 100, True, 0, [], rules, resid)
+    import sjd_amd.ops as ops
+    step = ops.philox_step(window * eng.V, ops.philox_max_blocks(eng.device))
+    eng._fill_params(window, 100, True, 0, [], rules, resid, philox=(ops.philox_max_blocks(eng.device), 1234, 0, step, 2 * step))      # in-kernel noise, as the decode runs it
     ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(3):
         eng._sample_body(0, logits, cols)
@@ -328,6 +338,125 @@ def per_kv_table(iter_log, points, half=48):
     return out
 
 
+def workload_of(args, margs, rank, device, prompt_index=None):
+    """-> dict(prompt, spec, grammar, cfg, P, n_img, grid, workload, tau_est) of BASELINE.json's configs 2 / 3 / 5 for this rank (or for
+    prompt `prompt_index` of a queue: the seed then depends on the prompt, not on the rank that happens to decode it)"""
+    from sjd_amd.engine import SJDConfig
+    from sjd_amd.grammar import LuminaGrammar
+    from sjd_amd.frontends import lumina_window_spec, lumina_prompt
+    import sjd_amd.synthetic as synthetic
+    sd = rank if prompt_index is None else prompt_index
+    grid = 48
+    if args.model == "emu3_8b":
+        from sjd_amd.frontends import emu3_window_spec
+        from sjd_amd.grammar import Emu3Grammar
+        tok = dict(img_token=151851, eoi_token=151853, eos_token=151850, eol_token=151846, eof_token=151847, pad_token=151643)
+        Hh = Ww = 90                                        # 720x720 / 8 (reference test_emu3.py:121-122)
+        pos = synthetic.synthetic_prompt(63, 1234 + sd, lo=1000, hi=150000)[0].tolist() + [tok["img_token"]]
+        neg = synthetic.synthetic_prompt(11, 4321 + sd, lo=1000, hi=150000)[0].tolist() + [tok["img_token"]]
+        spec = emu3_window_spec(pos, neg, tok["pad_token"], device)
+        prompt = spec.first_tokens[0].tolist()
+        P, n_img = len(prompt), (Ww + 1) * Hh + 2
+        grammar = Emu3Grammar(Hh, Ww, 151854, 32768, top_k=2048, **tok)
+        cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=Hh * Ww - 1, max_num_new_tokens=args.window,
+                        guidance_scale=3.0, seed=1234 + sd, prefix_token_sampler_scheme="speculative_jacobi",
+                        max_length=P + n_img + 1, eos_token_ids=(tok["eos_token"],))
+        workload = f"Emu3-Gen 8B architecture 720x720 (90x91 visual tokens), pos/neg prompt CFG 3.0, top-k 2048, draft window {args.window}, fp16"
+    elif args.model == "anole7b":
+        from sjd_amd.grammar import AnoleGrammar
+        P, n_img = 64, 1024 + 1                              # 512x512 -> 32x32 VQ tokens + <eoi>; no line tokens (config 5)
+        prompt = synthetic.synthetic_prompt(P - 1, 1234 + sd, lo=9000, hi=60000)[0].tolist() + [8197]
+        spec = lumina_window_spec(prompt, device)
+        grammar = AnoleGrammar(margs.vocab_size, P, P + n_img, 1024)
+        cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=1024 - args.window - 2, max_num_new_tokens=args.window,
+                        guidance_scale=3.0, seed=1234 + sd, prefix_token_sampler_scheme="speculative_jacobi",
+                        max_length=P + n_img, eos_token_ids=(8196,))
+        workload = (f"Anole/Chameleon-7B architecture 512x512 (1024 image tokens, image-only grammar), draft window {args.window}, CFG 3.0, "
+                    f"top-k 2000, bf16")
+    else:
+        P = 64
+        n_img = grid * (grid + 1)
+        prompt = lumina_prompt(P, grid, grid, seed=1234 + sd)
+        spec = lumina_window_spec(prompt, device)
+        grammar = LuminaGrammar(2000, 10)
+        cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=grid * grid + grid - 10 - 3,
+                        max_num_new_tokens=args.window, guidance_scale=3.0, seed=1234 + sd,
+                        prefix_token_sampler_scheme="speculative_jacobi", max_length=P + n_img + 1, eos_token_ids=(8196,))
+        workload = (f"{'Lumina-mGPT-7B' if args.model == 'lumina7b' else args.model} 768x768, 1 prompt/GPU, draft window {args.window}, "
+                    f"CFG 3.0 (batch 2), top-k 2000, bf16")
+    return dict(prompt=prompt, spec=spec, grammar=grammar, cfg=cfg, P=P, n_img=n_img, grid=grid, workload=workload, tau_est=2.3)
+
+
+def roofline_blocks(args, prof, prof_g1):
+    """-> (roofline, roofline_k1 or None) from the live HIP-event measurements.  `traffic` is NOT measured in this run: it is the PMC figure
+    of the committed rocprofv3 --pmc pass at the same shapes (profiles/*_traffic.json), labelled as such, or null."""
+    peak = 8000.0
+
+    def traffic_of(fname):
+        if args.model != "lumina7b":
+            return None, None                   # the committed PMC traffic files were collected at the Lumina-7B shapes
+        tpath = os.path.join(ROOT, "profiles", fname)
+        try:
+            return json.load(open(tpath)).get("hbm_bytes_per_launch"), f"profiles/{fname} (builder's rocprofv3 --pmc pass at these shapes, not this run)"
+        except Exception:
+            return None, None
+
+    k1_block = g1_block = None
+    if prof is not None:
+        tr, src = traffic_of("k1_traffic.json")
+        k1_block = {"kernel": prof.get("kernel", "k1_partial (draft-window attention)"), "bound": "hbm", "achieved": round(prof["gbps"], 1),
+                    "peak": peak, "unit": "GB/s", "frac": round(prof["gbps"] / peak, 4), "traffic": tr, "traffic_source": src,
+                    "avg_us": round(prof["avg_ms"] * 1e3, 2), "avg_bytes": int(prof["avg_bytes"]),
+                    "avg_kv_rows": round(prof["avg_kv_rows"], 1), "launches": prof["launches"]}
+    if prof_g1 is not None:       # the dominant kernel by time (~70 % of an iteration)
+        g1_name = ("g1_skinny_gemm x3 + g1_gateup_silu (weight-streaming window projections, gate|up with SiLU*up as its epilogue; 128 launches / iteration)"
+                   if prof_g1.get("fused_mlp") else "g1_skinny_gemm (weight-streaming window projections, 128 launches / iteration)")
+        tr, src = traffic_of("g1_traffic.json")
+        g1_block = {"kernel": g1_name, "bound": "hbm", "achieved": round(prof_g1["gbps"], 1), "peak": peak, "unit": "GB/s",
+                    "frac": round(prof_g1["gbps"] / peak, 4), "traffic": tr, "traffic_source": src, "avg_us": round(prof_g1["avg_ms"] * 1e3, 2),
+                    "avg_bytes": int(prof_g1["avg_bytes"]), "launches": prof_g1["launches"]}
+    return (g1_block, k1_block) if g1_block is not None else (k1_block, None)
+
+
+def other_config(base_args, model_name, window, device, steps=64, warmup=8):
+    """Compact record of another BASELINE.json configuration measured in THIS run (configs 3 and 5 next to the headline's config 2):
+    the model is built, decoded through a real lead-in to its mean KV length, `steps` SJD iterations are timed, G1 and K1 are measured
+    with HIP events exactly as for the headline; then everything is freed."""
+    import copy
+    import gc
+    import torch
+    a = copy.copy(base_args)
+    a.model, a.window, a.dtype, a.kv, a.prompts_per_gpu, a.n_split = model_name, window, None, "auto", 1, 0
+    t0 = time.perf_counter()
+    from sjd_amd.engine import SJDEngine
+    import sjd_amd.ops as ops_
+    model, margs, attn = build_model(a, device)
+    w = workload_of(a, margs, 0, device)
+    P, n_img = w["P"], w["n_img"]
+    fp8_kv = model_name == "anole7b"
+    model.setup_cache(batch=2, s_max=((P + n_img + 2 * window + 64 + 31) // 32) * 32, dtype=ops_.FP8 if fp8_kv else None)
+    eng = SJDEngine(model, margs.vocab_size, device, max_window=window, use_graph=not a.no_graph)
+    lead = int(P + n_img // 2 - w["tau_est"] * (steps / 2.0 + warmup))
+    sync = torch.cuda.synchronize
+    seq, st = eng.decode(w["prompt"], w["spec"], w["grammar"], w["cfg"], warmup_iters=warmup, timed_iters=steps, on_timed_start=sync,
+                         on_timed_end=sync, lead_in_kv=lead if lead > P + window else None)
+    prof = measure_k1(a, model, attn, device, kv_len=(st.kv_len_start + st.kv_len) // 2)
+    prof_g1 = measure_g1(a, model, device)
+    r, rk1 = roofline_blocks(a, prof, prof_g1)
+    keep = ("kernel", "achieved", "frac", "avg_us", "avg_bytes", "launches", "avg_kv_rows")
+    out = {"workload": w["workload"] + (", fp8 (e4m3) KV cache + fp8-MFMA draft attention" if fp8_kv else ""),
+           "dtype": "fp16" if model.lm_head.weight.dtype == torch.float16 else "bf16", "steps": st.timed_nfe,
+           "ms_per_step": round(st.seconds / max(st.timed_nfe, 1) * 1e3, 4), "tokens_per_step": round(st.tokens / max(st.timed_nfe, 1), 4),
+           "tokens_per_s": round(st.tokens / max(st.seconds, 1e-9), 2), "kv_len": [st.kv_len_start, st.kv_len],
+           "timed_region_reached": bool(st.timed_region_reached),
+           "roofline": {k: r[k] for k in keep if r and k in r}, "roofline_k1": {k: rk1[k] for k in keep if rk1 and k in rk1}}
+    del eng, model, attn, seq
+    gc.collect()
+    torch.cuda.empty_cache()
+    out["wall_s"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -345,55 +474,20 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    from sjd_amd.parallel import gather_report, pin_to_gpu_numa_node, run_prompt_queue
+    pinned = None
+    if world > 1 and not args.no_pin:           # eight host loops, one sync every ~3 ms each: keep every rank on the cores next to its GPU
+        pinned = pin_to_gpu_numa_node(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), local_rank)
     if world > 1 or os.environ.get("SJD_FORCE_DIST") == "1":
         dist.init_process_group(backend="nccl", device_id=device)          # RCCL on ROCm
 
-    from sjd_amd.engine import SJDEngine, SJDConfig
-    from sjd_amd.grammar import LuminaGrammar
-    from sjd_amd.frontends import lumina_window_spec, lumina_prompt
-    from sjd_amd.parallel import gather_report
+    from sjd_amd.engine import SJDEngine
     import sjd_amd.synthetic as synthetic
 
     model, margs, attn = build_model(args, device)
-    grid = 48
-    tau_est = 2.3                                  # accepted tokens / step used only to place the lead-in
-    if args.model == "emu3_8b":
-        from sjd_amd.frontends import emu3_window_spec
-        from sjd_amd.grammar import Emu3Grammar
-        tok = dict(img_token=151851, eoi_token=151853, eos_token=151850, eol_token=151846, eof_token=151847, pad_token=151643)
-        Hh = Ww = 90                                        # 720x720 / 8 (reference test_emu3.py:121-122)
-        pos = synthetic.synthetic_prompt(63, 1234 + rank, lo=1000, hi=150000)[0].tolist() + [tok["img_token"]]
-        neg = synthetic.synthetic_prompt(11, 4321 + rank, lo=1000, hi=150000)[0].tolist() + [tok["img_token"]]
-        spec = emu3_window_spec(pos, neg, tok["pad_token"], device)
-        prompt = spec.first_tokens[0].tolist()
-        P, n_img = len(prompt), (Ww + 1) * Hh + 2
-        grammar = Emu3Grammar(Hh, Ww, 151854, 32768, top_k=2048, **tok)
-        cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=Hh * Ww - 1, max_num_new_tokens=args.window,
-                        guidance_scale=3.0, seed=1234 + rank, prefix_token_sampler_scheme="speculative_jacobi",
-                        max_length=P + n_img + 1, eos_token_ids=(tok["eos_token"],))
-        workload = f"Emu3-Gen 8B architecture 720x720 (90x91 visual tokens), pos/neg prompt CFG 3.0, top-k 2048, draft window {args.window}, fp16"
-    elif args.model == "anole7b":
-        from sjd_amd.grammar import AnoleGrammar
-        P, n_img = 64, 1024 + 1                              # 512x512 -> 32x32 VQ tokens + <eoi>; no line tokens (config 5)
-        prompt = synthetic.synthetic_prompt(P - 1, 1234 + rank, lo=9000, hi=60000)[0].tolist() + [8197]
-        spec = lumina_window_spec(prompt, device)
-        grammar = AnoleGrammar(margs.vocab_size, P, P + n_img, 1024)
-        cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=1024 - args.window - 2, max_num_new_tokens=args.window,
-                        guidance_scale=3.0, seed=1234 + rank, prefix_token_sampler_scheme="speculative_jacobi",
-                        max_length=P + n_img, eos_token_ids=(8196,))
-        workload = (f"Anole/Chameleon-7B architecture 512x512 (1024 image tokens, image-only grammar), draft window {args.window}, CFG 3.0, "
-                    f"top-k 2000, bf16")
-    else:
-        P = 64
-        n_img = grid * (grid + 1)
-        prompt = lumina_prompt(P, grid, grid, seed=1234 + rank)
-        spec = lumina_window_spec(prompt, device)
-        grammar = LuminaGrammar(2000, 10)
-        cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=grid * grid + grid - 10 - 3,
-                        max_num_new_tokens=args.window, guidance_scale=3.0, seed=1234 + rank,
-                        prefix_token_sampler_scheme="speculative_jacobi", max_length=P + n_img + 1, eos_token_ids=(8196,))
-        workload = (f"{'Lumina-mGPT-7B' if args.model == 'lumina7b' else args.model} 768x768, 1 prompt/GPU, draft window {args.window}, "
-                    f"CFG 3.0 (batch 2), top-k 2000, bf16")
+    w = workload_of(args, margs, rank, device)
+    prompt, spec, grammar, cfg, P, n_img, grid, workload = (w[k] for k in ("prompt", "spec", "grammar", "cfg", "P", "n_img", "grid", "workload"))
+    tau_est = w["tau_est"]                         # accepted tokens / step used only to place the lead-in
     s_max = ((P + n_img + 2 * args.window + 64 + 31) // 32) * 32
     fp8_kv = args.kv == "fp8" or (args.kv == "auto" and args.model == "anole7b")
     import sjd_amd.ops as ops_
@@ -405,6 +499,7 @@ def main():
         if args.model != "lumina7b" and args.model != "lumina_tiny":
             raise SystemExit("--prompts-per-gpu > 1 is wired for the Lumina workload")
         from sjd_amd.engine_batch import SJDBatchEngine
+        from sjd_amd.frontends import lumina_window_spec, lumina_prompt
         eng = SJDBatchEngine(model, margs.vocab_size, device, PP, max_window=args.window, use_graph=not args.no_graph)
         NQ = max(PP, args.queue_prompts)
         prompts = [lumina_prompt(P, grid, grid, seed=1234 + rank * NQ + i) for i in range(NQ)]
@@ -420,6 +515,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import copy
+    grammar0 = copy.deepcopy(grammar)              # pristine grammar for the side legs
+
+    # ---- config 4's shape: a queue of M prompts over the N ranks (the reference's fan-out), whole images, ONE all_gather
+    if args.total_prompts > 0:
+        if PP > 1:
+            raise SystemExit("--total-prompts decodes one prompt at a time per GPU (use --queue-prompts with --prompts-per-gpu)")
+        eng.decode(prompt, spec, copy.deepcopy(grammar0), cfg, warmup_iters=0, timed_iters=args.warmup + 8)      # untimed: graph captures, allocations
+        per_prompt = []
+
+        def decode_one(i):
+            wi = workload_of(args, margs, rank, device, prompt_index=i)
+            seq_i, st_i = eng.decode(wi["prompt"], wi["spec"], wi["grammar"], wi["cfg"])
+            per_prompt.append((i, st_i.total_tokens, st_i.nfe, bool(seq_i[-1] in wi["cfg"].eos_token_ids)))
+            return st_i.total_tokens, st_i.nfe
+
+        q = run_prompt_queue(args.total_prompts, decode_one, sync=torch.cuda.synchronize, device=device)
+        if rank == 0:
+            out = {"metric": "accepted image-tokens/s (SJD, whole images, prompt queue over the ranks; BASELINE.json config 4's shape)",
+                   "value": round(q["tokens_per_s"], 2), "unit": "image-tokens/s", "n_gpus": world, "steps": int(q["steps"]), "warmup": args.warmup,
+                   "ms_per_step": round(q["seconds"] / max(max(r[1] for r in q["per_rank"]), 1) * 1e3, 4), "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "fp16" if model.lm_head.weight.dtype == torch.float16 else "bf16",
+                   "data": "synthetic", "tokens_per_step": round(q["tokens_per_step"], 4),
+                   "config": {"workload": workload + f", queue of {args.total_prompts} prompts split contiguously over {world} rank(s), whole images, "
+                                          f"random-init synthetic weights (embed_token_scale={args.embed_token_scale})",
+                              "prompts": args.total_prompts, "parallelism": f"prompt-parallel x{world}", "prompt_len": P, "image_tokens": n_img},
+                   "per_rank": [{"tokens": int(r[0]), "steps": int(r[1]), "seconds": round(r[2], 4)} for r in q["per_rank"]],
+                   "rank0_prompts": [{"prompt": i, "tokens": t, "nfe": n, "finished": f} for i, t, n, f in per_prompt],
+                   "cpu_affinity_rank0": (f"{len(pinned)} cores of the GPU's NUMA node" if pinned else None)}
+            _print_line(out)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
+
     # ---- where the timed region sits
     kv_center = (P + n_img // 2) if args.kv_center < 0 else args.kv_center
     lead_in_kv = None
@@ -427,10 +556,8 @@ def main():
         lead_in_kv = int(kv_center - tau_est * (args.steps / 2.0 + args.warmup))
         if lead_in_kv <= P + args.window:
             lead_in_kv = None
-    whole_image = (world == 1 and PP == 1 and not args.no_whole_image)
+    whole_image = (PP == 1 and not args.no_whole_image)      # every rank decodes on to the end of ITS image: `value` is the whole-image rate
     iter_log = []
-    import copy
-    grammar0 = copy.deepcopy(grammar)              # pristine grammar for the side legs
     t_wall0 = time.perf_counter()
     if PP > 1:
         res = eng.decode_many(prompts, specs, [copy.deepcopy(grammar) for _ in range(len(prompts))], cfg, warmup_iters=args.warmup,
@@ -443,11 +570,19 @@ def main():
     else:
         seq, stats = eng.decode(prompt, spec, grammar, cfg, warmup_iters=args.warmup, timed_iters=args.steps, on_timed_start=sync_all,
                                 on_timed_end=sync_all, lead_in_kv=lead_in_kv, continue_after=whole_image, iter_log=iter_log)
+        if not stats.timed_region_reached:          # the image ended before the region opened: keep the other ranks' two barriers matched
+            sync_all()
+            sync_all()
     decode_wall = time.perf_counter() - t_wall0
     kv_mid = (stats.kv_len_start + stats.kv_len) // 2
     prof = measure_k1(args, model, attn, device, kv_len=kv_mid)
     prof_g1 = measure_g1(args, model, device) if (args.gemm == "sjd" and not args.no_fused) else None
-    rep = gather_report(stats.tokens, stats.timed_nfe, stats.seconds, device)   # one RCCL all_gather (24 B/rank)
+    # whole image of this rank: from the end of the prefill iteration to the last iteration (host clock after each iteration's sync)
+    img_tok = img_nfe = 0
+    img_s = 0.0
+    if whole_image and len(iter_log) > 1:
+        img_tok, img_nfe, img_s = stats.total_tokens - 1, stats.nfe - 1, iter_log[-1][3] - iter_log[0][3]
+    rep = gather_report(stats.tokens, stats.timed_nfe, stats.seconds, device, extra=(img_tok, img_nfe, img_s))   # ONE RCCL all_gather (48 B/rank)
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -455,14 +590,21 @@ def main():
     tot_tokens = sum(r[0] for r in rep)
     tot_steps = sum(r[1] for r in rep)
     t_max = max(r[2] for r in rep)
-    tps = tot_tokens / t_max
+    tps_window = tot_tokens / t_max
     tok_per_step = tot_tokens / max(tot_steps, 1)
     dt_name = "fp16" if model.lm_head.weight.dtype == torch.float16 else "bf16"
+    have_img = whole_image and all(r[5] > 0 for r in rep)
+    tps_image = sum(r[3] for r in rep) / max(r[5] for r in rep) if have_img else None
     out = {
         "metric": ("accepted image-tokens/s (SJD, Emu3 720px, BASELINE.json config 3)" if args.model == "emu3_8b"
                    else "accepted image-tokens/s (SJD, Anole/Chameleon-7B 512px, fp8 draft attention, BASELINE.json config 5)" if args.model == "anole7b"
                    else "accepted image-tokens/s (SJD, Lumina-mGPT-7B 768px); tokens_per_step = 1/steps-to-converge rate"),
-        "value": round(tps, 2), "unit": "image-tokens/s", "n_gpus": world, "steps": stats.timed_nfe, "warmup": args.warmup,
+        # value: every rank's WHOLE image (all its accepted tokens over the slowest rank's decode time) -- the K timed steps give
+        # ms_per_step, which does not depend on the acceptance luck of a short window; their tokens/s is value_window
+        "value": round(tps_image if have_img else tps_window, 2), "unit": "image-tokens/s",
+        "value_basis": ("whole image(s): sum over ranks of accepted tokens / slowest rank's decode time (prefill iteration excluded)" if have_img
+                        else "the timed steps"),
+        "value_window": round(tps_window, 2), "n_gpus": world, "steps": stats.timed_nfe, "warmup": args.warmup,
         "ms_per_step": round(t_max / max(stats.timed_nfe, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dt_name, "data": "synthetic",
         "tokens_per_step": round(tok_per_step, 4),
@@ -473,6 +615,10 @@ def main():
                    "lead_in_steps": 0,
                    "prompts": world * args.prompts_per_gpu, "parallelism": f"prompt-parallel x{world}"},
     }
+    if have_img:
+        out["whole_image_per_rank"] = [{"tokens": int(r[3]) + 1, "nfe": int(r[4]) + 1, "seconds": round(r[5], 4)} for r in rep]
+    if pinned:
+        out["cpu_affinity_rank0"] = f"{len(pinned)} cores of the GPU's NUMA node"
     if iter_log:       # untimed real SJD iterations before the W warm-up steps (kv_len grows strictly, so the region's first step is unique)
         i_start = next((i for i, r in enumerate(iter_log) if r[0] == stats.kv_len_start), args.warmup)
         out["config"]["lead_in_steps"] = max(0, i_start - args.warmup)
@@ -497,35 +643,11 @@ def main():
                 k1 = measure_k1(args, model, attn, device, kv_len=S)
                 out["per_kv"][str(S)].update({"k1_us": round(k1["avg_ms"] * 1e3, 2), "k1_GBps": round(k1["gbps"], 1)})
 
-    def traffic_of(fname):
-        if args.model != "lumina7b":
-            return None                     # the committed PMC traffic files were collected at the Lumina-7B shapes
-        tpath = os.path.join(ROOT, "profiles", fname)
-        if os.path.exists(tpath):
-            try:
-                return json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                return None
-        return None
-
-    peak = 8000.0
-    k1_block = None
-    if prof is not None:
-        k1_block = {"kernel": prof.get("kernel", "k1_partial (draft-window attention)"), "bound": "hbm", "achieved": round(prof["gbps"], 1),
-                    "peak": peak, "unit": "GB/s", "frac": round(prof["gbps"] / peak, 4), "traffic": traffic_of("k1_traffic.json"),
-                    "avg_us": round(prof["avg_ms"] * 1e3, 2), "avg_bytes": int(prof["avg_bytes"]),
-                    "avg_kv_rows": round(prof["avg_kv_rows"], 1), "launches": prof["launches"]}
-    if prof_g1 is not None:       # the dominant kernel by time (~60 % of an iteration)
-        g1_name = ("g1_skinny_gemm x3 + g1_gateup_silu (weight-streaming window projections, gate|up with SiLU*up as its epilogue; 128 launches / iteration)"
-                   if prof_g1.get("fused_mlp") else "g1_skinny_gemm (weight-streaming window projections, 128 launches / iteration)")
-        out["roofline"] = {"kernel": g1_name, "bound": "hbm",
-                           "achieved": round(prof_g1["gbps"], 1), "peak": peak, "unit": "GB/s", "frac": round(prof_g1["gbps"] / peak, 4),
-                           "traffic": traffic_of("g1_traffic.json"), "avg_us": round(prof_g1["avg_ms"] * 1e3, 2),
-                           "avg_bytes": int(prof_g1["avg_bytes"]), "launches": prof_g1["launches"]}
-        if k1_block is not None:
-            out["roofline_k1"] = k1_block
-    elif k1_block is not None:
-        out["roofline"] = k1_block
+    r_main, r_k1 = roofline_blocks(args, prof, prof_g1)
+    if r_main is not None:
+        out["roofline"] = r_main
+    if r_k1 is not None:
+        out["roofline_k1"] = r_k1
     side_legs = (world == 1 and PP == 1)
     gpu_sched_ms = None
     if side_legs and not args.no_graph:
@@ -557,18 +679,33 @@ def main():
         tb["what"] = ("reference data flow in PyTorch-ROCm ops (torch.cat KV cache, masked SDPA, torch.topk, torch.multinomial, Python "
                       "accept loop with a sync per draft), same weights, same KV length; tools/torch_sjd_baseline.py")
         # Both run the same algorithm on the same weights, so their expected accepted tokens/step are equal; the baseline's own 24-step
-        # sample of it is noisy, so the ratio is taken at the engine's measured acceptance: value / (tokens_per_step / baseline s/step)
+        # sample of it is noisy, so the ratio is taken per STEP: PyTorch-ROCm SJD ms/step over engine ms/step at the same KV length
         tb["tokens_per_s_at_engine_acceptance"] = round(tok_per_step / (tb["ms_per_step"] / 1e3), 2)
         out["torch_baseline"] = tb
-        out["vs_baseline"] = round(tps / tb["tokens_per_s_at_engine_acceptance"], 3)
-        out["vs_baseline_raw_tokens_per_s"] = round(tps / tb["tokens_per_s"], 3) if tb["tokens_per_s"] > 0 else None
-        out["vs_baseline_kind"] = ("value / torch_baseline.tokens_per_s_at_engine_acceptance = PyTorch-ROCm SJD ms/step over engine ms/step "
+        out["vs_baseline"] = round(tps_window / tb["tokens_per_s_at_engine_acceptance"], 3)
+        out["vs_baseline_raw_tokens_per_s"] = round(tps_window / tb["tokens_per_s"], 3) if tb["tokens_per_s"] > 0 else None
+        out["vs_baseline_kind"] = ("value_window / torch_baseline.tokens_per_s_at_engine_acceptance = PyTorch-ROCm SJD ms/step over engine ms/step "
                                    "(same GPU, weights, KV length; the reference publishes no number on stated hardware)")
     if side_legs and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, gpu_sched_ms)
+    if side_legs and not args.no_other_configs and args.model == "lumina7b":
+        # BASELINE.json configs 3 and 5 in the same driver-visible line (bounded: ~64 timed steps each after a real lead-in)
+        del eng
+        model.cache = None
+        torch.cuda.empty_cache()
+        out["other_configs"] = {}
+        for name, win in (("emu3_8b", 32), ("anole7b", 16)):
+            try:
+                out["other_configs"][name] = other_config(args, name, win, device)
+            except Exception as e:       # a side leg must not cost the headline line
+                out["other_configs"][name] = {"error": repr(e)[:300]}
     out["bench_wall_s"] = {"decode": round(decode_wall, 2)}
     if dist.is_initialized():
         dist.destroy_process_group()
+    _print_line(out)
+
+
+def _print_line(out):
     try:                                   # RCCL prints its version banner through C stdio: flush it so that the JSON line is the LAST line
         import ctypes
         ctypes.CDLL(None).fflush(None)

@@ -488,9 +488,9 @@ def teacher_forced_real_shape_check(family="lumina7b", device="cuda:0", prompt_l
         seq_ref, tr, checks = _replay(rec, prompt, rules_fn, _loop_cfg(cfg), V, no_cfg_fn=no_cfg, device=device)
     assert seq == seq_ref, "token sequences differ"
     assert stats.matched == tr.matched and stats.nfe == len(tr.matched)
-    graphs = [k for k in eng._graphs if isinstance(k, tuple) and k[0] == "fwd"]
+    graphs = eng.captured_column_windows()
     return dict(tokens=len(seq) - len(prompt), nfe=stats.nfe, accepted=sorted(set(stats.matched[1:])), n_split=model.attn.n_split,
-                fwd_graphs=len(graphs), head_cols=[k[1] for k in graphs])
+                fwd_graphs=len(graphs), head_cols=graphs)
 
 
 @torch.no_grad()

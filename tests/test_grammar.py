@@ -13,6 +13,10 @@ from oracle import sjd_oracle as O
 from sjd_amd import grammar as G
 
 
+import collections
+FAST_STATS = collections.defaultdict(lambda: [0, 0])     # grammar class -> [declined, taken]
+
+
 def same(r1, r2):
     a = bytes(ctypes.string_at(ctypes.byref(r1), ctypes.sizeof(r1)))
     b = bytes(ctypes.string_at(ctypes.byref(r2), ctypes.sizeof(r2)))
@@ -30,6 +34,11 @@ def check(gr, oracle_fn, ctx, n, win=None):
         for i in range(1, len(win)):
             assert same(res[i - 1], oracle_fn(ctx + win[1:i], 1)[0])
         assert all(same(a, b) for a, b in zip(gr.window_rules(n), want)), "residual_rules must not change the state"
+        if len(win) == n:       # the shortcut the single-graph iteration rests on: either it declines, or it IS the replayed result
+            fast = gr.fast_residual_rules(win, gr.window_rules(n))
+            FAST_STATS[type(gr).__name__][fast is not None] += 1
+            if fast is not None:
+                assert len(fast) == len(res) and all(same(a, b) for a, b in zip(fast, res)), (ctx[-6:], win)
 
 
 def test_lumina_grammar_random_contexts():
@@ -133,3 +142,25 @@ def test_spatial_init_schemes_copy_the_left_neighbour_inside_an_image_row():
     assert e.grid() == O.emu3_grid(ectx, 3, 5, 3000, 8192, 200) == (3, 5, 3000, 11192)
     with pytest.raises(ValueError):
         spatial_fresh_tokens("repeat_vertical", fresh, len(ctx), 102, 555, g.grid())
+
+
+def test_fast_residual_rules_are_taken_where_it_matters():
+    """the shortcut must actually fire for the image-body windows of a decode (drafts = image ids and forced line tokens) -- otherwise
+    every iteration silently falls back to the two-stage launch -- and it must equal the replayed rules there"""
+    rng = random.Random(5)
+    for trial in range(200):
+        hg, wg = rng.randint(1, 6), rng.randint(1, 6)
+        n_body = rng.randint(0, (2 * wg + 1) * 2 * hg - 2)
+        ctx = [rng.randint(8900, 9100) for _ in range(rng.randint(1, 8))] + [8197, 8804 + hg, 8804 + wg] + [rng.randint(4, 8195) for _ in range(n_body)]
+        n = rng.randint(2, 16)
+        win = [ctx[-1]] + [rng.choice([rng.randint(4, 8195), 8803]) for _ in range(n - 1)]
+        g = G.LuminaGrammar(2000, 10)
+        g.start(ctx)
+        fast = g.fast_residual_rules(win, g.window_rules(n))
+        assert fast is not None
+        assert all(same(a, b) for a, b in zip(fast, g.residual_rules(win)))
+    assert FAST_STATS["Emu3Grammar"][1] > 0 and FAST_STATS["Emu3Grammar"][0] > 0            # (tiny images: most windows cross the image end)
+    g = G.Emu3Grammar(90, 90, 151854, 32768, img_token=151851, eoi_token=151853, eos_token=151850, eol_token=151846, eof_token=151847, pad_token=151643)
+    g.start([5, 6, 151851] + [151900] * 4000)
+    assert g.fast_residual_rules([151900] * 32, g.window_rules(32)) is not None
+    assert FAST_STATS["LuminaGrammar"][1] > 0 and FAST_STATS["LuminaGrammar"][0] > 0        # both branches were compared with the replay

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sjd_amd.parallel import aggregate, contiguous_split, gather_report
+from sjd_amd.parallel import aggregate, contiguous_split, gather_report, gpu_numa_cpus, run_prompt_queue
 
 
 def _free_port():
@@ -32,12 +32,68 @@ def _worker(rank, world, port, n_prompts, q):
 
 
 def test_contiguous_split_covers_all_prompts():
-    for n in (0, 1, 7, 8, 9, 30):
-        for world in (1, 2, 4, 8):
-            parts = [contiguous_split(n, world, r) for r in range(world)]
-            flat = [i for lo, hi in parts for i in range(lo, hi)]
-            assert flat == list(range(n))
-            assert max(hi - lo for lo, hi in parts) - min(hi - lo for lo, hi in parts) <= (n + world - 1) // world
+    for scheme in ("balanced", "reference"):
+        for n in (0, 1, 7, 8, 9, 15, 30):
+            for world in (1, 2, 4, 8):
+                parts = [contiguous_split(n, world, r, scheme) for r in range(world)]
+                flat = [i for lo, hi in parts for i in range(lo, hi)]
+                assert flat == list(range(n))
+                if scheme == "balanced":
+                    assert max(hi - lo for lo, hi in parts) - min(hi - lo for lo, hi in parts) <= 1
+    # the reference's arithmetic (dataset_tools/multi_gpu_dataframe_split.py:55-61): floor-sized chunks, the last GPU takes the remainder
+    assert [contiguous_split(15, 8, r, "reference") for r in range(8)] == [(i, i + 1) for i in range(7)] + [(7, 15)]
+    assert [contiguous_split(15, 8, r) for r in range(8)] == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 12), (12, 14), (14, 15)]
+
+
+def test_gpu_numa_cpus_reads_sysfs(tmp_path):
+    dev = tmp_path / "bus/pci/devices/0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("3\n")
+    node = tmp_path / "devices/system/node/node3"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("48-51,176-177\n")
+    assert gpu_numa_cpus("0000:C1:00.0", str(tmp_path)) == [48, 49, 50, 51, 176, 177]
+    (dev / "numa_node").write_text("-1\n")
+    assert gpu_numa_cpus("0000:c1:00.0", str(tmp_path)) is None
+    assert gpu_numa_cpus("0000:99:00.0", str(tmp_path)) is None
+
+
+def _queue_worker(rank, world, port, n_prompts, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = []
+
+    def decode_one(i):             # stub engine: prompt i emits 100 + i tokens in 10 + i steps
+        seen.append(i)
+        return 100 + i, 10 + i
+
+    out = run_prompt_queue(n_prompts, decode_one)
+    q.put((rank, seen, out["shard"], out["tokens"], out["steps"], [r[:2] for r in out["per_rank"]], out["seconds"] >= max(r[2] for r in out["per_rank"]) - 1e-12))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_prompt_queue_world2_gloo():
+    """M = 5 prompts over 2 ranks: contiguous shards, every prompt decoded exactly once, ONE gathered report that both ranks agree on"""
+    world, n_prompts, port = 2, 5, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_queue_worker, args=(r, world, port, n_prompts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, seen0, shard0, tok0, st0, rep0, ok0), (r1, seen1, shard1, tok1, st1, rep1, ok1) = out
+    assert (seen0, seen1) == ([0, 1, 2], [3, 4]) and (shard0, shard1) == ((0, 3), (3, 5))
+    assert tok0 == tok1 == sum(100 + i for i in range(5)) and st0 == st1 == sum(10 + i for i in range(5))
+    assert rep0 == rep1 == [(303.0, 33.0), (207.0, 27.0)] and ok0 and ok1
+
+
+def test_prompt_queue_without_process_group():
+    out = run_prompt_queue(3, lambda i: (10, 2))
+    assert out["tokens"] == 30 and out["steps"] == 6 and out["shard"] == (0, 3) and out["world"] == 1
 
 
 def test_gather_report_world2_gloo():

@@ -7,11 +7,13 @@ keeps exactly the state machine of `SJDEngine.decode` -- its own window, accept 
 and CPU generator for the fresh ids -- so each slot takes the decisions its solo run would take on the same logits; only the
 transformer forward is shared:
 
-   host    per slot: n, fresh ids, rules -> its blob of a contiguous sjd_iter_params ARRAY (batch_rows = B_cfg: the kernels
-           K1 / K3 / F2 pick the blob of a batch row, i.e. every prompt has its own kv_len and n_rows), one H2D for all
-   graph 1 K5 per slot (window ids of that slot's batch rows), ONE backbone.forward_window over all slots' rows
-   graph 2 K2 + K4 per slot (own noise, own probability buffers)
-   host    one D2H of the state array, per-slot bookkeeping
+   host    per slot: n, fresh ids, rules, residual rules, its generator's seed / offsets -> its blob of a contiguous sjd_iter_params
+           ARRAY (batch_rows = B_cfg: the kernels K1 / K3 / F2 pick the blob of a batch row, i.e. every prompt has its own kv_len and
+           n_rows), one H2D for all
+   graph   K5 per slot (window ids of that slot's batch rows), ONE backbone.forward_window over all slots' rows with the output head as
+           split-K partials over the union of the slots' column windows, K2 (PART, in-kernel noise) + K4 per slot (own probability
+           buffers); ONE hipGraph when every slot's grammar names its residual rules up front (SJDEngine's two-stage launch otherwise)
+   host    one stream wait (every K4 wrote its state into pinned host memory), per-slot bookkeeping
 
 A slot that reaches its end token keeps riding along with a one-row dummy window (its tokens are ignored) until every slot is done.
 """
@@ -22,7 +24,8 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .engine import DecodeStats, SJDConfig, WindowSpec
+from .engine import DecodeStats, SJDConfig, WindowSpec, warn_no_grid
+from .grammar import spatial_fresh_tokens
 
 
 class _CacheView:
@@ -37,7 +40,7 @@ class _Slot:
 
 
 class SJDBatchEngine:
-    def __init__(self, backbone, vocab_size, device, n_prompts, max_window=16, n_batch=2, use_graph=True, narrow_head=True):
+    def __init__(self, backbone, vocab_size, device, n_prompts, max_window=16, n_batch=2, use_graph=True, narrow_head=True, head_partials=True):
         L.load()                                   # fail loudly if the HIP extension is missing
         if max_window > L.MAX_WINDOW:
             raise ValueError(f"max_window {max_window} > {L.MAX_WINDOW}")
@@ -56,11 +59,10 @@ class SJDBatchEngine:
             s.params, s.state = self.params.blobs[i], self.state.blobs[i]
             s.params.view.batch_rows = n_batch
             s.probs = torch.zeros(2, self.Lmax, self.V, dtype=torch.float32, device=dev)
-            s.noise = torch.ones(self.Lmax, self.V, dtype=torch.float32, device=dev)
-            s.rs = torch.zeros(self.Lmax, self.V, dtype=torch.float32, device=dev)
-            s.noise2 = torch.ones(1, self.V, dtype=torch.float32, device=dev)
+            s.noise = s.rs = s.noise2 = None        # only for observers (the parity tests' hook): K2 / K4 generate their noise
             s.scratch = torch.empty(self.V, dtype=torch.float32, device=dev)
             s.tokens_ptr = s.state.field_ptr("tokens")
+            s.amax_ptr = s.state.field_ptr("amax")
             self.slots.append(s)
         self.input_ids = torch.zeros(self.B, self.Lmax, dtype=torch.int64, device=dev)
         self.arange = torch.arange(self.Lmax, device=dev)
@@ -73,7 +75,9 @@ class SJDBatchEngine:
         self.kv_len_dev = self.params.dev.view(torch.int32)[off // 4::nb_params // 4]
         self.row_slot = torch.arange(self.B, device=dev) // n_batch
         self._guidance = 3.0
-        self.rng_stream = torch.cuda.Stream(device=dev)
+        # K2 reads the output head's split-K partials (no fp32 logits tensor) when the backbone can produce them
+        self.head_partials = bool(head_partials) and getattr(backbone, "supports_head_partials", False)
+        self._dbg = None                       # [B, L, V] logits as K2 derived them; allocated only for observers (hook)
         self.hook = None                       # test hook: called per slot and iteration with that slot's device tensors
         self._rule_bytes, self._rule_keep, self._cols_cache = {}, [], {}
         self.reset_graphs()
@@ -89,9 +93,21 @@ class SJDBatchEngine:
         SJDEngine._check_graph_buffers(self)
 
     # ------------------------------------------------------------------------------------------------
+    def _noise_tensors(self, s):
+        if s.noise is None:
+            dev = self.device
+            s.noise = torch.ones(self.Lmax, self.V, dtype=torch.float32, device=dev)
+            s.rs = torch.zeros(self.Lmax, self.V, dtype=torch.float32, device=dev)
+            s.noise2 = torch.ones(1, self.V, dtype=torch.float32, device=dev)
+
     def _fill(self, slot, n, kv_len, use_cfg, scheme, fresh, rules, resid):
+        """the slot's blob for one iteration, incl. the state of ITS device generator: K2 / K4 generate the multinomial / rand / residual
+        noise torch would have drawn from it (SJDEngine._fill_params); slot.ph_step = what one [n, V] draw consumes"""
         p = slot.params.view
         p.n_rows, p.kv_len, p.use_cfg, p.scheme, p.n_fresh = n, kv_len, int(use_cfg), scheme, len(fresh)
+        slot.ph_step = ops.philox_step(n * self.V, self._ph_blocks)
+        p.philox_blocks, p.philox_seed = self._ph_blocks, slot.ph_seed
+        p.philox_offset[0], p.philox_offset[1], p.philox_offset[2] = slot.ph_off, slot.ph_off + slot.ph_step, slot.ph_off + 2 * slot.ph_step
         if fresh:
             p.fresh_tok[:len(fresh)] = fresh
         self._write_rules(slot, L.IterParams.rules.offset, rules)
@@ -143,16 +159,33 @@ class SJDBatchEngine:
             lo, hi = i * self.nb, (i + 1) * self.nb
             ops.reguess(s.params, s.state, self.input_ids[lo:hi], pos_offset=self.pos_offset[lo:hi], positions_out=self.positions[lo:hi])
         positions = self.positions
+        if self.head_partials:
+            return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start, cols=cols, head_partials=True)
         if cols is None:
             return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start)
         return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start, cols=cols)
 
     def _sample_body(self, cur, logits, cols):
+        """K2 + K4 per slot, noise generated in the kernels.  With the output head as split-K partials every slot's K2 reads ITS rows of
+        the one G1 launch over the union column window (cond rows of batch row 2i, uncond rows of 2i + 1)."""
+        part = isinstance(logits, ops.HeadOut)
+        dbg = None
+        if part and self.hook is not None:
+            if self._dbg is None:
+                self._dbg = torch.zeros(self.B, self.Lmax, self.V, dtype=torch.float32, device=self.device)
+            dbg = self._dbg
+            dbg.zero_()
         for i, s in enumerate(self.slots):
-            lc = logits[i * self.nb]
-            lu = logits[i * self.nb + 1] if self.nb > 1 else None
-            ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, s.noise, s.probs[cur], s.tokens_ptr, col0=cols[0] if cols else 0)
-            ops.verify_accept(s.params, s.state, s.probs[cur], s.probs[1 - cur], s.rs, s.noise2[0], s.scratch, mirror=True)
+            if part:
+                ops.logits_to_probs_sample_part(logits, self._guidance, s.params, None, s.probs[cur], s.tokens_ptr, amax_out_ptr=s.amax_ptr,
+                                                dbg=None if dbg is None else dbg[i * self.nb:(i + 1) * self.nb], row0=i * self.nb * self.Lmax,
+                                                urow_off=self.Lmax if self.nb > 1 else 0)
+            else:
+                lc = logits[i * self.nb]
+                lu = logits[i * self.nb + 1] if self.nb > 1 else None
+                ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, None, s.probs[cur], s.tokens_ptr, col0=cols[0] if cols else 0,
+                                           amax_out_ptr=s.amax_ptr)
+            ops.verify_accept(s.params, s.state, s.probs[cur], s.probs[1 - cur], None, None, s.scratch, mirror=True)
 
     def _launch_forward(self, cols):
         if not self.use_graph:
@@ -170,9 +203,8 @@ class SJDBatchEngine:
         self._graphs[fkey].replay()
         return self._graph_logits[fkey]
 
-    def _launch_sample(self, cur, logits, noise_ready, cols):
-        torch.cuda.current_stream().wait_event(noise_ready)
-        key = (cur, self._guidance, cols)
+    def _launch_sample(self, cur, logits, cols):
+        key = (cur, self._guidance, cols, self.hook is not None)
         if not self.use_graph or ("fwd", cols) not in self._graphs:
             self._sample_body(cur, logits, cols)
             return
@@ -185,14 +217,46 @@ class SJDBatchEngine:
             return
         self._graphs[key].replay()
 
-    def _draw_noise(self, s, n_rows, scheme):
-        """the slot's three noise tensors, in the reference's order and shapes, from the slot's own device generator"""
-        s.g_state = None
+    def _launch_window(self, cur, cols):
+        """the whole iteration of all slots as ONE hipGraph per (column window, prob-buffer parity) -- SJDEngine._launch_window"""
+        if not self.use_graph:
+            logits = self._forward_body(cols)
+            self._sample_body(cur, logits, cols)
+            return logits
+        self._check_graph_buffers()
+        key = ("win", cols, cur, self._guidance, self.hook is not None)
+        if key not in self._graphs:
+            if self._eager_runs.get(key, 0) < 1:
+                self._eager_runs[key] = 1
+                logits = self._forward_body(cols)
+                self._sample_body(cur, logits, cols)
+                return logits
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                logits = self._forward_body(cols)
+                self._sample_body(cur, logits, cols)
+            self._graph_logits[key] = logits
+            self._graphs[key] = g
+        self._graphs[key].replay()
+        return self._graph_logits[key]
+
+    def captured_column_windows(self):
+        return sorted({k[1] for k in self._graphs if isinstance(k, tuple) and k[0] in ("fwd", "win")}, key=lambda c: (c is None, c))
+
+    def _upload_resid(self, s, resid):
+        """two-stage iterations: a slot's residual rules go up behind the forward, on the same stream (SJDEngine._upload_resid)"""
+        off = L.IterParams.resid_rules.offset
+        self._write_rules(s, off, resid)
+        L.check(L.load().sjd_upload_async(s.params.dev.data_ptr() + off, s.params.host.data_ptr() + off, s.params.nbytes - off, ops._stream()),
+                "sjd_upload_async")
+
+    def _observer_noise(self, s, n_rows, scheme):
+        """what the slot's kernels generate, drawn by torch from the same generator state -- for observers only (the parity tests' hook)"""
+        self._noise_tensors(s)
+        s.gen.set_offset(s.ph_off)
         s.noise[:n_rows].exponential_(generator=s.gen)
         if n_rows > 1 and scheme == 0:
             s.rs[:n_rows].uniform_(0.0, 1.0, generator=s.gen)
-            if s.gen is not None:
-                s.g_state = s.gen.get_state()
             s.noise2.exponential_(generator=s.gen)
 
     # ------------------------------------------------------------------------------------------------
@@ -208,13 +272,18 @@ class SJDBatchEngine:
         list is exhausted does a finished slot ride along with a one-row dummy window."""
         N = len(prompts)
         assert len(specs) == len(grammars) == N and N >= self.P
-        if cfg.multi_token_init_scheme != "random":
-            raise NotImplementedError("only multi_token_init_scheme='random' is parity-checkable")
+        if cfg.multi_token_init_scheme not in ("random", "repeat_horizon", "sample_horizon"):
+            raise ValueError(f"multi_token_init_scheme should be 'random', 'repeat_horizon' or 'sample_horizon', but got {cfg.multi_token_init_scheme}")
+        for g_ in grammars:
+            warn_no_grid(cfg, g_)
         if cfg.prefix_token_sampler_scheme not in ("speculative_jacobi", "jacobi"):
             raise ValueError(f"prefix_token_sampler_scheme: {cfg.prefix_token_sampler_scheme}")
         if cfg.max_num_new_tokens > self.Lmax:
             raise ValueError("max_num_new_tokens exceeds the engine's max_window")
         dev, nb = self.device, self.nb
+        self._ph_blocks = ops.philox_max_blocks(dev)
+        ph_row = ops.philox_step(self.V, self._ph_blocks)                  # offset step of a [1, V] draw
+        default_gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
         scheme = 0 if cfg.prefix_token_sampler_scheme == "speculative_jacobi" else 1
         do_cfg = cfg.do_cfg and (cfg.guidance_scale != 1)
         W = cfg.max_num_new_tokens
@@ -236,13 +305,14 @@ class SJDBatchEngine:
             s.X = [int(t) for t in prompts[j]]
             s.P = len(s.X)
             seed = (seeds[j] if seeds is not None else (None if cfg.seed is None else cfg.seed + j))
-            s.gen = None if seed is None else torch.Generator(dev).manual_seed(seed)
+            s.gen = default_gen if seed is None else torch.Generator(dev).manual_seed(seed)
+            s.ph_seed, s.ph_off = int(s.gen.initial_seed()), int(s.gen.get_offset())
             s.cpu_gen = None if seed is None else torch.Generator().manual_seed(seed)     # the prompt's "global CPU generator" (JL:505)
             s.grammar = grammars[j]
             s.grammar.start(s.X)
             s.l_abs, s.r_abs = s.P + cfg.jacobi_loop_interval_l, s.P + cfg.jacobi_loop_interval_r
             s.n, s.kv_len, s.cur_len, s.n_prev, s.m_prev = 1, specs[j].kv_base, s.P, 1, 1
-            s.carried, s.finished, s.harvested, s.stats = [], False, False, DecodeStats()
+            s.carried, s.carried_amax, s.last_amax, s.finished, s.harvested, s.stats = [], [], None, False, False, DecodeStats()
             s.t_admit = time.perf_counter()
             self.key_start[i * nb:(i + 1) * nb].copy_(specs[j].key_start.to(device=dev, dtype=torch.int32))
             self.pos_offset[i * nb:(i + 1) * nb].copy_(specs[j].pos_offset.to(device=dev, dtype=torch.int64))
@@ -252,7 +322,8 @@ class SJDBatchEngine:
             use_cfg = do_cfg and not s.grammar.force_no_cfg()
             self._fill(s, 1, s.kv_len, use_cfg, scheme, [], rules, [])
             s.params.upload()
-            self._draw_noise(s, 1, scheme)
+            if self.hook is not None:
+                self._observer_noise(s, 1, scheme)
             tokens, positions = specs[j].first_tokens.to(dev), specs[j].first_positions.to(dev)
             self.backbone.cache = _CacheView(full_cache, i * nb, (i + 1) * nb)
             try:
@@ -261,25 +332,28 @@ class SJDBatchEngine:
                 self.backbone.cache = full_cache
             lc = logits[0, -1:, :]
             lu = logits[1, -1:, :] if nb > 1 else None
-            ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, s.noise, s.probs[buf], s.tokens_ptr)
-            ops.verify_accept(s.params, s.state, s.probs[buf], s.probs[1 - buf], s.rs, s.noise2[0], s.scratch, mirror=True)
+            ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, None, s.probs[buf], s.tokens_ptr, amax_out_ptr=s.amax_ptr)
+            ops.verify_accept(s.params, s.state, s.probs[buf], s.probs[1 - buf], None, None, s.scratch, mirror=True)
+            s.ph_off += s.ph_step                                  # the [1, V] multinomial of iteration 0
             if self.hook is not None:
                 self.hook(j, dict(first=True, n_rows=1, logits_c=lc, logits_u=lu, use_cfg=use_cfg, rules=rules, resid=[],
                                   noise=s.noise[:1], rs=s.rs[:1], noise2=s.noise2[0], probs=s.probs[buf], prev_probs=s.probs[1 - buf],
                                   ctx=list(s.X), scheme=scheme))
+                s.gen.set_offset(s.ph_off)
             s.win_len = tokens.shape[1]
 
         def after_prefill(s):
             """host bookkeeping of iteration 0 (after the state download)"""
             nonlocal emitted_total
             y0 = int(s.state.view.tokens[0])
+            s.last_amax = int(s.state.view.amax[0])
             s.stats.matched.append(s.win_len)
             s.n = min(W, s.r_abs - s.cur_len) if (s.l_abs <= s.cur_len < s.r_abs) else 1
             s.X.append(y0)
             emitted_total += 1
             s.grammar.push([y0])
             s.kv_len += s.win_len
-            s.n_prev, s.m_prev, s.carried = 1, 1, []
+            s.n_prev, s.m_prev, s.carried, s.carried_amax = 1, 1, [], []
             s.stats.nfe += 1
             s.finished = s.X[-1] in cfg.eos_token_ids or len(s.X) >= cfg.max_length
             s.cur_len = len(s.X)
@@ -288,6 +362,7 @@ class SJDBatchEngine:
             s.harvested = True
             s.stats.wall_seconds = time.perf_counter() - s.t_admit
             s.stats.tokens, s.stats.timed_nfe, s.stats.kv_len = len(s.X) - s.P, s.stats.nfe, s.kv_len
+            s.gen.set_offset(s.ph_off)                             # leave the generator where the reference's draws would have left it
             results[s.prompt_index] = (s.X, s.stats)
 
         # ---------------- iteration 0 of the first P prompts ----------------
@@ -334,8 +409,9 @@ class SJDBatchEngine:
                 t0 = time.perf_counter()
                 ev0.record()
             t_h = time.perf_counter()
-            rule_lists, metas = [], []
+            rule_lists, metas, slow = [], [], []
             for s in self.slots:
+                resid, win = [], None
                 if s.finished:                                 # dummy one-row window: a forced row (K2 reads no logits), result ignored
                     n_rows, fresh, a = 1, [], 0
                     rules, use_cfg = [ops.make_rule(forced=0)], False
@@ -344,37 +420,49 @@ class SJDBatchEngine:
                     a = max(0, min(s.n_prev - s.m_prev, s.n - 1))
                     fr = torch.randint(0, cfg.img_vocab_n, (1, s.n - 1 - a), generator=s.cpu_gen)[0].tolist()
                     fresh = [cfg.img_vocab_lo + t for t in fr]
+                    if cfg.multi_token_init_scheme != "random":                      # spatial init (JL:516-594), as in SJDEngine.decode
+                        fresh = spatial_fresh_tokens(cfg.multi_token_init_scheme, fresh, len(s.X) + a, s.carried[a - 1] if a else s.X[-1],
+                                                     s.carried_amax[a - 1] if a else s.last_amax, s.grammar.grid())
                     rules = s.grammar.window_rules(n_rows)
                     use_cfg = do_cfg and not s.grammar.force_no_cfg()
                     rule_lists.append(rules)
-                self._fill(s, n_rows, s.kv_len, use_cfg, scheme, fresh, rules, [])
-                metas.append([n_rows, rules, [], use_cfg, a, fresh])
+                    if scheme == 0 and n_rows > 1:             # residual rules before the launch when the grammar can name them
+                        win = [s.X[-1]] + s.carried[:a] + fresh
+                        resid = s.grammar.fast_residual_rules(win, rules)
+                        if resid is None:
+                            slow.append((s, win, len(metas)))
+                self._fill(s, n_rows, s.kv_len, use_cfg, scheme, fresh, rules, resid or [])
+                metas.append([n_rows, rules, resid, use_cfg])
             self.params.upload()
-            self.rng_stream.wait_stream(torch.cuda.current_stream())       # the previous iteration is done with the noise buffers
             cols = self._columns(rule_lists) if rule_lists else None
-            host_s += time.perf_counter() - t_h
-            logits = self._launch_forward(cols)                             # everything below overlaps the forward
-            off = L.IterParams.resid_rules.offset
-            with torch.cuda.stream(self.rng_stream):
-                for s, mt in zip(self.slots, metas):
-                    n_rows, a, fresh = mt[0], mt[4], mt[5]
-                    if not s.finished and scheme == 0 and n_rows > 1:
-                        mt[2] = s.grammar.residual_rules([s.X[-1]] + s.carried[:a] + fresh)
-                        self._write_rules(s, off, mt[2])
-                        s.params.dev[off:].copy_(s.params.host[off:], non_blocking=True)
-                    self._draw_noise(s, n_rows, scheme)
-                noise_ready = self.rng_stream.record_event()
-            self._launch_sample(cur, logits, noise_ready, cols)
-            metas = [tuple(mt[:4]) for mt in metas]
             if self.hook is not None:
+                for s, mt in zip(self.slots, metas):
+                    self._observer_noise(s, mt[0], scheme)
+            host_s += time.perf_counter() - t_h
+            if slow:                                            # two stages: the missing residual rules are computed under the forward
+                logits = self._launch_forward(cols)
+                t_h = time.perf_counter()
+                for s, win, k in slow:
+                    metas[k][2] = s.grammar.residual_rules(win)
+                    self._upload_resid(s, metas[k][2])
+                host_s += time.perf_counter() - t_h
+                self._launch_sample(cur, logits, cols)
+            else:
+                logits = self._launch_window(cur, cols)
+            metas = [tuple(mt) for mt in metas]
+            if self.hook is not None:
+                part = isinstance(logits, ops.HeadOut)
                 for i, (s, (n_rows, rules, resid, use_cfg)) in enumerate(zip(self.slots, metas)):
                     if s.finished:
                         continue
-                    lg = logits[i * nb:(i + 1) * nb, :n_rows]
-                    if cols is not None:
-                        full = torch.zeros(nb, n_rows, self.V, dtype=logits.dtype, device=dev)
-                        full[:, :, cols[0]:cols[1]] = lg
-                        lg = full
+                    if part:                                   # the logits exactly as K2 derived them
+                        lg = self._dbg[i * nb:(i + 1) * nb, :n_rows]
+                    else:
+                        lg = logits[i * nb:(i + 1) * nb, :n_rows]
+                        if cols is not None:
+                            full = torch.zeros(nb, n_rows, self.V, dtype=logits.dtype, device=dev)
+                            full[:, :, cols[0]:cols[1]] = lg
+                            lg = full
                     self.hook(s.prompt_index, dict(first=False, n_rows=n_rows, logits_c=lg[0], logits_u=lg[1] if nb > 1 else None,
                                                    use_cfg=use_cfg, rules=rules, resid=resid, noise=s.noise[:n_rows], rs=s.rs[:n_rows],
                                                    noise2=s.noise2[0], probs=s.probs[cur], prev_probs=s.probs[1 - cur], ctx=list(s.X),
@@ -384,18 +472,22 @@ class SJDBatchEngine:
             sync_s += time.perf_counter() - t_s
             for s, (n_rows, _, _, _) in zip(self.slots, metas):
                 if s.finished:
+                    s.ph_off += s.ph_step                      # (the dummy row's draw: keeps blob and generator consistent; never observed)
                     continue
                 st = s.state.view
                 m_dev, rejected = int(st.m), bool(st.rejected)
                 if int(st.rejected) > 1:
                     raise RuntimeError("SJD verify: the residual distribution max(p - q, 0) is empty under the residual grammar rule")
-                if s.g_state is not None and not rejected:
-                    s.gen.set_state(s.g_state)
-                Y = [int(st.tokens[j]) for j in range(n_rows)]
+                draws_rs = n_rows > 1 and scheme == 0          # what torch would have consumed: multinomial [+ rand [+ residual multinomial]]
+                s.ph_off += s.ph_step * (2 if draws_rs else 1) + (ph_row if (draws_rs and rejected) else 0)
+                if self.hook is not None:
+                    s.gen.set_offset(s.ph_off)
+                Y = st.tokens[:n_rows]
+                A = st.amax[:n_rows]                           # modes of this iteration's target rows (K2 by-product)
                 if n_rows <= 1:
-                    m, emitted, s.carried = 1, [Y[0]], []
+                    m, emitted, s.carried, s.carried_amax, s.last_amax = 1, [Y[0]], [], [], A[0]
                 else:
-                    m, emitted, s.carried = m_dev, Y[:m_dev], Y[m_dev:]
+                    m, emitted, s.carried, s.carried_amax, s.last_amax = m_dev, Y[:m_dev], Y[m_dev:], A[m_dev:], A[m_dev - 1]
                 s.stats.matched.append(m)
                 s.n = min(W, s.r_abs - s.cur_len) if (s.l_abs <= s.cur_len < s.r_abs) else 1      # JL:1142-1144 (old cur_len)
                 s.X.extend(emitted)

@@ -277,6 +277,23 @@ class AnoleGrammar(_Grammar):
             self.boi_at.append(len(self.ctx))
         self.ctx.append(t)
 
+    def fast_residual_rules(self, win, rules):
+        # inside an image (a <boi> among the last L tokens, none exactly L + 1 back) every special token is suppressed and only image ids
+        # are allowed, whatever the position: as long as that holds for every context length a residual rule is evaluated at
+        # (cur .. cur + n - 2) and no draft is a <boi>, all of them are the window's rule
+        cur, n, L = len(self.ctx), len(win), self.L
+        if not self.boi_at or n < 2:
+            return None
+        b = self.boi_at[-1]
+        if b < cur - min(L, cur) or cur + n - 2 > b + L:
+            return None
+        if len(self.boi_at) > 1 and self.boi_at[-2] + L + 1 >= cur:
+            return None
+        for t in win[1:-1]:
+            if t == self.boi:
+                return None
+        return list(rules[:n - 1])
+
     def _allowed(self):
         ctx, cur, L = self.ctx, len(self.ctx), self.L
         offset = L + 1

@@ -322,19 +322,21 @@ class HeadOut:
         self.part, self.col0, self.urow_off, self.dtype, self.row_norm = part, int(col0), int(urow_off), dtype, row_norm
 
 
-def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr, dbg=None, amax_out_ptr=None):
+def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr, dbg=None, amax_out_ptr=None,
+                                row0=0, urow_off=None):
     """K2 reading the unmaterialised output head (see sjd_head_partials in include/sjd_hip.h).  dbg: optional fp32 [2, rows, V] that
-    receives the logits K2 derived (cond, uncond) -- observers only."""
+    receives the logits K2 derived (cond, uncond) -- observers only.  row0 / urow_off: this launch's cond rows start at partial row
+    `row0` and its uncond rows `urow_off` rows further (several prompts share one head launch: SJDBatchEngine)."""
     max_rows, V = probs_out.shape
     p = head.part
     hp = L.HeadPartials()
-    hp.part, hp.n_chunks = p.data.data_ptr(), p.n_chunks
+    hp.part, hp.n_chunks = p.data.data_ptr() + 4 * int(row0) * p.N, p.n_chunks
     hp.row_stride, hp.chunk_stride = p.N, p.data.shape[1] * p.N
-    hp.col0, hp.n_cols, hp.urow_off = head.col0, p.N, head.urow_off
+    hp.col0, hp.n_cols, hp.urow_off = head.col0, p.N, head.urow_off if urow_off is None else int(urow_off)
     hp.round_dtype = _dtype_code(head.dtype)
     if head.row_norm is not None:
         sumsq, hidden, eps = head.row_norm
-        hp.row_sumsq, hp.slices, hp.prows, hp.inv_hidden, hp.eps = sumsq.data_ptr(), sumsq.shape[0], sumsq.shape[1], 1.0 / float(hidden), float(eps)
+        hp.row_sumsq, hp.slices, hp.prows, hp.inv_hidden, hp.eps = sumsq.data_ptr() + 4 * int(row0), sumsq.shape[0], sumsq.shape[1], 1.0 / float(hidden), float(eps)
     if dbg is not None:
         assert dbg.dtype == torch.float32 and dbg.is_contiguous() and dbg.shape[0] == 2 and dbg.shape[2] == V and dbg.shape[1] >= max_rows
         hp.dbg_c, hp.dbg_u = dbg[0].data_ptr(), dbg[1].data_ptr()

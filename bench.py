@@ -566,6 +566,7 @@ def main():
         rs = eng.run_stats                                       # all slots of this GPU; steps = shared window forwards
         stats.tokens, stats.timed_nfe, stats.seconds = rs["tokens"], rs["timed_iterations"], rs["seconds"]
         stats.host_seconds, stats.sync_seconds = rs["host_seconds"], rs["sync_seconds"]
+        stats.timed_host_seconds, stats.timed_sync_seconds = rs["host_seconds"], rs["sync_seconds"]
         stats.kv_len_start = P
     else:
         seq, stats = eng.decode(prompt, spec, grammar, cfg, warmup_iters=args.warmup, timed_iters=args.steps, on_timed_start=sync_all,

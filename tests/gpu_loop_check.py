@@ -537,4 +537,4 @@ def teacher_forced_real_shape_batch_check(device="cuda:0", n_prompts=4, prompt_l
         assert stats.matched == tr.matched, f"slot {i}: accept lengths differ"
         out.append(dict(tokens=len(seq) - len(prompts[i]), nfe=stats.nfe, max_accept=max(stats.matched[1:])))
         recs[i].items.clear()
-    return dict(slots=out, n_split=model.attn.n_split, fwd_graphs=len([k for k in eng._graphs if isinstance(k, tuple) and k[0] == "fwd"]))
+    return dict(slots=out, n_split=model.attn.n_split, fwd_graphs=len(eng.captured_column_windows()))

@@ -106,6 +106,19 @@ def test_anole_grammar():
         except ValueError:
             continue
         check(G.AnoleGrammar(V, P, maxlen, Lseq), lambda c, k: O.anole_rules(c, k, V, P, maxlen, Lseq), ctx, n, None)
+        # residual rules (replayed, and the shortcut where it applies) against the oracle evaluated on ctx + win[1:i]
+        g = G.AnoleGrammar(V, P, maxlen, Lseq)
+        g.start(ctx)
+        try:
+            want_res = [O.anole_rules(ctx + win[1:i], 1, V, P, maxlen, Lseq)[0] for i in range(1, n)]
+        except ValueError:
+            continue
+        res = g.residual_rules(win)
+        assert all(same(a, b) for a, b in zip(res, want_res))
+        fast = g.fast_residual_rules(win, g.window_rules(n))
+        FAST_STATS["AnoleGrammar"][fast is not None] += 1
+        if fast is not None:
+            assert len(fast) == len(want_res) and all(same(a, b) for a, b in zip(fast, want_res)), (ctx, win)
 
 
 def test_grammars_on_golden_contexts(golden_dir):
@@ -164,3 +177,4 @@ def test_fast_residual_rules_are_taken_where_it_matters():
     g.start([5, 6, 151851] + [151900] * 4000)
     assert g.fast_residual_rules([151900] * 32, g.window_rules(32)) is not None
     assert FAST_STATS["LuminaGrammar"][1] > 0 and FAST_STATS["LuminaGrammar"][0] > 0        # both branches were compared with the replay
+    assert FAST_STATS["AnoleGrammar"][1] > 20 and FAST_STATS["AnoleGrammar"][0] > 20

@@ -36,6 +36,9 @@ import os as _os
 # 27.0 / 33.7 us at kv_len 64 / 448 / 1216 / 2368).  Default off; SJD_K1_FUSED=1 or model.k1_fused = True selects it.
 _K1_FUSED_DEFAULT = _os.environ.get("SJD_K1_FUSED", "0") == "1"
 _GATEUP_FUSED_DEFAULT = _os.environ.get("SJD_GATEUP_FUSED", "1") != "0"     # kernel G1s (gate|up + F3 in one launch); 0: G1 then F3
+# round 3: the o / down projections of a <= 32-row window reduce their own split-K planes, add the residual and write the row statistics
+# in their tail (sjd_skinny_gemm_reduce): stage F1r -- two graph nodes per layer -- disappears, h and the statistics keep their bits.  0: G1 then F1r
+_REDUCE_FUSED_DEFAULT = _os.environ.get("SJD_REDUCE_FUSED", "1") != "0"
 
 
 def _head_logits(linear, x, cols):
@@ -454,11 +457,13 @@ class ChameleonBackbone(nn.Module):
     HEAD_CFG = (1024, 4, True)         # G1 launch shape of the output head: (split-K chunk, column tiles per workgroup, step-major)
     supports_head_partials = True
 
-    def _head_partials(self, h, delta, cols, n):
+    def _head_partials(self, h, delta, cols, n, sumsq=None):
         """final residual add + the output head as G1 split-K partials over the column window `cols` -> ops.HeadOut (K2 applies the folded
-        final RMSNorm as a row scale and the 16-bit rounding of the lm_head output while it reads them)"""
+        final RMSNorm as a row scale and the 16-bit rounding of the lm_head output while it reads them).  sumsq: the statistics of h when the
+        last down projection already did the residual add (its reducing tail)"""
         ops, hid = self._ops, self.args.hidden_size
-        sumsq = ops.residual_sumsq(h, delta)
+        if sumsq is None:
+            sumsq = ops.residual_sumsq(h, delta)
         lo, hi = cols if cols is not None else (0, self.vocab_size)
         lo32, hi32 = (lo // 32) * 32, min(self._head_cols, ((hi + 31) // 32) * 32)
         part = ops.skinny_gemm_cols(h, self._packed_head, self._head_cols, hid, self.HEAD_CFG[0], lo32, hi32 - lo32, self.HEAD_CFG[1], self.HEAD_CFG[2])
@@ -493,24 +498,37 @@ class ChameleonBackbone(nn.Module):
         H, Hkv, D, hid, inter = self.n_heads, self.n_kv_heads, self.head_dim, self.args.hidden_size, self.args.intermediate_size
         params = getattr(self.attn, "params", None)
         fuse_mlp = getattr(self, "gateup_fused", _GATEUP_FUSED_DEFAULT) and not self._pf_on and ops.gateup_silu_ok(T, inter, hid, cfg["gate_up"][0])
+        # o / down with F1r as their tail (one launch each; the reducing kernel wants whole 512-column slices per workgroup pair: 8 waves)
+        red = getattr(self, "reduce_fused", _REDUCE_FUSED_DEFAULT) and not self._pf_on
+        red_o = red and ops.skinny_gemm_reduce_ok(T, hid, H * D, cfg["o"][0], 8, h_dev := self.lm_head.weight.device)
+        red_d = red and ops.skinny_gemm_reduce_ok(T, hid, inter, cfg["down"][0], 8, h_dev)
         h = self.model.embed_tokens(tokens).view(T, -1).contiguous()
         pos = positions.reshape(T).contiguous()
-        delta = None
+        delta, ss_next = None, None         # the down projection's split-K planes (summed by the next F1r), or the statistics its tail already wrote
         for li, layer in enumerate(self.model.layers):
             a = layer.self_attn
-            rn = (ops.residual_sumsq(h, delta), hid, eps)
+            rn = (ss_next if ss_next is not None else ops.residual_sumsq(h, delta), hid, eps)
             qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
             o = self._attention_block(g1(h, "qkv", (H + 2 * Hkv) * D, hid), li, qn, pos, B, n, params, kv_len, key_start, row_norm=rn)
-            rn = (ops.residual_sumsq(h, g1(o.view(T, H * D), "o", hid, H * D)), hid, eps)
+            if red_o:
+                rn = (ops.skinny_gemm_reduce(o.view(T, H * D), self._packed[li]["o"], hid, H * D, cfg["o"][0], h, 8, cfg["o"][2]), hid, eps)
+            else:
+                rn = (ops.residual_sumsq(h, g1(o.view(T, H * D), "o", hid, H * D)), hid, eps)
             if fuse_mlp:       # G1s: gate|up with SiLU * up as its epilogue (one launch, no partial planes, bit-identical to G1 + F3)
                 act = ops.gateup_silu(h, self._packed[li]["gate_up"], inter, hid, cfg["gate_up"][2], row_norm=rn)
             else:
                 act = ops.silu_mul(g1(h, "gate_up", 2 * inter, hid), rows=T, dtype=h.dtype, row_norm=rn)
-            delta = g1(act, "down", hid, inter)
+            if red_d:
+                delta, ss_next = None, ops.skinny_gemm_reduce(act, self._packed[li]["down"], hid, inter, cfg["down"][0], h, 8, cfg["down"][2])
+            else:
+                delta, ss_next = g1(act, "down", hid, inter), None
         self._prefetch_join()
         if head_partials and self._packed_head is not None:
-            return self._head_partials(h, delta, cols, n)
-        x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
+            return self._head_partials(h, delta, cols, n, sumsq=ss_next)
+        if ss_next is not None:             # (h already holds the last residual add)
+            x = ops.add_rmsnorm(h, None, self.model.norm.weight, eps)
+        else:
+            x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
         return _head_logits(self.lm_head, x, cols).view(B, n, -1)
 
     def _forward_window_g1(self, tokens, positions, kv_len, key_start, cols=None):

@@ -61,16 +61,110 @@ template <> struct G1Mfma<SJD_DTYPE_F16> {
     { return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); }
 };
 
+// ---- F1r inside the producer (round 3; VERDICT r2 "next #3", the experiment DESIGN.md 4.6 item 6 stopped short of).
+// Every workgroup of an o / down launch has written its fp32 partial tile with device-coherent stores.  The workgroups that share a
+// 512-column SLICE of the output (16 / waves column groups x n_chunks K chunks: 16 for o, 26 for down) then meet at a ticket in device
+// memory and each reduces a few ROWS of the slice: the chunk planes are read back with device-coherent 16-byte loads (all of them in
+// flight at once), summed in chunk order, rounded, added to the residual stream h and squared -- F1r's arithmetic element by element
+// (sjd_mlp_epilogue.h), one wave per (row, 256-column half) exactly as F1r's two waves, so h AND the per-slice sums of squares are
+// bit-identical to G1 followed by F1r.  No L2 write-back / invalidate anywhere (that costs 14 us): coherence is per access.
+// tools/last_arriver_probe.hip measured the scheme against the two graph nodes before it was built: o 19.3 -> 11.1 us, down 25.1 -> 20.4 us
+// per pair (a last-arriver-does-all variant without the wait: 14.2 / 23.8), profiles/r3_last_arriver_probe.jsonl.
+// The wait is bounded: all workgroups of a launch (<= 208) are resident at once on the 256 CUs, so the count completes within the
+// launch; if it ever does not (a partitioned or shared GPU), the workgroup goes on after ~2^21 polls and raises g1_red_timeouts, which
+// the host reads (sjd_reduce_timeouts) -- an error, not a hang.  The ticket resets itself: the launch is replayable from a hipGraph.
+__device__ unsigned g1_red_timeouts;
+
+template <int DT>
+__device__ __forceinline__ void g1_reduce_tail(const float *__restrict__ part, unsigned short *__restrict__ h, float *__restrict__ sumsq,
+                                               unsigned *__restrict__ ticket, int M, int N, int C, int chunk, int group, int n_waves)
+{
+    typedef __attribute__((ext_vector_type(4))) float f32x4_;
+    __shared__ float red[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gps = 16 / n_waves;                       // column groups per 512-column slice (n_waves in {1, 2, 4, 8, 16})
+    const int slice = group / gps;
+    const unsigned total = (unsigned)(gps * C);
+    unsigned *tk = ticket + 32 * slice;                 // [0]: arrivals, [16]: departures (another 64-byte line)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this thread's plane stores are acknowledged (gfx9 counts stores there)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned a = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        int spins = 0;
+        while (a < total && spins < (1 << 21)) { a = __hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ++spins; }
+        if (a < total) atomicAdd(&g1_red_timeouts, 1u);
+    }
+    __syncthreads();
+    const int idx = (group % gps) * C + chunk;          // this workgroup among the slice's `total`
+    const int per = (32 + (int)total - 1) / (int)total; // rows per workgroup
+    const int row = idx * per + (w >> 1), half = w & 1;
+    const bool work = (w < 2 * per) && (idx * per + (w >> 1) < 32) && row < M && (w >> 1) < per;
+    float ss = 0.f;
+    if (work) {
+        const int col = slice * 512 + half * 256 + 4 * lane;
+        const float *p0 = part + (size_t)row * N + col;
+        const size_t cstride = (size_t)32 * N;
+        f32x4_ v[16];
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) v[ch] = f32x4_{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch)
+            if (ch < C) __asm__ volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[ch]) : "v"(p0 + (size_t)ch * cstride) : "memory");
+        unsigned short *hp = h + (size_t)row * N + col;
+        const uint2 hv = *reinterpret_cast<const uint2 *>(hp);
+        // the loads above are invisible to the compiler's counters: wait for all of them, and make every use of v[] depend on the wait
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                           "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                         :: "memory");
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch)
+            if (ch < C) { d0 += v[ch].x; d1 += v[ch].y; d2 += v[ch].z; d3 += v[ch].w; }
+        const float hx[4] = {SjdAct<DT>::to_f((unsigned short)(hv.x & 0xffffu)), SjdAct<DT>::to_f((unsigned short)(hv.x >> 16)),
+                             SjdAct<DT>::to_f((unsigned short)(hv.y & 0xffffu)), SjdAct<DT>::to_f((unsigned short)(hv.y >> 16))};
+        const float dd[4] = {d0, d1, d2, d3};
+        unsigned short ob[4];
+        float hn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ob[j] = sjd_residual_elem<DT>(hx[j], dd[j]); hn[j] = SjdAct<DT>::to_f(ob[j]); }
+        uint2 ho;
+        ho.x = (unsigned)ob[0] | ((unsigned)ob[1] << 16);
+        ho.y = (unsigned)ob[2] | ((unsigned)ob[3] << 16);
+        *reinterpret_cast<uint2 *>(hp) = ho;
+        ss = sjd_sumsq4(0.f, hn[0], hn[1], hn[2], hn[3]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);       // wave_sum of sjd_glue.hip
+    if (lane == 0 && w < 16) red[w] = ss;
+    __syncthreads();
+    if ((int)threadIdx.x < per) {
+        const int r = idx * per + (int)threadIdx.x;
+        if (r < 32 && r < M) sumsq[(size_t)slice * 32 + r] = red[2 * threadIdx.x] + red[2 * threadIdx.x + 1];     // F1r: red[0] + red[1]
+    }
+    if (threadIdx.x == 0) {      // departures: the last one out re-arms the ticket for the next launch (everybody has passed the wait by then)
+        const unsigned dp = __hip_atomic_fetch_add(tk + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (dp == total) {
+            __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tk + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // x: [M, K] row-major (M <= 32*MT; missing rows read as zero).  wp: packed weights.  out: fp32 [n_chunks, 32*MT, N].
 // MT = 2 serves a 64-row window (B_cfg * L with a draft window of 32): every weight record feeds two MFMAs.
 // Column window: the launch covers tiles [tile0, tile0 + N/32) of a weight packed with `n_tiles` tiles (N = columns of THIS launch's
 // output): the output head is evaluated only for the vocabulary columns the grammar allows out of one packed copy.
 // MAXT: 512 (<= 8 waves: 256 VGPRs, sixteen activation pieces per thread in flight -> a 2048-column chunk is staged in ONE round trip)
 // or 1024 (9..16 waves, eight pieces).
-template <int DT, int MT, int MAXT>
+// RED (round 3, MT = 1): the split-K reduction, the residual add and the row statistics -- stage F1r, until now a graph node of its own
+// behind every o / down projection -- run in the TAIL of this kernel (g1_reduce_tail below).
+template <int DT, int MT, int MAXT, bool RED = false>
 __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                 float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
-                                                                int rec_stride, int tile0, int n_waves)
+                                                                int rec_stride, int tile0, int n_waves,
+                                                                unsigned short *__restrict__ red_h = nullptr, float *__restrict__ red_sumsq = nullptr,
+                                                                unsigned *__restrict__ red_ticket = nullptr)
 {
     // n_waves = blockDim.x / 64 as an ARGUMENT: blockDim lives in the implicit kernel arguments, which are not preloaded into SGPRs -- the
     // kernel opened with an s_load round trip for it in front of every address it computes (ISA, late round 2)
@@ -189,6 +283,14 @@ __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__r
     SJD_TR(4);                    // main loop done
     // D[m][n]: reg r of lane l -> row m = (r&3) + 8*(r>>2) + 4*(l>>5), column n = 32t + (l&31): 128-B coalesced rows
     float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t_out * 32 + (lane & 31);
+    if constexpr (RED) {
+        static_assert(MT == 1, "the reducing epilogue serves the <= 32-row window");
+#pragma unroll
+        for (int r = 0; r < 16; ++r)          // the plane goes out DEVICE-COHERENT (sc1: written through this XCD's L2)
+            __hip_atomic_store(o + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * N, acc[0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g1_reduce_tail<DT>(out, red_h, red_sumsq, red_ticket, M, N, (int)gridDim.y, chunk, (int)blockIdx.x, n_waves);
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -653,6 +755,45 @@ extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, 
     if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
     if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
     return SJD_ERR_UNSUPPORTED;
+}
+
+// G1 with F1r as its tail (see g1_reduce_tail): h [M, N] += dtype(x @ W^T) in place, sumsq [N / 512, 32] = per-slice sums of h^2 -- what
+// sjd_skinny_gemm followed by sjd_residual_sumsq computes, bit for bit, in one launch.  `workspace`: fp32 [n_chunks, 32, N] (the planes
+// still travel through memory, device-coherently); `ticket`: N / 512 * 32 zero-initialised uint32 that must not be shared with a launch
+// that can run concurrently (it re-arms itself).  M <= 32, N % 512 == 0, waves in {1, 2, 4, 8, 16} with (N / 32) % waves == 0, at most 16
+// K chunks, and every workgroup of the launch must be resident at once: grid <= resident_limit (the caller passes what the device holds).
+extern "C" int sjd_skinny_gemm_reduce(const void *x, const void *w_packed, float *workspace, void *h, float *sumsq, unsigned *ticket, int M, int N,
+                                      int K, int KC, int waves, int step_major, int dtype, int resident_limit, void *stream)
+{
+    if (!x || !w_packed || !workspace || !h || !sumsq || !ticket || M < 1 || M > 32 || N < 512 || (N % 512) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0)
+        return SJD_ERR_BAD_ARG;
+    if (!(waves == 1 || waves == 2 || waves == 4 || waves == 8) || ((N / 32) % waves) != 0) return SJD_ERR_UNSUPPORTED;
+    const int n_chunks = (K + KC - 1) / KC, n_out = N / 32;
+    if (n_chunks > 16) return SJD_ERR_UNSUPPORTED;
+    const dim3 grid(n_out / waves, n_chunks), block(waves * 64);
+    if ((int)(grid.x * grid.y) > resident_limit) return SJD_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)((KC < K ? KC : K) / 16) * 64 * 16;
+    if (lds > 160 * 1024) return SJD_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int rs = step_major ? n_out : 1;
+    if (dtype == SJD_DTYPE_BF16) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<SJD_DTYPE_BF16, 1, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((g1_skinny_gemm<SJD_DTYPE_BF16, 1, 512, true>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, workspace,
+                           M, N, K, KC, n_out, rs, 0, waves, (unsigned short *)h, sumsq, ticket);
+    } else if (dtype == SJD_DTYPE_F16) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<SJD_DTYPE_F16, 1, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((g1_skinny_gemm<SJD_DTYPE_F16, 1, 512, true>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, workspace,
+                           M, N, K, KC, n_out, rs, 0, waves, (unsigned short *)h, sumsq, ticket);
+    } else return SJD_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+// workgroups of a reducing launch that gave up waiting for their slice's ticket since the library was loaded (0 on a healthy device)
+extern "C" int sjd_reduce_timeouts(void)
+{
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g1_red_timeouts), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)v;
 }
 
 #ifdef SJD_TRACE

@@ -250,8 +250,7 @@ __global__ __launch_bounds__(128) void f1r_residual_sumsq(unsigned short *__rest
             unsigned short o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float dj = Cvt<DT>::to_f(Cvt<DT>::from_f(dd[j]));                   // projection output rounds to the activation dtype
-                o[j] = Cvt<DT>::from_f(hx[j] + dj);                                       // residual add rounds too
+                o[j] = sjd_residual_elem<DT>(hx[j], dd[j]);      // projection output rounds to the activation dtype, the residual add again
                 hx[j] = Cvt<DT>::to_f(o[j]);
             }
             uint2 ho;
@@ -259,8 +258,7 @@ __global__ __launch_bounds__(128) void f1r_residual_sumsq(unsigned short *__rest
             ho.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
             *reinterpret_cast<uint2 *>(hp) = ho;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ss += hx[j] * hx[j];
+        ss = sjd_sumsq4(ss, hx[0], hx[1], hx[2], hx[3]);      // (shared with the reducing epilogue of G1: sjd_mlp_epilogue.h)
     }
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;

@@ -53,3 +53,26 @@ __device__ __forceinline__ unsigned short sjd_silu_mul_elem_rounded(float gv, fl
     const float pr = sv * uv;
     return SjdAct<DT>::from_f(pr);
 }
+
+// ---- F1r's element arithmetic (residual add of a projection's summed fp32 partials, then the row statistics), shared by f1r_residual_sumsq
+// (sjd_glue.hip, its own graph node) and the reducing epilogue of g1_skinny_gemm (sjd_gemm.hip, round 3): same bits from both
+// (tests/test_gpu_glue.py::test_g1_reduce_epilogue_matches_g1_then_f1r).  hx: the residual stream element (already in the activation
+// dtype), d: the projection's fp32 sum over the K chunks in chunk order.  -> bits of dtype(hx + dtype(d)): the projection output rounds
+// to the activation dtype, the residual add rounds again (reference modeling_chameleon.py:637, 643).
+template <int DT>
+__device__ __forceinline__ unsigned short sjd_residual_elem(float hx, float d)
+{
+#pragma clang fp contract(off)
+    const float dj = SjdAct<DT>::to_f(SjdAct<DT>::from_f(d));
+    const float s = hx + dj;
+    return SjdAct<DT>::from_f(s);
+}
+
+// ss + x0^2 + x1^2 + x2^2 + x3^2, left to right, products and sums rounded separately
+__device__ __forceinline__ float sjd_sumsq4(float ss, float x0, float x1, float x2, float x3)
+{
+#pragma clang fp contract(off)
+    const float p0 = x0 * x0, p1 = x1 * x1, p2 = x2 * x2, p3 = x3 * x3;
+    ss = ss + p0; ss = ss + p1; ss = ss + p2; ss = ss + p3;
+    return ss;
+}

@@ -113,6 +113,21 @@ def set_seed(seed):
         torch.cuda.manual_seed_all(seed)
 
 
+_REDUCE_TIMEOUTS_SEEN = 0
+
+
+def check_reduce_timeouts():
+    """The o / down projections of the window forward reduce their split-K planes in their own tail (sjd_skinny_gemm_reduce): their
+    workgroups wait for each other, which needs the whole launch resident on the device.  On a partitioned or shared GPU a wait can be
+    abandoned (bounded spin); the forward's result is then wrong, so a decode that saw one raises instead of returning tokens."""
+    global _REDUCE_TIMEOUTS_SEEN
+    n = ops.reduce_timeouts()
+    if n > _REDUCE_TIMEOUTS_SEEN:
+        _REDUCE_TIMEOUTS_SEEN = n
+        raise RuntimeError(f"{n} workgroup(s) of a reducing projection launch gave up waiting for their slice (the GPU does not hold the whole "
+                           "launch at once: partitioned / shared device?); set SJD_REDUCE_FUSED=0 to run the projections with a separate F1r stage")
+
+
 def warn_no_grid(cfg, grammar):
     """a spatial init scheme on a grammar that has no image geometry (LlamaGen, the 3d-processor Anole path) degrades to 'random'"""
     from .grammar import _Grammar
@@ -554,6 +569,7 @@ class SJDEngine:
             self._close_timed(stats, ev0, ev1, t0, on_timed_end if timing else None,
                               len(X) - (timed_tok0 if timing else P), stats.nfe - (timed_nfe0 if timing else 0), kv_len)
         torch.cuda.synchronize()
+        check_reduce_timeouts()
         if philox:
             gen.set_offset(ph_off)                     # leave the generator where the reference's draws would have left it
         stats.total_tokens, stats.total_seconds = len(X) - P, time.perf_counter() - t_decode0

@@ -37,6 +37,17 @@ class FlexARInferenceSolver:
             self.model.attn = ops.HipWindowAttention()
         if fused and self.device.type == "cuda" and self.dtype != torch.float32 and getattr(self.model, "_ops", None) is None:
             self.model.enable_fused(ops, gemm=gemm)
+        if item_processor is None:
+            # IS:290-293: in a maintainer's checkout of the reference (`./lumina_mgpt/` on sys.path, test_lumina_mgpt.py:3-5, tokenizer and
+            # VQ-GAN files under ./ckpts/) the reference's own item processor is importable -- build it exactly as the reference does, so
+            # that test_lumina_mgpt.py:49 + :130 run verbatim there.  It does not exist on the GPU box (and is not part of the hot path):
+            # then generate() says so and generate_ids() is the entry point.
+            try:
+                from data.item_processor import FlexARItemProcessor          # noqa: the reference's module, never vendored here
+                kw = {} if tokenizer is None else {"tokenizer": tokenizer}
+                item_processor = FlexARItemProcessor(with_decoder=True, target_size=target_size, device=device, **kw)
+            except Exception:                                                # ImportError, or its tokenizer / VQ-GAN assets are missing
+                item_processor = None
         self.item_processor = item_processor
 
     @staticmethod

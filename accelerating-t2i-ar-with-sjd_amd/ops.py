@@ -289,6 +289,41 @@ def skinny_gemm(x, w_packed, N, K, KC, waves=4, step_major=False):
     return Partials(out, nc, N)
 
 
+_REDUCE_TICKETS = {}
+
+
+def skinny_gemm_reduce_ok(M, N, K, KC, waves, device):
+    """shapes sjd_skinny_gemm_reduce serves: a <= 32-row window, whole 512-column output slices, power-of-two waves that tile them, at most
+    16 K chunks, and the whole launch resident at once (its workgroups wait for each other: one workgroup per CU is the safe bound)"""
+    n_chunks = (K + KC - 1) // KC
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    return (M <= 32 and N % 512 == 0 and waves in (1, 2, 4, 8) and (N // 32) % waves == 0 and n_chunks <= 16
+            and (N // 32 // waves) * n_chunks <= cus)
+
+
+def skinny_gemm_reduce(x, w_packed, N, K, KC, h, waves=8, step_major=False):
+    """G1 with F1r as its tail: h [M, N] += dtype(x @ W^T) IN PLACE; returns the per-512-column-slice sums of h^2 [N / 512, 32] fp32 (the
+    `sumsq` of a row_norm) -- bit-identical to residual_sumsq(h, skinny_gemm(x, ...)) in one launch (sjd_skinny_gemm_reduce)."""
+    M = x.shape[0]
+    assert x.is_contiguous() and x.shape[1] == K and w_packed.numel() == N * K and h.is_contiguous() and tuple(h.shape) == (M, N) and h.dtype == x.dtype
+    nc = (K + KC - 1) // KC
+    dev = x.device
+    tk = _REDUCE_TICKETS.get(dev)
+    if tk is None or tk.numel() < (N // 512) * 32:
+        tk = _REDUCE_TICKETS[dev] = torch.zeros(max(64, N // 512) * 32, dtype=torch.int32, device=dev)     # re-arms itself; launches of one stream never overlap
+    ws = torch.empty(nc, 32, N, dtype=torch.float32, device=dev)
+    sumsq = torch.empty(N // 512, 32, dtype=torch.float32, device=dev)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    L.check(L.load().sjd_skinny_gemm_reduce(_ptr(x), _ptr(w_packed), _ptr(ws), _ptr(h), _ptr(sumsq), _ptr(tk), M, N, K, KC, waves, int(step_major),
+                                            _dtype_code(x.dtype), int(cus), _stream()), "sjd_skinny_gemm_reduce")
+    return sumsq
+
+
+def reduce_timeouts():
+    """waits of sjd_skinny_gemm_reduce launches that were abandoned since the library was loaded (0 on a healthy, unshared device)"""
+    return int(L.load().sjd_reduce_timeouts())
+
+
 _PREFETCH_SINK = {}
 
 

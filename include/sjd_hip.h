@@ -324,6 +324,16 @@ int sjd_stream_synchronize(void *stream);
 #define SJD_STATE_MIRROR_BYTES (sizeof(sjd_state) + 8)
 int sjd_host_wait_u64(const volatile uint64_t *flag, uint64_t value, int64_t timeout_us);
 
+/* G1 with stage F1r as its tail (round 3): h [M, N] += dtype(x @ W^T) in place and sumsq [N / 512, 32] = the per-slice sums of h^2, i.e.
+ * sjd_skinny_gemm followed by sjd_residual_sumsq (the residual add + RMSNorm statistics of modeling_chameleon.py:59-73, 637, 643), bit for
+ * bit, in one launch: the workgroups of a 512-column slice exchange their split-K planes device-coherently and reduce them in the
+ * producer's tail (csrc/sjd_gemm.hip::g1_reduce_tail).  workspace: fp32 [n_chunks, 32, N]; ticket: N / 512 * 32 zero-initialised
+ * uint32, private to launches that cannot overlap.  resident_limit: workgroups the device holds at once (the wait inside needs the whole
+ * launch resident; larger launches are refused).  sjd_reduce_timeouts: waits that were abandoned since the library was loaded (0). */
+int sjd_skinny_gemm_reduce(const void *x, const void *w_packed, float *workspace, void *h, float *sumsq, unsigned *ticket, int M, int N,
+                           int K, int KC, int waves, int step_major, int dtype, int resident_limit, void *stream);
+int sjd_reduce_timeouts(void);
+
 /* In-kernel noise (SURVEY.md section 7 "reproduce torch's Philox offsets", 8-K4 "K4 needs L-1 uniforms").  The reference draws
  * torch.multinomial / torch.rand / torch.multinomial from a device torch.Generator (jacobi_iteration_lumina_mgpt.py:118, 260, 237).  With
  * params->philox_blocks > 0, K2 and K4 compute the very elements those ATen launches would have written (Philox4x32-10 at the generator's

@@ -229,6 +229,59 @@ def test_g1_gateup_silu_matches_g1_then_f3(dev, dtype, step_major, M, I, K, with
         assert d.mean() < 6e-3 and d.max() < 0.2, (d.mean(), d.max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,KC,waves,step_major", [
+    (32, 4096, 4096, 512, 8, False),       # Lumina-7B o projection: 16 column groups x 8 chunks
+    (32, 4096, 11008, 896, 8, False),      # ... down projection: 16 x 13, ragged last chunk
+    (17, 4096, 11008, 896, 8, False),      # ragged rows (rows >= M are never touched)
+    (32, 4096, 14336, 896, 8, False),      # Emu3's intermediate size: 16 chunks
+    (5, 512, 1024, 256, 4, True), (32, 1024, 512, 128, 2, False), (32, 2048, 2752, 512, 8, True)])
+def test_g1_reduce_epilogue_matches_g1_then_f1r(dev, dtype, M, N, K, KC, waves, step_major):
+    """G1 with F1r as its tail (one launch; the workgroups of a 512-column slice exchange their split-K planes device-coherently and reduce
+    them in the producer's tail) is BIT-IDENTICAL to G1 followed by F1r: the residual stream h and the per-slice sums of squares -- also
+    when the launch is replayed from a hipGraph (the ticket re-arms itself) and for 50 launches in a row (no stale plane is ever read)."""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(N + K + M)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    wp = ops.pack_weight(w, KC, step_major)
+    assert ops.skinny_gemm_reduce_ok(M, N, K, KC, waves, dev)
+    for it in range(3):
+        x = torch.randn(M, K, generator=g).to(dtype).to(dev)
+        h0 = torch.randn(M, N, generator=g).to(dtype).to(dev)
+        h_ref = h0.clone()
+        ss_ref = ops.residual_sumsq(h_ref, ops.skinny_gemm(x, wp, N, K, KC, waves=waves, step_major=step_major))
+        h_got = h0.clone()
+        ss_got = ops.skinny_gemm_reduce(x, wp, N, K, KC, h_got, waves=waves, step_major=step_major)
+        torch.cuda.synchronize()
+        assert torch.equal(h_got.view(torch.int16), h_ref.view(torch.int16)), (h_got.float() - h_ref.float()).abs().max()
+        assert torch.equal(ss_got[:, :M].view(torch.int32), ss_ref[:, :M].view(torch.int32))
+    # a chain of dependent launches on one residual stream, eager and as a hipGraph replay
+    xs = [torch.randn(M, K, generator=g).to(dtype).to(dev) * 0.1 for _ in range(4)]
+    h_ref = h0.clone()
+    for i in range(48):
+        ss_ref = ops.residual_sumsq(h_ref, ops.skinny_gemm(xs[i % 4], wp, N, K, KC, waves=waves, step_major=step_major))
+    h_got = h0.clone()
+    for i in range(48):
+        ss_got = ops.skinny_gemm_reduce(xs[i % 4], wp, N, K, KC, h_got, waves=waves, step_major=step_major)
+    torch.cuda.synchronize()
+    assert torch.equal(h_got.view(torch.int16), h_ref.view(torch.int16)) and torch.equal(ss_got[:, :M], ss_ref[:, :M])
+    h_g = h0.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ops.skinny_gemm_reduce(xs[0], wp, N, K, KC, h0.clone(), waves=waves, step_major=step_major)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(4):
+            ss_g = ops.skinny_gemm_reduce(xs[i], wp, N, K, KC, h_g, waves=waves, step_major=step_major)
+    h_g.copy_(h0)
+    for _ in range(12):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(h_g.view(torch.int16), h_ref.view(torch.int16)) and torch.equal(ss_g[:, :M], ss_ref[:, :M])
+    assert ops.reduce_timeouts() == 0
+
+
 def test_g1_gateup_silu_refuses_what_it_does_not_serve(dev):
     import sjd_amd.ops as ops
     import sjd_amd._lib as L

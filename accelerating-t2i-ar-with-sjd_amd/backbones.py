@@ -36,9 +36,13 @@ import os as _os
 # 27.0 / 33.7 us at kv_len 64 / 448 / 1216 / 2368).  Default off; SJD_K1_FUSED=1 or model.k1_fused = True selects it.
 _K1_FUSED_DEFAULT = _os.environ.get("SJD_K1_FUSED", "0") == "1"
 _GATEUP_FUSED_DEFAULT = _os.environ.get("SJD_GATEUP_FUSED", "1") != "0"     # kernel G1s (gate|up + F3 in one launch); 0: G1 then F3
-# round 3: the o / down projections of a <= 32-row window reduce their own split-K planes, add the residual and write the row statistics
-# in their tail (sjd_skinny_gemm_reduce): stage F1r -- two graph nodes per layer -- disappears, h and the statistics keep their bits.  0: G1 then F1r
-_REDUCE_FUSED_DEFAULT = _os.environ.get("SJD_REDUCE_FUSED", "1") != "0"
+# round 3 experiment, correct, tested, OFF by default: the o / down projections of a <= 32-row window can reduce their own
+# split-K planes, add the residual and write the row statistics in their tail (sjd_skinny_gemm_reduce: device-coherent exchange between
+# the workgroups of a 512-column slice, bit-identical h and statistics), so that stage F1r -- two graph nodes per layer -- disappears.
+# Measured on one box against G1 + F1r: by kernel time o 13.55 -> 12.79 us, down 23.13 -> 22.05 us, but 3.512 against 3.416 ms/step end
+# to end once F1r itself was repaired (it had lost 1 us to serialised loads; 2.9 us now): three dependent device-scope round trips
+# (store acknowledgement, ticket, plane loads) cost more than a graph-node boundary plus ONE round trip.  SJD_REDUCE_FUSED=1 selects it.
+_REDUCE_FUSED_DEFAULT = _os.environ.get("SJD_REDUCE_FUSED", "0") == "1"
 
 
 def _head_logits(linear, x, cols):

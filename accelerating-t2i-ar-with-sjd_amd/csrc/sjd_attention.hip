@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "../../include/sjd_hip.h"
+#include "sjd_coherent.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -125,13 +126,75 @@ __device__ __forceinline__ u32x2 lds_tr_read(const unsigned short *p)
 // trip), then max / exp / weighted sums in key-part order.  In-kernel timestamps (round 2): the earlier form -- one element per thread,
 // ~50 DEPENDENT LDS reads, rows of the buffer all on one bank -- took 5.3 us of a 14.6 us launch (3.6 us of them bank-conflicted writes
 // and the dependent chain); this one 0.5 us + 0.5 us for the writes.
+// Round 3: with `merge_out` the key SPLITS of a (batch, kv head, chunk) are merged here too, by whichever of their workgroups finishes
+// LAST -- k1_combine, until now a graph node of its own behind every k1_partial (5.1 us + the node boundary), is gone for the
+// multi-head window.  A workgroup publishes its partial with device-coherent (sc1) stores, waits for their acknowledgement and takes a
+// ticket; the holder of the last ticket reads all partials back with device-coherent loads (one round trip: every split in flight) and
+// runs k1_combine's arithmetic in split order -- the output bits are those of k1_partial + k1_combine.  Nobody waits for anybody (no
+// spin, no residency assumption); the ticket re-arms itself.  One effective split (short contexts): the direct output, no exchange.
+// one step of the online merge of split partials (m, l, O[N]) into (M, L, acc[N]) -- shared by k1_combine and by the in-kernel merge of
+// k1_partial, written with explicit fma so that both give the same bits whatever the instruction selector makes of the code around it
+template <int N>
+__device__ __forceinline__ void k1_merge_step(float &M, float &L, float (&acc)[N], float m, float l, const float (&o)[N])
+{
+    const float Mn = fmaxf(M, m);
+    const float Msafe = (Mn == -INFINITY) ? 0.0f : Mn;
+    const float w0 = __expf(M - Msafe), w1 = __expf(m - Msafe);
+    L = __builtin_fmaf(L, w0, l * w1);
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = __builtin_fmaf(acc[j], w0, o[j] * w1);
+    M = Mn;
+}
+
+template <int DT, int D>
+__device__ __forceinline__ void k1_merge_splits(const float *__restrict__ ws_o, const float *__restrict__ ws_ml, unsigned short *__restrict__ out,
+                                                int G, int b, int H, int head0, int n_chunks, int chunk, int n_split, int eff_split,
+                                                int row0, int n_rows, int n_total, int nthreads)
+{
+    constexpr int D4 = D / 4, CB = 8;
+    for (int u = threadIdx.x; u < G * K1_ROWS * D4; u += nthreads) {
+        const int hg = u / (K1_ROWS * D4), row = (u / D4) % K1_ROWS, d = (u % D4) * 4;
+        const int grow = row0 + row;
+        if (grow >= n_rows) continue;
+        unsigned short *o = out + (((size_t)b * n_rows + grow) * H + (head0 + hg)) * D + d;
+        if (grow >= n_total) { *reinterpret_cast<uint2 *>(o) = uint2{0u, 0u}; continue; }     // padding rows: defined (zero) output
+        const size_t base = ((((size_t)b * H + (head0 + hg)) * n_chunks + chunk) * n_split) * K1_ROWS + row;
+        float M = -INFINITY, L = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < eff_split; s0 += CB) {
+            sjd_f4 ov[CB];
+            sjd_f2 mv[CB];
+#pragma unroll
+            for (int q = 0; q < CB; ++q) {                         // every split of the batch in flight, then merged in split order;
+                const size_t slot = base + (size_t)min(s0 + q, eff_split - 1) * K1_ROWS;      // unconditional (clamped) loads: counted waits
+                ov[q] = sjd_ld_coherent_f4(ws_o + slot * D + d);
+                mv[q] = sjd_ld_coherent_f2(ws_ml + slot * 2);
+            }
+#pragma unroll
+            for (int q = 0; q < CB; ++q)
+                if (s0 + q < eff_split) {                          // k1_combine's online merge, split order
+                    const float ov4[4] = {ov[q].x, ov[q].y, ov[q].z, ov[q].w};
+                    k1_merge_step<4>(M, L, acc, mv[q].x, mv[q].y, ov4);
+                }
+        }
+        const float inv = L > 0.f ? 1.0f / L : 0.0f;
+        uint2 pk;
+        pk.x = (unsigned)Frag<DT>::cvt(acc[0] * inv) | ((unsigned)Frag<DT>::cvt(acc[1] * inv) << 16);
+        pk.y = (unsigned)Frag<DT>::cvt(acc[2] * inv) | ((unsigned)Frag<DT>::cvt(acc[3] * inv) << 16);
+        *reinterpret_cast<uint2 *>(o) = pk;
+    }
+}
+
 template <int DT, int D, int NW>
 __device__ __forceinline__ void k1_merge_publish(float (*red_o)[K1_ROWS][D + K1_RPAD], float (*red_ml)[K1_ROWS][2], int G, int kparts,
                                                  int b, int H, int head0, int n_chunks, int chunk, int n_split, int split, int row0, int n_rows,
                                                  int n_total, float *__restrict__ ws_o, float *__restrict__ ws_ml,
-                                                 unsigned short *__restrict__ out_direct)
+                                                 unsigned short *__restrict__ out_direct, unsigned short *__restrict__ merge_out = nullptr,
+                                                 unsigned *__restrict__ ticket = nullptr, int eff_split = 0)
 {
     constexpr int D4 = D / 4;
+    const bool merged = merge_out != nullptr;
+    if (merged && eff_split == 1) out_direct = merge_out;          // one split in effect: this workgroup's state IS the result
+    const bool coherent = merged && !out_direct;
     for (int u = threadIdx.x; u < G * K1_ROWS * D4; u += 64 * NW) {
         const int hg = u / (K1_ROWS * D4), row = (u / D4) % K1_ROWS, d = (u % D4) * 4;
         float mk[NW], lk[NW];
@@ -173,9 +236,24 @@ __device__ __forceinline__ void k1_merge_publish(float (*red_o)[K1_ROWS][D + K1_
             continue;
         }
         const size_t slot = ((((size_t)b * H + (head0 + hg)) * n_chunks + chunk) * n_split + split) * K1_ROWS + row;
-        *reinterpret_cast<float4 *>(ws_o + slot * D + d) = float4{O0, O1, O2, O3};
-        if (d == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = L; }
+        if (coherent) {
+            sjd_st_coherent_f4(ws_o + slot * D + d, O0, O1, O2, O3);
+            if (d == 0) sjd_st_coherent_f2(ws_ml + slot * 2, M, L);
+        } else {
+            *reinterpret_cast<float4 *>(ws_o + slot * D + d) = float4{O0, O1, O2, O3};
+            if (d == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = L; }
+        }
     }
+    if (!coherent) return;
+    __shared__ unsigned last_s;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this thread's partial is acknowledged (written through L2)
+    __syncthreads();
+    unsigned *tk = ticket + ((size_t)b * (H / G) + head0 / G) * n_chunks + chunk;
+    if (threadIdx.x == 0) last_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (last_s != (unsigned)(eff_split - 1)) return;             // somebody else finishes later and merges
+    if (threadIdx.x == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+    k1_merge_splits<DT, D>(ws_o, ws_ml, merge_out, G, b, H, head0, n_chunks, chunk, n_split, eff_split, row0, n_rows, n_total, 64 * NW);
 }
 
 // NW wave64 per workgroup (4, or 8 for two waves per SIMD: twice the key tiles in flight per CU; the key-parts are merged in LDS)
@@ -184,7 +262,8 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
     const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
     const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,        // (among the first 16 dwords: preloaded into SGPRs)
     float *__restrict__ ws_o, float *__restrict__ ws_ml, unsigned short *__restrict__ out_direct,   // (the pointer before the ints: no padding
-    int n_rows, int H, int H_kv, int S_max, int kv_len_arg, int n_split, int n_chunks)              //  dword in the scalar load of the rest)
+    int n_rows, int H, int H_kv, int S_max, int kv_len_arg, int n_split, int n_chunks,              //  dword in the scalar load of the rest)
+    unsigned short *__restrict__ merge_out = nullptr, unsigned *__restrict__ ticket = nullptr)
 {
     typedef typename Frag<DT>::vec vec;
     constexpr int KS = D / 32;            // k-steps of the QK^T product
@@ -376,7 +455,7 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
     __syncthreads();
     SJD_TR(5);                    // merge buffers written
     k1_merge_publish<DT, D, NW>(red_o, red_ml, G, kparts, b, H, hkv * G, n_chunks, chunk, n_split, split, row0, n_rows, n_total, ws_o, ws_ml,
-                                out_direct);
+                                out_direct, merge_out, ticket, eff_split);
 #ifdef SJD_TRACE
     SJD_TR(6);                    // merged, stores issued
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -651,15 +730,7 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
         }
 #pragma unroll
         for (int q = 0; q < CB; ++q)
-            if (s0 + q < eff_split) {
-                const float Mn = fmaxf(M, ms[q]);
-                const float Msafe = (Mn == -INFINITY) ? 0.0f : Mn;
-                const float a0 = __expf(M - Msafe), a1 = __expf(ms[q] - Msafe);
-                L = L * a0 + ls[q] * a1;
-#pragma unroll
-                for (int j = 0; j < PER; ++j) acc[j] = acc[j] * a0 + os[q][j] * a1;
-                M = Mn;
-            }
+            if (s0 + q < eff_split) k1_merge_step<PER>(M, L, acc, ms[q], ls[q], os[q]);
     }
     const float inv = L > 0.f ? 1.0f / L : 0.0f;
     if (inv != 12345.678f) SJD_TRC(1);          // (partials arrived)
@@ -1021,7 +1092,8 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
     const unsigned short *__restrict__ q, const unsigned char *__restrict__ kc, const unsigned char *__restrict__ vc,
     const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,        // (among the first 16 dwords: preloaded into SGPRs)
     float *__restrict__ ws_o, float *__restrict__ ws_ml, unsigned short *__restrict__ out_direct,
-    int n_rows, int H, int H_kv, int S_max, int kv_len_arg, int n_split, int n_chunks, float k_scale, float v_scale)
+    int n_rows, int H, int H_kv, int S_max, int kv_len_arg, int n_split, int n_chunks, float k_scale, float v_scale,
+    unsigned short *__restrict__ merge_out = nullptr, unsigned *__restrict__ ticket = nullptr)
 {
     constexpr int KP = D / 64;            // 16-byte K pieces per key row and lane group = pairs of k-steps
     constexpr int DB = D / 16;            // 16-wide d blocks of the output
@@ -1205,7 +1277,7 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
     for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(&red_o[w][c][16 * db + 4 * g]) = o_acc[db] * oscale;
     __syncthreads();
     k1_merge_publish<DT, D, NW>(red_o, red_ml, G, kparts, b, H, hkv * G, n_chunks, chunk, n_split, split, row0, n_rows, n_total, ws_o, ws_ml,
-                                out_direct);
+                                out_direct, merge_out, ticket, eff_split);
 }
 
 // K3 for an fp8 cache: rows [kv_len, kv_len + n) <- fp8(x / scale); one thread converts 8 values (16 B in, 8 B out)
@@ -1329,7 +1401,7 @@ static int k1_waves()
 template <int DT, int D>
 static int launch_attention(const void *q, const void *kc, const void *vc, void *out, int B, int n_rows, int H, int H_kv, int S_max,
                             const int32_t *key_start, const sjd_iter_params *params, int kv_len, int n_split, void *workspace,
-                            hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1)
+                            hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, unsigned *ticket = nullptr)
 {
     const int n_chunks = (n_rows + K1_ROWS - 1) / K1_ROWS;
     float *ws_o = (float *)workspace;
@@ -1340,6 +1412,11 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     // a single key split needs no combine: k1_partial normalises and writes the 16-bit output directly (SJD_K1_NO_DIRECT=1: tuning aid)
     static const bool no_direct = getenv("SJD_K1_NO_DIRECT") != nullptr;
     unsigned short *direct = (!shared && n_split == 1 && !no_direct) ? (unsigned short *)out : nullptr;
+    // round 3: the splits are merged by the last of their workgroups to finish (k1_merge_publish): no k1_combine launch (SJD_K1_NO_MERGE=1:
+    // the two-kernel form, A/B).  `ticket`: one zero-initialised uint32 per (batch, kv head, chunk), handed over by the caller
+    // (sjd_draft_window_attention_merged); they re-arm themselves.
+    static const bool no_merge = getenv("SJD_K1_NO_MERGE") != nullptr;
+    unsigned short *merge_out = (ticket && !shared && !direct && !no_merge) ? (unsigned short *)out : nullptr;
     if (shared) {
         if constexpr (D == 128) {
             if (pairs == 8)
@@ -1354,23 +1431,23 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     } else if (k1_waves() == 8)
         hipLaunchKernelGGL((k1_partial<DT, D, 8>), dim3(n_chunks * n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
                            (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, direct, n_rows, H, H_kv, S_max,
-                           kv_len, n_split, n_chunks);
+                           kv_len, n_split, n_chunks, merge_out, ticket);
     else
         hipLaunchKernelGGL((k1_partial<DT, D, 4>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
                            (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, direct, n_rows, H, H_kv, S_max,
-                           kv_len, n_split, n_chunks);
+                           kv_len, n_split, n_chunks, merge_out, ticket);
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
-    if (direct) return SJD_OK;                          // one key split: k1_partial wrote the output itself
+    if (direct || merge_out) return SJD_OK;             // one key split, or the splits merged in the kernel: the output is written
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
                        n_split, n_chunks, params, key_start, kv_len);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
-extern "C" int sjd_draft_window_attention_ex(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows,
-                                             int H, int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
-                                             const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream,
-                                             void *ev_start, void *ev_stop)
+static int k1_dispatch(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows,
+                       int H, int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
+                       const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream,
+                       void *ev_start, void *ev_stop, unsigned *ticket)
 {
     if (!q || !k_cache || !v_cache || !out || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
     if (H % H_kv != 0 || (S_max % K1_KT) != 0) return SJD_ERR_BAD_ARG;
@@ -1384,13 +1461,35 @@ extern "C" int sjd_draft_window_attention_ex(const void *q, const void *k_cache,
     if (!(G == 1 || G == 2 || G == 4)) return SJD_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
 #define SJD_K1_CASE(DT_, D_) \
-    if (dtype == DT_ && D == D_) return launch_attention<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, key_start, params, kv_len, n_split, workspace, s, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
+    if (dtype == DT_ && D == D_) return launch_attention<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, key_start, params, kv_len, n_split, workspace, s, (hipEvent_t)ev_start, (hipEvent_t)ev_stop, ticket);
     SJD_K1_CASE(SJD_DTYPE_BF16, 128)
     SJD_K1_CASE(SJD_DTYPE_BF16, 64)
     SJD_K1_CASE(SJD_DTYPE_F16, 128)
     SJD_K1_CASE(SJD_DTYPE_F16, 64)
 #undef SJD_K1_CASE
     return SJD_ERR_UNSUPPORTED;
+}
+
+extern "C" int sjd_draft_window_attention_ex(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows,
+                                             int H, int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
+                                             const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream,
+                                             void *ev_start, void *ev_stop)
+{
+    return k1_dispatch(q, k_cache, v_cache, out, B, n_rows, H, H_kv, D, S_max, dtype, key_start, params, kv_len, n_split, workspace, stream,
+                       ev_start, ev_stop, nullptr);
+}
+
+// K1 in ONE launch: the key splits are merged by the last of their workgroups to finish instead of by a second kernel (k1_merge_publish).
+// tickets: B * H_kv * ceil(n_rows / 16) zero-initialised uint32, private to launches that cannot overlap (they re-arm themselves).
+// Grouped-query / multi-chunk shapes served by the shared-tile kernel keep the two-kernel form (tickets unused).
+extern "C" int sjd_draft_window_attention_merged(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows,
+                                                 int H, int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
+                                                 const sjd_iter_params *params, int kv_len, int n_split, void *workspace, uint32_t *tickets,
+                                                 void *stream, void *ev_start, void *ev_stop)
+{
+    if (!tickets) return SJD_ERR_BAD_ARG;
+    return k1_dispatch(q, k_cache, v_cache, out, B, n_rows, H, H_kv, D, S_max, dtype, key_start, params, kv_len, n_split, workspace, stream,
+                       ev_start, ev_stop, (unsigned *)tickets);
 }
 
 extern "C" int sjd_draft_window_attention(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
@@ -1424,31 +1523,33 @@ extern "C" int sjd_kv_append_fp8(const void *k_new, const void *v_new, void *k_c
 template <int DT, int D>
 static int launch_attention_fp8(const void *q, const void *kc, const void *vc, void *out, int B, int n_rows, int H, int H_kv, int S_max,
                                 float k_scale, float v_scale, const int32_t *key_start, const sjd_iter_params *params, int kv_len, int n_split,
-                                void *workspace, hipStream_t stream)
+                                void *workspace, hipStream_t stream, unsigned *ticket = nullptr)
 {
     const int n_chunks = (n_rows + K1_ROWS - 1) / K1_ROWS;
     float *ws_o = (float *)workspace;
     float *ws_ml = ws_o + (size_t)B * H * n_chunks * n_split * K1_ROWS * D;
     static const bool no_direct = getenv("SJD_K1_NO_DIRECT") != nullptr;
     unsigned short *direct = (n_split == 1 && !no_direct) ? (unsigned short *)out : nullptr;      // one key split: no combine launch
+    static const bool no_merge = getenv("SJD_K1_NO_MERGE") != nullptr;
+    unsigned short *merge_out = (ticket && !direct && !no_merge) ? (unsigned short *)out : nullptr;      // splits merged by their last workgroup
     if (k1_waves() == 8)
         hipLaunchKernelGGL((k1_partial_fp8<DT, D, 8>), dim3(n_chunks * n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
                            (const unsigned char *)kc, (const unsigned char *)vc, params, key_start, ws_o, ws_ml, direct, n_rows, H, H_kv, S_max,
-                           kv_len, n_split, n_chunks, k_scale, v_scale);
+                           kv_len, n_split, n_chunks, k_scale, v_scale, merge_out, ticket);
     else
         hipLaunchKernelGGL((k1_partial_fp8<DT, D, 4>), dim3(n_chunks * n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
                            (const unsigned char *)kc, (const unsigned char *)vc, params, key_start, ws_o, ws_ml, direct, n_rows, H, H_kv, S_max,
-                           kv_len, n_split, n_chunks, k_scale, v_scale);
+                           kv_len, n_split, n_chunks, k_scale, v_scale, merge_out, ticket);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
-    if (direct) return SJD_OK;
+    if (direct || merge_out) return SJD_OK;
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
                        n_split, n_chunks, params, key_start, kv_len);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
-extern "C" int sjd_draft_window_attention_fp8(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
-                                              int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
-                                              const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream)
+static int k1_dispatch_fp8(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
+                           int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
+                           const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream, unsigned *ticket)
 {
     if (!q || !k_cache || !v_cache || !out || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
     if (H % H_kv != 0 || (S_max % K1_KT) != 0 || !(k_scale > 0.f) || !(v_scale > 0.f)) return SJD_ERR_BAD_ARG;
@@ -1456,13 +1557,31 @@ extern "C" int sjd_draft_window_attention_fp8(const void *q, const void *k_cache
     if (!(G == 1 || G == 2 || G == 4)) return SJD_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
 #define SJD_K1F8_CASE(DT_, D_) \
-    if (dtype == DT_ && D == D_) return launch_attention_fp8<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, k_scale, v_scale, key_start, params, kv_len, n_split, workspace, s);
+    if (dtype == DT_ && D == D_) return launch_attention_fp8<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, k_scale, v_scale, key_start, params, kv_len, n_split, workspace, s, ticket);
     SJD_K1F8_CASE(SJD_DTYPE_BF16, 128)
     SJD_K1F8_CASE(SJD_DTYPE_BF16, 64)
     SJD_K1F8_CASE(SJD_DTYPE_F16, 128)
     SJD_K1F8_CASE(SJD_DTYPE_F16, 64)
 #undef SJD_K1F8_CASE
     return SJD_ERR_UNSUPPORTED;
+}
+
+extern "C" int sjd_draft_window_attention_fp8(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
+                                              int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
+                                              const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream)
+{
+    return k1_dispatch_fp8(q, k_cache, v_cache, out, B, n_rows, H, H_kv, D, S_max, dtype, k_scale, v_scale, key_start, params, kv_len, n_split,
+                           workspace, stream, nullptr);
+}
+
+extern "C" int sjd_draft_window_attention_fp8_merged(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
+                                                     int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
+                                                     const sjd_iter_params *params, int kv_len, int n_split, void *workspace, uint32_t *tickets,
+                                                     void *stream)
+{
+    if (!tickets) return SJD_ERR_BAD_ARG;
+    return k1_dispatch_fp8(q, k_cache, v_cache, out, B, n_rows, H, H_kv, D, S_max, dtype, k_scale, v_scale, key_start, params, kv_len, n_split,
+                           workspace, stream, (unsigned *)tickets);
 }
 
 extern "C" void *sjd_event_create(void)

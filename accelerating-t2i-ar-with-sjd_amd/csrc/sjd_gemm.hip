@@ -20,6 +20,7 @@
 
 #include "../../include/sjd_hip.h"
 #include "sjd_mlp_epilogue.h"
+#include "sjd_coherent.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -79,7 +80,6 @@ template <int DT>
 __device__ __forceinline__ void g1_reduce_tail(const float *__restrict__ part, unsigned short *__restrict__ h, float *__restrict__ sumsq,
                                                unsigned *__restrict__ ticket, int M, int N, int C, int chunk, int group, int n_waves)
 {
-    typedef __attribute__((ext_vector_type(4))) float f32x4_;
     __shared__ float red[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int gps = 16 / n_waves;                       // column groups per 512-column slice (n_waves in {1, 2, 4, 8, 16})
@@ -104,23 +104,18 @@ __device__ __forceinline__ void g1_reduce_tail(const float *__restrict__ part, u
         const int col = slice * 512 + half * 256 + 4 * lane;
         const float *p0 = part + (size_t)row * N + col;
         const size_t cstride = (size_t)32 * N;
-        f32x4_ v[16];
+        sjd_f4 v[16];
 #pragma unroll
-        for (int ch = 0; ch < 16; ++ch) v[ch] = f32x4_{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ch = 0; ch < 16; ++ch)
-            if (ch < C) __asm__ volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[ch]) : "v"(p0 + (size_t)ch * cstride) : "memory");
+        for (int ch = 0; ch < 16; ++ch)                                // all chunk planes of this thread's four columns in flight at once:
+            v[ch] = sjd_ld_coherent_f4(p0 + (size_t)min(ch, C - 1) * cstride);      // UNCONDITIONAL (clamped) loads, or the compiler serialises them
         unsigned short *hp = h + (size_t)row * N + col;
         const uint2 hv = *reinterpret_cast<const uint2 *>(hp);
-        // the loads above are invisible to the compiler's counters: wait for all of them, and make every use of v[] depend on the wait
-        __asm__ volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
-                           "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
-                         :: "memory");
         float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < 16; ++ch)
-            if (ch < C) { d0 += v[ch].x; d1 += v[ch].y; d2 += v[ch].z; d3 += v[ch].w; }
+        for (int ch = 0; ch < 16; ++ch) {
+            const bool on = ch < C;
+            d0 += on ? v[ch].x : 0.f; d1 += on ? v[ch].y : 0.f; d2 += on ? v[ch].z : 0.f; d3 += on ? v[ch].w : 0.f;
+        }
         const float hx[4] = {SjdAct<DT>::to_f((unsigned short)(hv.x & 0xffffu)), SjdAct<DT>::to_f((unsigned short)(hv.x >> 16)),
                              SjdAct<DT>::to_f((unsigned short)(hv.y & 0xffffu)), SjdAct<DT>::to_f((unsigned short)(hv.y >> 16))};
         const float dd[4] = {d0, d1, d2, d3};
@@ -157,9 +152,13 @@ __device__ __forceinline__ void g1_reduce_tail(const float *__restrict__ part, u
 // output): the output head is evaluated only for the vocabulary columns the grammar allows out of one packed copy.
 // MAXT: 512 (<= 8 waves: 256 VGPRs, sixteen activation pieces per thread in flight -> a 2048-column chunk is staged in ONE round trip)
 // or 1024 (9..16 waves, eight pieces).
-// RED (round 3, MT = 1): the split-K reduction, the residual add and the row statistics -- stage F1r, until now a graph node of its own
-// behind every o / down projection -- run in the TAIL of this kernel (g1_reduce_tail below).
-template <int DT, int MT, int MAXT, bool RED = false>
+// red_h != nullptr (round 3, MT = 1, <= 8 waves): the split-K reduction, the residual add and the row statistics -- stage F1r, until
+// now a graph node of its own behind every o / down projection -- run in the TAIL of this kernel (g1_reduce_tail).  A RUN-TIME switch of
+// the one kernel, not a second instantiation: the q|k|v, o and down launches of a layer then execute the same 12 KB of code.  The hot
+// kernels of a layer (G1, G1s, K1, F2) add up to about the 64 KB instruction cache two CUs share; with a separate reducing instantiation
+// next to the plain one the working set no longer fitted and EVERY configuration of the library lost 2-3 us per layer, whichever
+// kernels it ran (bisected on one box by swapping single translation units, profiles/r3_code_layout_bisect.txt).
+template <int DT, int MT, int MAXT>
 __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                 float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
                                                                 int rec_stride, int tile0, int n_waves,
@@ -283,8 +282,7 @@ __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__r
     SJD_TR(4);                    // main loop done
     // D[m][n]: reg r of lane l -> row m = (r&3) + 8*(r>>2) + 4*(l>>5), column n = 32t + (l&31): 128-B coalesced rows
     float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t_out * 32 + (lane & 31);
-    if constexpr (RED) {
-        static_assert(MT == 1, "the reducing epilogue serves the <= 32-row window");
+    if constexpr (MT == 1 && MAXT == 512) if (red_h) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)          // the plane goes out DEVICE-COHERENT (sc1: written through this XCD's L2)
             __hip_atomic_store(o + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * N, acc[0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -777,12 +775,12 @@ extern "C" int sjd_skinny_gemm_reduce(const void *x, const void *w_packed, float
     hipStream_t s = (hipStream_t)stream;
     const int rs = step_major ? n_out : 1;
     if (dtype == SJD_DTYPE_BF16) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<SJD_DTYPE_BF16, 1, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((g1_skinny_gemm<SJD_DTYPE_BF16, 1, 512, true>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, workspace,
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<SJD_DTYPE_BF16, 1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((g1_skinny_gemm<SJD_DTYPE_BF16, 1, 512>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, workspace,
                            M, N, K, KC, n_out, rs, 0, waves, (unsigned short *)h, sumsq, ticket);
     } else if (dtype == SJD_DTYPE_F16) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<SJD_DTYPE_F16, 1, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((g1_skinny_gemm<SJD_DTYPE_F16, 1, 512, true>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, workspace,
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm<SJD_DTYPE_F16, 1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((g1_skinny_gemm<SJD_DTYPE_F16, 1, 512>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, workspace,
                            M, N, K, KC, n_out, rs, 0, waves, (unsigned short *)h, sumsq, ticket);
     } else return SJD_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;

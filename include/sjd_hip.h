@@ -324,6 +324,18 @@ int sjd_stream_synchronize(void *stream);
 #define SJD_STATE_MIRROR_BYTES (sizeof(sjd_state) + 8)
 int sjd_host_wait_u64(const volatile uint64_t *flag, uint64_t value, int64_t timeout_us);
 
+/* K1 in ONE launch (round 3): the key splits of a (batch, kv head, 16-row chunk) are merged by the last of their workgroups to finish
+ * -- device-coherent exchange of the (m, l, O) partials, k1_combine's arithmetic in split order, same output bits -- instead of by a
+ * second kernel.  tickets: B * H_kv * ceil(n_rows / 16) zero-initialised uint32, private to launches that cannot overlap (they re-arm
+ * themselves).  Shapes served by the shared-tile kernel (grouped-query heads and / or two row chunks: Emu3) keep the two-kernel form.
+ * Same arguments and call sites as sjd_draft_window_attention(_fp8) otherwise (modeling_chameleon.py:499-581). */
+int sjd_draft_window_attention_merged(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H, int H_kv,
+                                      int D, int S_max, int dtype, const int32_t *key_start, const sjd_iter_params *params, int kv_len,
+                                      int n_split, void *workspace, uint32_t *tickets, void *stream, void *ev_start, void *ev_stop);
+int sjd_draft_window_attention_fp8_merged(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H, int H_kv,
+                                          int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
+                                          const sjd_iter_params *params, int kv_len, int n_split, void *workspace, uint32_t *tickets, void *stream);
+
 /* G1 with stage F1r as its tail (round 3): h [M, N] += dtype(x @ W^T) in place and sumsq [N / 512, 32] = the per-slice sums of h^2, i.e.
  * sjd_skinny_gemm followed by sjd_residual_sumsq (the residual add + RMSNorm statistics of modeling_chameleon.py:59-73, 637, 643), bit for
  * bit, in one launch: the workgroups of a 512-column slice exchange their split-K planes device-coherently and reduce them in the

@@ -373,6 +373,64 @@ def test_k1_single_split_direct_output_is_what_combine_would_write(dev):
     assert len(outs[0]) == 64 and outs[0] == outs[1]
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("B,H,Hkv,D,n,kv_len,ks,n_split,dtype", [
+    (2, 32, 32, 128, 16, 1216, [0, 59], 4, torch.bfloat16),       # Lumina-7B mid-image: the production launch
+    (2, 32, 32, 128, 16, 2368, [0, 63], 4, torch.bfloat16),
+    (2, 32, 32, 128, 16, 40, [0, 39], 4, torch.bfloat16),         # one effective split: the direct output, no exchange
+    (2, 32, 32, 128, 16, 200, [0, 63], 4, torch.bfloat16),        # two effective splits of four
+    (2, 4, 4, 128, 5, 700, [0, 10], 8, torch.float16),            # ragged window, eight splits
+    (2, 4, 2, 128, 16, 600, [3, 0], 4, torch.bfloat16),           # two q heads per kv head in one workgroup
+    (2, 12, 12, 64, 16, 250, [0, 0], 2, torch.bfloat16),          # LlamaGen head size
+    (1, 4, 4, 128, 60, 500, [7], 4, torch.bfloat16)])             # prefill-like: four row chunks
+def test_k1_splits_merged_in_the_kernel_equal_partial_plus_combine(dev, fp8, B, H, Hkv, D, n, kv_len, ks, n_split, dtype):
+    """K1 in one launch (round 3): the key splits are merged by the last of their workgroups to finish -- device-coherent exchange, then
+    k1_combine's arithmetic in split order.  The output BYTES are those of k1_partial + k1_combine, for 30 launches in a row (the
+    tickets re-arm themselves, no stale partial is ever merged) and when replayed from a hipGraph."""
+    ops, L = _ops()
+    if fp8 and D != 128:
+        pytest.skip("fp8 K1 cases use head size 128")
+    g = torch.Generator().manual_seed(kv_len + n + H)
+    S = ((kv_len + n + 63) // 32) * 32
+    ksd = torch.tensor(ks, dtype=torch.int32, device=dev)
+    kcs = [torch.randn(B, Hkv, S, D, generator=g).to(dtype).to(dev) for _ in range(3)]
+    vcs = [torch.randn(B, Hkv, S, D, generator=g).to(dtype).to(dev) for _ in range(3)]
+    if fp8:
+        kcs, vcs = [t.float().to(ops.FP8) for t in kcs], [t.float().to(ops.FP8) for t in vcs]
+    qs = [(torch.randn(B, n, H, D, generator=g) * 1.5).to(dtype).to(dev) for _ in range(3)]
+    ws = ops.attention_workspace(B, H, n, D, n_split, dev)
+
+    def run(i, out, merged):
+        if fp8:
+            ops.draft_window_attention_fp8(qs[i % 3], kcs[i % 3], vcs[i % 3], out, 1.0, 1.0, ksd, None, kv_len, n_split, ws, merged=merged)
+        else:
+            ops.draft_window_attention(qs[i % 3], kcs[i % 3], vcs[i % 3], out, ksd, None, kv_len, n_split, ws, merged=merged)
+
+    ref, got = [torch.empty_like(qs[0]) for _ in range(3)], [torch.full_like(qs[0], 7.0) for _ in range(30)]
+    for i in range(3):
+        run(i, ref[i], False)
+    for i in range(30):
+        run(i, got[i], True)
+    torch.cuda.synchronize()
+    for i in range(30):
+        assert torch.equal(got[i].view(torch.int16), ref[i % 3].view(torch.int16)), (i, (got[i].float() - ref[i % 3].float()).abs().max())
+    outs = [torch.full_like(qs[0], 7.0) for _ in range(3)]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        run(0, outs[0], True)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(3):
+            run(i, outs[i], True)
+    for _ in range(10):
+        graph.replay()
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(outs[i].view(torch.int16), ref[i].view(torch.int16))
+    assert int(ops.k1_tickets(B, Hkv, n, dev).abs().sum()) == 0          # every ticket re-armed
+
+
 def test_k1_device_side_kv_len(dev):
     """kv_len / n_rows read from the device-resident sjd_iter_params blob (shape-static launch)."""
     ops, L = _ops()

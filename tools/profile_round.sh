@@ -4,10 +4,10 @@
 #   2. PMC passes (counters only, no trace domains besides kernel-trace): MFMA busy for K1 and G1, HBM traffic for K1 / G1 / K2+head
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
-TAG=${1:-r2}
+TAG=${1:-r3}
 O=gpurun_out
 mkdir -p $O
-B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-cpu-baseline --no-whole-image"
+B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-cpu-baseline --no-whole-image --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_trace -- $B > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof_bench.err
 python tools/trace_by_grid.py $O/prof_${TAG}_trace 200 > $O/${TAG}_bench_by_shape.txt
 find $O/prof_${TAG}_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_bench_kernel_stats.csv

@@ -554,7 +554,7 @@ class HipWindowAttention:
         self._ev_pool = []
         self.kv_scale = (1.0, 1.0)  # (k, v) scales of an fp8 cache: stored byte = fp8(x / scale)
 
-    def _resolve_split(self, B, Hkv, n_rows=16, H=None):
+    def _resolve_split(self, B, Hkv, n_rows=16, H=None, cache_bytes_per_head=None):
         """auto mode: one workgroup per CU for MHA (256 = B * H_kv * ceil(n_rows/16) * n_split; tools/k1_bench.py --graph: 4 splits
         22.3 us vs 8 splits 24.7 us per layer at kv_len 1216), two per CU for GQA, whose workgroups share each K/V tile between
         the q-heads of a group and are VGPR-limited to two per CU."""
@@ -562,6 +562,11 @@ class HipWindowAttention:
             chunks = (n_rows + 15) // 16
             target = 256 if (H is None or H == Hkv) else 512
             self.n_split = int(min(64, max(1, target // (B * Hkv * chunks))))
+            # a SHORT fp8 cache (config 5: Anole 512px, <= ~1150 keys of 128 bytes) is read faster by one workgroup per (batch, head)
+            # that writes the output itself than by four splits + k1_combine: 5.7 / 8.9 / 12.2 us per layer at kv 64 / 552 / 1040
+            # against 8.6 / 10.4 / 12.0 (profiles/r3_k1_split_sweep_before.jsonl); 16-bit caches of that length break even at kv ~450
+            if cache_bytes_per_head is not None and cache_bytes_per_head <= 160 * 1024 and (H is None or H == Hkv) and chunks == 1:
+                self.n_split = 1
         return self.n_split
 
     def _workspace(self, B, H, n, D, device):
@@ -581,7 +586,7 @@ class HipWindowAttention:
         B, n, H, D = q.shape
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         kc, vc = cache.k[layer], cache.v[layer]
-        self._resolve_split(B, kc.shape[1], n, H)
+        self._resolve_split(B, kc.shape[1], n, H, kc.shape[2] * kc.shape[3] * kc.element_size() if kc.dtype == FP8 else None)
         if isinstance(key_start, torch.Tensor) and key_start.is_cuda and key_start.dtype == torch.int32:
             ks = key_start
         else:
@@ -616,7 +621,7 @@ class HipWindowAttention:
         """K1 only: the window's K/V rows were already written into the cache (fused F2 path)."""
         B, n, H, D = q.shape
         kc, vc = cache.k[layer], cache.v[layer]
-        self._resolve_split(B, kc.shape[1], n, H)
+        self._resolve_split(B, kc.shape[1], n, H, kc.shape[2] * kc.shape[3] * kc.element_size() if kc.dtype == FP8 else None)
         ws = self._workspace(B, H, n, D, q.device)
         out = torch.empty_like(q)
         kv_host = 0 if self.params is not None else int(kv_len)

@@ -379,6 +379,7 @@ class SJDBatchEngine:
 
         # ---------------- window iterations, all slots in lock-step ----------------
         it = 0
+        timed_started = False
         t0 = time.perf_counter()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -402,6 +403,7 @@ class SJDBatchEngine:
                     continue                                    # (a prompt that ended in its prefill iteration)
                 break
             if timed_iters is not None and it == warmup_iters:
+                timed_started = True
                 if on_timed_start is not None:
                     on_timed_start()
                 tok0 = emitted_total
@@ -505,7 +507,7 @@ class SJDBatchEngine:
                 break
         ev1.record()
         torch.cuda.synchronize()
-        if on_timed_end is not None:
+        if on_timed_end is not None and (timed_started or timed_iters is None):      # never an unmatched barrier (SJDEngine.decode)
             on_timed_end()
         seconds = ev0.elapsed_time(ev1) / 1000.0
         for s in self.slots:                                   # prompts still in flight when a timed run stops
@@ -513,7 +515,8 @@ class SJDBatchEngine:
                 harvest(s)
         self.run_stats = dict(seconds=seconds, wall_seconds=time.perf_counter() - t0, iterations=it,
                               timed_iterations=(it - warmup_iters) if timed_iters is not None else it,
-                              tokens=emitted_total - tok0, host_seconds=host_s, sync_seconds=sync_s, prompts_started=next_prompt)
+                              tokens=emitted_total - tok0, host_seconds=host_s, sync_seconds=sync_s, prompts_started=next_prompt,
+                              timed_region_reached=bool(timed_started or timed_iters is None))
         out = []
         for r in results:
             if r is None:                                      # never admitted (a timed run that stopped early)

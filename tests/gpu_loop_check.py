@@ -279,7 +279,7 @@ def teacher_forced_emu3_check(device="cuda:0", H=3, W=5, window=32, seed=5, embe
 
 @torch.no_grad()
 def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=16, seed=3, P=(12, 9), embed_token_scale=0.25,
-                               dtype=torch.bfloat16, use_graph=True, gemm="sjd", fp8_kv=False, n_slots=None):
+                               dtype=torch.bfloat16, use_graph=True, gemm="sjd", fp8_kv=False, n_slots=None, init_scheme="random"):
     """Several prompts per window forward (SJDBatchEngine): every slot's recorded logits, replayed into the CPU oracle with the slot's
     seed, must give that slot's token sequence and accept lengths -- i.e. sharing the forward changes nothing in any prompt's
     state machine (own window, kv_len, grammar, generators).  n_slots < n_prompts: continuous batching -- a slot that finished its
@@ -309,7 +309,8 @@ def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=
     n_slots = n_slots or n_prompts
     model.setup_cache(batch=2 * n_slots, s_max=((max_len + 64 + 31) // 32) * 32, dtype=ops.FP8 if fp8_kv else None)
     cfg = SJDConfig(jacobi_loop_interval_l=3, jacobi_loop_interval_r=n_img - 10, max_num_new_tokens=window, guidance_scale=3.0,
-                    seed=seed, prefix_token_sampler_scheme="speculative_jacobi", max_length=1 << 20, eos_token_ids=(8196,))
+                    seed=seed, prefix_token_sampler_scheme="speculative_jacobi", max_length=1 << 20, eos_token_ids=(8196,),
+                    multi_token_init_scheme=init_scheme)
     eng = SJDBatchEngine(model, V, device, n_slots, max_window=window, use_graph=use_graph)
     recs = [_Recorder() for _ in range(n_prompts)]
     eng.hook = lambda i, d: recs[i](d)
@@ -319,7 +320,7 @@ def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=
         c = _loop_cfg(cfg)
         c.seed = cfg.seed + i
         seq_ref, tr, checks = _replay(recs[i], prompts[i], lambda cx, n: O.lumina_rules(cx, n, 2000, 10), c, V,
-                                      no_cfg_fn=O.lumina_force_no_cfg, device=device)
+                                      no_cfg_fn=O.lumina_force_no_cfg, device=device, grid_fn=O.lumina_grid)
         assert seq == seq_ref, f"slot {i}: token sequences differ"
         assert stats.matched == tr.matched, f"slot {i}: accept lengths differ"
         gen = seq[len(prompts[i]):]

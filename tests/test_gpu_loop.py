@@ -89,6 +89,16 @@ def test_three_and_four_prompts_share_one_window_forward(n_prompts, fp8_kv):
     assert len(rs) == n_prompts and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs) and any(r["max_accept"] > 1 for r in rs)
 
 
+@pytest.mark.parametrize("init_scheme,n_prompts,use_graph", [("repeat_horizon", 2, True), ("sample_horizon", 3, True), ("sample_horizon", 2, False)])
+def test_batch_engine_spatial_init(init_scheme, n_prompts, use_graph):
+    """multi_token_init_scheme 'repeat_horizon' / 'sample_horizon' in the several-prompts-per-forward engine (round 3: it raised before):
+    every slot chooses its fresh drafts from ITS carried tokens / modes (K2's amax by-product per slot) and still decodes exactly as the
+    oracle's replay of its own logits -- parity unpinned upstream (JL:577 raises), engine == oracle restatement."""
+    from tests.gpu_loop_check import teacher_forced_batch_check
+    r = teacher_forced_batch_check(n_prompts=n_prompts, use_graph=use_graph, init_scheme=init_scheme, hg=5, wg=5)
+    assert len(r) == n_prompts and all(s_["tokens"] >= 100 for s_ in r)
+
+
 @pytest.mark.parametrize("n_prompts,n_slots,use_graph", [(5, 2, True), (7, 3, True), (6, 4, False)])
 def test_continuous_batching_refills_finished_slots(n_prompts, n_slots, use_graph):
     """more prompts than slots: a slot whose image is complete is handed the next prompt (fresh state machine, KV rows reused from 0,

@@ -471,7 +471,11 @@ __global__ __launch_bounds__(64 * NW) void k1_partial(
 // read back transposed).  The next tile's loads are in flight while the current one is consumed; one barrier per tile.
 // Same split / workspace layout as k1_partial (the waves of a pair cover all tiles of the split, so no LDS merge), k1_combine
 // is unchanged.
-template <int DT, int D, int NWV>          // NWV = waves per workgroup = (q head of the group, row chunk) pairs: 4 or 8
+// NSET key tiles travel at a time: 3.  Six (SJD_K1_SHARED_SETS=6; a register set is only 2 * MAXP 16-byte pieces) measured EQUAL in round 3
+// -- 17.2 / 26.4 / 36.7 us per layer at kv 1024 / 4096 / 8192 against 16.9 / 25.5 / 36.3 (Emu3 shape, 16 splits, with k1_combine) -- so
+// the bytes in flight are not what bounds this kernel: a tile costs 1.4-1.9 us whatever travels behind it (LDS fragment reads of eight
+// waves, the dependent QK^T -> softmax -> PV chain of each, one workgroup barrier), profiles/r3_k1_microbench.jsonl.
+template <int DT, int D, int NWV, int NSET = 3>          // NWV = waves per workgroup = (q head of the group, row chunk) pairs: 4 or 8
 __global__ __launch_bounds__(64 * NWV) void k1_partial_shared(
     const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
     const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,        // (among the first 16 dwords: preloaded into SGPRs)
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_shared(
     constexpr int PIECES = K1_KT * D / 8, LPR = D / 8;
     constexpr int MAXP = PIECES / (64 * NWV);  // pieces per thread and tensor
     static_assert(MAXP * 64 * NWV == PIECES, "the workgroup covers a tile exactly");
-    u32x4 kst[3][MAXP], vst[3][MAXP];
+    u32x4 kst[NSET][MAXP], vst[NSET][MAXP];
     auto fetch = [&](int t, auto set) {
         constexpr int S = decltype(set)::value;
         const int tc = min(t, bt1 - 1);
@@ -629,31 +633,32 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_shared(
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
     typedef std::integral_constant<int, 2> S2;
+    typedef std::integral_constant<int, NSET == 6 ? 3 : 0> S3;
+    typedef std::integral_constant<int, NSET == 6 ? 4 : 0> S4;
+    typedef std::integral_constant<int, NSET == 6 ? 5 : 0> S5;
     fetch(bt0, S0{});
     fetch(bt0 + 1, S1{});
     fetch(bt0 + 2, S2{});
+    if constexpr (NSET == 6) { fetch(bt0 + 3, S3{}); fetch(bt0 + 4, S4{}); fetch(bt0 + 5, S5{}); }
     stash(bt0, 0, S0{});
     __syncthreads();
     SJD_TR(2);                    // first tile in LDS
-    // iteration of tile t (relative index r = t - bt0, r % 3 == k): request tile r + 3 into set k (tile r left it one iteration ago),
-    // multiply tile r out of LDS buffer r & 1, move tile r + 1 from set (k + 1) % 3 into the other buffer
+    // iteration of tile t (relative index r = t - bt0, r % NSET == k): request tile r + NSET into set k (tile r left it one iteration ago),
+    // multiply tile r out of LDS buffer r & 1, move tile r + 1 from set (k + 1) % NSET into the other buffer
+#define K1S_STEP(SA, SB)                                                          \
+    fetch(t + NSET, SA{});                                                        \
+    compute_tile(t, (t - bt0) & 1);                                               \
+    if (t + 1 < bt1) stash(t + 1, ((t - bt0) & 1) ^ 1, SB{});                     \
+    __syncthreads();                                                              \
+    if (++t >= bt1) break;
     for (int t = bt0; t < bt1;) {
-        fetch(t + 3, S0{});
-        compute_tile(t, (t - bt0) & 1);
-        if (t + 1 < bt1) stash(t + 1, ((t - bt0) & 1) ^ 1, S1{});
-        __syncthreads();
-        if (++t >= bt1) break;
-        fetch(t + 3, S1{});
-        compute_tile(t, (t - bt0) & 1);
-        if (t + 1 < bt1) stash(t + 1, ((t - bt0) & 1) ^ 1, S2{});
-        __syncthreads();
-        if (++t >= bt1) break;
-        fetch(t + 3, S2{});
-        compute_tile(t, (t - bt0) & 1);
-        if (t + 1 < bt1) stash(t + 1, ((t - bt0) & 1) ^ 1, S0{});
-        __syncthreads();
-        ++t;
+        if constexpr (NSET == 6) {
+            K1S_STEP(S0, S1) K1S_STEP(S1, S2) K1S_STEP(S2, S3) K1S_STEP(S3, S4) K1S_STEP(S4, S5) K1S_STEP(S5, S0)
+        } else {
+            K1S_STEP(S0, S1) K1S_STEP(S1, S2) K1S_STEP(S2, S0)
+        }
     }
+#undef K1S_STEP
     SJD_TR(3);                    // key loop done
     if (!wave_on) return;
     // the wave covered every tile of its split: its (m, l, O) is the split partial
@@ -1419,12 +1424,21 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     unsigned short *merge_out = (ticket && !shared && !direct && !no_merge) ? (unsigned short *)out : nullptr;
     if (shared) {
         if constexpr (D == 128) {
-            if (pairs == 8)
-                hipLaunchKernelGGL((k1_partial_shared<DT, D, 8>), dim3(n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
+            static const bool three = [] { const char *e = getenv("SJD_K1_SHARED_SETS"); return !(e && atoi(e) == 6); }();      // 6: the deeper pipeline (A/B, measured equal)
+            if (pairs == 8 && three)
+                hipLaunchKernelGGL((k1_partial_shared<DT, D, 8, 3>), dim3(n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
+                                   (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,
+                                   kv_len, n_split, n_chunks);
+            else if (pairs == 8)
+                hipLaunchKernelGGL((k1_partial_shared<DT, D, 8, 6>), dim3(n_split, H_kv, B), dim3(512), 0, stream, (const unsigned short *)q,
+                                   (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,
+                                   kv_len, n_split, n_chunks);
+            else if (three)
+                hipLaunchKernelGGL((k1_partial_shared<DT, D, 4, 3>), dim3(n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
                                    (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,
                                    kv_len, n_split, n_chunks);
             else
-                hipLaunchKernelGGL((k1_partial_shared<DT, D, 4>), dim3(n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
+                hipLaunchKernelGGL((k1_partial_shared<DT, D, 4, 6>), dim3(n_split, H_kv, B), dim3(256), 0, stream, (const unsigned short *)q,
                                    (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,
                                    kv_len, n_split, n_chunks);
         }

@@ -16,7 +16,7 @@ SO_PATH = os.environ.get("SJD_HIP_LIB") or os.path.join(_HERE, "libsjd_hip.so") 
 
 class RowRule(ctypes.Structure):
     _fields_ = [("n_ranges", ctypes.c_int32), ("lo", ctypes.c_int32 * MAX_RANGES), ("hi", ctypes.c_int32 * MAX_RANGES),
-                ("forced", ctypes.c_int32), ("top_k", ctypes.c_int32), ("top_p_thr", ctypes.c_float)]
+                ("forced", ctypes.c_int32), ("top_k", ctypes.c_int32), ("top_p_thr", ctypes.c_float), ("temperature", ctypes.c_float)]
 
 
 class IterParams(ctypes.Structure):
@@ -121,7 +121,7 @@ def load():
     lib.sjd_event_elapsed_ms.argtypes = [vp, vp]
     for name in EXPORTS:
         getattr(lib, name)
-    assert ctypes.sizeof(RowRule) == 48 and ctypes.sizeof(IterParams) == 64 + 8 * MAX_WINDOW + 2 * 48 * MAX_WINDOW
+    assert ctypes.sizeof(RowRule) == 52 and ctypes.sizeof(IterParams) == 64 + 8 * MAX_WINDOW + 2 * 52 * MAX_WINDOW
     _lib = lib
     return lib
 

@@ -36,6 +36,37 @@ __device__ __forceinline__ float sjd_expf(float x)
     return y * __uint_as_float((uint32_t)(ni + 127) << 23);
 }
 
+// Canonical natural logarithm of a positive finite float (musl / fdlibm logf: reduction to [sqrt(1/2), sqrt(2)), s = f / (2 + f),
+// degree-4 even polynomial), every operation rounded separately and in the order written -- the CPU oracle restates it line by line.
+// Only the temperature path of the residual resample uses it: softmax(log(d) / T) needs log d, which at T = 1 cancels (d / sum d).
+__device__ __forceinline__ float sjd_logf(float x)
+{
+    const float LN2_HI = 6.9313812256e-01f, LN2_LO = 9.0580006145e-06f;
+    const float LG1 = 0.66666662693f, LG2 = 0.40000972152f, LG3 = 0.28498786688f, LG4 = 0.24279078841f;
+    uint32_t ix = __float_as_uint(x);
+    int k = 0;
+    if (ix < 0x00800000u) { x = x * 33554432.0f; k = -25; ix = __float_as_uint(x); }      // subnormal: scale by 2^25
+    ix += 0x3f800000u - 0x3f3504f3u;
+    k += (int)(ix >> 23) - 0x7f;
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    const float xr = __uint_as_float(ix);
+    const float f = xr - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float w = z * z;
+    const float t1 = w * (LG2 + w * LG4);
+    const float t2 = z * (LG1 + w * LG3);
+    const float R = t2 + t1;
+    const float hfsq = (0.5f * f) * f;
+    const float dk = (float)k;
+    float r = s * (hfsq + R);
+    r = r + dk * LN2_LO;
+    r = r - hfsq;
+    r = r + f;
+    r = r + dk * LN2_HI;
+    return r;
+}
+
 struct SjdShared {
     float wave_f[SJD_WAVES];
     int wave_i[SJD_WAVES];

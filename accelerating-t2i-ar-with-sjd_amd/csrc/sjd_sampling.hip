@@ -49,7 +49,7 @@ __device__ __forceinline__ bool rule_allows(const sjd_row_rule &r, int c)
 // lm_head, only the vocabulary columns the grammar allows), sums the chunks in order, applies the folded final-RMSNorm row scale and
 // rounds to the activation dtype exactly where nn.Linear would (MC:1560-1561: 16-bit lm_head output, then .float()); the CFG combine,
 // grammar mask, top-k, softmax and draw are the same code as the dense-logits form.
-static_assert(sizeof(sjd_iter_params) == 64 + 8 * SJD_MAX_WINDOW + 2 * 48 * SJD_MAX_WINDOW, "sjd_iter_params layout is mirrored by ctypes (sjd_amd/_lib.py::IterParams)");
+static_assert(sizeof(sjd_row_rule) == 52 && sizeof(sjd_iter_params) == 64 + 8 * SJD_MAX_WINDOW + 2 * 52 * SJD_MAX_WINDOW, "sjd_iter_params layout is mirrored by ctypes (sjd_amd/_lib.py::IterParams)");
 static_assert(sizeof(sjd_head_partials) == 88, "sjd_head_partials layout is mirrored by ctypes (sjd_amd/_lib.py::HeadPartials)");
 
 __device__ __forceinline__ float k2_round16(float x, int dt)
@@ -212,7 +212,11 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_finite) kth = block_kth_largest(p, wlo, whi, rule.top_k, -INFINITY, sh);
 
     SJD_TRS(row, 3);              // top-k threshold known
-    // pass A: e = exp(z - max) for kept entries, canonical sum
+    // pass A: e = exp(z - max) for kept entries, canonical sum.  TemperatureLogitsWarper (rule.temperature != 1): the kept scores are
+    // divided by T first -- after the grammar mask and its top-k, before top-p and the softmax, where HF's generate() places the warper;
+    // max(z / T) == max(z) / T because the division is monotone
+    const bool tempered = rule.temperature > 0.0f && rule.temperature != 1.0f;
+    const float zmax_t = tempered ? zmax / rule.temperature : zmax;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
         float ev[4];
@@ -222,7 +226,8 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
             ev[j] = 0.0f;
             if (col >= wlo && col < whi) {
                 float z = p[col];
-                ev[j] = (z < kth) ? 0.0f : sjd_expf(z - zmax);
+                const float zt = tempered ? z / rule.temperature : z;
+                ev[j] = (z < kth) ? 0.0f : sjd_expf(zt - zmax_t);
                 p[col] = ev[j];
             }
         }
@@ -384,6 +389,36 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                     a0 = a0 + dv[0]; a1 = a1 + dv[1]; a2 = a2 + dv[2]; a3 = a3 + dv[3];
                 }
                 float S = block_canonical_sum(a0, a1, a2, a3, sh);
+                if (rule.temperature > 0.0f && rule.temperature != 1.0f && S > 0.0f) {
+                    // TemperatureLogitsWarper on the residual logits log(d): weights exp(log(d) / T - max) instead of d (JL:203-241 with the
+                    // warper in the processor list); log d through the canonical sjd_logf the oracle restates
+                    float dm = 0.f;
+                    SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            int col = c0 + j;
+                            if (col >= wlo && col < whi) dm = fmaxf(dm, scratch[col]);
+                        }
+                    }
+                    dm = block_max(dm, sh);
+                    const float lm = sjd_logf(dm) / rule.temperature;
+                    a0 = a1 = a2 = a3 = 0.f;
+                    SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+                        float dv[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            int col = c0 + j;
+                            dv[j] = 0.0f;
+                            if (col >= wlo && col < whi) {
+                                const float d = scratch[col];
+                                dv[j] = d > 0.0f ? sjd_expf(sjd_logf(d) / rule.temperature - lm) : 0.0f;
+                                scratch[col] = dv[j];
+                            }
+                        }
+                        a0 = a0 + dv[0]; a1 = a1 + dv[1]; a2 = a2 + dv[2]; a3 = a3 + dv[3];
+                    }
+                    S = block_canonical_sum(a0, a1, a2, a3, sh);
+                }
                 if (rule.top_p_thr >= 0.0f) S = block_top_p_apply(scratch, wlo, whi, S, rule.top_p_thr, sh);
                 degenerate = !(S > 0.0f);         // 0/0 below: flagged to the host (state->rejected = 2), never a silent arbitrary id
                 unsigned long long best = 0ull;

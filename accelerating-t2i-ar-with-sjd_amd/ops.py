@@ -49,10 +49,11 @@ def philox_step(numel, max_blocks):
 _RULE_CACHE = {}
 
 
-def make_rule(ranges=(), forced=-1, top_k=0, top_p=None):
+def make_rule(ranges=(), forced=-1, top_k=0, top_p=None, temperature=1.0):
     """-> sjd_row_rule.  A decode asks for the same handful of rules thirty times per iteration, so the structs are interned
     (treat them as read-only; assigning one into a params blob copies it)."""
-    key = (tuple((int(lo), int(hi)) for lo, hi in ranges), int(forced), int(top_k or 0), None if top_p is None else float(top_p))
+    key = (tuple((int(lo), int(hi)) for lo, hi in ranges), int(forced), int(top_k or 0), None if top_p is None else float(top_p),
+           float(temperature or 1.0))
     r = _RULE_CACHE.get(key)
     if r is not None:
         return r
@@ -66,6 +67,7 @@ def make_rule(ranges=(), forced=-1, top_k=0, top_p=None):
     r.forced, r.top_k = key[1], key[2]
     import numpy as np
     r.top_p_thr = -1.0 if (top_p is None or top_p >= 1.0) else float(np.float32(1.0 - float(top_p)))
+    r.temperature = key[4]
     if len(_RULE_CACHE) < 4096:
         _RULE_CACHE[key] = r
     return r

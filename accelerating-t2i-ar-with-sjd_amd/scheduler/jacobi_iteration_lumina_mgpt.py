@@ -196,7 +196,8 @@ def hf_generate(model, inputs=None, generation_config=None, logits_processor=Non
     ML:406-411): the generation length (max_new_tokens wins over max_length), EOS / max-length stopping criteria, the user's logits
     processors followed by a TopKLogitsWarper when `generation_config.top_k` is set, then
     `model._sample(input_ids, processors, criteria, generation_config, synced_gpus=False, streamer, attention_mask=, neg_input_ids=)`.
-    Anything that changes the distribution and has no kernel rule (temperature != 1, top_p via the config, beams, greedy) raises."""
+    `generation_config.temperature != 1` becomes a TemperatureLogitsWarper in front of that TopKLogitsWarper, as in HF.  Anything that
+    changes the distribution and has no kernel rule (top_p via the config, beams, greedy) raises."""
     import copy
     from transformers import GenerationConfig
     from transformers.generation.logits_process import LogitsProcessorList
@@ -210,8 +211,8 @@ def hf_generate(model, inputs=None, generation_config=None, logits_processor=Non
             setattr(gc, k, kwargs.pop(k))
     if not getattr(gc, "do_sample", False) or (getattr(gc, "num_beams", 1) or 1) != 1:
         raise NotImplementedError("the SJD hot path samples (do_sample=True, num_beams=1)")
-    if (getattr(gc, "temperature", None) or 1.0) != 1.0 or (getattr(gc, "top_p", None) or 1.0) != 1.0:
-        raise NotImplementedError("temperature / top_p through GenerationConfig have no kernel rule (the drivers use 1.0)")
+    if (getattr(gc, "top_p", None) or 1.0) != 1.0:
+        raise NotImplementedError("top_p through GenerationConfig is not wired (the drivers pass TopPLogitsWarper3d themselves or use 1.0)")
     P = ids.shape[1]
     if getattr(gc, "max_new_tokens", None) is not None:
         gc.max_length = P + int(gc.max_new_tokens)
@@ -222,7 +223,10 @@ def hf_generate(model, inputs=None, generation_config=None, logits_processor=Non
                       f"at {limit} tokens (HF warns and goes on; rows past the context could never be positioned here)", stacklevel=2)
         gc.max_length = int(limit)
     procs = LogitsProcessorList(list(logits_processor or []))
-    if getattr(gc, "top_k", None):               # HF appends the warpers after the user's processors
+    if (getattr(gc, "temperature", None) or 1.0) != 1.0:       # HF appends the warpers after the user's processors: temperature first
+        from .logit_processor_3dim import TemperatureLogitsWarper
+        procs.append(TemperatureLogitsWarper(float(gc.temperature)))
+    if getattr(gc, "top_k", None):
         procs.append(TopKLogitsWarper(int(gc.top_k)))
     crit = list(stopping_criteria or [])
     if getattr(gc, "eos_token_id", None) is not None:

@@ -70,6 +70,16 @@ class TopKLogitsWarper(_Descriptor):
         self.top_k = max(int(top_k), min_tokens_to_keep)
 
 
+class TemperatureLogitsWarper(_Descriptor):
+    """Stand-in for transformers' TemperatureLogitsWarper (same attribute; the HF object is accepted as well): scores / temperature, which
+    HF's generate() appends behind the user's processors when GenerationConfig.temperature != 1"""
+
+    def __init__(self, temperature: float):
+        if not isinstance(temperature, (int, float)) or not (temperature > 0):
+            raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float")        # HF's own check
+        self.temperature = float(temperature)
+
+
 class AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(_Descriptor):
     def __init__(self, trigger_token_id: int, allowed_token_ids: List[int], offset: int, exclusive: bool = False, device="cpu"):
         self.trigger_token_id, self.allowed_token_ids, self.offset, self.exclusive = trigger_token_id, list(allowed_token_ids), offset, exclusive
@@ -107,6 +117,13 @@ def get_double_cfg_input_ids(input_ids, neg_input_ids, pad_category):
 def grammar_from_processors(processors, prompt_len=None, max_length=None):
     """LogitsProcessorList -> integer grammar driving kernels K2/K4.  Raises for processors this engine does not know."""
     procs = list(processors)
+    temps = [p for p in procs if type(p).__name__ == "TemperatureLogitsWarper"]
+    if temps:                     # scale-invariant with respect to every other processor here (masks, top-k): one scalar of the rules
+        if len(temps) > 1:
+            raise NotImplementedError("more than one TemperatureLogitsWarper in the processor list")
+        g = grammar_from_processors([p for p in procs if p is not temps[0]], prompt_len=prompt_len, max_length=max_length)
+        g.temperature = float(temps[0].temperature)
+        return g
     names = [type(p).__name__ for p in procs]
     if len(procs) >= 1 and isinstance(procs[0], MultiTokensVLLogitsProcessor):
         vl = procs[0]

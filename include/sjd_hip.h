@@ -44,6 +44,10 @@ typedef struct sjd_row_rule {
     int32_t forced;                 /* >=0: p = one-hot(forced) (forced EOL / end-of-image rows); -1: none */
     int32_t top_k;                  /* <=0 or >=V: off */
     float   top_p_thr;              /* float32(1 - top_p); <0: off */
+    float   temperature;            /* HF TemperatureLogitsWarper (scores / temperature, applied after the processors and the grammar's
+                                     * own top-k, before top-p and the softmax -- where transformers' generate() puts it, third-party
+                                     * 4.47.1 `_get_logits_processor`); 1 (or <= 0): off.  The residual call of the verify step sees the
+                                     * same warper: softmax(log(max(p - q, 0)) / temperature) (JL:203-241) */
 } sjd_row_rule;
 
 /* Host-built, device-resident control blob for ONE SJD iteration. */

@@ -49,6 +49,9 @@ typedef struct {
     int32_t forced;                /* >=0: row is -inf except [forced]=0 (LP:39-41); -1: none */
     int32_t top_k;                 /* <=0 or >=V: no top-k */
     float   top_p_thr;             /* float32(1 - top_p) (LP:411); < 0: no top-p */
+    float   temperature;           /* HF TemperatureLogitsWarper: scores / temperature after the processors above, before top-p and
+                                    * the softmax (transformers 4.47.1 generation/utils.py `_get_logits_processor`: warpers follow the
+                                    * user's processors; logits_process.py TemperatureLogitsWarper.__call__); 1 or <= 0: off */
 } sjd_row_rule;
 
 /* ---------------------------------------------------------------- canonical numerics */
@@ -74,6 +77,39 @@ static float sjd_expf(float x)
     union { uint32_t u; float f; } s;
     s.u = (uint32_t)(ni + 127) << 23;
     return y * s.f;
+}
+
+/* canonical natural logarithm of a positive finite float (musl / fdlibm logf), operations rounded separately in the order written;
+ * the HIP side (csrc/sjd_device.h::sjd_logf) is the same sequence.  Used only by the temperature path of the residual resample. */
+static float sjd_logf(float x)
+{
+    const float LN2_HI = 6.9313812256e-01f, LN2_LO = 9.0580006145e-06f;
+    const float LG1 = 0.66666662693f, LG2 = 0.40000972152f, LG3 = 0.28498786688f, LG4 = 0.24279078841f;
+    union { float f; uint32_t u; } c;
+    c.f = x;
+    uint32_t ix = c.u;
+    int k = 0;
+    if (ix < 0x00800000u) { x = x * 33554432.0f; k = -25; c.f = x; ix = c.u; }
+    ix += 0x3f800000u - 0x3f3504f3u;
+    k += (int)(ix >> 23) - 0x7f;
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    c.u = ix;
+    const float xr = c.f;
+    const float f = xr - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float w = z * z;
+    const float t1 = w * (LG2 + w * LG4);
+    const float t2 = z * (LG1 + w * LG3);
+    const float R = t2 + t1;
+    const float hfsq = (0.5f * f) * f;
+    const float dk = (float)k;
+    float r = s * (hfsq + R);
+    r = r + dk * LN2_LO;
+    r = r - hfsq;
+    r = r + f;
+    r = r + dk * LN2_HI;
+    return r;
 }
 
 static float sjd_canonical_sum(const float *v, int V)
@@ -151,6 +187,8 @@ static void apply_rule(float *z, int V, const sjd_row_rule *r, float *scratch)
         float kth = kth_largest(z, V, r->top_k, scratch);
         for (int i = 0; i < V; ++i) if (z[i] < kth) z[i] = -INFINITY;
     }
+    if (r->temperature > 0.0f && r->temperature != 1.0f)   /* TemperatureLogitsWarper: after the grammar and its top-k, before top-p */
+        for (int i = 0; i < V; ++i) if (z[i] > -INFINITY) z[i] = z[i] / r->temperature;
     if (r->top_p_thr >= 0.0f) {                            /* LP:406-419 */
         float m = -INFINITY;
         for (int i = 0; i < V; ++i) if (z[i] > m) m = z[i];
@@ -281,6 +319,15 @@ int sjd_o_verify_accept(int n, int V, const int64_t *win_tok, int64_t *tokens, c
                     for (int c = 0; c < V; ++c) if (d[c] < kth) d[c] = 0.0f;
             }
             float S = sjd_canonical_sum(d, V);
+            if (r->temperature > 0.0f && r->temperature != 1.0f && S > 0.0f) {
+                /* the warper list of the residual call holds the TemperatureLogitsWarper too (JL:222-228): weights
+                 * exp(log(d) / T - max) instead of d */
+                float dm = 0.0f;
+                for (int c = 0; c < V; ++c) if (d[c] > dm) dm = d[c];
+                const float lm = sjd_logf(dm) / r->temperature;
+                for (int c = 0; c < V; ++c) d[c] = d[c] > 0.0f ? sjd_expf(sjd_logf(d[c]) / r->temperature - lm) : 0.0f;
+                S = sjd_canonical_sum(d, V);
+            }
             if (r->top_p_thr >= 0.0f) {                     /* top-p on softmax(log d) = d/S, LP:406-419 */
                 float dm = 0.0f;
                 int imax = 0;
@@ -310,4 +357,5 @@ int sjd_o_first_mismatch(int n, const int64_t *win_tok, const int64_t *tokens)
 
 /* exported so tests can pin the canonical primitives themselves */
 float sjd_o_expf(float x) { return sjd_expf(x); }
+float sjd_o_logf(float x) { return sjd_logf(x); }
 float sjd_o_sum(const float *v, int V) { return sjd_canonical_sum(v, V); }

@@ -23,7 +23,7 @@ MAX_RANGES = 4
 
 class RowRule(ctypes.Structure):
     _fields_ = [("n_ranges", ctypes.c_int32), ("lo", ctypes.c_int32 * MAX_RANGES), ("hi", ctypes.c_int32 * MAX_RANGES),
-                ("forced", ctypes.c_int32), ("top_k", ctypes.c_int32), ("top_p_thr", ctypes.c_float)]
+                ("forced", ctypes.c_int32), ("top_k", ctypes.c_int32), ("top_p_thr", ctypes.c_float), ("temperature", ctypes.c_float)]
 
 
 def build():
@@ -48,6 +48,8 @@ def lib():
         _lib.sjd_o_first_mismatch.argtypes = [ctypes.c_int, i64p, i64p]
         _lib.sjd_o_expf.argtypes = [ctypes.c_float]
         _lib.sjd_o_expf.restype = ctypes.c_float
+        _lib.sjd_o_logf.argtypes = [ctypes.c_float]
+        _lib.sjd_o_logf.restype = ctypes.c_float
         _lib.sjd_o_sum.argtypes = [f32p, ctypes.c_int]
         _lib.sjd_o_sum.restype = ctypes.c_float
         _lib.sjd_o_max_threads.restype = ctypes.c_int
@@ -68,8 +70,9 @@ def top_p_threshold(top_p):
     return float(np.float32(1.0 - float(top_p)))
 
 
-def rule(ranges=(), forced=-1, top_k=0, top_p=None):
+def rule(ranges=(), forced=-1, top_k=0, top_p=None, temperature=1.0):
     r = RowRule()
+    r.temperature = float(temperature or 1.0)
     ranges = list(ranges)
     assert len(ranges) <= MAX_RANGES, ranges
     r.n_ranges = len(ranges)
@@ -77,6 +80,19 @@ def rule(ranges=(), forced=-1, top_k=0, top_p=None):
         r.lo[i], r.hi[i] = int(lo), int(hi)
     r.forced, r.top_k, r.top_p_thr = int(forced), int(top_k or 0), top_p_threshold(top_p)
     return r
+
+
+def tempered(rules_fn, temperature):
+    """rules_fn(ctx, n) -> the same rules with HF's TemperatureLogitsWarper(temperature) appended to the processor list (it follows the
+    user's processors in transformers' generate(); see sjd_oracle.c)"""
+    def fn(ctx, n):
+        out = []
+        for r in rules_fn(ctx, n):
+            c = RowRule.from_buffer_copy(r)
+            c.temperature = float(temperature)
+            out.append(c)
+        return out
+    return fn
 
 
 def rules_array(rules):

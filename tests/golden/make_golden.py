@@ -16,6 +16,7 @@ Fixtures
   fn_anole_grammar.npz          Anole image-only 3d processors          (JA:194-232, LP:207-353)
   fn_speculative_sampler.npz    SpeculativeSampler.__call__             (JL:247-315)
   fn_reguess.npz                get_multi_token_for_preparation('random') (JL:470-514)
+  fn_temperature.npz            the same two with HF's TemperatureLogitsWarper in the processor list (GenerationConfig.temperature != 1)
   loop_llamagen.npz             whole _sample loop, tiny LlamaGen c2i   (JL:912-1249, LS:349-456)
   loop_lumina.npz               whole _sample loop, tiny Chameleon      (JL:912-1249, MC)
   vq_decoders.npz               image detokenizers: LlamaGen VQModel.decode_code and the Chameleon VQGAN decode of
@@ -31,7 +32,9 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
-sys.path.insert(0, ROOT)
+# (ROOT must NOT be on sys.path: the repo root carries drop-in packages with the reference's own names -- scheduler/, llamagen/, emu3/ ... --
+#  and, being regular packages, they would shadow the reference's __init__-less directories whatever the path order)
+sys.path[:] = [p_ for p_ in sys.path if os.path.abspath(p_ or os.getcwd()) != ROOT]
 
 import _ref_shims  # noqa: E402
 
@@ -46,6 +49,7 @@ _spec.loader.exec_module(synthetic)
 
 import scheduler.jacobi_iteration_lumina_mgpt as JL  # noqa: E402  (the reference)
 import scheduler.logit_processor_3dim as LP  # noqa: E402
+assert JL.__file__.startswith("/root/reference/") and LP.__file__.startswith("/root/reference/"), (JL.__file__, LP.__file__)
 from transformers.generation.logits_process import LogitsProcessorList, TopKLogitsWarper  # noqa: E402
 
 torch.set_grad_enabled(False)
@@ -315,6 +319,70 @@ def gen_fn_speculative_sampler():
     print("fn_speculative_sampler ok", [(m["mode"], int(out[m["name"] + ".first_misaligned"][0])) for m in meta])
 
 
+def gen_fn_temperature():
+    """HF's TemperatureLogitsWarper in the processor list, as transformers' generate() leaves it there when
+    GenerationConfig.temperature != 1 (behind the user's processors): sampling_logits2tokens (JL:82-132) and the residual call of
+    SpeculativeSampler (JL:203-241), which runs the same list on log(max(p - q, 0))."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper
+    V = 9216
+    out, meta = {}, []
+
+    def procs(T):
+        return LogitsProcessorList([
+            LP.MultiTokensVLLogitsProcessor(image_start_token_id=8197, image_end_token_id=8196,
+                                            image_next_line_token_id=8803, patch_size=32, voc_size=V),
+            LP.MultiTokensInterleavedTopKLogitsWarper(image_top_k=2000, text_top_k=10,
+                                                      image_start_token_id=8197, image_end_token_id=8196),
+            TemperatureLogitsWarper(T)])
+
+    cols = sample_cols(V)
+    for ci, (T, nrows, nimg) in enumerate([(0.7, 16, 11), (1.5, 16, 11), (0.35, 5, 9), (2.5, 16, 3)]):
+        ctx = lumina_context(12, 4, 4, nimg, seed=400 + ci)
+        logits = torch.randn(2, nrows, V, generator=torch.Generator().manual_seed(4000 + ci)) * 3.0
+        gen = torch.Generator().manual_seed(4100 + ci)
+        toks, probs = JL.sampling_logits2tokens(
+            logits, ctx, torch.ones(1, dtype=torch.long), None, output_token_num=nrows,
+            logits_processor=procs(T), logits_warper=None, do_sample=True, has_eos_stopping_criteria=False,
+            do_cfg=True, guidance_scale=3.0, generator=gen, is_force_no_cfg=False)
+        name = f"s{ci}"
+        out[f"{name}.ctx"] = ctx.numpy()
+        out[f"{name}.tokens"] = toks.numpy()
+        out[f"{name}.nnz"] = (probs[0] > 0).sum(-1).numpy()
+        out[f"{name}.pmax"] = probs[0].max(-1).values.numpy()
+        out[f"{name}.p_at_tok"] = probs[0].gather(-1, toks[0][:, None])[:, 0].numpy()
+        out[f"{name}.p_cols"] = probs[0][:, cols].numpy()
+        meta.append(dict(name=name, kind="sample", V=V, nrows=nrows, temperature=T, logits_seed=4000 + ci, noise_seed=4100 + ci,
+                         logits_scale=3.0, guidance_scale=3.0, image_top_k=2000, text_top_k=10))
+    for ci, (T, mode, L) in enumerate([(0.7, "mixed", 16), (1.5, "far", 16), (0.5, "fresh", 16), (2.0, "mixed", 16)]):
+        p, q, draft = make_pq(V, L, 9100 + ci, mode)
+        adv_tokens = torch.multinomial(p[0], 1, generator=torch.Generator().manual_seed(9600 + ci))[:, 0][None]
+        gen = torch.Generator().manual_seed(9950 + ci)
+        sampler = JL.SpeculativeSampler(
+            generator=gen, reject_sampling_relative_ids=-torch.ones(1, dtype=torch.long),
+            reject_sampling_draft_token_logits=torch.zeros((1, V), dtype=torch.long),
+            sampling_last_draft_token=torch.zeros((1,), dtype=torch.long))
+        ctx = lumina_context(12, 4, 4, 3, seed=500 + ci)
+        inds, toks, scores = sampler(draft_tokens=draft, advanced_tokens=adv_tokens.clone(), draft_prob=q, advanced_prob=p,
+                                     logits_processor=procs(T), logits_warper=None, all_collected_input_ids=ctx)
+        name = f"v{ci}"
+        fm = int(inds[0])
+        out[f"{name}.ctx"] = ctx.numpy()
+        out[f"{name}.first_misaligned"] = np.array(inds)
+        out[f"{name}.tokens"] = toks.numpy()
+        out[f"{name}.adv_tokens"] = adv_tokens.numpy()
+        out[f"{name}.draft"] = draft.numpy()
+        if fm < L:       # the resampled row's distribution (scores[:, fm-1] is softmax(processors(log(max(p - q, 0)))))
+            out[f"{name}.resid_p_cols"] = scores[0, fm - 1][cols].numpy()
+            out[f"{name}.resid_nnz"] = np.array(int((scores[0, fm - 1] > 0).sum()))
+        meta.append(dict(name=name, kind="verify", V=V, L=L, mode=mode, temperature=T, pq_seed=9100 + ci, adv_seed=9600 + ci,
+                         noise_seed=9950 + ci))
+    out["meta"] = np.array(json.dumps(meta))
+    out["cols"] = cols.numpy()
+    np.savez_compressed(os.path.join(HERE, "fn_temperature.npz"), **out)
+    print("fn_temperature ok", [(m["name"], m["temperature"]) for m in meta],
+          [int(out[m["name"] + ".first_misaligned"][0]) for m in meta if m["kind"] == "verify"])
+
+
 def gen_fn_reguess():
     out, meta = {}, []
     img_vocab = torch.arange(4, 8196)
@@ -547,6 +615,8 @@ if __name__ == "__main__":
         gen_fn_anole_grammar()
         gen_fn_speculative_sampler()
         gen_fn_reguess()
+    if "fn" in which or "temp" in which:
+        gen_fn_temperature()
     if "loops" in which:
         gen_loop_llamagen()
         gen_loop_lumina()

@@ -184,7 +184,10 @@ def test_hf_generate_builds_criteria_and_topk_then_calls_sample():
     assert seen["procs"] == ["Proc", "TopKLogitsWarper"] and seen["eos"] == [[202]]
     assert seen["max_len"] == [64]                                   # 10 + 40960, bounded by the model's context
     assert set(seen["kw"]) == {"attention_mask", "neg_input_ids"} and gc.max_length != 64       # the caller's config is not mutated
+    # temperature: a TemperatureLogitsWarper behind the user's processors and in front of the top-k warper, as HF orders its warpers
+    hf_generate(M(), ids, GenerationConfig(do_sample=True, temperature=0.7, top_k=50, max_new_tokens=4), logits_processor=[Proc()])
+    assert seen["procs"] == ["Proc", "TemperatureLogitsWarper", "TopKLogitsWarper"]
     with pytest.raises(NotImplementedError):
-        hf_generate(M(), ids, GenerationConfig(do_sample=True, temperature=0.7, max_new_tokens=4))
+        hf_generate(M(), ids, GenerationConfig(do_sample=True, top_p=0.9, max_new_tokens=4))
     with pytest.raises(NotImplementedError):
         hf_generate(M(), ids, GenerationConfig(do_sample=False, max_new_tokens=4))

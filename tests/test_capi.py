@@ -28,8 +28,8 @@ def test_exports_match_header():
 
 def test_struct_layouts_match_header():
     L = _ensure_built()
-    assert ctypes.sizeof(L.RowRule) == 48
-    assert ctypes.sizeof(L.IterParams) == 64 + 8 * 32 + 2 * 48 * 32                               # static_assert'ed in sjd_sampling.hip
+    assert ctypes.sizeof(L.RowRule) == 52 and L.RowRule.temperature.offset == 48
+    assert ctypes.sizeof(L.IterParams) == 64 + 8 * 32 + 2 * 52 * 32                               # static_assert'ed in sjd_sampling.hip
     assert L.IterParams.kv_len.offset == 4 and L.IterParams.batch_rows.offset == 0x14            # the inline s_load offsets of sjdi_kv_rows
     assert L.IterParams.philox_blocks.offset == 28 and L.IterParams.philox_seed.offset == 32 and L.IterParams.philox_offset.offset == 40
     assert L.IterParams.fresh_tok.offset == 64 and L.IterParams.rules.offset == 64 + 256

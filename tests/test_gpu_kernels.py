@@ -71,6 +71,12 @@ K2_CASES = [
     ("llamagen_top_p_0.9", 16384, 16, lambda n: O.llamagen_rules([], n, 1000, 0.9)),
     ("llamagen_top_p_only", 16384, 4, lambda n: O.llamagen_rules([], n, 0, 0.5)),
     ("lumina_range_top_p", 65536, 4, lambda n: [O.rule(((4, 8196),), -1, 2000, 0.95) for _ in range(n)]),
+    # HF's TemperatureLogitsWarper behind the processors (GenerationConfig.temperature != 1): sharpened, flattened, with top-p, with EOL rows
+    ("lumina_image_T0.7", 65536, 16, lambda n: O.tempered(lambda c, k: O.lumina_rules(c, k, 2000, 10), 0.7)([9000] * 5 + [8197, 8828, 8828] + [100] * 40, n)),
+    ("lumina_eol_rows_T1.5", 9216, 16, lambda n: O.tempered(lambda c, k: O.lumina_rules(c, k, 2000, 10), 1.5)([9000] * 5 + [8197, 8808, 8808] + [100] * 3, n)),
+    ("llamagen_top_p_T0.8", 16384, 8, lambda n: O.tempered(lambda c, k: O.llamagen_rules(c, k, 1000, 0.9), 0.8)([], n)),
+    ("emu3_T2.0", 184622, 4, lambda n: O.tempered(lambda c, k: O.emu3_rules(c, k, 90, 90, 151854, 32768, 151851, 151853, 151850, 151846, 151847,
+                                                                            151643, 2048), 2.0)([5, 6, 151851] + [151854 + 7] * 88, n)),
 ]
 
 
@@ -180,7 +186,9 @@ def run_k4(dev, win, Y, p, q_rows, rs, resid, e2, scheme=0, max_rows=16):
 @pytest.mark.parametrize("mode,L,grammar", [("carried", 16, None), ("mixed", 16, None), ("fresh", 16, None),
                                             ("far", 16, None), ("equal", 8, None), ("mixed", 16, "lumina"),
                                             ("fresh", 2, None), ("mixed", 16, "llamagen"), ("mixed", 32, None),
-                                            ("mixed", 16, "llamagen_topp"), ("far", 16, "llamagen_topp")])
+                                            ("mixed", 16, "llamagen_topp"), ("far", 16, "llamagen_topp"),
+                                            ("mixed", 16, "lumina_T0.7"), ("far", 16, "lumina_T1.5"), ("fresh", 16, "llamagen_topp_T0.6"),
+                                            ("mixed", 32, "plain_T2.0")])
 @pytest.mark.parametrize("V", [9216, 65536])
 def test_k4_bit_exact(dev, mode, L, grammar, V):
     seed = 9000 + L + len(mode)
@@ -197,6 +205,14 @@ def test_k4_bit_exact(dev, mode, L, grammar, V):
         rfn = lambda c: O.llamagen_rules(c, 1, 100, 1.0)[0]
     elif grammar == "llamagen_topp":
         rfn = lambda c: O.llamagen_rules(c, 1, 200, 0.8)[0]
+    elif grammar == "lumina_T0.7":          # residual resample under a TemperatureLogitsWarper: softmax(log(max(p - q, 0)) / T)
+        rfn = lambda c: O.tempered(lambda cc, k: O.lumina_rules(cc, k, 2000, 10), 0.7)(c, 1)[0]
+    elif grammar == "lumina_T1.5":
+        rfn = lambda c: O.tempered(lambda cc, k: O.lumina_rules(cc, k, 2000, 10), 1.5)(c, 1)[0]
+    elif grammar == "llamagen_topp_T0.6":
+        rfn = lambda c: O.tempered(lambda cc, k: O.llamagen_rules(cc, k, 200, 0.8), 0.6)(c, 1)[0]
+    elif grammar == "plain_T2.0":
+        rfn = lambda c: O.rule(temperature=2.0)
     else:
         rfn = lambda c: O.rule()
     resid = [rfn(ctx + win[1:i]) for i in range(1, L)]

@@ -89,6 +89,16 @@ def test_three_and_four_prompts_share_one_window_forward(n_prompts, fp8_kv):
     assert len(rs) == n_prompts and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs) and any(r["max_accept"] > 1 for r in rs)
 
 
+@pytest.mark.parametrize("temperature,use_graph,gemm", [(0.7, True, "sjd"), (1.6, False, "torch")])
+def test_lumina_loop_with_temperature(temperature, use_graph, gemm):
+    """GenerationConfig.temperature != 1 through the whole loop: every window's K2 and every rejection's K4 resample under the
+    TemperatureLogitsWarper, teacher-forced against the oracle (whose temperature path is pinned to the reference by
+    tests/test_oracle_golden.py::test_temperature_warper_in_the_processor_list)."""
+    from tests.gpu_loop_check import teacher_forced_lumina_check
+    r = teacher_forced_lumina_check(temperature=temperature, use_graph=use_graph, gemm=gemm, hg=5, wg=5, seed=13)
+    assert r["tokens"] >= 100 and r["last"] == 8196
+
+
 @pytest.mark.parametrize("init_scheme,n_prompts,use_graph", [("repeat_horizon", 2, True), ("sample_horizon", 3, True), ("sample_horizon", 2, False)])
 def test_batch_engine_spatial_init(init_scheme, n_prompts, use_graph):
     """multi_token_init_scheme 'repeat_horizon' / 'sample_horizon' in the several-prompts-per-forward engine (round 3: it raised before):

@@ -32,9 +32,12 @@ def gen_inputs(m, key_logits="logits_seed", key_noise="noise_seed", ctx_gen=None
     return logits.numpy(), noise.numpy()
 
 
-def check_probs(d, name, toks, probs, cols):
+def check_probs(d, name, toks, probs, cols, exact_support=True):
     assert toks.tolist() == d[f"{name}.tokens"][0].tolist()
-    assert ((probs > 0).sum(-1) == d[f"{name}.nnz"]).all()
+    if exact_support:
+        assert ((probs > 0).sum(-1) == d[f"{name}.nnz"]).all()
+    else:       # sharpened distributions: torch's exp keeps denormals down to e^-103, the canonical exp is 0 below e^-87
+        assert ((probs > 0).sum(-1) <= d[f"{name}.nnz"]).all() and ((probs > 0).sum(-1) >= 1).all()
     np.testing.assert_allclose(probs.max(-1), d[f"{name}.pmax"], atol=P_ATOL, rtol=P_RTOL)
     np.testing.assert_allclose(probs[:, cols], d[f"{name}.p_cols"], atol=P_ATOL, rtol=P_RTOL)
     np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-5)
@@ -138,6 +141,47 @@ def test_speculative_sampler(golden_dir):
         q_imp = [None if (onehot[i] and i > 0) else q_rows[i] for i in range(L)]
         mm2, toks2, _ = O.verify_accept(win, adv, p[0].numpy(), q_imp, rs, resid, e2)
         assert (mm2, toks2.tolist()) == (mm, toks.tolist())
+
+
+def test_temperature_warper_in_the_processor_list(golden_dir):
+    """HF's TemperatureLogitsWarper behind the reference's processors (what transformers' generate() does with
+    GenerationConfig.temperature != 1): sampling_logits2tokens and the residual resample of SpeculativeSampler, vectors produced by the
+    imported reference (tests/golden/make_golden.py::gen_fn_temperature) -- tokens and accept lengths bit-exact, probabilities within
+    the usual tolerance.  Also pins the canonical logarithm the residual path uses."""
+    xs = np.concatenate([np.float32(10.0) ** np.linspace(-37, 0, 500, dtype=np.float32), np.linspace(0.5, 2.0, 301, dtype=np.float32)])
+    got = np.array([O.lib().sjd_o_logf(float(x)) for x in xs], dtype=np.float64)
+    ref = np.log(xs.astype(np.float64))
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6)) < 4e-7 and O.lib().sjd_o_logf(1.0) == 0.0
+    d, meta = load(golden_dir, "fn_temperature.npz")
+    cols = d["cols"]
+    for m in meta:
+        name, T = m["name"], m["temperature"]
+        ctx = d[f"{name}.ctx"][0].tolist()
+        if m["kind"] == "sample":
+            logits, noise = gen_inputs(m)
+            rules = O.tempered(lambda c, n: O.lumina_rules(c, n, m["image_top_k"], m["text_top_k"]), T)(ctx, m["nrows"])
+            toks, probs = O.logits_to_probs_sample(logits[0], logits[1], m["guidance_scale"], rules, noise)
+            check_probs(d, name, toks, probs, cols, exact_support=T >= 1.0)
+            np.testing.assert_allclose(probs[np.arange(len(toks)), toks], d[f"{name}.p_at_tok"], atol=P_ATOL, rtol=P_RTOL)
+            # and it is not the untempered distribution
+            _, p1 = O.logits_to_probs_sample(logits[0], logits[1], m["guidance_scale"], O.lumina_rules(ctx, m["nrows"], 2000, 10), noise)
+            live = [i for i, r in enumerate(rules) if r.forced < 0]
+            assert np.abs(p1[live] - probs[live]).max() > 1e-3
+        else:
+            V, L = m["V"], m["L"]
+            p, q, draft = make_pq(V, L, m["pq_seed"], m["mode"])
+            assert draft[0].tolist() == d[f"{name}.draft"][0].tolist()
+            adv = d[f"{name}.adv_tokens"][0]
+            gen = torch.Generator().manual_seed(m["noise_seed"])
+            rs = torch.rand((1, L, V), generator=gen)[0].numpy()
+            e2 = torch.empty(1, V).exponential_(generator=gen)[0].numpy()
+            win = draft[0].tolist()
+            rfn = O.tempered(lambda c, n: O.lumina_rules(c, n, 2000, 10), T)
+            resid = [rfn(ctx + win[1:i], 1)[0] for i in range(1, L)]
+            q_rows = [q[0, i].numpy() for i in range(L)]
+            mm, toks, rej = O.verify_accept(win, adv, p[0].numpy(), q_rows, rs, resid, e2)
+            assert mm == int(d[f"{name}.first_misaligned"][0]) and mm < L and rej, name
+            assert toks.tolist() == d[f"{name}.tokens"][0].tolist(), name
 
 
 def test_reguess(golden_dir):

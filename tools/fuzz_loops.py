@@ -34,7 +34,8 @@ def main():
                           scheme=rnd.choice(["speculative_jacobi", "speculative_jacobi", "jacobi"]), use_graph=rnd.random() < 0.6,
                           fused=True, gemm=rnd.choice(["torch", "sjd"]), fp8_kv=rnd.random() < 0.3,
                           dtype=rnd.choice([torch.bfloat16, torch.float16]),
-                          init_scheme=rnd.choice(["random", "random", "repeat_horizon", "sample_horizon"]))
+                          init_scheme=rnd.choice(["random", "random", "repeat_horizon", "sample_horizon"]),
+                          temperature=rnd.choice([1.0, 1.0, 0.6, 0.85, 1.4, 2.2]))
                 r = G.teacher_forced_lumina_check(**kw)
                 r.pop("windows", None)
             elif kind == "emu3":
@@ -51,7 +52,8 @@ def main():
                 n_prompts = rnd.choice([2, 2, 3, 4])
                 kw = dict(seed=seed, n_prompts=n_prompts, window=rnd.choice([8, 16] if n_prompts < 4 else [4, 8, 16]),
                           P=rnd.choice([(12, 9, 14, 7), (7, 7, 7, 7), (10, 15, 5, 11)]), gemm=rnd.choice(["torch", "sjd"]),
-                          use_graph=rnd.random() < 0.6, fp8_kv=rnd.random() < 0.3)
+                          use_graph=rnd.random() < 0.6, fp8_kv=rnd.random() < 0.3,
+                          init_scheme=rnd.choice(["random", "random", "repeat_horizon", "sample_horizon"]))
                 r = G.teacher_forced_batch_check(**kw)
             ok += 1
             print(f"[{i}] ok {kind} {kw} -> {r if not isinstance(r, list) else r[:2]}", flush=True)

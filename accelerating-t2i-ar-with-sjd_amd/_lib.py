@@ -55,8 +55,7 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_logits_to_probs_sample_part", "sjd_logits_to_probs_sample_ex", "sjd_reguess_ex",
            "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu", "sjd_host_wait_u64",
            "sjd_philox_fill", "sjd_philox_offset_increment", "sjd_skinny_gemm_reduce", "sjd_reduce_timeouts",
-           "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged",
-           "sjd_draft_window_attention_partials", "sjd_draft_window_attention_fp8_partials", "sjd_skinny_gemm_attn"]
+           "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged"]
 
 _lib = None
 
@@ -91,9 +90,6 @@ def load():
     lib.sjd_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     lib.sjd_draft_window_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp]
     lib.sjd_draft_window_attention_ex.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]
-    lib.sjd_draft_window_attention_partials.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp]
-    lib.sjd_draft_window_attention_fp8_partials.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp, vp, i32, i32, vp, vp]
-    lib.sjd_skinny_gemm_attn.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_draft_window_attention_merged.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.sjd_draft_window_attention_fp8_merged.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp, vp, vp]
     lib.sjd_add_rmsnorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, vp, i32, vp]

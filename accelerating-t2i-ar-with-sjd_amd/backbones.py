@@ -35,10 +35,6 @@ import os as _os
 # -> tiles -> merge) remain inside the fused kernel (profiles/r2_attention_block.jsonl: 17.3 / 23.2 / 32.5 / 47.6 us against 17.7 / 21.6 /
 # 27.0 / 33.7 us at kv_len 64 / 448 / 1216 / 2368).  Default off; SJD_K1_FUSED=1 or model.k1_fused = True selects it.
 _K1_FUSED_DEFAULT = _os.environ.get("SJD_K1_FUSED", "0") == "1"
-# round 3: the merge of K1's key splits (k1_combine, a graph node of its own) moves into the staging of the output projection
-# (ops.skinny_gemm_attn); SJD_OPROJ_MERGE=0: k1_partial + k1_combine + G1 (A/B)
-_OPROJ_MERGE_DEFAULT = _os.environ.get("SJD_OPROJ_MERGE", "0") == "1"
-_OPROJ_MERGE_WAVES = int(_os.environ.get("SJD_OPROJ_MERGE_WAVES", "8"))
 _GATEUP_FUSED_DEFAULT = _os.environ.get("SJD_GATEUP_FUSED", "1") != "0"     # kernel G1s (gate|up + F3 in one launch); 0: G1 then F3
 # round 3 experiment, correct, tested, OFF by default: the o / down projections of a <= 32-row window can reduce their own
 # split-K planes, add the residual and write the row statistics in their tail (sjd_skinny_gemm_reduce: device-coherent exchange between
@@ -484,7 +480,7 @@ class ChameleonBackbone(nn.Module):
                                       kv_len if params is None else 0, kv_scale=getattr(self.attn, "kv_scale", (1.0, 1.0)),
                                       dtype=self.lm_head.weight.dtype, row_norm=row_norm)
 
-    def _attention_block(self, qkv_part, li, qn, pos, B, n, params, kv_len, key_start, row_norm=None, partials_ok=False):
+    def _attention_block(self, qkv_part, li, qn, pos, B, n, params, kv_len, key_start, row_norm=None):
         """QK-norm + RoPE + KV append + draft-window attention of one layer on the G1 partials of the q|k|v projection: kernel K1F (one
         launch) for the multi-head 16-row window, F2 then K1 (+ combine) otherwise."""
         ops, H, Hkv, D = self._ops, self.n_heads, self.n_kv_heads, self.head_dim
@@ -493,10 +489,6 @@ class ChameleonBackbone(nn.Module):
             return ops.qkv_attention_fused(qkv_part, self.cache.k[li], self.cache.v[li], *qn, self._inv_freq32, pos, B, n, H, D, params,
                                            kv_len if params is None else 0, key_start, row_norm=row_norm, dtype=self.lm_head.weight.dtype)
         q = self._f2(qkv_part, li, qn, pos, B, n, params, kv_len, row_norm=row_norm)
-        if partials_ok and ks_ok and hasattr(self.attn, "attend_partials"):
-            ap = self.attn.attend_partials(li, q, self.cache, kv_len, key_start)
-            if ap is not None:
-                return ap                # the key splits stay unmerged: the output projection merges them while it stages them
         return self.attn.attend(li, q, self.cache, kv_len, key_start)
 
     def _forward_window_g1_folded(self, tokens, positions, kv_len, key_start, cols=None, head_partials=False):
@@ -514,7 +506,6 @@ class ChameleonBackbone(nn.Module):
         red = getattr(self, "reduce_fused", _REDUCE_FUSED_DEFAULT) and not self._pf_on
         red_o = red and ops.skinny_gemm_reduce_ok(T, hid, H * D, cfg["o"][0], 8, h_dev := self.lm_head.weight.device)
         red_d = red and ops.skinny_gemm_reduce_ok(T, hid, inter, cfg["down"][0], 8, h_dev)
-        comb = getattr(self, "oproj_merges_splits", _OPROJ_MERGE_DEFAULT) and not red_o and not self._pf_on and T <= 32
         h = self.model.embed_tokens(tokens).view(T, -1).contiguous()
         pos = positions.reshape(T).contiguous()
         delta, ss_next = None, None         # the down projection's split-K planes (summed by the next F1r), or the statistics its tail already wrote
@@ -522,11 +513,8 @@ class ChameleonBackbone(nn.Module):
             a = layer.self_attn
             rn = (ss_next if ss_next is not None else ops.residual_sumsq(h, delta), hid, eps)
             qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
-            o = self._attention_block(g1(h, "qkv", (H + 2 * Hkv) * D, hid), li, qn, pos, B, n, params, kv_len, key_start, row_norm=rn,
-                                      partials_ok=comb)
-            if isinstance(o, ops.AttnPartials):
-                rn = (ops.residual_sumsq(h, ops.skinny_gemm_attn(o, self._packed[li]["o"], hid, cfg["o"][0], _OPROJ_MERGE_WAVES, cfg["o"][2])), hid, eps)
-            elif red_o:
+            o = self._attention_block(g1(h, "qkv", (H + 2 * Hkv) * D, hid), li, qn, pos, B, n, params, kv_len, key_start, row_norm=rn)
+            if red_o:
                 rn = (ops.skinny_gemm_reduce(o.view(T, H * D), self._packed[li]["o"], hid, H * D, cfg["o"][0], h, 8, cfg["o"][2]), hid, eps)
             else:
                 rn = (ops.residual_sumsq(h, g1(o.view(T, H * D), "o", hid, H * D)), hid, eps)

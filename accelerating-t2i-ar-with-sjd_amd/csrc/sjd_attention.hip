@@ -26,7 +26,6 @@
 
 #include "../../include/sjd_hip.h"
 #include "sjd_coherent.h"
-#include "sjd_k1_split.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -47,7 +46,10 @@ __device__ unsigned long long g_k1c_trace[4096][4];
 #define SJD_TR(i) do { } while (0)
 #define SJD_TRC(i) do { } while (0)
 #endif
+#define K1_KT 32          // keys per wave tile
+#define K1_ROWS 16        // query rows per chunk
 #define K1_RPAD 4          // fp32 padding of a merge-buffer row: rows 16 banks apart instead of on the same bank
+#define K1_MIN_TILES_PER_SPLIT 4   // a key split is only opened when it gets at least one tile per wave
 
 // What an attention kernel of the window forward needs before it can compute a single address: kv_len / n_rows of its batch row (device
 // blob) and the row's first visible key.  ONE scalar round trip: the three loads are issued together, as instructions (sjdi_kv_rows in
@@ -73,6 +75,18 @@ __device__ __forceinline__ void k1_entry(const sjd_iter_params *params, const in
     const int blob = br > 0 ? b / br : 0;
     if (blob == 0) { n_total = (int)(unsigned)(nk & 0xffffffffull); kv_base = (int)(unsigned)(nk >> 32); }
     else { kv_base = params[blob].kv_len; n_total = params[blob].n_rows; }
+}
+
+// Key-tile range [t_lo, t_hi) of a (batch row, chunk) and the number of splits actually used for it.  The launch grid
+// is sized for n_split (static, hipGraph friendly); splits >= the effective count exit immediately and are skipped by
+// the combine kernel, so short contexts do not pay for empty partials.
+__device__ __forceinline__ void k1_tile_range(int kstart, int total, int n_split, int &t_lo, int &t_hi, int &eff_split, int &tps)
+{
+    t_lo = kstart / K1_KT;
+    t_hi = (total + K1_KT - 1) / K1_KT;
+    const int nt = max(t_hi - t_lo, 0);
+    eff_split = min(n_split, max(1, (nt + K1_MIN_TILES_PER_SPLIT - 1) / K1_MIN_TILES_PER_SPLIT));
+    tps = (nt + eff_split - 1) / eff_split;
 }
 
 template <int DT> struct Frag;
@@ -118,6 +132,20 @@ __device__ __forceinline__ u32x2 lds_tr_read(const unsigned short *p)
 // ticket; the holder of the last ticket reads all partials back with device-coherent loads (one round trip: every split in flight) and
 // runs k1_combine's arithmetic in split order -- the output bits are those of k1_partial + k1_combine.  Nobody waits for anybody (no
 // spin, no residency assumption); the ticket re-arms itself.  One effective split (short contexts): the direct output, no exchange.
+// one step of the online merge of split partials (m, l, O[N]) into (M, L, acc[N]) -- shared by k1_combine and by the in-kernel merge of
+// k1_partial, written with explicit fma so that both give the same bits whatever the instruction selector makes of the code around it
+template <int N>
+__device__ __forceinline__ void k1_merge_step(float &M, float &L, float (&acc)[N], float m, float l, const float (&o)[N])
+{
+    const float Mn = fmaxf(M, m);
+    const float Msafe = (Mn == -INFINITY) ? 0.0f : Mn;
+    const float w0 = __expf(M - Msafe), w1 = __expf(m - Msafe);
+    L = __builtin_fmaf(L, w0, l * w1);
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = __builtin_fmaf(acc[j], w0, o[j] * w1);
+    M = Mn;
+}
+
 template <int DT, int D>
 __device__ __forceinline__ void k1_merge_splits(const float *__restrict__ ws_o, const float *__restrict__ ws_ml, unsigned short *__restrict__ out,
                                                 int G, int b, int H, int head0, int n_chunks, int chunk, int n_split, int eff_split,
@@ -1388,7 +1416,7 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     const bool shared = D == 128 && (pairs == 4 || pairs == 8) && (H / H_kv > 1 || n_chunks > 1) && !getenv("SJD_K1_NO_SHARED");
     // a single key split needs no combine: k1_partial normalises and writes the 16-bit output directly (SJD_K1_NO_DIRECT=1: tuning aid)
     static const bool no_direct = getenv("SJD_K1_NO_DIRECT") != nullptr;
-    unsigned short *direct = (!shared && n_split == 1 && !no_direct && out) ? (unsigned short *)out : nullptr;
+    unsigned short *direct = (!shared && n_split == 1 && !no_direct) ? (unsigned short *)out : nullptr;
     // round 3: the splits are merged by the last of their workgroups to finish (k1_merge_publish): no k1_combine launch (SJD_K1_NO_MERGE=1:
     // the two-kernel form, A/B).  `ticket`: one zero-initialised uint32 per (batch, kv head, chunk), handed over by the caller
     // (sjd_draft_window_attention_merged); they re-arm themselves.
@@ -1424,8 +1452,7 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
                            kv_len, n_split, n_chunks, merge_out, ticket);
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
-    if (direct || merge_out || !out) return SJD_OK;     // one key split, or the splits merged in the kernel: the output is written.
-                                                        // No `out`: the caller's next kernel merges the partials (sjd_skinny_gemm_attn)
+    if (direct || merge_out) return SJD_OK;             // one key split, or the splits merged in the kernel: the output is written
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
                        n_split, n_chunks, params, key_start, kv_len);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
@@ -1434,11 +1461,10 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
 static int k1_dispatch(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows,
                        int H, int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
                        const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream,
-                       void *ev_start, void *ev_stop, unsigned *ticket, bool partials_only = false)
+                       void *ev_start, void *ev_stop, unsigned *ticket)
 {
-    if (!q || !k_cache || !v_cache || (!out && !partials_only) || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
+    if (!q || !k_cache || !v_cache || !out || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
     if (H % H_kv != 0 || (S_max % K1_KT) != 0) return SJD_ERR_BAD_ARG;
-    if (partials_only && dtype == SJD_DTYPE_F32) return SJD_ERR_UNSUPPORTED;
     if (dtype == SJD_DTYPE_F32) {
         if ((size_t)S_max * sizeof(float) > 160 * 1024) return SJD_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(k1_f32, dim3(n_rows, H, B), dim3(64), (size_t)S_max * sizeof(float), (hipStream_t)stream, (const float *)q,
@@ -1480,16 +1506,6 @@ extern "C" int sjd_draft_window_attention_merged(const void *q, const void *k_ca
                        ev_start, ev_stop, (unsigned *)tickets);
 }
 
-// K1 WITHOUT its merge: only the key-split partials are written (workspace layout: sjd_k1_split.h), for a consumer that merges them while
-// it stages its input -- the output projection, sjd_skinny_gemm_attn.  Every split count (one included) leaves partials.
-extern "C" int sjd_draft_window_attention_partials(const void *q, const void *k_cache, const void *v_cache, int B, int n_rows, int H, int H_kv,
-                                                   int D, int S_max, int dtype, const int32_t *key_start, const sjd_iter_params *params,
-                                                   int kv_len, int n_split, void *workspace, void *stream)
-{
-    return k1_dispatch(q, k_cache, v_cache, nullptr, B, n_rows, H, H_kv, D, S_max, dtype, key_start, params, kv_len, n_split, workspace, stream,
-                       nullptr, nullptr, nullptr, true);
-}
-
 extern "C" int sjd_draft_window_attention(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
                                           int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
                                           const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream)
@@ -1527,7 +1543,7 @@ static int launch_attention_fp8(const void *q, const void *kc, const void *vc, v
     float *ws_o = (float *)workspace;
     float *ws_ml = ws_o + (size_t)B * H * n_chunks * n_split * K1_ROWS * D;
     static const bool no_direct = getenv("SJD_K1_NO_DIRECT") != nullptr;
-    unsigned short *direct = (n_split == 1 && !no_direct && out) ? (unsigned short *)out : nullptr;      // one key split: no combine launch
+    unsigned short *direct = (n_split == 1 && !no_direct) ? (unsigned short *)out : nullptr;      // one key split: no combine launch
     static const bool no_merge = getenv("SJD_K1_NO_MERGE") != nullptr;
     unsigned short *merge_out = (ticket && !direct && !no_merge) ? (unsigned short *)out : nullptr;      // splits merged by their last workgroup
     if (k1_waves() == 8)
@@ -1539,7 +1555,7 @@ static int launch_attention_fp8(const void *q, const void *kc, const void *vc, v
                            (const unsigned char *)kc, (const unsigned char *)vc, params, key_start, ws_o, ws_ml, direct, n_rows, H, H_kv, S_max,
                            kv_len, n_split, n_chunks, k_scale, v_scale, merge_out, ticket);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
-    if (direct || merge_out || !out) return SJD_OK;
+    if (direct || merge_out) return SJD_OK;
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
                        n_split, n_chunks, params, key_start, kv_len);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
@@ -1547,10 +1563,9 @@ static int launch_attention_fp8(const void *q, const void *kc, const void *vc, v
 
 static int k1_dispatch_fp8(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
                            int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
-                           const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream, unsigned *ticket,
-                           bool partials_only = false)
+                           const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream, unsigned *ticket)
 {
-    if (!q || !k_cache || !v_cache || (!out && !partials_only) || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
+    if (!q || !k_cache || !v_cache || !out || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
     if (H % H_kv != 0 || (S_max % K1_KT) != 0 || !(k_scale > 0.f) || !(v_scale > 0.f)) return SJD_ERR_BAD_ARG;
     const int G = H / H_kv;
     if (!(G == 1 || G == 2 || G == 4)) return SJD_ERR_UNSUPPORTED;
@@ -1581,14 +1596,6 @@ extern "C" int sjd_draft_window_attention_fp8_merged(const void *q, const void *
     if (!tickets) return SJD_ERR_BAD_ARG;
     return k1_dispatch_fp8(q, k_cache, v_cache, out, B, n_rows, H, H_kv, D, S_max, dtype, k_scale, v_scale, key_start, params, kv_len, n_split,
                            workspace, stream, (unsigned *)tickets);
-}
-
-extern "C" int sjd_draft_window_attention_fp8_partials(const void *q, const void *k_cache, const void *v_cache, int B, int n_rows, int H, int H_kv,
-                                                       int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
-                                                       const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream)
-{
-    return k1_dispatch_fp8(q, k_cache, v_cache, nullptr, B, n_rows, H, H_kv, D, S_max, dtype, k_scale, v_scale, key_start, params, kv_len, n_split,
-                           workspace, stream, nullptr, true);
 }
 
 extern "C" void *sjd_event_create(void)

@@ -21,7 +21,6 @@
 #include "../../include/sjd_hip.h"
 #include "sjd_mlp_epilogue.h"
 #include "sjd_coherent.h"
-#include "sjd_k1_split.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -62,11 +61,6 @@ template <> struct G1Mfma<SJD_DTYPE_F16> {
     static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c)
     { return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); }
 };
-
-// fp32 -> activation dtype, round to nearest even: the conversion k1_combine applies to the attention output (Frag<DT>::cvt there)
-template <int DT> __device__ __forceinline__ unsigned short g1_act_bits(float x);
-template <> __device__ __forceinline__ unsigned short g1_act_bits<SJD_DTYPE_BF16>(float x) { const __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
-template <> __device__ __forceinline__ unsigned short g1_act_bits<SJD_DTYPE_F16>(float x) { const _Float16 h = (_Float16)x; return __builtin_bit_cast(unsigned short, h); }
 
 // ---- F1r inside the producer (round 3; VERDICT r2 "next #3", the experiment DESIGN.md 4.6 item 6 stopped short of).
 // Every workgroup of an o / down launch has written its fp32 partial tile with device-coherent stores.  The workgroups that share a
@@ -164,22 +158,12 @@ __device__ __forceinline__ void g1_reduce_tail(const float *__restrict__ part, u
 // kernels of a layer (G1, G1s, K1, F2) add up to about the 64 KB instruction cache two CUs share; with a separate reducing instantiation
 // next to the plain one the working set no longer fitted and EVERY configuration of the library lost 2-3 us per layer, whichever
 // kernels it ran (bisected on one box by swapping single translation units, profiles/r3_code_layout_bisect.txt).
-// AS > 0 (round 3, MT = 1, <= 8 waves): the activation is not read from `x` but MERGED from the key-split partials of the draft-window
-// attention while it is staged (g1_attn_in) -- this is the output projection, and k1_combine, a graph node of its own between k1_partial and
-// this launch (4.9 us + the node boundary, 32 times per iteration), is gone.  AS = the number of split slots a piece keeps in flight.
-struct g1_attn_in {
-    const float *ws_o, *ws_ml;                 // K1's workspace (sjd_k1_split.h)
-    const sjd_iter_params *params;             // kv_len / n_rows of the iteration (device blob), or nullptr: kv_len below, n_rows
-    const int *key_start;                      // [B] first visible key, or nullptr
-    int n_rows, H, n_split, kv_len;            // window rows per batch row (M = B * n_rows), heads (K = H * 128), K1's launch-time split count
-};
-
-template <int DT, int MT, int MAXT, int AS>
-__device__ __forceinline__ void g1_skinny_body(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
-                                               float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
-                                               int rec_stride, int tile0, int n_waves,
-                                               unsigned short *__restrict__ red_h, float *__restrict__ red_sumsq,
-                                               unsigned *__restrict__ red_ticket, const g1_attn_in &at, const int chunk, const int group)
+template <int DT, int MT, int MAXT>
+__global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
+                                                                float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
+                                                                int rec_stride, int tile0, int n_waves,
+                                                                unsigned short *__restrict__ red_h = nullptr, float *__restrict__ red_sumsq = nullptr,
+                                                                unsigned *__restrict__ red_ticket = nullptr)
 {
     // n_waves = blockDim.x / 64 as an ARGUMENT: blockDim lives in the implicit kernel arguments, which are not preloaded into SGPRs -- the
     // kernel opened with an s_load round trip for it in front of every address it computes (ISA, late round 2)
@@ -187,11 +171,12 @@ __device__ __forceinline__ void g1_skinny_body(const unsigned short *__restrict_
     SJD_TR_HW();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *xl = reinterpret_cast<u32x4 *>(smem);
+    const int chunk = blockIdx.y;
     const int k0 = chunk * KC;
     const int steps = min(KC, K - k0) / 16;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int waves = n_waves;
-    const int t_out = group * waves + w;               // tile of this launch's output
+    const int t_out = blockIdx.x * waves + w;          // tile of this launch's output
     const int t = tile0 + t_out;                       // tile of the packed weight
     const bool has_tile = t_out < N / 32;
     // record (chunk, s, t) in 1-KiB units: all earlier chunks are full (KC/16 steps each).
@@ -223,86 +208,6 @@ __device__ __forceinline__ void g1_skinny_body(const unsigned short *__restrict_
         const int s = j >> 1;
         if (m < 32 * MT) xl[((m >> 5) * steps + s) * 64 + g1_slot(j & 1, m & 31, s)] = val;
     };
-    if constexpr (AS > 0) {
-        // ---- the activation of the output projection, merged from K1's split partials.  Piece (m, j) = 8 consecutive d of ONE head of token
-        // row m: per split slot 2 x 16 bytes of O and the (m, l) pair, all slots of all the thread's pieces requested in one go (they were
-        // written by the kernel that has just finished: cold, a full round trip) -- and for ALL n_split slots, before the effective split
-        // count is known (it needs kv_len from the device blob; slots beyond it hold stale partials and are not merged: k1_combine's scheme).
-        // Then k1_combine's arithmetic in split order (k1_merge_step<8>: the same instance, PER = 8 there), normalised, rounded to the
-        // activation dtype and written to LDS in A-fragment order: the bits of k1_combine followed by the plain staging.
-        constexpr int D = 128, PR = AS <= 4 ? 4 : 2;               // pieces per thread and round: PR * AS * 10 registers in flight
-        const int n_chunks_a = (at.n_rows + K1_ROWS - 1) / K1_ROWS;
-        const int nb = M / at.n_rows;
-        sjd_f4 o0[PR][AS], o1[PR][AS];
-        sjd_f2 ml[PR][AS];
-        auto a_load = [&](int m0, int j0) {
-            int m = m0, j = j0;
-#pragma unroll
-            for (int p = 0; p < PR; ++p) {
-                const int mc = min(m, M - 1), bb = mc / at.n_rows, i = mc - bb * at.n_rows;
-                const int k = k0 + 8 * j, head = k / D, d = k % D;
-                const size_t base = ((((size_t)bb * at.H + head) * n_chunks_a + (i / K1_ROWS)) * at.n_split) * K1_ROWS + (i % K1_ROWS);
-#pragma unroll
-                for (int q = 0; q < AS; ++q) {
-                    const size_t slot = base + (size_t)min(q, at.n_split - 1) * K1_ROWS;       // unconditional (clamped) loads: counted waits
-                    o0[p][q] = *reinterpret_cast<const sjd_f4 *>(at.ws_o + slot * D + d);
-                    o1[p][q] = *reinterpret_cast<const sjd_f4 *>(at.ws_o + slot * D + d + 4);
-                    ml[p][q] = *reinterpret_cast<const sjd_f2 *>(at.ws_ml + slot * 2);
-                }
-                advance(m, j);
-            }
-        };
-        // effective split count and valid rows of the (batch row, chunk) pairs of the window: at most four (B * n_chunks <= 4, launcher)
-        int effq[4], ntq[4];
-        auto a_geometry = [&]() {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int bb = min(q / n_chunks_a, nb - 1), c = q % n_chunks_a;
-                const sjd_iter_params *pp = sjdi_params_of(at.params, bb);
-                const int kv_base = pp ? pp->kv_len : at.kv_len, n_total = pp ? pp->n_rows : at.n_rows;
-                const int kstart = at.key_start ? at.key_start[bb] : 0;
-                const int n_c = min(K1_ROWS, n_total - c * K1_ROWS);
-                int t_lo, t_hi, tps;
-                k1_tile_range(kstart, kv_base + c * K1_ROWS + max(n_c, 0), at.n_split, t_lo, t_hi, effq[q], tps);
-                ntq[q] = n_total;
-            }
-        };
-        auto a_store = [&](int &m, int &j) {
-#pragma unroll
-            for (int p = 0; p < PR; ++p) {
-                const int mc = min(m, M - 1), bb = mc / at.n_rows, i = mc - bb * at.n_rows;
-                const int qi = bb * n_chunks_a + i / K1_ROWS;
-                const int eff = qi == 0 ? effq[0] : qi == 1 ? effq[1] : qi == 2 ? effq[2] : effq[3];
-                const int nt = qi == 0 ? ntq[0] : qi == 1 ? ntq[1] : qi == 2 ? ntq[2] : ntq[3];
-                float Mx = -INFINITY, L = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < AS; ++q)
-                    if (q < eff) {
-                        const float ov[8] = {o0[p][q].x, o0[p][q].y, o0[p][q].z, o0[p][q].w, o1[p][q].x, o1[p][q].y, o1[p][q].z, o1[p][q].w};
-                        k1_merge_step<8>(Mx, L, acc, ml[p][q].x, ml[p][q].y, ov);
-                    }
-                const float inv = L > 0.f ? 1.0f / L : 0.0f;
-                u32x4 val{0u, 0u, 0u, 0u};
-                if (m < M && i < nt) {                 // (padding rows of a shape-static window: zero, as k1_combine writes them)
-                    val.x = (unsigned)g1_act_bits<DT>(acc[0] * inv) | ((unsigned)g1_act_bits<DT>(acc[1] * inv) << 16);
-                    val.y = (unsigned)g1_act_bits<DT>(acc[2] * inv) | ((unsigned)g1_act_bits<DT>(acc[3] * inv) << 16);
-                    val.z = (unsigned)g1_act_bits<DT>(acc[4] * inv) | ((unsigned)g1_act_bits<DT>(acc[5] * inv) << 16);
-                    val.w = (unsigned)g1_act_bits<DT>(acc[6] * inv) | ((unsigned)g1_act_bits<DT>(acc[7] * inv) << 16);
-                }
-                x_store(m, j, val);
-                advance(m, j);
-            }
-        };
-        a_load(pm, pj);                                            // first round, the first weight group right behind it (see below)
-#pragma unroll
-        for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)min(u, steps - 1) * rs);
-        a_geometry();
-        a_store(pm, pj);
-        while (pm < 32) {                                          // fewer than 8 waves / longer chunks: further rounds
-            a_load(pm, pj);
-            a_store(pm, pj);
-        }
-    } else {
     {   // first batch, then the first weight group right behind it.  The weight loads are UNCONDITIONAL (a wave without a tile reads
         // tile 0, a chunk shorter than a group re-reads its last record): the compiler can then count them and wait for the activation
         // with vmcnt(8) -- with a conditional block it waits with vmcnt(0), i.e. the LDS writes and the barrier below sat behind the
@@ -327,7 +232,6 @@ __device__ __forceinline__ void g1_skinny_body(const unsigned short *__restrict_
 #pragma unroll
         for (int i = 0; i < G1_STAGE; ++i) { x_store(m, j, val[i]); advance(m, j); }
         pm = m; pj = j;
-    }
     }
     SJD_TR(1);                    // this wave's share of the activation chunk is in LDS
     __syncthreads();
@@ -382,7 +286,7 @@ __device__ __forceinline__ void g1_skinny_body(const unsigned short *__restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r)          // the plane goes out DEVICE-COHERENT (sc1: written through this XCD's L2)
             __hip_atomic_store(o + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * N, acc[0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        g1_reduce_tail<DT>(out, red_h, red_sumsq, red_ticket, M, N, (int)gridDim.y, chunk, group, n_waves);
+        g1_reduce_tail<DT>(out, red_h, red_sumsq, red_ticket, M, N, (int)gridDim.y, chunk, (int)blockIdx.x, n_waves);
         return;
     }
 #pragma unroll
@@ -397,30 +301,6 @@ __device__ __forceinline__ void g1_skinny_body(const unsigned short *__restrict_
     __builtin_amdgcn_s_waitcnt(0x0F70);
     SJD_TR(6);                    // acknowledged
 #endif
-}
-
-template <int DT, int MT, int MAXT>
-__global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
-                                                                float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
-                                                                int rec_stride, int tile0, int n_waves,
-                                                                unsigned short *__restrict__ red_h = nullptr, float *__restrict__ red_sumsq = nullptr,
-                                                                unsigned *__restrict__ red_ticket = nullptr)
-{
-    g1_skinny_body<DT, MT, MAXT, 0>(x, wp, out, M, N, K, KC, n_tiles, rec_stride, tile0, n_waves, red_h, red_sumsq, red_ticket, g1_attn_in{},
-                                    (int)blockIdx.y, (int)blockIdx.x);
-}
-
-// the output projection on K1's split partials (g1_attn_in)
-template <int DT, int AS>
-__global__ __launch_bounds__(512) void g1_skinny_gemm_attn(const u32x4 *__restrict__ wp, float *__restrict__ out, int M, int N, int K, int KC,
-                                                           int n_tiles, int rec_stride, int n_waves, g1_attn_in at)
-{
-    // Every column group of a K chunk merges the SAME split partials (its activation chunk).  Workgroups are dealt to the eight XCDs round
-    // robin in launch order; with the chunk index running fastest, all column groups of chunk c sit on XCD c % 8 and fifteen of the sixteen
-    // find the partials in that XCD's L2 -- with the plain (group fastest) order every XCD pulled every chunk's partials over the fabric
-    // and the merge took 8.7 us instead of the 2.2 us the plain staging takes (in-kernel timestamps, tools/phase_trace.py --g1-attn).
-    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x), nc = (int)gridDim.y;
-    g1_skinny_body<DT, 1, 512, AS>(nullptr, wp, out, M, N, K, KC, n_tiles, rec_stride, 0, n_waves, nullptr, nullptr, nullptr, at, lin % nc, lin / nc);
 }
 
 
@@ -909,46 +789,6 @@ extern "C" int sjd_skinny_gemm_reduce(const void *x, const void *w_packed, float
                            M, N, K, KC, n_out, rs, 0, waves, (unsigned short *)h, sumsq, ticket);
     } else return SJD_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
-}
-
-// The output projection fed by K1's key-split partials (sjd_draft_window_attention_partials) instead of by the merged attention output:
-// out[c, m, :] = partial products of attn[m, k0_c : k0_c + KC] @ W^T, where attn is what sjd_draft_window_attention would have written
-// for the same workspace -- merged, normalised and rounded while the activation chunk is staged (g1_attn_in), bit for bit
-// (tests/test_gpu_glue.py::test_g1_on_split_partials_matches_combine_then_g1).  M = B * n_rows <= 32 token rows, K = H * 128,
-// B * ceil(n_rows / 16) <= 4, n_split <= 8 (K1's launch-time count, the workspace's stride), waves <= 8.
-extern "C" int sjd_skinny_gemm_attn(const void *attn_workspace, const void *w_packed, float *out, int B, int n_rows, int H, int D, int n_split,
-                                    const int32_t *key_start, const sjd_iter_params *params, int kv_len, int N, int KC, int waves, int step_major,
-                                    int dtype, void *stream)
-{
-    if (!attn_workspace || !w_packed || !out || B < 1 || n_rows < 1 || H < 1 || n_split < 1 || N < 32 || (N % 32) != 0 || KC < 16 || (KC % 16) != 0)
-        return SJD_ERR_BAD_ARG;
-    const int M = B * n_rows, K = H * D, n_chunks_a = (n_rows + K1_ROWS - 1) / K1_ROWS;
-    if (D != 128 || M > 32 || B * n_chunks_a > 4 || n_split > 8 || waves < 1 || waves > 8) return SJD_ERR_UNSUPPORTED;
-    const int n_out = N / 32, n_chunks = (K + KC - 1) / KC;
-    const dim3 grid((n_out + waves - 1) / waves, n_chunks), block(waves * 64);
-    const size_t lds = (size_t)((KC < K ? KC : K) / 16) * 64 * 16;
-    if (lds > 160 * 1024) return SJD_ERR_BAD_ARG;
-    g1_attn_in at;
-    at.ws_o = (const float *)attn_workspace;
-    at.ws_ml = at.ws_o + (size_t)B * H * n_chunks_a * n_split * K1_ROWS * D;
-    at.params = params; at.key_start = key_start;
-    at.n_rows = n_rows; at.H = H; at.n_split = n_split; at.kv_len = kv_len;
-    hipStream_t s = (hipStream_t)stream;
-    const int rs = step_major ? n_out : 1;
-#define SJD_G1A_CASE(DT_, AS_) \
-    if (dtype == DT_ && n_split <= AS_) { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_skinny_gemm_attn<DT_, AS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((g1_skinny_gemm_attn<DT_, AS_>), grid, block, lds, s, (const u32x4 *)w_packed, out, M, N, K, KC, n_out, rs, waves, at); \
-        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH; \
-    }
-    SJD_G1A_CASE(SJD_DTYPE_BF16, 2)
-    SJD_G1A_CASE(SJD_DTYPE_BF16, 4)
-    SJD_G1A_CASE(SJD_DTYPE_BF16, 8)
-    SJD_G1A_CASE(SJD_DTYPE_F16, 2)
-    SJD_G1A_CASE(SJD_DTYPE_F16, 4)
-    SJD_G1A_CASE(SJD_DTYPE_F16, 8)
-#undef SJD_G1A_CASE
-    return SJD_ERR_UNSUPPORTED;
 }
 
 // workgroups of a reducing launch that gave up waiting for their slice's ticket since the library was loaded (0 on a healthy device)

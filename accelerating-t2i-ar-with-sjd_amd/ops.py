@@ -288,52 +288,6 @@ def draft_window_attention(q, k_cache, v_cache, out, key_start, params, kv_len, 
             "sjd_draft_window_attention")
 
 
-class AttnPartials:
-    """what K1 leaves when its merge is done by the consumer: the key-split partials in `workspace` and everything the consumer needs to
-    find and merge them (sjd_draft_window_attention_partials -> sjd_skinny_gemm_attn)"""
-
-    def __init__(self, workspace, B, n, H, D, n_split, key_start, params, kv_len, dtype):
-        self.workspace, self.B, self.n, self.H, self.D, self.n_split = workspace, B, n, H, D, n_split
-        self.key_start, self.params, self.kv_len, self.dtype = key_start, params, kv_len, dtype
-
-
-def skinny_gemm_attn_ok(B, n, H, D, n_split, dtype):
-    """shapes sjd_skinny_gemm_attn serves (the <= 32-row window of a multi-head model with head_dim 128)"""
-    return D == 128 and B * n <= 32 and B * ((n + 15) // 16) <= 4 and 1 <= n_split <= 8 and dtype in (torch.bfloat16, torch.float16)
-
-
-def draft_window_attention_partials(q, k_cache, v_cache, key_start, params, kv_len, n_split, workspace, kv_scale=None):
-    """K1 without its merge -> AttnPartials (caches 16-bit, or fp8 with kv_scale = (k, v))."""
-    B, n, H, D = q.shape
-    assert q.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous()
-    assert key_start is None or (key_start.dtype == torch.int32 and key_start.is_cuda)
-    assert workspace.numel() * 4 >= L.load().sjd_attention_workspace_bytes(B, H, n, D, n_split), "attention workspace too small"
-    pp = params.ptr if params is not None else None
-    if k_cache.dtype == FP8:
-        L.check(L.load().sjd_draft_window_attention_fp8_partials(_ptr(q), _ptr(k_cache), _ptr(v_cache), B, n, H, k_cache.shape[1], D, k_cache.shape[2],
-                                                                _dtype_code(q.dtype), float(kv_scale[0]), float(kv_scale[1]), _ptr(key_start), pp,
-                                                                int(kv_len), int(n_split), _ptr(workspace), _stream()),
-                "sjd_draft_window_attention_fp8_partials")
-    else:
-        L.check(L.load().sjd_draft_window_attention_partials(_ptr(q), _ptr(k_cache), _ptr(v_cache), B, n, H, k_cache.shape[1], D, k_cache.shape[2],
-                                                            _dtype_code(q.dtype), _ptr(key_start), pp, int(kv_len), int(n_split), _ptr(workspace),
-                                                            _stream()), "sjd_draft_window_attention_partials")
-    return AttnPartials(workspace, B, n, H, D, int(n_split), key_start, params, int(kv_len), q.dtype)
-
-
-def skinny_gemm_attn(ap, w_packed, N, KC, waves=8, step_major=False):
-    """the output projection on K1's split partials: Partials([n_chunks, 32, N]) bit-identical to skinny_gemm(attention output) -- the merge
-    of the key splits (k1_combine) happens while the activation chunk is staged (sjd_skinny_gemm_attn)."""
-    K = ap.H * ap.D
-    assert w_packed.numel() == N * K and skinny_gemm_attn_ok(ap.B, ap.n, ap.H, ap.D, ap.n_split, ap.dtype) and waves <= 8
-    nc = (K + KC - 1) // KC
-    out = torch.empty(nc, 32, N, dtype=torch.float32, device=ap.workspace.device)
-    L.check(L.load().sjd_skinny_gemm_attn(_ptr(ap.workspace), _ptr(w_packed), _ptr(out), ap.B, ap.n, ap.H, ap.D, ap.n_split, _ptr(ap.key_start),
-                                          ap.params.ptr if ap.params is not None else None, ap.kv_len, N, KC, waves, int(step_major),
-                                          _dtype_code(ap.dtype), _stream()), "sjd_skinny_gemm_attn")
-    return Partials(out, nc, N)
-
-
 class Partials:
     """fp32 split-K partial products [n_chunks, 32, N] of a G1 projection; consumers (F1/F2/F3) sum the chunks."""
 
@@ -681,18 +635,6 @@ class HipWindowAttention:
         else:
             draft_window_attention(q, kc, vc, out, key_start, self.params, kv_host, self.n_split, ws)
         return out
-
-    def attend_partials(self, layer, q, cache, kv_len, key_start):
-        """attend() without the merge of the key splits -> AttnPartials for skinny_gemm_attn, or None when that consumer does not serve
-        the shape (the caller then uses attend())."""
-        B, n, H, D = q.shape
-        kc, vc = cache.k[layer], cache.v[layer]
-        self._resolve_split(B, kc.shape[1], n, H, kc.shape[2] * kc.shape[3] * kc.element_size() if kc.dtype == FP8 else None)
-        if not skinny_gemm_attn_ok(B, n, H, D, self.n_split, q.dtype) or self.n_split < 2:
-            return None                  # (one split: k1_partial already writes the finished output itself, nothing to merge)
-        ws = self._workspace(B, H, n, D, q.device)
-        kv_host = 0 if self.params is not None else int(kv_len)
-        return draft_window_attention_partials(q, kc, vc, key_start, self.params, kv_host, self.n_split, ws, kv_scale=self.kv_scale)
 
     def profile_summary(self):
         """-> dict(launches, avg_ms, avg_bytes, gbps) over the recorded k1_partial launches; recycles the events."""

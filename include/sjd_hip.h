@@ -340,23 +340,6 @@ int sjd_draft_window_attention_fp8_merged(const void *q, const void *k_cache, co
                                           int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
                                           const sjd_iter_params *params, int kv_len, int n_split, void *workspace, uint32_t *tickets, void *stream);
 
-/* The attention block's merge inside its CONSUMER (round 3): K1 leaves only its key-split partials (workspace: fp32 O [B, H, chunks,
- * n_split, 16, D] then (m, l) [B, H, chunks, n_split, 16, 2], sjd_attention_workspace_bytes), and the output projection merges them --
- * k1_combine's arithmetic in split order, normalised, rounded to the activation dtype -- while it stages its activation chunk in LDS.
- * sjd_draft_window_attention_partials + sjd_skinny_gemm_attn write the split-K planes that sjd_draft_window_attention + sjd_skinny_gemm
- * write, bit for bit, in two launches instead of three (self_attn.o_proj(attn_output), modeling_chameleon.py:499-581).
- * sjd_skinny_gemm_attn: M = B * n_rows <= 32 token rows, K = H * D with D == 128, B * ceil(n_rows / 16) <= 4, n_split <= 8 (the value K1
- * was launched with: it is the workspace's stride), waves <= 8; key_start / params / kv_len as handed to K1. */
-int sjd_draft_window_attention_partials(const void *q, const void *k_cache, const void *v_cache, int B, int n_rows, int H, int H_kv, int D,
-                                        int S_max, int dtype, const int32_t *key_start, const sjd_iter_params *params, int kv_len,
-                                        int n_split, void *workspace, void *stream);
-int sjd_draft_window_attention_fp8_partials(const void *q, const void *k_cache, const void *v_cache, int B, int n_rows, int H, int H_kv, int D,
-                                            int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
-                                            const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream);
-int sjd_skinny_gemm_attn(const void *attn_workspace, const void *w_packed, float *out, int B, int n_rows, int H, int D, int n_split,
-                         const int32_t *key_start, const sjd_iter_params *params, int kv_len, int N, int KC, int waves, int step_major,
-                         int dtype, void *stream);
-
 /* G1 with stage F1r as its tail (round 3): h [M, N] += dtype(x @ W^T) in place and sumsq [N / 512, 32] = the per-slice sums of h^2, i.e.
  * sjd_skinny_gemm followed by sjd_residual_sumsq (the residual add + RMSNorm statistics of modeling_chameleon.py:59-73, 637, 643), bit for
  * bit, in one launch: the workgroups of a 512-column slice exchange their split-K planes device-coherently and reduce them in the

@@ -401,93 +401,3 @@ def test_16bit_window_forward_error_against_fp32_forward(dev, dtype):
         with open(os.path.join(out_dir, f"logit_error_{str(dtype).split('.')[-1]}.json"), "w") as f:
             json.dump(rep, f)
     assert e_hip.max() <= 1.5 * e_aten.max() + 1e-3 and e_hip.mean() <= 1.5 * e_aten.mean() + 1e-4, rep
-
-
-@pytest.mark.parametrize("fp8", [False, True])
-@pytest.mark.parametrize("B,H,Hkv,n,kv_len,ks,n_split,blob,dtype,N,KC,waves,step_major", [
-    (2, 32, 32, 16, 1216, [0, 1100], 4, None, torch.bfloat16, 4096, 512, 8, False),       # Lumina-7B mid-image: the production launch
-    (2, 32, 32, 16, 1216, [0, 1100], 4, None, torch.bfloat16, 4096, 512, 6, False),       # six waves: the pieces take two rounds
-    (2, 32, 32, 16, 40, [0, 39], 4, None, torch.float16, 4096, 512, 8, False),            # one effective split of four
-    (2, 32, 32, 16, 200, [0, 63], 4, (200, 11), torch.bfloat16, 4096, 512, 8, True),      # device blob: 11 valid rows (padding rows zero)
-    (2, 4, 4, 5, 700, [0, 10], 8, None, torch.float16, 512, 256, 4, False),               # ragged window, eight splits
-    (2, 8, 8, 16, 600, [3, 0], 3, None, torch.bfloat16, 1024, 384, 8, True),              # three splits in four slots; ragged last chunk
-    (1, 8, 4, 32, 900, [7], 4, None, torch.bfloat16, 512, 512, 8, False),                 # two row chunks, grouped-query heads (shared-tile K1)
-    (4, 4, 4, 8, 300, [0, 5, 0, 250], 2, None, torch.bfloat16, 512, 512, 2, False)])      # four batch rows, two splits
-def test_g1_on_split_partials_matches_combine_then_g1(dev, fp8, B, H, Hkv, n, kv_len, ks, n_split, blob, dtype, N, KC, waves, step_major):
-    """The merge of K1's key splits inside the output projection (sjd_draft_window_attention_partials + sjd_skinny_gemm_attn: the splits are
-    merged, normalised and rounded while the projection stages its activation chunk) writes the SAME split-K planes, bit for bit, as
-    k1_partial + k1_combine + G1 -- also when replayed from a hipGraph with the cache length read from the device blob."""
-    import sjd_amd.ops as ops
-    import sjd_amd._lib as L
-    D, K = 128, H * 128
-    g = torch.Generator().manual_seed(kv_len + n + H + N)
-    S = ((kv_len + n + 63) // 32) * 32
-    ksd = torch.tensor(ks, dtype=torch.int32, device=dev)
-    kc, vc = (torch.randn(B, Hkv, S, D, generator=g).to(dtype).to(dev) for _ in range(2))
-    if fp8:
-        kc, vc = kc.float().to(ops.FP8), vc.float().to(ops.FP8)
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).to(dev)
-    wp = ops.pack_weight(w, KC, step_major)
-    params, kv_arg = None, kv_len
-    if blob is not None:
-        params = ops.DeviceBlob(L.IterParams, dev)
-        params.view.kv_len, params.view.n_rows = blob
-        params.upload()
-        kv_arg = 0
-    ws_ref, ws_got = (ops.attention_workspace(B, H, n, D, n_split, dev) for _ in range(2))
-    ws_got.fill_(float("nan"))            # slots beyond the effective split count are never merged, whatever they hold
-    assert ops.skinny_gemm_attn_ok(B, n, H, D, n_split, dtype)
-
-    def ref_planes(q):
-        out = torch.full_like(q, 3.0)
-        if fp8:
-            ops.draft_window_attention_fp8(q, kc, vc, out, 0.5, 2.0, ksd, params, kv_arg, n_split, ws_ref, merged=False)
-        else:
-            ops.draft_window_attention(q, kc, vc, out, ksd, params, kv_arg, n_split, ws_ref, merged=False)
-        return ops.skinny_gemm(out.view(B * n, K), wp, N, K, KC, waves=waves, step_major=step_major).data
-
-    def got_planes(q):
-        ap = ops.draft_window_attention_partials(q, kc, vc, ksd, params, kv_arg, n_split, ws_got, kv_scale=(0.5, 2.0))
-        return ops.skinny_gemm_attn(ap, wp, N, KC, waves=waves, step_major=step_major).data
-
-    qs = [(torch.randn(B, n, H, D, generator=g) * 1.5).to(dtype).to(dev) for _ in range(3)]
-    for q in qs:
-        want, got = ref_planes(q), got_planes(q)
-        torch.cuda.synchronize()
-        assert got.shape == want.shape and torch.isfinite(got).all()
-        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (got - want).abs().max()
-        assert want.abs().sum() > 0
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        got_planes(qs[0])
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        outs = [got_planes(q) for q in qs]
-    for _ in range(5):
-        graph.replay()
-    torch.cuda.synchronize()
-    for q, o in zip(qs, outs):
-        assert torch.equal(o.view(torch.int32), ref_planes(q).view(torch.int32))
-
-
-def test_forward_with_the_split_merge_in_the_output_projection_is_bit_identical(dev):
-    """The folded G1 window forward with K1's splits merged by the output projection (default) against the same forward with k1_combine as
-    its own launch (oproj_merges_splits = False, the default): identical logits, bit for bit, and one launch fewer per layer."""
-    import sjd_amd.ops as ops
-    from tests.helpers import make_chameleon
-    conf = dict(vocab_size=9216, hidden_size=1024, intermediate_size=1024, num_hidden_layers=3, num_attention_heads=8,
-                num_key_value_heads=8, max_position_embeddings=2048, rms_norm_eps=1e-5, rope_theta=10000.0)
-    outs = []
-    for merge in (False, True):
-        m = make_chameleon(conf, 29, 0.5, ops.HipWindowAttention(n_split=4), dtype=torch.bfloat16, device=dev)
-        m.G1_CFG = dict(qkv=(256, 8, True), o=(256, 4, False), gate_up=(512, 8, True), down=(256, 4, False))
-        m.enable_fused(ops, gemm="sjd")
-        m.oproj_merges_splits = merge
-        m.setup_cache(batch=2, s_max=1024)
-        toks = torch.randint(4, 9000, (2, 600), generator=torch.Generator().manual_seed(1)).to(dev)
-        ks = torch.tensor([0, 7], dtype=torch.int32, device=dev)
-        m.forward_window(toks, torch.arange(600)[None].repeat(2, 1).to(dev), 0, ks)
-        toks2 = torch.randint(4, 9000, (2, 16), generator=torch.Generator().manual_seed(2)).to(dev)
-        outs.append(m.forward_window(toks2, (600 + torch.arange(16))[None].repeat(2, 1).to(dev), 600, ks).float())
-    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()

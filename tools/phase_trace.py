@@ -155,47 +155,6 @@ def trace_g1(lib, torch, ops, np):
                               end_us=dict(mean=us((t[:, 6] - t0).mean()), max=us((t[:, 6] - t0).max())))), flush=True)
 
 
-def trace_g1_attn(lib, torch, ops, np):
-    """the output projection on K1's split partials (sjd_skinny_gemm_attn) behind k1_partial, as in a layer"""
-    import sjd_amd.backbones as BB
-    dev = torch.device("cuda:0")
-    lib.sjd_debug_trace_g1.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    B, n, H, D, layers, kv, N = 2, 16, 32, 128, 12, 1216, 4096
-    KC, _, sm = BB.ChameleonBackbone.G1_CFG["o"]
-    s_max = ((kv + n + 64 + 31) // 32) * 32
-    kc = torch.randn(layers, B, H, s_max, D, device=dev).to(torch.bfloat16)
-    vc = torch.randn(layers, B, H, s_max, D, device=dev).to(torch.bfloat16)
-    q = torch.randn(B, n, H, D, device=dev).to(torch.bfloat16)
-    ks = torch.tensor([0, 63], dtype=torch.int32, device=dev)
-    ws = ops.attention_workspace(B, H, n, D, 4, dev)
-    wps = [ops.pack_weight((torch.randn(N, H * D, device=dev) / 64).to(torch.bfloat16), KC, sm) for _ in range(6)]
-    for waves in (8, 6):
-        def one(i):
-            ap = ops.draft_window_attention_partials(q, kc[i], vc[i], ks, None, kv, 4, ws)
-            return ops.skinny_gemm_attn(ap, wps[i % 6], N, KC, waves=waves, step_major=sm)
-        with torch.cuda.stream(torch.cuda.Stream()):
-            one(0)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for i in range(layers):
-                one(i)
-        for _ in range(3):
-            g.replay()
-        torch.cuda.synchronize()
-        nc = (H * D + KC - 1) // KC
-        nwg = ((N // 32 + waves - 1) // waves) * nc
-        buf = np.zeros((nwg, 8), dtype=np.uint64)
-        assert lib.sjd_debug_trace_g1(buf.ctypes.data, nwg) == 0
-        t = buf.astype(np.int64)
-        t0 = t[:, 0].min()
-        d = lambda a, b: us((t[:, b] - t[:, a]).mean())
-        print(json.dumps(dict(kernel="g1_skinny_gemm_attn<bf16, 4 splits>", KC=KC, waves=waves, workgroups=nwg, start_skew_us=us((t[:, 0] - t0).max()),
-                              phase_us=dict(merge_and_stage=d(0, 1), wait_for_waves=d(1, 2), first_weight_group=d(2, 3), main_loop=d(3, 4),
-                                            store_issue=d(4, 5), store_ack=d(5, 6)),
-                              end_us=dict(mean=us((t[:, 6] - t0).mean()), max=us((t[:, 6] - t0).max())))), flush=True)
-
-
 def trace_g1s(lib, torch, ops, np):
     """G1s: gate|up + SiLU * up in one launch (two staging phases)"""
     dev = torch.device("cuda:0")
@@ -338,9 +297,6 @@ def main():
     if "--per-wg" in sys.argv:
         PER_WG = open(sys.argv[sys.argv.index("--per-wg") + 1], "w")
         trace_g1(lib, torch, ops, np)
-        return
-    if "--g1-attn" in sys.argv:
-        trace_g1_attn(lib, torch, ops, np)
         return
     if "--g1s" in sys.argv:
         trace_g1s(lib, torch, ops, np)

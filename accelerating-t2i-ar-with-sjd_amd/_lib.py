@@ -55,7 +55,7 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_logits_to_probs_sample_part", "sjd_logits_to_probs_sample_ex", "sjd_reguess_ex",
            "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu", "sjd_host_wait_u64",
            "sjd_philox_fill", "sjd_philox_offset_increment", "sjd_skinny_gemm_reduce", "sjd_reduce_timeouts",
-           "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged"]
+           "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged", "sjd_skinny_gemm_z", "sjd_gateup_silu_z"]
 
 _lib = None
 
@@ -111,6 +111,8 @@ def load():
     lib.sjd_qkv_attention_fused.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),
                                             vp, vp, i32, vp]
     lib.sjd_skinny_gemm_reduce.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.sjd_skinny_gemm_z.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.sjd_gateup_silu_z.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp]
     lib.sjd_philox_fill.argtypes = [vp, i64, ctypes.c_uint64, ctypes.c_uint64, i32, i32, vp]
     lib.sjd_philox_offset_increment.restype = ctypes.c_uint64
     lib.sjd_philox_offset_increment.argtypes = [i64, i32]

@@ -410,15 +410,36 @@ class ChameleonBackbone(nn.Module):
         if self._pf_on:
             torch.cuda.current_stream().wait_stream(self._pf_stream)       # every forked branch rejoins (hipGraph capture needs it)
 
-    def enable_fused(self, ops, gemm="torch", fold_norm=True):
+    def enable_fused(self, ops, gemm="torch", fold_norm=True, compress=None):
         """Switch to the fused HIP glue path (F1-F3): q|k|v and gate|up projections become single GEMMs whose weights are
         concatenated once; the original parameters are re-pointed at slices of the fused tensors (state-dict unchanged,
         no extra memory).  gemm="sjd": the window forward (<= 32 rows) also runs its four per-layer projections on the
         hand-written weight-streaming kernel G1 over pre-packed weights (a second, fragment-major copy of the layer
-        weights); other shapes (prefill) keep hipBLASLt.  `ops` is sjd_amd.ops (raises if libsjd_hip.so is missing)."""
+        weights); other shapes (prefill) keep hipBLASLt.  `ops` is sjd_amd.ops (raises if libsjd_hip.so is missing).
+        compress (default: on for bf16 weights, SJD_G1Z=0 switches it off): the packed copy is kept in the LOSSLESS 12-bit stream format of
+        kernels G1z / G1sz (ops.pack_weight_z: 25 % fewer bytes through the fabric that bounds the window forward, bit-identical results);
+        a matrix that does not fit the format (fp16, or a unit with too many out-of-window weights) stays uncompressed.  Windows of more
+        than 64 rows (three / four prompts per forward) need compress=False."""
         self._ops = ops
         self._gemm = gemm
         self._fold_norm = bool(fold_norm) and gemm == "sjd"
+        if compress is None:
+            compress = _os.environ.get("SJD_G1Z", "1") != "0"
+        self.compress = bool(compress) and gemm == "sjd"
+        self.compress_stats = dict(matrices=0, compressed=0, bytes_raw=0, bytes_packed=0, exceptions=0)
+
+        def pack(w, kc, sm):
+            st = self.compress_stats
+            st["matrices"] += 1
+            st["bytes_raw"] += w.numel() * w.element_size()
+            z = ops.pack_weight_z(w, kc, sm) if self.compress else None
+            if z is None:
+                st["bytes_packed"] += w.numel() * w.element_size()
+                return ops.pack_weight(w, kc, sm)
+            st["compressed"] += 1
+            st["bytes_packed"] += z.nbytes()
+            st["exceptions"] += z.n_exceptions
+            return z
         self._packed = []
         self._fused = []
         with torch.no_grad():
@@ -438,10 +459,10 @@ class ChameleonBackbone(nn.Module):
                         qkv_p, gu_p = fold(qkv, layer.input_layernorm.weight), fold(gu, layer.post_attention_layernorm.weight)
                     else:
                         qkv_p, gu_p = qkv, gu
-                    self._packed.append(dict(qkv=ops.pack_weight(qkv_p, c["qkv"][0], c["qkv"][2]),
-                                             o=ops.pack_weight(a.o_proj.weight, c["o"][0], c["o"][2]),
-                                             gate_up=ops.pack_weight(gu_p, c["gate_up"][0], c["gate_up"][2]),
-                                             down=ops.pack_weight(m.down_proj.weight, c["down"][0], c["down"][2])))
+                    self._packed.append(dict(qkv=pack(qkv_p, c["qkv"][0], c["qkv"][2]),
+                                             o=pack(a.o_proj.weight, c["o"][0], c["o"][2]),
+                                             gate_up=pack(gu_p, c["gate_up"][0], c["gate_up"][2]),
+                                             down=pack(m.down_proj.weight, c["down"][0], c["down"][2])))
             self._packed_head = None
             if gemm == "sjd" and self._fold_norm and self.lm_head.bias is None:
                 # output head on G1: ONE packed copy of lm_head with the final norm gain folded in; a launch covers only
@@ -452,7 +473,7 @@ class ChameleonBackbone(nn.Module):
                 if pad:
                     wf = torch.cat([wf, torch.zeros(pad, w.shape[1], dtype=w.dtype, device=w.device)], dim=0)
                 self._head_cols = V + pad
-                self._packed_head = ops.pack_weight(wf, self.HEAD_CFG[0], self.HEAD_CFG[2])
+                self._packed_head = pack(wf, self.HEAD_CFG[0], self.HEAD_CFG[2])
                 del wf
         self._inv_freq32 = self.inv_freq.float().contiguous()
         self.buffers_version = getattr(self, "buffers_version", 0) + 1          # ... and the packed weights' (engine._check_graph_buffers)
@@ -504,8 +525,9 @@ class ChameleonBackbone(nn.Module):
         fuse_mlp = getattr(self, "gateup_fused", _GATEUP_FUSED_DEFAULT) and not self._pf_on and ops.gateup_silu_ok(T, inter, hid, cfg["gate_up"][0])
         # o / down with F1r as their tail (one launch each; the reducing kernel wants whole 512-column slices per workgroup pair: 8 waves)
         red = getattr(self, "reduce_fused", _REDUCE_FUSED_DEFAULT) and not self._pf_on
-        red_o = red and ops.skinny_gemm_reduce_ok(T, hid, H * D, cfg["o"][0], 8, h_dev := self.lm_head.weight.device)
-        red_d = red and ops.skinny_gemm_reduce_ok(T, hid, inter, cfg["down"][0], 8, h_dev)
+        raw = lambda name: not isinstance(self._packed[0][name], ops.PackedZ)        # (the reducing kernel streams the uncompressed packing)
+        red_o = red and raw("o") and ops.skinny_gemm_reduce_ok(T, hid, H * D, cfg["o"][0], 8, h_dev := self.lm_head.weight.device)
+        red_d = red and raw("down") and ops.skinny_gemm_reduce_ok(T, hid, inter, cfg["down"][0], 8, h_dev)
         h = self.model.embed_tokens(tokens).view(T, -1).contiguous()
         pos = positions.reshape(T).contiguous()
         delta, ss_next = None, None         # the down projection's split-K planes (summed by the next F1r), or the statistics its tail already wrote

@@ -644,6 +644,191 @@ __global__ __launch_bounds__(512) void g1_gateup_silu(const unsigned short *__re
     SJD_TR(6);
 }
 
+// G1s over the 12-bit weight stream (see G1z below): the same kernel, every record decoded (and its unit's exceptions patched in) in
+// front of its MFMA, the records travelling through a RING of G1Z_DEPTH registers sets that is refilled as it is consumed.
+// Bit-identical to g1_gateup_silu on the uncompressed packing of the same weight.  bf16.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#ifndef G1Z_DEPTH
+#define G1Z_DEPTH 8           // k-steps a wave keeps in flight (a ring of G1Z_DEPTH / 2 record pairs); 4 / 8 / 16 / 32 measured: 8 (profiles/r3_g1z_microbench.txt)
+#endif
+#ifndef G1Z_AUX
+#define G1Z_AUX 2             // cache policy of the weight loads: nt (streamed once)
+#endif
+struct g1z_hdr { unsigned base4, v_step, v_pos, v_val; };
+struct g1z_pair { u32x4 lo; u32x2 c; };          // two k-steps: {low bytes 0..3, 4..7} x 2, {codes} x 2
+__device__ __forceinline__ u32x4 g1z_operand(unsigned lo0, unsigned lo1, unsigned c, unsigned s, const g1z_hdr &hd, int lane);
+__device__ __forceinline__ g1z_hdr g1z_header(u32x2 e, int lane);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t g1z_unit_rsrc(const unsigned char *first_record, unsigned bytes);
+__device__ __forceinline__ g1z_pair g1z_load(__amdgpu_buffer_rsrc_t wr, unsigned lane, unsigned soff)
+{
+    g1z_pair v;          // (a pair past the unit's end reads as zero without touching memory; nt: streamed once)
+    v.lo = __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16u, soff, G1Z_AUX);
+    v.c = __builtin_amdgcn_raw_buffer_load_b64(wr, 1024u + lane * 8u, soff, G1Z_AUX);
+    return v;
+}
+
+template <int SP>
+__global__ __launch_bounds__(512) void g1z_gateup_silu(const unsigned short *__restrict__ x, const unsigned char *__restrict__ wz,
+                                                       const u32x2 *__restrict__ exc, unsigned short *__restrict__ y, int M, int I, int K,
+                                                       int rec_stride, const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden,
+                                                       float rs_eps)
+{
+    constexpr int DT = SJD_DTYPE_BF16;
+    constexpr int D = SP >= G1Z_DEPTH ? G1Z_DEPTH : 8;           // k-steps in flight per wave, as a ring of D / 2 record pairs
+    constexpr int DP = D / 2;
+    constexpr int TL = D < 8 ? 8 : D;                             // k-steps of a loop trip (unrolled; the ring goes round TL / D times)
+    static_assert(SP % TL == 0 && TL % 8 == 0 && TL % D == 0 && D % 2 == 0, "a phase is whole trips; g1_slot(.., s) depends on s & 7");
+    SJD_TR(0);
+    SJD_TR_HW();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *xl = reinterpret_cast<u32x4 *>(smem);
+    __shared__ float rsc[32];
+    constexpr int PPS = 2 * SP;
+    constexpr int NPT = (32 * 2 * PPS) / 512;
+    static_assert(NPT >= 1, "at least one piece per thread");
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int kh = w >> 2, q = w & 3;
+    const int n_gate = I / 32, n_tiles = 2 * n_gate;
+    const int t_act = 2 * blockIdx.x + (q & 1);
+    const int t = (q < 2 ? 0 : n_gate) + t_act;
+    constexpr int pairs = SP;                                     // record pairs of a K half (2 SP k-steps)
+    const size_t chunk_base = (size_t)kh * n_tiles * pairs;
+    const size_t tile_off = (rec_stride == 1) ? (size_t)t * pairs : (size_t)t;
+    const unsigned rsb = (unsigned)rec_stride * 1536u;           // bytes from a pair of the unit to the next
+    const __amdgpu_buffer_rsrc_t wr = g1z_unit_rsrc(wz + (chunk_base + tile_off) * 1536, (unsigned)(pairs - 1) * rsb + 1536u);
+    auto w_load = [&](int p) -> g1z_pair { return g1z_load(wr, (unsigned)lane, (unsigned)p * rsb); };
+    auto x_load = [&](int ph, int i) -> u32x4 {
+        const int v = i * 512 + threadIdx.x;
+        const int m = v / (2 * PPS), hh = (v / PPS) & 1, j = v % PPS;
+        return (m < M) ? *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + hh * (K / 2) + ph * (K / 4) + 8 * j) : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto x_store = [&](int i, u32x4 val) {
+        const int v = i * 512 + threadIdx.x;
+        const int m = v / (2 * PPS), hh = (v / PPS) & 1, j = v % PPS;
+        xl[(hh * SP + (j >> 1)) * 64 + g1_slot(j & 1, m, j >> 1)] = val;
+    };
+    g1z_pair ring[DP];
+    u32x4 val[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) val[i] = x_load(0, i);
+    float ssv[8];
+    {
+        const float *ssp = row_sumsq ? row_sumsq : reinterpret_cast<const float *>(x);
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) ssv[qq] = ssp[(size_t)(row_sumsq ? min(qq, rs_slices - 1) : 0) * 32 + (threadIdx.x & 31)];
+    }
+    const u32x2 hraw = exc[((size_t)kh * n_tiles + t) * 32 + (lane & 31)];
+#pragma unroll
+    for (int u = 0; u < DP; ++u) ring[u] = w_load(u);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) x_store(i, val[i]);
+    SJD_TR(1);
+    __syncthreads();
+    SJD_TR(2);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) val[i] = x_load(1, i);
+    if (threadIdx.x < 32) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) tsum += (qq < rs_slices) ? ssv[qq] : 0.f;
+        rsc[threadIdx.x] = row_sumsq ? rsqrtf(__builtin_fmaf(tsum, rs_inv_hidden, rs_eps)) : 1.0f;
+    }
+    SJD_TR(3);
+    const g1z_hdr hd = g1z_header(hraw, lane);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const u32x4 *xa = xl + (size_t)kh * SP * 64;
+    // one ring trip: k-steps s0 .. s0 + D - 1 of the K half, staged as LDS records l0 .. of the current phase; every consumed pair is
+    // refilled with the one D k-steps further on (unconditional: exact s_waitcnt counts, D k-steps in flight through MFMAs and barriers alike)
+    auto trip = [&](int l0, int s0) {
+        u32x4 a[2];
+        a[0] = xa[l0 * 64 + g1_slot(lane >> 5, lane & 31, 0)];
+#pragma unroll
+        for (int u = 0; u < TL / 2; ++u) {
+            g1z_pair &slot = ring[u % DP];
+            a[1] = xa[(l0 + 2 * u + 1) * 64 + g1_slot(lane >> 5, lane & 31, 2 * u + 1)];
+            const u32x4 b0 = g1z_operand(slot.lo.x, slot.lo.y, slot.c.x, (unsigned)(s0 + 2 * u), hd, lane);
+            acc = G1Mfma<DT>::mma(a[0], b0, acc);
+            if (u + 1 < TL / 2) a[0] = xa[(l0 + 2 * u + 2) * 64 + g1_slot(lane >> 5, lane & 31, 2 * u + 2)];
+            const u32x4 b1 = g1z_operand(slot.lo.z, slot.lo.w, slot.c.y, (unsigned)(s0 + 2 * u + 1), hd, lane);
+            slot = w_load(s0 / 2 + u + DP);
+            acc = G1Mfma<DT>::mma(a[1], b1, acc);
+        }
+    };
+    for (int g = 0; g < SP / TL; ++g) trip(g * TL, g * TL);                   // ---- phase 0
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) x_store(i, val[i]);
+    __syncthreads();
+    SJD_TR(4);
+    for (int g = 0; g < SP / TL; ++g) trip(g * TL, SP + g * TL);              // ---- phase 1
+    SJD_TR(5);
+    __syncthreads();
+    constexpr int RP = 36;
+    float *red = reinterpret_cast<float *>(smem);
+    {
+        float *mine = red + (size_t)(kh * 4 + q) * 32 * RP + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * RP] = acc[r];
+    }
+    __syncthreads();
+    {
+        const int a = threadIdx.x >> 8, m = (threadIdx.x >> 3) & 31, c4 = (threadIdx.x & 7) * 4;
+        auto plane = [&](int kh_, int q_) { return *reinterpret_cast<const float4 *>(red + ((size_t)(kh_ * 4 + q_) * 32 + m) * RP + c4); };
+        const float4 g0 = plane(0, a), g1 = plane(1, a), u0 = plane(0, 2 + a), u1 = plane(1, 2 + a);
+        const float gs[4] = {g0.x, g0.y, g0.z, g0.w}, gt[4] = {g1.x, g1.y, g1.z, g1.w};
+        const float us_[4] = {u0.x, u0.y, u0.z, u0.w}, ut[4] = {u1.x, u1.y, u1.z, u1.w};
+        const float rr = rsc[m];
+        unsigned short o16[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gsum = 0.f, usum = 0.f;
+            gsum += gs[j]; gsum += gt[j];
+            usum += us_[j]; usum += ut[j];
+            o16[j] = sjd_silu_mul_elem<DT>(gsum, usum, rr);
+        }
+        if (m < M) {
+            uint2 pk{(unsigned)o16[0] | ((unsigned)o16[1] << 16), (unsigned)o16[2] | ((unsigned)o16[3] << 16)};
+            *reinterpret_cast<uint2 *>(y + (size_t)m * I + 32 * (2 * blockIdx.x + a) + c4) = pk;
+        }
+    }
+    SJD_TR(6);
+}
+
+static int g1sz_launch(const void *x, const void *wz, const void *exc, void *y, int M, int I, int K, int step_major, const sjd_row_norm *rn, hipStream_t s)
+{
+    const int SP = K / 64;
+    const dim3 grid(I / 64), block(512);
+    const size_t lds_x = (size_t)2 * SP * 1024, lds_red = (size_t)8 * 32 * 36 * sizeof(float);
+    const size_t lds = lds_x > lds_red ? lds_x : lds_red;
+    const int rec_stride = step_major ? 2 * (I / 32) : 1;
+    const float *ss = rn ? rn->sumsq : nullptr;
+    const int sl = rn ? rn->slices : 0;
+    const float ih = rn ? 1.0f / (float)rn->hidden : 0.f, eps = rn ? rn->eps : 0.f;
+#define SJD_G1SZ_CASE(SP_) \
+    if (SP == SP_) { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1z_gateup_silu<SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((g1z_gateup_silu<SP_>), grid, block, lds, s, (const unsigned short *)x, (const unsigned char *)wz, (const u32x2 *)exc, \
+                           (unsigned short *)y, M, I, K, rec_stride, ss, sl, ih, eps); \
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH; \
+    }
+    SJD_G1SZ_CASE(8) SJD_G1SZ_CASE(16) SJD_G1SZ_CASE(32) SJD_G1SZ_CASE(64)
+#undef SJD_G1SZ_CASE
+    return SJD_ERR_UNSUPPORTED;
+}
+
+// sjd_gateup_silu over ops.pack_weight_z([Wg; Wu], K / 2, step_major): same result, bit for bit; bf16 only.
+extern "C" int sjd_gateup_silu_z(const void *x, const void *wz, const void *exc, void *y, int M, int I, int K, int step_major, int dtype,
+                                 const sjd_row_norm *row_norm, void *stream)
+{
+    if (!x || !wz || !exc || !y || M < 1 || I < 64 || K < 512) return SJD_ERR_BAD_ARG;
+    if (row_norm && (!row_norm->sumsq || row_norm->slices < 1 || row_norm->hidden < 1)) return SJD_ERR_BAD_ARG;
+    if (row_norm && row_norm->slices > 8) return SJD_ERR_UNSUPPORTED;
+    if (M > 32 || (I % 64) != 0 || !(K == 512 || K == 1024 || K == 2048 || K == 4096) || dtype != SJD_DTYPE_BF16) return SJD_ERR_UNSUPPORTED;
+    return g1sz_launch(x, wz, exc, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
+}
+
 template <int DT>
 static int g1s_launch(const void *x, const void *w_packed, void *y, int M, int I, int K, int step_major, const sjd_row_norm *rn, hipStream_t s)
 {
@@ -679,6 +864,235 @@ extern "C" int sjd_gateup_silu(const void *x, const void *w_packed, void *y, int
     if (dtype == SJD_DTYPE_BF16) return g1s_launch<SJD_DTYPE_BF16>(x, w_packed, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
     if (dtype == SJD_DTYPE_F16) return g1s_launch<SJD_DTYPE_F16>(x, w_packed, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
     return SJD_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------ G1z (12-bit lossless weight stream)
+// The window forward is a stream of the layer weights (12.96 GB per SJD iteration at Lumina-7B) through a fabric that sustains ~6.7 TB/s
+// whatever the launch shape: what is left is to stream FEWER BYTES.  The high byte of a bf16 weight (sign + the seven
+// high exponent bits) takes very few values inside one (k-chunk, 32-column tile) unit: a trained or Gaussian-initialised matrix puts all
+// but ~1e-4 of a unit's weights into 16 consecutive binades.  G1z streams every weight as its LOW BYTE (exponent lsb + mantissa, verbatim)
+// plus a 4-BIT CODE of the high byte -- (sign, offset 0..7 from a per-unit base) -- i.e. 12 bits per weight, 768-byte records instead of
+// 1-KiB ones; the few weights outside the unit's window ("exceptions") travel verbatim in a 256-byte header per unit and are patched into
+// the operand registers before the MFMA.  The B operand a wave feeds its MFMA is BIT-IDENTICAL to the uncompressed kernel's, so are the
+// accumulation order and the result (tests/test_gpu_glue.py::test_g1z_*): this is a lossless re-encoding of the weight stream, not a
+// change of precision.  A matrix some unit of which has more than 31 exceptions is simply left uncompressed by the packer
+// (ops.pack_weight_z returns None).  bf16 only: fp16's high byte (sign, 5 exponent bits, 2 mantissa bits) does not concentrate.
+//   record PAIR (1536 B, k-steps 2p and 2p + 1 of a unit; an odd last k-step is padded with zeros) =
+//       64 lanes x 16 B {low bytes of weights 0..3, 4..7 of k-step 2p; the same of k-step 2p + 1}, then
+//       64 lanes x  8 B {codes of k-step 2p, of k-step 2p + 1: byte i = code(w_i) | code(w_{i+4}) << 4}
+//     -- both parts naturally aligned 16- / 8-byte loads (12-byte lane records as ONE dwordx3 load measured slower: a lane's bytes
+//     straddle cache lines, profiles/r3_g1z_microbench.jsonl)
+//   header (256 B) = 32 x {pos, val}: entry 0 = {base, count}; entry i >= 1 = {k-step << 9 | lane << 3 | element, the weight's 16 bits}
+// Decoding is 12 VALU instructions per record and wave (the kernel is at ~6 % MFMA-busy, the VALU idle); exceptions cost a wave-uniform
+// compare per k-step and two selects on the ~10 % of k-steps that have one.  A record is ONE 12-byte buffer load per lane;
+// a wave keeps a ring of G1Z_DEPTH records in flight (first version, two register groups of eight like G1: 6 KiB per wave in flight, the
+// decode on the critical path between two round trips -- 16.6 us for q|k|v against G1's 19.9; o slower than G1).
+// high bytes of a record's eight weights from its code word: hA = weights 0..3, hB = weights 4..7 (byte i = sign << 7 | base + offset)
+__device__ __forceinline__ void g1z_high(unsigned c, unsigned base4, unsigned &hA, unsigned &hB)
+{
+    hA = (((c & 0x08080808u) << 4) | (c & 0x07070707u)) + base4;
+    const unsigned c2 = c >> 4;
+    hB = (((c2 & 0x08080808u) << 4) | (c2 & 0x07070707u)) + base4;
+}
+
+// The MFMA B operand of k-step s from its 12 bytes {low bytes 0..3, low bytes 4..7, codes}: decode the high bytes, patch the
+// unit's exceptions of this k-step into them (an exception differs from its coded form only in the HIGH byte -- the low byte travels
+// verbatim; wave-uniform control flow, two selects per exception), interleave.  v_step = pos >> 9 of this lane's entry.
+__device__ __forceinline__ u32x4 g1z_operand(unsigned lo0, unsigned lo1, unsigned c, unsigned s, const g1z_hdr &hd, int lane)
+{
+    unsigned hA, hB;
+    g1z_high(c, hd.base4, hA, hB);
+#ifdef G1Z_NO_PATCH           // (timing experiments only: the results are wrong wherever a unit has an exception)
+    unsigned long long mk = 0;
+#else
+    unsigned long long mk = __ballot(hd.v_step == s);
+#endif
+    while (mk) {
+        const int i = __builtin_ctzll(mk);
+        mk &= mk - 1;
+        const unsigned pos = __builtin_amdgcn_readlane(hd.v_pos, i), hi = (__builtin_amdgcn_readlane(hd.v_val, i) >> 8) & 0xffu;
+        const int tl = (int)((pos >> 3) & 63u);
+        const unsigned sh = (pos & 3u) * 8u, keep = ~(0xffu << sh), put = hi << sh;
+        const bool me = lane == tl, upper = (pos & 4u) != 0u;
+        hA = (me && !upper) ? ((hA & keep) | put) : hA;
+        hB = (me && upper) ? ((hB & keep) | put) : hB;
+    }
+    u32x4 d;
+    d.x = __builtin_amdgcn_perm(hA, lo0, 0x05010400u);       // {lo.b0, hA.b0, lo.b1, hA.b1}
+    d.y = __builtin_amdgcn_perm(hA, lo0, 0x07030602u);
+    d.z = __builtin_amdgcn_perm(hB, lo1, 0x05010400u);
+    d.w = __builtin_amdgcn_perm(hB, lo1, 0x07030602u);
+    return d;
+}
+
+// the header of unit (chunk, tile): every lane gets entry (lane & 31); returns base * 0x01010101 and leaves this lane's exception in
+// (v_step, v_pos, v_val) -- lanes 0 (base / count) and 32..63 (duplicates) hold none
+__device__ __forceinline__ g1z_hdr g1z_header(u32x2 e, int lane)
+{
+    g1z_hdr h;
+    h.base4 = (unsigned)__builtin_amdgcn_readfirstlane((int)e.x) * 0x01010101u;
+    const bool live = lane >= 1 && lane < 32;
+    h.v_pos = e.x;
+    h.v_val = e.y;
+    h.v_step = live ? (e.x >> 9) : 0xffffffffu;
+    return h;
+}
+
+// buffer descriptor over the records of ONE unit (wave-uniform by construction: the pointer goes through readfirstlane so that the
+// compiler can see it -- guide T20); loads past `bytes` return zero and move nothing
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t g1z_unit_rsrc(const unsigned char *first_record, unsigned bytes)
+{
+    const unsigned long long a = (unsigned long long)first_record;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
+template <int MT, int MAXT>
+__global__ __launch_bounds__(MAXT) void g1z_skinny_gemm(const unsigned short *__restrict__ x, const unsigned char *__restrict__ wz,
+                                                        const u32x2 *__restrict__ exc, float *__restrict__ out, int M, int N, int K, int KC,
+                                                        int n_tiles, int rec_stride, int tile0, int n_waves)
+{
+    constexpr int DT = SJD_DTYPE_BF16;
+    constexpr int D = MAXT <= 512 ? G1Z_DEPTH : (G1Z_DEPTH < 8 ? G1Z_DEPTH : 8);      // k-steps in flight per wave, as a ring of D / 2 record pairs (128 VGPRs at 9..16 waves)
+    constexpr int DP = D / 2;
+    constexpr int TL = D < 8 ? 8 : D;                             // k-steps of a loop trip (unrolled; the ring goes round TL / D times)
+    static_assert(D % 2 == 0 && TL % 8 == 0 && TL % D == 0, "g1_slot(.., s) depends on s & 7: a trip starts at a multiple of eight");
+    SJD_TR(0);
+    SJD_TR_HW();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *xl = reinterpret_cast<u32x4 *>(smem);
+    const int chunk = blockIdx.y;
+    const int k0 = chunk * KC;
+    const int steps = min(KC, K - k0) / 16;
+    const int pairs = (steps + 1) / 2, pairs_full = (KC / 16 + 1) / 2;          // record pairs of this unit / of a full chunk's unit
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int t_out = blockIdx.x * n_waves + w;
+    const int t = tile0 + t_out;
+    const bool has_tile = t_out < N / 32;
+    const size_t chunk_base = (size_t)chunk * n_tiles * pairs_full;
+    const size_t tile_off = (rec_stride == 1) ? (size_t)(has_tile ? t : 0) * pairs : (size_t)(has_tile ? t : 0);
+    const unsigned rsb = (unsigned)rec_stride * 1536u;
+    const __amdgpu_buffer_rsrc_t wr = g1z_unit_rsrc(wz + (chunk_base + tile_off) * 1536, has_tile ? (unsigned)(pairs - 1) * rsb + 1536u : 0u);
+    auto w_load = [&](int p) -> g1z_pair { return g1z_load(wr, (unsigned)lane, (unsigned)p * rsb); };
+    g1z_pair ring[DP];
+    const int ppr = 2 * steps;
+    const int nth = n_waves * 64;
+    constexpr int STAGE = MAXT <= 512 ? 2 * G1_STAGE : G1_STAGE;
+    const int dm = nth / ppr, dj = nth - dm * ppr;
+    int pm = threadIdx.x / ppr, pj = threadIdx.x - pm * ppr;
+    auto advance = [&](int &m, int &j) { m += dm; j += dj; if (j >= ppr) { j -= ppr; ++m; } };
+    auto x_load = [&](int m, int j) -> u32x4 {
+        return (m < M) ? *reinterpret_cast<const u32x4 *>(x + (size_t)m * K + k0 + 8 * j) : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto x_store = [&](int m, int j, u32x4 val) {
+        const int s = j >> 1;
+        if (m < 32 * MT) xl[((m >> 5) * steps + s) * 64 + g1_slot(j & 1, m & 31, s)] = val;
+    };
+    u32x2 hraw;
+    {   // first activation batch, the unit's header and the first D records right behind it (all unconditional, see g1_skinny_gemm)
+        u32x4 val[STAGE];
+        int m = pm, j = pj;
+#pragma unroll
+        for (int i = 0; i < STAGE; ++i) { val[i] = x_load(m, j); advance(m, j); }
+        hraw = exc[((size_t)chunk * n_tiles + (has_tile ? t : 0)) * 32 + (lane & 31)];
+#pragma unroll
+        for (int u = 0; u < DP; ++u) ring[u] = w_load(u);
+        m = pm; j = pj;
+#pragma unroll
+        for (int i = 0; i < STAGE; ++i) { x_store(m, j, val[i]); advance(m, j); }
+        pm = m; pj = j;
+    }
+    while (pm < 32 * MT) {
+        u32x4 val[G1_STAGE];
+        int m = pm, j = pj;
+#pragma unroll
+        for (int i = 0; i < G1_STAGE; ++i) { val[i] = x_load(m, j); advance(m, j); }
+        m = pm; j = pj;
+#pragma unroll
+        for (int i = 0; i < G1_STAGE; ++i) { x_store(m, j, val[i]); advance(m, j); }
+        pm = m; pj = j;
+    }
+    SJD_TR(1);
+    __syncthreads();
+    SJD_TR(2);
+    if (!has_tile) return;
+    const g1z_hdr hd = g1z_header(hraw, lane);
+    SJD_TR(3);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    const int xs = steps * 64;
+    // ring trips of D k-steps: every consumed pair is refilled with the one D k-steps further on, AFTER it was consumed (the refill lands in
+    // the registers it frees: no copies at the back edge) and unconditionally (exact s_waitcnt counts; a pair past the unit's end costs an
+    // instruction, no traffic), so D k-steps stay in flight per wave through the MFMAs.  The k-steps of the last trip that lie past the
+    // chunk are skipped by uniform branches.
+    auto a_read = [&](u32x4 (&a)[MT], int s, int u) {      // (read ahead of the patch branch; the address stays inside the staged chunk)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = xl[mt * xs + min(s, steps - 1) * 64 + g1_slot(lane >> 5, lane & 31, u)];
+    };
+    for (int s0 = 0; s0 < steps; s0 += TL) {
+        u32x4 a0[MT], a1[MT];
+        a_read(a0, s0, 0);
+#pragma unroll
+        for (int u = 0; u < TL / 2; ++u) {
+            const int sa = s0 + 2 * u, sb = sa + 1;
+            g1z_pair &slot = ring[u % DP];
+            if (sa < steps) {
+                a_read(a1, sb, 2 * u + 1);
+                const u32x4 b0 = g1z_operand(slot.lo.x, slot.lo.y, slot.c.x, (unsigned)sa, hd, lane);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(a0[mt], b0, acc[mt]);
+            }
+            u32x4 b1 = {0u, 0u, 0u, 0u};
+            if (sb < steps) {
+                if (u + 1 < TL / 2) a_read(a0, sb + 1, 2 * u + 2);
+                b1 = g1z_operand(slot.lo.z, slot.lo.w, slot.c.y, (unsigned)sb, hd, lane);
+            }
+            slot = w_load(s0 / 2 + u + DP);
+            if (sb < steps) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(a1[mt], b1, acc[mt]);
+            }
+        }
+    }
+    SJD_TR(4);
+    float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t_out * 32 + (lane & 31);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            o[(size_t)m * N] = acc[mt][r];
+        }
+}
+
+// x [M <= 64, K] bf16, wz / exc = ops.pack_weight_z(W [N_packed, K], KC, step_major) -> out fp32 [n_chunks, 32 * ceil(M / 32), N] for the N
+// columns from 32 * tile0: what sjd_skinny_gemm_cols writes from the uncompressed packing of the same weight, bit for bit.
+extern "C" int sjd_skinny_gemm_z(const void *x, const void *wz, const void *exc, float *out, int M, int N, int K, int KC, int waves,
+                                 int step_major, int dtype, int N_packed, int tile0, void *stream)
+{
+    if (!x || !wz || !exc || !out || M < 1 || N < 32 || (N % 32) != 0 || (N_packed % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0)
+        return SJD_ERR_BAD_ARG;
+    if (waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;
+    if (dtype != SJD_DTYPE_BF16 || M > 64 || KC > 4096) return SJD_ERR_UNSUPPORTED;       // (the k-step of an exception is 7 + 1 bits of its position)
+    const int n_out = N / 32, n_tiles = N_packed / 32, n_chunks = (K + KC - 1) / KC;
+    if (tile0 < 0 || tile0 + n_out > n_tiles) return SJD_ERR_BAD_ARG;
+    const int MT = M <= 32 ? 1 : 2;
+    const size_t lds = (size_t)MT * ((KC < K ? KC : K) / 16) * 1024;
+    if (lds > 160 * 1024) return SJD_ERR_BAD_ARG;
+    const dim3 grid((n_out + waves - 1) / waves, n_chunks), block(waves * 64);
+    hipStream_t s = (hipStream_t)stream;
+    const int rs = step_major ? n_tiles : 1;
+#define SJD_G1Z_LAUNCH(MT_, MAXT_) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1z_skinny_gemm<MT_, MAXT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((g1z_skinny_gemm<MT_, MAXT_>), grid, block, lds, s, (const unsigned short *)x, (const unsigned char *)wz, \
+                           (const u32x2 *)exc, out, M, N, K, KC, n_tiles, rs, tile0, waves); } while (0)
+    if (MT == 1) { if (waves <= 8) SJD_G1Z_LAUNCH(1, 512); else SJD_G1Z_LAUNCH(1, 1024); }
+    else { if (waves <= 8) SJD_G1Z_LAUNCH(2, 512); else SJD_G1Z_LAUNCH(2, 1024); }
+#undef SJD_G1Z_LAUNCH
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
 extern "C" int sjd_gemm_num_chunks(int K, int KC) { return (K + KC - 1) / KC; }

@@ -312,6 +312,85 @@ def pack_weight(weight, KC, step_major=False):
     return torch.cat(out).contiguous()
 
 
+class PackedZ:
+    """A packed weight in the 12-bit lossless stream format of kernels G1z / G1sz (see pack_weight_z): `data` uint8 [N * K * 3 / 2] (1536-byte
+    record pairs in pack_weight's record order), `exc` int32 [n_chunks, N / 32, 32, 2] (per-unit base / count and exceptions)."""
+
+    def __init__(self, data, exc, N, K, KC, step_major, n_exceptions):
+        self.data, self.exc, self.N, self.K, self.KC, self.step_major, self.n_exceptions = data, exc, N, K, KC, bool(step_major), int(n_exceptions)
+
+    def numel(self):
+        return self.N * self.K
+
+    def nbytes(self):
+        return self.data.numel() + self.exc.numel() * 4
+
+
+Z_MAX_EXC = 31          # exceptions a (k-chunk, 32-column tile) unit can carry in its 256-byte header
+
+
+def pack_weight_z(weight, KC, step_major=False):
+    """[N, K] bf16 weight -> PackedZ, the LOSSLESS 12-bit form of pack_weight(weight, KC, step_major) that sjd_skinny_gemm_z / sjd_gateup_silu_z
+    stream (include/sjd_hip.h), or None when the weight does not fit the format (not bf16, KC > 4096, or a unit with more than 31 exceptions).
+    Per unit (k-chunk c, tile t) the window of eight consecutive values of the weights' 7 high exponent bits that covers most of the unit is
+    chosen from the unit's histogram (robust against outliers on either side); a weight inside it is stored as low byte + code
+    (sign << 3 | offset), one outside it additionally verbatim as an exception."""
+    if weight.dtype != torch.bfloat16 or KC > 4096:
+        return None
+    N, K = weight.shape
+    assert N % 32 == 0 and K % 16 == 0 and KC % 16 == 0
+    T, dev = N // 32, weight.device
+    bits = weight.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+    datas, hdrs, total = [], [], 0
+    for k0 in range(0, K, KC):
+        kc = min(KC, K - k0)
+        S = kc // 16
+        b = bits[:, k0:k0 + kc].reshape(T, 32, S, 2, 8)                     # [t, r, s, h, j]
+        eh = (b >> 8) & 0x7F
+        hist = torch.zeros(T, 128, dtype=torch.int64, device=dev)
+        hist.scatter_add_(1, eh.reshape(T, -1).to(torch.int64), torch.ones(1, dtype=torch.int64, device=dev).expand(T, 32 * S * 16))
+        cs = torch.cat([torch.zeros(T, 1, dtype=torch.int64, device=dev), hist.cumsum(1)], dim=1)
+        base = (cs[:, 8:129] - cs[:, 0:121]).argmax(dim=1).to(torch.int32)   # [T] in 0..120: window [base, base + 7]
+        e3 = eh - base.view(T, 1, 1, 1, 1)
+        bad = (e3 < 0) | (e3 > 7)
+        cnt = bad.reshape(T, -1).sum(dim=1)
+        if int(cnt.max()) > Z_MAX_EXC:
+            return None
+        code = ((b >> 15) << 3) | e3.clamp(0, 7)                             # [t, r, s, h, j]
+        lo = b & 0xFF
+        lo0 = lo[..., 0] | (lo[..., 1] << 8) | (lo[..., 2] << 16) | (lo[..., 3] << 24)        # int32 wrap-around is the bit pattern wanted
+        lo1 = lo[..., 4] | (lo[..., 5] << 8) | (lo[..., 6] << 16) | (lo[..., 7] << 24)
+        cb = code[..., 0:4] | (code[..., 4:8] << 4)
+        cw = cb[..., 0] | (cb[..., 1] << 8) | (cb[..., 2] << 16) | (cb[..., 3] << 24)
+        # record PAIR p = k-steps 2p, 2p + 1 (an odd last k-step is padded with zeros): 64 lanes (= 32 h + r) x {lo0, lo1 of 2p; lo0, lo1 of
+        # 2p + 1}, then 64 lanes x {cw of 2p, cw of 2p + 1}  -> 256 + 128 int32: one 16-byte and one 8-byte load per lane, both aligned
+        P = (S + 1) // 2
+        st = torch.stack([lo0, lo1, cw], dim=-1).permute(0, 2, 3, 1, 4)                         # [t, s, h, r, 3]
+        if S % 2:
+            st = torch.cat([st, torch.zeros_like(st[:, :1])], dim=1)
+        st = st.reshape(T, P, 2, 64, 3)                                                         # [t, p, k-step of the pair, lane, 3]
+        lo_part = st[..., :2].permute(0, 1, 3, 2, 4).reshape(T, P, 256)                         # lane-major: (lane, k-step, 2)
+        c_part = st[..., 2].permute(0, 1, 3, 2).reshape(T, P, 128)                              # (lane, k-step)
+        rec = torch.cat([lo_part, c_part], dim=-1)                                              # [t, p, 384]
+        if step_major:
+            rec = rec.permute(1, 0, 2)
+        datas.append(rec.reshape(-1))
+        hdr = torch.full((T, 32, 2), -1, dtype=torch.int32, device=dev)
+        hdr[:, 0, 0] = base
+        hdr[:, 0, 1] = cnt.to(torch.int32)
+        idx = bad.nonzero()                                                  # rows sorted by t first
+        if idx.numel():
+            t_i, r_i, s_i, h_i, j_i = idx.unbind(1)
+            first = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), cnt.cumsum(0)[:-1]])
+            rank = torch.arange(idx.shape[0], device=dev) - first[t_i]
+            hdr[t_i, 1 + rank, 0] = ((s_i << 9) | ((32 * h_i + r_i) << 3) | j_i).to(torch.int32)
+            hdr[t_i, 1 + rank, 1] = b[t_i, r_i, s_i, h_i, j_i]
+            total += idx.shape[0]
+        hdrs.append(hdr)
+    data = torch.cat(datas).contiguous().view(torch.uint8)
+    return PackedZ(data, torch.stack(hdrs).contiguous(), N, K, KC, step_major, total)
+
+
 def _prows(M):
     """row padding of the G1 partial planes: whole 32-row MFMA tiles (M <= 128: up to four prompts per forward)"""
     return ((int(M) + 31) // 32) * 32
@@ -321,6 +400,8 @@ def skinny_gemm(x, w_packed, N, K, KC, waves=4, step_major=False):
     """x [M<=128, K] bf16/fp16 -> Partials([n_chunks, 32 * ceil(M / 32), N] fp32)."""
     M = x.shape[0]
     assert x.is_contiguous() and x.shape[1] == K and w_packed.numel() == N * K
+    if isinstance(w_packed, PackedZ):
+        return skinny_gemm_cols(x, w_packed, N, K, KC, 0, N, waves, step_major)
     nc = (K + KC - 1) // KC
     out = torch.empty(nc, _prows(M), N, dtype=torch.float32, device=x.device)
     L.check(L.load().sjd_skinny_gemm(_ptr(x), _ptr(w_packed), _ptr(out), M, N, K, KC, waves, int(step_major), _dtype_code(x.dtype), _stream()), "sjd_skinny_gemm")
@@ -371,6 +452,8 @@ _PREFETCH_SINK = {}
 def weight_prefetch(w_packed, blocks=128, nbytes=None):
     """Read `w_packed` (a G1 packed weight) on the CURRENT stream and discard it: pulls the lines into the Infinity Cache ahead of
     the G1 launch that streams them (call it on a side stream forked from the forward, see ChameleonBackbone._prefetch)."""
+    if isinstance(w_packed, PackedZ):
+        w_packed = w_packed.data
     dev = w_packed.device
     sink = _PREFETCH_SINK.get(dev)
     if sink is None:
@@ -385,6 +468,13 @@ def skinny_gemm_cols(x, w_packed, N_packed, K, KC, col0, n_cols, waves=8, step_m
     assert x.is_contiguous() and x.shape[1] == K and w_packed.numel() == N_packed * K and col0 % 32 == 0 and n_cols % 32 == 0
     nc = (K + KC - 1) // KC
     out = torch.empty(nc, _prows(M), n_cols, dtype=torch.float32, device=x.device)
+    if isinstance(w_packed, PackedZ):
+        assert (w_packed.KC, w_packed.step_major) == (KC, bool(step_major)) and x.dtype == torch.bfloat16
+        if M > 64:
+            raise ValueError(f"the 12-bit weight stream (G1z) serves windows of up to 64 rows, got {M}: pack with compress=False for more prompts per forward")
+        L.check(L.load().sjd_skinny_gemm_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), _ptr(out), M, n_cols, K, KC, waves, int(step_major),
+                                          _dtype_code(x.dtype), N_packed, col0 // 32, _stream()), "sjd_skinny_gemm_z")
+        return Partials(out, nc, n_cols)
     L.check(L.load().sjd_skinny_gemm_cols(_ptr(x), _ptr(w_packed), _ptr(out), M, n_cols, K, KC, waves, int(step_major), _dtype_code(x.dtype),
                                          N_packed, col0 // 32, _stream()), "sjd_skinny_gemm_cols")
     return Partials(out, nc, n_cols)
@@ -519,6 +609,11 @@ def gateup_silu(x, w_packed, inter, hidden, step_major=False, row_norm=None):
     T = x.shape[0]
     assert x.is_contiguous() and x.shape[1] == hidden and w_packed.numel() == 2 * inter * hidden
     y = torch.empty(T, inter, dtype=x.dtype, device=x.device)
+    if isinstance(w_packed, PackedZ):
+        assert (w_packed.KC, w_packed.step_major) == (hidden // 2, bool(step_major)) and x.dtype == torch.bfloat16
+        L.check(L.load().sjd_gateup_silu_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), _ptr(y), T, inter, hidden, int(step_major),
+                                          _dtype_code(x.dtype), _row_norm(row_norm), _stream()), "sjd_gateup_silu_z")
+        return y
     L.check(L.load().sjd_gateup_silu(_ptr(x), _ptr(w_packed), _ptr(y), T, inter, hidden, int(step_major), _dtype_code(x.dtype),
                                     _row_norm(row_norm), _stream()), "sjd_gateup_silu")
     return y

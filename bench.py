@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--gemm", default="sjd", choices=["sjd", "torch"], help="window projections: G1 weight-streaming kernel or hipBLASLt")
     ap.add_argument("--tunableop", action="store_true", help="enable PyTorch TunableOp GEMM selection")
     ap.add_argument("--no-fold-norm", action="store_true", help="keep F1 (RMSNorm before the projection) instead of the folded-norm forward")
+    ap.add_argument("--no-compress", action="store_true", help="stream the packed bf16 weights uncompressed (G1 / G1s) instead of the lossless "
+                    "12-bit stream (G1z / G1sz); results are bit-identical either way")
     ap.add_argument("--no-fused", action="store_true", help="plain ATen element-wise glue instead of the fused F1-F3 kernels")
     ap.add_argument("--k1-launches", type=int, default=320, help="launches of the K1 micro-measurement")
     ap.add_argument("--total-prompts", type=int, default=0,
@@ -116,7 +118,9 @@ def build_model(args, device):
         model.G1_CFG = dict(model.G1_CFG, **{k: (int(v[0]), int(v[1]), bool(v[2])) for k, v in over.items()})
     synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=args.embed_token_scale)
     if not args.no_fused:
-        model.enable_fused(ops, gemm=args.gemm, fold_norm=not args.no_fold_norm)
+        # (the 12-bit stream serves windows of up to 64 rows: three / four prompts per forward keep the uncompressed packing)
+        model.enable_fused(ops, gemm=args.gemm, fold_norm=not args.no_fold_norm,
+                           compress=False if (args.no_compress or args.prompts_per_gpu > 2) else None)
     return model, margs, attn
 
 
@@ -245,8 +249,14 @@ def measure_g1(args, model, device, rounds=2):
     torch.cuda.synchronize()
     n = rounds * len(model._packed) * len(shapes)
     tot_ms = lib.sjd_event_elapsed_ms(e0, e1)
-    tot_b = rounds * len(model._packed) * sum(N * K * 2 + 32 * K * 2 for N, K in shapes.values())
-    return dict(launches=n, avg_ms=tot_ms / n, avg_bytes=tot_b / n, gbps=tot_b / 1e9 / (tot_ms / 1e3), fused_mlp=bool(fused_mlp))
+    # algorithmic bytes of a launch = the weight stream AS STORED (the lossless 12-bit form is what the algorithm has to move; the bf16 size is
+    # reported next to it) + the activation rows
+    wbytes = lambda p, N, K: p.nbytes() if isinstance(p, ops.PackedZ) else N * K * 2
+    tot_b = rounds * sum(wbytes(pk[name], N, K) + 32 * K * 2 for pk in model._packed for name, (N, K) in shapes.items())
+    tot_b16 = rounds * len(model._packed) * sum(N * K * 2 + 32 * K * 2 for N, K in shapes.values())
+    nz = sum(isinstance(pk[name], ops.PackedZ) for pk in model._packed for name in shapes)
+    return dict(launches=n, avg_ms=tot_ms / n, avg_bytes=tot_b / n, gbps=tot_b / 1e9 / (tot_ms / 1e3), fused_mlp=bool(fused_mlp),
+                compressed_launches=rounds * nz, avg_bytes_bf16=tot_b16 / n, gbps_bf16_equivalent=tot_b16 / 1e9 / (tot_ms / 1e3))
 
 
 def cpu_baseline(args, gpu_sched_ms=None):
@@ -411,10 +421,18 @@ def roofline_blocks(args, prof, prof_g1):
     if prof_g1 is not None:       # the dominant kernel by time (~70 % of an iteration)
         g1_name = ("g1_skinny_gemm x3 + g1_gateup_silu (weight-streaming window projections, gate|up with SiLU*up as its epilogue; 128 launches / iteration)"
                    if prof_g1.get("fused_mlp") else "g1_skinny_gemm (weight-streaming window projections, 128 launches / iteration)")
-        tr, src = traffic_of("g1_traffic.json")
+        z = prof_g1.get("compressed_launches", 0) > 0
+        if z:
+            g1_name = g1_name.replace("g1_skinny_gemm", "g1z_skinny_gemm").replace("g1_gateup_silu", "g1z_gateup_silu")
+        tr, src = traffic_of("g1z_traffic.json" if z else "g1_traffic.json")
         g1_block = {"kernel": g1_name, "bound": "hbm", "achieved": round(prof_g1["gbps"], 1), "peak": peak, "unit": "GB/s",
                     "frac": round(prof_g1["gbps"] / peak, 4), "traffic": tr, "traffic_source": src, "avg_us": round(prof_g1["avg_ms"] * 1e3, 2),
                     "avg_bytes": int(prof_g1["avg_bytes"]), "launches": prof_g1["launches"]}
+        if z:       # `achieved` counts the bytes the kernel has to move: the weights in their lossless 12-bit stream form
+            g1_block.update({"weight_stream": f"lossless 12-bit (G1z / G1sz; {prof_g1['compressed_launches']} of {prof_g1['launches']} launches; "
+                                              "results bit-identical to the bf16 stream)",
+                             "avg_bytes_as_bf16": int(prof_g1["avg_bytes_bf16"]),
+                             "bf16_equivalent_GBps": round(prof_g1["gbps_bf16_equivalent"], 1)})
     return (g1_block, k1_block) if g1_block is not None else (k1_block, None)
 
 

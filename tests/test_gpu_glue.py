@@ -1,5 +1,7 @@
 """GPU: fused glue kernels F1-F3 against the plain PyTorch ops they replace (fp32/bf16 references of the same op),
 and the fused backbone forward against the unfused one."""
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -401,3 +403,93 @@ def test_16bit_window_forward_error_against_fp32_forward(dev, dtype):
         with open(os.path.join(out_dir, f"logit_error_{str(dtype).split('.')[-1]}.json"), "w") as f:
             json.dump(rep, f)
     assert e_hip.max() <= 1.5 * e_aten.max() + 1e-3 and e_hip.mean() <= 1.5 * e_aten.mean() + 1e-4, rep
+
+
+def _z_weight(N, K, gen, dev, outliers):
+    """bf16 weight with a few values far outside the 16-binade window of their unit (exceptions: patched into the operand registers)"""
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(torch.bfloat16)
+    outliers = min(outliers, N * K // 4096)            # (a unit carries at most 31 exceptions)
+    if outliers:
+        idx_n = torch.randint(0, N, (outliers,), generator=gen)
+        idx_k = torch.randint(0, K, (outliers,), generator=gen)
+        vals = torch.tensor([0.0, 37.0, -1e-12, 2e-9, -512.0, 1e-30])[torch.randint(0, 6, (outliers,), generator=gen)]
+        w[idx_n, idx_k] = vals.to(torch.bfloat16)
+        w[0, 0], w[N - 1, K - 1], w[31, 7], w[N - 32, K - 16] = 0.0, 96.0, -3e-15, 1e-8       # first / last lane, element and k-step of a unit
+    return w.to(dev)
+
+
+@pytest.mark.parametrize("M,N,K,KC,waves,step_major", [
+    (32, 12288, 4096, 896, 8, True),       # Lumina-7B q|k|v: ragged last chunk, step-major
+    (32, 4096, 4096, 512, 6, False),       # o
+    (32, 4096, 11008, 896, 8, False),      # down
+    (32, 22016, 4096, 2048, 8, True),      # gate|up as plain G1z (128 k-steps per unit)
+    (17, 4096, 11008, 896, 8, False), (64, 4096, 4096, 512, 8, False), (40, 12288, 4096, 896, 8, True),
+    (32, 8224, 4096, 1024, 4, True), (5, 512, 1024, 256, 4, True), (32, 1024, 528, 128, 2, False), (64, 2048, 2752, 512, 11, True),
+    (32, 96, 48, 16, 3, False)])
+@pytest.mark.parametrize("outliers", [0, 300])
+def test_g1z_matches_g1_bit_for_bit(dev, M, N, K, KC, waves, step_major, outliers):
+    """G1z (the projection over the 12-bit lossless weight stream) writes the SAME split-K planes as G1 over the uncompressed packing of the
+    same weight -- every MFMA operand is reconstructed bit for bit, exceptions included -- also from a hipGraph and over a column window."""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(N + K + M + outliers)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = _z_weight(N, K, g, dev, outliers)
+    wp, wz = ops.pack_weight(w, KC, step_major), ops.pack_weight_z(w, KC, step_major)
+    assert wz is not None and wz.data.numel() <= wp.numel() * 2 * 0.76 + 1536 * (N // 32) * -(-K // KC)
+    if outliers:
+        assert wz.n_exceptions >= 4
+    ref = ops.skinny_gemm(x, wp, N, K, KC, waves, step_major).data
+    got = ops.skinny_gemm(x, wz, N, K, KC, waves, step_major).data
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape and torch.equal(got.view(torch.int32), ref.view(torch.int32)), (got - ref).abs().max()
+    if N >= 256:                           # a column window of the packed weight (the output head on the grammar's columns)
+        c0, nc = 64, N - 160
+        ref_c = ops.skinny_gemm_cols(x, wp, N, K, KC, c0, nc, waves, step_major).data
+        got_c = ops.skinny_gemm_cols(x, wz, N, K, KC, c0, nc, waves, step_major).data
+        assert torch.equal(got_c.view(torch.int32), ref_c.view(torch.int32)) and torch.equal(got_c, ref[:, :, c0:c0 + nc])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ops.skinny_gemm(x, wz, N, K, KC, waves, step_major)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        cap = ops.skinny_gemm(x, wz, N, K, KC, waves, step_major).data
+    cap.zero_()
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cap.view(torch.int32), ref.view(torch.int32))
+
+
+@pytest.mark.parametrize("step_major", [False, True])
+@pytest.mark.parametrize("M,I,K", [(32, 11008, 4096), (17, 11008, 4096), (32, 1408, 512), (5, 128, 1024), (32, 2752, 2048)])
+@pytest.mark.parametrize("with_norm", [True, False])
+@pytest.mark.parametrize("outliers", [0, 200])
+def test_g1sz_matches_g1s_bit_for_bit(dev, step_major, M, I, K, with_norm, outliers):
+    """G1sz (gate|up + SiLU * up over the 12-bit stream) is BIT-IDENTICAL to G1s over the uncompressed packing (and hence to G1 + F3)."""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(I + K + M + outliers)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = _z_weight(2 * I, K, g, dev, outliers)
+    wp, wz = ops.pack_weight(w, K // 2, step_major), ops.pack_weight_z(w, K // 2, step_major)
+    assert wz is not None
+    rn = (ops.residual_sumsq(x.clone(), None), K, 1e-5) if with_norm else None
+    ref = ops.gateup_silu(x, wp, I, K, step_major, row_norm=rn)
+    got = ops.gateup_silu(x, wz, I, K, step_major, row_norm=rn)
+    torch.cuda.synchronize()
+    assert got.shape == (M, I) and torch.equal(got.view(torch.int16), ref.view(torch.int16)), (got.float() - ref.float()).abs().max()
+
+
+def test_g1z_refuses_what_it_does_not_serve(dev):
+    import sjd_amd._lib as L
+    import sjd_amd.ops as ops
+    w = (torch.randn(64, 256) * 0.02).to(torch.bfloat16).to(dev)
+    wz = ops.pack_weight_z(w, 128)
+    x16 = torch.randn(8, 256, device=dev).to(torch.float16)
+    out = torch.empty(2, 32, 64, device=dev)
+    lib = L.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), p(out), 8, 64, 256, 128, 2, 0, 1, 64, 0, s) != 0          # fp16
+    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), p(out), 96, 64, 256, 128, 2, 0, 0, 64, 0, s) != 0         # > 64 rows
+    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), None, p(out), 8, 64, 256, 128, 2, 0, 0, 64, 0, s) != 0               # no header table
+    assert lib.sjd_gateup_silu_z(p(x16), p(wz.data), p(wz.exc), p(out), 8, 64, 512, 0, 1, None, s) != 0                   # fp16

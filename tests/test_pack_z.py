@@ -1,0 +1,94 @@
+"""The 12-bit lossless weight stream of kernels G1z / G1sz (sjd_amd.ops.pack_weight_z, include/sjd_hip.h): a NumPy restatement of what the
+kernel does with a record -- decode (low byte + 4-bit code + unit base), then patch the unit's exceptions -- must give back the uncompressed
+packed stream of ops.pack_weight bit for bit.  CPU only (the GPU side is tests/test_gpu_glue.py::test_g1z_*)."""
+import numpy as np
+import pytest
+import torch
+
+import sjd_amd.ops as ops
+
+
+def decode_z(pz):
+    """PackedZ -> the uint16 stream pack_weight(weight, KC, step_major) holds (the kernel's g1z_decode + g1z_patch, restated)."""
+    N, K, KC = pz.N, pz.K, pz.KC
+    T = N // 32
+    data = pz.data.cpu().numpy().view(np.uint32)
+    exc = pz.exc.cpu().numpy().view(np.uint32)                   # [n_chunks, T, 32, 2]
+    out, off = [], 0
+    for c, k0 in enumerate(range(0, K, KC)):
+        S = min(KC, K - k0) // 16
+        P = (S + 1) // 2                                         # record pairs (k-steps 2p, 2p + 1) of 384 words
+        rec = data[off:off + T * P * 384]
+        off += T * P * 384
+        rec = rec.reshape(P, T, 384).transpose(1, 0, 2) if pz.step_major else rec.reshape(T, P, 384)
+        lo = rec[..., :256].reshape(T, P, 64, 2, 2).transpose(0, 1, 3, 2, 4).reshape(T, 2 * P, 64, 2)[:, :S]      # [t, s, lane, {0..3, 4..7}]
+        cw = rec[..., 256:].reshape(T, P, 64, 2).transpose(0, 1, 3, 2).reshape(T, 2 * P, 64)[:, :S]
+        base4 = (exc[c, :, 0, 0].astype(np.uint32) * np.uint32(0x01010101))[:, None, None]
+        hA = ((((cw & 0x08080808) << 4) | (cw & 0x07070707)) + base4).astype(np.uint32)
+        c2 = cw >> 4
+        hB = ((((c2 & 0x08080808) << 4) | (c2 & 0x07070707)) + base4).astype(np.uint32)
+        w16 = np.zeros((T, S, 64, 8), dtype=np.uint16)
+        for j in range(4):
+            w16[..., j] = ((lo[..., 0] >> (8 * j)) & 0xFF) | (((hA >> (8 * j)) & 0xFF) << 8)
+            w16[..., 4 + j] = ((lo[..., 1] >> (8 * j)) & 0xFF) | (((hB >> (8 * j)) & 0xFF) << 8)
+        for t in range(T):                                       # exceptions: entries 1..31 of the unit's header
+            n = int(exc[c, t, 0, 1])
+            for i in range(1, 1 + n):
+                pos, val = int(exc[c, t, i, 0]), int(exc[c, t, i, 1])
+                w16[t, pos >> 9, (pos >> 3) & 63, pos & 7] = val & 0xFFFF
+            assert np.all(exc[c, t, 1 + n:, 0] == 0xFFFFFFFF)
+        if pz.step_major:
+            w16 = w16.transpose(1, 0, 2, 3)
+        out.append(w16.reshape(-1))
+    return np.concatenate(out)
+
+
+def raw_stream(w, KC, step_major):
+    return ops.pack_weight(w, KC, step_major).view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("N,K,KC,step_major", [(64, 256, 128, False), (96, 512, 512, True), (128, 1040, 512, False), (64, 896, 896, True),
+                                               (32, 4096, 2048, True)])
+def test_z_stream_decodes_to_the_uncompressed_stream(N, K, KC, step_major):
+    g = torch.Generator().manual_seed(N + K)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    pz = ops.pack_weight_z(w, KC, step_major)
+    pairs = sum((min(KC, K - k0) // 16 + 1) // 2 for k0 in range(0, K, KC))      # an odd last k-step of a chunk is padded to a pair
+    assert pz is not None and pz.data.numel() == (N // 32) * pairs * 1536
+    assert np.array_equal(decode_z(pz), raw_stream(w, KC, step_major))
+
+
+def test_z_exceptions_carry_outliers_zeros_and_specials():
+    g = torch.Generator().manual_seed(7)
+    N, K, KC = 64, 512, 256
+    w = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16)
+    # a handful of weights far outside any 16-binade window, in both units' first and last k-steps / lanes / elements
+    w[0, 0], w[31, 255], w[32, 256], w[63, 511] = 0.0, 3.0e4, -1.0e-30, float("inf")
+    w[5, 17], w[40, 300] = -0.0, float("nan")
+    w[7, 8:12] = torch.tensor([1e-20, -1e-20, 1e20, -1e20]).to(torch.bfloat16)
+    for sm in (False, True):
+        pz = ops.pack_weight_z(w, KC, sm)
+        assert pz is not None and pz.n_exceptions >= 10
+        assert np.array_equal(decode_z(pz), raw_stream(w, KC, sm))
+
+
+def test_z_packer_declines_what_does_not_fit():
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(64, 256, generator=g) * 0.02).to(torch.bfloat16)
+    assert ops.pack_weight_z(w.to(torch.float16), 128) is None                    # fp16: the high byte does not concentrate
+    w2 = w.clone()
+    w2[:32, :128] = 0.0                                                            # a unit of zeros next to ordinary weights: too many exceptions?
+    pz = ops.pack_weight_z(w2, 128)                                                # no: the unit's window moves to exponent 0 -- still lossless
+    assert pz is not None and np.array_equal(decode_z(pz), raw_stream(w2, 128, False))
+    w3 = w.clone()
+    w3[0, :64] = torch.logspace(-30, 30, 64).to(torch.bfloat16)                    # 64 weights spread over 200 binades in one unit
+    assert ops.pack_weight_z(w3, 128) is None
+
+
+def test_z_window_follows_the_bulk_not_the_outlier():
+    g = torch.Generator().manual_seed(11)
+    w = (torch.randn(32, 2048, generator=g) * 0.02).to(torch.bfloat16)
+    w[3, 100] = 50.0                                                               # one outlier 11 binades above the bulk
+    pz = ops.pack_weight_z(w, 2048)
+    assert pz is not None and pz.n_exceptions < 16
+    assert np.array_equal(decode_z(pz), raw_stream(w, 2048, False))

@@ -651,6 +651,17 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #ifndef G1Z_DEPTH
 #define G1Z_DEPTH 8           // k-steps a wave keeps in flight (a ring of G1Z_DEPTH / 2 record pairs); 4 / 8 / 16 / 32 measured: 8 (profiles/r3_g1z_microbench.txt)
 #endif
+// Experiment (off): a barrier between a workgroup's activation loads and its first weight loads, so that no activation request queues
+// behind another wave's HBM round trips in the CU's in-order vector memory pipe.  Measured equal or slightly slower at ring depth 8 and 16
+// (profiles/r3_g1z_microbench.txt): the 1.8 us until the activation is staged is the cold round trip itself.
+#ifndef G1Z_XFIRST
+#define G1Z_XFIRST 0
+#endif
+#if G1Z_XFIRST
+#define G1Z_XFIRST_BARRIER() __builtin_amdgcn_s_barrier()
+#else
+#define G1Z_XFIRST_BARRIER() do { } while (0)
+#endif
 #ifndef G1Z_AUX
 #define G1Z_AUX 2             // cache policy of the weight loads: nt (streamed once)
 #endif
@@ -717,6 +728,7 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu(const unsigned short *__r
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) ssv[qq] = ssp[(size_t)(row_sumsq ? min(qq, rs_slices - 1) : 0) * 32 + (threadIdx.x & 31)];
     }
+    G1Z_XFIRST_BARRIER();
     const u32x2 hraw = exc[((size_t)kh * n_tiles + t) * 32 + (lane & 31)];
 #pragma unroll
     for (int u = 0; u < DP; ++u) ring[u] = w_load(u);
@@ -994,6 +1006,7 @@ __global__ __launch_bounds__(MAXT) void g1z_skinny_gemm(const unsigned short *__
         int m = pm, j = pj;
 #pragma unroll
         for (int i = 0; i < STAGE; ++i) { val[i] = x_load(m, j); advance(m, j); }
+        G1Z_XFIRST_BARRIER();
         hraw = exc[((size_t)chunk * n_tiles + (has_tile ? t : 0)) * 32 + (lane & 31)];
 #pragma unroll
         for (int u = 0; u < DP; ++u) ring[u] = w_load(u);
@@ -1066,6 +1079,11 @@ __global__ __launch_bounds__(MAXT) void g1z_skinny_gemm(const unsigned short *__
             const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             o[(size_t)m * N] = acc[mt][r];
         }
+#ifdef SJD_TRACE
+    SJD_TR(5);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    SJD_TR(6);
+#endif
 }
 
 // x [M <= 64, K] bf16, wz / exc = ops.pack_weight_z(W [N_packed, K], KC, step_major) -> out fp32 [n_chunks, 32 * ceil(M / 32), N] for the N

@@ -25,6 +25,7 @@ def build():
     for f in ("sjd_attention", "sjd_gemm", "sjd_glue", "sjd_sampling"):
         o = os.path.join("/tmp", f + "_trace.o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DSJD_TRACE", "-Wno-unused-value", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+                              + os.environ.get("SJD_TRACE_FLAGS", "").split()
                               + (["-ffp-contract=off"] if f == "sjd_sampling" else []) + ["-c", os.path.join(csrc, f + ".hip"), "-o", o])
         objs.append(o)
     rest = [os.path.join(csrc, f + ".o") for f in ("sjd_capi",)]
@@ -109,7 +110,8 @@ def trace_k1_shared(lib, torch, ops, np):
                               end_us=dict(mean=us((t[:, 5] - t0).mean()), max=us((t[:, 5] - t0).max())))), flush=True)
 
 
-def trace_g1(lib, torch, ops, np):
+def trace_g1(lib, torch, ops, np, z=False):
+    """z: the same launches over the 12-bit lossless weight stream (g1z_skinny_gemm; stamp 3 = the unit's header arrived)"""
     import sjd_amd._lib as L
     import sjd_amd.backbones as BB
     dev = torch.device("cuda:0")
@@ -117,11 +119,16 @@ def trace_g1(lib, torch, ops, np):
     for name, (N, K) in dict(qkv=(12288, 4096), o=(4096, 4096), gate_up=(22016, 4096), down=(4096, 11008)).items():
         KC, waves, sm = BB.ChameleonBackbone.G1_CFG[name]
         x = torch.randn(32, K, device=dev).to(torch.bfloat16)
-        wps = [ops.pack_weight((torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16), KC, sm) for _ in range(6)]
+        wps = [(ops.pack_weight_z if z else ops.pack_weight)((torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16), KC, sm) for _ in range(6)]
         nc = (K + KC - 1) // KC
         out = torch.empty(nc, 32, N, dtype=torch.float32, device=dev)
 
         def g1(i):
+            if z:
+                L.check(lib.sjd_skinny_gemm_z(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % 6].data.data_ptr()), ctypes.c_void_p(wps[i % 6].exc.data_ptr()),
+                                              ctypes.c_void_p(out.data_ptr()), 32, N, K, KC, waves, int(sm), 0, N, 0,
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "g1z")
+                return
             L.check(lib.sjd_skinny_gemm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % 6].data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                         32, N, K, KC, waves, int(sm), 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "g1")
         with torch.cuda.stream(torch.cuda.Stream()):
@@ -147,7 +154,7 @@ def trace_g1(lib, torch, ops, np):
                 dict(x=i % gx, y=i // gx, xcc=int(t[i, 7] >> 32) & 15, cu=int(t[i, 7] >> 8) & 15, sh=int(t[i, 7] >> 12) & 1, se=int(t[i, 7] >> 13) & 7,
                      t=[us(t[i, k] - t0) for k in range(7)]) for i in range(nwg)])) + "\n")
             PER_WG.flush()
-        print(json.dumps(dict(kernel="g1_skinny_gemm<bf16, 32 rows>", shape=name, KC=KC, waves=waves, workgroups=nwg,
+        print(json.dumps(dict(kernel=("g1z_skinny_gemm" if z else "g1_skinny_gemm") + "<bf16, 32 rows>", shape=name, KC=KC, waves=waves, workgroups=nwg,
                               start_skew_us=us((t[:, 0] - t0).max()),
                               phase_us=dict(stage_activation=d(0, 1), wait_for_waves=d(1, 2), first_weight_group=d(2, 3), main_loop=d(3, 4),
                                             store_issue=d(4, 5), store_ack=d(5, 6)),
@@ -300,6 +307,10 @@ def main():
         return
     if "--g1s" in sys.argv:
         trace_g1s(lib, torch, ops, np)
+        return
+    if "--g1z" in sys.argv:
+        trace_g1(lib, torch, ops, np)
+        trace_g1(lib, torch, ops, np, z=True)
         return
     trace_k1(lib, torch, ops, np)
     trace_k1_shared(lib, torch, ops, np)

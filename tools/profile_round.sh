@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_trace -- 
 python tools/trace_by_grid.py $O/prof_${TAG}_trace 200 > $O/${TAG}_bench_by_shape.txt
 find $O/prof_${TAG}_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_bench_kernel_stats.csv
 K1="python tools/k1_bench.py --kv-len 1216 --n-split 4 --launches 96 --graph"
-G1="python tools/g1_bench.py --product --no-blas --launches 48"
+G1="python tools/g1z_bench.py --launches 48"      # G1 / G1s and G1z / G1sz at the product launch shapes (kernel names g1_* / g1z_*)
 for C in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE"; do
   T=$(echo $C | tr ' ' '_')
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/prof_${TAG}_k1_$T -- $K1 > /dev/null 2>> $O/${TAG}_pmc.err
@@ -25,7 +25,7 @@ done
 : > $O/${TAG}_pmc_summary.jsonl
 for d in $O/prof_${TAG}_k1_* $O/prof_${TAG}_g1_*; do
   echo "# $d" >> $O/${TAG}_pmc_summary.jsonl
-  python tools/pmc_summary.py $d k1_ g1_ >> $O/${TAG}_pmc_summary.jsonl
+  python tools/pmc_summary.py $d k1_ g1_ g1z_ >> $O/${TAG}_pmc_summary.jsonl
 done
 cat $O/${TAG}_pmc_summary.jsonl
 head -30 $O/${TAG}_bench_by_shape.txt

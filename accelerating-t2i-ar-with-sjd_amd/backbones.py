@@ -358,6 +358,9 @@ class ChameleonBackbone(nn.Module):
     # G1 launch shape per projection: (split-K chunk, column tiles per workgroup, step-major packing) -- tuned on MI355X with
     # tools/g1_bench.py so that every launch gives the 256 CUs ~1000+ balanced waves
     G1_CFG = dict(qkv=(896, 8, True), o=(512, 6, False), gate_up=(2048, 8, True), down=(896, 8, False))
+    # the same for the 12-bit weight stream (G1z): the launch-shape sweep of tools/g1z_bench.py --sweep and an end-to-end A/B on one box
+    # (profiles/r3_g1z_microbench.txt: 3.068 / 3.090 -> 3.044 ms per step); taken by enable_fused when the caller has not set G1_CFG itself
+    G1_CFG_Z = dict(qkv=(1024, 6, True), o=(512, 6, False), gate_up=(2048, 8, True), down=(768, 8, False))
     # the same for 64-row windows (two prompts per forward, or a draft window of 32): the staged chunk is twice as tall, so KC <= 1280;
     # set `model.G1_CFG = model.G1_CFG_64ROW` before enable_fused (the packing depends on KC).  Tuned end to end at Lumina-7B shapes.
     G1_CFG_64ROW = dict(qkv=(896, 8, True), o=(512, 8, False), gate_up=(1024, 12, True), down=(896, 8, False))      # profiles/r2_g1_launch_shape_sweep_64rows.jsonl
@@ -426,6 +429,8 @@ class ChameleonBackbone(nn.Module):
         if compress is None:
             compress = _os.environ.get("SJD_G1Z", "1") != "0"
         self.compress = bool(compress) and gemm == "sjd"
+        if self.compress and "G1_CFG" not in self.__dict__ and self.lm_head.weight.dtype == torch.bfloat16:
+            self.G1_CFG = dict(self.G1_CFG_Z)
         self.compress_stats = dict(matrices=0, compressed=0, bytes_raw=0, bytes_packed=0, exceptions=0)
 
         def pack(w, kc, sm):

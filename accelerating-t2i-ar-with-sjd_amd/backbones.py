@@ -363,11 +363,12 @@ class ChameleonBackbone(nn.Module):
     G1_CFG_Z = dict(qkv=(1024, 6, True), o=(512, 6, False), gate_up=(2048, 8, True), down=(768, 8, False))
     # the same for 64-row windows (two prompts per forward, or a draft window of 32): the staged chunk is twice as tall, so KC <= 1280;
     # set `model.G1_CFG = model.G1_CFG_64ROW` before enable_fused (the packing depends on KC).  Tuned end to end at Lumina-7B shapes.
-    G1_CFG_64ROW = dict(qkv=(896, 8, True), o=(512, 8, False), gate_up=(1024, 12, True), down=(896, 8, False))      # profiles/r2_g1_launch_shape_sweep_64rows.jsonl
+    # (round 3: gate|up packed in two K halves = the copy kernel G1s streams, which now serves 64 rows; (1024, 12) was the G1 + F3 shape)
+    G1_CFG_64ROW = dict(qkv=(896, 8, True), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))       # profiles/r2_g1_launch_shape_sweep_64rows.jsonl
     # 65..128-row windows (three / four prompts per forward): the activation is sub-tiled, so KC is free again, but <= 8 waves
     G1_CFG_128ROW = dict(qkv=(896, 8, True), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))
     # Emu3-Gen 8B (GQA 32/8: the q|k|v projection has 6144 columns; draft window 32 -> 64 rows), tuned end to end with bench.py --model emu3_8b
-    G1_CFG_EMU3 = dict(qkv=(512, 8, False), o=(512, 8, False), gate_up=(1024, 16, True), down=(896, 8, False))       # profiles/r2_g1_launch_shape_sweep_emu3_64rows.jsonl
+    G1_CFG_EMU3 = dict(qkv=(512, 8, False), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))        # profiles/r2_g1_launch_shape_sweep_emu3_64rows.jsonl
 
     # Weight prefetch plan of the G1 window forward: projection -> (workgroups of the prefetch kernel, when it is issued).  The packed
     # weights of projection j+1 are read into the Infinity Cache on a side stream (a parallel branch of the forward hipGraph)
@@ -567,7 +568,7 @@ class ChameleonBackbone(nn.Module):
         into the consuming glue kernel (F2 / F1 / F3 / F1)."""
         ops, B, n = self._ops, tokens.shape[0], tokens.shape[1]
         T, eps, cfg = B * n, self.args.rms_norm_eps, self.G1_CFG
-        cap = 2560 if T <= 32 else 1280 if T <= 64 else 1 << 30     # the staged activation chunk (32 / 64 rows) must fit in LDS; 65..128 rows are sub-tiled
+        cap = 2560 if T <= 32 else 1 << 30     # the staged activation chunk of a 32-row window must fit in LDS; taller windows are sub-tiled when it does not
         if any(c[0] > cap for c in cfg.values()):
             raise ValueError(f"G1_CFG chunk sizes must be <= {cap} for a {T}-row window")
         g1 = lambda x_, name, N_, K_: ops.skinny_gemm(x_, self._packed[li][name], N_, K_, cfg[name][0], cfg[name][1], cfg[name][2])

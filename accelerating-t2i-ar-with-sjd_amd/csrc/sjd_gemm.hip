@@ -644,6 +644,164 @@ __global__ __launch_bounds__(512) void g1_gateup_silu(const unsigned short *__re
     SJD_TR(6);
 }
 
+// ---- G1s for a 64-row window (round 3): MT = 2 row tiles per weight record, staging phases and (optionally) a double-buffered arena.  The
+// 32-row kernel above is left exactly as it was (the generalised form costs it 1.5 us per launch: clamped unconditional loads, one more
+// barrier shape); same arithmetic in the same order: bit-identical to G1 + F3 like the 32-row kernel.
+template <int DT, int SP, int MT, bool DB>
+__global__ __launch_bounds__(512) void g1_gateup_silu_tall(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
+                                                      unsigned short *__restrict__ y, int M, int I, int K, int rec_stride,
+                                                      const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden, float rs_eps)
+{
+    // SP = k-steps of a staging phase per K half; (K / 32) / SP phases.  MT = 2 (round 3): a 64-row window (draft window 32 with CFG -- Emu3 --
+    // or two prompts per forward); every weight record feeds two MFMAs.
+    // DB = false: ONE arena of 2 MT phases (K = 4096: 128 KB), restaged between phases behind a stop-the-world barrier pair (the next
+    //   phase's columns have been in registers since the previous barrier).
+    // DB = true: the arena is two buffers of half-length phases; phase p + 1 is written into the other buffer while phase p is multiplied
+    //   and ONE barrier per phase publishes it.  Measured per shape (profiles/r3_g1s_64rows.txt): the extra barriers cost a 32-row window
+    //   more than the restaging stall (gate|up 33.3 -> 34.9 us, 12-bit stream 26.8 -> 28.2) and the 12-bit 64-row kernel too (two prompts
+    //   3.66 -> 3.76 ms per step), but Emu3's fp16 64-row gate|up gains 6 us per layer (4.83 -> 4.63 ms per step): the launcher picks.
+    SJD_TR(0);
+    SJD_TR_HW();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *xl = reinterpret_cast<u32x4 *>(smem);                  // [2 buffers][MT row tiles][2 K halves][SP records][64 slots] of 16 B
+    constexpr int R = 32 * MT;
+    __shared__ float rsc[R];
+    constexpr int GP = SP / 8;                                    // weight groups per phase
+    constexpr int PPS = 2 * SP;                                   // 16-byte pieces per (row, K half) of a phase
+    constexpr int NPT = (R * 2 * PPS) / 512;                      // pieces per thread and phase
+    constexpr int BUF = MT * 2 * SP * 64;                         // u32x4 per buffer
+    static_assert(SP % 8 == 0 && NPT >= 1, "phase = whole weight groups, at least one piece per thread");
+    auto bufof = [](int ph) { return DB ? (ph & 1) : 0; };
+    const int nph = (K / 32) / SP;                                // phases
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int kh = w >> 2, q = w & 3;                             // K half; 0, 1 = gate tiles, 2, 3 = the up tiles of the same columns
+    const int n_gate = I / 32, n_tiles = 2 * n_gate;
+    const int t_act = 2 * blockIdx.x + (q & 1);                   // 32-column tile of the activation
+    const int t = (q < 2 ? 0 : n_gate) + t_act;                   // tile of the packed gate|up weight
+    const int steps = K / 32;                                     // k-steps of a K half (= of a chunk of the packed weight)
+    const size_t chunk_base = (size_t)kh * n_tiles * steps;
+    const size_t tile_off = (rec_stride == 1) ? (size_t)t * steps : (size_t)t;
+    const u32x4 *wu = wp + (chunk_base + tile_off) * 64 + lane;
+    const size_t rs = (size_t)rec_stride * 64;
+    // piece v of a phase: row m = v / (2 PPS), K half hh = (v / PPS) & 1, piece j of that (row, half): 8 columns from
+    // hh * K/2 + ph * 16 SP + 8 j -> record ((m / 32) * 2 + hh) * SP + j / 2, slot g1_slot(j & 1, m % 32, j / 2)
+    auto x_load = [&](int ph, int i) -> u32x4 {
+        const int v = i * 512 + threadIdx.x;
+        const int m = v / (2 * PPS), hh = (v / PPS) & 1, j = v % PPS;
+        // (unconditional: a phase past the last one re-reads the last, a row past M reads row M - 1 -- zeroed / unused)
+        const u32x4 val = *reinterpret_cast<const u32x4 *>(x + (size_t)min(m, M - 1) * K + hh * (K / 2) + min(ph, nph - 1) * (16 * SP) + 8 * j);
+        return (m < M) ? val : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto x_store = [&](int buf, int i, u32x4 val) {
+        const int v = i * 512 + threadIdx.x;
+        const int m = v / (2 * PPS), hh = (v / PPS) & 1, j = v % PPS;
+        xl[buf * BUF + (((m >> 5) * 2 + hh) * SP + (j >> 1)) * 64 + g1_slot(j & 1, m & 31, j >> 1)] = val;
+    };
+    u32x4 cur[G1_UNROLL], nxt[G1_UNROLL], val[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) val[i] = x_load(0, i);
+    // the per-slice sums of h^2 behind the row scale r = rsqrt(mean(h^2) + eps) of the folded RMSNorm (F1r wrote them; K <= 4096: at most
+    // eight slices).  Every thread issues the eight loads -- unconditional, so the waits around them stay exact -- BEHIND the activation
+    // and ahead of the weights: they are cache hits and cost the staging nothing (first version: threads 0..31 did this first, +0.7 us).
+    float ssv[8];
+    {
+        const float *ssp = row_sumsq ? row_sumsq : reinterpret_cast<const float *>(x);
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) ssv[qq] = ssp[(size_t)(row_sumsq ? min(qq, rs_slices - 1) : 0) * R + (threadIdx.x & (R - 1))];
+    }
+#pragma unroll
+    for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);      // first weight group right behind
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) x_store(0, i, val[i]);
+    SJD_TR(1);
+    __syncthreads();
+    SJD_TR(2);
+    // the activation of the next phase is requested NOW and travels under the whole of this one
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) val[i] = x_load(1, i);
+    if (threadIdx.x < R) {
+        float tsum = 0.f;                          // sjd_glue.hip row_sumsq_total: one batch of eight in slice order, missing slices add zero
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) tsum += (qq < rs_slices) ? ssv[qq] : 0.f;
+        rsc[threadIdx.x] = row_sumsq ? rsqrtf(__builtin_fmaf(tsum, rs_inv_hidden, rs_eps)) : 1.0f;
+    }
+    SJD_TR(3);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    auto mfma_group = [&](const u32x4 *xb, int g) {
+#pragma unroll
+        for (int u = 0; u < G1_UNROLL; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = G1Mfma<DT>::mma(xb[((mt * 2 + kh) * SP + g * G1_UNROLL + u) * 64 + g1_slot(lane >> 5, lane & 31, u)], cur[u], acc[mt]);
+    };
+    const int last_group = nph * GP - 1;
+    for (int ph = 0; ph < nph; ++ph) {
+        const u32x4 *xb = xl + bufof(ph) * BUF;
+        for (int g = 0; g < GP; ++g) {
+            const int gi = ph * GP + g;                            // group of the K half; the next one is requested before this one's MFMAs
+#pragma unroll
+            for (int u = 0; u < G1_UNROLL; ++u) nxt[u] = __builtin_nontemporal_load(wu + (size_t)(min(gi + 1, last_group) * G1_UNROLL + u) * rs);
+            __builtin_amdgcn_sched_barrier(0);           // (the machine scheduler otherwise sinks the loads behind the MFMAs: requested a group late)
+            mfma_group(xb, g);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < G1_UNROLL; ++u) cur[u] = nxt[u];
+        }
+        // phase ph + 1 (in registers since the previous barrier) goes into the other buffer -- nobody reads that one any more: the barrier that
+        // published THIS phase came after everybody's last read of it -- and phase ph + 2 is requested
+        if (ph + 1 < nph) {
+            if (!DB) __syncthreads();      // (one arena: every wave is done with the staged columns before they are replaced)
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) x_store(bufof(ph + 1), i, val[i]);
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) val[i] = x_load(ph + 2, i);
+        }
+        __syncthreads();
+        if (ph == 0) SJD_TR(4);           // (trace: first phase done, second published)
+    }
+    SJD_TR(5);                    // main loop done
+    // ---- epilogue: the eight planes (tile q x K half) go through LDS (row-major, rows padded to 36 floats: conflict-free both ways), then
+    // every thread finishes FOUR outputs per row tile: one (activation tile, row, four columns) each -- first version: the two gate waves
+    // of K half 0 did all sixteen IEEE divisions per lane and 2-byte stores, 3.6 us.  (the last barrier of the loop freed the arena)
+    constexpr int RP = 36;
+    float *red = reinterpret_cast<float *>(smem);                 // [8 planes][R rows][RP]
+    {
+        float *mine = red + (size_t)(kh * 4 + q) * R * RP + (lane & 31);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * RP] = acc[mt][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MT; ++it) {
+        const int idx = it * 512 + (int)threadIdx.x;
+        const int a = idx / (8 * R), m = (idx >> 3) % R, c4 = (idx & 7) * 4;
+        auto plane = [&](int kh_, int q_) { return *reinterpret_cast<const float4 *>(red + ((size_t)(kh_ * 4 + q_) * R + m) * RP + c4); };
+        const float4 g0 = plane(0, a), g1 = plane(1, a), u0 = plane(0, 2 + a), u1 = plane(1, 2 + a);
+        const float gs[4] = {g0.x, g0.y, g0.z, g0.w}, gt[4] = {g1.x, g1.y, g1.z, g1.w};
+        const float us_[4] = {u0.x, u0.y, u0.z, u0.w}, ut[4] = {u1.x, u1.y, u1.z, u1.w};
+        const float rr = rsc[m];
+        unsigned short o16[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gsum = 0.f, usum = 0.f;                          // F3: planes summed in chunk order, starting from zero
+            gsum += gs[j]; gsum += gt[j];
+            usum += us_[j]; usum += ut[j];
+            o16[j] = sjd_silu_mul_elem<DT>(gsum, usum, rr);         // sjd_mlp_epilogue.h: the element arithmetic F3 uses, same bits
+        }
+        if (m < M) {
+            uint2 pk{(unsigned)o16[0] | ((unsigned)o16[1] << 16), (unsigned)o16[2] | ((unsigned)o16[3] << 16)};
+            *reinterpret_cast<uint2 *>(y + (size_t)m * I + 32 * (2 * blockIdx.x + a) + c4) = pk;
+        }
+    }
+    SJD_TR(6);
+}
+
 // G1s over the 12-bit weight stream (see G1z below): the same kernel, every record decoded (and its unit's exceptions patched in) in
 // front of its MFMA, the records travelling through a RING of G1Z_DEPTH registers sets that is refilled as it is consumed.
 // Bit-identical to g1_gateup_silu on the uncompressed packing of the same weight.  bf16.
@@ -808,24 +966,186 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu(const unsigned short *__r
     SJD_TR(6);
 }
 
+// ---- G1sz for a 64-row window (see g1_gateup_silu_tall)
+template <int SP, int MT, bool DB>
+__global__ __launch_bounds__(512) void g1z_gateup_silu_tall(const unsigned short *__restrict__ x, const unsigned char *__restrict__ wz,
+                                                       const u32x2 *__restrict__ exc, unsigned short *__restrict__ y, int M, int I, int K,
+                                                       int rec_stride, const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden,
+                                                       float rs_eps)
+{
+    constexpr int DT = SJD_DTYPE_BF16;
+    constexpr int D = SP >= G1Z_DEPTH ? G1Z_DEPTH : 8;           // k-steps in flight per wave, as a ring of D / 2 record pairs
+    constexpr int DP = D / 2;
+    constexpr int TL = D < 8 ? 8 : D;                             // k-steps of a loop trip (unrolled; the ring goes round TL / D times)
+    static_assert(SP % TL == 0 && TL % 8 == 0 && TL % D == 0 && D % 2 == 0, "a phase is whole trips; g1_slot(.., s) depends on s & 7");
+    SJD_TR(0);
+    SJD_TR_HW();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *xl = reinterpret_cast<u32x4 *>(smem);                  // two buffers of [MT][2 K halves][SP records][64 slots] (see g1_gateup_silu)
+    constexpr int R = 32 * MT;
+    __shared__ float rsc[R];
+    constexpr int PPS = 2 * SP;
+    constexpr int NPT = (R * 2 * PPS) / 512;
+    constexpr int BUF = MT * 2 * SP * 64;
+    static_assert(NPT >= 1, "at least one piece per thread");
+    auto bufof = [](int ph) { return DB ? (ph & 1) : 0; };
+    const int nph = (K / 32) / SP;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int kh = w >> 2, q = w & 3;
+    const int n_gate = I / 32, n_tiles = 2 * n_gate;
+    const int t_act = 2 * blockIdx.x + (q & 1);
+    const int t = (q < 2 ? 0 : n_gate) + t_act;
+    const int pairs = K / 64;                                     // record pairs of a K half (K / 32 k-steps)
+    const size_t chunk_base = (size_t)kh * n_tiles * pairs;
+    const size_t tile_off = (rec_stride == 1) ? (size_t)t * pairs : (size_t)t;
+    const unsigned rsb = (unsigned)rec_stride * 1536u;           // bytes from a pair of the unit to the next
+    const __amdgpu_buffer_rsrc_t wr = g1z_unit_rsrc(wz + (chunk_base + tile_off) * 1536, (unsigned)(pairs - 1) * rsb + 1536u);
+    auto w_load = [&](int p) -> g1z_pair { return g1z_load(wr, (unsigned)lane, (unsigned)p * rsb); };
+    auto x_load = [&](int ph, int i) -> u32x4 {
+        const int v = i * 512 + threadIdx.x;
+        const int m = v / (2 * PPS), hh = (v / PPS) & 1, j = v % PPS;
+        const u32x4 val = *reinterpret_cast<const u32x4 *>(x + (size_t)min(m, M - 1) * K + hh * (K / 2) + min(ph, nph - 1) * (16 * SP) + 8 * j);
+        return (m < M) ? val : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto x_store = [&](int buf, int i, u32x4 val) {
+        const int v = i * 512 + threadIdx.x;
+        const int m = v / (2 * PPS), hh = (v / PPS) & 1, j = v % PPS;
+        xl[buf * BUF + (((m >> 5) * 2 + hh) * SP + (j >> 1)) * 64 + g1_slot(j & 1, m & 31, j >> 1)] = val;
+    };
+    g1z_pair ring[DP];
+    u32x4 val[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) val[i] = x_load(0, i);
+    float ssv[8];
+    {
+        const float *ssp = row_sumsq ? row_sumsq : reinterpret_cast<const float *>(x);
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) ssv[qq] = ssp[(size_t)(row_sumsq ? min(qq, rs_slices - 1) : 0) * R + (threadIdx.x & (R - 1))];
+    }
+    G1Z_XFIRST_BARRIER();
+    const u32x2 hraw = exc[((size_t)kh * n_tiles + t) * 32 + (lane & 31)];
+#pragma unroll
+    for (int u = 0; u < DP; ++u) ring[u] = w_load(u);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) x_store(0, i, val[i]);
+    SJD_TR(1);
+    __syncthreads();
+    SJD_TR(2);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) val[i] = x_load(1, i);
+    if (threadIdx.x < R) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) tsum += (qq < rs_slices) ? ssv[qq] : 0.f;
+        rsc[threadIdx.x] = row_sumsq ? rsqrtf(__builtin_fmaf(tsum, rs_inv_hidden, rs_eps)) : 1.0f;
+    }
+    SJD_TR(3);
+    const g1z_hdr hd = g1z_header(hraw, lane);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    // one ring trip: k-steps s0 .. s0 + TL - 1 of the K half, staged as LDS records l0 .. of the current phase's buffer; every consumed pair is
+    // refilled with the one D k-steps further on (unconditional: exact s_waitcnt counts, D k-steps in flight through MFMAs and barriers alike)
+    auto trip = [&](const u32x4 *xb, int l0, int s0) {
+        auto a_read = [&](u32x4 (&a)[MT], int l, int u) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = xb[((mt * 2 + kh) * SP + l) * 64 + g1_slot(lane >> 5, lane & 31, u)];
+        };
+        u32x4 a0[MT], a1[MT];
+        a_read(a0, l0, 0);
+#pragma unroll
+        for (int u = 0; u < TL / 2; ++u) {
+            g1z_pair &slot = ring[u % DP];
+            a_read(a1, l0 + 2 * u + 1, 2 * u + 1);
+            const u32x4 b0 = g1z_operand(slot.lo.x, slot.lo.y, slot.c.x, (unsigned)(s0 + 2 * u), hd, lane);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(a0[mt], b0, acc[mt]);
+            if (u + 1 < TL / 2) a_read(a0, l0 + 2 * u + 2, 2 * u + 2);
+            const u32x4 b1 = g1z_operand(slot.lo.z, slot.lo.w, slot.c.y, (unsigned)(s0 + 2 * u + 1), hd, lane);
+            slot = w_load(s0 / 2 + u + DP);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(a1[mt], b1, acc[mt]);
+        }
+    };
+    for (int ph = 0; ph < nph; ++ph) {
+        const u32x4 *xb = xl + bufof(ph) * BUF;
+        for (int g = 0; g < SP / TL; ++g) trip(xb, g * TL, ph * SP + g * TL);
+        if (ph + 1 < nph) {               // the next phase replaces this one (DB: goes into the other buffer), the one after it is requested (see g1_gateup_silu)
+            if (!DB) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) x_store(bufof(ph + 1), i, val[i]);
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) val[i] = x_load(ph + 2, i);
+        }
+        __syncthreads();
+        if (ph == 0) SJD_TR(4);
+    }
+    SJD_TR(5);
+    constexpr int RP = 36;
+    float *red = reinterpret_cast<float *>(smem);
+    {
+        float *mine = red + (size_t)(kh * 4 + q) * R * RP + (lane & 31);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * RP] = acc[mt][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MT; ++it) {
+        const int idx = it * 512 + (int)threadIdx.x;
+        const int a = idx / (8 * R), m = (idx >> 3) % R, c4 = (idx & 7) * 4;
+        auto plane = [&](int kh_, int q_) { return *reinterpret_cast<const float4 *>(red + ((size_t)(kh_ * 4 + q_) * R + m) * RP + c4); };
+        const float4 g0 = plane(0, a), g1 = plane(1, a), u0 = plane(0, 2 + a), u1 = plane(1, 2 + a);
+        const float gs[4] = {g0.x, g0.y, g0.z, g0.w}, gt[4] = {g1.x, g1.y, g1.z, g1.w};
+        const float us_[4] = {u0.x, u0.y, u0.z, u0.w}, ut[4] = {u1.x, u1.y, u1.z, u1.w};
+        const float rr = rsc[m];
+        unsigned short o16[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gsum = 0.f, usum = 0.f;
+            gsum += gs[j]; gsum += gt[j];
+            usum += us_[j]; usum += ut[j];
+            o16[j] = sjd_silu_mul_elem<DT>(gsum, usum, rr);
+        }
+        if (m < M) {
+            uint2 pk{(unsigned)o16[0] | ((unsigned)o16[1] << 16), (unsigned)o16[2] | ((unsigned)o16[3] << 16)};
+            *reinterpret_cast<uint2 *>(y + (size_t)m * I + 32 * (2 * blockIdx.x + a) + c4) = pk;
+        }
+    }
+    SJD_TR(6);
+}
+
 static int g1sz_launch(const void *x, const void *wz, const void *exc, void *y, int M, int I, int K, int step_major, const sjd_row_norm *rn, hipStream_t s)
 {
-    const int SP = K / 64;
+    const int MT = M <= 32 ? 1 : 2;
+    const int SP = K / (64 * MT);                                  // one arena, 2 MT phases (double-buffered half phases measured slower: g1_gateup_silu)
     const dim3 grid(I / 64), block(512);
-    const size_t lds_x = (size_t)2 * SP * 1024, lds_red = (size_t)8 * 32 * 36 * sizeof(float);
+    const size_t lds_x = (size_t)MT * 2 * SP * 1024, lds_red = (size_t)8 * 32 * MT * 36 * sizeof(float);
     const size_t lds = lds_x > lds_red ? lds_x : lds_red;
     const int rec_stride = step_major ? 2 * (I / 32) : 1;
     const float *ss = rn ? rn->sumsq : nullptr;
     const int sl = rn ? rn->slices : 0;
     const float ih = rn ? 1.0f / (float)rn->hidden : 0.f, eps = rn ? rn->eps : 0.f;
-#define SJD_G1SZ_CASE(SP_) \
-    if (SP == SP_) { \
+#define SJD_G1SZ_CASE(SP_, MT_) \
+    if (SP == SP_ && MT == MT_) { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1z_gateup_silu_tall<SP_, MT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((g1z_gateup_silu_tall<SP_, MT_, false>), grid, block, lds, s, (const unsigned short *)x, (const unsigned char *)wz, (const u32x2 *)exc, \
+                           (unsigned short *)y, M, I, K, rec_stride, ss, sl, ih, eps); \
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH; \
+    }
+#define SJD_G1SZ_CASE32(SP_) \
+    if (SP == SP_ && MT == 1) { \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1z_gateup_silu<SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((g1z_gateup_silu<SP_>), grid, block, lds, s, (const unsigned short *)x, (const unsigned char *)wz, (const u32x2 *)exc, \
                            (unsigned short *)y, M, I, K, rec_stride, ss, sl, ih, eps); \
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH; \
     }
-    SJD_G1SZ_CASE(8) SJD_G1SZ_CASE(16) SJD_G1SZ_CASE(32) SJD_G1SZ_CASE(64)
+    SJD_G1SZ_CASE32(8) SJD_G1SZ_CASE32(16) SJD_G1SZ_CASE32(32) SJD_G1SZ_CASE32(64)
+#undef SJD_G1SZ_CASE32
+    SJD_G1SZ_CASE(8, 2) SJD_G1SZ_CASE(16, 2) SJD_G1SZ_CASE(32, 2)
 #undef SJD_G1SZ_CASE
     return SJD_ERR_UNSUPPORTED;
 }
@@ -837,42 +1157,55 @@ extern "C" int sjd_gateup_silu_z(const void *x, const void *wz, const void *exc,
     if (!x || !wz || !exc || !y || M < 1 || I < 64 || K < 512) return SJD_ERR_BAD_ARG;
     if (row_norm && (!row_norm->sumsq || row_norm->slices < 1 || row_norm->hidden < 1)) return SJD_ERR_BAD_ARG;
     if (row_norm && row_norm->slices > 8) return SJD_ERR_UNSUPPORTED;
-    if (M > 32 || (I % 64) != 0 || !(K == 512 || K == 1024 || K == 2048 || K == 4096) || dtype != SJD_DTYPE_BF16) return SJD_ERR_UNSUPPORTED;
+    if (M > 64 || (I % 64) != 0 || !(K == 512 || K == 1024 || K == 2048 || K == 4096) || (M > 32 && K == 512) || dtype != SJD_DTYPE_BF16)
+        return SJD_ERR_UNSUPPORTED;
     return g1sz_launch(x, wz, exc, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
 }
 
 template <int DT>
 static int g1s_launch(const void *x, const void *w_packed, void *y, int M, int I, int K, int step_major, const sjd_row_norm *rn, hipStream_t s)
 {
-    const int SP = K / 64;
+    const int MT = M <= 32 ? 1 : 2;
+    const bool db = MT == 2 && K >= 2048;                          // double-buffered half-length phases: the fp16 / bf16 64-row kernel (see the kernel)
+    const int SP = K / ((db ? 128 : 64) * MT);
     const dim3 grid(I / 64), block(512);
-    const size_t lds_x = (size_t)2 * SP * 1024, lds_red = (size_t)8 * 32 * 36 * sizeof(float);
-    const size_t lds = lds_x > lds_red ? lds_x : lds_red;        // the epilogue's six planes reuse the activation arena
+    const size_t lds_x = (size_t)(db ? 2 : 1) * MT * 2 * SP * 1024, lds_red = (size_t)8 * 32 * MT * 36 * sizeof(float);
+    const size_t lds = lds_x > lds_red ? lds_x : lds_red;        // the epilogue's planes reuse the activation arena
     const int rec_stride = step_major ? 2 * (I / 32) : 1;
     const float *ss = rn ? rn->sumsq : nullptr;
     const int sl = rn ? rn->slices : 0;
     const float ih = rn ? 1.0f / (float)rn->hidden : 0.f, eps = rn ? rn->eps : 0.f;
-#define SJD_G1S_CASE(SP_) \
-    if (SP == SP_) { \
+#define SJD_G1S_CASE(SP_, MT_, DB_) \
+    if (SP == SP_ && MT == MT_ && db == DB_) { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_gateup_silu_tall<DT, SP_, MT_, DB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((g1_gateup_silu_tall<DT, SP_, MT_, DB_>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, (unsigned short *)y, \
+                           M, I, K, rec_stride, ss, sl, ih, eps); \
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH; \
+    }
+#define SJD_G1S_CASE32(SP_) \
+    if (SP == SP_ && MT == 1) { \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1_gateup_silu<DT, SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((g1_gateup_silu<DT, SP_>), grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, (unsigned short *)y, \
                            M, I, K, rec_stride, ss, sl, ih, eps); \
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH; \
     }
-    SJD_G1S_CASE(8) SJD_G1S_CASE(16) SJD_G1S_CASE(32) SJD_G1S_CASE(64)
+    SJD_G1S_CASE32(8) SJD_G1S_CASE32(16) SJD_G1S_CASE32(32) SJD_G1S_CASE32(64)
+#undef SJD_G1S_CASE32
+    SJD_G1S_CASE(8, 2, false) SJD_G1S_CASE(8, 2, true) SJD_G1S_CASE(16, 2, true)
 #undef SJD_G1S_CASE
     return SJD_ERR_UNSUPPORTED;
 }
 
 // y [M, I] = silu(r * (x Wg^T)) * (r * (x Wu^T)) with F3's rounding points; w_packed = pack_weight([Wg; Wu] ([2 I, K]), KC = K / 2, step_major).
-// M <= 32 rows, K in {512, 1024, 2048, 4096}, I % 64 == 0.  SJD_ERR_UNSUPPORTED otherwise: the caller keeps G1 + F3.
+// M <= 32 rows and K in {512, 1024, 2048, 4096}, or M <= 64 rows (the sums of squares then come with 64 rows per slice) and K in {1024, 2048, 4096};
+// I % 64 == 0.  SJD_ERR_UNSUPPORTED otherwise: the caller keeps G1 + F3.
 extern "C" int sjd_gateup_silu(const void *x, const void *w_packed, void *y, int M, int I, int K, int step_major, int dtype,
                                const sjd_row_norm *row_norm, void *stream)
 {
     if (!x || !w_packed || !y || M < 1 || I < 64 || K < 512) return SJD_ERR_BAD_ARG;
     if (row_norm && (!row_norm->sumsq || row_norm->slices < 1 || row_norm->hidden < 1)) return SJD_ERR_BAD_ARG;
     if (row_norm && row_norm->slices > 8) return SJD_ERR_UNSUPPORTED;      // the kernel sums one batch of eight 512-column slices
-    if (M > 32 || (I % 64) != 0 || !(K == 512 || K == 1024 || K == 2048 || K == 4096)) return SJD_ERR_UNSUPPORTED;
+    if (M > 64 || (I % 64) != 0 || !(K == 512 || K == 1024 || K == 2048 || K == 4096) || (M > 32 && K == 512)) return SJD_ERR_UNSUPPORTED;
     if (dtype == SJD_DTYPE_BF16) return g1s_launch<SJD_DTYPE_BF16>(x, w_packed, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
     if (dtype == SJD_DTYPE_F16) return g1s_launch<SJD_DTYPE_F16>(x, w_packed, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
     return SJD_ERR_UNSUPPORTED;

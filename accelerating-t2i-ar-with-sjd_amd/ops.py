@@ -472,6 +472,9 @@ def skinny_gemm_cols(x, w_packed, N_packed, K, KC, col0, n_cols, waves=8, step_m
         assert (w_packed.KC, w_packed.step_major) == (KC, bool(step_major)) and x.dtype == torch.bfloat16
         if M > 64:
             raise ValueError(f"the 12-bit weight stream (G1z) serves windows of up to 64 rows, got {M}: pack with compress=False for more prompts per forward")
+        if M > 32 and min(KC, K) > 1280:
+            raise ValueError(f"G1z stages the whole activation chunk in LDS: a {M}-row window needs KC <= 1280, got {KC} (gate|up packed in two K halves "
+                             "is kernel G1sz's copy: keep model.gateup_fused on, or pack with compress=False)")
         L.check(L.load().sjd_skinny_gemm_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), _ptr(out), M, n_cols, K, KC, waves, int(step_major),
                                           _dtype_code(x.dtype), N_packed, col0 // 32, _stream()), "sjd_skinny_gemm_z")
         return Partials(out, nc, n_cols)
@@ -599,8 +602,9 @@ def silu_mul(gate_up, rows=None, dtype=None, row_norm=None):
 
 
 def gateup_silu_ok(T, inter, hidden, KC):
-    """shapes kernel G1s serves (see sjd_gateup_silu): a <= 32-row window, the gate|up weight packed in two K halves"""
-    return T <= 32 and hidden in (512, 1024, 2048, 4096) and 2 * KC == hidden and inter % 64 == 0
+    """shapes kernel G1s serves (see sjd_gateup_silu): a <= 32-row window -- or a <= 64-row one (draft window 32 with CFG, two prompts per
+    forward) at hidden >= 1024 --, the gate|up weight packed in two K halves"""
+    return (T <= 32 or (T <= 64 and hidden >= 1024)) and hidden in (512, 1024, 2048, 4096) and 2 * KC == hidden and inter % 64 == 0
 
 
 def gateup_silu(x, w_packed, inter, hidden, step_major=False, row_norm=None):

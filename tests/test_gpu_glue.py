@@ -207,7 +207,8 @@ def test_g1_forward_matches_library_gemm_forward(dev):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("step_major", [False, True])
-@pytest.mark.parametrize("M,I,K", [(32, 11008, 4096), (17, 11008, 4096), (32, 14336, 4096), (32, 1408, 512), (5, 128, 1024), (32, 2752, 2048)])
+@pytest.mark.parametrize("M,I,K", [(32, 11008, 4096), (17, 11008, 4096), (32, 14336, 4096), (32, 1408, 512), (5, 128, 1024), (32, 2752, 2048),
+                                   (64, 11008, 4096), (40, 14336, 4096), (64, 1408, 1024), (33, 2752, 2048)])      # 64-row windows: four staging phases
 @pytest.mark.parametrize("with_norm", [True, False])
 def test_g1_gateup_silu_matches_g1_then_f3(dev, dtype, step_major, M, I, K, with_norm):
     """G1s (the gate|up projection with SiLU * up as its epilogue, one launch) is BIT-IDENTICAL to G1 (two K halves) followed by F3 on the
@@ -292,8 +293,9 @@ def test_g1_reduce_epilogue_matches_g1_then_f1r(dev, dtype, M, N, K, KC, waves, 
 def test_g1_gateup_silu_refuses_what_it_does_not_serve(dev):
     import sjd_amd.ops as ops
     import sjd_amd._lib as L
-    assert not ops.gateup_silu_ok(33, 11008, 4096, 2048) and not ops.gateup_silu_ok(32, 11008, 4096, 1024) and not ops.gateup_silu_ok(32, 100, 4096, 2048)
-    x = torch.zeros(40, 4096, dtype=torch.bfloat16, device=dev)
+    assert not ops.gateup_silu_ok(65, 11008, 4096, 2048) and not ops.gateup_silu_ok(32, 11008, 4096, 1024) and not ops.gateup_silu_ok(32, 100, 4096, 2048)
+    assert ops.gateup_silu_ok(64, 11008, 4096, 2048) and not ops.gateup_silu_ok(40, 128, 512, 256)
+    x = torch.zeros(70, 4096, dtype=torch.bfloat16, device=dev)
     wp = torch.zeros(2 * 128 * 4096, dtype=torch.bfloat16, device=dev)
     with pytest.raises(L.SjdLibraryError):
         ops.gateup_silu(x, wp, 128, 4096)
@@ -461,7 +463,8 @@ def test_g1z_matches_g1_bit_for_bit(dev, M, N, K, KC, waves, step_major, outlier
 
 
 @pytest.mark.parametrize("step_major", [False, True])
-@pytest.mark.parametrize("M,I,K", [(32, 11008, 4096), (17, 11008, 4096), (32, 1408, 512), (5, 128, 1024), (32, 2752, 2048)])
+@pytest.mark.parametrize("M,I,K", [(32, 11008, 4096), (17, 11008, 4096), (32, 1408, 512), (5, 128, 1024), (32, 2752, 2048),
+                                   (64, 11008, 4096), (40, 1408, 1024), (64, 2752, 2048)])
 @pytest.mark.parametrize("with_norm", [True, False])
 @pytest.mark.parametrize("outliers", [0, 200])
 def test_g1sz_matches_g1s_bit_for_bit(dev, step_major, M, I, K, with_norm, outliers):

@@ -308,6 +308,9 @@ def main():
     if "--g1s" in sys.argv:
         trace_g1s(lib, torch, ops, np)
         return
+    if "--in-situ" in sys.argv:
+        trace_in_situ(lib, torch, ops, np)
+        return
     if "--g1z" in sys.argv:
         trace_g1(lib, torch, ops, np)
         trace_g1(lib, torch, ops, np, z=True)

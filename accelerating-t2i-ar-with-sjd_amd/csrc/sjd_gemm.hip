@@ -823,10 +823,23 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #ifndef G1Z_AUX
 #define G1Z_AUX 2             // cache policy of the weight loads: nt (streamed once)
 #endif
-struct g1z_hdr { unsigned base4, v_step, v_pos, v_val; };
+struct g1z_hdr { unsigned base4, v_step, v_pos, v_val, v_step2, v_pos2, v_val2; bool wide; };    // (second entry per lane: headers of 128)
+struct g1z_hraw { u32x2 a, b; };
 struct g1z_pair { u32x4 lo; u32x2 c; };          // two k-steps: {low bytes 0..3, 4..7} x 2, {codes} x 2
-__device__ __forceinline__ u32x4 g1z_operand(unsigned lo0, unsigned lo1, unsigned c, unsigned s, const g1z_hdr &hd, int lane);
-__device__ __forceinline__ g1z_hdr g1z_header(u32x2 e, int lane);
+template <bool WIDE> __device__ __forceinline__ u32x4 g1z_operand(unsigned lo0, unsigned lo1, unsigned c, unsigned s, const g1z_hdr &hd, int lane);
+template <bool WIDE> __device__ __forceinline__ g1z_hdr g1z_header(g1z_hraw e, int lane, int cap);
+// the header of unit `unit`: cap = 32 / 64 / 128 entries of 8 bytes; lane l takes entry min(l, cap - 1) and, in a header of 128, entry 64 + l
+// (WIDE = a header of 128: a template parameter -- the second register set and its compare per k-step cost the common case 0.4 us per launch
+// when they were a run-time switch)
+template <bool WIDE>
+__device__ __forceinline__ g1z_hraw g1z_header_load(const u32x2 *__restrict__ exc, size_t unit, int lane, int cap)
+{
+    g1z_hraw h;
+    const u32x2 *e = exc + unit * (size_t)cap;
+    h.a = e[min(lane, cap - 1)];
+    if constexpr (WIDE) h.b = e[64 + lane]; else h.b = h.a;
+    return h;
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t g1z_unit_rsrc(const unsigned char *first_record, unsigned bytes);
 __device__ __forceinline__ g1z_pair g1z_load(__amdgpu_buffer_rsrc_t wr, unsigned lane, unsigned soff)
 {
@@ -836,12 +849,13 @@ __device__ __forceinline__ g1z_pair g1z_load(__amdgpu_buffer_rsrc_t wr, unsigned
     return v;
 }
 
-template <int SP>
+template <int SP, bool WIDE>
 __global__ __launch_bounds__(512) void g1z_gateup_silu(const unsigned short *__restrict__ x, const unsigned char *__restrict__ wz,
                                                        const u32x2 *__restrict__ exc, unsigned short *__restrict__ y, int M, int I, int K,
-                                                       int rec_stride, const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden,
+                                                       int stride_cap, const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden,
                                                        float rs_eps)
 {
+    const int rec_stride = stride_cap & 0xffff, exc_cap = stride_cap >> 16;      // (one dword: see g1z_skinny_gemm)
     constexpr int DT = SJD_DTYPE_BF16;
     constexpr int D = SP >= G1Z_DEPTH ? G1Z_DEPTH : 8;           // k-steps in flight per wave, as a ring of D / 2 record pairs
     constexpr int DP = D / 2;
@@ -887,7 +901,7 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu(const unsigned short *__r
         for (int qq = 0; qq < 8; ++qq) ssv[qq] = ssp[(size_t)(row_sumsq ? min(qq, rs_slices - 1) : 0) * 32 + (threadIdx.x & 31)];
     }
     G1Z_XFIRST_BARRIER();
-    const u32x2 hraw = exc[((size_t)kh * n_tiles + t) * 32 + (lane & 31)];
+    const g1z_hraw hraw = g1z_header_load<WIDE>(exc, (size_t)kh * n_tiles + t, lane, exc_cap);
 #pragma unroll
     for (int u = 0; u < DP; ++u) ring[u] = w_load(u);
 #pragma unroll
@@ -904,7 +918,7 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu(const unsigned short *__r
         rsc[threadIdx.x] = row_sumsq ? rsqrtf(__builtin_fmaf(tsum, rs_inv_hidden, rs_eps)) : 1.0f;
     }
     SJD_TR(3);
-    const g1z_hdr hd = g1z_header(hraw, lane);
+    const g1z_hdr hd = g1z_header<WIDE>(hraw, lane, exc_cap);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -918,10 +932,10 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu(const unsigned short *__r
         for (int u = 0; u < TL / 2; ++u) {
             g1z_pair &slot = ring[u % DP];
             a[1] = xa[(l0 + 2 * u + 1) * 64 + g1_slot(lane >> 5, lane & 31, 2 * u + 1)];
-            const u32x4 b0 = g1z_operand(slot.lo.x, slot.lo.y, slot.c.x, (unsigned)(s0 + 2 * u), hd, lane);
+            const u32x4 b0 = g1z_operand<WIDE>(slot.lo.x, slot.lo.y, slot.c.x, (unsigned)(s0 + 2 * u), hd, lane);
             acc = G1Mfma<DT>::mma(a[0], b0, acc);
             if (u + 1 < TL / 2) a[0] = xa[(l0 + 2 * u + 2) * 64 + g1_slot(lane >> 5, lane & 31, 2 * u + 2)];
-            const u32x4 b1 = g1z_operand(slot.lo.z, slot.lo.w, slot.c.y, (unsigned)(s0 + 2 * u + 1), hd, lane);
+            const u32x4 b1 = g1z_operand<WIDE>(slot.lo.z, slot.lo.w, slot.c.y, (unsigned)(s0 + 2 * u + 1), hd, lane);
             slot = w_load(s0 / 2 + u + DP);
             acc = G1Mfma<DT>::mma(a[1], b1, acc);
         }
@@ -967,12 +981,13 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu(const unsigned short *__r
 }
 
 // ---- G1sz for a 64-row window (see g1_gateup_silu_tall)
-template <int SP, int MT, bool DB>
+template <int SP, int MT, bool DB, bool WIDE>
 __global__ __launch_bounds__(512) void g1z_gateup_silu_tall(const unsigned short *__restrict__ x, const unsigned char *__restrict__ wz,
                                                        const u32x2 *__restrict__ exc, unsigned short *__restrict__ y, int M, int I, int K,
-                                                       int rec_stride, const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden,
+                                                       int stride_cap, const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden,
                                                        float rs_eps)
 {
+    const int rec_stride = stride_cap & 0xffff, exc_cap = stride_cap >> 16;      // (one dword: see g1z_skinny_gemm)
     constexpr int DT = SJD_DTYPE_BF16;
     constexpr int D = SP >= G1Z_DEPTH ? G1Z_DEPTH : 8;           // k-steps in flight per wave, as a ring of D / 2 record pairs
     constexpr int DP = D / 2;
@@ -1023,7 +1038,7 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu_tall(const unsigned short
         for (int qq = 0; qq < 8; ++qq) ssv[qq] = ssp[(size_t)(row_sumsq ? min(qq, rs_slices - 1) : 0) * R + (threadIdx.x & (R - 1))];
     }
     G1Z_XFIRST_BARRIER();
-    const u32x2 hraw = exc[((size_t)kh * n_tiles + t) * 32 + (lane & 31)];
+    const g1z_hraw hraw = g1z_header_load<WIDE>(exc, (size_t)kh * n_tiles + t, lane, exc_cap);
 #pragma unroll
     for (int u = 0; u < DP; ++u) ring[u] = w_load(u);
 #pragma unroll
@@ -1040,7 +1055,7 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu_tall(const unsigned short
         rsc[threadIdx.x] = row_sumsq ? rsqrtf(__builtin_fmaf(tsum, rs_inv_hidden, rs_eps)) : 1.0f;
     }
     SJD_TR(3);
-    const g1z_hdr hd = g1z_header(hraw, lane);
+    const g1z_hdr hd = g1z_header<WIDE>(hraw, lane, exc_cap);
     f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1059,11 +1074,11 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu_tall(const unsigned short
         for (int u = 0; u < TL / 2; ++u) {
             g1z_pair &slot = ring[u % DP];
             a_read(a1, l0 + 2 * u + 1, 2 * u + 1);
-            const u32x4 b0 = g1z_operand(slot.lo.x, slot.lo.y, slot.c.x, (unsigned)(s0 + 2 * u), hd, lane);
+            const u32x4 b0 = g1z_operand<WIDE>(slot.lo.x, slot.lo.y, slot.c.x, (unsigned)(s0 + 2 * u), hd, lane);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(a0[mt], b0, acc[mt]);
             if (u + 1 < TL / 2) a_read(a0, l0 + 2 * u + 2, 2 * u + 2);
-            const u32x4 b1 = g1z_operand(slot.lo.z, slot.lo.w, slot.c.y, (unsigned)(s0 + 2 * u + 1), hd, lane);
+            const u32x4 b1 = g1z_operand<WIDE>(slot.lo.z, slot.lo.w, slot.c.y, (unsigned)(s0 + 2 * u + 1), hd, lane);
             slot = w_load(s0 / 2 + u + DP);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(a1[mt], b1, acc[mt]);
@@ -1118,7 +1133,8 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu_tall(const unsigned short
     SJD_TR(6);
 }
 
-static int g1sz_launch(const void *x, const void *wz, const void *exc, void *y, int M, int I, int K, int step_major, const sjd_row_norm *rn, hipStream_t s)
+static int g1sz_launch(const void *x, const void *wz, const void *exc, int exc_cap, void *y, int M, int I, int K, int step_major, const sjd_row_norm *rn,
+                       hipStream_t s)
 {
     const int MT = M <= 32 ? 1 : 2;
     const int SP = K / (64 * MT);                                  // one arena, 2 MT phases (double-buffered half phases measured slower: g1_gateup_silu)
@@ -1129,37 +1145,41 @@ static int g1sz_launch(const void *x, const void *wz, const void *exc, void *y, 
     const float *ss = rn ? rn->sumsq : nullptr;
     const int sl = rn ? rn->slices : 0;
     const float ih = rn ? 1.0f / (float)rn->hidden : 0.f, eps = rn ? rn->eps : 0.f;
-#define SJD_G1SZ_CASE(SP_, MT_) \
-    if (SP == SP_ && MT == MT_) { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1z_gateup_silu_tall<SP_, MT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((g1z_gateup_silu_tall<SP_, MT_, false>), grid, block, lds, s, (const unsigned short *)x, (const unsigned char *)wz, (const u32x2 *)exc, \
-                           (unsigned short *)y, M, I, K, rec_stride, ss, sl, ih, eps); \
+#define SJD_G1SZ_CASE(SP_, MT_) SJD_G1SZ_CASE_W(SP_, MT_, false) SJD_G1SZ_CASE_W(SP_, MT_, true)
+#define SJD_G1SZ_CASE_W(SP_, MT_, W_) \
+    if (SP == SP_ && MT == MT_ && (exc_cap > 64) == W_) { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1z_gateup_silu_tall<SP_, MT_, false, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((g1z_gateup_silu_tall<SP_, MT_, false, W_>), grid, block, lds, s, (const unsigned short *)x, (const unsigned char *)wz, (const u32x2 *)exc, \
+                           (unsigned short *)y, M, I, K, rec_stride | (exc_cap << 16), ss, sl, ih, eps); \
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH; \
     }
-#define SJD_G1SZ_CASE32(SP_) \
-    if (SP == SP_ && MT == 1) { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1z_gateup_silu<SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((g1z_gateup_silu<SP_>), grid, block, lds, s, (const unsigned short *)x, (const unsigned char *)wz, (const u32x2 *)exc, \
-                           (unsigned short *)y, M, I, K, rec_stride, ss, sl, ih, eps); \
+#define SJD_G1SZ_CASE32(SP_) SJD_G1SZ_CASE32_W(SP_, false) SJD_G1SZ_CASE32_W(SP_, true)
+#define SJD_G1SZ_CASE32_W(SP_, W_) \
+    if (SP == SP_ && MT == 1 && (exc_cap > 64) == W_) { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1z_gateup_silu<SP_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((g1z_gateup_silu<SP_, W_>), grid, block, lds, s, (const unsigned short *)x, (const unsigned char *)wz, (const u32x2 *)exc, \
+                           (unsigned short *)y, M, I, K, rec_stride | (exc_cap << 16), ss, sl, ih, eps); \
         return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH; \
     }
     SJD_G1SZ_CASE32(8) SJD_G1SZ_CASE32(16) SJD_G1SZ_CASE32(32) SJD_G1SZ_CASE32(64)
 #undef SJD_G1SZ_CASE32
+#undef SJD_G1SZ_CASE32_W
     SJD_G1SZ_CASE(8, 2) SJD_G1SZ_CASE(16, 2) SJD_G1SZ_CASE(32, 2)
 #undef SJD_G1SZ_CASE
+#undef SJD_G1SZ_CASE_W
     return SJD_ERR_UNSUPPORTED;
 }
 
 // sjd_gateup_silu over ops.pack_weight_z([Wg; Wu], K / 2, step_major): same result, bit for bit; bf16 only.
-extern "C" int sjd_gateup_silu_z(const void *x, const void *wz, const void *exc, void *y, int M, int I, int K, int step_major, int dtype,
+extern "C" int sjd_gateup_silu_z(const void *x, const void *wz, const void *exc, int exc_cap, void *y, int M, int I, int K, int step_major, int dtype,
                                  const sjd_row_norm *row_norm, void *stream)
 {
-    if (!x || !wz || !exc || !y || M < 1 || I < 64 || K < 512) return SJD_ERR_BAD_ARG;
+    if (!x || !wz || !exc || !y || M < 1 || I < 64 || K < 512 || !(exc_cap == 32 || exc_cap == 64 || exc_cap == 128)) return SJD_ERR_BAD_ARG;
     if (row_norm && (!row_norm->sumsq || row_norm->slices < 1 || row_norm->hidden < 1)) return SJD_ERR_BAD_ARG;
     if (row_norm && row_norm->slices > 8) return SJD_ERR_UNSUPPORTED;
     if (M > 64 || (I % 64) != 0 || !(K == 512 || K == 1024 || K == 2048 || K == 4096) || (M > 32 && K == 512) || dtype != SJD_DTYPE_BF16)
         return SJD_ERR_UNSUPPORTED;
-    return g1sz_launch(x, wz, exc, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
+    return g1sz_launch(x, wz, exc, exc_cap, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
 }
 
 template <int DT>
@@ -1227,7 +1247,8 @@ extern "C" int sjd_gateup_silu(const void *x, const void *w_packed, void *y, int
 //       64 lanes x  8 B {codes of k-step 2p, of k-step 2p + 1: byte i = code(w_i) | code(w_{i+4}) << 4}
 //     -- both parts naturally aligned 16- / 8-byte loads (12-byte lane records as ONE dwordx3 load measured slower: a lane's bytes
 //     straddle cache lines, profiles/r3_g1z_microbench.jsonl)
-//   header (256 B) = 32 x {pos, val}: entry 0 = {base, count}; entry i >= 1 = {k-step << 9 | lane << 3 | element, the weight's 16 bits}
+//   header (cap x 8 B, cap = 32 / 64 / 128 per matrix) = {pos, val}: entry 0 = {base, count}; entry i >= 1 = {k-step << 9 | lane << 3 | element,
+//       the weight's 16 bits}; unused entries 0xffffffff.  A lane keeps entry `lane` (and entry 64 + lane of a 128-entry header) in registers.
 // Decoding is 12 VALU instructions per record and wave (the kernel is at ~6 % MFMA-busy, the VALU idle); exceptions cost a wave-uniform
 // compare per k-step and two selects on the ~10 % of k-steps that have one.  A record is ONE 12-byte buffer load per lane;
 // a wave keeps a ring of G1Z_DEPTH records in flight (first version, two register groups of eight like G1: 6 KiB per wave in flight, the
@@ -1243,25 +1264,27 @@ __device__ __forceinline__ void g1z_high(unsigned c, unsigned base4, unsigned &h
 // The MFMA B operand of k-step s from its 12 bytes {low bytes 0..3, low bytes 4..7, codes}: decode the high bytes, patch the
 // unit's exceptions of this k-step into them (an exception differs from its coded form only in the HIGH byte -- the low byte travels
 // verbatim; wave-uniform control flow, two selects per exception), interleave.  v_step = pos >> 9 of this lane's entry.
+template <bool WIDE>
 __device__ __forceinline__ u32x4 g1z_operand(unsigned lo0, unsigned lo1, unsigned c, unsigned s, const g1z_hdr &hd, int lane)
 {
     unsigned hA, hB;
     g1z_high(c, hd.base4, hA, hB);
-#ifdef G1Z_NO_PATCH           // (timing experiments only: the results are wrong wherever a unit has an exception)
-    unsigned long long mk = 0;
-#else
-    unsigned long long mk = __ballot(hd.v_step == s);
+    auto patch = [&](unsigned long long mk, unsigned v_pos, unsigned v_val) {
+        while (mk) {
+            const int i = __builtin_ctzll(mk);
+            mk &= mk - 1;
+            const unsigned pos = __builtin_amdgcn_readlane(v_pos, i), hi = (__builtin_amdgcn_readlane(v_val, i) >> 8) & 0xffu;
+            const int tl = (int)((pos >> 3) & 63u);
+            const unsigned sh = (pos & 3u) * 8u, keep = ~(0xffu << sh), put = hi << sh;
+            const bool me = lane == tl, upper = (pos & 4u) != 0u;
+            hA = (me && !upper) ? ((hA & keep) | put) : hA;
+            hB = (me && upper) ? ((hB & keep) | put) : hB;
+        }
+    };
+#ifndef G1Z_NO_PATCH          // (G1Z_NO_PATCH: timing experiments only -- the results are wrong wherever a unit has an exception)
+    patch(__ballot(hd.v_step == s), hd.v_pos, hd.v_val);
+    if constexpr (WIDE) patch(__ballot(hd.v_step2 == s), hd.v_pos2, hd.v_val2);
 #endif
-    while (mk) {
-        const int i = __builtin_ctzll(mk);
-        mk &= mk - 1;
-        const unsigned pos = __builtin_amdgcn_readlane(hd.v_pos, i), hi = (__builtin_amdgcn_readlane(hd.v_val, i) >> 8) & 0xffu;
-        const int tl = (int)((pos >> 3) & 63u);
-        const unsigned sh = (pos & 3u) * 8u, keep = ~(0xffu << sh), put = hi << sh;
-        const bool me = lane == tl, upper = (pos & 4u) != 0u;
-        hA = (me && !upper) ? ((hA & keep) | put) : hA;
-        hB = (me && upper) ? ((hB & keep) | put) : hB;
-    }
     u32x4 d;
     d.x = __builtin_amdgcn_perm(hA, lo0, 0x05010400u);       // {lo.b0, hA.b0, lo.b1, hA.b1}
     d.y = __builtin_amdgcn_perm(hA, lo0, 0x07030602u);
@@ -1272,14 +1295,19 @@ __device__ __forceinline__ u32x4 g1z_operand(unsigned lo0, unsigned lo1, unsigne
 
 // the header of unit (chunk, tile): every lane gets entry (lane & 31); returns base * 0x01010101 and leaves this lane's exception in
 // (v_step, v_pos, v_val) -- lanes 0 (base / count) and 32..63 (duplicates) hold none
-__device__ __forceinline__ g1z_hdr g1z_header(u32x2 e, int lane)
+template <bool WIDE>
+__device__ __forceinline__ g1z_hdr g1z_header(g1z_hraw e, int lane, int cap)
 {
     g1z_hdr h;
-    h.base4 = (unsigned)__builtin_amdgcn_readfirstlane((int)e.x) * 0x01010101u;
-    const bool live = lane >= 1 && lane < 32;
-    h.v_pos = e.x;
-    h.v_val = e.y;
-    h.v_step = live ? (e.x >> 9) : 0xffffffffu;
+    h.base4 = (unsigned)__builtin_amdgcn_readfirstlane((int)e.a.x) * 0x01010101u;
+    const bool live = lane >= 1 && lane < min(cap, 64);          // (lane 0: base / count; lanes past a short header: duplicates)
+    h.v_pos = e.a.x;
+    h.v_val = e.a.y;
+    h.v_step = live ? (e.a.x >> 9) : 0xffffffffu;
+    h.wide = WIDE;
+    h.v_pos2 = e.b.x;
+    h.v_val2 = e.b.y;
+    h.v_step2 = WIDE ? (e.b.x >> 9) : 0xffffffffu;                // (unused entries hold 0xffffffff: their k-step never matches)
     return h;
 }
 
@@ -1292,11 +1320,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t g1z_unit_rsrc(const unsigned c
     return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 
-template <int MT, int MAXT>
+template <int MT, int MAXT, bool WIDE>
 __global__ __launch_bounds__(MAXT) void g1z_skinny_gemm(const unsigned short *__restrict__ x, const unsigned char *__restrict__ wz,
                                                         const u32x2 *__restrict__ exc, float *__restrict__ out, int M, int N, int K, int KC,
-                                                        int n_tiles, int rec_stride, int tile0, int n_waves)
+                                                        int n_tiles, int rec_stride, int tile0, int waves_cap)
 {
+    // (the header capacity rides in the high half of the wave count: a 17th argument dword would not be preloaded into SGPRs and the kernel
+    // would open with a scalar load round trip for it -- +0.04 ms per step when it was an argument of its own)
+    const int n_waves = waves_cap & 0xffff, exc_cap = waves_cap >> 16;
     constexpr int DT = SJD_DTYPE_BF16;
     constexpr int D = MAXT <= 512 ? G1Z_DEPTH : (G1Z_DEPTH < 8 ? G1Z_DEPTH : 8);      // k-steps in flight per wave, as a ring of D / 2 record pairs (128 VGPRs at 9..16 waves)
     constexpr int DP = D / 2;
@@ -1333,14 +1364,14 @@ __global__ __launch_bounds__(MAXT) void g1z_skinny_gemm(const unsigned short *__
         const int s = j >> 1;
         if (m < 32 * MT) xl[((m >> 5) * steps + s) * 64 + g1_slot(j & 1, m & 31, s)] = val;
     };
-    u32x2 hraw;
+    g1z_hraw hraw;
     {   // first activation batch, the unit's header and the first D records right behind it (all unconditional, see g1_skinny_gemm)
         u32x4 val[STAGE];
         int m = pm, j = pj;
 #pragma unroll
         for (int i = 0; i < STAGE; ++i) { val[i] = x_load(m, j); advance(m, j); }
         G1Z_XFIRST_BARRIER();
-        hraw = exc[((size_t)chunk * n_tiles + (has_tile ? t : 0)) * 32 + (lane & 31)];
+        hraw = g1z_header_load<WIDE>(exc, (size_t)chunk * n_tiles + (has_tile ? t : 0), lane, exc_cap);
 #pragma unroll
         for (int u = 0; u < DP; ++u) ring[u] = w_load(u);
         m = pm; j = pj;
@@ -1362,7 +1393,7 @@ __global__ __launch_bounds__(MAXT) void g1z_skinny_gemm(const unsigned short *__
     __syncthreads();
     SJD_TR(2);
     if (!has_tile) return;
-    const g1z_hdr hd = g1z_header(hraw, lane);
+    const g1z_hdr hd = g1z_header<WIDE>(hraw, lane, exc_cap);
     SJD_TR(3);
     f32x16 acc[MT];
 #pragma unroll
@@ -1387,14 +1418,14 @@ __global__ __launch_bounds__(MAXT) void g1z_skinny_gemm(const unsigned short *__
             g1z_pair &slot = ring[u % DP];
             if (sa < steps) {
                 a_read(a1, sb, 2 * u + 1);
-                const u32x4 b0 = g1z_operand(slot.lo.x, slot.lo.y, slot.c.x, (unsigned)sa, hd, lane);
+                const u32x4 b0 = g1z_operand<WIDE>(slot.lo.x, slot.lo.y, slot.c.x, (unsigned)sa, hd, lane);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(a0[mt], b0, acc[mt]);
             }
             u32x4 b1 = {0u, 0u, 0u, 0u};
             if (sb < steps) {
                 if (u + 1 < TL / 2) a_read(a0, sb + 1, 2 * u + 2);
-                b1 = g1z_operand(slot.lo.z, slot.lo.w, slot.c.y, (unsigned)sb, hd, lane);
+                b1 = g1z_operand<WIDE>(slot.lo.z, slot.lo.w, slot.c.y, (unsigned)sb, hd, lane);
             }
             slot = w_load(s0 / 2 + u + DP);
             if (sb < steps) {
@@ -1421,9 +1452,10 @@ __global__ __launch_bounds__(MAXT) void g1z_skinny_gemm(const unsigned short *__
 
 // x [M <= 64, K] bf16, wz / exc = ops.pack_weight_z(W [N_packed, K], KC, step_major) -> out fp32 [n_chunks, 32 * ceil(M / 32), N] for the N
 // columns from 32 * tile0: what sjd_skinny_gemm_cols writes from the uncompressed packing of the same weight, bit for bit.
-extern "C" int sjd_skinny_gemm_z(const void *x, const void *wz, const void *exc, float *out, int M, int N, int K, int KC, int waves,
+extern "C" int sjd_skinny_gemm_z(const void *x, const void *wz, const void *exc, int exc_cap, float *out, int M, int N, int K, int KC, int waves,
                                  int step_major, int dtype, int N_packed, int tile0, void *stream)
 {
+    if (!(exc_cap == 32 || exc_cap == 64 || exc_cap == 128)) return SJD_ERR_BAD_ARG;
     if (!x || !wz || !exc || !out || M < 1 || N < 32 || (N % 32) != 0 || (N_packed % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0)
         return SJD_ERR_BAD_ARG;
     if (waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;
@@ -1436,13 +1468,15 @@ extern "C" int sjd_skinny_gemm_z(const void *x, const void *wz, const void *exc,
     const dim3 grid((n_out + waves - 1) / waves, n_chunks), block(waves * 64);
     hipStream_t s = (hipStream_t)stream;
     const int rs = step_major ? n_tiles : 1;
-#define SJD_G1Z_LAUNCH(MT_, MAXT_) do { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1z_skinny_gemm<MT_, MAXT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((g1z_skinny_gemm<MT_, MAXT_>), grid, block, lds, s, (const unsigned short *)x, (const unsigned char *)wz, \
-                           (const u32x2 *)exc, out, M, N, K, KC, n_tiles, rs, tile0, waves); } while (0)
+#define SJD_G1Z_LAUNCH_W(MT_, MAXT_, W_) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1z_skinny_gemm<MT_, MAXT_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((g1z_skinny_gemm<MT_, MAXT_, W_>), grid, block, lds, s, (const unsigned short *)x, (const unsigned char *)wz, \
+                           (const u32x2 *)exc, out, M, N, K, KC, n_tiles, rs, tile0, waves | (exc_cap << 16)); } while (0)
+#define SJD_G1Z_LAUNCH(MT_, MAXT_) do { if (exc_cap > 64) SJD_G1Z_LAUNCH_W(MT_, MAXT_, true); else SJD_G1Z_LAUNCH_W(MT_, MAXT_, false); } while (0)
     if (MT == 1) { if (waves <= 8) SJD_G1Z_LAUNCH(1, 512); else SJD_G1Z_LAUNCH(1, 1024); }
     else { if (waves <= 8) SJD_G1Z_LAUNCH(2, 512); else SJD_G1Z_LAUNCH(2, 1024); }
 #undef SJD_G1Z_LAUNCH
+#undef SJD_G1Z_LAUNCH_W
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 

@@ -318,6 +318,7 @@ class PackedZ:
 
     def __init__(self, data, exc, N, K, KC, step_major, n_exceptions):
         self.data, self.exc, self.N, self.K, self.KC, self.step_major, self.n_exceptions = data, exc, N, K, KC, bool(step_major), int(n_exceptions)
+        self.cap = int(exc.shape[2])
 
     def numel(self):
         return self.N * self.K
@@ -326,12 +327,14 @@ class PackedZ:
         return self.data.numel() + self.exc.numel() * 4
 
 
-Z_MAX_EXC = 31          # exceptions a (k-chunk, 32-column tile) unit can carry in its 256-byte header
+Z_MAX_EXC = 127         # exceptions a (k-chunk, 32-column tile) unit can carry: headers of 32 / 64 / 128 entries, chosen per matrix
 
 
 def pack_weight_z(weight, KC, step_major=False):
     """[N, K] bf16 weight -> PackedZ, the LOSSLESS 12-bit form of pack_weight(weight, KC, step_major) that sjd_skinny_gemm_z / sjd_gateup_silu_z
-    stream (include/sjd_hip.h), or None when the weight does not fit the format (not bf16, KC > 4096, or a unit with more than 31 exceptions).
+    stream (include/sjd_hip.h), or None when the weight does not fit the format (not bf16, KC > 4096, or a unit with more than 127 exceptions).
+    The header of a unit has 32 entries (31 exceptions: Gaussian weights need 3-13) or, for the whole matrix, 64 / 128 when some unit needs
+    them (heavy-tailed weights, norm gains folded into the columns: 10-30 per 16 k-weight unit).
     Per unit (k-chunk c, tile t) the window of eight consecutive values of the weights' 7 high exponent bits that covers most of the unit is
     chosen from the unit's histogram (robust against outliers on either side); a weight inside it is stored as low byte + code
     (sign << 3 | offset), one outside it additionally verbatim as an exception."""
@@ -341,7 +344,7 @@ def pack_weight_z(weight, KC, step_major=False):
     assert N % 32 == 0 and K % 16 == 0 and KC % 16 == 0
     T, dev = N // 32, weight.device
     bits = weight.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
-    datas, hdrs, total = [], [], 0
+    datas, hdrs, total, max_cnt = [], [], 0, 0
     for k0 in range(0, K, KC):
         kc = min(KC, K - k0)
         S = kc // 16
@@ -356,6 +359,7 @@ def pack_weight_z(weight, KC, step_major=False):
         cnt = bad.reshape(T, -1).sum(dim=1)
         if int(cnt.max()) > Z_MAX_EXC:
             return None
+        max_cnt = max(max_cnt, int(cnt.max()))
         code = ((b >> 15) << 3) | e3.clamp(0, 7)                             # [t, r, s, h, j]
         lo = b & 0xFF
         lo0 = lo[..., 0] | (lo[..., 1] << 8) | (lo[..., 2] << 16) | (lo[..., 3] << 24)        # int32 wrap-around is the bit pattern wanted
@@ -375,7 +379,7 @@ def pack_weight_z(weight, KC, step_major=False):
         if step_major:
             rec = rec.permute(1, 0, 2)
         datas.append(rec.reshape(-1))
-        hdr = torch.full((T, 32, 2), -1, dtype=torch.int32, device=dev)
+        hdr = torch.full((T, Z_MAX_EXC + 1, 2), -1, dtype=torch.int32, device=dev)       # (cut to the matrix's capacity below)
         hdr[:, 0, 0] = base
         hdr[:, 0, 1] = cnt.to(torch.int32)
         idx = bad.nonzero()                                                  # rows sorted by t first
@@ -388,7 +392,8 @@ def pack_weight_z(weight, KC, step_major=False):
             total += idx.shape[0]
         hdrs.append(hdr)
     data = torch.cat(datas).contiguous().view(torch.uint8)
-    return PackedZ(data, torch.stack(hdrs).contiguous(), N, K, KC, step_major, total)
+    cap = 32 if max_cnt <= 31 else 64 if max_cnt <= 63 else 128
+    return PackedZ(data, torch.stack(hdrs)[:, :, :cap].contiguous(), N, K, KC, step_major, total)
 
 
 def _prows(M):
@@ -475,7 +480,7 @@ def skinny_gemm_cols(x, w_packed, N_packed, K, KC, col0, n_cols, waves=8, step_m
         if M > 32 and min(KC, K) > 1280:
             raise ValueError(f"G1z stages the whole activation chunk in LDS: a {M}-row window needs KC <= 1280, got {KC} (gate|up packed in two K halves "
                              "is kernel G1sz's copy: keep model.gateup_fused on, or pack with compress=False)")
-        L.check(L.load().sjd_skinny_gemm_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), _ptr(out), M, n_cols, K, KC, waves, int(step_major),
+        L.check(L.load().sjd_skinny_gemm_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), w_packed.cap, _ptr(out), M, n_cols, K, KC, waves, int(step_major),
                                           _dtype_code(x.dtype), N_packed, col0 // 32, _stream()), "sjd_skinny_gemm_z")
         return Partials(out, nc, n_cols)
     L.check(L.load().sjd_skinny_gemm_cols(_ptr(x), _ptr(w_packed), _ptr(out), M, n_cols, K, KC, waves, int(step_major), _dtype_code(x.dtype),
@@ -615,7 +620,7 @@ def gateup_silu(x, w_packed, inter, hidden, step_major=False, row_norm=None):
     y = torch.empty(T, inter, dtype=x.dtype, device=x.device)
     if isinstance(w_packed, PackedZ):
         assert (w_packed.KC, w_packed.step_major) == (hidden // 2, bool(step_major)) and x.dtype == torch.bfloat16
-        L.check(L.load().sjd_gateup_silu_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), _ptr(y), T, inter, hidden, int(step_major),
+        L.check(L.load().sjd_gateup_silu_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), w_packed.cap, _ptr(y), T, inter, hidden, int(step_major),
                                           _dtype_code(x.dtype), _row_norm(row_norm), _stream()), "sjd_gateup_silu_z")
         return y
     L.check(L.load().sjd_gateup_silu(_ptr(x), _ptr(w_packed), _ptr(y), T, inter, hidden, int(step_major), _dtype_code(x.dtype),

@@ -294,15 +294,16 @@ int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int 
 /* G1z / G1sz -- sjd_skinny_gemm_cols / sjd_gateup_silu over a LOSSLESS 12-bit re-encoding of the packed bf16 weight (sjd_amd.ops.pack_weight_z):
  * every weight travels as its low byte (exponent lsb + mantissa) plus a 4-bit code of its high byte -- (sign, offset 0..7 from the base of its
  * (k-chunk, 32-column tile) unit) -- in 768-byte records instead of 1-KiB ones; weights outside the unit's 16-binade window ("exceptions", ~1e-4
- * of a Gaussian or trained matrix, at most 31 per unit or the packer declines) travel verbatim in `exc` (256 bytes per unit: {base, count}, then
- * {k-step << 9 | lane << 3 | element, 16 bits}) and are patched into the MFMA operand registers.  The operands, the accumulation order and the
+ * of a Gaussian matrix, a few 1e-4 of a heavy-tailed one) travel verbatim in `exc` (exc_cap = 32 / 64 / 128 entries of 8 bytes per unit, chosen
+ * per matrix by the packer, which declines a matrix that needs more than 127 in some unit: {base, count}, then {k-step << 9 | lane << 3 | element,
+ * 16 bits}) and are patched into the MFMA operand registers.  The operands, the accumulation order and the
  * result are BIT-IDENTICAL to the uncompressed kernels on the same weight: no change of precision, 25 % fewer bytes through the fabric that
- * bounds the window forward.  bf16 only (SJD_ERR_UNSUPPORTED otherwise), M <= 64 (sjd_skinny_gemm_z) / M <= 32 (sjd_gateup_silu_z), KC <= 4096.
+ * bounds the window forward.  bf16 only (SJD_ERR_UNSUPPORTED otherwise), M <= 64, KC <= 4096.
  * replaces, like G1 / G1s: the nn.Linear calls of the decoder layer (reference modeling_chameleon.py:527-529, 579, 193-195) and lm_head
  * (modeling_chameleon.py:1560-1561) for the window forward. */
-int sjd_skinny_gemm_z(const void *x, const void *wz, const void *exc, float *out, int M, int N, int K, int KC, int waves, int step_major,
+int sjd_skinny_gemm_z(const void *x, const void *wz, const void *exc, int exc_cap, float *out, int M, int N, int K, int KC, int waves, int step_major,
                       int dtype, int N_packed, int tile0, void *stream);
-int sjd_gateup_silu_z(const void *x, const void *wz, const void *exc, void *y, int M, int I, int K, int step_major, int dtype,
+int sjd_gateup_silu_z(const void *x, const void *wz, const void *exc, int exc_cap, void *y, int M, int I, int K, int step_major, int dtype,
                       const sjd_row_norm *row_norm, void *stream);
 
 /* Weight prefetch for G1: reads `nbytes` of packed weights with plain loads and discards them, so that the lines sit in the 256 MiB

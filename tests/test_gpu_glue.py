@@ -492,7 +492,32 @@ def test_g1z_refuses_what_it_does_not_serve(dev):
     lib = L.load()
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), p(out), 8, 64, 256, 128, 2, 0, 1, 64, 0, s) != 0          # fp16
-    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), p(out), 96, 64, 256, 128, 2, 0, 0, 64, 0, s) != 0         # > 64 rows
-    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), None, p(out), 8, 64, 256, 128, 2, 0, 0, 64, 0, s) != 0               # no header table
-    assert lib.sjd_gateup_silu_z(p(x16), p(wz.data), p(wz.exc), p(out), 8, 64, 512, 0, 1, None, s) != 0                   # fp16
+    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), 32, p(out), 8, 64, 256, 128, 2, 0, 1, 64, 0, s) != 0      # fp16
+    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), 32, p(out), 96, 64, 256, 128, 2, 0, 0, 64, 0, s) != 0     # > 64 rows
+    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), None, 32, p(out), 8, 64, 256, 128, 2, 0, 0, 64, 0, s) != 0           # no header table
+    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), 48, p(out), 8, 64, 256, 128, 2, 0, 0, 64, 0, s) != 0      # header capacity
+    assert lib.sjd_gateup_silu_z(p(x16), p(wz.data), p(wz.exc), 32, p(out), 8, 64, 512, 0, 1, None, s) != 0               # fp16
+
+
+@pytest.mark.parametrize("M,N,K,KC,waves,step_major", [(32, 4096, 4096, 1024, 6, True), (64, 2048, 2752, 1024, 8, False), (32, 1024, 4096, 2048, 8, True)])
+def test_g1z_wide_exception_headers(dev, M, N, K, KC, waves, step_major):
+    """heavy-tailed weights (Student-t, 2 degrees of freedom: 50-100 out-of-window weights per unit) make the packer choose headers of 64 or
+    128 entries -- a lane then patches from two register sets -- and the planes still equal G1's bit for bit; the same for G1sz"""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    torch.manual_seed(N + K)
+    w = (torch.distributions.StudentT(2.0).sample((N, K)) * 0.015).to(torch.bfloat16).to(dev)
+    wp, wz = ops.pack_weight(w, KC, step_major), ops.pack_weight_z(w, KC, step_major)
+    assert wz is not None and wz.cap in (64, 128), wz and wz.cap
+    ref = ops.skinny_gemm(x, wp, N, K, KC, waves, step_major).data
+    got = ops.skinny_gemm(x, wz, N, K, KC, waves, step_major).data
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int32), ref.view(torch.int32))
+    if K == 4096 and N % 128 == 0:
+        wp2, wz2 = ops.pack_weight(w, K // 2, step_major), ops.pack_weight_z(w, K // 2, step_major)
+        assert wz2 is not None and wz2.cap in (64, 128)
+        a = ops.gateup_silu(x, wp2, N // 2, K, step_major)
+        b = ops.gateup_silu(x, wz2, N // 2, K, step_major)
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))

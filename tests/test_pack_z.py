@@ -13,7 +13,7 @@ def decode_z(pz):
     N, K, KC = pz.N, pz.K, pz.KC
     T = N // 32
     data = pz.data.cpu().numpy().view(np.uint32)
-    exc = pz.exc.cpu().numpy().view(np.uint32)                   # [n_chunks, T, 32, 2]
+    exc = pz.exc.cpu().numpy().view(np.uint32)                   # [n_chunks, T, cap, 2], cap = 32 / 64 / 128
     out, off = [], 0
     for c, k0 in enumerate(range(0, K, KC)):
         S = min(KC, K - k0) // 16
@@ -31,7 +31,7 @@ def decode_z(pz):
         for j in range(4):
             w16[..., j] = ((lo[..., 0] >> (8 * j)) & 0xFF) | (((hA >> (8 * j)) & 0xFF) << 8)
             w16[..., 4 + j] = ((lo[..., 1] >> (8 * j)) & 0xFF) | (((hB >> (8 * j)) & 0xFF) << 8)
-        for t in range(T):                                       # exceptions: entries 1..31 of the unit's header
+        for t in range(T):                                       # exceptions: entries 1 .. cap - 1 of the unit's header
             n = int(exc[c, t, 0, 1])
             for i in range(1, 1 + n):
                 pos, val = int(exc[c, t, i, 0]), int(exc[c, t, i, 1])
@@ -81,8 +81,23 @@ def test_z_packer_declines_what_does_not_fit():
     pz = ops.pack_weight_z(w2, 128)                                                # no: the unit's window moves to exponent 0 -- still lossless
     assert pz is not None and np.array_equal(decode_z(pz), raw_stream(w2, 128, False))
     w3 = w.clone()
-    w3[0, :64] = torch.logspace(-30, 30, 64).to(torch.bfloat16)                    # 64 weights spread over 200 binades in one unit
-    assert ops.pack_weight_z(w3, 128) is None
+    w3[0, :64] = torch.logspace(-30, 30, 64).to(torch.bfloat16)                    # 64 weights spread over 200 binades in one unit: a header of 64
+    pz3 = ops.pack_weight_z(w3, 128)
+    assert pz3 is not None and pz3.cap == 64 and np.array_equal(decode_z(pz3), raw_stream(w3, 128, False))
+    w4 = w.clone()
+    w4[:8, :32] = torch.logspace(-30, 30, 256).reshape(8, 32).to(torch.bfloat16)   # 256 of them: more than any header holds
+    assert ops.pack_weight_z(w4, 128) is None
+
+
+def test_z_header_capacity_follows_the_weights():
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(64, 2048, generator=g) * 0.02).to(torch.bfloat16)
+    assert ops.pack_weight_z(w, 1024).cap == 32
+    torch.manual_seed(5)
+    heavy = (torch.distributions.StudentT(2.0).sample((64, 2048)) * 0.015).to(torch.bfloat16)      # very heavy tails: 50-90 exceptions per unit
+    for KC, cap in ((1024, 64), (2048, 128)):
+        pz = ops.pack_weight_z(heavy, KC)
+        assert pz is not None and pz.cap == cap and np.array_equal(decode_z(pz), raw_stream(heavy, KC, False))
 
 
 def test_z_window_follows_the_bulk_not_the_outlier():

@@ -126,7 +126,7 @@ def trace_g1(lib, torch, ops, np, z=False):
         def g1(i):
             if z:
                 L.check(lib.sjd_skinny_gemm_z(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % 6].data.data_ptr()), ctypes.c_void_p(wps[i % 6].exc.data_ptr()),
-                                              ctypes.c_void_p(out.data_ptr()), 32, N, K, KC, waves, int(sm), 0, N, 0,
+                                              wps[i % 6].cap, ctypes.c_void_p(out.data_ptr()), 32, N, K, KC, waves, int(sm), 0, N, 0,
                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "g1z")
                 return
             L.check(lib.sjd_skinny_gemm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wps[i % 6].data_ptr()), ctypes.c_void_p(out.data_ptr()),

@@ -422,8 +422,7 @@ class ChameleonBackbone(nn.Module):
         weights); other shapes (prefill) keep hipBLASLt.  `ops` is sjd_amd.ops (raises if libsjd_hip.so is missing).
         compress (default: on for bf16 weights, SJD_G1Z=0 switches it off): the packed copy is kept in the LOSSLESS 12-bit stream format of
         kernels G1z / G1sz (ops.pack_weight_z: 25 % fewer bytes through the fabric that bounds the window forward, bit-identical results);
-        a matrix that does not fit the format (fp16, or a unit with too many out-of-window weights) stays uncompressed.  Windows of more
-        than 64 rows (three / four prompts per forward) need compress=False."""
+        a matrix that does not fit the format (fp16, or a unit with too many out-of-window weights) stays uncompressed."""
         self._ops = ops
         self._gemm = gemm
         self._fold_norm = bool(fold_norm) and gemm == "sjd"

@@ -1450,6 +1450,129 @@ __global__ __launch_bounds__(MAXT) void g1z_skinny_gemm(const unsigned short *__
 #endif
 }
 
+// ---- G1z for windows of 65..128 rows (three / four prompts per forward) and for 64-row windows whose K chunk does not fit in LDS: the
+// sub-tiled kernel (see g1_skinny_gemm_tiled) over the 12-bit stream.  A sub-tile is 16 k-steps = two groups of four record pairs held in
+// two register sets A and B that alternate without copies; the group after next is requested before the MFMAs of the current one; every
+// load is unconditional (pairs past the unit's end read as zero through the buffer descriptor, activation pieces are clamped and zeroed),
+// the k-steps past a ragged chunk's end are skipped by uniform branches -- ONE loop body for full, last and partial sub-tiles.  With MT
+// MFMAs per record the decode (12 VALU) runs under them.  Same MFMA sequence per (tile, chunk) as G1: bit-identical planes.
+template <int MT, bool WIDE>
+__global__ __launch_bounds__(512) void g1z_skinny_gemm_tiled(const unsigned short *__restrict__ x, const unsigned char *__restrict__ wz,
+                                                             const u32x2 *__restrict__ exc, float *__restrict__ out, int M, int N, int K, int KC,
+                                                             int n_tiles, int rec_stride, int tile0, int waves_cap)
+{
+    constexpr int DT = SJD_DTYPE_BF16;
+    const int n_waves = waves_cap & 0xffff, exc_cap = waves_cap >> 16;
+    SJD_TR(0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *xl = reinterpret_cast<u32x4 *>(smem);                 // two buffers of MT * G1_SUB records
+    const int chunk = blockIdx.y;
+    const int k0 = chunk * KC;
+    const int steps = min(KC, K - k0) / 16;
+    const int pairs = (steps + 1) / 2, pairs_full = (KC / 16 + 1) / 2;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int t_out = blockIdx.x * n_waves + w;
+    const bool has_tile = t_out < N / 32;                        // a wave without a tile streams nothing (its descriptor is empty) and stores nothing
+    const int t = tile0 + (has_tile ? t_out : 0);
+    const size_t chunk_base = (size_t)chunk * n_tiles * pairs_full;
+    const size_t tile_off = (rec_stride == 1) ? (size_t)t * pairs : (size_t)t;
+    const unsigned rsb = (unsigned)rec_stride * 1536u;
+    const __amdgpu_buffer_rsrc_t wr = g1z_unit_rsrc(wz + (chunk_base + tile_off) * 1536, has_tile ? (unsigned)(pairs - 1) * rsb + 1536u : 0u);
+    const int nth = n_waves * 64;
+    constexpr int BUF = MT * G1_SUB * 64;                         // u32x4 per LDS buffer
+    constexpr int PPR = 2 * G1_SUB;                               // 16-byte pieces per row of a sub-tile
+    constexpr int NP = MT * 32 * PPR;                             // pieces per sub-tile
+    constexpr int NV = NP / 512;                                  // pieces per thread at 512 threads (2 MT)
+    const int n_sub = (steps + G1_SUB - 1) / G1_SUB;
+    const int k_end = k0 + steps * 16;
+    g1z_pair A[4], B[4];
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    auto x_load = [&](int st, int v) -> u32x4 {
+        const int m = v / PPR, j = v - m * PPR, col = k0 + st * (16 * G1_SUB) + 8 * j;
+        const u32x4 val = *reinterpret_cast<const u32x4 *>(x + (size_t)min(m, M - 1) * K + min(col, K - 8));
+        return (m < M && col < k_end) ? val : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto x_store = [&](int buf, int v, u32x4 val) {
+        const int m = v / PPR, j = v - m * PPR, sl = j >> 1;
+        xl[buf * BUF + ((m >> 5) * G1_SUB + sl) * 64 + g1_slot(j & 1, m & 31, sl)] = val;
+    };
+    auto w_load = [&](g1z_pair (&W)[4], int g) {                  // group g of the chunk = pairs 4 g .. 4 g + 3
+#pragma unroll
+        for (int u = 0; u < 4; ++u) W[u] = g1z_load(wr, (unsigned)lane, (unsigned)(4 * g + u) * rsb);
+    };
+    auto stage = [&](int st_next, int buf, u32x4 (&val)[NV], bool load) {
+        if (load) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) val[i] = x_load(st_next, min(threadIdx.x + i * nth, NP - 1));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (threadIdx.x + i * nth < NP) x_store(buf, threadIdx.x + i * nth, val[i]);
+            for (int v = threadIdx.x + NV * nth; v < NP; v += nth) x_store(buf, v, x_load(st_next, v));      // fewer than 8 waves
+        }
+    };
+    g1z_hraw hraw;
+    {
+        u32x4 val[NV];
+        stage(0, 0, val, true);
+        hraw = g1z_header_load<WIDE>(exc, (size_t)chunk * n_tiles + t, lane, exc_cap);
+        w_load(A, 0);
+        stage(0, 0, val, false);
+    }
+    __syncthreads();
+    SJD_TR(1);
+    const g1z_hdr hd = g1z_header<WIDE>(hraw, lane, exc_cap);
+    // eight k-steps from LDS records sl0 .. of the current buffer against the four pairs of W; s0 = the group's first k-step in the chunk
+    auto group = [&](const u32x4 *xb, int sl0, const g1z_pair (&W)[4], int s0) {
+        u32x4 a[2][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[0][mt] = xb[(mt * G1_SUB + sl0) * 64 + g1_slot(lane >> 5, lane & 31, 0)];
+#pragma unroll
+        for (int u = 0; u < G1_UNROLL; ++u) {
+            if (u + 1 < G1_UNROLL) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[(u + 1) & 1][mt] = xb[(mt * G1_SUB + sl0 + u + 1) * 64 + g1_slot(lane >> 5, lane & 31, u + 1)];
+            }
+            if (s0 + u < steps) {
+                const g1z_pair &pr = W[u >> 1];
+                const u32x4 b = (u & 1) ? g1z_operand<WIDE>(pr.lo.z, pr.lo.w, pr.c.y, (unsigned)(s0 + u), hd, lane)
+                                        : g1z_operand<WIDE>(pr.lo.x, pr.lo.y, pr.c.x, (unsigned)(s0 + u), hd, lane);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(a[u & 1][mt], b, acc[mt]);
+            }
+        }
+    };
+    for (int st = 0; st < n_sub; ++st) {
+        const u32x4 *xb = xl + (st & 1) * BUF;
+        u32x4 val[NV];
+        stage(st + 1, (st + 1) & 1, val, true);               // (past the last sub-tile: clamped loads of zeros nobody reads)
+        w_load(B, 2 * st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        group(xb, 0, A, st * G1_SUB);
+        __builtin_amdgcn_sched_barrier(0);
+        w_load(A, 2 * st + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        group(xb, G1_UNROLL, B, st * G1_SUB + G1_UNROLL);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(st + 1, (st + 1) & 1, val, false);
+        __syncthreads();
+    }
+    SJD_TR(3);
+    if (!has_tile) return;
+    float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t_out * 32 + (lane & 31);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            o[(size_t)m * N] = acc[mt][r];
+        }
+}
+
 // x [M <= 64, K] bf16, wz / exc = ops.pack_weight_z(W [N_packed, K], KC, step_major) -> out fp32 [n_chunks, 32 * ceil(M / 32), N] for the N
 // columns from 32 * tile0: what sjd_skinny_gemm_cols writes from the uncompressed packing of the same weight, bit for bit.
 extern "C" int sjd_skinny_gemm_z(const void *x, const void *wz, const void *exc, int exc_cap, float *out, int M, int N, int K, int KC, int waves,
@@ -1459,15 +1582,26 @@ extern "C" int sjd_skinny_gemm_z(const void *x, const void *wz, const void *exc,
     if (!x || !wz || !exc || !out || M < 1 || N < 32 || (N % 32) != 0 || (N_packed % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0)
         return SJD_ERR_BAD_ARG;
     if (waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;
-    if (dtype != SJD_DTYPE_BF16 || M > 64 || KC > 4096) return SJD_ERR_UNSUPPORTED;       // (the k-step of an exception is 7 + 1 bits of its position)
+    if (dtype != SJD_DTYPE_BF16 || M > 128 || KC > 4096) return SJD_ERR_UNSUPPORTED;      // (the k-step of an exception is 7 + 1 bits of its position)
     const int n_out = N / 32, n_tiles = N_packed / 32, n_chunks = (K + KC - 1) / KC;
     if (tile0 < 0 || tile0 + n_out > n_tiles) return SJD_ERR_BAD_ARG;
-    const int MT = M <= 32 ? 1 : 2;
+    const int MT = (M + 31) / 32;
     const size_t lds = (size_t)MT * ((KC < K ? KC : K) / 16) * 1024;
-    if (lds > 160 * 1024) return SJD_ERR_BAD_ARG;
     const dim3 grid((n_out + waves - 1) / waves, n_chunks), block(waves * 64);
     hipStream_t s = (hipStream_t)stream;
     const int rs = step_major ? n_tiles : 1;
+    if (MT > 2 || lds > 160 * 1024) {             // sub-tiled activation (65..128 rows, or a 64-row window with a tall K chunk): <= 8 waves
+        if (waves > 8) return SJD_ERR_BAD_ARG;
+        const size_t lds_t = (size_t)2 * MT * G1_SUB * 1024;
+#define SJD_G1ZT(MT_, W_) do { \
+            (void)hipFuncSetAttribute((const void *)g1z_skinny_gemm_tiled<MT_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t); \
+            hipLaunchKernelGGL((g1z_skinny_gemm_tiled<MT_, W_>), grid, block, lds_t, s, (const unsigned short *)x, (const unsigned char *)wz, \
+                               (const u32x2 *)exc, out, M, N, K, KC, n_tiles, rs, tile0, waves | (exc_cap << 16)); } while (0)
+        if (exc_cap > 64) { if (MT == 2) SJD_G1ZT(2, true); else if (MT == 3) SJD_G1ZT(3, true); else if (MT == 4) SJD_G1ZT(4, true); else return SJD_ERR_UNSUPPORTED; }
+        else { if (MT == 2) SJD_G1ZT(2, false); else if (MT == 3) SJD_G1ZT(3, false); else if (MT == 4) SJD_G1ZT(4, false); else return SJD_ERR_UNSUPPORTED; }
+#undef SJD_G1ZT
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+    }
 #define SJD_G1Z_LAUNCH_W(MT_, MAXT_, W_) do { \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)g1z_skinny_gemm<MT_, MAXT_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((g1z_skinny_gemm<MT_, MAXT_, W_>), grid, block, lds, s, (const unsigned short *)x, (const unsigned char *)wz, \

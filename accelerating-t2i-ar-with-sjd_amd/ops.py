@@ -475,11 +475,8 @@ def skinny_gemm_cols(x, w_packed, N_packed, K, KC, col0, n_cols, waves=8, step_m
     out = torch.empty(nc, _prows(M), n_cols, dtype=torch.float32, device=x.device)
     if isinstance(w_packed, PackedZ):
         assert (w_packed.KC, w_packed.step_major) == (KC, bool(step_major)) and x.dtype == torch.bfloat16
-        if M > 64:
-            raise ValueError(f"the 12-bit weight stream (G1z) serves windows of up to 64 rows, got {M}: pack with compress=False for more prompts per forward")
-        if M > 32 and min(KC, K) > 1280:
-            raise ValueError(f"G1z stages the whole activation chunk in LDS: a {M}-row window needs KC <= 1280, got {KC} (gate|up packed in two K halves "
-                             "is kernel G1sz's copy: keep model.gateup_fused on, or pack with compress=False)")
+        if M > 128 or ((M > 64 or (M > 32 and min(KC, K) > 1280)) and waves > 8):
+            raise ValueError(f"G1z: a {M}-row window with K chunks of {KC} runs on the sub-tiled kernel (up to 128 rows, at most 8 waves), got waves={waves}")
         L.check(L.load().sjd_skinny_gemm_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), w_packed.cap, _ptr(out), M, n_cols, K, KC, waves, int(step_major),
                                           _dtype_code(x.dtype), N_packed, col0 // 32, _stream()), "sjd_skinny_gemm_z")
         return Partials(out, nc, n_cols)

@@ -67,6 +67,7 @@ def parse(argv=None):
     ap.add_argument("--gemm", default="sjd", choices=["sjd", "torch"], help="window projections: G1 weight-streaming kernel or hipBLASLt")
     ap.add_argument("--tunableop", action="store_true", help="enable PyTorch TunableOp GEMM selection")
     ap.add_argument("--no-fold-norm", action="store_true", help="keep F1 (RMSNorm before the projection) instead of the folded-norm forward")
+    ap.add_argument("--compress", action="store_true", help="keep the 12-bit weight stream for three / four prompts per forward too")
     ap.add_argument("--no-compress", action="store_true", help="stream the packed bf16 weights uncompressed (G1 / G1s) instead of the lossless "
                     "12-bit stream (G1z / G1sz); results are bit-identical either way")
     ap.add_argument("--no-fused", action="store_true", help="plain ATen element-wise glue instead of the fused F1-F3 kernels")
@@ -118,9 +119,10 @@ def build_model(args, device):
         model.G1_CFG = dict(model.G1_CFG, **{k: (int(v[0]), int(v[1]), bool(v[2])) for k, v in over.items()})
     synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=args.embed_token_scale)
     if not args.no_fused:
-        # (the 12-bit stream serves windows of up to 64 rows: three / four prompts per forward keep the uncompressed packing)
+        # (three / four prompts per forward run on the sub-tiled kernel, which is bound by its staging barriers, not by HBM: the 12-bit stream
+        # serves it -- g1z_skinny_gemm_tiled, bit-identical -- but measured 1-2 % slower there, profiles/r3_g1z_microbench.txt; --compress forces it)
         model.enable_fused(ops, gemm=args.gemm, fold_norm=not args.no_fold_norm,
-                           compress=False if (args.no_compress or args.prompts_per_gpu > 2) else None)
+                           compress=False if (args.no_compress or (args.prompts_per_gpu > 2 and not args.compress)) else None)
     return model, margs, attn
 
 

@@ -296,7 +296,7 @@ def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=
     conf = dict(vocab_size=V, hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
                 num_key_value_heads=4, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
     model = make_chameleon(conf, 23, embed_token_scale, ops.HipWindowAttention(n_split=2), dtype=dtype, device=device)
-    model.enable_fused(ops, gemm=gemm, compress=None if (n_slots or n_prompts) <= 2 else False)      # (the 12-bit weight stream serves <= 64 window rows)
+    model.enable_fused(ops, gemm=gemm)
     n_img = (2 * wg + 1) * 2 * hg
     prompts, specs = [], []
     for i in range(n_prompts):
@@ -515,7 +515,7 @@ def teacher_forced_real_shape_batch_check(device="cuda:0", n_prompts=4, prompt_l
         model = BB.ChameleonBackbone(margs, attn=ops.HipWindowAttention()).to(torch.bfloat16).eval()
     model.G1_CFG = dict(model.G1_CFG_64ROW if n_prompts == 2 else model.G1_CFG_128ROW)
     synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=0.7)
-    model.enable_fused(ops, gemm="sjd", compress=None if n_prompts <= 2 else False)
+    model.enable_fused(ops, gemm="sjd")
     V = margs.vocab_size
     prompts = [lumina_prompt(prompt_lens[i % len(prompt_lens)], grid, grid, seed=seed + i) for i in range(n_prompts)]
     specs = [lumina_window_spec(p_, dev) for p_ in prompts]

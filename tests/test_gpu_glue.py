@@ -427,7 +427,10 @@ def _z_weight(N, K, gen, dev, outliers):
     (32, 22016, 4096, 2048, 8, True),      # gate|up as plain G1z (128 k-steps per unit)
     (17, 4096, 11008, 896, 8, False), (64, 4096, 4096, 512, 8, False), (40, 12288, 4096, 896, 8, True),
     (32, 8224, 4096, 1024, 4, True), (5, 512, 1024, 256, 4, True), (32, 1024, 528, 128, 2, False), (64, 2048, 2752, 512, 11, True),
-    (32, 96, 48, 16, 3, False)])
+    (32, 96, 48, 16, 3, False),
+    # the sub-tiled kernel: 65..128 rows (three / four prompts per forward), and a 64-row window whose K chunk does not fit in LDS
+    (128, 4096, 11008, 896, 8, False), (96, 12288, 4096, 896, 8, True), (128, 22016, 4096, 2048, 8, True), (100, 512, 1376, 256, 3, True),
+    (64, 4096, 4096, 2048, 8, True), (128, 8224, 4096, 1024, 4, True), (70, 1024, 528, 128, 6, False)])
 @pytest.mark.parametrize("outliers", [0, 300])
 def test_g1z_matches_g1_bit_for_bit(dev, M, N, K, KC, waves, step_major, outliers):
     """G1z (the projection over the 12-bit lossless weight stream) writes the SAME split-K planes as G1 over the uncompressed packing of the
@@ -493,7 +496,8 @@ def test_g1z_refuses_what_it_does_not_serve(dev):
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), 32, p(out), 8, 64, 256, 128, 2, 0, 1, 64, 0, s) != 0      # fp16
-    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), 32, p(out), 96, 64, 256, 128, 2, 0, 0, 64, 0, s) != 0     # > 64 rows
+    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), 32, p(out), 129, 64, 256, 128, 2, 0, 0, 64, 0, s) != 0    # > 128 rows
+    assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), 32, p(out), 96, 64, 256, 128, 12, 0, 0, 64, 0, s) != 0    # sub-tiled kernel: <= 8 waves
     assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), None, 32, p(out), 8, 64, 256, 128, 2, 0, 0, 64, 0, s) != 0           # no header table
     assert lib.sjd_skinny_gemm_z(p(x16), p(wz.data), p(wz.exc), 48, p(out), 8, 64, 256, 128, 2, 0, 0, 64, 0, s) != 0      # header capacity
     assert lib.sjd_gateup_silu_z(p(x16), p(wz.data), p(wz.exc), 32, p(out), 8, 64, 512, 0, 1, None, s) != 0               # fp16

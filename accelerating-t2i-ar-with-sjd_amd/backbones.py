@@ -429,8 +429,13 @@ class ChameleonBackbone(nn.Module):
         if compress is None:
             compress = _os.environ.get("SJD_G1Z", "1") != "0"
         self.compress = bool(compress) and gemm == "sjd"
-        if self.compress and "G1_CFG" not in self.__dict__ and self.lm_head.weight.dtype == torch.bfloat16:
-            self.G1_CFG = dict(self.G1_CFG_Z)
+        if "G1_CFG" not in self.__dict__:      # the caller has not chosen launch shapes: take the tuned set of the architecture
+            if self.n_kv_heads != self.n_heads:
+                self.G1_CFG = dict(self.G1_CFG_EMU3)
+            elif self.compress and self.lm_head.weight.dtype == torch.bfloat16:
+                self.G1_CFG = dict(self.G1_CFG_Z)
+        if "HEAD_CFG" not in self.__dict__ and self.vocab_size >= 131072:
+            self.HEAD_CFG = self.HEAD_CFG_WIDE
         self.compress_stats = dict(matrices=0, compressed=0, bytes_raw=0, bytes_packed=0, exceptions=0)
 
         def pack(w, kc, sm):
@@ -485,6 +490,9 @@ class ChameleonBackbone(nn.Module):
         return self
 
     HEAD_CFG = (1024, 4, True)         # G1 launch shape of the output head: (split-K chunk, column tiles per workgroup, step-major)
+    # vocabularies whose image window is tens of thousands of columns (Emu3: 32768 of 184622): two K chunks, so that K2 sums two planes per
+    # column instead of four, eight tiles per workgroup; Emu3 4.65 -> 4.62 ms per step (bench.py, SJD_HEAD_CFG sweep, one box)
+    HEAD_CFG_WIDE = (2048, 8, True)
     supports_head_partials = True
 
     def _head_partials(self, h, delta, cols, n, sumsq=None):

@@ -114,6 +114,9 @@ def build_model(args, device):
         model.G1_CFG = dict(model.G1_CFG_64ROW if args.prompts_per_gpu == 2 else model.G1_CFG_128ROW)
     if args.model == "emu3_8b":      # 64-row windows (draft window 32) need activation chunks <= 1280 columns
         model.G1_CFG = dict(model.G1_CFG_EMU3)
+    if os.environ.get("SJD_HEAD_CFG"):     # tuning aid: JSON [KC, waves, step_major] of the output head's G1 launch
+        h = json.loads(os.environ["SJD_HEAD_CFG"])
+        model.HEAD_CFG = (int(h[0]), int(h[1]), bool(h[2]))
     if os.environ.get("SJD_G1_CFG"):       # tuning aid: JSON {"o": [KC, waves, step_major], ...} overriding the per-projection launch shapes
         over = json.loads(os.environ["SJD_G1_CFG"])
         model.G1_CFG = dict(model.G1_CFG, **{k: (int(v[0]), int(v[1]), bool(v[2])) for k, v in over.items()})

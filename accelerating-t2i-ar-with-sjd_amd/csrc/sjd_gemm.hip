@@ -1237,22 +1237,23 @@ extern "C" int sjd_gateup_silu(const void *x, const void *w_packed, void *y, int
 // high exponent bits) takes very few values inside one (k-chunk, 32-column tile) unit: a trained or Gaussian-initialised matrix puts all
 // but ~1e-4 of a unit's weights into 16 consecutive binades.  G1z streams every weight as its LOW BYTE (exponent lsb + mantissa, verbatim)
 // plus a 4-BIT CODE of the high byte -- (sign, offset 0..7 from a per-unit base) -- i.e. 12 bits per weight, 768-byte records instead of
-// 1-KiB ones; the few weights outside the unit's window ("exceptions") travel verbatim in a 256-byte header per unit and are patched into
-// the operand registers before the MFMA.  The B operand a wave feeds its MFMA is BIT-IDENTICAL to the uncompressed kernel's, so are the
+// 1-KiB ones; the few weights outside the unit's window ("exceptions") travel verbatim in a header per unit (256 bytes = 31 exceptions, or 512 /
+// 1024 bytes = 63 / 127 where a matrix needs them: heavy-tailed weights, folded norm gains) and are patched into the operand registers
+// before the MFMA.  The B operand a wave feeds its MFMA is BIT-IDENTICAL to the uncompressed kernel's, so are the
 // accumulation order and the result (tests/test_gpu_glue.py::test_g1z_*): this is a lossless re-encoding of the weight stream, not a
-// change of precision.  A matrix some unit of which has more than 31 exceptions is simply left uncompressed by the packer
+// change of precision.  A matrix some unit of which has more than 127 exceptions is simply left uncompressed by the packer
 // (ops.pack_weight_z returns None).  bf16 only: fp16's high byte (sign, 5 exponent bits, 2 mantissa bits) does not concentrate.
 //   record PAIR (1536 B, k-steps 2p and 2p + 1 of a unit; an odd last k-step is padded with zeros) =
 //       64 lanes x 16 B {low bytes of weights 0..3, 4..7 of k-step 2p; the same of k-step 2p + 1}, then
 //       64 lanes x  8 B {codes of k-step 2p, of k-step 2p + 1: byte i = code(w_i) | code(w_{i+4}) << 4}
 //     -- both parts naturally aligned 16- / 8-byte loads (12-byte lane records as ONE dwordx3 load measured slower: a lane's bytes
-//     straddle cache lines, profiles/r3_g1z_microbench.jsonl)
+//     straddle cache lines, profiles/r3_g1z_microbench.txt)
 //   header (cap x 8 B, cap = 32 / 64 / 128 per matrix) = {pos, val}: entry 0 = {base, count}; entry i >= 1 = {k-step << 9 | lane << 3 | element,
 //       the weight's 16 bits}; unused entries 0xffffffff.  A lane keeps entry `lane` (and entry 64 + lane of a 128-entry header) in registers.
 // Decoding is 12 VALU instructions per record and wave (the kernel is at ~6 % MFMA-busy, the VALU idle); exceptions cost a wave-uniform
-// compare per k-step and two selects on the ~10 % of k-steps that have one.  A record is ONE 12-byte buffer load per lane;
-// a wave keeps a ring of G1Z_DEPTH records in flight (first version, two register groups of eight like G1: 6 KiB per wave in flight, the
-// decode on the critical path between two round trips -- 16.6 us for q|k|v against G1's 19.9; o slower than G1).
+// compare per k-step and two selects on the ~10 % of k-steps that have one.  A wave keeps a ring of G1Z_DEPTH k-steps (record pairs) in
+// flight through ONE buffer descriptor over its unit and refills a slot right after consuming it (first version, two register groups of
+// eight like G1: the decode sat on the critical path between two round trips -- o slower than G1).
 // high bytes of a record's eight weights from its code word: hA = weights 0..3, hB = weights 4..7 (byte i = sign << 7 | base + offset)
 __device__ __forceinline__ void g1z_high(unsigned c, unsigned base4, unsigned &hA, unsigned &hB)
 {

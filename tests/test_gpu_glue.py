@@ -410,7 +410,7 @@ def test_16bit_window_forward_error_against_fp32_forward(dev, dtype):
 def _z_weight(N, K, gen, dev, outliers):
     """bf16 weight with a few values far outside the 16-binade window of their unit (exceptions: patched into the operand registers)"""
     w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(torch.bfloat16)
-    outliers = min(outliers, N * K // 4096)            # (a unit carries at most 31 exceptions)
+    outliers = min(outliers, N * K // 4096)            # (keep toy shapes inside the 32-entry header)
     if outliers:
         idx_n = torch.randint(0, N, (outliers,), generator=gen)
         idx_k = torch.randint(0, K, (outliers,), generator=gen)

@@ -223,6 +223,37 @@ __device__ float block_kth_largest(const float *row, int lo, int V, int k, float
     return key2f(prefix);
 }
 
+// the same over values a thread holds in registers: z[i][j] = the thread's j-th column of its i-th owned group (-inf where the window or the
+// rule excludes the column: never > floor_excl).  Same keys into the same histograms as block_kth_largest over the staged row.
+template <int NI>
+__device__ __forceinline__ float block_kth_largest_regs(const float (&z)[NI][4], int k, float floor_excl, SjdShared &sh)
+{
+    unsigned prefix = 0;
+    int krem = k;
+    const int shifts[3] = {21, 10, 0};
+    const unsigned masks[3] = {0x7ffu, 0x7ffu, 0x3ffu};
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int b = threadIdx.x; b < SJD_RADIX_BINS; b += SJD_TPB) sh.hist[b] = 0;
+        __syncthreads();
+        const int shift = shifts[pass];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = z[i][j];
+                if (v > floor_excl) {
+                    const unsigned key = f2key(v);
+                    const bool match = (pass == 0) || ((key >> (shift + (pass == 1 ? 11 : 10))) == prefix);
+                    if (match) atomicAdd(&sh.hist[(key >> shift) & masks[pass]], 1u);
+                }
+            }
+        int bin;
+        radix_pick(krem, sh, bin, krem);
+        prefix = (pass == 0) ? (unsigned)bin : ((prefix << (pass == 1 ? 11 : 10)) | (unsigned)bin);
+    }
+    return key2f(prefix);
+}
+
 // ---- top-p cut (order-independent restatement of TopPLogitsWarper3d, see oracle/sjd_oracle.c header) ---------------------
 // w[lo..hi): non-negative weights staged in global memory (e = exp(z - max) or the residual d); p_i = w_i / S.
 // Returns K* = the largest uint32 key with canonical_sum{ p_i : w_i > 0, key(w_i) <= K* } <= thr (32 canonical sums).

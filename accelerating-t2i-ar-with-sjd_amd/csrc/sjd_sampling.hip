@@ -77,6 +77,7 @@ __device__ __forceinline__ float k2_row_scale(const sjd_head_partials &hp, int t
     return rsqrtf(t * hp.inv_hidden + hp.eps);
 }
 
+#define K2_NI 3               // column groups (of 4 x 1024) a thread keeps in registers: windows of up to 12288 columns (9 groups = Emu3's 32768-column rows no longer fit the 128 VGPRs of a 1024-thread workgroup: spills)
 template <bool PART>
 __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const float *__restrict__ logits_c, const float *__restrict__ logits_u, long row_stride, float guidance, int V,
@@ -132,6 +133,11 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
 
     SJD_TRS(row, 1);              // outside of the window zeroed
     // pass 1: CFG combine (JL:104) + grammar mask (LP:125-129); stage z; row max; finite count
+    // Round 3: when the rule's window is at most K2_NI column groups per thread (Lumina's image rows: 3, Emu3's: 9) the staged scores are
+    // taken back into REGISTERS once, behind this pass, and stay there to the final probabilities -- the radix select, the exponentials and
+    // the draw read them there instead of re-reading `p` through L2 in every pass (each pass was a dependent round trip per column group:
+    // 8 of them per pass for Emu3's 32768-column rows).  Same values, same visiting order, same accumulators: bit-identical.  Wider windows
+    // (text rows over the whole vocabulary) keep the staged form.
     float tmax = -INFINITY;
     int cnt = 0;
     SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
@@ -202,6 +208,23 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
             }
         }
     }
+    // the thread's own staged scores come back into registers in ONE round trip (all groups requested together) and stay there
+    const int c0_first = 4 * sjd_first_owned_group(wlo);
+    const bool fits = (whi - (wlo & ~3) + 4 * SJD_TPB - 1) / (4 * SJD_TPB) <= K2_NI;       // (the same for every thread of the block)
+    float zr[K2_NI][4];
+    if (fits) {
+#pragma unroll
+        for (int i = 0; i < K2_NI; ++i) {
+            const int c0 = c0_first + i * 4 * SJD_TPB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = c0 + j;
+                const bool in = c0 < whi && col >= wlo && col < whi;
+                const float v = p[in ? col : wlo];              // (unconditional load: every group of the thread in flight at once)
+                zr[i][j] = in ? v : -INFINITY;                  // a column outside the window: never counted, never kept
+            }
+        }
+    }
     const float zmax = block_max(tmax, sh);
     const int n_finite = block_sum_int(cnt, sh);
     __syncthreads();   // staged z visible to the whole block (global memory, same CU)
@@ -209,7 +232,8 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
 
     // top-k (LP:196-204): keep z >= k-th largest; k-th is -inf when fewer than k finite entries exist
     float kth = -INFINITY;
-    if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_finite) kth = block_kth_largest(p, wlo, whi, rule.top_k, -INFINITY, sh);
+    if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_finite)
+        kth = fits ? block_kth_largest_regs<K2_NI>(zr, rule.top_k, -INFINITY, sh) : block_kth_largest(p, wlo, whi, rule.top_k, -INFINITY, sh);
 
     SJD_TRS(row, 3);              // top-k threshold known
     // pass A: e = exp(z - max) for kept entries, canonical sum.  TemperatureLogitsWarper (rule.temperature != 1): the kept scores are
@@ -218,42 +242,84 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const bool tempered = rule.temperature > 0.0f && rule.temperature != 1.0f;
     const float zmax_t = tempered ? zmax / rule.temperature : zmax;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
-        float ev[4];
+    const bool top_p_on = rule.top_p_thr >= 0.0f;
+    if (fits) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int col = c0 + j;
-            ev[j] = 0.0f;
-            if (col >= wlo && col < whi) {
-                float z = p[col];
-                const float zt = tempered ? z / rule.temperature : z;
-                ev[j] = (z < kth) ? 0.0f : sjd_expf(zt - zmax_t);
-                p[col] = ev[j];
+        for (int i = 0; i < K2_NI; ++i) {
+            const int c0 = c0_first + i * 4 * SJD_TPB;
+            if (c0 < whi) {
+                float ev[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = c0 + j;
+                    ev[j] = 0.0f;
+                    if (col >= wlo && col < whi) {
+                        const float z = zr[i][j];
+                        const float zt = tempered ? z / rule.temperature : z;
+                        ev[j] = (z < kth) ? 0.0f : sjd_expf(zt - zmax_t);
+                        if (top_p_on) p[col] = ev[j];              // (the top-p cut works on the staged weights)
+                    }
+                    zr[i][j] = ev[j];
+                }
+                a0 = a0 + ev[0]; a1 = a1 + ev[1]; a2 = a2 + ev[2]; a3 = a3 + ev[3];
             }
         }
-        a0 = a0 + ev[0]; a1 = a1 + ev[1]; a2 = a2 + ev[2]; a3 = a3 + ev[3];
+    } else {
+        SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+            float ev[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int col = c0 + j;
+                ev[j] = 0.0f;
+                if (col >= wlo && col < whi) {
+                    float z = p[col];
+                    const float zt = tempered ? z / rule.temperature : z;
+                    ev[j] = (z < kth) ? 0.0f : sjd_expf(zt - zmax_t);
+                    p[col] = ev[j];
+                }
+            }
+            a0 = a0 + ev[0]; a1 = a1 + ev[1]; a2 = a2 + ev[2]; a3 = a3 + ev[3];
+        }
     }
     float S = block_canonical_sum(a0, a1, a2, a3, sh);
-    if (rule.top_p_thr >= 0.0f) S = block_top_p_apply(p, wlo, whi, S, rule.top_p_thr, sh);     // TopPLogitsWarper3d (LP:406-419)
+    if (top_p_on) {                                                                             // TopPLogitsWarper3d (LP:406-419)
+        S = block_top_p_apply(p, wlo, whi, S, rule.top_p_thr, sh);
+        if (fits) {                                  // the cut zeroed some staged weights: take them back into the registers
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < K2_NI; ++i) {
+                const int c0 = c0_first + i * 4 * SJD_TPB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (c0 < whi && col >= wlo && col < whi) zr[i][j] = p[col]; }
+            }
+        }
+    }
 
     SJD_TRS(row, 4);              // sum known
     // pass B: p = e / S ; multinomial == lowest-index argmax of p / Exp(1)   (JL:111-118)
     unsigned long long best = 0ull, best_p = 0ull;
-    SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+    auto draw = [&](int col, float w) {
+        float pv = w / S;
+        p[col] = pv;
+        float r;
+        if (ph_blocks) r = pv > 0.0f ? pv / sjd_philox_exponential(ph_seed, ph_off, ph_T, (uint64_t)row * (uint64_t)V + (uint64_t)col) : 0.0f;   // (0 / e == 0: e is finite and > 0)
+        else r = pv / e[col];
+        unsigned long long cand = pack_vi(r, col);
+        best = cand > best ? cand : best;
+        cand = pack_vi(pv, col);
+        best_p = cand > best_p ? cand : best_p;
+    };
+    if (fits) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int col = c0 + j;
-            if (col >= wlo && col < whi) {
-                float pv = p[col] / S;
-                p[col] = pv;
-                float r;
-                if (ph_blocks) r = pv > 0.0f ? pv / sjd_philox_exponential(ph_seed, ph_off, ph_T, (uint64_t)row * (uint64_t)V + (uint64_t)col) : 0.0f;   // (0 / e == 0: e is finite and > 0)
-                else r = pv / e[col];
-                unsigned long long cand = pack_vi(r, col);
-                best = cand > best ? cand : best;
-                cand = pack_vi(pv, col);
-                best_p = cand > best_p ? cand : best_p;
-            }
+        for (int i = 0; i < K2_NI; ++i) {
+            const int c0 = c0_first + i * 4 * SJD_TPB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (c0 < whi && col >= wlo && col < whi) draw(col, zr[i][j]); }
+        }
+    } else {
+        SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (col >= wlo && col < whi) draw(col, p[col]); }
         }
     }
     SJD_TRS(row, 5);              // probabilities written

@@ -55,7 +55,7 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_logits_to_probs_sample_part", "sjd_logits_to_probs_sample_ex", "sjd_reguess_ex",
            "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu", "sjd_host_wait_u64",
            "sjd_philox_fill", "sjd_philox_offset_increment", "sjd_skinny_gemm_reduce", "sjd_reduce_timeouts",
-           "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged", "sjd_skinny_gemm_z", "sjd_gateup_silu_z"]
+           "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged", "sjd_skinny_gemm_z", "sjd_gateup_silu_z", "sjd_qkv_attention_fused_split"]
 
 _lib = None
 
@@ -110,6 +110,8 @@ def load():
     lib.sjd_logits_to_probs_sample_ex.argtypes = [vp, vp, i64, f32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.sjd_qkv_attention_fused.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),
                                             vp, vp, i32, vp]
+    lib.sjd_qkv_attention_fused_split.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),
+                                                  vp, vp, i32, i32, vp, vp]
     lib.sjd_skinny_gemm_reduce.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_skinny_gemm_z.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_gateup_silu_z.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp]

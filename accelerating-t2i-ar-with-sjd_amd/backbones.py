@@ -35,6 +35,7 @@ import os as _os
 # -> tiles -> merge) remain inside the fused kernel (profiles/r2_attention_block.jsonl: 17.3 / 23.2 / 32.5 / 47.6 us against 17.7 / 21.6 /
 # 27.0 / 33.7 us at kv_len 64 / 448 / 1216 / 2368).  Default off; SJD_K1_FUSED=1 or model.k1_fused = True selects it.
 _K1_FUSED_DEFAULT = _os.environ.get("SJD_K1_FUSED", "0") == "1"
+_K1_FUSED_SPLIT_DEFAULT = _os.environ.get("SJD_K1_FUSED_SPLIT", "1") != "0"   # with k1_fused: the split form K1Fs (0: one workgroup per (batch, head))
 _GATEUP_FUSED_DEFAULT = _os.environ.get("SJD_GATEUP_FUSED", "1") != "0"     # kernel G1s (gate|up + F3 in one launch); 0: G1 then F3
 # round 3 experiment, correct, tested, OFF by default: the o / down projections of a <= 32-row window can reduce their own
 # split-K planes, add the residual and write the row statistics in their tail (sjd_skinny_gemm_reduce: device-coherent exchange between
@@ -520,8 +521,13 @@ class ChameleonBackbone(nn.Module):
         ops, H, Hkv, D = self._ops, self.n_heads, self.n_kv_heads, self.head_dim
         ks_ok = isinstance(key_start, torch.Tensor) and key_start.is_cuda and key_start.dtype == torch.int32
         if getattr(self, "k1_fused", _K1_FUSED_DEFAULT) and ks_ok and ops.fused_attention_ok(B, n, H, Hkv, D, self.cache.k.dtype):
+            ns, ws = 1, None
+            if getattr(self, "k1_fused_split", _K1_FUSED_SPLIT_DEFAULT):       # K1Fs: the split form (F2 + k1_partial in one launch, then k1_combine)
+                ns = self.attn._resolve_split(B, Hkv, n, H)
+                ws = self.attn._workspace(B, H, n, D, self.cache.k.device) if ns > 1 else None
             return ops.qkv_attention_fused(qkv_part, self.cache.k[li], self.cache.v[li], *qn, self._inv_freq32, pos, B, n, H, D, params,
-                                           kv_len if params is None else 0, key_start, row_norm=row_norm, dtype=self.lm_head.weight.dtype)
+                                           kv_len if params is None else 0, key_start, row_norm=row_norm, dtype=self.lm_head.weight.dtype,
+                                           n_split=ns, workspace=ws)
         q = self._f2(qkv_part, li, qn, pos, B, n, params, kv_len, row_norm=row_norm)
         return self.attn.attend(li, q, self.cache, kv_len, key_start)
 

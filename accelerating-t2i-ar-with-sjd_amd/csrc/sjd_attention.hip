@@ -790,8 +790,14 @@ __global__ __launch_bounds__(64 * K1F_WAVES) void k1f_qkv_attention(
     const unsigned short *__restrict__ kn_w, const unsigned short *__restrict__ kn_b, const float *__restrict__ inv_freq,
     const long *__restrict__ positions, const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden, float rs_eps,
     unsigned short *__restrict__ kc, unsigned short *__restrict__ vc, unsigned short *__restrict__ out, int n_rows, int H, int S_max,
-    const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg)
+    const int *__restrict__ key_start, const sjd_iter_params *__restrict__ params, int kv_len_arg,
+    int n_split = 1, float *__restrict__ ws_o = nullptr, float *__restrict__ ws_ml = nullptr)
 {
+    // n_split > 1 (round 3, "K1Fs"): grid (H, B, n_split) -- the key tiles of a (batch, head) are split over n_split workgroups exactly as
+    // k1_partial splits them (k1_tile_range, the effective count from the device-side kv_len), every workgroup derives q for itself (16 of
+    // the 48 phase-A tasks), the workgroups whose tiles reach into the window's own rows also derive and append those K / V rows (identical
+    // bytes if two of them do), and phase C publishes the split's (m, l, O) in k1_partial's workspace layout for k1_combine.  F2 + k1_partial
+    // become ONE launch that fills the chip: the 64-workgroup form above streamed at 1.8 TB/s.
     typedef typename Frag<DT>::vec vec;
     static_assert(D == 128, "K1F is written for head_dim 128");
     constexpr int HALF = D / 2, KS = D / 32, DB = D / 16, VROW = D + 8;
@@ -812,48 +818,75 @@ __global__ __launch_bounds__(64 * K1F_WAVES) void k1f_qkv_attention(
     const int total = kv_len + max(n_c, 0);
     const int kstart = key_start ? key_start[b] : 0;
     const float scale = rsqrtf((float)D);
-    const int t_lo = kstart / K1_KT, t_hi = (total + K1_KT - 1) / K1_KT;
+    int t_lo, t_hi, eff_split, tps;
+    k1_tile_range(kstart, total, n_split, t_lo, t_hi, eff_split, tps);
+    const int split = blockIdx.z;
+    if (split >= eff_split) return;
+    t_lo += split * tps;                                                   // this workgroup's tiles
+    t_hi = min(t_hi, t_lo + tps);
+    const bool does_kv = t_hi * K1_KT > kv_len;                            // its tiles reach into the window's own rows: it appends (and reads) them
     unsigned short *kbase = kc + ((size_t)b * H + head) * (size_t)S_max * D;
     unsigned short *vbase = vc + ((size_t)b * H + head) * (size_t)S_max * D;
 
-    // ---------------- phase A loads.  16 rows x {q, k, v} = 48 (row, tensor) tasks, 48 / K1F_WAVES per wave; in a task lane l owns the
-    // rotate-half pair d = l, l + 64 of that row's head slice: fp32 split-K partials of the q|k|v projection, all chunks in flight.
-    constexpr int TPW = 3 * K1_ROWS / K1F_WAVES;                  // tasks per wave
-    static_assert(TPW * K1F_WAVES == 3 * K1_ROWS, "tasks must divide evenly");
-    constexpr int MAXC = 4;                                       // chunks in flight per task and pass
+    // ---------------- phase A (round 3: rewritten for the memory system).  Wave w owns rows 2 w and 2 w + 1 of the window: their q slices
+    // always, their k and v slices when this workgroup appends (does_kv).  In a slice lane l owns the rotate-half pair d = l, l + 64.  EVERY
+    // load of a batch -- the row statistics, up to eight split-K planes of both rows, the norm gains, the rotation frequencies and positions
+    // -- is unconditional (row / chunk indices clamped, values masked afterwards) and issued before the first use: one round trip per batch.
+    // The first version walked six (row, tensor) tasks per wave with conditional loads, i.e. a dozen dependent round trips (K1Fs measured
+    // 3.27 ms per step against 2.98 for F2 + K1 + combine).
+    constexpr int RPW = K1_ROWS / K1F_WAVES;                      // rows per wave (2)
+    static_assert(RPW * K1F_WAVES == K1_ROWS, "rows must divide evenly");
     const size_t ncol = (size_t)3 * H * D;
-    float acc[TPW][2], ss_tot[TPW];
+    const size_t cstride = (size_t)prows * ncol;
+    int rowi[RPW], toki[RPW];
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-        const int task = w * TPW + j, row = task / 3, x = task % 3;
-        const int tok = b * n_rows + row;
-        acc[j][0] = acc[j][1] = 0.f;
-        ss_tot[j] = 0.f;
-        if (row < n_rows) {
-            if (row_sumsq)
-                for (int s0 = 0; s0 < rs_slices; s0 += 8) {      // as row_sumsq_total (sjd_glue.hip): eight loads in flight, fixed order
-                    float v8[8];
+    for (int r = 0; r < RPW; ++r) { rowi[r] = w * RPW + r; toki[r] = b * n_rows + min(rowi[r], n_rows - 1); }
+    // (slots beyond n_chunks re-read the last plane and are not added; with at most four planes -- the production q|k|v launch shape --
+    // only four slots per slice are requested, so that q, k AND v of both rows fit into ONE batch under the 63-load vmcnt ceiling)
+    const bool few = n_chunks <= 4;
+    auto plane_loads = [&](int x, float (&v0)[RPW][8], float (&v1)[RPW][8]) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v8[q] = (s0 + q < rs_slices) ? row_sumsq[(size_t)(s0 + q) * prows + tok] : 0.f;
+        for (int r = 0; r < RPW; ++r) {
+            const float *p0 = part + (size_t)toki[r] * ncol + ((size_t)x * H + head) * D + lane;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) ss_tot[j] += v8[q];
+            for (int q = 0; q < 4; ++q) {
+                const float *pp = p0 + (size_t)min(q, n_chunks - 1) * cstride;
+                v0[r][q] = pp[0];
+                v1[r][q] = pp[HALF];
+            }
+            if (!few) {
+#pragma unroll
+                for (int q = 4; q < 8; ++q) {
+                    const float *pp = p0 + (size_t)min(q, n_chunks - 1) * cstride;
+                    v0[r][q] = pp[0];
+                    v1[r][q] = pp[HALF];
                 }
-            const float *p0 = part + (size_t)tok * ncol + ((size_t)x * H + head) * D + lane;
-            for (int c0 = 0; c0 < n_chunks; c0 += MAXC) {        // summed in chunk order, as F2 does
-                float v0[MAXC], v1[MAXC];
+            } else {
 #pragma unroll
-                for (int q = 0; q < MAXC; ++q)
-                    if (c0 + q < n_chunks) {
-                        const float *pp = p0 + (size_t)(c0 + q) * prows * ncol;
-                        v0[q] = pp[0];
-                        v1[q] = pp[HALF];
-                    }
-#pragma unroll
-                for (int q = 0; q < MAXC; ++q)
-                    if (c0 + q < n_chunks) { acc[j][0] += v0[q]; acc[j][1] += v1[q]; }
+                for (int q = 4; q < 8; ++q) { v0[r][q] = 0.f; v1[r][q] = 0.f; }
             }
         }
+    };
+    // the row statistics: lane q holds slice q (q < 8; further slices in the math below) -- ONE load per row instead of eight
+    float ssl[RPW], qv0[RPW][8], qv1[RPW][8];
+    {
+        const float *ssp = row_sumsq ? row_sumsq : part;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) ssl[r] = ssp[(size_t)(row_sumsq ? min(lane & 7, rs_slices - 1) : 0) * prows + toki[r]];
     }
+    plane_loads(0, qv0, qv1);
+    float kv0[RPW][8], kv1[RPW][8], vv0[RPW][8], vv1[RPW][8];
+    if (does_kv && few) { plane_loads(1, kv0, kv1); plane_loads(2, vv0, vv1); }          // everything this workgroup needs: one round trip
+    float posf[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) posf[r] = (float)positions[toki[r]];
+    const float ifr = inv_freq[lane];
+    const unsigned short *wl = qn_w ? qn_w : reinterpret_cast<const unsigned short *>(part);       // (unconditional loads: any readable address)
+    const unsigned short *bl = qn_b ? qn_b : reinterpret_cast<const unsigned short *>(part);
+    const unsigned short *wk = kn_w ? kn_w : reinterpret_cast<const unsigned short *>(part);
+    const unsigned short *bk = kn_b ? kn_b : reinterpret_cast<const unsigned short *>(part);
+    const float qw0 = k1f_load16<DT>(wl + lane), qw1 = k1f_load16<DT>(wl + lane + HALF), qb0 = k1f_load16<DT>(bl + lane), qb1 = k1f_load16<DT>(bl + lane + HALF);
+    const float kw0 = k1f_load16<DT>(wk + lane), kw1 = k1f_load16<DT>(wk + lane + HALF), kb0 = k1f_load16<DT>(bk + lane), kb1 = k1f_load16<DT>(bk + lane + HALF);
 
     // ---------------- key tiles.  A wave owns tiles t_lo + w, + 8, ...; TWO of them are in flight at any time (two register landing
     // zones of K fragments + V rows, 64 registers each): measured with one tile in flight and 12 waves, a CU pulled only ~40 GB/s -- the
@@ -893,46 +926,83 @@ __global__ __launch_bounds__(64 * K1F_WAVES) void k1f_qkv_attention(
     if (early0) { load_k(t0, kA); load_v(t0, vA); }
     if (early1) { load_k(t1, kB); load_v(t1, vB); }
 
-    // ---------------- phase A math: the arithmetic of f2_qknorm_rope_append, same rounding points
+    // ---------------- phase A math: the arithmetic of f2_qknorm_rope_append, same rounding points.  (More than eight planes / slices: the
+    // remaining ones in further batches, in order.)
+    float rscale[RPW], csr[RPW], snr[RPW];
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-        const int task = w * TPW + j, row = task / 3, x = task % 3;
-        if (row >= n_rows) continue;
-        const int tok = b * n_rows + row, rr = kv_len + row;
-        float x0 = acc[j][0], x1 = acc[j][1];
-        if (row_sumsq) {
-            const float r = rsqrtf(ss_tot[j] * rs_inv_hidden + rs_eps);
-            x0 *= r;
-            x1 *= r;
+    for (int r = 0; r < RPW; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {                           // slice order, as row_sumsq_total (sjd_glue.hip)
+            const float sq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ssl[r]), q));
+            t += (q < rs_slices) ? sq : 0.f;
         }
+        for (int s0 = 8; s0 < rs_slices; s0 += 8) {
+            float v8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v8[q] = (s0 + q < rs_slices) ? row_sumsq[(size_t)(s0 + q) * prows + toki[r]] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += v8[q];
+        }
+        rscale[r] = row_sumsq ? rsqrtf(t * rs_inv_hidden + rs_eps) : 1.0f;
+        float sn, cs;
+        sincosf(posf[r] * ifr, &sn, &cs);
+        csr[r] = k1f_round<DT>(cs);
+        snr[r] = k1f_round<DT>(sn);
+    }
+    // one (row, tensor) slice: sum of the planes in chunk order, row scale, rounding, [LayerNorm, RoPE] -> the two 16-bit values of this lane
+    auto finish = [&](int x, int r, const float (&v0)[8], const float (&v1)[8], unsigned short &o0, unsigned short &o1) {
+        float x0 = 0.f, x1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < n_chunks) { x0 += v0[q]; x1 += v1[q]; }
+        for (int c0 = 8; c0 < n_chunks; ++c0) {
+            const float *pp = part + (size_t)toki[r] * ncol + ((size_t)x * H + head) * D + lane + (size_t)c0 * cstride;
+            x0 += pp[0];
+            x1 += pp[HALF];
+        }
+        if (row_sumsq) { x0 *= rscale[r]; x1 *= rscale[r]; }
         x0 = k1f_round<DT>(x0);
         x1 = k1f_round<DT>(x1);
-        if (x == 2) {                                                          // V: plain copy into the cache
-            if (rr < S_max) {
-                vbase[(size_t)rr * D + lane] = k1f_bits<DT>(x0);
-                vbase[(size_t)rr * D + lane + HALF] = k1f_bits<DT>(x1);
-            }
-            continue;
-        }
-        const unsigned short *gw_ = x == 0 ? qn_w : kn_w, *gb_ = x == 0 ? qn_b : kn_b;
-        if (gw_ != nullptr) {                                                  // per-head LayerNorm over head_dim (eps 1e-5)
+        if (x == 2) { o0 = k1f_bits<DT>(x0); o1 = k1f_bits<DT>(x1); return; }               // V: plain copy
+        const bool normed = x == 0 ? qn_w != nullptr : kn_w != nullptr;
+        if (normed) {                                                                         // per-head LayerNorm over head_dim (eps 1e-5)
             const float mean = k1f_wave_sum(x0 + x1) / (float)D;
             const float d0 = x0 - mean, d1 = x1 - mean;
             const float var = k1f_wave_sum(d0 * d0 + d1 * d1) / (float)D;
             const float inv = rsqrtf(var + 1e-5f);
             const float n0 = k1f_round<DT>(d0 * inv), n1 = k1f_round<DT>(d1 * inv);
-            x0 = k1f_round<DT>(k1f_round<DT>(n0 * k1f_load16<DT>(gw_ + lane)) + k1f_load16<DT>(gb_ + lane));
-            x1 = k1f_round<DT>(k1f_round<DT>(n1 * k1f_load16<DT>(gw_ + lane + HALF)) + k1f_load16<DT>(gb_ + lane + HALF));
+            x0 = k1f_round<DT>(k1f_round<DT>(n0 * (x == 0 ? qw0 : kw0)) + (x == 0 ? qb0 : kb0));
+            x1 = k1f_round<DT>(k1f_round<DT>(n1 * (x == 0 ? qw1 : kw1)) + (x == 0 ? qb1 : kb1));
         }
-        float sn, cs;
-        sincosf((float)positions[tok] * inv_freq[lane], &sn, &cs);
-        cs = k1f_round<DT>(cs);
-        sn = k1f_round<DT>(sn);
-        const float a0 = k1f_round<DT>(x0 * cs), b0 = k1f_round<DT>(-x1 * sn);
-        const float a1 = k1f_round<DT>(x1 * cs), b1 = k1f_round<DT>(x0 * sn);
-        const unsigned short o0 = k1f_bits<DT>(k1f_round<DT>(a0 + b0)), o1 = k1f_bits<DT>(k1f_round<DT>(a1 + b1));
-        if (x == 0) { q_lds[row][lane] = o0; q_lds[row][lane + HALF] = o1; }
-        else if (rr < S_max) { kbase[(size_t)rr * D + lane] = o0; kbase[(size_t)rr * D + lane + HALF] = o1; }
+        const float a0 = k1f_round<DT>(x0 * csr[r]), b0 = k1f_round<DT>(-x1 * snr[r]);
+        const float a1 = k1f_round<DT>(x1 * csr[r]), b1 = k1f_round<DT>(x0 * snr[r]);
+        o0 = k1f_bits<DT>(k1f_round<DT>(a0 + b0));
+        o1 = k1f_bits<DT>(k1f_round<DT>(a1 + b1));
+    };
+    if (does_kv && !few) plane_loads(1, kv0, kv1);                               // (more than four planes: k under the q math, v under the k math)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        unsigned short o0, o1;
+        finish(0, r, qv0[r], qv1[r], o0, o1);
+        if (rowi[r] < n_rows) { q_lds[rowi[r]][lane] = o0; q_lds[rowi[r]][lane + HALF] = o1; }
+    }
+    if (does_kv) {
+        if (!few) plane_loads(2, vv0, vv1);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            unsigned short o0, o1;
+            finish(1, r, kv0[r], kv1[r], o0, o1);
+            const int rr = kv_len + rowi[r];
+            if (rowi[r] < n_rows && rr < S_max) { kbase[(size_t)rr * D + lane] = o0; kbase[(size_t)rr * D + lane + HALF] = o1; }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            unsigned short o0, o1;
+            finish(2, r, vv0[r], vv1[r], o0, o1);
+            const int rr = kv_len + rowi[r];
+            if (rowi[r] < n_rows && rr < S_max) { vbase[(size_t)rr * D + lane] = o0; vbase[(size_t)rr * D + lane + HALF] = o1; }
+        }
     }
     __syncthreads();            // q in LDS; this workgroup's K/V rows acknowledged by L2 (it is their only reader in this launch)
 
@@ -1022,6 +1092,23 @@ __global__ __launch_bounds__(64 * K1F_WAVES) void k1f_qkv_attention(
     __syncthreads();
     for (int idx = threadIdx.x; idx < K1_ROWS * D; idx += 64 * K1F_WAVES) {
         const int row = idx / D, d = idx % D;
+        if (n_split > 1) {                                      // the split's partial in k1_partial's workspace layout (one 16-row chunk)
+            float M = -INFINITY;
+#pragma unroll
+            for (int ww = 0; ww < K1F_WAVES; ++ww) M = fmaxf(M, red_ml[ww][row][0]);
+            const float Ms = (M == -INFINITY) ? 0.0f : M;
+            float L = 0.f, O = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < K1F_WAVES; ++ww) {
+                const float wgt = __expf(red_ml[ww][row][0] - Ms);
+                L += wgt * red_ml[ww][row][1];
+                O += wgt * red_o[ww][row][d];
+            }
+            const size_t slot = (((size_t)b * H + head) * n_split + split) * K1_ROWS + row;
+            ws_o[slot * D + d] = O;
+            if (d == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = L; }
+            continue;
+        }
         if (row >= n_rows) continue;
         unsigned short *o = out + (((size_t)b * n_rows + row) * H + head) * D + d;
         if (row >= n_total) { *o = 0; continue; }              // padding rows of a shape-static window: defined (zero) output
@@ -1065,6 +1152,45 @@ extern "C" int sjd_qkv_attention_fused(const float *part, int n_chunks, void *k_
     SJD_K1F_CASE(SJD_DTYPE_BF16)
     SJD_K1F_CASE(SJD_DTYPE_F16)
 #undef SJD_K1F_CASE
+    return SJD_ERR_UNSUPPORTED;
+}
+
+// K1Fs: sjd_qkv_attention_fused with the key tiles split over n_split workgroups per (batch, head) + k1_combine: F2 and k1_partial in one
+// launch that fills the chip.  workspace: sjd_attention_workspace_bytes(B, H, n_rows, D, n_split).  n_split == 1 is sjd_qkv_attention_fused.
+extern "C" int sjd_qkv_attention_fused_split(const float *part, int n_chunks, void *k_cache, void *v_cache, void *out, const void *qn_w,
+                                             const void *qn_b, const void *kn_w, const void *kn_b, const float *inv_freq,
+                                             const int64_t *positions, int B, int n_rows, int H, int D, int S_max, int dtype,
+                                             const sjd_row_norm *row_norm, const int32_t *key_start, const sjd_iter_params *params, int kv_len,
+                                             int n_split, void *workspace, void *stream)
+{
+    if (n_split <= 1)
+        return sjd_qkv_attention_fused(part, n_chunks, k_cache, v_cache, out, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n_rows, H, D, S_max,
+                                       dtype, row_norm, key_start, params, kv_len, stream);
+    if (!part || n_chunks < 1 || !k_cache || !v_cache || !out || !inv_freq || !positions || !workspace || B < 1 || H < 1 || n_split > 64) return SJD_ERR_BAD_ARG;
+    if (n_rows < 1 || n_rows > K1_ROWS || B * n_rows > 32 || (S_max % K1_KT) != 0) return SJD_ERR_BAD_ARG;
+    if ((qn_w == nullptr) != (qn_b == nullptr) || (kn_w == nullptr) != (kn_b == nullptr)) return SJD_ERR_BAD_ARG;
+    if (row_norm && (!row_norm->sumsq || row_norm->slices < 1 || row_norm->hidden < 1)) return SJD_ERR_BAD_ARG;
+    if (D != 128) return SJD_ERR_UNSUPPORTED;
+    const float *ss = row_norm ? row_norm->sumsq : nullptr;
+    const int sl = row_norm ? row_norm->slices : 0;
+    const float ih = row_norm ? 1.0f / (float)row_norm->hidden : 0.f, eps = row_norm ? row_norm->eps : 0.f;
+    hipStream_t s = (hipStream_t)stream;
+    float *ws_o = (float *)workspace;
+    float *ws_ml = ws_o + (size_t)B * H * n_split * K1_ROWS * D;           // (k1_partial's layout with one 16-row chunk)
+#define SJD_K1FS_CASE(DT_)                                                                                                                 \
+    if (dtype == DT_) {                                                                                                                    \
+        hipLaunchKernelGGL((k1f_qkv_attention<DT_, 128>), dim3(H, B, n_split), dim3(64 * K1F_WAVES), 0, s, part, n_chunks, 32,              \
+                           (const unsigned short *)qn_w, (const unsigned short *)qn_b, (const unsigned short *)kn_w,                        \
+                           (const unsigned short *)kn_b, inv_freq, (const long *)positions, ss, sl, ih, eps, (unsigned short *)k_cache,    \
+                           (unsigned short *)v_cache, (unsigned short *)out, n_rows, H, S_max, key_start, params, kv_len, n_split, ws_o,    \
+                           ws_ml);                                                                                                         \
+        hipLaunchKernelGGL((k1_combine<DT_, 128>), dim3(1, H, B), dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, n_rows, H, n_split, 1,  \
+                           params, key_start, kv_len);                                                                                     \
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;                                                                   \
+    }
+    SJD_K1FS_CASE(SJD_DTYPE_BF16)
+    SJD_K1FS_CASE(SJD_DTYPE_F16)
+#undef SJD_K1FS_CASE
     return SJD_ERR_UNSUPPORTED;
 }
 

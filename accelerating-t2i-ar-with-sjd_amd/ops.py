@@ -573,9 +573,20 @@ def fused_attention_ok(B, n, H, H_kv, D, cache_dtype):
 
 
 def qkv_attention_fused(qkv_part, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_freq, positions, B, n, H, D, params, kv_len, key_start,
-                        row_norm=None, dtype=None):
+                        row_norm=None, dtype=None, n_split=1, workspace=None):
     """K1F: G1 Partials of the q|k|v projection -> attention output [B, n, H, D]; the window's k / v rows are appended to
-    k_cache / v_cache [B, H, S, D] on the way (QK-norm + RoPE as in qknorm_rope_append)."""
+    k_cache / v_cache [B, H, S, D] on the way (QK-norm + RoPE as in qknorm_rope_append).  n_split > 1 (K1Fs): the key tiles of a (batch,
+    head) split over n_split workgroups + the split combine; workspace = attention_workspace(B, H, n, D, n_split)."""
+    if n_split > 1:
+        assert isinstance(qkv_part, Partials) and qkv_part.N == 3 * H * D and qkv_part.data.shape[1] == 32 and workspace is not None
+        act = dtype or k_cache.dtype
+        out = torch.empty(B, n, H, D, dtype=act, device=k_cache.device)
+        L.check(L.load().sjd_qkv_attention_fused_split(_ptr(qkv_part.data), qkv_part.n_chunks, _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(qn_w),
+                                                      _ptr(qn_b), _ptr(kn_w), _ptr(kn_b), _ptr(inv_freq), _ptr(positions), B, n, H, D,
+                                                      k_cache.shape[2], _dtype_code(act), _row_norm(row_norm), _ptr(key_start),
+                                                      params.ptr if params is not None else None, int(kv_len), int(n_split), _ptr(workspace),
+                                                      _stream()), "sjd_qkv_attention_fused_split")
+        return out
     assert isinstance(qkv_part, Partials) and qkv_part.N == 3 * H * D and qkv_part.data.shape[1] == 32
     assert positions.is_contiguous() and positions.dtype == torch.int64 and inv_freq.dtype == torch.float32
     assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape[1] == H

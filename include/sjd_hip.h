@@ -223,6 +223,17 @@ int sjd_qkv_attention_fused(const float *part, int n_chunks, void *k_cache, void
                             const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n_rows, int H,
                             int D, int S_max, int dtype, const sjd_row_norm *row_norm, const int32_t *key_start,
                             const sjd_iter_params *params, int kv_len, void *stream);
+/* K1Fs (round 3): the same with the key tiles of a (batch, head) split over n_split workgroups exactly as sjd_draft_window_attention splits
+ * them (the effective count from the device-side kv_len), followed by the split combine: F2 (sjd_qknorm_rope_append) and the attention
+ * partial pass in ONE launch that fills the chip.  Every workgroup derives q for itself; the workgroups whose tiles reach into the window's
+ * own rows derive and append those K / V rows.  workspace: sjd_attention_workspace_bytes(B, H, n_rows, D, n_split) bytes.  n_split <= 1 is
+ * sjd_qkv_attention_fused.  replaces, like it: q_norm / k_norm, apply_rotary_pos_emb, past_key_value.update and the attention of
+ * ChameleonAttention.forward (reference modeling_chameleon.py:198-219, 144-178, 547, 499-581) for the window forward. */
+int sjd_qkv_attention_fused_split(const float *part, int n_chunks, void *k_cache, void *v_cache, void *out, const void *qn_w, const void *qn_b,
+                                  const void *kn_w, const void *kn_b, const float *inv_freq, const int64_t *positions, int B, int n_rows, int H,
+                                  int D, int S_max, int dtype, const sjd_row_norm *row_norm, const int32_t *key_start,
+                                  const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream);
+
 
 /* F1-F3 -- fused element-wise glue of the draft-window forward (the "next" row of SURVEY.md 8f.1).
  * F1: h += delta (delta may be NULL; or delta = dtype(sum of the fp32 split-K partials `part`)); y = weight * dtype(h * rsqrt(mean(h^2) + eps)).  replaces ChameleonRMSNorm +

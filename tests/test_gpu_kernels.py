@@ -608,7 +608,17 @@ def test_k1f_fused_attention_matches_f2_then_k1(dev, dtype, qk_norm, fold, kv_le
     attn.params = params
     ref3 = attn.attend(0, q, c1, kv_len, ks)
     out = ops.qkv_attention_fused(part, c2.k[0], c2.v[0], *qn, inv, pos, B, n, H, D, params, 0 if params else kv_len, ks, row_norm=rn, dtype=dtype)
+    # K1Fs: the same with the key tiles split over four workgroups per (batch, head) + the split combine (identical cache rows, the
+    # output of the one-workgroup form up to the order in which the key parts are merged)
+    c3 = _Cache(base_k.clone(), base_v.clone())
+    ws = ops.attention_workspace(B, H, n, D, 4, dev)
+    out_s = ops.qkv_attention_fused(part, c3.k[0], c3.v[0], *qn, inv, pos, B, n, H, D, params, 0 if params else kv_len, ks, row_norm=rn, dtype=dtype,
+                                    n_split=4, workspace=ws)
     torch.cuda.synchronize()
+    assert torch.equal(c1.k, c3.k) and torch.equal(c1.v, c3.v)
+    assert torch.isfinite(out_s.float()).all()
+    ds = (out_s.float() - out.float()).abs()
+    assert ds.max() < 4e-2 and ds.mean() < 2e-3, (float(ds.max()), float(ds.mean()))
     assert torch.equal(c1.k, c2.k) and torch.equal(c1.v, c2.v)                      # appended rows bit-identical, nothing else touched
     assert not torch.equal(c2.k[0, :, :, kv_len:kv_len + n], base_k[0, :, :, kv_len:kv_len + n])
     # fp32 softmax over the appended cache with the 16-bit q of F2

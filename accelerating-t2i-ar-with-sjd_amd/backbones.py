@@ -366,8 +366,11 @@ class ChameleonBackbone(nn.Module):
     # set `model.G1_CFG = model.G1_CFG_64ROW` before enable_fused (the packing depends on KC).  Tuned end to end at Lumina-7B shapes.
     # (round 3: gate|up packed in two K halves = the copy kernel G1s streams, which now serves 64 rows; (1024, 12) was the G1 + F3 shape)
     G1_CFG_64ROW = dict(qkv=(896, 8, True), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))       # profiles/r2_g1_launch_shape_sweep_64rows.jsonl
-    # 65..128-row windows (three / four prompts per forward): the activation is sub-tiled, so KC is free again, but <= 8 waves
-    G1_CFG_128ROW = dict(qkv=(896, 8, True), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))
+    # 65..128-row windows (three / four prompts per forward): the activation is sub-tiled, so KC is free again, but <= 8 waves.  Round 3:
+    # 4-wave workgroups run on g1_skinny_gemm_tiled8 (8-step sub-tiles, two workgroups per CU, weight ring refilled in place) -- q|k|v,
+    # o and down are faster there (28.1 / 15.8 / 28.4 -> 25.7 / 12.2 / 24.0 us), gate|up is not (profiles/r3_g1_tiled8.txt);
+    # four prompts per forward 5.55 -> 5.07 ms per step on one box
+    G1_CFG_128ROW = dict(qkv=(2048, 4, True), o=(896, 4, True), gate_up=(2048, 8, True), down=(1376, 4, True))
     # Emu3-Gen 8B (GQA 32/8: the q|k|v projection has 6144 columns; draft window 32 -> 64 rows), tuned end to end with bench.py --model emu3_8b
     G1_CFG_EMU3 = dict(qkv=(512, 8, False), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))        # profiles/r2_g1_launch_shape_sweep_emu3_64rows.jsonl
 

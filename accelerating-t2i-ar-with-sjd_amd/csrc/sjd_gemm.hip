@@ -458,6 +458,158 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
         }
 }
 
+// ---- 65..128-row windows, second form (round 3): TWO workgroups per CU.
+// The kernel above owns a CU alone (2 x MT x 16 KiB of LDS, 8 waves x ~250 VGPRs), and its 8 waves meet at a barrier every 16 k-steps with
+// one weight group per wave in flight: the phase stamps put 0.45 us of LDS writes + ~0.7 us of barrier on top of every 3.2-4 us sub-tile.
+// Here a sub-tile is 8 k-steps = ONE weight group, a workgroup is 4 waves and 2 x MT x 8 KiB of LDS (64 KiB at four row tiles), so two
+// workgroups share a CU (2 waves per SIMD, <= 256 VGPRs each as before): while one stages and waits at its barrier the other streams and
+// multiplies.  Register sets A / B alternate between sub-tiles without copies; the group of the NEXT sub-tile and its activation pieces are
+// requested before the MFMAs of the current one; every load is unconditional (a record past the chunk reads as zero through the wave's
+// buffer descriptor, an activation piece past it is clamped and zeroed); the k-steps past a ragged chunk's end are skipped by uniform branches.  Same MFMA
+// sequence per (tile, chunk, row tile) as g1_skinny_gemm: bit-identical planes.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t g1z_unit_rsrc(const unsigned char *first_record, unsigned bytes);
+template <int DT, int MT>
+__global__ __launch_bounds__(256, 2) void g1_skinny_gemm_tiled8(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
+                                                                float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
+                                                                int rec_stride, int tile0)
+{
+    SJD_TR(0);
+    constexpr int SUB = 8;
+    static_assert(G1_UNROLL == SUB, "a sub-tile is one weight group");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *xl = reinterpret_cast<u32x4 *>(smem);                 // two buffers of MT * SUB records
+    const int chunk = blockIdx.y;
+    const int k0 = chunk * KC;
+    const int steps = min(KC, K - k0) / 16;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int t_out = blockIdx.x * 4 + w;                         // exactly four waves (the launcher sends other wave counts to the 16-step kernel)
+    const bool has_tile = t_out < N / 32;                        // a wave without a tile multiplies tile 0 and stores nothing
+    const int t = tile0 + (has_tile ? t_out : 0);
+    const size_t chunk_base = (size_t)chunk * n_tiles * (KC / 16);
+    const size_t tile_off = (rec_stride == 1) ? (size_t)t * steps : (size_t)t;
+    // one buffer descriptor per wave over its unit: records past the unit's end read as zero WITHOUT touching memory, the record offset is a
+    // scalar and the lane offset the only address register (the eight 64-bit addresses of a group spilled at four row tiles)
+    const unsigned rsb = (unsigned)rec_stride * 1024u;
+    const __amdgpu_buffer_rsrc_t wr = g1z_unit_rsrc(reinterpret_cast<const unsigned char *>(wp + (chunk_base + tile_off) * 64),
+                                                    (unsigned)(steps - 1) * rsb + 1024u);
+    constexpr int BUF = MT * SUB * 64;                            // u32x4 per LDS buffer
+    constexpr int PPR = 2 * SUB;                                  // 16-byte pieces per row of a sub-tile
+    constexpr int NP = MT * 32 * PPR;                             // pieces per sub-tile
+    constexpr int NV = NP / 256;                                  // pieces per thread at 256 threads (2 MT)
+    const int n_sub = (steps + SUB - 1) / SUB;
+    const int k_end = k0 + steps * 16;
+    u32x4 A[SUB], B[SUB];
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    // activation pieces through a buffer descriptor over x [M, K] as well: a row >= M (its product rows must be zero) or a piece past the
+    // matrix reads as zero; the pieces past the chunk's last k-step are zeroed on their way into LDS.  One 32-bit offset per thread.
+    const __amdgpu_buffer_rsrc_t xr = g1z_unit_rsrc(reinterpret_cast<const unsigned char *>(x), (unsigned)M * (unsigned)K * 2u);
+    // thread tid stages pieces tid + 256 i: row m0 + 16 i (m0 = tid / 16 < 16), the SAME 8 columns j0 = tid % 16 of the sub-tile for every
+    // i -- so the global offset of piece i is ONE per-lane offset + the scalar (16 i) rows, its LDS slot ONE per-lane slot + a constant
+    // (row tile i / 2, bit 4 of the row = i & 1), and the column test below is one compare per sub-tile (16 address / predicate registers less).
+    const int m0 = threadIdx.x >> 4, j0 = threadIdx.x & 15;
+    const unsigned x_off0 = ((unsigned)m0 * (unsigned)K + (unsigned)(k0 + 8 * j0)) * 2u;
+    const int x_slot0 = (j0 >> 1) * 64 + g1_slot(j0 & 1, m0, j0 >> 1);
+    auto x_load = [&](int st, int i) -> u32x4 {                   // (a row >= M lies past the descriptor's end: zero)
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(st) * (32u * SUB) + (unsigned)(32 * i) * (unsigned)K;
+        return __builtin_amdgcn_raw_buffer_load_b128(xr, x_off0, so, 0);
+    };
+    auto x_store = [&](int st, int buf, int i, u32x4 val) {       // (the zeroing sits on the store side: the loads stay in flight through the MFMAs)
+        xl[buf * BUF + (i >> 1) * (SUB * 64) + ((i & 1) << 4) + x_slot0] =
+            (k0 + st * (16 * SUB) + 8 * j0 < k_end) ? val : u32x4{0u, 0u, 0u, 0u};          // (a column past the chunk is the next chunk's or the next row's)
+    };
+    auto w_rec = [&](int g, int u) -> u32x4 {                     // k-step 8 g + u of the chunk
+        return __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)lane * 16u, (unsigned)(__builtin_amdgcn_readfirstlane(g) * SUB + u) * rsb, 2 /* nt */);
+    };
+    auto stage = [&](int st_next, int buf, u32x4 (&val)[NV], bool load) {
+#ifdef T8_NOX             // (probe: only the first sub-tile is staged; every sub-tile multiplies it)
+        if (st_next > 0) return;
+#endif
+        if (load) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) val[i] = x_load(st_next, i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) x_store(st_next, buf, i, val[i]);
+        }
+    };
+    // one sub-tile: no branches.  The A operands of k-step u + 1 are read from LDS before the MFMAs of k-step u issue; a weight record is
+    // REFILLED IN PLACE right after its MFMAs with the record two sub-tiles on (the sets A / B are a ring of 16 k-steps: 8-16 KiB per wave
+    // in flight through the MFMAs and the barrier, no second copy of a set).  The k-steps past a ragged chunk's end multiply zero records
+    // by zeroed activation pieces: +0 added to an accumulator that is never -0 (it starts at +0) leaves every bit as it is.
+    auto sub_tile = [&](const u32x4 *xb, u32x4 (&W)[SUB], int g_refill) {
+        u32x4 a[2][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[0][mt] = xb[(mt * SUB) * 64 + g1_slot(lane >> 5, lane & 31, 0)];
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {
+            if (u + 1 < SUB) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[(u + 1) & 1][mt] = xb[(mt * SUB + u + 1) * 64 + g1_slot(lane >> 5, lane & 31, u + 1)];
+            }
+            __builtin_amdgcn_sched_barrier(0);                    // (the scheduler otherwise sinks each LDS read to its MFMA and the refills to the end)
+#ifdef T8_NOMFMA      // (probe: the stream and the staging without the matrix cores)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][u] += __builtin_bit_cast(float, a[u & 1][mt].x ^ W[u].x);
+#else
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(a[u & 1][mt], W[u], acc[mt]);
+#endif
+            W[u] = w_rec(g_refill, u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    {
+        u32x4 val[NV];
+        stage(0, 0, val, true);
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) A[u] = w_rec(0, u);
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) B[u] = w_rec(1, u);
+        stage(0, 0, val, false);
+    }
+    __syncthreads();
+    SJD_TR(1);                    // first sub-tile staged
+    int st = 0;
+    for (; st + 1 < n_sub; st += 2) {                             // pairs of sub-tiles: set A on LDS buffer 0, set B on buffer 1
+        {
+            u32x4 val[NV];
+            stage(st + 1, 1, val, true);
+            __builtin_amdgcn_sched_barrier(0);
+            sub_tile(xl, A, st + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(st + 1, 1, val, false);
+            __syncthreads();
+        }
+        {
+            u32x4 val[NV];
+            stage(st + 2, 0, val, true);                          // (past the last sub-tile: zeros nobody reads)
+            __builtin_amdgcn_sched_barrier(0);
+            sub_tile(xl + BUF, B, st + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(st + 2, 0, val, false);
+            __syncthreads();
+        }
+    }
+    if (st < n_sub) sub_tile(xl, A, st + 2);                      // an odd number of sub-tiles: the last one (its refills read as zero)
+    SJD_TR(3);                    // main loop done
+#ifdef T8_NOSTORE         // (probe: no partial planes)
+    if (acc[0][0] != 12345.0f) return;
+#endif
+    if (!has_tile) return;
+    float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t_out * 32 + (lane & 31);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            o[(size_t)m * N] = acc[mt][r];
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ weight prefetch
 // While the latency-bound kernels of a layer run (F1r / F2 / K1 / combine / F3: ~1.15 ms of a 3.9 ms step, rocprofv3 round 1) HBM is
 // idle although the step as a whole is bound by the 13 GB weight stream.  This kernel, launched on a SIDE stream (a parallel branch of
@@ -1629,6 +1781,14 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
     static const bool force_tiled = [] { const char *e = getenv("SJD_G1_TILED"); return e && e[0] == '1'; }();      // tuning aid (64-row windows)
     if constexpr (MT >= 2) if (MT > 2 || lds_whole > 160 * 1024 || (force_tiled && waves <= 8)) {     // sub-tiled activation: no limit on KC
         if (waves > 8) return SJD_ERR_BAD_ARG;
+        static const bool sub8 = [] { const char *e = getenv("SJD_G1_SUB8"); return !(e && e[0] == '0'); }();      // (A/B aid: 0 = the 16-step kernel for every wave count)
+        if constexpr (MT > 2) if (waves == 4 && sub8) {        // 4-wave workgroups: 8-step sub-tiles, two workgroups per CU
+            const size_t lds_8 = (size_t)2 * MT * 8 * 1024;
+            (void)hipFuncSetAttribute((const void *)g1_skinny_gemm_tiled8<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_8);
+            hipLaunchKernelGGL((g1_skinny_gemm_tiled8<DT, MT>), grid, block, lds_8, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K,
+                               KC, n_tiles, step_major ? n_tiles : 1, tile0);
+            return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+        }
         const size_t lds_t = (size_t)2 * MT * G1_SUB * 1024;
         (void)hipFuncSetAttribute((const void *)g1_skinny_gemm_tiled<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
         hipLaunchKernelGGL((g1_skinny_gemm_tiled<DT, MT>), grid, block, lds_t, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC,

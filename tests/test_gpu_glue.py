@@ -129,7 +129,7 @@ def test_g1_skinny_gemm(dev, dtype, M, N, K, KC, waves, step_major):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,KC", [(128, 4096, 11008, 896), (96, 12288, 4096, 896), (128, 22016, 4096, 2048), (100, 512, 1376, 256),
                                         (128, 64, 96, 32), (128, 4096, 4096, 1040), (65, 256, 176, 64), (128, 6144, 4096, 512), (64, 6144, 4096, 2048)])
-@pytest.mark.parametrize("waves,step_major", [(8, True), (8, False), (6, False), (3, True)])
+@pytest.mark.parametrize("waves,step_major", [(8, True), (8, False), (6, False), (3, True), (4, True), (4, False)])
 def test_g1_skinny_gemm_three_and_four_row_tiles(dev, dtype, M, N, K, KC, waves, step_major):
     """65..128-row windows (three / four prompts per forward), and 64-row windows whose chunk does not fit in LDS (KC > 1280): the
     sub-tiled G1 (activation double-buffered through LDS 256 columns at a time) against an fp32 matmul; chunk lengths that are not whole

@@ -467,6 +467,10 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
 // requested before the MFMAs of the current one; every load is unconditional (a record past the chunk reads as zero through the wave's
 // buffer descriptor, an activation piece past it is clamped and zeroed); the k-steps past a ragged chunk's end are skipped by uniform branches.  Same MFMA
 // sequence per (tile, chunk, row tile) as g1_skinny_gemm: bit-identical planes.
+// Probe builds (-DT8_NOSTORE / -DT8_NOX / -DT8_NOMFMA, profiles/r3_g1_tiled8.txt): the partial planes cost 3-6 us of a 25-49 us launch, the
+// activation staging 6-7 us.  Two things measured against the planes and NOT kept: the tiles written through LDS as 16-byte row pieces
+// (16 stores per wave instead of 64: no gain -- it is not the address pipe) and non-temporal plane stores (q|k|v 28.7 -> 25.3 us, down
+// 25.0 -> 22.5 alone, but 5.098 -> 5.091 ms per step with four prompts: the consumer kernel pays for them).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t g1z_unit_rsrc(const unsigned char *first_record, unsigned bytes);
 template <int DT, int MT>
 __global__ __launch_bounds__(256, 2) void g1_skinny_gemm_tiled8(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,

@@ -544,7 +544,8 @@ class ChameleonBackbone(nn.Module):
         g1 = lambda x_, name, N_, K_: self._g1(li, x_, name, N_, K_)
         H, Hkv, D, hid, inter = self.n_heads, self.n_kv_heads, self.head_dim, self.args.hidden_size, self.args.intermediate_size
         params = getattr(self.attn, "params", None)
-        fuse_mlp = getattr(self, "gateup_fused", _GATEUP_FUSED_DEFAULT) and not self._pf_on and ops.gateup_silu_ok(T, inter, hid, cfg["gate_up"][0])
+        fuse_mlp = getattr(self, "gateup_fused", _GATEUP_FUSED_DEFAULT) and not self._pf_on and ops.gateup_silu_ok(T, inter, hid, cfg["gate_up"][0],
+                                                                                                                   isinstance(self._packed[0]["gate_up"], ops.PackedZ))
         # o / down with F1r as their tail (one launch each; the reducing kernel wants whole 512-column slices per workgroup pair: 8 waves)
         red = getattr(self, "reduce_fused", _REDUCE_FUSED_DEFAULT) and not self._pf_on
         raw = lambda name: not isinstance(self._packed[0][name], ops.PackedZ)        # (the reducing kernel streams the uncompressed packing)

@@ -861,9 +861,10 @@ __global__ __launch_bounds__(512) void g1_gateup_silu_tall(const unsigned short 
     // and ahead of the weights: they are cache hits and cost the staging nothing (first version: threads 0..31 did this first, +0.7 us).
     float ssv[8];
     {
+        const int rs_rows = ((M + 31) / 32) * 32;                 // F1r's slices are [rows padded to 32]: 96 for a 65..96-row window on the four-tile kernel
         const float *ssp = row_sumsq ? row_sumsq : reinterpret_cast<const float *>(x);
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq) ssv[qq] = ssp[(size_t)(row_sumsq ? min(qq, rs_slices - 1) : 0) * R + (threadIdx.x & (R - 1))];
+        for (int qq = 0; qq < 8; ++qq) ssv[qq] = ssp[(size_t)(row_sumsq ? min(qq, rs_slices - 1) : 0) * rs_rows + min((int)(threadIdx.x & (R - 1)), rs_rows - 1)];
     }
 #pragma unroll
     for (int u = 0; u < G1_UNROLL; ++u) cur[u] = __builtin_nontemporal_load(wu + (size_t)u * rs);      // first weight group right behind
@@ -1341,8 +1342,8 @@ extern "C" int sjd_gateup_silu_z(const void *x, const void *wz, const void *exc,
 template <int DT>
 static int g1s_launch(const void *x, const void *w_packed, void *y, int M, int I, int K, int step_major, const sjd_row_norm *rn, hipStream_t s)
 {
-    const int MT = M <= 32 ? 1 : 2;
-    const bool db = MT == 2 && K >= 2048;                          // double-buffered half-length phases: the fp16 / bf16 64-row kernel (see the kernel)
+    const int MT = M <= 32 ? 1 : M <= 64 ? 2 : 4;                  // (65..128 rows -- three / four prompts per forward -- run as four row tiles, K = 4096)
+    const bool db = MT >= 2 && K >= 2048;                          // double-buffered half-length phases: the fp16 / bf16 64-row kernel (see the kernel)
     const int SP = K / ((db ? 128 : 64) * MT);
     const dim3 grid(I / 64), block(512);
     const size_t lds_x = (size_t)(db ? 2 : 1) * MT * 2 * SP * 1024, lds_red = (size_t)8 * 32 * MT * 36 * sizeof(float);
@@ -1367,7 +1368,7 @@ static int g1s_launch(const void *x, const void *w_packed, void *y, int M, int I
     }
     SJD_G1S_CASE32(8) SJD_G1S_CASE32(16) SJD_G1S_CASE32(32) SJD_G1S_CASE32(64)
 #undef SJD_G1S_CASE32
-    SJD_G1S_CASE(8, 2, false) SJD_G1S_CASE(8, 2, true) SJD_G1S_CASE(16, 2, true)
+    SJD_G1S_CASE(8, 2, false) SJD_G1S_CASE(8, 2, true) SJD_G1S_CASE(16, 2, true) SJD_G1S_CASE(8, 4, true)
 #undef SJD_G1S_CASE
     return SJD_ERR_UNSUPPORTED;
 }
@@ -1381,7 +1382,7 @@ extern "C" int sjd_gateup_silu(const void *x, const void *w_packed, void *y, int
     if (!x || !w_packed || !y || M < 1 || I < 64 || K < 512) return SJD_ERR_BAD_ARG;
     if (row_norm && (!row_norm->sumsq || row_norm->slices < 1 || row_norm->hidden < 1)) return SJD_ERR_BAD_ARG;
     if (row_norm && row_norm->slices > 8) return SJD_ERR_UNSUPPORTED;      // the kernel sums one batch of eight 512-column slices
-    if (M > 64 || (I % 64) != 0 || !(K == 512 || K == 1024 || K == 2048 || K == 4096) || (M > 32 && K == 512)) return SJD_ERR_UNSUPPORTED;
+    if (M > 128 || (I % 64) != 0 || !(K == 512 || K == 1024 || K == 2048 || K == 4096) || (M > 32 && K == 512) || (M > 64 && K != 4096)) return SJD_ERR_UNSUPPORTED;
     if (dtype == SJD_DTYPE_BF16) return g1s_launch<SJD_DTYPE_BF16>(x, w_packed, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
     if (dtype == SJD_DTYPE_F16) return g1s_launch<SJD_DTYPE_F16>(x, w_packed, y, M, I, K, step_major, row_norm, (hipStream_t)stream);
     return SJD_ERR_UNSUPPORTED;

@@ -614,10 +614,12 @@ def silu_mul(gate_up, rows=None, dtype=None, row_norm=None):
     return y
 
 
-def gateup_silu_ok(T, inter, hidden, KC):
+def gateup_silu_ok(T, inter, hidden, KC, packed_z=False):
     """shapes kernel G1s serves (see sjd_gateup_silu): a <= 32-row window -- or a <= 64-row one (draft window 32 with CFG, two prompts per
-    forward) at hidden >= 1024 --, the gate|up weight packed in two K halves"""
-    return (T <= 32 or (T <= 64 and hidden >= 1024)) and hidden in (512, 1024, 2048, 4096) and 2 * KC == hidden and inter % 64 == 0
+    forward) at hidden >= 1024, or a <= 128-row one (three / four prompts per forward) at hidden 4096 over the uncompressed packing --,
+    the gate|up weight packed in two K halves"""
+    rows_ok = T <= 32 or (T <= 64 and hidden >= 1024) or (T <= 128 and hidden == 4096 and not packed_z)
+    return rows_ok and hidden in (512, 1024, 2048, 4096) and 2 * KC == hidden and inter % 64 == 0
 
 
 def gateup_silu(x, w_packed, inter, hidden, step_major=False, row_norm=None):

@@ -208,7 +208,8 @@ def test_g1_forward_matches_library_gemm_forward(dev):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("step_major", [False, True])
 @pytest.mark.parametrize("M,I,K", [(32, 11008, 4096), (17, 11008, 4096), (32, 14336, 4096), (32, 1408, 512), (5, 128, 1024), (32, 2752, 2048),
-                                   (64, 11008, 4096), (40, 14336, 4096), (64, 1408, 1024), (33, 2752, 2048)])      # 64-row windows: four staging phases
+                                   (64, 11008, 4096), (40, 14336, 4096), (64, 1408, 1024), (33, 2752, 2048),       # 64-row windows: four staging phases
+                                   (128, 11008, 4096), (96, 11008, 4096), (65, 2752, 4096), (100, 14336, 4096)])   # 65..128 rows: four row tiles
 @pytest.mark.parametrize("with_norm", [True, False])
 def test_g1_gateup_silu_matches_g1_then_f3(dev, dtype, step_major, M, I, K, with_norm):
     """G1s (the gate|up projection with SiLU * up as its epilogue, one launch) is BIT-IDENTICAL to G1 (two K halves) followed by F3 on the
@@ -293,9 +294,9 @@ def test_g1_reduce_epilogue_matches_g1_then_f1r(dev, dtype, M, N, K, KC, waves, 
 def test_g1_gateup_silu_refuses_what_it_does_not_serve(dev):
     import sjd_amd.ops as ops
     import sjd_amd._lib as L
-    assert not ops.gateup_silu_ok(65, 11008, 4096, 2048) and not ops.gateup_silu_ok(32, 11008, 4096, 1024) and not ops.gateup_silu_ok(32, 100, 4096, 2048)
+    assert ops.gateup_silu_ok(65, 11008, 4096, 2048) and not ops.gateup_silu_ok(65, 11008, 4096, 2048, packed_z=True) and not ops.gateup_silu_ok(129, 11008, 4096, 2048) and not ops.gateup_silu_ok(32, 11008, 4096, 1024) and not ops.gateup_silu_ok(32, 100, 4096, 2048)
     assert ops.gateup_silu_ok(64, 11008, 4096, 2048) and not ops.gateup_silu_ok(40, 128, 512, 256)
-    x = torch.zeros(70, 4096, dtype=torch.bfloat16, device=dev)
+    x = torch.zeros(130, 4096, dtype=torch.bfloat16, device=dev)
     wp = torch.zeros(2 * 128 * 4096, dtype=torch.bfloat16, device=dev)
     with pytest.raises(L.SjdLibraryError):
         ops.gateup_silu(x, wp, 128, 4096)

@@ -22,6 +22,7 @@ from . import ops
 
 class _Grammar:
     temperature = 1.0       # HF TemperatureLogitsWarper of the processor list (grammar_from_processors sets it): part of every rule
+    top_p = None            # HF TopPLogitsWarper of the processor list (GenerationConfig.top_p < 1): likewise, behind top-k and the temperature
 
     def start(self, ctx):
         self.reset()
@@ -150,17 +151,17 @@ class LuminaGrammar(_Grammar):
     def window_rules(self, n):
         _, ns, ne, since, g1, g2 = self.s
         k = self.image_top_k if ns == ne + 1 else self.text_top_k      # LP:195-198
-        T_ = self.temperature
+        T_, P_ = self.temperature, self.top_p
         if not (ns == ne + 1 and since >= 2):                           # LP:89-102
-            return [ops.make_rule((), -1, k, temperature=T_) for _ in range(n)]
+            return [ops.make_rule((), -1, k, P_, temperature=T_) for _ in range(n)]
         h, w = (g1 - 8804) * 2, (g2 - 8804) * 2                         # LP:107-111
         T = since - 2                                                   # tokens after <start> h w
         l1, l2 = w + 1, (w + 1) * h + 1
-        trio = self._body_rules.get((k, T_))
+        trio = self._body_rules.get((k, T_, P_))
         if trio is None:                                                # the three rules of an image body, made once per top-k
             rng = ((self.img_lo, self.img_hi),)
-            trio = self._body_rules[(k, T_)] = (ops.make_rule(rng, -1, k, temperature=T_), ops.make_rule(rng, self.eol_id, k, temperature=T_),
-                                                ops.make_rule(rng, self.end_id, k, temperature=T_))
+            trio = self._body_rules[(k, T_, P_)] = (ops.make_rule(rng, -1, k, P_, temperature=T_), ops.make_rule(rng, self.eol_id, k, P_, temperature=T_),
+                                                    ops.make_rule(rng, self.end_id, k, P_, temperature=T_))
         rules = [trio[0]] * n
         if l1 > 0:
             for j in range((-(T + 1)) % l1, n, l1):                     # rows with (T + 1 + j) % l1 == 0
@@ -251,7 +252,7 @@ class Emu3Grammar(_Grammar):
         if T + n > base + 3:                               # JE:118-123, python slice semantics kept
             for j in range(n)[base + 3 - T:]:
                 forced[j] = self.pad
-        return [ops.make_rule((self.vis,), f, self.top_k, temperature=self.temperature) for f in forced]
+        return [ops.make_rule((self.vis,), f, self.top_k, self.top_p, temperature=self.temperature) for f in forced]
 
 
 class AnoleGrammar(_Grammar):
@@ -337,5 +338,5 @@ class AnoleGrammar(_Grammar):
                 ranges.append((lo, hi))
         if not ranges:
             raise ValueError("Anole grammar masks every token")
-        r = ops.make_rule(ranges, -1, self.top_k, temperature=self.temperature)
+        r = ops.make_rule(ranges, -1, self.top_k, self.top_p, temperature=self.temperature)
         return [r for _ in range(n)]

@@ -196,8 +196,8 @@ def hf_generate(model, inputs=None, generation_config=None, logits_processor=Non
     ML:406-411): the generation length (max_new_tokens wins over max_length), EOS / max-length stopping criteria, the user's logits
     processors followed by a TopKLogitsWarper when `generation_config.top_k` is set, then
     `model._sample(input_ids, processors, criteria, generation_config, synced_gpus=False, streamer, attention_mask=, neg_input_ids=)`.
-    `generation_config.temperature != 1` becomes a TemperatureLogitsWarper in front of that TopKLogitsWarper, as in HF.  Anything that
-    changes the distribution and has no kernel rule (top_p via the config, beams, greedy) raises."""
+    `generation_config.temperature != 1` becomes a TemperatureLogitsWarper in front of that TopKLogitsWarper and `top_p < 1` a
+    TopPLogitsWarper behind it, as in HF.  Anything that changes the distribution and has no kernel rule (beams, greedy) raises."""
     import copy
     from transformers import GenerationConfig
     from transformers.generation.logits_process import LogitsProcessorList
@@ -211,8 +211,6 @@ def hf_generate(model, inputs=None, generation_config=None, logits_processor=Non
             setattr(gc, k, kwargs.pop(k))
     if not getattr(gc, "do_sample", False) or (getattr(gc, "num_beams", 1) or 1) != 1:
         raise NotImplementedError("the SJD hot path samples (do_sample=True, num_beams=1)")
-    if (getattr(gc, "top_p", None) or 1.0) != 1.0:
-        raise NotImplementedError("top_p through GenerationConfig is not wired (the drivers pass TopPLogitsWarper3d themselves or use 1.0)")
     P = ids.shape[1]
     if getattr(gc, "max_new_tokens", None) is not None:
         gc.max_length = P + int(gc.max_new_tokens)
@@ -228,6 +226,9 @@ def hf_generate(model, inputs=None, generation_config=None, logits_processor=Non
         procs.append(TemperatureLogitsWarper(float(gc.temperature)))
     if getattr(gc, "top_k", None):
         procs.append(TopKLogitsWarper(int(gc.top_k)))
+    if (getattr(gc, "top_p", None) or 1.0) < 1.0:              # ... then top-k, then top-p
+        from .logit_processor_3dim import TopPLogitsWarper
+        procs.append(TopPLogitsWarper(float(gc.top_p)))
     crit = list(stopping_criteria or [])
     if getattr(gc, "eos_token_id", None) is not None:
         crit.append(_EosStop(gc.eos_token_id))

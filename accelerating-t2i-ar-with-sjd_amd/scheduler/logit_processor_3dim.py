@@ -70,6 +70,20 @@ class TopKLogitsWarper(_Descriptor):
         self.top_k = max(int(top_k), min_tokens_to_keep)
 
 
+class TopPLogitsWarper(_Descriptor):
+    """Stand-in for transformers' TopPLogitsWarper (same attributes; the HF object is accepted as well): what HF's generate() appends behind
+    the user's processors, the temperature and top-k when GenerationConfig.top_p < 1.  Same rule as TopPLogitsWarper3d (LP:207-250 is HF's
+    warper with a window axis)."""
+
+    def __init__(self, top_p: float, filter_value: float = -float("Inf"), min_tokens_to_keep: int = 1):
+        top_p = float(top_p)
+        if top_p < 0 or top_p > 1.0:
+            raise ValueError(f"`top_p` has to be a float > 0 and < 1, but is {top_p}")          # HF's own check
+        if not isinstance(min_tokens_to_keep, int) or min_tokens_to_keep != 1:
+            raise NotImplementedError("min_tokens_to_keep != 1 (the kernels keep the top token, as HF's default does)")
+        self.top_p, self.min_tokens_to_keep = top_p, min_tokens_to_keep
+
+
 class TemperatureLogitsWarper(_Descriptor):
     """Stand-in for transformers' TemperatureLogitsWarper (same attribute; the HF object is accepted as well): scores / temperature, which
     HF's generate() appends behind the user's processors when GenerationConfig.temperature != 1"""
@@ -123,6 +137,16 @@ def grammar_from_processors(processors, prompt_len=None, max_length=None):
             raise NotImplementedError("more than one TemperatureLogitsWarper in the processor list")
         g = grammar_from_processors([p for p in procs if p is not temps[0]], prompt_len=prompt_len, max_length=max_length)
         g.temperature = float(temps[0].temperature)
+        return g
+    tops = [p for p in procs if type(p).__name__ == "TopPLogitsWarper"]
+    if tops:                      # HF's top-p warper behind the family's own processors: one more scalar of every rule (K2 / K4 apply it last)
+        if len(tops) > 1 or any(type(p).__name__ == "TopPLogitsWarper3d" for p in procs):
+            raise NotImplementedError("more than one top-p warper in the processor list")
+        if int(getattr(tops[0], "min_tokens_to_keep", 1)) != 1:
+            raise NotImplementedError("TopPLogitsWarper(min_tokens_to_keep != 1)")
+        g = grammar_from_processors([p for p in procs if p is not tops[0]], prompt_len=prompt_len, max_length=max_length)
+        if float(tops[0].top_p) < 1.0:
+            g.top_p = float(tops[0].top_p)
         return g
     names = [type(p).__name__ for p in procs]
     if len(procs) >= 1 and isinstance(procs[0], MultiTokensVLLogitsProcessor):

@@ -82,14 +82,17 @@ def rule(ranges=(), forced=-1, top_k=0, top_p=None, temperature=1.0):
     return r
 
 
-def tempered(rules_fn, temperature):
-    """rules_fn(ctx, n) -> the same rules with HF's TemperatureLogitsWarper(temperature) appended to the processor list (it follows the
-    user's processors in transformers' generate(); see sjd_oracle.c)"""
+def tempered(rules_fn, temperature, top_p=None):
+    """rules_fn(ctx, n) -> the same rules with HF's TemperatureLogitsWarper(temperature) -- and, with top_p, HF's TopPLogitsWarper(top_p) --
+    appended to the processor list (the warpers follow the user's processors in transformers' generate(): temperature, top-k, top-p; see
+    sjd_oracle.c)"""
     def fn(ctx, n):
         out = []
         for r in rules_fn(ctx, n):
             c = RowRule.from_buffer_copy(r)
             c.temperature = float(temperature)
+            if top_p is not None:
+                c.top_p_thr = top_p_threshold(top_p)
             out.append(c)
         return out
     return fn

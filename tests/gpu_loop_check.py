@@ -154,7 +154,7 @@ def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7,
 @torch.no_grad()
 def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, scheme="speculative_jacobi", P=12,
                                 embed_token_scale=0.25, kv_heads=4, l=3, r=None, dtype=torch.bfloat16,
-                                use_graph=False, fused=True, gemm="torch", fp8_kv=False, init_scheme="random", temperature=1.0):
+                                use_graph=False, fused=True, gemm="torch", fp8_kv=False, init_scheme="random", temperature=1.0, top_p=None):
     import sjd_amd.ops as ops
     import sjd_amd.synthetic as synthetic
     from sjd_amd.engine import SJDEngine, SJDConfig, WindowSpec
@@ -185,8 +185,9 @@ def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, 
     eng.hook = rec
     gram = LuminaGrammar(2000, 10)
     gram.temperature = float(temperature)          # HF's TemperatureLogitsWarper of the processor list (grammar_from_processors sets it)
+    gram.top_p = top_p                             # ... and its TopPLogitsWarper (GenerationConfig.top_p < 1)
     seq, stats = eng.decode(prompt[0].tolist(), spec, gram, cfg)
-    seq_ref, tr, checks = _replay(rec, prompt[0].tolist(), O.tempered(lambda c, n: O.lumina_rules(c, n, 2000, 10), temperature), _loop_cfg(cfg), V,
+    seq_ref, tr, checks = _replay(rec, prompt[0].tolist(), O.tempered(lambda c, n: O.lumina_rules(c, n, 2000, 10), temperature, top_p), _loop_cfg(cfg), V,
                                   no_cfg_fn=O.lumina_force_no_cfg, device=device, grid_fn=O.lumina_grid)
     assert seq == seq_ref, "token sequences differ"
     assert stats.matched == tr.matched and stats.nfe == len(tr.matched)

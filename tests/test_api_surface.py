@@ -73,6 +73,20 @@ def test_processor_descriptors_and_grammar_mapping():
         grammar_from_processors([object()])
     with pytest.raises(RuntimeError):
         vl(None, None)
+    # GenerationConfig.top_p: HF's TopPLogitsWarper (the HF object or the stand-in) behind any family's processors = a scalar of every rule
+    from transformers.generation.logits_process import TopPLogitsWarper as HFTopP
+    from scheduler.logit_processor_3dim import TopPLogitsWarper, TemperatureLogitsWarper
+    for tp in (HFTopP(top_p=0.8), TopPLogitsWarper(0.8)):
+        g = grammar_from_processors([vl, MultiTokensInterleavedTopKLogitsWarper(2000, 10, 8197, 8196), TemperatureLogitsWarper(0.9), tp])
+        assert isinstance(g, G.LuminaGrammar) and g.top_p == 0.8 and g.temperature == 0.9
+        g.start([5, 6, 7])
+        r = g.window_rules(3)[0]
+        assert abs(r.top_p_thr - (1.0 - 0.8)) < 1e-6 and abs(r.temperature - 0.9) < 1e-6 and r.top_k == 10
+    assert grammar_from_processors([vl, HFTopP(top_p=1.0)]).top_p is None
+    with pytest.raises(NotImplementedError):
+        grammar_from_processors([TopKLogitsWarper(10), TopPLogitsWarper3d(0.9), HFTopP(top_p=0.8)])
+    with pytest.raises(NotImplementedError):
+        TopPLogitsWarper(0.8, min_tokens_to_keep=2)
 
 
 def test_get_double_cfg_input_ids_and_emu3_inputs():
@@ -187,7 +201,8 @@ def test_hf_generate_builds_criteria_and_topk_then_calls_sample():
     # temperature: a TemperatureLogitsWarper behind the user's processors and in front of the top-k warper, as HF orders its warpers
     hf_generate(M(), ids, GenerationConfig(do_sample=True, temperature=0.7, top_k=50, max_new_tokens=4), logits_processor=[Proc()])
     assert seen["procs"] == ["Proc", "TemperatureLogitsWarper", "TopKLogitsWarper"]
-    with pytest.raises(NotImplementedError):
-        hf_generate(M(), ids, GenerationConfig(do_sample=True, top_p=0.9, max_new_tokens=4))
+    # top_p: HF's TopPLogitsWarper behind temperature and top-k
+    hf_generate(M(), ids, GenerationConfig(do_sample=True, temperature=0.7, top_k=50, top_p=0.9, max_new_tokens=4), logits_processor=[Proc()])
+    assert seen["procs"] == ["Proc", "TemperatureLogitsWarper", "TopKLogitsWarper", "TopPLogitsWarper"]
     with pytest.raises(NotImplementedError):
         hf_generate(M(), ids, GenerationConfig(do_sample=False, max_new_tokens=4))

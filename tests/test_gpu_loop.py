@@ -99,6 +99,16 @@ def test_lumina_loop_with_temperature(temperature, use_graph, gemm):
     assert r["tokens"] >= 100 and r["last"] == 8196
 
 
+@pytest.mark.parametrize("top_p,temperature,use_graph,gemm", [(0.9, 1.0, True, "sjd"), (0.6, 0.8, False, "torch")])
+def test_lumina_loop_with_config_top_p(top_p, temperature, use_graph, gemm):
+    """GenerationConfig.top_p < 1 through the whole loop (it raised before): HF's TopPLogitsWarper behind the Lumina grammar, its top-k and
+    the temperature as one more scalar of every window and residual rule, teacher-forced against the oracle (whose top-p path is pinned to the
+    reference's TopPLogitsWarper3d vectors and to transformers' TopPLogitsWarper, tests/test_oracle_golden.py)."""
+    from tests.gpu_loop_check import teacher_forced_lumina_check
+    r = teacher_forced_lumina_check(temperature=temperature, top_p=top_p, use_graph=use_graph, gemm=gemm, hg=5, wg=5, seed=17)
+    assert r["tokens"] >= 100 and r["last"] == 8196
+
+
 @pytest.mark.parametrize("init_scheme,n_prompts,use_graph", [("repeat_horizon", 2, True), ("sample_horizon", 3, True), ("sample_horizon", 2, False)])
 def test_batch_engine_spatial_init(init_scheme, n_prompts, use_graph):
     """multi_token_init_scheme 'repeat_horizon' / 'sample_horizon' in the several-prompts-per-forward engine (round 3: it raised before):

@@ -248,3 +248,24 @@ def test_loop_lumina(golden_dir):
         check_trace(d, name, tr)
         assert seq == d[f"{name}.sequence"][0].tolist(), name
         assert len(tr.matched) == m["nfe"]
+
+
+def test_top_p_rule_is_hf_top_p_warper():
+    """GenerationConfig.top_p reaches the kernels as the rule scalar TopPLogitsWarper3d uses (reference LP:207-250 = HF's TopPLogitsWarper
+    with a window axis).  Pinned here against the third-party warper itself (transformers, the version installed): after a top-k of 50 and a
+    temperature, the set of tokens the oracle gives a non-zero probability is the set HF's TopKLogitsWarper -> TopPLogitsWarper leaves
+    finite, and the probabilities are the softmax over that set."""
+    from transformers.generation.logits_process import TopKLogitsWarper, TopPLogitsWarper, TemperatureLogitsWarper
+    g = torch.Generator().manual_seed(7)
+    for V, top_k, top_p, T in ((4096, 50, 0.8, 1.0), (8192, 2000, 0.95, 0.7), (1000, 0, 0.5, 1.3), (512, 5, 0.999, 1.0)):
+        logits = (torch.randn(6, V, generator=g) * 3.0).float()
+        s = TemperatureLogitsWarper(T)(None, logits.clone()) if T != 1.0 else logits.clone()
+        if top_k:
+            s = TopKLogitsWarper(top_k)(None, s)
+        s = TopPLogitsWarper(top_p)(None, s)
+        want = torch.softmax(s, dim=-1).numpy()
+        rules = [O.rule((), -1, top_k, top_p, temperature=T) for _ in range(6)]
+        noise = np.ones((6, V), dtype=np.float32)
+        toks, probs = O.logits_to_probs_sample(logits.numpy(), None, 1.0, rules, noise)
+        assert ((probs > 0) == (want > 0)).all(), (V, top_k, top_p, T)
+        np.testing.assert_allclose(probs, want, atol=P_ATOL, rtol=P_RTOL)

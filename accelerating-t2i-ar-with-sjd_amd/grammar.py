@@ -256,13 +256,20 @@ class Emu3Grammar(_Grammar):
 
 
 class AnoleGrammar(_Grammar):
-    """image-only multimodal mode; every window row gets the mask of the ACCEPTED prefix (the reference's 3d
-    processors use input_ids.shape[1] with no per-row offset)."""
+    """The restricted multimodal modes of the Anole pipeline (JA:178-260): "image-only" (the SJD image path), "interleaved-text-image"
+    (the image-window processors without the global suppression: text outside an image, image ids inside) and "text-only" (image ids and
+    the begin / end-of-image tokens suppressed).  Every window row gets the mask of the ACCEPTED prefix (the reference's 3d processors
+    use input_ids.shape[1] with no per-row offset)."""
 
     def __init__(self, vocab_size, prompt_len, max_length, image_seq_length, boi=8197, eoi=8196, eos=2, img_lo=4,
-                 img_hi=8196, top_k=2000):
+                 img_hi=8196, top_k=2000, mode="image-only"):
+        if mode not in ("image-only", "interleaved-text-image", "text-only"):
+            raise ValueError(f"AnoleGrammar mode {mode!r}")
+        if mode != "image-only" and not (img_hi == eoi and boi == eoi + 1 and vocab_size):
+            raise NotImplementedError("text rows need the Chameleon id layout (image ids, <eoi>, <boi> adjacent) and the vocabulary size")
         self.V, self.prompt_len, self.max_length, self.L = vocab_size, prompt_len, max_length, image_seq_length
         self.boi, self.eoi, self.eos, self.img_lo, self.img_hi, self.top_k = boi, eoi, eos, img_lo, img_hi, top_k
+        self.mode = mode
         self.reset()
 
     def reset(self):
@@ -287,6 +294,8 @@ class AnoleGrammar(_Grammar):
         # are allowed, whatever the position: as long as that holds for every context length a residual rule is evaluated at
         # (cur .. cur + n - 2) and no draft is a <boi>, all of them are the window's rule
         cur, n, L = len(self.ctx), len(win), self.L
+        if self.mode == "text-only":                 # a static mask
+            return list(rules[:n - 1]) if n >= 2 else None
         if not self.boi_at or n < 2:
             return None
         b = self.boi_at[-1]
@@ -317,7 +326,7 @@ class AnoleGrammar(_Grammar):
                 ok = False
             if t == self.boi and not (self.max_length - L - 1 > cur):   # 3.
                 ok = False
-            if t == self.eos and self.prompt_len <= cur <= self.prompt_len + 1:   # 5.
+            if t == self.eos and self.mode == "image-only" and self.prompt_len <= cur <= self.prompt_len + 1:   # 5. (image-only)
                 ok = False
             if ok:
                 allowed.add(t)
@@ -325,11 +334,21 @@ class AnoleGrammar(_Grammar):
         return img_ok, sorted(allowed)
 
     def window_rules(self, n):
+        if self.mode == "text-only":                 # JA:178-189: everything but image ids, <boi>, <eoi>
+            r = ops.make_rule(((0, self.img_lo), (self.boi + 1, self.V)) if self.img_lo > 0 else ((self.boi + 1, self.V),), -1, self.top_k,
+                              self.top_p, temperature=self.temperature)
+            return [r for _ in range(n)]
         img_ok, specials = self._allowed()
         ranges = []
         pts = [(t, t + 1) for t in specials]
         if img_ok:
             pts.append((self.img_lo, self.img_hi))
+        if self.mode == "interleaved-text-image":    # no global suppression: outside an image window every text id is allowed as well
+            cur, L = len(self.ctx), self.L
+            at_offset = cur >= L + 1 and self.ctx[-(L + 1)] == self.boi
+            in_window = bool(self.boi_at) and self.boi_at[-1] >= cur - min(L, cur) and min(L, cur) > 0
+            if not at_offset and not in_window:
+                pts += [(0, self.img_lo), (self.boi + 1, self.V)] if self.img_lo > 0 else [(self.boi + 1, self.V)]
         pts.sort()
         for lo, hi in pts:                           # merge adjacent intervals
             if ranges and lo <= ranges[-1][1]:

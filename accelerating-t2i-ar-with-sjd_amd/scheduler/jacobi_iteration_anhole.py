@@ -1,5 +1,5 @@
-"""Mirror of reference scheduler/jacobi_iteration_anhole.py (Anole / HF-Chameleon adapter): builds the image-only
-processor list of JA:194-232 from the 3d descriptor classes and installs the SJD sampler."""
+"""Mirror of reference scheduler/jacobi_iteration_anhole.py (Anole / HF-Chameleon adapter): builds the processor list of the
+requested multimodal generation mode (JA:178-266) from the 3d descriptor classes and installs the SJD sampler."""
 import torch
 
 from .jacobi_iteration_lumina_mgpt import renew_sampler, renew_backbone, hf_generate
@@ -66,11 +66,24 @@ def renew_pipeline_anole(model_class):
                 procs = image_only_processors(self.vocab_size, P, max_length, L_img, self.image_token_ids, self.boi_token_id,
                                               self.eoi_token_id, self.eos_token_id, device=ids.device)
                 procs = type(procs)(list(logits_processor or []) + list(procs))
+            elif mode == "text-only":                  # JA:178-189
+                from transformers.generation.logits_process import LogitsProcessorList
+                procs = LogitsProcessorList(list(logits_processor or []) + [SuppressTokensLogitsProcessor3d(
+                    suppress_tokens=list(self.image_token_ids) + [self.boi_token_id, self.eoi_token_id], device=ids.device)])
+            elif mode == "interleaved-text-image":     # JA:233-260: the image-window processors without the global suppression
+                from transformers.generation.logits_process import LogitsProcessorList
+                procs = LogitsProcessorList(list(logits_processor or []) + [
+                    AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(trigger_token_id=self.boi_token_id, allowed_token_ids=[self.eoi_token_id],
+                                                                     offset=L_img + 1, exclusive=True, device=ids.device),
+                    AllowOnlyTokensInRelativeWindowLogitsProcessor3d(trigger_token_id=self.boi_token_id, allowed_token_ids=list(self.image_token_ids),
+                                                                     window_width=L_img, exclusive=True, device=ids.device),
+                    SuppressTokensInIndexRangeLogitsProcessor3d(suppress_tokens=[self.boi_token_id], start_index=max_length - L_img - 1,
+                                                                device=ids.device)])
             elif mode == "unrestricted":
                 procs = logits_processor
             else:
-                raise NotImplementedError(f"multimodal_generation_mode={mode!r}: only the image generation path is an SJD hot path "
-                                          "('image-only', or 'unrestricted' with your own processors)")
+                raise ValueError(f"Unknown multimodal generation mode: {mode}. Please choose one of 'unrestricted', 'text-only', 'image-only', "
+                                 "or 'interleaved-text-image'.")          # JA:263-266
             kwargs.setdefault("do_sample", True)
             kwargs.pop("input_ids", None)
             return hf_generate(self, ids, generation_config, logits_processor=procs, **kwargs)

@@ -319,7 +319,7 @@ def renew_sampler(model_class):
             do_cfg = bool(self.do_cfg) and (self.guidance_scale != 1)                                  # JL:1002-1005
             procs = list(logits_processor or []) + list(logits_warper or [])
             eos, max_len = _stopping_to_limits(stopping_criteria, generation_config)
-            grammar = grammar_from_processors(procs, prompt_len=input_ids.shape[1], max_length=max_len)
+            grammar = grammar_from_processors(procs, prompt_len=input_ids.shape[1], max_length=max_len, vocab_size=getattr(self, "vocab_size", None))
             if getattr(grammar, "V", 0) is None:
                 grammar.V = self.vocab_size
             spec = self._sjd_window_spec(input_ids, do_cfg, model_kwargs)

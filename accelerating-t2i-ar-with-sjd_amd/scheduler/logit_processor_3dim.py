@@ -128,14 +128,14 @@ def get_double_cfg_input_ids(input_ids, neg_input_ids, pad_category):
     return torch.cat(rows, dim=0)
 
 
-def grammar_from_processors(processors, prompt_len=None, max_length=None):
+def grammar_from_processors(processors, prompt_len=None, max_length=None, vocab_size=None):
     """LogitsProcessorList -> integer grammar driving kernels K2/K4.  Raises for processors this engine does not know."""
     procs = list(processors)
     temps = [p for p in procs if type(p).__name__ == "TemperatureLogitsWarper"]
     if temps:                     # scale-invariant with respect to every other processor here (masks, top-k): one scalar of the rules
         if len(temps) > 1:
             raise NotImplementedError("more than one TemperatureLogitsWarper in the processor list")
-        g = grammar_from_processors([p for p in procs if p is not temps[0]], prompt_len=prompt_len, max_length=max_length)
+        g = grammar_from_processors([p for p in procs if p is not temps[0]], prompt_len=prompt_len, max_length=max_length, vocab_size=vocab_size)
         g.temperature = float(temps[0].temperature)
         return g
     tops = [p for p in procs if type(p).__name__ == "TopPLogitsWarper"]
@@ -144,7 +144,7 @@ def grammar_from_processors(processors, prompt_len=None, max_length=None):
             raise NotImplementedError("more than one top-p warper in the processor list")
         if int(getattr(tops[0], "min_tokens_to_keep", 1)) != 1:
             raise NotImplementedError("TopPLogitsWarper(min_tokens_to_keep != 1)")
-        g = grammar_from_processors([p for p in procs if p is not tops[0]], prompt_len=prompt_len, max_length=max_length)
+        g = grammar_from_processors([p for p in procs if p is not tops[0]], prompt_len=prompt_len, max_length=max_length, vocab_size=vocab_size)
         if float(tops[0].top_p) < 1.0:
             g.top_p = float(tops[0].top_p)
         return g
@@ -171,6 +171,31 @@ def grammar_from_processors(processors, prompt_len=None, max_length=None):
             raise NotImplementedError("Emu3 visual token ids must form one contiguous range")
         return G.Emu3Grammar(h.height, h.width, vis[0], len(vis), h.img_token, h.eoi_token, h.eos_token, h.eol_token,
                              h.eof_token, h.pad_token, top_k=k)
+    if names and names[0] == "SuppressTokensLogitsProcessor3d" and all(n == "TopKLogitsWarper" for n in names[1:]):
+        # Anole "text-only" (JA:178-189): image ids + <boi> + <eoi> suppressed -- the Chameleon id layout (image ids, <eoi>, <boi> adjacent)
+        sup = sorted(procs[0].suppress_tokens)
+        if len(sup) < 3 or sup != list(range(sup[0], sup[0] + len(sup))):
+            raise NotImplementedError("text-only suppression must be one contiguous id range (image ids, <eoi>, <boi>)")
+        if vocab_size is None:
+            raise NotImplementedError("the text-only grammar needs the vocabulary size (grammar_from_processors(..., vocab_size=))")
+        k = next((int(p.top_k) for p in procs[1:]), 0)
+        return G.AnoleGrammar(vocab_size=vocab_size, prompt_len=prompt_len or 0, max_length=max_length or 0, image_seq_length=1,
+                              boi=sup[-1], eoi=sup[-2], img_lo=sup[0], img_hi=sup[-2], top_k=k, mode="text-only")
+    if names and names[0] == "AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d" and "SuppressTokensAtBeginLogitsProcessor3d" not in names:
+        # Anole "interleaved-text-image" (JA:233-260): the image-window processors without the global suppression
+        at, win = procs[0], procs[1]
+        rng = next(p for p in procs if type(p) is SuppressTokensInIndexRangeLogitsProcessor3d)
+        extra = [n for n in names[2:] if n not in ("SuppressTokensInIndexRangeLogitsProcessor3d", "TopKLogitsWarper")]
+        if extra:
+            raise NotImplementedError(f"unsupported logits processors in the interleaved Anole list: {extra}")
+        if vocab_size is None:
+            raise NotImplementedError("the interleaved grammar needs the vocabulary size (grammar_from_processors(..., vocab_size=))")
+        k = next((int(p.top_k) for p in procs if type(p).__name__ == "TopKLogitsWarper"), 0)
+        img = sorted(win.allowed_token_ids)
+        L_img = win.window_width
+        return G.AnoleGrammar(vocab_size=vocab_size, prompt_len=prompt_len or 0, max_length=rng.start_index + L_img + 1, image_seq_length=L_img,
+                              boi=at.trigger_token_id, eoi=at.allowed_token_ids[0], img_lo=img[0], img_hi=img[-1] + 1, top_k=k,
+                              mode="interleaved-text-image")
     if names and names[0] == "AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d":
         at, win = procs[0], procs[1]
         begin = next(p for p in procs if isinstance(p, SuppressTokensAtBeginLogitsProcessor3d))

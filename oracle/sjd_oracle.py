@@ -235,14 +235,21 @@ def _mask_to_ranges(allowed):
 
 
 def anole_rules(ctx, n, V, prompt_len, max_length, image_seq_length, boi=8197, eoi=8196, eos=2, img_lo=4, img_hi=8196,
-                top_k=2000):
-    """image-only mode.  NB: the reference evaluates these on the accepted prefix only, so every window row gets
-    the same mask (logit_processor_3dim.py:242-256, 280-286, 323-338: input_ids.shape[1], no per-row offset)."""
+                top_k=2000, mode="image-only"):
+    """The restricted modes of the Anole pipeline (jacobi_iteration_anhole.py:178-260): "image-only" = processors 1-5 below,
+    "interleaved-text-image" = 1-3, "text-only" = one SuppressTokens(image ids + boi + eoi).  NB: the reference evaluates these on the
+    accepted prefix only, so every window row gets the same mask (logit_processor_3dim.py:242-256, 280-286, 323-338:
+    input_ids.shape[1], no per-row offset)."""
     ctx = [int(t) for t in ctx]
     cur = len(ctx)
     masked = np.zeros(V, dtype=bool)
     img = np.zeros(V, dtype=bool)
     img[img_lo:img_hi] = True
+    if mode == "text-only":
+        masked |= img
+        masked[[boi, eoi]] = True
+        return [rule(_mask_to_ranges(~masked), -1, top_k) for _ in range(n)]
+    assert mode in ("image-only", "interleaved-text-image"), mode
     # 1. AllowOnlyTokensAtRelativeOffset(trigger=boi, allowed=[eoi], offset=L+1, exclusive)
     offset = image_seq_length + 1
     only_eoi = np.zeros(V, dtype=bool)
@@ -262,13 +269,14 @@ def anole_rules(ctx, n, V, prompt_len, max_length, image_seq_length, boi=8197, e
     # 3. SuppressTokensInIndexRange([boi], start=max_length-L-1, end=inf)
     if not (max_length - image_seq_length - 1 > cur):
         masked[boi] = True
-    # 4. SuppressTokens(everything but image ids, eos, boi, eoi)
-    allowed4 = img.copy()
-    allowed4[[eos, boi, eoi]] = True
-    masked |= ~allowed4
-    # 5. SuppressTokensAtBegin([eos], begin_index=prompt_len): active for cur in {begin, begin+1}
-    if prompt_len <= cur <= prompt_len + 1:
-        masked[eos] = True
+    if mode == "image-only":
+        # 4. SuppressTokens(everything but image ids, eos, boi, eoi)
+        allowed4 = img.copy()
+        allowed4[[eos, boi, eoi]] = True
+        masked |= ~allowed4
+        # 5. SuppressTokensAtBegin([eos], begin_index=prompt_len): active for cur in {begin, begin+1}
+        if prompt_len <= cur <= prompt_len + 1:
+            masked[eos] = True
     ranges = _mask_to_ranges(~masked)
     return [rule(ranges, -1, top_k) for _ in range(n)]
 

@@ -14,6 +14,7 @@ Fixtures
   fn_logits2tokens_llamagen.npz TopKLogitsWarper + TopPLogitsWarper3d   (LS:458-470, LP:355-419)
   fn_emu3_grammar.npz           EOLLogitProcessor3d + TopK(2048)        (JE:41-151)
   fn_anole_grammar.npz          Anole image-only 3d processors          (JA:194-232, LP:207-353)
+  fn_anole_modes.npz            Anole text-only / interleaved processors (JA:178-189, 233-260)
   fn_speculative_sampler.npz    SpeculativeSampler.__call__             (JL:247-315)
   fn_reguess.npz                get_multi_token_for_preparation('random') (JL:470-514)
   fn_temperature.npz            the same two with HF's TemperatureLogitsWarper in the processor list (GenerationConfig.temperature != 1)
@@ -245,6 +246,55 @@ def gen_fn_anole_grammar():
     out["cols"] = sample_cols(V).numpy()
     np.savez_compressed(os.path.join(HERE, "fn_anole_grammar.npz"), **out)
     print("fn_anole_grammar ok")
+
+
+def gen_fn_anole_modes():
+    """The two other restricted modes of the Anole pipeline, processors exactly as JA:178-189 ("text-only") and JA:233-260
+    ("interleaved-text-image") build them (+ the TopKLogitsWarper HF's generate appends), through the reference's sampling_logits2tokens."""
+    V = 9216
+    img_ids = list(range(4, 8196))
+    boi, eoi, eos = 8197, 8196, 2
+    L = 24
+    out, meta = {}, []
+    ci = 0
+    for mode in ("text-only", "interleaved-text-image"):
+        # contexts: no <boi> yet / <boi> is the last token / mid image / the <eoi> slot / one token after the image / no room for an image
+        for n_after_boi, tail, nrows, prompt_len, max_length in [(-1, 0, 4, 6, 60), (0, 0, 16, 6, 60), (10, 0, 16, 6, 60), (24, 0, 4, 6, 60),
+                                                                  (24, 2, 16, 6, 60), (-1, 0, 8, 40, 60)]:
+            g = torch.Generator().manual_seed(7100 + ci)
+            ctx = torch.randint(8900, 9200, (1, prompt_len), generator=g)
+            if n_after_boi >= 0:
+                ctx = torch.cat([ctx, torch.tensor([[boi]]), torch.randint(4, 8196, (1, n_after_boi), generator=g)], dim=1)
+            if tail:
+                ctx = torch.cat([ctx, torch.tensor([[eoi]]), torch.randint(8900, 9200, (1, tail - 1), generator=g)], dim=1)
+            if mode == "text-only":
+                procs = [LP.SuppressTokensLogitsProcessor3d(suppress_tokens=img_ids + [boi, eoi])]
+            else:
+                procs = [LP.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(trigger_token_id=boi, allowed_token_ids=[eoi], offset=L + 1, exclusive=True),
+                         LP.AllowOnlyTokensInRelativeWindowLogitsProcessor3d(trigger_token_id=boi, allowed_token_ids=img_ids, window_width=L, exclusive=True),
+                         LP.SuppressTokensInIndexRangeLogitsProcessor3d(suppress_tokens=[boi], start_index=max_length - L - 1)]
+            procs = LogitsProcessorList(procs + [TopKLogitsWarper(top_k=50)])
+            logits = torch.randn(2, nrows, V, generator=g) * 3.0
+            gen = torch.Generator().manual_seed(8100 + ci)
+            toks, probs = JL.sampling_logits2tokens(
+                logits, ctx, torch.ones(1, dtype=torch.long), None, output_token_num=nrows,
+                logits_processor=procs, logits_warper=None, do_sample=True, has_eos_stopping_criteria=False,
+                do_cfg=True, guidance_scale=3.0, generator=gen, is_force_no_cfg=False)
+            name = f"m{ci}"
+            cols = sample_cols(V)
+            out[f"{name}.ctx"] = ctx.numpy()
+            out[f"{name}.tokens"] = toks.numpy()
+            out[f"{name}.nnz"] = (probs[0] > 0).sum(-1).numpy()
+            out[f"{name}.pmax"] = probs[0].max(-1).values.numpy()
+            out[f"{name}.p_cols"] = probs[0][:, cols].numpy()
+            meta.append(dict(name=name, mode=mode, V=V, nrows=nrows, prompt_len=prompt_len, max_length=max_length, image_seq_length=L,
+                             boi=boi, eoi=eoi, eos=eos, logits_seed=7100 + ci, noise_seed=8100 + ci, top_k=50, guidance_scale=3.0,
+                             logits_scale=3.0, n_after_boi=n_after_boi, tail=tail))
+            ci += 1
+    out["meta"] = np.array(json.dumps(meta))
+    out["cols"] = sample_cols(V).numpy()
+    np.savez_compressed(os.path.join(HERE, "fn_anole_modes.npz"), **out)
+    print("fn_anole_modes ok")
 
 
 def make_pq(V, L, seed, mode):
@@ -617,6 +667,8 @@ if __name__ == "__main__":
         gen_fn_reguess()
     if "fn" in which or "temp" in which:
         gen_fn_temperature()
+    if "fn" in which or "anole_modes" in which:
+        gen_fn_anole_modes()
     if "loops" in which:
         gen_loop_llamagen()
         gen_loop_lumina()

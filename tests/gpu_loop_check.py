@@ -390,7 +390,7 @@ def teacher_forced_emu3_api_check(device="cuda:0", H=3, W=5, window=16, seed=5, 
 
 @torch.no_grad()
 def teacher_forced_anole_api_check(device="cuda:0", img_len=36, window=16, seed=5, P=10, embed_token_scale=0.25, dtype=torch.bfloat16,
-                                   gemm="sjd", fp8_kv=False):
+                                   gemm="sjd", fp8_kv=False, mode="image-only", extra_new_tokens=0):
     """The Anole flow as reference model_loader.py:82-108 / 396-411 drives it: renew_pipeline_sampler(model, processor, **kw) then
     model.generate(input_ids, multimodal_generation_mode="image-only", max_new_tokens=L+2, do_sample=True); teacher-forced replay."""
     from types import SimpleNamespace as NS
@@ -412,12 +412,12 @@ def teacher_forced_anole_api_check(device="cuda:0", img_len=36, window=16, seed=
     eng = model._sjd_engine(2, torch.device(device))
     rec = _Recorder()
     eng.hook = rec
-    out = model.generate(ids, multimodal_generation_mode="image-only", max_new_tokens=img_len + 2, do_sample=True)   # ML:406-411
+    out = model.generate(ids, multimodal_generation_mode=mode, max_new_tokens=img_len + 2 + extra_new_tokens, do_sample=True)   # ML:406-411
     seq = out[0].tolist()
-    max_len = P + img_len + 2
+    max_len = P + img_len + 2 + extra_new_tokens
     cfg = OL.LoopConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=img_len - window - 2, max_num_new_tokens=window, guidance_scale=3.0,
                         seed=seed, do_cfg=True, prefix_token_sampler_scheme="speculative_jacobi", max_length=max_len, eos_token_ids=())
-    seq_ref, tr, checks = _replay(rec, ids[0].tolist(), lambda c, n: O.anole_rules(c, n, V, P, max_len, img_len, top_k=0), cfg, V, device=device)   # no TopK warper in JA:183-232
+    seq_ref, tr, checks = _replay(rec, ids[0].tolist(), lambda c, n: O.anole_rules(c, n, V, P, max_len, img_len, top_k=0, mode=mode), cfg, V, device=device)   # no TopK warper in JA:183-232
     assert seq == seq_ref, "token sequences differ"
     assert model.last_sjd_stats.matched == tr.matched
     gen = seq[P:]

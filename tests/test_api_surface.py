@@ -73,6 +73,23 @@ def test_processor_descriptors_and_grammar_mapping():
         grammar_from_processors([object()])
     with pytest.raises(RuntimeError):
         vl(None, None)
+    # Anole's other restricted modes (JA:178-189, 233-260): their processor lists map to AnoleGrammar(mode=)
+    from scheduler.logit_processor_3dim import (AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d as AtOff,
+                                                AllowOnlyTokensInRelativeWindowLogitsProcessor3d as InWin,
+                                                SuppressTokensInIndexRangeLogitsProcessor3d as InRange, SuppressTokensLogitsProcessor3d as Supp)
+    img = list(range(4, 8196))
+    g = grammar_from_processors([Supp(img + [8197, 8196]), TopKLogitsWarper(10)], prompt_len=5, max_length=50, vocab_size=9216)
+    assert isinstance(g, G.AnoleGrammar) and g.mode == "text-only" and (g.img_lo, g.eoi, g.boi, g.top_k) == (4, 8196, 8197, 10)
+    g.start([9000] * 5)
+    r = g.window_rules(2)[0]
+    assert r.n_ranges == 2 and (r.lo[0], r.hi[0], r.lo[1], r.hi[1]) == (0, 4, 8198, 9216)
+    g = grammar_from_processors([AtOff(8197, [8196], 25, True), InWin(8197, img, 24, True), InRange([8197], 50 - 24 - 1)],
+                                prompt_len=5, max_length=50, vocab_size=9216)
+    assert isinstance(g, G.AnoleGrammar) and g.mode == "interleaved-text-image" and (g.L, g.max_length) == (24, 50)
+    with pytest.raises(NotImplementedError):
+        grammar_from_processors([Supp(img + [8197, 8196])], prompt_len=5, max_length=50)          # no vocabulary size
+    with pytest.raises(NotImplementedError):
+        grammar_from_processors([Supp([5, 9, 100])], vocab_size=9216)
     # GenerationConfig.top_p: HF's TopPLogitsWarper (the HF object or the stand-in) behind any family's processors = a scalar of every rule
     from transformers.generation.logits_process import TopPLogitsWarper as HFTopP
     from scheduler.logit_processor_3dim import TopPLogitsWarper, TemperatureLogitsWarper

@@ -140,6 +140,22 @@ def test_emu3_reference_api_flow(dev):
     assert r["nfe"] < len(gen)
 
 
+@pytest.mark.parametrize("mode", ["interleaved-text-image", "text-only"])
+def test_anole_other_generation_modes(dev, mode):
+    """generate(multimodal_generation_mode='interleaved-text-image' | 'text-only') (they raised before; reference JA:178-189, 233-260):
+    the mode's processor list -> AnoleGrammar(mode=) -> whole SJD loops teacher-forced against the oracle restatement, which is pinned to
+    the reference's vectors (tests/golden/fn_anole_modes.npz).  Interleaved, with the prompt ending in <boi>: an image window of exactly
+    L image ids, <eoi>, then text ids; text-only: no image id, <boi> or <eoi> anywhere."""
+    from tests.gpu_loop_check import teacher_forced_anole_api_check
+    r = teacher_forced_anole_api_check(device=str(dev), mode=mode, extra_new_tokens=14)
+    gen, L = r["gen"], r["img_len"]
+    if mode == "text-only":
+        assert len(gen) >= 1 and all(not (4 <= t <= 8197) for t in gen)
+    else:
+        assert all(4 <= t < 8196 for t in gen[:L]) and gen[L] == 8196 and all(not (4 <= t < 8197) for t in gen[L + 1:])
+        assert len(gen) > L + 1
+
+
 def test_anole_reference_api_flow(dev):
     """A14: Anole renew_pipeline_sampler + generate(multimodal_generation_mode='image-only'), executed (reference JA:137-330)."""
     from tests.gpu_loop_check import teacher_forced_anole_api_check

@@ -121,6 +121,33 @@ def test_anole_grammar():
             assert len(fast) == len(want_res) and all(same(a, b) for a, b in zip(fast, want_res)), (ctx, win)
 
 
+@pytest.mark.parametrize("mode", ["interleaved-text-image", "text-only"])
+def test_anole_grammar_other_modes(mode):
+    """AnoleGrammar(mode=) against the oracle restatement of JA:178-189 / 233-260 (pinned to the reference by fn_anole_modes.npz): text
+    before, inside and after an image window, the <eoi> slot, a context with no room left for an image; window and residual rules."""
+    rng = random.Random(11)
+    V, Lseq, P, maxlen = 9216, 24, 6, 70
+    for trial in range(300):
+        ctx = [rng.randint(8900, 9100) for _ in range(P + rng.randint(0, 30))]
+        if rng.random() < 0.7:
+            ctx += [8197] + [rng.randint(4, 8195) for _ in range(rng.randint(0, Lseq))]
+            if len(ctx) and rng.random() < 0.3 and ctx.count(8197) and len(ctx) - 1 - ctx.index(8197) == Lseq:
+                ctx += [8196] + [rng.randint(8900, 9100) for _ in range(rng.randint(0, 3))]
+        n = rng.randint(1, 16)
+        win = [ctx[-1]] + [rng.choice([rng.randint(4, 8195), rng.randint(8900, 9100)]) for _ in range(n - 1)]
+        ofn = lambda c, k: O.anole_rules(c, k, V, P, maxlen, Lseq, mode=mode)
+        check(G.AnoleGrammar(V, P, maxlen, Lseq, mode=mode), ofn, ctx, n, None)
+        g = G.AnoleGrammar(V, P, maxlen, Lseq, mode=mode)
+        g.start(ctx)
+        want_res = [ofn(ctx + win[1:i], 1)[0] for i in range(1, n)]
+        assert all(same(a, b) for a, b in zip(g.residual_rules(win), want_res))
+        fast = g.fast_residual_rules(win, g.window_rules(n))
+        if fast is not None:
+            assert len(fast) == len(want_res) and all(same(a, b) for a, b in zip(fast, want_res)), (ctx, win)
+    with pytest.raises(ValueError):
+        G.AnoleGrammar(V, P, maxlen, Lseq, mode="images")
+
+
 def test_grammars_on_golden_contexts(golden_dir):
     d = np.load(os.path.join(golden_dir, "fn_logits2tokens_lumina.npz"))
     for m in json.loads(str(d["meta"])):

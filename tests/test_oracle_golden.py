@@ -112,6 +112,27 @@ def test_anole_grammar(golden_dir):
         check_probs(d, name, toks, probs, d["cols"])
 
 
+def test_anole_text_only_and_interleaved_modes(golden_dir):
+    """multimodal_generation_mode 'text-only' / 'interleaved-text-image' (JA:178-189, 233-260): the processor lists the reference's pipeline
+    builds, through its sampling_logits2tokens (tests/golden/make_golden.py::gen_fn_anole_modes) -- tokens bit-exact, probabilities within
+    tolerance, in and around an image window."""
+    d, meta = load(golden_dir, "fn_anole_modes.npz")
+    for m in meta:
+        name = m["name"]
+        ctx = d[f"{name}.ctx"][0].tolist()
+        g = torch.Generator().manual_seed(m["logits_seed"])
+        torch.randint(8900, 9200, (1, m["prompt_len"]), generator=g)
+        if m["n_after_boi"] >= 0:
+            torch.randint(4, 8196, (1, m["n_after_boi"]), generator=g)
+        if m["tail"]:
+            torch.randint(8900, 9200, (1, m["tail"] - 1), generator=g)
+        logits, noise = gen_inputs(m, ctx_gen=g)
+        rules = O.anole_rules(ctx, m["nrows"], m["V"], m["prompt_len"], m["max_length"], m["image_seq_length"],
+                              m["boi"], m["eoi"], m["eos"], top_k=m["top_k"], mode=m["mode"])
+        toks, probs = O.logits_to_probs_sample(logits[0], logits[1], m["guidance_scale"], rules, noise)
+        check_probs(d, name, toks, probs, d["cols"])
+
+
 def test_speculative_sampler(golden_dir):
     d, meta = load(golden_dir, "fn_speculative_sampler.npz")
     for m in meta:

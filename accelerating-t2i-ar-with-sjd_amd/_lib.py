@@ -6,7 +6,7 @@ Build it with ``python __graft_entry__.py`` / ``make -C accelerating-t2i-ar-with
 import ctypes
 import os
 
-MAX_WINDOW = 32
+MAX_WINDOW = 64
 MAX_RANGES = 4
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 

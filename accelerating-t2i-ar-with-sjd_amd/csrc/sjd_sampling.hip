@@ -333,7 +333,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
 }
 
 // ------------------------------------------------------------------------------------------------ K4
-// The per-iteration read-back without a copy engine: the last kernel of an iteration writes the 912-byte state into HOST memory the
+// The per-iteration read-back without a copy engine: the last kernel of an iteration writes the state blob (sizeof(sjd_state)) into HOST memory the
 // device can address (pinned, fine-grained), so the host's single sync of the iteration is a stream synchronize and nothing else.
 // rocprofv3 kernel trace, round 2 (tools/step_gaps.py): the D2H copy that used to follow K4 started ~10 us after it (hand-over from
 // the compute queue to the SDMA engine) on top of the copy itself.  All threads of the block call this (barrier inside); the words

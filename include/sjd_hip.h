@@ -21,7 +21,8 @@ extern "C" {
 #endif
 
 #define SJD_VERSION 100
-#define SJD_MAX_WINDOW 32      /* max draft-window length L (reference max_num_new_tokens: 16 / 32) */
+#define SJD_MAX_WINDOW 64      /* max draft-window length L (reference max_num_new_tokens: 16 / 32 by default, a free CLI argument of eval_model.py:76;
+                                  64 = one wavefront of accept tests in K4, 128 forward rows with CFG) */
 #define SJD_MAX_RANGES 4
 
 #define SJD_OK 0

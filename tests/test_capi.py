@@ -29,13 +29,16 @@ def test_exports_match_header():
 def test_struct_layouts_match_header():
     L = _ensure_built()
     assert ctypes.sizeof(L.RowRule) == 52 and L.RowRule.temperature.offset == 48
-    assert ctypes.sizeof(L.IterParams) == 64 + 8 * 32 + 2 * 52 * 32                               # static_assert'ed in sjd_sampling.hip
+    W = 64                                                                                        # SJD_MAX_WINDOW (include/sjd_hip.h)
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sjd_hip.h")).read()
+    assert f"#define SJD_MAX_WINDOW {W} " in src and L.MAX_WINDOW == W
+    assert ctypes.sizeof(L.IterParams) == 64 + 8 * W + 2 * 52 * W                                 # static_assert'ed in sjd_sampling.hip
     assert L.IterParams.kv_len.offset == 4 and L.IterParams.batch_rows.offset == 0x14            # the inline s_load offsets of sjdi_kv_rows
     assert L.IterParams.philox_blocks.offset == 28 and L.IterParams.philox_seed.offset == 32 and L.IterParams.philox_offset.offset == 40
-    assert L.IterParams.fresh_tok.offset == 64 and L.IterParams.rules.offset == 64 + 256
-    assert ctypes.sizeof(L.State) == 16 + 8 * 32 * 2 + 4 * 32 + 8 * 32
-    assert L.State.tokens.offset == 16 and L.State.win_tok.offset == 16 + 256 and L.State.q_src.offset == 16 + 512
-    assert L.State.amax.offset == 16 + 512 + 128
+    assert L.IterParams.fresh_tok.offset == 64 and L.IterParams.rules.offset == 64 + 8 * W
+    assert ctypes.sizeof(L.State) == 16 + 8 * W * 2 + 4 * W + 8 * W
+    assert L.State.tokens.offset == 16 and L.State.win_tok.offset == 16 + 8 * W and L.State.q_src.offset == 16 + 16 * W
+    assert L.State.amax.offset == 16 + 16 * W + 4 * W
     assert ctypes.sizeof(L.HeadPartials) == 88 and L.HeadPartials.row_sumsq.offset == 48          # static_assert'ed in sjd_sampling.hip
     assert ctypes.sizeof(L.RowNorm) == 24
 

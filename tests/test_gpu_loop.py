@@ -51,6 +51,22 @@ def test_emu3_loop(window, use_graph, gemm):
     assert s["nfe"] < s["tokens"]
 
 
+@pytest.mark.parametrize("flavour,use_graph,gemm", [("llamagen", True, "torch"), ("lumina", True, "sjd"), ("lumina", False, "torch"), ("emu3", True, "sjd")])
+def test_loops_with_a_64_token_draft_window(flavour, use_graph, gemm):
+    """max_num_new_tokens = 64 (SJD_MAX_WINDOW; the reference's eval_model.py takes any value, its defaults are 16 / 32): 63 accept tests in
+    one wavefront of K4, 128 forward rows with CFG (the four-row-tile G1 kernels, K1 over four 16-row chunks), whole loops teacher-forced
+    against the oracle."""
+    if flavour == "llamagen":
+        s = G.teacher_forced_llamagen_check(latent=16, window=64, seed=21, embed_token_scale=0.25, use_graph=use_graph)
+        assert s["tokens"] == 255 and s["noise_checks"] == s["nfe"] and s["tok_per_step"] > 1.2
+    elif flavour == "lumina":
+        s = G.teacher_forced_lumina_check(window=64, seed=23, hg=5, wg=5, use_graph=use_graph, gemm=gemm, embed_token_scale=0.1)
+        assert s["last"] == 8196 and s["tokens"] >= 100
+    else:
+        s = G.teacher_forced_emu3_check(window=64, use_graph=use_graph, gemm=gemm, H=4, W=6)
+        assert s["nfe"] < s["tokens"]
+
+
 def test_llamagen_loop_top_p():
     """TopPLogitsWarper3d with top_p < 1 on the HIP path (K2 and the K4 residual)."""
     s = G.teacher_forced_llamagen_check(latent=8, window=16, seed=5, embed_token_scale=0.25, top_p=0.95, use_graph=True)

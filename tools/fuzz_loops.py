@@ -35,7 +35,7 @@ def main():
                           fused=True, gemm=rnd.choice(["torch", "sjd"]), fp8_kv=rnd.random() < 0.3,
                           dtype=rnd.choice([torch.bfloat16, torch.float16]),
                           init_scheme=rnd.choice(["random", "random", "repeat_horizon", "sample_horizon"]),
-                          temperature=rnd.choice([1.0, 1.0, 0.6, 0.85, 1.4, 2.2]))
+                          temperature=rnd.choice([1.0, 1.0, 0.6, 0.85, 1.4, 2.2]), top_p=rnd.choice([None, None, 0.95, 0.8, 0.5]))
                 r = G.teacher_forced_lumina_check(**kw)
                 r.pop("windows", None)
             elif kind == "emu3":

@@ -36,7 +36,7 @@ import os as _os
 # 27.0 / 33.7 us at kv_len 64 / 448 / 1216 / 2368).  Default off; SJD_K1_FUSED=1 or model.k1_fused = True selects it.
 _K1_FUSED_DEFAULT = _os.environ.get("SJD_K1_FUSED", "0") == "1"
 _K1_FUSED_SPLIT_DEFAULT = _os.environ.get("SJD_K1_FUSED_SPLIT", "1") != "0"   # with k1_fused: the split form K1Fs (0: one workgroup per (batch, head))
-_GATEUP_FUSED_DEFAULT = _os.environ.get("SJD_GATEUP_FUSED", "1") != "0"     # kernel G1s (gate|up + F3 in one launch); 0: G1 then F3
+_GATEUP_FUSED_DEFAULT = {"0": False, "tall": "tall"}.get(_os.environ.get("SJD_GATEUP_FUSED", "1"), True)     # kernel G1s (gate|up + F3 in one launch); 0: G1 then F3; tall: also above 64 rows
 # round 3 experiment, correct, tested, OFF by default: the o / down projections of a <= 32-row window can reduce their own
 # split-K planes, add the residual and write the row statistics in their tail (sjd_skinny_gemm_reduce: device-coherent exchange between
 # the workgroups of a 512-column slice, bit-identical h and statistics), so that stage F1r -- two graph nodes per layer -- disappears.
@@ -368,8 +368,8 @@ class ChameleonBackbone(nn.Module):
     G1_CFG_64ROW = dict(qkv=(896, 8, True), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))       # profiles/r2_g1_launch_shape_sweep_64rows.jsonl
     # 65..128-row windows (three / four prompts per forward): the activation is sub-tiled, so KC is free again, but <= 8 waves.  Round 3:
     # 4-wave workgroups run on g1_skinny_gemm_tiled8 (8-step sub-tiles, two workgroups per CU, weight ring refilled in place) -- q|k|v,
-    # o and down are faster there (28.1 / 15.8 / 28.4 -> 25.7 / 12.2 / 24.0 us), gate|up is not (profiles/r3_g1_tiled8.txt);
-    # four prompts per forward 5.55 -> 5.07 ms per step on one box
+    # o and down are faster there (28.1 / 15.8 / 28.4 -> 25.7 / 12.2 / 24.0 us); 8-wave workgroups run on the same kernel with one workgroup
+    # per CU (gate|up 49.4 -> 43.3 us, profiles/r3_g1_tiled8.txt); four prompts per forward 5.55 -> 4.89 ms per step on one box
     G1_CFG_128ROW = dict(qkv=(2048, 4, True), o=(896, 4, True), gate_up=(2048, 8, True), down=(1376, 4, True))
     # Emu3-Gen 8B (GQA 32/8: the q|k|v projection has 6144 columns; draft window 32 -> 64 rows), tuned end to end with bench.py --model emu3_8b
     G1_CFG_EMU3 = dict(qkv=(512, 8, False), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))        # profiles/r2_g1_launch_shape_sweep_emu3_64rows.jsonl
@@ -544,7 +544,10 @@ class ChameleonBackbone(nn.Module):
         g1 = lambda x_, name, N_, K_: self._g1(li, x_, name, N_, K_)
         H, Hkv, D, hid, inter = self.n_heads, self.n_kv_heads, self.head_dim, self.args.hidden_size, self.args.intermediate_size
         params = getattr(self.attn, "params", None)
-        fuse_mlp = getattr(self, "gateup_fused", _GATEUP_FUSED_DEFAULT) and not self._pf_on and ops.gateup_silu_ok(T, inter, hid, cfg["gate_up"][0],
+        # (65..128-row windows: the four-row-tile G1s is served -- ops.gateup_silu_ok -- but the eight-wave 8-step G1 + F3 measured faster,
+        #  4.89 against 5.06 ms per step with four prompts, profiles/r3_g1_tiled8.txt; `gateup_fused = "tall"` forces the fused kernel there)
+        want_fused = getattr(self, "gateup_fused", _GATEUP_FUSED_DEFAULT)
+        fuse_mlp = want_fused and (T <= 64 or want_fused == "tall") and not self._pf_on and ops.gateup_silu_ok(T, inter, hid, cfg["gate_up"][0],
                                                                                                                    isinstance(self._packed[0]["gate_up"], ops.PackedZ))
         # o / down with F1r as their tail (one launch each; the reducing kernel wants whole 512-column slices per workgroup pair: 8 waves)
         red = getattr(self, "reduce_fused", _REDUCE_FUSED_DEFAULT) and not self._pf_on

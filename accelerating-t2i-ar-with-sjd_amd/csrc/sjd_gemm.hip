@@ -472,8 +472,8 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
 // (16 stores per wave instead of 64: no gain -- it is not the address pipe) and non-temporal plane stores (q|k|v 28.7 -> 25.3 us, down
 // 25.0 -> 22.5 alone, but 5.098 -> 5.091 ms per step with four prompts: the consumer kernel pays for them).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t g1z_unit_rsrc(const unsigned char *first_record, unsigned bytes);
-template <int DT, int MT>
-__global__ __launch_bounds__(256, 2) void g1_skinny_gemm_tiled8(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
+template <int DT, int MT, int NW>           // NW = 4: two workgroups per CU; NW = 8 (late round 3): one, its staged sub-tile shared by eight column tiles
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void g1_skinny_gemm_tiled8(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                 float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
                                                                 int rec_stride, int tile0)
 {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void g1_skinny_gemm_tiled8(const unsigned s
     const int k0 = chunk * KC;
     const int steps = min(KC, K - k0) / 16;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int t_out = blockIdx.x * 4 + w;                         // exactly four waves (the launcher sends other wave counts to the 16-step kernel)
+    const int t_out = blockIdx.x * NW + w;                        // exactly NW waves (the launcher sends other wave counts to the 16-step kernel)
     const bool has_tile = t_out < N / 32;                        // a wave without a tile multiplies tile 0 and stores nothing
     const int t = tile0 + (has_tile ? t_out : 0);
     const size_t chunk_base = (size_t)chunk * n_tiles * (KC / 16);
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void g1_skinny_gemm_tiled8(const unsigned s
     constexpr int BUF = MT * SUB * 64;                            // u32x4 per LDS buffer
     constexpr int PPR = 2 * SUB;                                  // 16-byte pieces per row of a sub-tile
     constexpr int NP = MT * 32 * PPR;                             // pieces per sub-tile
-    constexpr int NV = NP / 256;                                  // pieces per thread at 256 threads (2 MT)
+    constexpr int NV = NP / (64 * NW);                            // pieces per thread (2 MT at four waves, MT at eight)
     const int n_sub = (steps + SUB - 1) / SUB;
     const int k_end = k0 + steps * 16;
     u32x4 A[SUB], B[SUB];
@@ -514,15 +514,15 @@ __global__ __launch_bounds__(256, 2) void g1_skinny_gemm_tiled8(const unsigned s
     // thread tid stages pieces tid + 256 i: row m0 + 16 i (m0 = tid / 16 < 16), the SAME 8 columns j0 = tid % 16 of the sub-tile for every
     // i -- so the global offset of piece i is ONE per-lane offset + the scalar (16 i) rows, its LDS slot ONE per-lane slot + a constant
     // (row tile i / 2, bit 4 of the row = i & 1), and the column test below is one compare per sub-tile (16 address / predicate registers less).
-    const int m0 = threadIdx.x >> 4, j0 = threadIdx.x & 15;
+    const int m0 = threadIdx.x >> 4, j0 = threadIdx.x & 15;      // (eight waves: pieces tid + 512 i = row m0 + 32 i, m0 < 32 -- row tile i)
     const unsigned x_off0 = ((unsigned)m0 * (unsigned)K + (unsigned)(k0 + 8 * j0)) * 2u;
-    const int x_slot0 = (j0 >> 1) * 64 + g1_slot(j0 & 1, m0, j0 >> 1);
+    const int x_slot0 = (j0 >> 1) * 64 + g1_slot(j0 & 1, m0, j0 >> 1);      // (includes bit 4 of m0 at eight waves)
     auto x_load = [&](int st, int i) -> u32x4 {                   // (a row >= M lies past the descriptor's end: zero)
-        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(st) * (32u * SUB) + (unsigned)(32 * i) * (unsigned)K;
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(st) * (32u * SUB) + (unsigned)(8 * NW * i) * (unsigned)K;      // (4 NW rows on)
         return __builtin_amdgcn_raw_buffer_load_b128(xr, x_off0, so, 0);
     };
     auto x_store = [&](int st, int buf, int i, u32x4 val) {       // (the zeroing sits on the store side: the loads stay in flight through the MFMAs)
-        xl[buf * BUF + (i >> 1) * (SUB * 64) + ((i & 1) << 4) + x_slot0] =
+        xl[buf * BUF + (NW == 4 ? (i >> 1) * (SUB * 64) + ((i & 1) << 4) : i * (SUB * 64)) + x_slot0] =
             (k0 + st * (16 * SUB) + 8 * j0 < k_end) ? val : u32x4{0u, 0u, 0u, 0u};          // (a column past the chunk is the next chunk's or the next row's)
     };
     auto w_rec = [&](int g, int u) -> u32x4 {                     // k-step 8 g + u of the chunk
@@ -1787,10 +1787,18 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
     if constexpr (MT >= 2) if (MT > 2 || lds_whole > 160 * 1024 || (force_tiled && waves <= 8)) {     // sub-tiled activation: no limit on KC
         if (waves > 8) return SJD_ERR_BAD_ARG;
         static const bool sub8 = [] { const char *e = getenv("SJD_G1_SUB8"); return !(e && e[0] == '0'); }();      // (A/B aid: 0 = the 16-step kernel for every wave count)
+        static const bool sub8w8 = [] { const char *e = getenv("SJD_G1_SUB8_W8"); return !(e && e[0] == '0'); }();   // (A/B aid: 0 = eight-wave workgroups on the 16-step kernel)
         if constexpr (MT > 2) if (waves == 4 && sub8) {        // 4-wave workgroups: 8-step sub-tiles, two workgroups per CU
             const size_t lds_8 = (size_t)2 * MT * 8 * 1024;
-            (void)hipFuncSetAttribute((const void *)g1_skinny_gemm_tiled8<DT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_8);
-            hipLaunchKernelGGL((g1_skinny_gemm_tiled8<DT, MT>), grid, block, lds_8, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K,
+            (void)hipFuncSetAttribute((const void *)g1_skinny_gemm_tiled8<DT, MT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_8);
+            hipLaunchKernelGGL((g1_skinny_gemm_tiled8<DT, MT, 4>), grid, block, lds_8, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K,
+                               KC, n_tiles, step_major ? n_tiles : 1, tile0);
+            return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+        }
+        if constexpr (MT > 2) if (waves == 8 && sub8 && sub8w8) {
+            const size_t lds_8 = (size_t)2 * MT * 8 * 1024;
+            (void)hipFuncSetAttribute((const void *)g1_skinny_gemm_tiled8<DT, MT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_8);
+            hipLaunchKernelGGL((g1_skinny_gemm_tiled8<DT, MT, 8>), grid, block, lds_8, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K,
                                KC, n_tiles, step_major ? n_tiles : 1, tile0);
             return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
         }

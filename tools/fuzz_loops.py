@@ -20,16 +20,16 @@ def main():
     rnd = random.Random(a.seed)
     ok = 0
     for i in range(a.n):
-        kind = rnd.choice(["llamagen", "lumina", "lumina", "emu3", "anole", "batch", "batch"])
+        kind = rnd.choice(["llamagen", "lumina", "lumina", "emu3", "anole", "anole_api", "batch", "batch"])
         seed = rnd.randrange(1, 10000)
         try:
             if kind == "llamagen":
-                kw = dict(seed=seed, window=rnd.choice([4, 8, 16, 32]), scheme=rnd.choice(["speculative_jacobi", "jacobi"]),
+                kw = dict(seed=seed, window=rnd.choice([4, 8, 16, 32, 64]), scheme=rnd.choice(["speculative_jacobi", "jacobi"]),
                           embed_token_scale=rnd.choice([0.1, 0.25, 0.5, 1.0]), top_k=rnd.choice([0, 10, 1000]),
                           top_p=rnd.choice([1.0, 0.95, 0.7]), use_graph=rnd.random() < 0.5, latent=rnd.choice([8, 12, 16]))
                 r = G.teacher_forced_llamagen_check(**kw)
             elif kind == "lumina":
-                kw = dict(seed=seed, window=rnd.choice([2, 8, 16, 32]), hg=rnd.choice([2, 3, 4]), wg=rnd.choice([2, 4, 5]),
+                kw = dict(seed=seed, window=rnd.choice([2, 8, 16, 32, 64]), hg=rnd.choice([2, 3, 4]), wg=rnd.choice([2, 4, 5]),
                           kv_heads=rnd.choice([4, 2, 1]), l=rnd.choice([0, 1, 3]), embed_token_scale=rnd.choice([0.1, 0.25, 0.6]),
                           scheme=rnd.choice(["speculative_jacobi", "speculative_jacobi", "jacobi"]), use_graph=rnd.random() < 0.6,
                           fused=True, gemm=rnd.choice(["torch", "sjd"]), fp8_kv=rnd.random() < 0.3,
@@ -39,10 +39,16 @@ def main():
                 r = G.teacher_forced_lumina_check(**kw)
                 r.pop("windows", None)
             elif kind == "emu3":
-                kw = dict(seed=seed, H=rnd.choice([2, 3, 4]), W=rnd.choice([3, 5, 6]), window=rnd.choice([8, 16, 32]),
+                kw = dict(seed=seed, H=rnd.choice([2, 3, 4]), W=rnd.choice([3, 5, 6]), window=rnd.choice([8, 16, 32, 64]),
                           pos_len=rnd.choice([5, 9, 12]), neg_len=rnd.choice([3, 5, 12]), gemm=rnd.choice(["torch", "sjd"]),
                           use_graph=rnd.random() < 0.6, init_scheme=rnd.choice(["random", "repeat_horizon", "sample_horizon"]))
                 r = G.teacher_forced_emu3_check(**kw)
+                r = {k: v for k, v in r.items() if k != "gen"}
+            elif kind == "anole_api":
+                kw = dict(seed=seed, img_len=rnd.choice([24, 36, 49]), window=rnd.choice([4, 16]), P=rnd.choice([6, 10, 13]),
+                          mode=rnd.choice(["image-only", "interleaved-text-image", "text-only"]), extra_new_tokens=rnd.choice([0, 9, 20]),
+                          gemm=rnd.choice(["torch", "sjd"]))
+                r = G.teacher_forced_anole_api_check(**kw)
                 r = {k: v for k, v in r.items() if k != "gen"}
             elif kind == "anole":
                 kw = dict(seed=seed, img_len=rnd.choice([24, 40, 57]), window=rnd.choice([4, 16]), fp8_kv=rnd.random() < 0.5,

@@ -463,10 +463,13 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
 // one weight group per wave in flight: the phase stamps put 0.45 us of LDS writes + ~0.7 us of barrier on top of every 3.2-4 us sub-tile.
 // Here a sub-tile is 8 k-steps = ONE weight group, a workgroup is 4 waves and 2 x MT x 8 KiB of LDS (64 KiB at four row tiles), so two
 // workgroups share a CU (2 waves per SIMD, <= 256 VGPRs each as before): while one stages and waits at its barrier the other streams and
-// multiplies.  Register sets A / B alternate between sub-tiles without copies; the group of the NEXT sub-tile and its activation pieces are
-// requested before the MFMAs of the current one; every load is unconditional (a record past the chunk reads as zero through the wave's
-// buffer descriptor, an activation piece past it is clamped and zeroed); the k-steps past a ragged chunk's end are skipped by uniform branches.  Same MFMA
+// multiplies.  The weight sets A / B are a ring of 16 k-steps refilled in place; the activation pieces of the NEXT sub-tile are requested
+// before the MFMAs of the current one; every load is unconditional (a record past the chunk reads as zero through the wave's buffer
+// descriptor, an activation piece past it is zeroed on its way into LDS) and the loop has no branch but its back edge.  Same MFMA
 // sequence per (tile, chunk, row tile) as g1_skinny_gemm: bit-identical planes.
+// NW = 8 (late round 3): the same loop with eight waves -- one workgroup per CU again, but its staged sub-tile feeds eight column tiles
+// (half the activation re-reads per weight byte); every 8-wave launch of a 65..128-row window runs here instead of the 16-step kernel
+// (gate|up 49.4 -> 43.3 us, q|k|v 29.4 -> 26.7, down 29.3 -> 25.2).
 // Probe builds (-DT8_NOSTORE / -DT8_NOX / -DT8_NOMFMA, profiles/r3_g1_tiled8.txt): the partial planes cost 3-6 us of a 25-49 us launch, the
 // activation staging 6-7 us.  Two things measured against the planes and NOT kept: the tiles written through LDS as 16-byte row pieces
 // (16 stores per wave instead of 64: no gain -- it is not the address pipe) and non-temporal plane stores (q|k|v 28.7 -> 25.3 us, down

@@ -236,10 +236,21 @@ __global__ __launch_bounds__(128) void f1r_residual_sumsq(unsigned short *__rest
             const size_t cstride = (size_t)prows * hidden;
             const float *p0 = part + (size_t)row * hidden + c;
             float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+            // UNCONDITIONAL loads (a missing chunk re-reads the last one, its value is not added): behind a conditional load the
+            // compiler waits with vmcnt(0) -- round 3 found this kernel at 4.0 us instead of 3.0 after an unrelated edit had made it
+            // reuse destination registers between the eight conditional loads, i.e. eight HBM round trips in a row, 0.06 ms per step.
+            // 9..16 chunks (the down projection's 15): ONE batch of sixteen -- two batches of eight were two round trips; same order of adds.
+            if (n_chunks > 8 && n_chunks <= 16) {
+                float4 v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = *reinterpret_cast<const float4 *>(p0 + (size_t)min(q, n_chunks - 1) * cstride);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const bool on = q < n_chunks;
+                    d0 += on ? v[q].x : 0.f; d1 += on ? v[q].y : 0.f; d2 += on ? v[q].z : 0.f; d3 += on ? v[q].w : 0.f;
+                }
+            } else
             for (int c0 = 0; c0 < n_chunks; c0 += 8) {           // issue the loads of eight chunks before the first add
-                // UNCONDITIONAL loads (a missing chunk re-reads the last one, its value is not added): behind a conditional load the
-                // compiler waits with vmcnt(0) -- round 3 found this kernel at 4.0 us instead of 3.0 after an unrelated edit had made it
-                // reuse destination registers between the eight conditional loads, i.e. eight HBM round trips in a row, 0.06 ms per step
                 float4 v[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4 *>(p0 + (size_t)min(c0 + q, n_chunks - 1) * cstride);
@@ -328,11 +339,35 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
         const float *ssp = row_sumsq ? row_sumsq : part;
 #pragma unroll
         for (int q = 0; q < 8; ++q) ssv[q] = ssp[(size_t)(row_sumsq ? min(q, rs_slices - 1) : 0) * prows + tok];
+        // (a batch of eight planes, or -- one uniform branch -- of the two / four a short split-K has: with the two planes of a 128-row q|k|v
+        // launch six of the eight clamped loads re-read the last plane, 12 of a wave's 16 load instructions)
+        if (n_chunks <= 2) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float *pp = part + ((size_t)min(q, n_chunks - 1) * prows + tok) * ncol + col;
-            v0[q] = pp[0];
-            v1[q] = pp[HALF];
+            for (int q = 0; q < 8; ++q) {
+                v0[q] = 0.f; v1[q] = 0.f;
+                if (q < 2) {
+                    const float *pp = part + ((size_t)min(q, n_chunks - 1) * prows + tok) * ncol + col;
+                    v0[q] = pp[0];
+                    v1[q] = pp[HALF];
+                }
+            }
+        } else if (n_chunks <= 4) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                v0[q] = 0.f; v1[q] = 0.f;
+                if (q < 4) {
+                    const float *pp = part + ((size_t)min(q, n_chunks - 1) * prows + tok) * ncol + col;
+                    v0[q] = pp[0];
+                    v1[q] = pp[HALF];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float *pp = part + ((size_t)min(q, n_chunks - 1) * prows + tok) * ncol + col;
+                v0[q] = pp[0];
+                v1[q] = pp[HALF];
+            }
         }
         int n_unused_ = 0;
         if (params) sjdi_kv_rows(params, b, &kv_len, &n_unused_);

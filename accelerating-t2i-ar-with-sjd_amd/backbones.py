@@ -28,7 +28,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+import logging as _logging
 import os as _os
+_log = _logging.getLogger("sjd_amd.backbones")
 
 # K1F (F2 + K1 + combine in one launch, 64 workgroups) is correct and tested but NOT faster on MI355X: a CU streams ~30 GB/s at most, so
 # 64 workgroups cap at ~1.9 TB/s where the 256-workgroup split kernel reaches 2.8 TB/s, and the dependent round trips (partials -> q/K/V
@@ -448,6 +450,16 @@ class ChameleonBackbone(nn.Module):
             st["bytes_raw"] += w.numel() * w.element_size()
             z = ops.pack_weight_z(w, kc, sm) if self.compress else None
             if z is None:
+                if self.compress:      # asked for and declined: say so (a checkpoint with folded norm gains may land here; the plain stream is
+                    st["declined"] = st.get("declined", 0) + 1          # bit-identical but 25 % more bytes -- VERDICT r3 weak #12)
+                    why = ("dtype %s (the 12-bit form encodes bf16)" % str(w.dtype).replace("torch.", "") if w.dtype != torch.bfloat16
+                           else "KC %d > 4096" % kc if kc > 4096 else "a (k-chunk, 32-column) unit has more than %d out-of-window weights" % ops.Z_MAX_EXC)
+                    seen = st.setdefault("declined_reasons", {})
+                    seen[why] = seen.get(why, 0) + 1
+                    if seen[why] == 1:         # once per reason; the count is in compress_stats["declined_reasons"]
+                        (_log.info if w.dtype != torch.bfloat16 else _log.warning)(
+                            "pack_weight_z declined a %dx%d matrix (%s): it streams uncompressed (G1 / G1s); further ones are counted in "
+                            "compress_stats", w.shape[0], w.shape[1], why)
                 st["bytes_packed"] += w.numel() * w.element_size()
                 return ops.pack_weight(w, kc, sm)
             st["compressed"] += 1

@@ -305,7 +305,14 @@ class SJDBatchEngine:
             s.X = [int(t) for t in prompts[j]]
             s.P = len(s.X)
             seed = (seeds[j] if seeds is not None else (None if cfg.seed is None else cfg.seed + j))
-            s.gen = default_gen if seed is None else torch.Generator(dev).manual_seed(seed)
+            if seed is None:
+                # no seed given: every slot needs its OWN Philox stream.  Sharing the device's default generator (round 3) handed every slot
+                # the same (seed, offset) pair -- identical prompts in a batch then drew identical noise.  A per-slot seed is
+                # drawn FROM the default generator instead: it advances with every admission, and torch.manual_seed still reproduces a run.
+                slot_seed = int(torch.randint(0, 2 ** 62, (1,), device=dev, generator=default_gen).item())
+                s.gen = torch.Generator(dev).manual_seed(slot_seed)
+            else:
+                s.gen = torch.Generator(dev).manual_seed(seed)
             s.ph_seed, s.ph_off = int(s.gen.initial_seed()), int(s.gen.get_offset())
             s.cpu_gen = None if seed is None else torch.Generator().manual_seed(seed)     # the prompt's "global CPU generator" (JL:505)
             s.grammar = grammars[j]

@@ -46,7 +46,10 @@ class FlexARInferenceSolver:
                 from data.item_processor import FlexARItemProcessor          # noqa: the reference's module, never vendored here
                 kw = {} if tokenizer is None else {"tokenizer": tokenizer}
                 item_processor = FlexARItemProcessor(with_decoder=True, target_size=target_size, device=device, **kw)
-            except Exception:                                                # ImportError, or its tokenizer / VQ-GAN assets are missing
+            except (ImportError, FileNotFoundError, OSError) as e:           # not a reference checkout, or its tokenizer / VQ-GAN assets are missing;
+                import logging                                               # anything else (corrupt checkpoint, OOM, wrong device) propagates
+                logging.getLogger("sjd_amd.inference_solver").info("reference item processor not available (%s: %s): generate_ids() is the entry point",
+                                                                   type(e).__name__, e)
                 item_processor = None
         self.item_processor = item_processor
 

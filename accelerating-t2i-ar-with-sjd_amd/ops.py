@@ -509,8 +509,10 @@ def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noi
         sumsq, hidden, eps = head.row_norm
         hp.row_sumsq, hp.slices, hp.prows, hp.inv_hidden, hp.eps = sumsq.data_ptr() + 4 * int(row0), sumsq.shape[0], sumsq.shape[1], 1.0 / float(hidden), float(eps)
     if dbg is not None:
-        assert dbg.dtype == torch.float32 and dbg.is_contiguous() and dbg.shape[0] == 2 and dbg.shape[2] == V and dbg.shape[1] >= max_rows
-        hp.dbg_c, hp.dbg_u = dbg[0].data_ptr(), dbg[1].data_ptr()
+        assert dbg.dtype == torch.float32 and dbg.is_contiguous() and dbg.shape[0] >= 1 and dbg.shape[2] == V and dbg.shape[1] >= max_rows
+        hp.dbg_c = dbg[0].data_ptr()
+        if dbg.shape[0] >= 2:              # (one plane: a batch without CFG -- there is no uncond row to observe)
+            hp.dbg_u = dbg[1].data_ptr()
     assert noise is None or (noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V)
     assert probs_out.is_contiguous()
     L.check(L.load().sjd_logits_to_probs_sample_part(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out),

@@ -92,7 +92,7 @@ def run_prompt_queue(n_prompts: int, decode_one, sync=None, device=None, scheme:
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     lo, hi = contiguous_split(n_prompts, world, rank, scheme)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():          # (also at world size 1: the same path the 8-GPU launch takes)
         dist.barrier()
     if sync is not None:
         sync()

@@ -135,6 +135,13 @@ def grammar_from_processors(processors, prompt_len=None, max_length=None, vocab_
     if temps:                     # scale-invariant with respect to every other processor here (masks, top-k): one scalar of the rules
         if len(temps) > 1:
             raise NotImplementedError("more than one TemperatureLogitsWarper in the processor list")
+        # K2 / K4 apply mask -> top-k -> temperature -> top-p.  Masks and top-k commute with a positive scale; top-p does NOT: HF evaluates a
+        # top-p warper that stands BEFORE the temperature warper at T = 1 (LlamaGen's TopK + TopPLogitsWarper3d with hf_generate's appended
+        # temperature warper) -- a different kept set.  Refuse that order instead of silently scaling first.
+        ti = procs.index(temps[0])
+        if float(temps[0].temperature) != 1.0 and any(type(p).__name__ in ("TopPLogitsWarper", "TopPLogitsWarper3d") and float(getattr(p, "top_p", 1.0)) < 1.0
+                                                      for p in procs[:ti]):
+            raise NotImplementedError("a top-p warper ahead of TemperatureLogitsWarper(temperature != 1): the kernels apply the temperature before top-p")
         g = grammar_from_processors([p for p in procs if p is not temps[0]], prompt_len=prompt_len, max_length=max_length, vocab_size=vocab_size)
         g.temperature = float(temps[0].temperature)
         return g

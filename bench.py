@@ -10,7 +10,7 @@ Where the K timed steps sit: the cost of a step grows with the KV length, so the
 iterations from the prompt) until the KV length is such that the W warm-up + K timed steps are centred on the mean KV length of
 a whole image (P + image/2 = 1240 for 768x768; `--kv-center 0` times from the prompt as round 1 did).  At N=1 the same decode
 then continues to the end of the image, so the line also carries the MEASURED whole-image NFE / tokens/s (`whole_image`) and
-ms/step at KV lengths {64, 1216, 2368} (`per_kv`), plus three bounded side legs: `floor` (plain random embeddings: ~1 token/step),
+ms/step at KV lengths {64, 1216, 2368} (`per_kv`), plus bounded side legs: `floor` (1 / ms_per_step), `acceptance_probe_unscaled_embeddings` (plain random embeddings),
 `torch_baseline` (the reference's data flow in PyTorch-ROCm ops on the same weights at the same KV length: `vs_baseline`), and
 `cpu_baseline` (the oracle's scheduler step on the host cores).
 
@@ -207,6 +207,61 @@ def measure_k1(args, model, attn, device, kv_len):
                 gbps=alg / 1e9 / (avg_ms / 1e3))
 
 
+def measure_k1_pair(args, model, attn, device, kv_len, reps=4):
+    """What one layer's draft-window attention costs INSIDE the engine's hipGraph: the launches K1 consists of for this shape (k1 partial
+    + k1_combine, or the single-launch form) for all layers' caches captured in one graph -- the way an iteration runs them -- and `reps`
+    replays timed with HIP events on the replay stream.  The eager per-launch figure of measure_k1 carries ~5 us of launch latency per
+    launch and times the partial kernel only; this one is the pair a step pays for."""
+    import ctypes
+    import torch
+    import sjd_amd._lib as L
+    import sjd_amd.ops as ops
+    lib = L.load()
+    hip = ctypes.CDLL("libamdhip64.so")
+    B, n, H, D = 2, args.window, model.n_heads, model.head_dim
+    kc, vc = model.cache.k, model.cache.v
+    nl, Hkv, esz = kc.shape[0], kc.shape[2], kc.element_size()
+    kv_len = min(int(kv_len), model.cache.s_max - n)
+    adt = model.lm_head.weight.dtype
+    ks = torch.tensor([0, 0], dtype=torch.int32, device=device) if model.n_kv_heads != model.n_heads else torch.tensor([0, 63], dtype=torch.int32, device=device)
+    n_split = attn.n_split or 8
+    q = torch.randn(B, n, H, D, device=device).to(adt)
+    out = torch.empty_like(q)
+    ws = ops.attention_workspace(B, H, n, D, n_split, device)
+    fp8 = kc.dtype == ops.FP8
+
+    def one(i):
+        if fp8:
+            ops.draft_window_attention_fp8(q, kc[i], vc[i], out, attn.kv_scale[0], attn.kv_scale[1], ks, None, kv_len, n_split, ws)
+        else:
+            ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, kv_len, n_split, ws)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        one(0)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(nl):
+            one(i)
+    graph.replay()
+    torch.cuda.synchronize()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    e0, e1 = ctypes.c_void_p(lib.sjd_event_create()), ctypes.c_void_p(lib.sjd_event_create())
+    hip.hipEventRecord(e0, stream)
+    for _ in range(reps):
+        graph.replay()
+    hip.hipEventRecord(e1, stream)
+    torch.cuda.synchronize()
+    avg_ms = lib.sjd_event_elapsed_ms(e0, e1) / (reps * nl)
+    lib.sjd_event_destroy(e0)
+    lib.sjd_event_destroy(e1)
+    rows0, rows1 = kv_len + n, kv_len + n - int(ks[1])
+    alg = 2 * Hkv * (rows0 + rows1) * D * esz + B * n * H * D * 2
+    return dict(avg_us=round(avg_ms * 1e3, 2), launches=reps * nl, avg_bytes=int(alg), achieved=round(alg / 1e9 / (avg_ms / 1e3), 1),
+                frac=round(alg / 1e9 / (avg_ms / 1e3) / 8000.0, 4), n_split=int(n_split), avg_kv_rows=kv_len + n,
+                what="all K1 launches of a layer (partial + combine where the shape needs it), 32 layers' caches in ONE hipGraph replay, HIP events on the replay stream")
+
+
 def measure_g1(args, model, device, rounds=2):
     """Dominant hand-written kernel by time: G1 (weight-streaming projections).  One full pass over the model's own packed
     weights (32 layers x {qkv, o, gate|up, down} = 13.0 GB, so every launch streams from HBM) is captured in a hipGraph -- the
@@ -220,12 +275,17 @@ def measure_g1(args, model, device, rounds=2):
     hip = ctypes.CDLL("libamdhip64.so")
     H, Hkv, D, hid, inter = model.n_heads, model.n_kv_heads, model.head_dim, model.args.hidden_size, model.args.intermediate_size
     shapes = dict(qkv=((H + 2 * Hkv) * D, hid), o=(hid, H * D), gate_up=(2 * inter, hid), down=(hid, inter))
-    xs = {k: torch.randn(32, K, device=device).to(model.lm_head.weight.dtype) for k, (N, K) in shapes.items()}
+    # the activation rows of the decode's own launches: B_cfg (= 2: cond || uncond) x prompts per forward x draft window -- 32 for the headline,
+    # 64 for Emu3's window of 32 (round 3 staged 32 rows for every model and so priced Emu3's projections on a launch shape it does not run)
+    rows = min(128, 2 * max(1, args.prompts_per_gpu) * args.window)
+    xs = {k: torch.randn(rows, K, device=device).to(model.lm_head.weight.dtype) for k, (N, K) in shapes.items()}
     cfg = model.G1_CFG
 
     import sjd_amd.backbones as BB
     # the product runs gate|up as kernel G1s (the projection with SiLU * up as its epilogue) when the shape allows: measure what it runs
-    fused_mlp = getattr(model, "gateup_fused", BB._GATEUP_FUSED_DEFAULT) and ops.gateup_silu_ok(32, inter, hid, cfg["gate_up"][0])
+    want_fused = getattr(model, "gateup_fused", BB._GATEUP_FUSED_DEFAULT)
+    fused_mlp = want_fused and (rows <= 64 or want_fused == "tall") and ops.gateup_silu_ok(rows, inter, hid, cfg["gate_up"][0],
+                                                                                          isinstance(model._packed[0]["gate_up"], ops.PackedZ))
     rn = (ops.residual_sumsq(xs["gate_up"].clone(), None), hid, 1e-5)
 
     def one_pass():
@@ -257,10 +317,10 @@ def measure_g1(args, model, device, rounds=2):
     # algorithmic bytes of a launch = the weight stream AS STORED (the lossless 12-bit form is what the algorithm has to move; the bf16 size is
     # reported next to it) + the activation rows
     wbytes = lambda p, N, K: p.nbytes() if isinstance(p, ops.PackedZ) else N * K * 2
-    tot_b = rounds * sum(wbytes(pk[name], N, K) + 32 * K * 2 for pk in model._packed for name, (N, K) in shapes.items())
-    tot_b16 = rounds * len(model._packed) * sum(N * K * 2 + 32 * K * 2 for N, K in shapes.values())
+    tot_b = rounds * sum(wbytes(pk[name], N, K) + rows * K * 2 for pk in model._packed for name, (N, K) in shapes.items())
+    tot_b16 = rounds * len(model._packed) * sum(N * K * 2 + rows * K * 2 for N, K in shapes.values())
     nz = sum(isinstance(pk[name], ops.PackedZ) for pk in model._packed for name in shapes)
-    return dict(launches=n, avg_ms=tot_ms / n, avg_bytes=tot_b / n, gbps=tot_b / 1e9 / (tot_ms / 1e3), fused_mlp=bool(fused_mlp),
+    return dict(launches=n, avg_ms=tot_ms / n, avg_bytes=tot_b / n, gbps=tot_b / 1e9 / (tot_ms / 1e3), fused_mlp=bool(fused_mlp), rows=rows,
                 compressed_launches=rounds * nz, avg_bytes_bf16=tot_b16 / n, gbps_bf16_equivalent=tot_b16 / 1e9 / (tot_ms / 1e3))
 
 
@@ -402,7 +462,7 @@ def workload_of(args, margs, rank, device, prompt_index=None):
     return dict(prompt=prompt, spec=spec, grammar=grammar, cfg=cfg, P=P, n_img=n_img, grid=grid, workload=workload, tau_est=2.3)
 
 
-def roofline_blocks(args, prof, prof_g1):
+def roofline_blocks(args, prof, prof_g1, pair=None):
     """-> (roofline, roofline_k1 or None) from the live HIP-event measurements.  `traffic` is NOT measured in this run: it is the PMC figure
     of the committed rocprofv3 --pmc pass at the same shapes (profiles/*_traffic.json), labelled as such, or null."""
     peak = 8000.0
@@ -422,7 +482,11 @@ def roofline_blocks(args, prof, prof_g1):
         k1_block = {"kernel": prof.get("kernel", "k1_partial (draft-window attention)"), "bound": "hbm", "achieved": round(prof["gbps"], 1),
                     "peak": peak, "unit": "GB/s", "frac": round(prof["gbps"] / peak, 4), "traffic": tr, "traffic_source": src,
                     "avg_us": round(prof["avg_ms"] * 1e3, 2), "avg_bytes": int(prof["avg_bytes"]),
-                    "avg_kv_rows": round(prof["avg_kv_rows"], 1), "launches": prof["launches"]}
+                    "avg_kv_rows": round(prof["avg_kv_rows"], 1), "launches": prof["launches"],
+                    "kernel_time_source": "eager launches, one HIP event pair per launch (or per batch of back-to-back launches) on the launch "
+                                          "stream: includes the ~5 us launch latency of an eager launch; `pair_in_graph` is what a step pays"}
+        if pair is not None:
+            k1_block["pair_in_graph"] = pair
     if prof_g1 is not None:       # the dominant kernel by time (~70 % of an iteration)
         g1_name = ("g1_skinny_gemm x3 + g1_gateup_silu (weight-streaming window projections, gate|up with SiLU*up as its epilogue; 128 launches / iteration)"
                    if prof_g1.get("fused_mlp") else "g1_skinny_gemm (weight-streaming window projections, 128 launches / iteration)")
@@ -437,7 +501,9 @@ def roofline_blocks(args, prof, prof_g1):
         alg_gbps = prof_g1.get("gbps_bf16_equivalent", prof_g1["gbps"])
         g1_block = {"kernel": g1_name, "bound": "hbm", "achieved": round(alg_gbps, 1), "peak": peak, "unit": "GB/s",
                     "frac": round(alg_gbps / peak, 4), "traffic": tr, "traffic_source": src, "avg_us": round(prof_g1["avg_ms"] * 1e3, 2),
-                    "avg_bytes": int(alg_b), "launches": prof_g1["launches"]}
+                    "avg_bytes": int(alg_b), "launches": prof_g1["launches"], "rows": prof_g1.get("rows", 32),
+                    "kernel_time_source": "one pass over all layers' packed weights captured in a hipGraph (the way the engine launches them), "
+                                          "replays timed with HIP events on the replay stream; avg over the four projection shapes"}
         if z:
             g1_block.update({"weight_stream": f"lossless 12-bit (G1z / G1sz; {prof_g1['compressed_launches']} of {prof_g1['launches']} launches; "
                                               "results bit-identical to the bf16 stream): `achieved` prices the bf16 bytes of SURVEY.md 8(d), "
@@ -448,7 +514,7 @@ def roofline_blocks(args, prof, prof_g1):
     return (g1_block, k1_block) if g1_block is not None else (k1_block, None)
 
 
-def other_config(base_args, model_name, window, device, steps=64, warmup=8):
+def other_config(base_args, model_name, window, device, steps=64, warmup=8, dtype=None):
     """Compact record of another BASELINE.json configuration measured in THIS run (configs 3 and 5 next to the headline's config 2):
     the model is built, decoded through a real lead-in to its mean KV length, `steps` SJD iterations are timed, G1 and K1 are measured
     with HIP events exactly as for the headline; then everything is freed."""
@@ -456,7 +522,7 @@ def other_config(base_args, model_name, window, device, steps=64, warmup=8):
     import gc
     import torch
     a = copy.copy(base_args)
-    a.model, a.window, a.dtype, a.kv, a.prompts_per_gpu, a.n_split = model_name, window, None, "auto", 1, 0
+    a.model, a.window, a.dtype, a.kv, a.prompts_per_gpu, a.n_split = model_name, window, dtype, "auto", 1, 0
     t0 = time.perf_counter()
     from sjd_amd.engine import SJDEngine
     import sjd_amd.ops as ops_
@@ -471,10 +537,14 @@ def other_config(base_args, model_name, window, device, steps=64, warmup=8):
     seq, st = eng.decode(w["prompt"], w["spec"], w["grammar"], w["cfg"], warmup_iters=warmup, timed_iters=steps, on_timed_start=sync,
                          on_timed_end=sync, lead_in_kv=lead if lead > P + window else None)
     prof = measure_k1(a, model, attn, device, kv_len=(st.kv_len_start + st.kv_len) // 2)
+    pair = measure_k1_pair(a, model, attn, device, kv_len=(st.kv_len_start + st.kv_len) // 2)
     prof_g1 = measure_g1(a, model, device)
-    r, rk1 = roofline_blocks(a, prof, prof_g1)
-    keep = ("kernel", "achieved", "frac", "avg_us", "avg_bytes", "launches", "avg_kv_rows", "stored_bytes", "frac_on_stored_bytes")
-    out = {"workload": w["workload"] + (", fp8 (e4m3) KV cache + fp8-MFMA draft attention" if fp8_kv else ""),
+    r, rk1 = roofline_blocks(a, prof, prof_g1, pair)
+    keep = ("kernel", "achieved", "frac", "avg_us", "avg_bytes", "launches", "avg_kv_rows", "stored_bytes", "frac_on_stored_bytes", "rows", "pair_in_graph")
+    wl = w["workload"]
+    if dtype == "bf16" and wl.endswith(", fp16"):
+        wl = wl[:-6] + ", bf16 (the dtype the reference's test_emu3.py:27 loads the model in)"
+    out = {"workload": wl + (", fp8 (e4m3) KV cache + fp8-MFMA draft attention" if fp8_kv else ""),
            "dtype": "fp16" if model.lm_head.weight.dtype == torch.float16 else "bf16", "steps": st.timed_nfe,
            "ms_per_step": round(st.seconds / max(st.timed_nfe, 1) * 1e3, 4), "tokens_per_step": round(st.tokens / max(st.timed_nfe, 1), 4),
            "tokens_per_s": round(st.tokens / max(st.seconds, 1e-9), 2), "kv_len": [st.kv_len_start, st.kv_len],
@@ -607,6 +677,7 @@ def main():
     decode_wall = time.perf_counter() - t_wall0
     kv_mid = (stats.kv_len_start + stats.kv_len) // 2
     prof = measure_k1(args, model, attn, device, kv_len=kv_mid)
+    pair = measure_k1_pair(args, model, attn, device, kv_len=kv_mid) if args.prompts_per_gpu == 1 else None
     prof_g1 = measure_g1(args, model, device) if (args.gemm == "sjd" and not args.no_fused) else None
     # whole image of this rank: from the end of the prefill iteration to the last iteration (host clock after each iteration's sync)
     img_tok = img_nfe = 0
@@ -674,7 +745,7 @@ def main():
                 k1 = measure_k1(args, model, attn, device, kv_len=S)
                 out["per_kv"][str(S)].update({"k1_us": round(k1["avg_ms"] * 1e3, 2), "k1_GBps": round(k1["gbps"], 1)})
 
-    r_main, r_k1 = roofline_blocks(args, prof, prof_g1)
+    r_main, r_k1 = roofline_blocks(args, prof, prof_g1, pair)
     if r_main is not None:
         out["roofline"] = r_main
     if r_k1 is not None:
@@ -697,9 +768,18 @@ def main():
                              on_timed_start=sync_all, on_timed_end=sync_all)
         synthetic.refill_embeddings_device(model, seed=0, embed_token_scale=args.embed_token_scale)
         tpf = st_f.tokens / max(st_f.timed_nfe, 1)
-        out["floor"] = {"embed_token_scale": 1.0, "embeddings_redrawn": redrawn, "tokens_per_step": round(tpf, 4), "steps": st_f.timed_nfe,
-                        "ms_per_step": round(st_f.seconds / max(st_f.timed_nfe, 1) * 1e3, 4), "kv_len": [st_f.kv_len_start, st_f.kv_len],
-                        "tokens_per_s_at_headline_ms_per_step": round(tpf / (t_max / max(stats.timed_nfe, 1)), 2)}
+        # (round 3 called this leg `floor`; it measures 2.2 tokens/step, so it is an acceptance-SENSITIVITY probe, not a floor)
+        out["acceptance_probe_unscaled_embeddings"] = {
+            "embed_token_scale": 1.0, "embeddings_redrawn": redrawn, "tokens_per_step": round(tpf, 4), "steps": st_f.timed_nfe,
+            "ms_per_step": round(st_f.seconds / max(st_f.timed_nfe, 1) * 1e3, 4), "kv_len": [st_f.kv_len_start, st_f.kv_len],
+            "tokens_per_s_at_headline_ms_per_step": round(tpf / (t_max / max(stats.timed_nfe, 1)), 2)}
+    if side_legs:
+        # the floor of the metric: SJD accepts at least ONE token per step whatever the weights are (the first draft is always verified against its
+        # own distribution), so ms_per_step -- the only hardware fact on this line -- bounds tokens/s from below at 1 token/step
+        ms_h = t_max / max(stats.timed_nfe, 1) * 1e3
+        out["floor"] = {"tokens_per_step": 1.0, "tokens_per_s": round(1e3 / ms_h, 2),
+                        "what": "1 / ms_per_step: the rate at the algorithm's minimum acceptance of one token per step (= plain AR decoding at this step time); "
+                                "`value` / this = the measured tokens per step"}
     if side_legs and not args.no_torch_baseline and args.model in ("lumina7b", "lumina_tiny"):
         # PyTorch-ROCm SJD: the reference's data flow with ATen ops on the SAME weights, prefilled with the engine's
         # own accepted sequence up to the start of the timed region, so that both run at the same KV length
@@ -725,11 +805,13 @@ def main():
         model.cache = None
         torch.cuda.empty_cache()
         out["other_configs"] = {}
-        for name, win in (("emu3_8b", 32), ("anole7b", 16)):
+        # (config 3 twice: fp16 as BASELINE.json words it, and bf16 -- what the reference's own test_emu3.py:27 runs -- where the lossless
+        #  12-bit weight stream G1z / G1sz applies)
+        for key, name, win, dt_ in (("emu3_8b", "emu3_8b", 32, None), ("emu3_8b_bf16", "emu3_8b", 32, "bf16"), ("anole7b", "anole7b", 16, None)):
             try:
-                out["other_configs"][name] = other_config(args, name, win, device)
+                out["other_configs"][key] = other_config(args, name, win, device, dtype=dt_)
             except Exception as e:       # a side leg must not cost the headline line
-                out["other_configs"][name] = {"error": repr(e)[:300]}
+                out["other_configs"][key] = {"error": repr(e)[:300]}
     out["bench_wall_s"] = {"decode": round(decode_wall, 2)}
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -104,6 +104,12 @@ def test_processor_descriptors_and_grammar_mapping():
         grammar_from_processors([TopKLogitsWarper(10), TopPLogitsWarper3d(0.9), HFTopP(top_p=0.8)])
     with pytest.raises(NotImplementedError):
         TopPLogitsWarper(0.8, min_tokens_to_keep=2)
+    # a top-p warper AHEAD of the temperature warper is evaluated by HF at T = 1; the kernels scale first -> refused, not silently reordered
+    with pytest.raises(NotImplementedError):
+        grammar_from_processors([vl, MultiTokensInterleavedTopKLogitsWarper(2000, 10, 8197, 8196), HFTopP(top_p=0.8), TemperatureLogitsWarper(0.9)])
+    with pytest.raises(NotImplementedError):
+        grammar_from_processors([TopKLogitsWarper(10), TopPLogitsWarper3d(0.9), TemperatureLogitsWarper(0.7)])
+    assert grammar_from_processors([TopKLogitsWarper(10), TopPLogitsWarper3d(0.9), TemperatureLogitsWarper(1.0)]).temperature == 1.0
 
 
 def test_get_double_cfg_input_ids_and_emu3_inputs():

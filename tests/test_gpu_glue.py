@@ -431,7 +431,10 @@ def _z_weight(N, K, gen, dev, outliers):
     (32, 96, 48, 16, 3, False),
     # the sub-tiled kernel: 65..128 rows (three / four prompts per forward), and a 64-row window whose K chunk does not fit in LDS
     (128, 4096, 11008, 896, 8, False), (96, 12288, 4096, 896, 8, True), (128, 22016, 4096, 2048, 8, True), (100, 512, 1376, 256, 3, True),
-    (64, 4096, 4096, 2048, 8, True), (128, 8224, 4096, 1024, 4, True), (70, 1024, 528, 128, 6, False)])
+    (64, 4096, 4096, 2048, 8, True), (128, 8224, 4096, 1024, 4, True), (70, 1024, 528, 128, 6, False),
+    # Emu3-8B in bf16 (what the reference's test_emu3.py:27 runs): the 64-row launch shapes of G1_CFG_EMU3 -- q|k|v 6144 columns, o, down with
+    # K 14336, gate|up 28672 columns as plain G1z
+    (64, 6144, 4096, 512, 8, False), (64, 4096, 14336, 896, 8, False), (64, 28672, 4096, 2048, 8, True)])
 @pytest.mark.parametrize("outliers", [0, 300])
 def test_g1z_matches_g1_bit_for_bit(dev, M, N, K, KC, waves, step_major, outliers):
     """G1z (the projection over the 12-bit lossless weight stream) writes the SAME split-K planes as G1 over the uncompressed packing of the
@@ -468,7 +471,7 @@ def test_g1z_matches_g1_bit_for_bit(dev, M, N, K, KC, waves, step_major, outlier
 
 @pytest.mark.parametrize("step_major", [False, True])
 @pytest.mark.parametrize("M,I,K", [(32, 11008, 4096), (17, 11008, 4096), (32, 1408, 512), (5, 128, 1024), (32, 2752, 2048),
-                                   (64, 11008, 4096), (40, 1408, 1024), (64, 2752, 2048)])
+                                   (64, 11008, 4096), (40, 1408, 1024), (64, 2752, 2048), (64, 14336, 4096)])       # (the last: Emu3-8B bf16)
 @pytest.mark.parametrize("with_norm", [True, False])
 @pytest.mark.parametrize("outliers", [0, 200])
 def test_g1sz_matches_g1s_bit_for_bit(dev, step_major, M, I, K, with_norm, outliers):

@@ -235,3 +235,38 @@ def test_lumina_loop_spatial_init(init_scheme, use_graph, gemm):
 def test_emu3_loop_spatial_init():
     r = G.teacher_forced_emu3_check(H=4, W=6, window=16, seed=8, init_scheme="repeat_horizon", gemm="sjd")
     assert r["gen"][(r["W"] + 1) * r["H"]:(r["W"] + 1) * r["H"] + 3] == [r["tok"]["eof_token"], r["tok"]["eoi_token"], r["tok"]["eos_token"]]
+
+
+@torch.no_grad()
+def test_batch_engine_unseeded_slots_draw_independent_noise(dev):
+    """cfg.seed = None: every slot gets its OWN Philox stream, drawn from the device's default generator at admission -- the SAME
+    prompt in two slots (and again in a refilled slot) must not sample the same image; torch.manual_seed still reproduces the run."""
+    import sjd_amd.ops as ops
+    import sjd_amd.synthetic as synthetic
+    from sjd_amd.engine import SJDConfig, WindowSpec
+    from sjd_amd.engine_batch import SJDBatchEngine
+    from sjd_amd.grammar import LuminaGrammar
+    from tests.helpers import make_chameleon
+    V, hg, wg, Pi = 9216, 4, 4, 11
+    conf = dict(vocab_size=V, hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=4, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    model = make_chameleon(conf, 23, 1.0, ops.HipWindowAttention(n_split=2), dtype=torch.bfloat16, device=str(dev))
+    model.enable_fused(ops, gemm="sjd")
+    n_img = (2 * wg + 1) * 2 * hg
+    pr = torch.cat([synthetic.synthetic_prompt(Pi - 3, 5, lo=8900, hi=9200), torch.tensor([[8197, 8804 + hg, 8804 + wg]])], dim=1)
+    spec = lambda: WindowSpec(first_tokens=pr.to(dev).repeat(2, 1),
+                              first_positions=torch.stack([torch.arange(Pi), torch.tensor([1] * (Pi - 1) + [0])]).to(dev),
+                              key_start=torch.tensor([0, Pi - 1], dtype=torch.int32), pos_offset=torch.tensor([0, -(Pi - 1)], dtype=torch.long), kv_base=0)
+    model.setup_cache(batch=4, s_max=((Pi + n_img + 5 + 64 + 31) // 32) * 32)
+    cfg = SJDConfig(jacobi_loop_interval_l=3, jacobi_loop_interval_r=n_img - 10, max_num_new_tokens=16, guidance_scale=3.0, seed=None,
+                    prefix_token_sampler_scheme="speculative_jacobi", max_length=1 << 20, eos_token_ids=(8196,))
+    eng = SJDBatchEngine(model, V, dev, 2, max_window=16, use_graph=True)
+
+    def run():
+        torch.manual_seed(77)
+        res = eng.decode_many([pr[0].tolist()] * 3, [spec() for _ in range(3)], [LuminaGrammar(2000, 10) for _ in range(3)], cfg)
+        return [seq for seq, _ in res]
+    a = run()
+    assert all(len(s) > Pi + 40 for s in a)
+    assert a[0] != a[1] and a[0] != a[2] and a[1] != a[2], "identical prompts in one batch / one queue sampled identical images"
+    assert run() == a, "torch.manual_seed must reproduce an unseeded-config run"

@@ -16,7 +16,7 @@ same token windows:
 
 Asserted: |hip16 - fp32| <= 1.5 x |aten16 - fp32| (max and mean) on the rows and vocabulary columns K2 reads, and the per-row argmax of
 hip16 agrees with aten16's unless the two candidates are closer in fp32 than the 16-bit error itself.  The numbers go to
-gpurun_out/r3_real_shape_forward_<family>.json (committed under profiles/).
+gpurun_out/r4_real_shape_forward_<family>[_P<prompt length>].json (committed under profiles/).
 """
 import json
 import math
@@ -124,9 +124,14 @@ def _allowed_columns(rules, V):
     return (lo, hi) if hi > lo else (0, V)
 
 
-@pytest.mark.parametrize("family", ["lumina7b", "emu3_8b"])
+# (family, prompt length, cache rows): P = 700 is round 3's case; P = 2300 (Lumina: the end of a 768x768 image) and P = 4100 (Emu3: the middle
+# of a 720x720 one, K1 with 16 splits x 8 tiles) put K1 and the late-image G1 / head launch shapes under the same INDEPENDENT check -- until
+# round 4 that region was only teacher-forced (VERDICT r3 missing #5, MC:499-581).  emu3_8b_bf16: the dtype the reference's test_emu3.py:27
+# loads Emu3 in; there the window projections run on the 12-bit stream (G1z / 64-row G1sz).
+@pytest.mark.parametrize("family,P,s_max", [("lumina7b", 700, 1024), ("emu3_8b", 700, 1024), ("emu3_8b_bf16", 700, 1024),
+                                            ("lumina7b", 2300, 2432), ("emu3_8b", 4100, 4224)])
 @torch.no_grad()
-def test_window_forward_at_production_shapes_against_independent_forwards(family):
+def test_window_forward_at_production_shapes_against_independent_forwards(family, P, s_max):
     import sjd_amd.ops as ops
     import sjd_amd.backbones as BB
     import sjd_amd.synthetic as synthetic
@@ -134,11 +139,13 @@ def test_window_forward_at_production_shapes_against_independent_forwards(family
     from sjd_amd.frontends import lumina_window_spec, lumina_prompt, emu3_window_spec
     from sjd_amd.grammar import LuminaGrammar, Emu3Grammar
     dev = torch.device("cuda:0")
-    P, seed = 700, 17
+    seed = 17
+    tag_name = family if P == 700 else f"{family}_P{P}"
     if family == "lumina7b":
         margs, dt, window = BB.LUMINA_7B, torch.bfloat16, 16
     else:
-        margs, dt, window = BB.EMU3_8B, torch.float16, 32
+        margs, dt, window = BB.EMU3_8B, (torch.bfloat16 if family.endswith("bf16") else torch.float16), 32
+        family = "emu3_8b"
     with torch.device(dev):
         model = BB.ChameleonBackbone(margs, attn=ops.HipWindowAttention()).to(dt).eval()
     if family == "emu3_8b":
@@ -147,8 +154,18 @@ def test_window_forward_at_production_shapes_against_independent_forwards(family
     model.enable_fused(ops, gemm="sjd")
     V = margs.vocab_size
     if family == "lumina7b":
-        prompt = lumina_prompt(P, 48, 48, seed=seed)
-        spec = lumina_window_spec(prompt, dev)
+        if P == 700:
+            prompt = lumina_prompt(P, 48, 48, seed=seed)
+            spec = lumina_window_spec(prompt, dev)
+        else:
+            # late in an image: a 64-token prompt followed by P - 64 image tokens, all handed over as the context, so that BOTH batch rows
+            # read a long cache (the uncond row hides only the 63 text tokens, as it does at the end of a real decode)
+            from sjd_amd.frontends import WindowSpec
+            prompt = lumina_prompt(64, 48, 48, seed=seed) + synthetic.synthetic_prompt(P - 64, seed + 5, lo=4, hi=8196)[0].tolist()
+            rows_ = torch.arange(P)
+            spec = WindowSpec(first_tokens=torch.tensor([prompt, prompt], dtype=torch.long, device=dev),
+                              first_positions=torch.stack([rows_, torch.where(rows_ < 63, torch.ones_like(rows_), rows_ - 63)]).to(dev),
+                              key_start=torch.tensor([0, 63], dtype=torch.int32), pos_offset=torch.tensor([0, -63], dtype=torch.long), kv_base=0)
         grammar = LuminaGrammar(2000, 10)
         cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=48 * 48 + 48 - 13, max_num_new_tokens=window, guidance_scale=3.0,
                         seed=seed, max_length=P + 400, eos_token_ids=(8196,))
@@ -161,7 +178,9 @@ def test_window_forward_at_production_shapes_against_independent_forwards(family
         grammar = Emu3Grammar(90, 90, 151854, 32768, top_k=2048, **tok)
         cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=90 * 90 - 1, max_num_new_tokens=window, guidance_scale=3.0,
                         seed=seed, max_length=P + 400, eos_token_ids=(tok["eos_token"],))
-    model.setup_cache(batch=2, s_max=1024)
+    if dt == torch.bfloat16:
+        assert model.compress_stats["compressed"] == model.compress_stats["matrices"], "bf16 weights stream in the 12-bit form"
+    model.setup_cache(batch=2, s_max=s_max)
     eng = SJDEngine(model, V, dev, max_window=window, use_graph=True)
     assert eng.head_partials, "the production path reads the output head's split-K partials"
     recs = []
@@ -183,6 +202,7 @@ def test_window_forward_at_production_shapes_against_independent_forwards(family
     wins = [r for r in recs if not r["first"] and r["n"] > 1]
     assert recs[0]["first"] and len(wins) >= 3 and any(r["graph"] for r in wins) and all(r["use_cfg"] for r in wins)
     assert model.attn.n_split >= 4, "a 700-token prompt must put K1 into the multi-split regime"
+    assert min(r["kv_len"] for r in wins) >= P
     ks, po = spec.key_start.to(dev), spec.pos_offset.to(dev)
     outs = {}
     for tag, fdt in (("aten16", dt), ("fp32", torch.float32)):
@@ -203,7 +223,7 @@ def test_window_forward_at_production_shapes_against_independent_forwards(family
         outs[tag] = res
         del f
         torch.cuda.empty_cache()
-    rep = dict(family=family, dtype=str(dt), prompt_len=P, window=window, n_split=int(model.attn.n_split), iterations=[])
+    rep = dict(family=tag_name, dtype=str(dt), prompt_len=P, window=window, n_split=int(model.attn.n_split), iterations=[])
     worst = dict(hip_max=0.0, aten_max=0.0, hip_mean=[], aten_mean=[])
     for i, r in enumerate(recs):
         rows = [0] if r["first"] else r["live"]
@@ -237,6 +257,6 @@ def test_window_forward_at_production_shapes_against_independent_forwards(family
     print("real-shape forward:", json.dumps(rep))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, f"r3_real_shape_forward_{family}.json"), "w") as fh:
+        with open(os.path.join(out_dir, f"r4_real_shape_forward_{tag_name}.json"), "w") as fh:
             json.dump(rep, fh, indent=1)
     assert rep["windows"]["argmax_agree"] >= 0.8, rep["windows"]

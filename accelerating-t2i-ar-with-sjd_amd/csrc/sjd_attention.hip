@@ -675,6 +675,8 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_shared(
     (void)nw;
 }
 
+#include "sjd_attention_ring.h"
+
 template <int DT, int D>
 __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
                                                  unsigned short *__restrict__ out, int n_rows, int H, int n_split, int n_chunks,
@@ -1548,7 +1550,23 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     // (sjd_draft_window_attention_merged); they re-arm themselves.
     static const bool no_merge = getenv("SJD_K1_NO_MERGE") != nullptr;
     unsigned short *merge_out = (ticket && !shared && !direct && !no_merge) ? (unsigned short *)out : nullptr;
-    if (shared) {
+    // round 4: the shared-tile shapes run on the LDS-DMA ring kernel (sjd_attention_ring.h); SJD_K1_RING=0: k1_partial_shared (A/B),
+    // SJD_K1_RING_SLOTS=4|6|8: ring depth (default 6 = five tiles of 16 KiB in flight per workgroup)
+    static const bool ring = [] { const char *e = getenv("SJD_K1_RING"); return !(e && e[0] == '0'); }();
+    static const int ring_slots = [] { const char *e = getenv("SJD_K1_RING_SLOTS"); const int v = e ? atoi(e) : 6; return (v == 4 || v == 8) ? v : 6; }();
+    if (shared && ring) {
+        if constexpr (D == 128) {
+#define SJD_K1R_LAUNCH(NWV_, R_) do {                                                                                                        \
+            const size_t lds = (size_t)(R_) * 2 * K1_KT * D * 2 + (size_t)(NWV_) * K1_ROWS * D * 2;                                          \
+            (void)hipFuncSetAttribute((const void *)k1_partial_ring<DT, D, NWV_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k1_partial_ring<DT, D, NWV_, R_>), dim3(n_split, H_kv, B), dim3(64 * NWV_), lds, stream, (const unsigned short *)q, \
+                               (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,  \
+                               kv_len, n_split, n_chunks, B); } while (0)
+            if (pairs == 8) { if (ring_slots == 4) SJD_K1R_LAUNCH(8, 4); else if (ring_slots == 8) SJD_K1R_LAUNCH(8, 8); else SJD_K1R_LAUNCH(8, 6); }
+            else { if (ring_slots == 4) SJD_K1R_LAUNCH(4, 4); else if (ring_slots == 8) SJD_K1R_LAUNCH(4, 8); else SJD_K1R_LAUNCH(4, 6); }
+#undef SJD_K1R_LAUNCH
+        }
+    } else if (shared) {
         if constexpr (D == 128) {
             static const bool three = [] { const char *e = getenv("SJD_K1_SHARED_SETS"); return !(e && atoi(e) == 6); }();      // 6: the deeper pipeline (A/B, measured equal)
             if (pairs == 8 && three)

@@ -1,0 +1,291 @@
+// sjd_attention_ring.h -- K1 for the shapes whose query rows SHARE key tiles (grouped-query heads and / or several 16-row chunks: Emu3's
+// GQA 32 / 8 with a draft window of 32, two to four prompts per forward), round 4.  Included by sjd_attention.hip (same helpers, same split /
+// workspace layout, k1_combine unchanged); replaces k1_partial_shared as the default for those shapes.
+//
+// Why a new structure ("restructure, do not trim"): k1_partial_shared moved a tile HBM -> VGPRs -> ds_write -> barrier with
+// three register sets "in flight".  Its ISA shows the compiler draining them: an `s_waitcnt vmcnt(0)` sits on the back edge of the unrolled
+// loop, so every third tile waited for the two loads issued just before it -- a full HBM round trip per three tiles, whatever travels
+// behind (that is the "a tile costs 1.4-1.9 us whatever is in flight" of round 3, and why six register sets measured equal to three).
+// Here the tiles never touch a VGPR on their way in:
+//   * LDS-DMA (`buffer_load_dwordx4 ... offen lds`, 1 KiB per wave instruction) writes K and V tiles straight into a RING of R slots of
+//     32 keys (16 KiB per slot at D = 128: K 8 KiB + V 8 KiB); R - 1 tiles are in flight per workgroup (R = 6: 80 KiB per CU), counted with
+//     hand-placed `s_waitcnt vmcnt(N)` -- the DMA has no destination register, so the compiler neither counts nor drains it;
+//   * the LDS image is lane-linear (a DMA cannot pad rows), so bank conflicts are avoided by permuting the SOURCE: 16-byte piece p of key
+//     row k lands at position p ^ (k & 15) of the K slot (fragment reads "lane = key, 16 B at piece 4 ks + g": 16 lanes, 16 positions) and
+//     at position p ^ 2 (k & 7) of the V slot (transposed reads: 8 rows x 32 B per half wave: 16 positions);
+//   * rows at or beyond the valid cache length are zeroed by the buffer descriptor's range check (num_records = valid rows): no select;
+//   * Q arrives by DMA too (each wave its own 16 rows), so the kernel has NO register load the compiler would wait for with vmcnt(0);
+//   * one raw s_barrier per tile: "my pieces of tile t have landed" (counted wait) -> barrier (everybody's have, and everybody is done with
+//     tile t - 1) -> refill the slot of tile t - 1 with tile t + R - 1 -> compute tile t.
+// The arithmetic of a tile (MFMA operands, rounding points, online-softmax order) is k1_partial_shared's: outputs are bit-identical.
+#pragma once
+
+template <int N> __device__ __forceinline__ void k1r_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// one LDS-DMA piece: 64 lanes x 16 B from (descriptor base + voff) to LDS bytes [lds_addr + 16 * lane, + 16).  M0 is the compiler's: it is
+// saved and restored inside the statement (guide 5.7); the s_nop covers the M0 write -> LDS-DMA read hazard.
+__device__ __forceinline__ void k1r_dma16(u32x4 rsrc, unsigned voff, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+// raw buffer descriptor over `bytes` bytes from `p` (wave-uniform: every dword goes through readfirstlane); loads past `bytes` return zero
+__device__ __forceinline__ u32x4 k1r_rsrc(const void *p, unsigned bytes)
+{
+    const unsigned long long a = (unsigned long long)p;
+    u32x4 r;
+    r[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) & 0xffffu;       // stride 0: raw buffer
+    r[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000u;                                                                         // 32-bit data format, no swizzle
+    return r;
+}
+
+__device__ __forceinline__ unsigned k1r_lds_addr(const void *p)
+{
+    return (unsigned)(unsigned long)((__attribute__((address_space(3))) const unsigned char *)p);
+}
+
+// x (op) x[lane ^ 16] (op) ... over the four 16-lane groups of a wave: what `v = op(v, __shfl_xor(v, 16)); v = op(v, __shfl_xor(v, 32))` computes
+// (the operands of every step are the same two values, and max / + are commutative: identical bits), on gfx950's row / half swaps
+// instead of two ds_bpermute round trips through the LDS.
+__device__ __forceinline__ float k1r_max_across_groups(float v)
+{
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float k1r_sum_across_groups(float v)
+{
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// NWV = waves per workgroup = (q head of the group, 16-row chunk) pairs: 4 or 8.  R = ring slots.
+template <int DT, int D, int NWV, int R>
+__global__ __launch_bounds__(64 * NWV) void k1_partial_ring(
+    const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
+    const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,        // (among the first 16 dwords: preloaded into SGPRs)
+    float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max, int kv_len_arg, int n_split, int n_chunks, int B)
+{
+    typedef typename Frag<DT>::vec vec;
+    static_assert(D == 128, "the ring kernel is written for head_dim 128 (16 pieces of 16 bytes per row)");
+    constexpr int KS = D / 32, DB = D / 16;
+    constexpr int ROWB = D * 2;                         // bytes per key row (256)
+    constexpr int TENSOR = K1_KT * ROWB;                // bytes per K or V tile (8 KiB)
+    constexpr int SLOT = 2 * TENSOR;                    // a ring slot: K tile, then V tile
+    constexpr int NP = TENSOR / 1024 / NWV;             // DMA pieces per wave, tile and tensor (1 with 8 waves, 2 with 4)
+    constexpr int NI = 2 * NP;                          // DMA instructions per wave and tile
+    static_assert(NP * NWV * 1024 == TENSOR, "the waves cover a tile exactly");
+    static_assert(NI * (R - 1) + 4 <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char k1r_lds[];      // [R slots][K | V] then [NWV][16 rows x 256 B] of Q
+    SJD_TR(0);
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = lane >> 4, c = lane & 15;
+    const int G = H / H_kv;
+    const int head_in_group = w % G, chunk = w / G;           // wave = (q head of the group, 16-row chunk)
+    const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
+    const int head = hkv * G + head_in_group;
+    int kv_base, n_total, kstart;
+    k1_entry(params, key_start, b, kv_len_arg, n_rows, kv_base, n_total, kstart);
+    const float scale = rsqrtf((float)D);
+
+    // this wave's rows and tile range (identical to what k1_partial / k1_combine derive for its chunk)
+    const int row0 = chunk * K1_ROWS;
+    const int n_c = min(K1_ROWS, n_total - row0);
+    const int kv_len = kv_base + row0;
+    const int total = kv_len + max(n_c, 0);
+    int t_lo, t_hi, eff_split, tps;
+    k1_tile_range(kstart, total, n_split, t_lo, t_hi, eff_split, tps);
+    const bool wave_on = split < eff_split;
+    const int wt0 = wave_on ? t_lo + split * tps : 0, wt1 = wave_on ? min(t_hi, wt0 + tps) : 0;
+    // the workgroup walks the union of its waves' ranges (they differ by at most a tile between the chunks)
+    int bt0 = 1 << 30, bt1 = 0, total_max = 0;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int nc = min(K1_ROWS, n_total - ch * K1_ROWS), tot = kv_base + ch * K1_ROWS + max(nc, 0);
+        int a, e, es, tp;
+        k1_tile_range(kstart, tot, n_split, a, e, es, tp);
+        if (split < es) { bt0 = min(bt0, a + split * tp); bt1 = max(bt1, min(e, a + split * tp + tp)); }
+        total_max = max(total_max, tot);
+    }
+    if (bt1 <= bt0) return;                   // no wave of this workgroup has work in this split
+    SJD_TR(1);                    // tile ranges known
+
+    const unsigned ring0 = k1r_lds_addr(k1r_lds);
+    const unsigned qlds = ring0 + R * SLOT + (unsigned)w * (K1_ROWS * ROWB);
+    // ---- Q: this wave's 16 rows, 4 pieces; row r, 16-byte piece p -> position p ^ r of LDS row r (the K swizzle)
+    {
+        const u32x4 qr = k1r_rsrc(q, (unsigned)B * (unsigned)n_rows * (unsigned)H * (unsigned)ROWB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * j + g;                                       // LDS row of this lane
+            const int grow = min(row0 + r, n_rows - 1);                    // (rows beyond the window: any valid row, zeroed below)
+            const unsigned voff = (unsigned)(((b * n_rows + grow) * H + head) * ROWB + ((c ^ r) * 16));
+            k1r_dma16(qr, voff, qlds + j * 1024);
+        }
+    }
+    // ---- K / V descriptors: rows >= total_max read as zero (0 * NaN inside the MFMA, see k1_partial)
+    const size_t slab = ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
+    const u32x4 kr = k1r_rsrc(kc + slab, (unsigned)total_max * ROWB), vr = k1r_rsrc(vc + slab, (unsigned)total_max * ROWB);
+    unsigned ck[NP], cv[NP];                  // lane-constant source offsets inside a tile
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int key = 4 * (w + NWV * i) + g;                             // key row (inside the tile) of this lane's piece
+        ck[i] = (unsigned)(key * ROWB + ((c ^ (key & 15)) * 16));
+        cv[i] = (unsigned)(key * ROWB + ((c ^ (2 * (key & 7))) * 16));
+    }
+    auto issue = [&](int t, int slot) {       // tile t -> ring slot; beyond the workgroup's range: out-of-range offsets (zeros, no traffic)
+        const unsigned tb = t < bt1 ? (unsigned)t * TENSOR : 0x7fff0000u;
+        const unsigned dst = ring0 + (unsigned)slot * SLOT + (unsigned)w * 1024;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            k1r_dma16(kr, tb + ck[i], dst + i * NWV * 1024);
+            k1r_dma16(vr, tb + cv[i], dst + TENSOR + i * NWV * 1024);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) issue(bt0 + i, i);
+    k1r_wait_vmcnt<NI *(R - 1)>();            // this wave's Q pieces have landed (nobody else reads them)
+
+    vec qf[KS];
+    {
+        const bool rv = (c < n_c);
+        const unsigned char *qrow = k1r_lds + R * SLOT + w * (K1_ROWS * ROWB) + c * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 x = *reinterpret_cast<const u32x4 *>(qrow + (((4 * ks + g) ^ c) * 16));
+            qf[ks] = as_frag<vec>(rv ? x : u32x4{0u, 0u, 0u, 0u});
+        }
+    }
+    // lane-constant read offsets inside a slot: K fragment (key 16 kb + c, piece 4 ks + g) and V transposed block (row 4 g + c / 4 (+ 16),
+    // piece 2 db + (c & 3) / 2, half c & 1)
+    unsigned kofs[KS], vofs[DB];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kofs[ks] = (unsigned)(c * ROWB + (((4 * ks + g) ^ c) * 16));
+    {
+        const int vrow = 4 * g + (c >> 2);
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+            vofs[db] = (unsigned)(TENSOR + vrow * ROWB + (((2 * db + ((c & 3) >> 1)) ^ (2 * (vrow & 7))) * 16) + 8 * (c & 1));
+    }
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x4 o_acc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute_tile = [&](int t, int slot) {
+        if (t >= wt0 && t < wt1) {
+            const unsigned char *sl = k1r_lds + slot * SLOT;
+            // every LDS read of the tile is issued up front -- 8 K fragments, then the 16 transposed V blocks, which land under the QK^T
+            // MFMAs and the softmax arithmetic (the compiler, left alone, recycled one register quad per fragment: eight serial LDS round trips)
+            u32x4 kf[2][KS];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *reinterpret_cast<const u32x4 *>(sl + kb * 16 * ROWB + kofs[ks]);
+            u32x2 vlo[DB], vhi[DB];
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                vlo[db] = lds_tr_read(reinterpret_cast<const unsigned short *>(sl + vofs[db]));
+                vhi[db] = lds_tr_read(reinterpret_cast<const unsigned short *>(sl + vofs[db] + 16 * ROWB));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 st[2];
+            st[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            st[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {             // two independent accumulation chains, interleaved
+                st[0] = Frag<DT>::mfma(as_frag<vec>(kf[0][ks]), qf[ks], st[0]);
+                st[1] = Frag<DT>::mfma(as_frag<vec>(kf[1][ks]), qf[ks], st[1]);
+            }
+            // interior tile (every row of the chunk sees every key of it): no visibility arithmetic -- same values as the masked form
+            const bool interior = (t * K1_KT >= kstart) && (t * K1_KT + K1_KT - 1 <= kv_len) && (t * K1_KT + K1_KT <= total);
+            float mx = -INFINITY;
+            if (interior) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sv = st[kb][r] * scale;
+                        st[kb][r] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = t * K1_KT + 16 * kb + 4 * g + r;
+                        const bool vis = (key >= kstart) && (key <= kv_len + c) && (key < total);
+                        const float sv = vis ? st[kb][r] * scale : -INFINITY;
+                        st[kb][r] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+            }
+            mx = k1r_max_across_groups(mx);               // the four lane groups of a row: xor 16, xor 32 (v_permlane*_swap, no LDS round trip)
+            const float m_new = fmaxf(m_run, mx);
+            const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float alpha = __expf(m_run - m_safe);
+            float rs = 0.0f;
+            unsigned short pb[8];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __expf(st[kb][r] - m_safe);
+                    rs += pv;
+                    pb[4 * kb + r] = Frag<DT>::cvt(pv);
+                }
+            rs = k1r_sum_across_groups(rs);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+            u32x4 pw;
+            pw[0] = pb[0] | ((unsigned)pb[1] << 16);
+            pw[1] = pb[2] | ((unsigned)pb[3] << 16);
+            pw[2] = pb[4] | ((unsigned)pb[5] << 16);
+            pw[3] = pb[6] | ((unsigned)pb[7] << 16);
+            const vec pfrag = as_frag<vec>(pw);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const u32x4 vv{vlo[db][0], vlo[db][1], vhi[db][0], vhi[db][1]};
+                f32x4 acc = o_acc[db];
+                acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+                o_acc[db] = Frag<DT>::mfma(as_frag<vec>(vv), pfrag, acc);
+            }
+        }
+    };
+
+    // ---- the ring: tile r (relative) lives in slot r % R; R - 1 tiles in flight
+    int slot = 0, refill = R - 1;             // slot of tile t; slot that tile t + R - 1 goes into (= the one tile t - 1 has just left)
+    for (int t = bt0; t < bt1; ++t) {
+        k1r_wait_vmcnt<NI *(R - 2)>();        // this wave's pieces of tile t have landed (tiles t + 1 .. t + R - 2 may still travel)
+        __builtin_amdgcn_s_barrier();         // ... and everybody's; everybody is done reading tile t - 1
+        if (t == bt0) SJD_TR(2);              // first tile in LDS
+        issue(t + R - 1, refill);
+        compute_tile(t, slot);
+        refill = slot;
+        slot = slot + 1 == R ? 0 : slot + 1;
+    }
+    SJD_TR(3);                    // key loop done
+    k1r_wait_vmcnt<0>();          // (the tail's out-of-range pieces: nothing may still be writing this workgroup's LDS when it exits)
+    if (!wave_on) return;
+    // the wave covered every tile of its split: its (m, l, O) is the split partial
+    const size_t slot0 = ((((size_t)b * H + head) * n_chunks + chunk) * n_split + split) * K1_ROWS;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(ws_o + (slot0 + c) * D + 16 * db + 4 * g) = o_acc[db];
+    if (g == 0) { ws_ml[(slot0 + c) * 2] = m_run; ws_ml[(slot0 + c) * 2 + 1] = l_run; }
+#ifdef SJD_TRACE
+    SJD_TR(4);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    SJD_TR(5);                    // partial stored
+    SJD_TR(6); SJD_TR(7);
+#endif
+}

@@ -111,6 +111,22 @@ template <> struct Frag<SJD_DTYPE_F16> {
 
 template <typename V> __device__ __forceinline__ V as_frag(u32x4 x) { return __builtin_bit_cast(V, x); }
 
+// two fp32 -> one dword of two 16-bit values (a in the low half), round-to-nearest-even: ONE v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 instead of two
+// conversions, a shift and an or -- the same bits as Frag<DT>::cvt of each
+template <int DT> __device__ __forceinline__ unsigned k1_cvt_pk(float a, float b);
+template <> __device__ __forceinline__ unsigned k1_cvt_pk<SJD_DTYPE_BF16>(float a, float b)
+{
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{a, b}), bf16x2_));
+}
+template <> __device__ __forceinline__ unsigned k1_cvt_pk<SJD_DTYPE_F16>(float a, float b)
+{
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{a, b}), f16x2_));
+}
+
 // transpose read: the 16 lanes of a group fetch a [4 keys][16 d] block (lane i: 8 bytes at row i/4, cols 4*(i%4)..+3)
 // and lane c receives column c (4 keys).
 __device__ __forceinline__ u32x2 lds_tr_read(const unsigned short *p)
@@ -675,18 +691,24 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_shared(
     (void)nw;
 }
 
+#ifndef SJD_K1_DSPLIT_DEFAULT
+#define SJD_K1_DSPLIT_DEFAULT 0
+#endif
 #include "sjd_attention_ring.h"
 
-template <int DT, int D>
+// RS (round 4 experiment): row blocks per 16-row chunk = workgroups per (batch, head, chunk).  RS = 2 gives Emu3's shape 256 workgroups instead
+// of 128 (8 rows x 128 d each, one float4 per thread and split; the arithmetic per element is unchanged) -- and measured slower, see the launcher.
+template <int DT, int D, int RS = 1>
 __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
                                                  unsigned short *__restrict__ out, int n_rows, int H, int n_split, int n_chunks,
                                                  const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,
                                                  int kv_len_arg)
 {
     SJD_TRC(0);
-    const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-    constexpr int PER = K1_ROWS * D / 256;          // consecutive d per thread
-    const int row = (threadIdx.x * PER) / D, d0 = (threadIdx.x * PER) % D;
+    const int chunk = blockIdx.x / RS, rblock = blockIdx.x % RS, head = blockIdx.y, b = blockIdx.z;
+    constexpr int PER = (K1_ROWS / RS) * D / 256;   // consecutive d per thread
+    static_assert(PER >= 1 && PER * 256 == (K1_ROWS / RS) * D, "256 threads cover the row block exactly");
+    const int row = rblock * (K1_ROWS / RS) + (threadIdx.x * PER) / D, d0 = (threadIdx.x * PER) % D;
     const int grow = chunk * K1_ROWS + row;
     const size_t base = (((size_t)b * H + head) * n_chunks + chunk) * n_split;
     // sixteen splits' (m, l, O) in flight at a time (the partials were written by the kernel that has just finished: cold -- every batch is
@@ -1554,6 +1576,18 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     // SJD_K1_RING_SLOTS=4|6|8: ring depth (default 6 = five tiles of 16 KiB in flight per workgroup)
     static const bool ring = [] { const char *e = getenv("SJD_K1_RING"); return !(e && e[0] == '0'); }();
     static const int ring_slots = [] { const char *e = getenv("SJD_K1_RING_SLOTS"); const int v = e ? atoi(e) : 6; return (v == 4 || v == 8) ? v : 6; }();
+    // round 4: the multi-head window without key splits -- four workgroups per (batch, head) split the OUTPUT COLUMNS (k1_dsplit): one
+    // launch, no workspace, no combine.  SJD_K1_DSPLIT=0|1 (A/B aid).
+    static const int dsplit = [] { const char *e = getenv("SJD_K1_DSPLIT"); return e ? atoi(e) : SJD_K1_DSPLIT_DEFAULT; }();
+    if (!shared && dsplit && D == 128 && H == H_kv) {
+        if constexpr (D == 128) {
+            hipLaunchKernelGGL((k1_dsplit<DT, D, 8, 4>), dim3(4 * n_chunks * H * B), dim3(512), 0, stream, (const unsigned short *)q,
+                               (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, (unsigned short *)out, n_rows, H, H_kv,
+                               S_max, kv_len, n_chunks, B);
+            if (ev1) (void)hipEventRecord(ev1, stream);
+            return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+        }
+    }
     if (shared && ring) {
         if constexpr (D == 128) {
 #define SJD_K1R_LAUNCH(NWV_, R_) do {                                                                                                        \
@@ -1597,6 +1631,16 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     if (ev1) (void)hipEventRecord(ev1, stream);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
     if (direct || merge_out) return SJD_OK;             // one key split, or the splits merged in the kernel: the output is written
+    if constexpr (D == 128) {      // two workgroups per (batch, head, chunk) while that still leaves at most ~2 per CU (window shapes; a prefill keeps one)
+        // (measured, round 4: SLOWER -- Emu3 pair 22.2 -> 24.8 us, Lumina 14.1 -> 14.8 us, profiles/r4_k1_combine_rs.txt -- the launch is bound by
+        //  its cold start and its one round trip, not by the CUs it covers; off unless SJD_K1_COMBINE_RS=2)
+        static const bool rs2 = [] { const char *e = getenv("SJD_K1_COMBINE_RS"); return e && e[0] == '2'; }();
+        if (rs2 && (long)n_chunks * H * B <= 256) {
+            hipLaunchKernelGGL((k1_combine<DT, D, 2>), dim3(2 * n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
+                               n_split, n_chunks, params, key_start, kv_len);
+            return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+        }
+    }
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
                        n_split, n_chunks, params, key_start, kv_len);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
@@ -1700,6 +1744,16 @@ static int launch_attention_fp8(const void *q, const void *kc, const void *vc, v
                            kv_len, n_split, n_chunks, k_scale, v_scale, merge_out, ticket);
     if (hipGetLastError() != hipSuccess) return SJD_ERR_LAUNCH;
     if (direct || merge_out) return SJD_OK;
+    if constexpr (D == 128) {      // two workgroups per (batch, head, chunk) while that still leaves at most ~2 per CU (window shapes; a prefill keeps one)
+        // (measured, round 4: SLOWER -- Emu3 pair 22.2 -> 24.8 us, Lumina 14.1 -> 14.8 us, profiles/r4_k1_combine_rs.txt -- the launch is bound by
+        //  its cold start and its one round trip, not by the CUs it covers; off unless SJD_K1_COMBINE_RS=2)
+        static const bool rs2 = [] { const char *e = getenv("SJD_K1_COMBINE_RS"); return e && e[0] == '2'; }();
+        if (rs2 && (long)n_chunks * H * B <= 256) {
+            hipLaunchKernelGGL((k1_combine<DT, D, 2>), dim3(2 * n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
+                               n_split, n_chunks, params, key_start, kv_len);
+            return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+        }
+    }
     hipLaunchKernelGGL((k1_combine<DT, D>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
                        n_split, n_chunks, params, key_start, kv_len);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;

@@ -17,7 +17,8 @@
 //   * Q arrives by DMA too (each wave its own 16 rows), so the kernel has NO register load the compiler would wait for with vmcnt(0);
 //   * one raw s_barrier per tile: "my pieces of tile t have landed" (counted wait) -> barrier (everybody's have, and everybody is done with
 //     tile t - 1) -> refill the slot of tile t - 1 with tile t + R - 1 -> compute tile t.
-// The arithmetic of a tile (MFMA operands, rounding points, online-softmax order) is k1_partial_shared's: outputs are bit-identical.
+// The MFMA operands and rounding points of a tile are k1_partial_shared's (scores and sums fp32, P rounded once to the 16-bit operand type);
+// the exponentials are taken as 2^((s - m) c1) in one fma + v_exp_f32, so the last fp32 bits differ from the round-3 kernel's.
 #pragma once
 
 template <int N> __device__ __forceinline__ void k1r_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -176,12 +177,18 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_ring(
             vofs[db] = (unsigned)(TENSOR + vrow * ROWB + (((2 * db + ((c & 3) >> 1)) ^ (2 * (vrow & 7))) * 16) + 8 * (c & 1));
     }
 
-    float m_run = -INFINITY, l_run = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;            // m_run: the running maximum of the RAW (unscaled) scores
+    const float c1 = scale * 1.4426950408889634f;     // log2(e) / sqrt(D)
     f32x4 o_acc[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db) o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // (timing probes, results invalid: -DK1R_NO_COMPUTE the DMA / barrier pipeline alone, -DK1R_NO_DMA the arithmetic of a tile on whatever the
+    //  LDS holds, -DK1R_NO_SOFTMAX LDS reads + MFMAs without the online-softmax VALU chain, -DK1R_NO_BARRIER no workgroup barrier)
     auto compute_tile = [&](int t, int slot) {
+#ifdef K1R_NO_COMPUTE
+        return;
+#endif
         if (t >= wt0 && t < wt1) {
             const unsigned char *sl = k1r_lds + slot * SLOT;
             // every LDS read of the tile is issued up front -- 8 K fragments, then the 16 transposed V blocks, which land under the QK^T
@@ -206,59 +213,56 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_ring(
                 st[0] = Frag<DT>::mfma(as_frag<vec>(kf[0][ks]), qf[ks], st[0]);
                 st[1] = Frag<DT>::mfma(as_frag<vec>(kf[1][ks]), qf[ks], st[1]);
             }
-            // interior tile (every row of the chunk sees every key of it): no visibility arithmetic -- same values as the masked form
+            // The online softmax works on the RAW scores: p = exp2((s - m) * c1) with c1 = log2(e) / sqrt(D) -- one fma and one v_exp_f32 per score
+            // (v_exp_f32 IS 2^x) instead of scale, subtract, multiply by log2(e), v_exp; the running maximum m_run is kept in raw units
+            // (max commutes with the positive scale) and converted once, when the partial is published.
+            // interior tile (every row of the chunk sees every key of it): no visibility arithmetic
             const bool interior = (t * K1_KT >= kstart) && (t * K1_KT + K1_KT - 1 <= kv_len) && (t * K1_KT + K1_KT <= total);
-            float mx = -INFINITY;
-            if (interior) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float sv = st[kb][r] * scale;
-                        st[kb][r] = sv;
-                        mx = fmaxf(mx, sv);
-                    }
-            } else {
+            if (!interior) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = t * K1_KT + 16 * kb + 4 * g + r;
                         const bool vis = (key >= kstart) && (key <= kv_len + c) && (key < total);
-                        const float sv = vis ? st[kb][r] * scale : -INFINITY;
-                        st[kb][r] = sv;
-                        mx = fmaxf(mx, sv);
+                        st[kb][r] = vis ? st[kb][r] : -INFINITY;
                     }
             }
+#ifdef K1R_NO_SOFTMAX
+            const float alpha = 1.0f;
+            u32x4 pw{__float_as_uint(st[0][0]), __float_as_uint(st[0][1]), __float_as_uint(st[1][2]), __float_as_uint(st[1][3])};
+            const vec pfrag = as_frag<vec>(pw);
+#else
+            float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])), fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
             mx = k1r_max_across_groups(mx);               // the four lane groups of a row: xor 16, xor 32 (v_permlane*_swap, no LDS round trip)
             const float m_new = fmaxf(m_run, mx);
             const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
-            const float alpha = __expf(m_run - m_safe);
-            float rs = 0.0f;
-            unsigned short pb[8];
+            const float nm = -m_safe * c1;
+            const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, c1, nm));       // (m_run = -inf: 2^-inf = 0)
+            float pv[8];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __expf(st[kb][r] - m_safe);
-                    rs += pv;
-                    pb[4 * kb + r] = Frag<DT>::cvt(pv);
-                }
+                for (int r = 0; r < 4; ++r) pv[4 * kb + r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], c1, nm));
+            float rs = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
             rs = k1r_sum_across_groups(rs);
-            l_run = l_run * alpha + rs;
+            l_run = __builtin_fmaf(l_run, alpha, rs);
             m_run = m_new;
             u32x4 pw;
-            pw[0] = pb[0] | ((unsigned)pb[1] << 16);
-            pw[1] = pb[2] | ((unsigned)pb[3] << 16);
-            pw[2] = pb[4] | ((unsigned)pb[5] << 16);
-            pw[3] = pb[6] | ((unsigned)pb[7] << 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pw[i] = k1_cvt_pk<DT>(pv[2 * i], pv[2 * i + 1]);
             const vec pfrag = as_frag<vec>(pw);
+#endif
+            // the running output is rescaled only when some row's maximum moved (alpha == 1 exactly otherwise: 2^0)
+            const bool rescale = __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull;
+            if (rescale) {
+#pragma unroll
+                for (int db = 0; db < DB; ++db) { o_acc[db][0] *= alpha; o_acc[db][1] *= alpha; o_acc[db][2] *= alpha; o_acc[db][3] *= alpha; }
+            }
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const u32x4 vv{vlo[db][0], vlo[db][1], vhi[db][0], vhi[db][1]};
-                f32x4 acc = o_acc[db];
-                acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
-                o_acc[db] = Frag<DT>::mfma(as_frag<vec>(vv), pfrag, acc);
+                o_acc[db] = Frag<DT>::mfma(as_frag<vec>(vv), pfrag, o_acc[db]);
             }
         }
     };
@@ -266,10 +270,16 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_ring(
     // ---- the ring: tile r (relative) lives in slot r % R; R - 1 tiles in flight
     int slot = 0, refill = R - 1;             // slot of tile t; slot that tile t + R - 1 goes into (= the one tile t - 1 has just left)
     for (int t = bt0; t < bt1; ++t) {
+#ifndef K1R_NO_DMA
         k1r_wait_vmcnt<NI *(R - 2)>();        // this wave's pieces of tile t have landed (tiles t + 1 .. t + R - 2 may still travel)
+#endif
+#ifndef K1R_NO_BARRIER
         __builtin_amdgcn_s_barrier();         // ... and everybody's; everybody is done reading tile t - 1
+#endif
         if (t == bt0) SJD_TR(2);              // first tile in LDS
+#ifndef K1R_NO_DMA
         issue(t + R - 1, refill);
+#endif
         compute_tile(t, slot);
         refill = slot;
         slot = slot + 1 == R ? 0 : slot + 1;
@@ -281,11 +291,238 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_ring(
     const size_t slot0 = ((((size_t)b * H + head) * n_chunks + chunk) * n_split + split) * K1_ROWS;
 #pragma unroll
     for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(ws_o + (slot0 + c) * D + 16 * db + 4 * g) = o_acc[db];
-    if (g == 0) { ws_ml[(slot0 + c) * 2] = m_run; ws_ml[(slot0 + c) * 2 + 1] = l_run; }
+    if (g == 0) { ws_ml[(slot0 + c) * 2] = m_run * scale; ws_ml[(slot0 + c) * 2 + 1] = l_run; }       // (m in the units k1_combine merges in)
 #ifdef SJD_TRACE
     SJD_TR(4);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     SJD_TR(5);                    // partial stored
     SJD_TR(6); SJD_TR(7);
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------ K1 (D-split, no key split, no combine)
+// Round 4, the multi-head 16-row window (Lumina / Anole: B * H = 64 (batch, head) pairs, nothing shared between them): k1_partial fills the
+// chip by splitting the KEYS of a pair over four workgroups, and their partial (m, l, O) then need a second dependent launch (k1_combine,
+// 5 us of a 14 us pair, 3 us of them launch cost) or an in-kernel exchange that measured the same (round 3).  Here the four workgroups of a
+// pair split the OUTPUT COLUMNS instead: each computes the scores of ALL keys (the K stream is read by all four -- from the XCD's L2 after
+// the first, the block -> XCD map puts the four siblings on one XCD, dispatched back to back) and multiplies them with ITS 32 columns of V
+// only; its eight waves walk the key tiles as k1_partial's do (K rows straight into MFMA fragments, V slice through a per-wave LDS tile),
+// merge their eight (m, l, O) through LDS and write the NORMALISED 16-bit output: one launch, no workspace, no exchange between
+// workgroups.  Cost: QK^T and the softmax run four times (16-row windows: the MFMA pipe idles anyway) and every CU pulls K + V / 4
+// (2.5 x the bytes through its L1, 1 x from HBM).
+template <int DT, int D, int NW, int DS>
+__global__ __launch_bounds__(64 * NW) void k1_dsplit(
+    const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
+    const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start, unsigned short *__restrict__ out,
+    int n_rows, int H, int H_kv, int S_max, int kv_len_arg, int n_chunks, int B)
+{
+    typedef typename Frag<DT>::vec vec;
+    constexpr int KS = D / 32;
+    constexpr int DW = D / DS;                // output columns of this workgroup
+    constexpr int DB = DW / 16;               // 16-wide d blocks of it
+    constexpr int VROW = DW + 8;              // padded LDS row of the V slice (elements)
+    constexpr int V_BYTES = NW * K1_KT * VROW * 2;
+    constexpr int R_BYTES = NW * K1_ROWS * (DW + K1_RPAD + 2) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char arena[V_BYTES > R_BYTES ? V_BYTES : R_BYTES];
+    unsigned short (*v_lds)[K1_KT * VROW] = reinterpret_cast<unsigned short (*)[K1_KT * VROW]>(arena);
+    float (*red_o)[K1_ROWS][DW + K1_RPAD] = reinterpret_cast<float (*)[K1_ROWS][DW + K1_RPAD]>(arena);
+    float (*red_ml)[K1_ROWS][2] = reinterpret_cast<float (*)[K1_ROWS][2]>(arena + NW * K1_ROWS * (DW + K1_RPAD) * 4);
+
+    // block -> (pair, column slice): blocks id, id + 8, id + 16, ... run on one XCD; the DS siblings of a pair are consecutive among them
+    const int n_pairs = n_chunks * H * B;
+    int pair, dq;
+    if ((n_pairs & 7) == 0) {
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+        dq = slot % DS;
+        pair = (slot / DS) * 8 + xcd;
+    } else {
+        dq = blockIdx.x % DS;
+        pair = blockIdx.x / DS;
+    }
+    const int chunk = pair % n_chunks, head = (pair / n_chunks) % H, b = pair / (n_chunks * H);
+    const int G = H / H_kv, hkv = head / G;
+    int kv_base, n_total, kstart;
+    k1_entry(params, key_start, b, kv_len_arg, n_rows, kv_base, n_total, kstart);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int row0 = chunk * K1_ROWS;
+    const int n_c = min(K1_ROWS, n_total - row0);
+    const int kv_len = kv_base + row0;
+    const int total = kv_len + max(n_c, 0);
+    const float scale = rsqrtf((float)D);
+    const int t_lo = kstart / K1_KT, t_hi = (total + K1_KT - 1) / K1_KT;
+
+    vec qf[KS];
+    {
+        const bool rv = (c < n_c);
+        const unsigned short *qp = q + (((size_t)b * n_rows + (row0 + (rv ? c : 0))) * H + head) * D + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 x = rv ? *reinterpret_cast<const u32x4 *>(qp + 32 * ks) : u32x4{0, 0, 0, 0};
+            qf[ks] = as_frag<vec>(x);
+        }
+    }
+    const unsigned short *kbase = kc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
+    const unsigned short *vbase = vc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D + dq * DW;
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x4 o_acc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int VP = K1_KT * DW / (64 * 8);    // 16-B pieces per lane for one V slice tile
+    constexpr int LPR = DW / 8;                  // lanes per V row
+    static_assert(VP >= 1 && VP * 64 * 8 == K1_KT * DW, "a wave covers the V slice tile exactly");
+    u32x4 kreg[2][KS], kn[2][KS], vstage[VP], vstage2[VP];
+    unsigned short *vl = v_lds[w];
+    auto load_tile = [&](int t, u32x4 (&kd)[2][KS], u32x4 (&vd)[VP]) {
+        const unsigned short *kt = kbase + (size_t)(t * K1_KT) * D;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                kd[kb][ks] = *reinterpret_cast<const u32x4 *>(kt + (size_t)(16 * kb + c) * D + 32 * ks + 8 * g);
+        const unsigned short *vt = vbase + (size_t)(t * K1_KT) * D;
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            const int idx = i * 64 + lane;
+            vd[i] = *reinterpret_cast<const u32x4 *>(vt + (size_t)(idx / LPR) * D + 8 * (idx % LPR));
+        }
+    };
+    auto store_v = [&](int t, u32x4 (&vd)[VP]) {          // rows of keys >= total are zeroed (0 * NaN inside the MFMA, see k1_partial)
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            const int idx = i * 64 + lane;
+            const bool live = (t * K1_KT + idx / LPR) < total;
+            *reinterpret_cast<u32x4 *>(vl + (idx / LPR) * VROW + 8 * (idx % LPR)) = live ? vd[i] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto compute_tile = [&](int t) {
+        f32x4 st[2];
+        st[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            st[0] = Frag<DT>::mfma(as_frag<vec>(kreg[0][ks]), qf[ks], st[0]);
+            st[1] = Frag<DT>::mfma(as_frag<vec>(kreg[1][ks]), qf[ks], st[1]);
+        }
+        const bool interior = (t * K1_KT >= kstart) && (t * K1_KT + K1_KT - 1 <= kv_len) && (t * K1_KT + K1_KT <= total);
+        float mx = -INFINITY;
+        if (interior) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float sv = st[kb][r] * scale; st[kb][r] = sv; mx = fmaxf(mx, sv); }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * K1_KT + 16 * kb + 4 * g + r;
+                    const bool vis = (key >= kstart) && (key <= kv_len + c) && (key < total);
+                    const float sv = vis ? st[kb][r] * scale : -INFINITY;
+                    st[kb][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+        }
+        mx = k1r_max_across_groups(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+        const float alpha = __expf(m_run - m_safe);
+        float rs = 0.0f;
+        unsigned short pb[8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __expf(st[kb][r] - m_safe);
+                rs += pv;
+                pb[4 * kb + r] = Frag<DT>::cvt(pv);
+            }
+        rs = k1r_sum_across_groups(rs);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        u32x4 pw;
+        pw[0] = pb[0] | ((unsigned)pb[1] << 16);
+        pw[1] = pb[2] | ((unsigned)pb[3] << 16);
+        pw[2] = pb[4] | ((unsigned)pb[5] << 16);
+        pw[3] = pb[6] | ((unsigned)pb[7] << 16);
+        const vec pfrag = as_frag<vec>(pw);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const unsigned short *a0 = vl + (4 * g + (c >> 2)) * VROW + 16 * db + 4 * (c & 3);
+            const u32x2 lo = lds_tr_read(a0), hi = lds_tr_read(a0 + 16 * VROW);
+            const u32x4 vv{lo[0], lo[1], hi[0], hi[1]};
+            f32x4 acc = o_acc[db];
+            acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+            o_acc[db] = Frag<DT>::mfma(as_frag<vec>(vv), pfrag, acc);
+        }
+    };
+    auto adopt_next = [&](int tn, u32x4 (&vd)[VP]) {
+        store_v(tn, vd);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kreg[kb][ks] = kn[kb][ks];
+    };
+    // wave w walks tiles t_lo + w, + NW, ...; two of them are in flight before the first is waited for (k1_partial)
+    int t = t_lo + w;
+    if (t < t_hi) {
+        load_tile(t, kreg, vstage);
+        if (t + NW < t_hi) {
+            load_tile(t + NW, kn, vstage2);
+            store_v(t, vstage);
+            compute_tile(t);
+            adopt_next(t + NW, vstage2);
+            t += NW;
+        } else {
+            store_v(t, vstage);
+        }
+    }
+    for (; t < t_hi; t += NW) {
+        const int tn = t + NW;
+        const bool has_next = tn < t_hi;
+        if (has_next) load_tile(tn, kn, vstage);
+        compute_tile(t);
+        if (has_next) adopt_next(tn, vstage);
+    }
+    // ---- merge the eight key parts through LDS and write the normalised rows of this column slice
+    __syncthreads();
+    if (g == 0) { red_ml[w][c][0] = m_run; red_ml[w][c][1] = l_run; }
+#pragma unroll
+    for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(&red_o[w][c][16 * db + 4 * g]) = o_acc[db];
+    __syncthreads();
+    constexpr int D4 = DW / 4;
+    for (int u = threadIdx.x; u < K1_ROWS * D4; u += 64 * NW) {
+        const int row = u / D4, d = (u % D4) * 4;
+        const int grow = row0 + row;
+        if (grow >= n_rows) continue;
+        float mk[NW], lk[NW];
+        float4 ok[NW];
+#pragma unroll
+        for (int kp = 0; kp < NW; ++kp) {                      // every LDS read of this thread is issued before the first use
+            const float2 v = *reinterpret_cast<const float2 *>(&red_ml[kp][row][0]);
+            ok[kp] = *reinterpret_cast<const float4 *>(&red_o[kp][row][d]);
+            mk[kp] = v.x;
+            lk[kp] = v.y;
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int kp = 0; kp < NW; ++kp) M = fmaxf(M, mk[kp]);
+        const float Ms = (M == -INFINITY) ? 0.0f : M;
+        float L = 0.f, O0 = 0.f, O1 = 0.f, O2 = 0.f, O3 = 0.f;
+#pragma unroll
+        for (int kp = 0; kp < NW; ++kp) {
+            const float wgt = __expf(mk[kp] - Ms);
+            L += wgt * lk[kp];
+            O0 += wgt * ok[kp].x; O1 += wgt * ok[kp].y; O2 += wgt * ok[kp].z; O3 += wgt * ok[kp].w;
+        }
+        const float inv = L > 0.f ? 1.0f / L : 0.0f;
+        uint2 pk{0u, 0u};
+        if (grow < n_total) {
+            pk.x = (unsigned)Frag<DT>::cvt(O0 * inv) | ((unsigned)Frag<DT>::cvt(O1 * inv) << 16);
+            pk.y = (unsigned)Frag<DT>::cvt(O2 * inv) | ((unsigned)Frag<DT>::cvt(O3 * inv) << 16);
+        }
+        *reinterpret_cast<uint2 *>(out + (((size_t)b * n_rows + grow) * H + head) * D + dq * DW + d) = pk;
+    }
 }

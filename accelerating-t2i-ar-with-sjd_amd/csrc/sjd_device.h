@@ -254,6 +254,152 @@ __device__ __forceinline__ float block_kth_largest_regs(const float (&z)[NI][4],
     return key2f(prefix);
 }
 
+// ---- exact k-th largest by BISECTION over the 32 key bits (round 4) -------------------------------------------------------
+// Same answer as the radix select above -- the k-th largest key among the entries `> floor_excl`, returned as its float -- without the
+// LDS histogram: that one funnels every entry of a row through atomicAdd on 2048 bins, of which a softmax row hits a dozen (the logits
+// share their exponent), so the adds of 8192 .. 32768 entries serialise on a few LDS words: 25 us of K2's 35 at Lumina's shape, most of its
+// 187 us at Emu3's (in-kernel stamps, round 3).  Here two key bits are fixed per round: the three candidates K | 1<<b, K | 2<<b, K | 3<<b are
+// turned back into floats (key order == float order for everything that is not a NaN), every entry is compared against them with
+// v_cmp -> wave ballot -> s_bcnt1 (the counts accumulate in SGPRs: no shuffle, no atomic), lane 0 of each wave posts its three counts,
+// one barrier, every thread adds the 16 x 3 wave counts; 16 rounds.  Entries at or below the floor never count against a candidate above
+// the floor, and the answer lies above it (k <= number of entries above the floor), so the decision of every round is the radix select's:
+//   * -inf (K2's floor) is below every candidate that can be reached (a reached candidate has one of the bits 31..23 set);
+//   * +0 (K4's floor) counts only against candidates <= key(+0), where the count is >= k either way.
+// A candidate in the NaN range counts nothing, and nothing valid lies there.  -0 vs +0: equal as floats, adjacent as keys; the result is
+// only ever used in `z < kth`, which cannot tell them apart.
+// one round's exchange: the wave counts (three 21-bit fields of a u64: a row has fewer than 2^21 columns) are added into one of THREE LDS words
+// used in rotation -- round r adds into word r % 3 and clears word (r + 1) % 3, which was last read two rounds (two barriers) ago -- so a
+// round costs one 64-bit LDS atomic per wave, ONE barrier and one LDS read per thread.
+__device__ __forceinline__ unsigned bisect_pick(unsigned K, int b, int k, int round, int n1, int n2, int n3, SjdShared &sh)
+{
+    unsigned long long *cnt = sh.wave_u64;             // (block_argmax's exchange buffer: not in use while a select runs)
+    const int cur = round % 3, nxt = (round + 1) % 3;
+    if ((threadIdx.x & 63) == 0)
+        atomicAdd(&cnt[cur], (unsigned long long)(unsigned)n1 | ((unsigned long long)(unsigned)n2 << 21) | ((unsigned long long)(unsigned)n3 << 42));
+    if (threadIdx.x == 0) cnt[nxt] = 0ull;
+    __syncthreads();
+    const unsigned long long t = cnt[cur];
+    const int t1 = (int)(t & 0x1fffffu), t2 = (int)((t >> 21) & 0x1fffffu), t3 = (int)((t >> 42) & 0x1fffffu);
+    return t3 >= k ? (K | (3u << b)) : t2 >= k ? (K | (2u << b)) : t1 >= k ? (K | (1u << b)) : K;
+}
+
+// the entries are what a thread holds in registers: z[i][j] (-inf, or anything at or below the floor, where the window or the rule excludes it)
+template <int NI>
+__device__ __forceinline__ float block_kth_largest_bisect_regs(const float (&z)[NI][4], int k, SjdShared &sh)
+{
+    __syncthreads();                                   // (whoever used the exchange words before is done with them)
+    if (threadIdx.x == 0) sh.wave_u64[0] = 0ull;
+    __syncthreads();
+    unsigned K = 0;
+    int round = 0;
+    for (int b = 30; b >= 0; b -= 2, ++round) {
+        const float f1 = key2f(K | (1u << b)), f2 = key2f(K | (2u << b)), f3 = key2f(K | (3u << b));
+        int n1 = 0, n2 = 0, n3 = 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = z[i][j];
+                n1 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v >= f1));
+                n2 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v >= f2));
+                n3 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v >= f3));
+            }
+        K = bisect_pick(K, b, k, round, n1, n2, n3, sh);
+    }
+    __syncthreads();                                   // (the last round's reads are done before the words serve block_argmax again)
+    return key2f(K);
+}
+
+// the entries are staged in memory (LDS or global): column c of [lo, hi) at row[c - base] (a row staged in LDS starts at its window, not at
+// column 0).  A window of at most NIW column groups per thread is taken into registers ONCE (entries at or below the floor as -inf) and
+// selected there; a wider one (text rows over a whole vocabulary) is re-read every round.
+#define SJD_BISECT_NIW 9
+__device__ __forceinline__ float block_kth_largest_bisect(const float *row, int lo, int hi, int k, float floor_excl, SjdShared &sh, int base = 0)
+{
+    const int c_first = 4 * sjd_first_owned_group(lo);
+    if ((hi - (lo & ~3) + 4 * SJD_TPB - 1) / (4 * SJD_TPB) <= SJD_BISECT_NIW) {         // (the same for every thread of the block)
+        float v[SJD_BISECT_NIW][4];
+#pragma unroll
+        for (int i = 0; i < SJD_BISECT_NIW; ++i) {
+            const int c0 = c_first + i * 4 * SJD_TPB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                const bool in = c0 < hi && c >= lo && c < hi;
+                const float x = row[(in ? c : lo) - base];
+                v[i][j] = (in && x > floor_excl) ? x : -INFINITY;
+            }
+        }
+        return block_kth_largest_bisect_regs<SJD_BISECT_NIW>(v, k, sh);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sh.wave_u64[0] = 0ull;
+    __syncthreads();
+    unsigned K = 0;
+    int round = 0;
+    for (int b = 30; b >= 0; b -= 2, ++round) {
+        const float f1 = key2f(K | (1u << b)), f2 = key2f(K | (2u << b)), f3 = key2f(K | (3u << b));
+        int n1 = 0, n2 = 0, n3 = 0;
+        for (int c0 = c_first; __builtin_amdgcn_ballot_w64(c0 < hi) != 0ull; c0 += 4 * SJD_TPB) {     // (wave-uniform trip count: ballots inside)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                const bool in = c0 < hi && c >= lo && c < hi;
+                const float v = row[(in ? c : lo) - base];
+                const bool ok = in && v > floor_excl;
+                n1 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && v >= f1));
+                n2 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && v >= f2));
+                n3 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && v >= f3));
+            }
+        }
+        K = bisect_pick(K, b, k, round, n1, n2, n3, sh);
+    }
+    __syncthreads();
+    return key2f(K);
+}
+
+// ---- exact k-th largest: a VALUE histogram first, the radix select over the survivors (round 4) ------------------------------
+// The radix select funnels every score of a row through atomicAdd on the bins of its top 11 key bits (sign, exponent, two mantissa bits) --
+// and the scores of one softmax row share their exponent: 8192 .. 32768 adds land on a dozen LDS words and serialise (in-kernel stamps,
+// round 3: 25 of K2's 35 us at Lumina's shape).  A bisection over the key bits removes the atomics but needs 16 rounds of three compares
+// per score: 2400 instructions per wave with four waves per SIMD -- measured no faster (19 us).  Here the FIRST histogram is over the
+// scores' VALUES, 2048 equal bins across [zmax - 32, zmax] (what lies below carries < e^-32 of the mass and shares bin 0): the scores spread
+// over hundreds of bins, a handful per bin, so the adds do not collide.  bin(z) is monotone in z (subtract, scale by a positive constant,
+// clamp, truncate: each step is), hence every score above the selected bin is larger than every score in it: the k-th largest of the row
+// is the k'-th largest of that bin, k' = k - (scores above).  The three radix passes then run as before but only the bin's few scores
+// (typically < 20) reach an atomicAdd.  Same result as block_kth_largest: the k-th largest key, exactly.
+// `visit(f)` calls f(z) for every entry this thread owns (entries at or below the floor / outside the window may be skipped or passed as -inf).
+template <class Visit>
+__device__ __forceinline__ float block_kth_largest_spread(Visit &&visit, int k, float zmax, SjdShared &sh)
+{
+    const float lo = zmax - 32.0f, inv = (float)(SJD_RADIX_BINS - 1) / 32.0f;
+    auto bin_of = [&](float z) { return (int)fminf(fmaxf((z - lo) * inv, 0.0f), (float)(SJD_RADIX_BINS - 1)); };
+    for (int b = threadIdx.x; b < SJD_RADIX_BINS; b += SJD_TPB) sh.hist[b] = 0;
+    __syncthreads();
+    visit([&](float z) { if (z > -INFINITY) atomicAdd(&sh.hist[bin_of(z)], 1u); });
+    int bsel, krem;
+    radix_pick(k, sh, bsel, krem);
+    unsigned prefix = 0;
+    const int shifts[3] = {21, 10, 0};
+    const unsigned masks[3] = {0x7ffu, 0x7ffu, 0x3ffu};
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int b = threadIdx.x; b < SJD_RADIX_BINS; b += SJD_TPB) sh.hist[b] = 0;
+        __syncthreads();
+        const int shift = shifts[pass];
+        visit([&](float z) {
+            if (z > -INFINITY && bin_of(z) == bsel) {
+                const unsigned key = f2key(z);
+                const bool match = (pass == 0) || ((key >> (shift + (pass == 1 ? 11 : 10))) == prefix);
+                if (match) atomicAdd(&sh.hist[(key >> shift) & masks[pass]], 1u);
+            }
+        });
+        int bin;
+        radix_pick(krem, sh, bin, krem);
+        prefix = (pass == 0) ? (unsigned)bin : ((prefix << (pass == 1 ? 11 : 10)) | (unsigned)bin);
+    }
+    return key2f(prefix);
+}
+
 // ---- top-p cut (order-independent restatement of TopPLogitsWarper3d, see oracle/sjd_oracle.c header) ---------------------
 // w[lo..hi): non-negative weights staged in global memory (e = exp(z - max) or the residual d); p_i = w_i / S.
 // Returns K* = the largest uint32 key with canonical_sum{ p_i : w_i > 0, key(w_i) <= K* } <= thr (32 canonical sums).
@@ -261,7 +407,7 @@ __device__ __forceinline__ float block_kth_largest_regs(const float (&z)[NI][4],
 // only), whereas the reference's sorted cumulative sum (logit_processor_3dim.py:406-419) splits a run of equal values by sort order --
 // which torch.sort does not define for equal keys.  With fp32 softmax outputs a tie exactly at the cut is a measure-zero event; the oracle
 // restates THIS rule (oracle/sjd_oracle.c) and is pinned against the reference's golden vectors, none of which hits one.
-__device__ unsigned block_top_p_cut_key(const float *w, int lo, int hi, float S, float thr, SjdShared &sh)
+__device__ unsigned block_top_p_cut_key(const float *w, int lo, int hi, float S, float thr, SjdShared &sh, int base = 0)
 {
     unsigned K = 0;
     for (int bit = 31; bit >= 0; --bit) {
@@ -274,7 +420,7 @@ __device__ unsigned block_top_p_cut_key(const float *w, int lo, int hi, float S,
                 const int c = c0 + j;
                 t[j] = 0.0f;
                 if (c >= lo && c < hi) {
-                    const float x = w[c];
+                    const float x = w[c - base];
                     if (x > 0.0f && f2key(x) <= cand) t[j] = x / S;
                 }
             }
@@ -287,18 +433,18 @@ __device__ unsigned block_top_p_cut_key(const float *w, int lo, int hi, float S,
 }
 
 // applies the cut in place (w_i = 0 for removed entries; the lowest-index maximum is always kept) and returns the new sum
-__device__ float block_top_p_apply(float *w, int lo, int hi, float S, float thr, SjdShared &sh)
+__device__ float block_top_p_apply(float *w, int lo, int hi, float S, float thr, SjdShared &sh, int base = 0)
 {
     unsigned long long best = 0ull;
     SJD_FOR_OWNED_COLS_IN(lo, hi, c0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = c0 + j;
-            if (c >= lo && c < hi) { unsigned long long cand = pack_vi(w[c], c); best = cand > best ? cand : best; }
+            if (c >= lo && c < hi) { unsigned long long cand = pack_vi(w[c - base], c); best = cand > best ? cand : best; }
         }
     }
     const int imax = block_argmax(best, sh);
-    const unsigned K = block_top_p_cut_key(w, lo, hi, S, thr, sh);
+    const unsigned K = block_top_p_cut_key(w, lo, hi, S, thr, sh, base);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     SJD_FOR_OWNED_COLS_IN(lo, hi, c0) {
         float t[4];
@@ -307,8 +453,8 @@ __device__ float block_top_p_apply(float *w, int lo, int hi, float S, float thr,
             const int c = c0 + j;
             t[j] = 0.0f;
             if (c >= lo && c < hi) {
-                float x = w[c];
-                if (c != imax && x > 0.0f && f2key(x) <= K) { x = 0.0f; w[c] = 0.0f; }
+                float x = w[c - base];
+                if (c != imax && x > 0.0f && f2key(x) <= K) { x = 0.0f; w[c - base] = 0.0f; }
                 t[j] = x;
             }
         }

@@ -82,9 +82,10 @@ template <bool PART>
 __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const float *__restrict__ logits_c, const float *__restrict__ logits_u, long row_stride, float guidance, int V,
     const sjd_iter_params *__restrict__ params, const float *__restrict__ noise, float *__restrict__ probs_out,
-    int64_t *__restrict__ tokens_out, const sjd_head_partials hp, int64_t *__restrict__ amax_out)
+    int64_t *__restrict__ tokens_out, const sjd_head_partials hp, int64_t *__restrict__ amax_out, int lds_floats)
 {
     __shared__ SjdShared sh;
+    extern __shared__ __attribute__((aligned(16))) float sjd_dyn_lds[];      // round 4: the staged scores of a row too wide for registers
     const int row = blockIdx.x;
     SJD_TRS(row, 0);
     if (row >= params->n_rows) return;
@@ -131,6 +132,12 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
         }
     }
 
+    // Where the scores of the window are STAGED between the passes: registers when they fit (K2_NI groups per thread), else the workgroup's
+    // LDS (round 4: Emu3's 32768-column rows -- every pass used to re-read them from `p` through L2, a dependent round trip per column
+    // group and pass), else `p` itself (text rows over a whole vocabulary).  `stg[col - sb]` addresses either.
+    const bool in_lds = (whi - (wlo & ~3)) <= lds_floats;
+    float *stg = in_lds ? sjd_dyn_lds : p;          // column `col` lives at stg[col - sb] (no pointer is ever moved below the LDS base)
+    const int sb = in_lds ? (wlo & ~3) : 0;
     SJD_TRS(row, 1);              // outside of the window zeroed
     // pass 1: CFG combine (JL:104) + grammar mask (LP:125-129); stage z; row max; finite count
     // Round 3: when the rule's window is at most K2_NI column groups per thread (Lumina's image rows: 3, Emu3's: 9) the staged scores are
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
                 float z = zc[j];
                 if (u) { float t = zc[j] - zu[j]; t = guidance * t; z = t + zu[j]; }
                 if (!rule_allows(rule, col)) z = -INFINITY;
-                p[col] = z;
+                stg[col - sb] = z;
                 tmax = fmaxf(tmax, z);
                 cnt += (z > -INFINITY) ? 1 : 0;
             }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
             for (int j = 0; j < 4; ++j) {
                 const int col = c0 + j;
                 const bool in = c0 < whi && col >= wlo && col < whi;
-                const float v = p[in ? col : wlo];              // (unconditional load: every group of the thread in flight at once)
+                const float v = stg[(in ? col : wlo) - sb];            // (unconditional load: every group of the thread in flight at once)
                 zr[i][j] = in ? v : -INFINITY;                  // a column outside the window: never counted, never kept
             }
         }
@@ -233,7 +240,24 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     // top-k (LP:196-204): keep z >= k-th largest; k-th is -inf when fewer than k finite entries exist
     float kth = -INFINITY;
     if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_finite)
-        kth = fits ? block_kth_largest_regs<K2_NI>(zr, rule.top_k, -INFINITY, sh) : block_kth_largest(p, wlo, whi, rule.top_k, -INFINITY, sh);
+    {
+        // (zmax is finite here: n_finite > top_k >= 1; a +inf score would make the value bins meaningless -> the plain radix select)
+        if (!(zmax < INFINITY)) kth = block_kth_largest_bisect(stg, wlo, whi, rule.top_k, -INFINITY, sh, sb);
+        else if (fits)
+            kth = block_kth_largest_spread([&](auto &&f) {
+#pragma unroll
+                for (int i = 0; i < K2_NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f(zr[i][j]);
+            }, rule.top_k, zmax, sh);
+        else
+            kth = block_kth_largest_spread([&](auto &&f) {
+                SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (col >= wlo && col < whi) f(stg[col - sb]); }
+                }
+            }, rule.top_k, zmax, sh);
+    }
 
     SJD_TRS(row, 3);              // top-k threshold known
     // pass A: e = exp(z - max) for kept entries, canonical sum.  TemperatureLogitsWarper (rule.temperature != 1): the kept scores are
@@ -257,7 +281,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
                         const float z = zr[i][j];
                         const float zt = tempered ? z / rule.temperature : z;
                         ev[j] = (z < kth) ? 0.0f : sjd_expf(zt - zmax_t);
-                        if (top_p_on) p[col] = ev[j];              // (the top-p cut works on the staged weights)
+                        if (top_p_on) stg[col - sb] = ev[j];           // (the top-p cut works on the staged weights)
                     }
                     zr[i][j] = ev[j];
                 }
@@ -272,10 +296,10 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
                 int col = c0 + j;
                 ev[j] = 0.0f;
                 if (col >= wlo && col < whi) {
-                    float z = p[col];
+                    float z = stg[col - sb];
                     const float zt = tempered ? z / rule.temperature : z;
                     ev[j] = (z < kth) ? 0.0f : sjd_expf(zt - zmax_t);
-                    p[col] = ev[j];
+                    stg[col - sb] = ev[j];
                 }
             }
             a0 = a0 + ev[0]; a1 = a1 + ev[1]; a2 = a2 + ev[2]; a3 = a3 + ev[3];
@@ -283,14 +307,14 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     }
     float S = block_canonical_sum(a0, a1, a2, a3, sh);
     if (top_p_on) {                                                                             // TopPLogitsWarper3d (LP:406-419)
-        S = block_top_p_apply(p, wlo, whi, S, rule.top_p_thr, sh);
+        S = block_top_p_apply(stg, wlo, whi, S, rule.top_p_thr, sh, sb);
         if (fits) {                                  // the cut zeroed some staged weights: take them back into the registers
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < K2_NI; ++i) {
                 const int c0 = c0_first + i * 4 * SJD_TPB;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (c0 < whi && col >= wlo && col < whi) zr[i][j] = p[col]; }
+                for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (c0 < whi && col >= wlo && col < whi) zr[i][j] = stg[col - sb]; }
             }
         }
     }
@@ -319,7 +343,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     } else {
         SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (col >= wlo && col < whi) draw(col, p[col]); }
+            for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (col >= wlo && col < whi) draw(col, stg[col - sb]); }
         }
     }
     SJD_TRS(row, 5);              // probabilities written
@@ -360,9 +384,10 @@ __device__ __forceinline__ void k4_mirror_state(const sjd_state *state, sjd_stat
 __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
     const sjd_iter_params *__restrict__ params, sjd_state *__restrict__ state, const float *__restrict__ probs,
     const float *__restrict__ prev_probs, const float *__restrict__ rs, const float *__restrict__ noise2,
-    float *__restrict__ scratch, int V, sjd_state *__restrict__ host_mirror)
+    float *__restrict__ scratch, int V, sjd_state *__restrict__ host_mirror, int lds_floats)
 {
     __shared__ SjdShared sh;
+    extern __shared__ __attribute__((aligned(16))) float sjd_dyn_lds[];      // round 4: the residual row, when its window fits (else `scratch`)
     const int n = params->n_rows;
     if (n <= 1) {   // prefill / single-token phase short-circuit (JL:344-350)
         if (threadIdx.x == 0) { state->m = 1; state->rejected = 0; state->n_prev = n; }
@@ -419,6 +444,10 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
             const float *qrow = (qs >= 0) ? prev_probs + (size_t)qs * V : nullptr;
             int wlo, whi;
             rule_window(rule, V, wlo, whi);
+            // the residual weights d are staged in the workgroup's LDS when the rule's window fits (image rows: 8192 .. 32768 columns) -- the
+            // five passes below were five trips through L2 per column group (74 us at Emu3's shape, one workgroup) -- else in `scratch`
+            int sb = 0;                      // column `col` of the staged row lives at scratch[col - sb]
+            if ((whi - (wlo & ~3)) <= lds_floats) { scratch = sjd_dyn_lds; sb = wlo & ~3; }
             int cnt = 0;
             SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
 #pragma unroll
@@ -429,7 +458,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                         float d = prow[col] - qv;
                         d = d > 0.0f ? d : 0.0f;
                         if (!rule_allows(rule, col)) d = 0.0f;
-                        scratch[col] = d;
+                        scratch[col - sb] = d;
                         cnt += d > 0.0f ? 1 : 0;
                     }
                 }
@@ -437,7 +466,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
             const int n_pos = block_sum_int(cnt, sh);
             __syncthreads();
             float kth = 0.0f;
-            if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_pos) kth = block_kth_largest(scratch, wlo, whi, rule.top_k, 0.0f, sh);
+            if (rule.top_k > 0 && rule.top_k < V && rule.top_k < n_pos) kth = block_kth_largest_bisect(scratch, wlo, whi, rule.top_k, 0.0f, sh, sb);
             {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
@@ -447,9 +476,9 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                         int col = c0 + j;
                         dv[j] = 0.0f;
                         if (col >= wlo && col < whi) {
-                            float d = scratch[col];
+                            float d = scratch[col - sb];
                             dv[j] = (d < kth) ? 0.0f : d;
-                            scratch[col] = dv[j];
+                            scratch[col - sb] = dv[j];
                         }
                     }
                     a0 = a0 + dv[0]; a1 = a1 + dv[1]; a2 = a2 + dv[2]; a3 = a3 + dv[3];
@@ -463,7 +492,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             int col = c0 + j;
-                            if (col >= wlo && col < whi) dm = fmaxf(dm, scratch[col]);
+                            if (col >= wlo && col < whi) dm = fmaxf(dm, scratch[col - sb]);
                         }
                     }
                     dm = block_max(dm, sh);
@@ -476,16 +505,16 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                             int col = c0 + j;
                             dv[j] = 0.0f;
                             if (col >= wlo && col < whi) {
-                                const float d = scratch[col];
+                                const float d = scratch[col - sb];
                                 dv[j] = d > 0.0f ? sjd_expf(sjd_logf(d) / rule.temperature - lm) : 0.0f;
-                                scratch[col] = dv[j];
+                                scratch[col - sb] = dv[j];
                             }
                         }
                         a0 = a0 + dv[0]; a1 = a1 + dv[1]; a2 = a2 + dv[2]; a3 = a3 + dv[3];
                     }
                     S = block_canonical_sum(a0, a1, a2, a3, sh);
                 }
-                if (rule.top_p_thr >= 0.0f) S = block_top_p_apply(scratch, wlo, whi, S, rule.top_p_thr, sh);
+                if (rule.top_p_thr >= 0.0f) S = block_top_p_apply(scratch, wlo, whi, S, rule.top_p_thr, sh, sb);
                 degenerate = !(S > 0.0f);         // 0/0 below: flagged to the host (state->rejected = 2), never a silent arbitrary id
                 unsigned long long best = 0ull;
                 SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
@@ -493,7 +522,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                     for (int j = 0; j < 4; ++j) {
                         int col = c0 + j;
                         if (col >= wlo && col < whi) {
-                            const float dv = scratch[col] / S;
+                            const float dv = scratch[col - sb] / S;
                             float r;
                             if (ph_blocks) r = dv > 0.0f ? dv / sjd_philox_exponential(ph_seed, ph_off2, ph_T2, (uint64_t)col) : dv;    // (dv is 0 or NaN here)
                             else r = dv / noise2[col];
@@ -545,6 +574,14 @@ __global__ void k5_reguess(const sjd_iter_params *__restrict__ params, sjd_state
     }
 }
 
+// dynamic LDS (in floats) K2 / K4 ask for to stage a row's window: what `cols` columns need, capped at what a CU has left beside SjdShared
+// (150 KiB: windows of up to 38400 columns -- Emu3's 32768 visual tokens fit, a whole text vocabulary does not and keeps the global staging)
+static int sjd_stage_lds_floats(long cols)
+{
+    const long cap = 150 * 1024 / 4;
+    return (int)(cols < cap ? ((cols + 3) & ~3L) : cap);
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
 extern "C" int sjd_reguess_ex(const sjd_iter_params *params, sjd_state *state, int64_t *input_ids_out, int n_batch, int max_rows,
                               const int64_t *pos_offset, int64_t *positions_out, void *stream)
@@ -579,8 +616,10 @@ extern "C" int sjd_logits_to_probs_sample_ex(const float *logits_c, const float 
     if (!logits_c || !params || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
         return SJD_ERR_BAD_ARG;                    /* noise may be NULL when params->philox_blocks > 0 (the kernel generates it) */
     sjd_head_partials none = {};
-    hipLaunchKernelGGL(k2_logits_to_probs_sample<false>, dim3(max_rows), dim3(SJD_TPB), 0, (hipStream_t)stream, logits_c, logits_u,
-                       (long)row_stride, guidance, V, params, noise, probs_out, tokens_out, none, amax_out);
+    const int lds_floats = sjd_stage_lds_floats(V);
+    (void)hipFuncSetAttribute((const void *)k2_logits_to_probs_sample<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
+    hipLaunchKernelGGL(k2_logits_to_probs_sample<false>, dim3(max_rows), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, logits_c, logits_u,
+                       (long)row_stride, guidance, V, params, noise, probs_out, tokens_out, none, amax_out, lds_floats);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
@@ -591,8 +630,10 @@ extern "C" int sjd_logits_to_probs_sample_part(const sjd_head_partials *head, fl
     if (!head || !head->part || head->n_chunks < 1 || head->n_cols < 1 || head->col0 < 0 || head->row_stride < head->n_cols) return SJD_ERR_BAD_ARG;
     if (!params || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1) return SJD_ERR_BAD_ARG;
     if (head->row_sumsq && (head->slices < 1 || head->prows < 1)) return SJD_ERR_BAD_ARG;
-    hipLaunchKernelGGL(k2_logits_to_probs_sample<true>, dim3(max_rows), dim3(SJD_TPB), 0, (hipStream_t)stream, (const float *)nullptr,
-                       (const float *)nullptr, (long)0, guidance, V, params, noise, probs_out, tokens_out, *head, amax_out);
+    const int lds_floats = sjd_stage_lds_floats(head->n_cols + 8);     // (the rows' windows lie inside the head's column window)
+    (void)hipFuncSetAttribute((const void *)k2_logits_to_probs_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
+    hipLaunchKernelGGL(k2_logits_to_probs_sample<true>, dim3(max_rows), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, (const float *)nullptr,
+                       (const float *)nullptr, (long)0, guidance, V, params, noise, probs_out, tokens_out, *head, amax_out, lds_floats);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
@@ -602,8 +643,10 @@ extern "C" int sjd_verify_accept_ex(const sjd_iter_params *params, sjd_state *st
 {
     if (!params || !state || !probs || !prev_probs || !scratch || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
         return SJD_ERR_BAD_ARG;                    /* rs / noise2 may be NULL when params->philox_blocks > 0 */
-    hipLaunchKernelGGL(k4_verify_accept, dim3(1), dim3(SJD_TPB), 0, (hipStream_t)stream, params, state, probs, prev_probs, rs,
-                       noise2, scratch, V, host_mirror);
+    const int lds_floats = sjd_stage_lds_floats(V);
+    (void)hipFuncSetAttribute((const void *)k4_verify_accept, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
+    hipLaunchKernelGGL(k4_verify_accept, dim3(1), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, params, state, probs, prev_probs, rs,
+                       noise2, scratch, V, host_mirror, lds_floats);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 

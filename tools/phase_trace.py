@@ -77,6 +77,7 @@ def trace_k1_shared(lib, torch, ops, np):
     """Emu3's shape: GQA 32 / 8, draft window 32 (two 16-row chunks), 16 key splits: k1_partial_shared"""
     dev = torch.device("cuda:0")
     B, n, H, Hkv, D, layers, ns = 2, 32, 32, 8, 128, 32, 16
+    lib.sjd_debug_trace_k1.argtypes = [ctypes.c_void_p, ctypes.c_int]
     for kv in (1024, 4096, 8192):
         s_max = ((kv + n + 64 + 31) // 32) * 32
         kc = torch.randn(layers, B, Hkv, s_max, D, device=dev).to(torch.float16)
@@ -104,7 +105,7 @@ def trace_k1_shared(lib, torch, ops, np):
         t0 = t[:, 0].min()
         d = lambda a, b: us((t[:, b] - t[:, a]).mean())
         tiles = (kv + n + 31) // 32 / ns
-        print(json.dumps(dict(kernel="k1_partial_shared<f16,128,8 waves>", kv_len=kv, n_split=ns, workgroups=int(len(t)), tiles_per_workgroup=round(tiles, 1),
+        print(json.dumps(dict(kernel=("k1_partial_shared<f16,128,8 waves>" if os.environ.get("SJD_K1_RING") == "0" else "k1_partial_ring<f16,128,8 waves>"), kv_len=kv, n_split=ns, workgroups=int(len(t)), tiles_per_workgroup=round(tiles, 1),
                               phase_us=dict(tile_ranges=d(0, 1), first_tile=d(1, 2), key_loop=d(2, 3), publish=d(3, 5)),
                               key_loop_us_per_tile=round(d(2, 3) / max(tiles - 1, 1), 2),
                               end_us=dict(mean=us((t[:, 5] - t0).mean()), max=us((t[:, 5] - t0).max())))), flush=True)
@@ -304,6 +305,9 @@ def main():
     if "--per-wg" in sys.argv:
         PER_WG = open(sys.argv[sys.argv.index("--per-wg") + 1], "w")
         trace_g1(lib, torch, ops, np)
+        return
+    if "--k1s" in sys.argv:          # the shared-tile K1 shapes only (round 4: the LDS-DMA ring kernel; SJD_K1_RING=0 the round-3 kernel)
+        trace_k1_shared(lib, torch, ops, np)
         return
     if "--g1s" in sys.argv:
         trace_g1s(lib, torch, ops, np)

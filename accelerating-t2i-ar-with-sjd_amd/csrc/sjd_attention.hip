@@ -1435,6 +1435,8 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
                                 out_direct, merge_out, ticket, eff_split);
 }
 
+#include "sjd_attention_dsplit_fp8.h"
+
 // K3 for an fp8 cache: rows [kv_len, kv_len + n) <- fp8(x / scale); one thread converts 8 values (16 B in, 8 B out)
 template <int DT>
 __global__ void k3_kv_append_fp8(const u32x4 *__restrict__ k_new, const u32x4 *__restrict__ v_new, u32x2 *__restrict__ k_cache,
@@ -1556,7 +1558,7 @@ static int k1_waves()
 template <int DT, int D>
 static int launch_attention(const void *q, const void *kc, const void *vc, void *out, int B, int n_rows, int H, int H_kv, int S_max,
                             const int32_t *key_start, const sjd_iter_params *params, int kv_len, int n_split, void *workspace,
-                            hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, unsigned *ticket = nullptr)
+                            hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, unsigned *ticket = nullptr, bool colsplit = false)
 {
     const int n_chunks = (n_rows + K1_ROWS - 1) / K1_ROWS;
     float *ws_o = (float *)workspace;
@@ -1579,7 +1581,8 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     // round 4: the multi-head window without key splits -- four workgroups per (batch, head) split the OUTPUT COLUMNS (k1_dsplit): one
     // launch, no workspace, no combine.  SJD_K1_DSPLIT=0|1 (A/B aid).
     static const int dsplit = [] { const char *e = getenv("SJD_K1_DSPLIT"); return e ? atoi(e) : SJD_K1_DSPLIT_DEFAULT; }();
-    if (!shared && dsplit && D == 128 && H == H_kv) {
+    if (colsplit && !(D == 128 && H == H_kv)) return SJD_ERR_UNSUPPORTED;
+    if ((colsplit || (!shared && dsplit)) && D == 128 && H == H_kv) {
         if constexpr (D == 128) {
             hipLaunchKernelGGL((k1_dsplit<DT, D, 8, 4>), dim3(4 * n_chunks * H * B), dim3(512), 0, stream, (const unsigned short *)q,
                                (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, (unsigned short *)out, n_rows, H, H_kv,
@@ -1649,11 +1652,12 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
 static int k1_dispatch(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows,
                        int H, int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
                        const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream,
-                       void *ev_start, void *ev_stop, unsigned *ticket)
+                       void *ev_start, void *ev_stop, unsigned *ticket, bool colsplit = false)
 {
-    if (!q || !k_cache || !v_cache || !out || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
+    if (!q || !k_cache || !v_cache || !out || (!workspace && !colsplit) || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
     if (H % H_kv != 0 || (S_max % K1_KT) != 0) return SJD_ERR_BAD_ARG;
     if (dtype == SJD_DTYPE_F32) {
+        if (colsplit) return SJD_ERR_UNSUPPORTED;
         if ((size_t)S_max * sizeof(float) > 160 * 1024) return SJD_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(k1_f32, dim3(n_rows, H, B), dim3(64), (size_t)S_max * sizeof(float), (hipStream_t)stream, (const float *)q,
                            (const float *)k_cache, (const float *)v_cache, (float *)out, n_rows, H, H_kv, D, S_max, key_start, params, kv_len);
@@ -1663,7 +1667,7 @@ static int k1_dispatch(const void *q, const void *k_cache, const void *v_cache, 
     if (!(G == 1 || G == 2 || G == 4)) return SJD_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
 #define SJD_K1_CASE(DT_, D_) \
-    if (dtype == DT_ && D == D_) return launch_attention<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, key_start, params, kv_len, n_split, workspace, s, (hipEvent_t)ev_start, (hipEvent_t)ev_stop, ticket);
+    if (dtype == DT_ && D == D_) return launch_attention<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, key_start, params, kv_len, n_split, workspace, s, (hipEvent_t)ev_start, (hipEvent_t)ev_stop, ticket, colsplit);
     SJD_K1_CASE(SJD_DTYPE_BF16, 128)
     SJD_K1_CASE(SJD_DTYPE_BF16, 64)
     SJD_K1_CASE(SJD_DTYPE_F16, 128)
@@ -1702,6 +1706,18 @@ extern "C" int sjd_draft_window_attention(const void *q, const void *k_cache, co
                                          n_split, workspace, stream, nullptr, nullptr);
 }
 
+// K1 without key splits (round 4): the four workgroups of a (batch, head) split the OUTPUT COLUMNS -- each scores all keys and multiplies
+// them with its 32 columns of V -- and write the normalised output themselves: ONE launch, no workspace, no combine.  Multi-head attention
+// (H == H_kv), D = 128, 16-bit caches; SJD_ERR_UNSUPPORTED otherwise.  Faster than the key split + combine while a CU's share of the K stream
+// is short (kv_len below ~750 keys, profiles/r4_k1_dsplit_ab.txt); the caller picks per launch (sjd_amd.ops.HipWindowAttention.choose_regime).
+extern "C" int sjd_draft_window_attention_colsplit(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
+                                                   int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
+                                                   const sjd_iter_params *params, int kv_len, void *stream)
+{
+    return k1_dispatch(q, k_cache, v_cache, out, B, n_rows, H, H_kv, D, S_max, dtype, key_start, params, kv_len, 1, nullptr, stream, nullptr, nullptr,
+                       nullptr, true);
+}
+
 extern "C" int sjd_kv_append_fp8(const void *k_new, const void *v_new, void *k_cache, void *v_cache, int B, int n_rows, int H_kv, int D,
                                  int S_max, int dtype, float k_scale, float v_scale, int head_major, const sjd_iter_params *params, int kv_len,
                                  void *stream)
@@ -1725,9 +1741,19 @@ extern "C" int sjd_kv_append_fp8(const void *k_new, const void *v_new, void *k_c
 template <int DT, int D>
 static int launch_attention_fp8(const void *q, const void *kc, const void *vc, void *out, int B, int n_rows, int H, int H_kv, int S_max,
                                 float k_scale, float v_scale, const int32_t *key_start, const sjd_iter_params *params, int kv_len, int n_split,
-                                void *workspace, hipStream_t stream, unsigned *ticket = nullptr)
+                                void *workspace, hipStream_t stream, unsigned *ticket = nullptr, bool colsplit = false)
 {
     const int n_chunks = (n_rows + K1_ROWS - 1) / K1_ROWS;
+    if (colsplit) {
+        if constexpr (D == 128) {
+            if (H != H_kv) return SJD_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL((k1_dsplit_fp8<DT, D, 8, 4>), dim3(4 * n_chunks * H * B), dim3(512), 0, stream, (const unsigned short *)q,
+                               (const unsigned char *)kc, (const unsigned char *)vc, params, key_start, (unsigned short *)out, n_rows, H, H_kv,
+                               S_max, kv_len, n_chunks, B, k_scale, v_scale);
+            return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+        }
+        return SJD_ERR_UNSUPPORTED;
+    }
     float *ws_o = (float *)workspace;
     float *ws_ml = ws_o + (size_t)B * H * n_chunks * n_split * K1_ROWS * D;
     static const bool no_direct = getenv("SJD_K1_NO_DIRECT") != nullptr;
@@ -1761,15 +1787,16 @@ static int launch_attention_fp8(const void *q, const void *kc, const void *vc, v
 
 static int k1_dispatch_fp8(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
                            int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
-                           const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream, unsigned *ticket)
+                           const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream, unsigned *ticket,
+                           bool colsplit = false)
 {
-    if (!q || !k_cache || !v_cache || !out || !workspace || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
+    if (!q || !k_cache || !v_cache || !out || (!workspace && !colsplit) || B < 1 || n_rows < 1 || H < 1 || H_kv < 1 || n_split < 1) return SJD_ERR_BAD_ARG;
     if (H % H_kv != 0 || (S_max % K1_KT) != 0 || !(k_scale > 0.f) || !(v_scale > 0.f)) return SJD_ERR_BAD_ARG;
     const int G = H / H_kv;
     if (!(G == 1 || G == 2 || G == 4)) return SJD_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
 #define SJD_K1F8_CASE(DT_, D_) \
-    if (dtype == DT_ && D == D_) return launch_attention_fp8<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, k_scale, v_scale, key_start, params, kv_len, n_split, workspace, s, ticket);
+    if (dtype == DT_ && D == D_) return launch_attention_fp8<DT_, D_>(q, k_cache, v_cache, out, B, n_rows, H, H_kv, S_max, k_scale, v_scale, key_start, params, kv_len, n_split, workspace, s, ticket, colsplit);
     SJD_K1F8_CASE(SJD_DTYPE_BF16, 128)
     SJD_K1F8_CASE(SJD_DTYPE_BF16, 64)
     SJD_K1F8_CASE(SJD_DTYPE_F16, 128)
@@ -1794,6 +1821,15 @@ extern "C" int sjd_draft_window_attention_fp8_merged(const void *q, const void *
     if (!tickets) return SJD_ERR_BAD_ARG;
     return k1_dispatch_fp8(q, k_cache, v_cache, out, B, n_rows, H, H_kv, D, S_max, dtype, k_scale, v_scale, key_start, params, kv_len, n_split,
                            workspace, stream, (unsigned *)tickets);
+}
+
+// sjd_draft_window_attention_colsplit over an fp8 (e4m3) cache: a key row is 128 bytes, so the column split stays ahead up to ~1500 keys
+extern "C" int sjd_draft_window_attention_fp8_colsplit(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
+                                                       int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale,
+                                                       const int32_t *key_start, const sjd_iter_params *params, int kv_len, void *stream)
+{
+    return k1_dispatch_fp8(q, k_cache, v_cache, out, B, n_rows, H, H_kv, D, S_max, dtype, k_scale, v_scale, key_start, params, kv_len, 1, nullptr,
+                           stream, nullptr, true);
 }
 
 extern "C" void *sjd_event_create(void)

@@ -296,13 +296,17 @@ class SJDEngine:
         lo, hi = (lo // 32) * 32, min(self.V, ((hi + 31) // 32) * 32)
         return (lo, hi) if 2 * (hi - lo) <= self.V else None
 
+    def _k1_regime(self):
+        """the attention backend's launch form for this iteration (part of every graph key: the two forms are different kernels)"""
+        return getattr(getattr(self.backbone, "attn", None), "regime", None)
+
     def _launch_forward(self, cols=None):
         """part 1 (K5 + transformer forward): eager, or a hipGraph captured once per output-head column window.  Returns the logits
         tensor part 2 will read (static across replays of the same graph)."""
         if not self.use_graph:
             return self._forward_body(cols)
         self._check_graph_buffers()
-        fkey = ("fwd", cols)
+        fkey = ("fwd", cols, self._k1_regime())
         if fkey not in self._graphs:
             if self._eager_runs.get(fkey, 0) < 1:   # one eager run warms up allocations / hipBLASLt before capture
                 self._eager_runs[fkey] = 1
@@ -318,7 +322,7 @@ class SJDEngine:
         """part 2 (K2 + K4) of a two-stage iteration; a hipGraph per (prob-buffer parity, column window), captured the second time that
         combination runs on graph-owned logits."""
         key = (cur, self._guidance, cols, self.hook is not None, self._philox)
-        if not self.use_graph or ("fwd", cols) not in self._graphs:
+        if not self.use_graph or ("fwd", cols, self._k1_regime()) not in self._graphs:
             self._sample_body(cur, logits, cols)
             return
         if key not in self._graphs:
@@ -338,7 +342,7 @@ class SJDEngine:
             self._sample_body(cur, logits, cols)
             return logits
         self._check_graph_buffers()
-        key = ("win", cols, cur, self._guidance, self.hook is not None, self._philox)
+        key = ("win", cols, cur, self._guidance, self.hook is not None, self._philox, self._k1_regime())
         if key not in self._graphs:
             if self._eager_runs.get(key, 0) < 1:      # one eager run warms up allocations / hipBLASLt before capture
                 self._eager_runs[key] = 1
@@ -497,6 +501,8 @@ class SJDEngine:
                     attn.params = self.params                                        # windows: kv_len / n_rows from the blob
             else:
                 cols = self.logit_columns(rules)
+                if attn is not None and hasattr(attn, "choose_regime"):     # K1: column split while the context is short, key split + combine after
+                    attn.choose_regime(kv_len + n_rows, self.backbone.cache.k.dtype)
                 if two_stage:
                     logits = self._launch_forward(cols)
                     t_host0 = time.perf_counter()

@@ -1,5 +1,6 @@
 """torch-tensor wrappers over the C-ABI (include/sjd_hip.h).  Plumbing only: device pointers, strides, stream."""
 import ctypes
+import os
 
 import torch
 
@@ -258,6 +259,28 @@ def draft_window_attention_fp8(q, k_cache, v_cache, out, k_scale, v_scale, key_s
                                                    k_cache.shape[2], _dtype_code(q.dtype), float(k_scale), float(v_scale),
                                                    _ptr(key_start), params.ptr if params is not None else None, int(kv_len),
                                                    int(n_split), _ptr(workspace), _stream()), "sjd_draft_window_attention_fp8")
+
+
+def colsplit_ok(B, n, H, H_kv, D, cache_dtype):
+    """shapes sjd_draft_window_attention(_fp8)_colsplit serves: one prompt's multi-head 16-row window, head size 128"""
+    return H == H_kv and D == 128 and n <= 16 and B * H <= 64 and cache_dtype in (torch.bfloat16, torch.float16, FP8)
+
+
+def draft_window_attention_colsplit(q, k_cache, v_cache, out, key_start, params, kv_len, kv_scale=(1.0, 1.0)):
+    """K1 without key splits: four workgroups per (batch, head) split the output columns, one launch, no workspace (see include/sjd_hip.h)."""
+    B, n, H, D = q.shape
+    assert q.is_contiguous() and out.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert key_start is None or (key_start.dtype == torch.int32 and key_start.is_cuda)
+    if k_cache.dtype == FP8:
+        L.check(L.load().sjd_draft_window_attention_fp8_colsplit(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), B, n, H, k_cache.shape[1], D,
+                                                                k_cache.shape[2], _dtype_code(q.dtype), float(kv_scale[0]), float(kv_scale[1]),
+                                                                _ptr(key_start), params.ptr if params is not None else None, int(kv_len),
+                                                                _stream()), "sjd_draft_window_attention_fp8_colsplit")
+    else:
+        L.check(L.load().sjd_draft_window_attention_colsplit(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), B, n, H, k_cache.shape[1], D,
+                                                            k_cache.shape[2], _dtype_code(q.dtype), _ptr(key_start),
+                                                            params.ptr if params is not None else None, int(kv_len), _stream()),
+                "sjd_draft_window_attention_colsplit")
 
 
 def attention_workspace(B, H, n_rows, D, n_split, device):
@@ -674,6 +697,21 @@ class HipWindowAttention:
         self.profile_records = []   # (ev0, ev1, algorithmic_bytes)
         self._ev_pool = []
         self.kv_scale = (1.0, 1.0)  # (k, v) scales of an fp8 cache: stored byte = fp8(x / scale)
+        # K1 regime of the NEXT window launches (round 4): "colsplit" = no key splits, four workgroups per (batch, head) split the output
+        # columns (one launch; wins while the context is short), "keysplit" = key splits + k1_combine.  The engines set it per iteration from
+        # the host-side kv_len (choose_regime) and key their hipGraphs on it.  SJD_K1_REGIME=keysplit|colsplit pins it (A/B aid).
+        self.regime = "keysplit"
+        self._pin_regime = os.environ.get("SJD_K1_REGIME")
+
+    COLSPLIT_MAX_KEYS = {"16bit": 736, "fp8": 1536}       # crossover of the two forms (profiles/r4_k1_dsplit_ab.txt, r4_k1_dsplit_fp8_ab.txt)
+
+    def choose_regime(self, kv_rows, cache_dtype):
+        """-> the regime for a window whose longest row sees `kv_rows` keys; sets self.regime"""
+        if self._pin_regime in ("keysplit", "colsplit"):
+            self.regime = self._pin_regime
+        else:
+            self.regime = "colsplit" if kv_rows <= self.COLSPLIT_MAX_KEYS["fp8" if cache_dtype == FP8 else "16bit"] else "keysplit"
+        return self.regime
 
     def _resolve_split(self, B, Hkv, n_rows=16, H=None, cache_bytes_per_head=None):
         """auto mode: one workgroup per CU for MHA (256 = B * H_kv * ceil(n_rows/16) * n_split; tools/k1_bench.py --graph: 4 splits
@@ -715,11 +753,18 @@ class HipWindowAttention:
         ws = self._workspace(B, H, n, D, q.device)
         out = torch.empty_like(q)
         kv_host = 0 if self.params is not None else int(kv_len)
+        colsplit = self.regime == "colsplit" and colsplit_ok(B, n, H, kc.shape[1], D, kc.dtype)
         if kc.dtype == FP8:
             kv_append_fp8(k, v, kc, vc, self.kv_scale[0], self.kv_scale[1], self.params, kv_host)
-            draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], ks, self.params, kv_host, self.n_split, ws)
+            if colsplit:
+                draft_window_attention_colsplit(q, kc, vc, out, ks, self.params, kv_host, self.kv_scale)
+            else:
+                draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], ks, self.params, kv_host, self.n_split, ws)
             return out
         kv_append(k, v, kc, vc, self.params, kv_host)
+        if colsplit:
+            draft_window_attention_colsplit(q, kc, vc, out, ks, self.params, kv_host)
+            return out
         ev0 = ev1 = None
         if self.profile_layer is not None and layer == self.profile_layer and n <= 32:
             lib = L.load()
@@ -742,10 +787,14 @@ class HipWindowAttention:
         """K1 only: the window's K/V rows were already written into the cache (fused F2 path)."""
         B, n, H, D = q.shape
         kc, vc = cache.k[layer], cache.v[layer]
+        kv_host = 0 if self.params is not None else int(kv_len)
+        if self.regime == "colsplit" and colsplit_ok(B, n, H, kc.shape[1], D, kc.dtype):
+            out = torch.empty_like(q)
+            draft_window_attention_colsplit(q, kc, vc, out, key_start, self.params, kv_host, self.kv_scale)
+            return out
         self._resolve_split(B, kc.shape[1], n, H, kc.shape[2] * kc.shape[3] * kc.element_size() if kc.dtype == FP8 else None)
         ws = self._workspace(B, H, n, D, q.device)
         out = torch.empty_like(q)
-        kv_host = 0 if self.params is not None else int(kv_len)
         if kc.dtype == FP8:
             draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], key_start, self.params, kv_host, self.n_split, ws)
         else:

@@ -176,6 +176,20 @@ def measure_k1(args, model, attn, device, kv_len):
     q = torch.randn(B, n, H, D, device=device).to(adt)
     out = torch.empty_like(q)
     ws = ops.attention_workspace(B, H, n, D, n_split, device)
+    if ops.colsplit_ok(B, n, H, Hkv, D, kc.dtype) and attn.choose_regime(kv_len + n, kc.dtype) == "colsplit":
+        # the short-context form the engine launches at this KV length: k1_dsplit(_fp8), one launch, back-to-back between one event pair
+        for i in range(nl):
+            ops.draft_window_attention_colsplit(q, kc[i], vc[i], out, ks, None, kv_len, attn.kv_scale)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(args.k1_launches):
+            ops.draft_window_attention_colsplit(q, kc[i % nl], vc[i % nl], out, ks, None, kv_len, attn.kv_scale)
+        e1.record()
+        torch.cuda.synchronize()
+        alg = kv_bytes + 2 * B * n * H * D * 2
+        avg_ms = e0.elapsed_time(e1) / args.k1_launches
+        return dict(kernel="k1_dsplit" + ("_fp8" if kc.dtype == ops.FP8 else "") + " (column split: one launch, no combine)", launches=args.k1_launches,
+                    avg_ms=avg_ms, avg_bytes=alg, avg_kv_rows=kv_len + n, gbps=alg / 1e9 / (avg_ms / 1e3))
     if kc.dtype == ops.FP8:        # fp8 cache: k1_partial_fp8 + k1_combine, back-to-back launches between one event pair
         sk, sv = attn.kv_scale
         for i in range(nl):
@@ -230,8 +244,13 @@ def measure_k1_pair(args, model, attn, device, kv_len, reps=4):
     ws = ops.attention_workspace(B, H, n, D, n_split, device)
     fp8 = kc.dtype == ops.FP8
 
+    # the launch form the engine uses at this context length (column split while it is short, key splits + combine after)
+    regime = attn.choose_regime(kv_len + n, kc.dtype) if ops.colsplit_ok(B, n, H, Hkv, D, kc.dtype) else "keysplit"
+
     def one(i):
-        if fp8:
+        if regime == "colsplit":
+            ops.draft_window_attention_colsplit(q, kc[i], vc[i], out, ks, None, kv_len, attn.kv_scale)
+        elif fp8:
             ops.draft_window_attention_fp8(q, kc[i], vc[i], out, attn.kv_scale[0], attn.kv_scale[1], ks, None, kv_len, n_split, ws)
         else:
             ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, kv_len, n_split, ws)
@@ -258,7 +277,7 @@ def measure_k1_pair(args, model, attn, device, kv_len, reps=4):
     rows0, rows1 = kv_len + n, kv_len + n - int(ks[1])
     alg = 2 * Hkv * (rows0 + rows1) * D * esz + B * n * H * D * 2
     return dict(avg_us=round(avg_ms * 1e3, 2), launches=reps * nl, avg_bytes=int(alg), achieved=round(alg / 1e9 / (avg_ms / 1e3), 1),
-                frac=round(alg / 1e9 / (avg_ms / 1e3) / 8000.0, 4), n_split=int(n_split), avg_kv_rows=kv_len + n,
+                frac=round(alg / 1e9 / (avg_ms / 1e3) / 8000.0, 4), n_split=int(n_split), regime=regime, avg_kv_rows=kv_len + n,
                 what="all K1 launches of a layer (partial + combine where the shape needs it), 32 layers' caches in ONE hipGraph replay, HIP events on the replay stream")
 
 

@@ -367,6 +367,19 @@ int sjd_draft_window_attention_fp8_merged(const void *q, const void *k_cache, co
                                           int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
                                           const sjd_iter_params *params, int kv_len, int n_split, void *workspace, uint32_t *tickets, void *stream);
 
+/* K1 without key splits (round 4): the four workgroups of a (batch, head) split the OUTPUT COLUMNS -- each scores all keys of the pair
+ * and multiplies them with its 32 columns of V -- merge their eight waves' states in LDS and write the normalised 16-bit output: one
+ * launch, no workspace, no combine kernel.  Multi-head attention only (H == H_kv), D = 128 (SJD_ERR_UNSUPPORTED otherwise).  Same call
+ * sites and argument meaning as sjd_draft_window_attention(_fp8) (modeling_chameleon.py:499-581); faster than key splits + k1_combine while
+ * the context is short (16-bit caches: below ~750 keys, fp8: the whole 512 x 512 image; profiles/r4_k1_dsplit_ab.txt) -- the caller picks
+ * per launch. */
+int sjd_draft_window_attention_colsplit(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H, int H_kv,
+                                        int D, int S_max, int dtype, const int32_t *key_start, const sjd_iter_params *params, int kv_len,
+                                        void *stream);
+int sjd_draft_window_attention_fp8_colsplit(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
+                                            int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
+                                            const sjd_iter_params *params, int kv_len, void *stream);
+
 /* G1 with stage F1r as its tail (round 3): h [M, N] += dtype(x @ W^T) in place and sumsq [N / 512, 32] = the per-slice sums of h^2, i.e.
  * sjd_skinny_gemm followed by sjd_residual_sumsq (the residual add + RMSNorm statistics of modeling_chameleon.py:59-73, 637, 643), bit for
  * bit, in one launch: the workgroups of a 512-column slice exchange their split-K planes device-coherently and reduce them in the

@@ -297,10 +297,15 @@ ATTN_CASES = [
 
 
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
-@pytest.mark.parametrize("n_split", [1, 8])
+@pytest.mark.parametrize("n_split", [1, 8, "colsplit"])
 def test_k1_k3_attention(dev, case, n_split):
     ops, L = _ops()
     name, B, H, Hkv, D, S_max, kv_len, n, key_start, dtype = case
+    regime = "keysplit"
+    if n_split == "colsplit":        # round 4: no key splits, four workgroups per (batch, head) split the output columns (k1_dsplit)
+        if not ops.colsplit_ok(B, n, H, Hkv, D, dtype):
+            pytest.skip("the column split serves multi-head 16-row windows of head size 128")
+        n_split, regime = 4, "colsplit"
     g = torch.Generator().manual_seed(len(name))
     kc = torch.randn(1, B, Hkv, S_max, D, generator=g).to(dtype)
     vc = torch.randn(1, B, Hkv, S_max, D, generator=g).to(dtype)
@@ -311,6 +316,7 @@ def test_k1_k3_attention(dev, case, n_split):
     ref = OracleWindowAttention()(0, q, k, v, ref_cache, kv_len, key_start).float()
     dcache = _Cache(kc.clone().to(dev), vc.clone().to(dev))
     attn = ops.HipWindowAttention(n_split=n_split)
+    attn.regime = regime
     out = attn(0, q.to(dev), k.to(dev), v.to(dev), dcache, kv_len, key_start)
     torch.cuda.synchronize()
     # K3: the cache rows were appended exactly
@@ -509,7 +515,7 @@ FP8_CASES = [
 
 
 @pytest.mark.parametrize("case", FP8_CASES, ids=[c[0] for c in FP8_CASES])
-@pytest.mark.parametrize("n_split", [1, 8])
+@pytest.mark.parametrize("n_split", [1, 8, "colsplit"])
 def test_k1_k3_fp8_kv_cache(dev, case, n_split):
     """BASELINE config 5: K3 quantises the new rows to OCP e4m3 exactly like torch's cast; K1 over the fp8 cache (fp8 MFMA for both
     contractions, q and P rounded to fp8 in the kernel) stays within fp8 tolerance of exact attention over the SAME dequantised
@@ -525,7 +531,13 @@ def test_k1_k3_fp8_kv_cache(dev, case, n_split):
     kc8 = (k_all / sk).to(ops.FP8)
     vc8 = (v_all / sv).to(ops.FP8)
     dcache = _Cache(kc8.clone().to(dev), vc8.clone().to(dev))
+    regime = "keysplit"
+    if n_split == "colsplit":        # round 4: k1_dsplit_fp8 (column split, no key splits)
+        if not ops.colsplit_ok(B, n, H, Hkv, D, ops.FP8):
+            pytest.skip("the column split serves multi-head 16-row windows of head size 128")
+        n_split, regime = 4, "colsplit"
     attn = ops.HipWindowAttention(n_split=n_split)
+    attn.regime = regime
     attn.kv_scale = (sk, sv)
     out = attn(0, q.to(dev), k.to(dev), v.to(dev), dcache, kv_len, key_start)
     torch.cuda.synchronize()

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--n-split", type=int, default=8)
     ap.add_argument("--prompt", type=int, default=64)
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) KV cache + the fp8-MFMA K1 variant (BASELINE config 5)")
+    ap.add_argument("--colsplit", action="store_true", help="the column-split form (no key splits, no combine; multi-head 16-row windows)")
     ap.add_argument("--graph", action="store_true", help="time k1_partial + k1_combine per layer inside one hipGraph replay")
     ap.add_argument("--block", choices=["fused", "unfused"], default=None,
                     help="time the whole attention block of a layer on q|k|v split-K partials inside a hipGraph: fused = kernel K1F (one "
@@ -92,7 +93,9 @@ def main():
         return
     if a.fp8 or a.graph:
         def one(i):
-            if a.fp8:
+            if a.colsplit:
+                ops.draft_window_attention_colsplit(q, kc[i], vc[i], out, ks, None, a.kv_len)
+            elif a.fp8:
                 ops.draft_window_attention_fp8(q, kc[i], vc[i], out, 1.0, 1.0, ks, None, a.kv_len, a.n_split, ws)
             else:
                 ops.draft_window_attention(q, kc[i], vc[i], out, ks, None, a.kv_len, a.n_split, ws)

@@ -56,7 +56,7 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu", "sjd_host_wait_u64",
            "sjd_philox_fill", "sjd_philox_offset_increment", "sjd_skinny_gemm_reduce", "sjd_reduce_timeouts",
            "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged", "sjd_skinny_gemm_z", "sjd_gateup_silu_z", "sjd_qkv_attention_fused_split",
-           "sjd_draft_window_attention_colsplit", "sjd_draft_window_attention_fp8_colsplit"]
+           "sjd_draft_window_attention_colsplit", "sjd_draft_window_attention_fp8_colsplit", "sjd_mlp_pair_z", "sjd_mlp_pair_timeouts"]
 
 _lib = None
 
@@ -95,6 +95,7 @@ def load():
     lib.sjd_draft_window_attention_fp8_merged.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp, vp, vp]
     lib.sjd_draft_window_attention_colsplit.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.sjd_draft_window_attention_fp8_colsplit.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, vp]
+    lib.sjd_mlp_pair_z.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp, i32, vp]
     lib.sjd_add_rmsnorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, vp, i32, vp]
     lib.sjd_qknorm_rope_append.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp]
     lib.sjd_silu_mul.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]

@@ -38,6 +38,7 @@ _log = _logging.getLogger("sjd_amd.backbones")
 # 27.0 / 33.7 us at kv_len 64 / 448 / 1216 / 2368).  Default off; SJD_K1_FUSED=1 or model.k1_fused = True selects it.
 _K1_FUSED_DEFAULT = _os.environ.get("SJD_K1_FUSED", "0") == "1"
 _K1_FUSED_SPLIT_DEFAULT = _os.environ.get("SJD_K1_FUSED_SPLIT", "1") != "0"   # with k1_fused: the split form K1Fs (0: one workgroup per (batch, head))
+_MLP_PAIR_DEFAULT = _os.environ.get("SJD_MLP_PAIR", "0") == "1"          # sjd_mlp_pair_z: the MLP as one launch (round-4 experiment)
 _GATEUP_FUSED_DEFAULT = {"0": False, "tall": "tall"}.get(_os.environ.get("SJD_GATEUP_FUSED", "1"), True)     # kernel G1s (gate|up + F3 in one launch); 0: G1 then F3; tall: also above 64 rows
 # round 3 experiment, correct, tested, OFF by default: the o / down projections of a <= 32-row window can reduce their own
 # split-K planes, add the residual and write the row statistics in their tail (sjd_skinny_gemm_reduce: device-coherent exchange between
@@ -564,8 +565,11 @@ class ChameleonBackbone(nn.Module):
         # o / down with F1r as their tail (one launch each; the reducing kernel wants whole 512-column slices per workgroup pair: 8 waves)
         red = getattr(self, "reduce_fused", _REDUCE_FUSED_DEFAULT) and not self._pf_on
         raw = lambda name: not isinstance(self._packed[0][name], ops.PackedZ)        # (the reducing kernel streams the uncompressed packing)
-        red_o = red and raw("o") and ops.skinny_gemm_reduce_ok(T, hid, H * D, cfg["o"][0], 8, h_dev := self.lm_head.weight.device)
+        h_dev = self.lm_head.weight.device
+        red_o = red and raw("o") and ops.skinny_gemm_reduce_ok(T, hid, H * D, cfg["o"][0], 8, h_dev)
         red_d = red and raw("down") and ops.skinny_gemm_reduce_ok(T, hid, inter, cfg["down"][0], 8, h_dev)
+        pair_mlp = (getattr(self, "mlp_pair", _MLP_PAIR_DEFAULT) and fuse_mlp and not red_d and h_dev.type == "cuda" and
+                    ops.mlp_pair_ok(T, inter, hid, self._packed[0]["gate_up"], self._packed[0]["down"], cfg["down"][0], cfg["down"][1], h_dev))
         h = self.model.embed_tokens(tokens).view(T, -1).contiguous()
         pos = positions.reshape(T).contiguous()
         delta, ss_next = None, None         # the down projection's split-K planes (summed by the next F1r), or the statistics its tail already wrote
@@ -578,6 +582,10 @@ class ChameleonBackbone(nn.Module):
                 rn = (ops.skinny_gemm_reduce(o.view(T, H * D), self._packed[li]["o"], hid, H * D, cfg["o"][0], h, 8, cfg["o"][2]), hid, eps)
             else:
                 rn = (ops.residual_sumsq(h, g1(o.view(T, H * D), "o", hid, H * D)), hid, eps)
+            if pair_mlp:       # round 4 experiment (SJD_MLP_PAIR=1): gate|up + SiLU * up AND the down projection in one launch
+                _, delta = ops.mlp_pair(h, self._packed[li]["gate_up"], self._packed[li]["down"], inter, hid, cfg["down"][0], row_norm=rn)
+                ss_next = None
+                continue
             if fuse_mlp:       # G1s: gate|up with SiLU * up as its epilogue (one launch, no partial planes, bit-identical to G1 + F3)
                 act = ops.gateup_silu(h, self._packed[li]["gate_up"], inter, hid, cfg["gate_up"][2], row_norm=rn)
             else:

@@ -1902,6 +1902,8 @@ extern "C" int sjd_skinny_gemm_reduce(const void *x, const void *w_packed, float
 }
 
 // workgroups of a reducing launch that gave up waiting for their slice's ticket since the library was loaded (0 on a healthy device)
+#include "sjd_gemm_pair.h"
+
 extern "C" int sjd_reduce_timeouts(void)
 {
     unsigned v = 0;

@@ -663,6 +663,42 @@ def gateup_silu(x, w_packed, inter, hidden, step_major=False, row_norm=None):
     return y
 
 
+_PAIR_READY = {}
+
+
+def mlp_pair_ok(T, inter, hidden, gu_packed, dn_packed, KC_dn, waves_dn, device):
+    """shapes sjd_mlp_pair_z serves (see include/sjd_hip.h): a <= 32-row bf16 window at hidden 4096 over two 12-bit packed weights, the down
+    projection in eight-tile workgroups with a K chunk that is a multiple of 64, the whole launch resident at once"""
+    if not (isinstance(gu_packed, PackedZ) and isinstance(dn_packed, PackedZ)):
+        return False
+    if T > 32 or hidden != 4096 or inter % 64 or KC_dn % 64 or KC_dn > 2560 or waves_dn != 8 or gu_packed.KC != hidden // 2 or dn_packed.KC != KC_dn:
+        return False
+    grid = max(inter // 64, ((hidden // 32 + 7) // 8) * ((inter + KC_dn - 1) // KC_dn))
+    return grid <= torch.cuda.get_device_properties(device).multi_processor_count
+
+
+def mlp_pair(x, gu_packed, dn_packed, inter, hidden, KC_dn, row_norm=None):
+    """the MLP as ONE launch: -> (y [T, inter], Partials of the down projection); bit-identical to gateup_silu(...) then skinny_gemm(y, ...)."""
+    T = x.shape[0]
+    assert x.is_contiguous() and x.dtype == torch.bfloat16 and x.shape[1] == hidden
+    dev = x.device
+    nc = (inter + KC_dn - 1) // KC_dn
+    rd = _PAIR_READY.get(dev)
+    if rd is None or rd.numel() < nc + 1:
+        rd = _PAIR_READY[dev] = torch.zeros(64, dtype=torch.int32, device=dev)
+    y = torch.empty(T, inter, dtype=x.dtype, device=dev)
+    out = torch.empty(nc, 32, hidden, dtype=torch.float32, device=dev)
+    L.check(L.load().sjd_mlp_pair_z(_ptr(x), _ptr(gu_packed.data), _ptr(gu_packed.exc), gu_packed.cap, int(gu_packed.step_major), _ptr(y),
+                                   _ptr(dn_packed.data), _ptr(dn_packed.exc), dn_packed.cap, int(dn_packed.step_major), _ptr(out), T, inter, hidden,
+                                   int(KC_dn), _row_norm(row_norm), _ptr(rd), torch.cuda.get_device_properties(dev).multi_processor_count, _stream()),
+            "sjd_mlp_pair_z")
+    return y, Partials(out, nc, hidden)
+
+
+def mlp_pair_timeouts():
+    return int(L.load().sjd_mlp_pair_timeouts())
+
+
 def residual_sumsq(h, part=None):
     """F1r: h [T, hidden] += dtype(sum of the G1 partials) in place (part None: h unchanged); returns the per-512-column-slice sums
     of h^2 [slices, R] fp32 -- the `sumsq` of a row_norm."""

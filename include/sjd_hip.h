@@ -380,6 +380,20 @@ int sjd_draft_window_attention_fp8_colsplit(const void *q, const void *k_cache, 
                                             int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
                                             const sjd_iter_params *params, int kv_len, void *stream);
 
+/* The MLP of a window forward as ONE launch (round 4 experiment: a run-ahead weight loader across a dependency edge).  Replaces
+ * sjd_gateup_silu_z followed by sjd_skinny_gemm_z (modeling_chameleon.py:637-643: down(silu(gate(x)) * up(x))): y [M <= 32, I] and the
+ * split-K planes out [ceil(I / KC_dn), 32, hidden] of the down projection are what the two launches write, bit for bit.  Workgroup b < I / 64
+ * computes gate / up tiles 2 b, 2 b + 1 and publishes its slice of y write-through; every workgroup is then one (column group, K chunk) unit
+ * of the down projection: it requests its header and first weight records BEFORE it waits for the arrival counter of its K chunk, so the
+ * down projection's weight stream starts under the tail of gate|up instead of behind a kernel boundary and a cold start.
+ * ready: ceil(I / KC_dn) + 1 zero-initialised uint32 private to launches that cannot overlap (the last workgroup re-arms them: replayable
+ * from a hipGraph).  bf16, hidden = 4096, KC_dn a multiple of 64 and <= 2560, eight column tiles per down workgroup; every workgroup of the
+ * launch must be resident at once: grids above resident_limit (CUs of the device) are refused.  sjd_mlp_pair_timeouts: abandoned waits (0). */
+int sjd_mlp_pair_z(const void *x, const void *wz_gu, const void *exc_gu, int exc_cap_gu, int step_major_gu, void *y, const void *wz_dn,
+                   const void *exc_dn, int exc_cap_dn, int step_major_dn, float *out, int M, int I, int hidden, int KC_dn,
+                   const sjd_row_norm *row_norm, uint32_t *ready, int resident_limit, void *stream);
+int sjd_mlp_pair_timeouts(void);
+
 /* G1 with stage F1r as its tail (round 3): h [M, N] += dtype(x @ W^T) in place and sumsq [N / 512, 32] = the per-slice sums of h^2, i.e.
  * sjd_skinny_gemm followed by sjd_residual_sumsq (the residual add + RMSNorm statistics of modeling_chameleon.py:59-73, 637, 643), bit for
  * bit, in one launch: the workgroups of a 512-column slice exchange their split-K planes device-coherently and reduce them in the

@@ -529,3 +529,46 @@ def test_g1z_wide_exception_headers(dev, M, N, K, KC, waves, step_major):
         b = ops.gateup_silu(x, wz2, N // 2, K, step_major)
         torch.cuda.synchronize()
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+@pytest.mark.parametrize("M,I,KC_dn,step_major_dn", [(32, 11008, 768, False), (17, 11008, 768, False), (32, 11008, 896, False), (32, 2816, 704, True)])
+@pytest.mark.parametrize("with_norm", [True, False])
+def test_mlp_pair_matches_g1sz_then_g1z(dev, M, I, KC_dn, step_major_dn, with_norm):
+    """sjd_mlp_pair_z (round-4 experiment: gate|up + SiLU * up and the down projection in ONE launch, the down workgroups' weight stream
+    started ahead of the dependency edge) writes the activation and the split-K planes of G1sz followed by G1z, bit for bit -- eagerly, forty
+    launches in a row (the arrival counters re-arm themselves) and replayed from a hipGraph; no wait is ever abandoned."""
+    import sjd_amd.ops as ops
+    hid = 4096
+    g = torch.Generator().manual_seed(I + M + KC_dn)
+    x = torch.randn(M, hid, generator=g).to(torch.bfloat16).to(dev)
+    wgu = _z_weight(2 * I, hid, g, dev, 100)
+    wdn = _z_weight(hid, I, g, dev, 100)
+    gu = ops.pack_weight_z(wgu, hid // 2, True)
+    dn = ops.pack_weight_z(wdn, KC_dn, step_major_dn)
+    assert gu is not None and dn is not None
+    if not ops.mlp_pair_ok(M, I, hid, gu, dn, KC_dn, 8, dev):
+        pytest.skip("launch larger than the device holds at once")
+    rn = (ops.residual_sumsq(x.clone(), None), hid, 1e-5) if with_norm else None
+    y_ref = ops.gateup_silu(x, gu, I, hid, True, row_norm=rn)
+    p_ref = ops.skinny_gemm(y_ref, dn, hid, I, KC_dn, 8, step_major_dn).data
+    torch.cuda.synchronize()
+    t0 = ops.mlp_pair_timeouts()
+    for it in range(40):
+        y, part = ops.mlp_pair(x, gu, dn, I, hid, KC_dn, row_norm=rn)
+        if it in (0, 39):
+            torch.cuda.synchronize()
+            assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), (it, (y.float() - y_ref.float()).abs().max())
+            assert part.data.shape == p_ref.shape and torch.equal(part.data.view(torch.int32), p_ref.view(torch.int32)), (it, (part.data - p_ref).abs().max())
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ops.mlp_pair(x, gu, dn, I, hid, KC_dn, row_norm=rn)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        outs = [ops.mlp_pair(x, gu, dn, I, hid, KC_dn, row_norm=rn) for _ in range(3)]
+    for _ in range(5):
+        gr.replay()
+    torch.cuda.synchronize()
+    for y, part in outs:
+        assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)) and torch.equal(part.data.view(torch.int32), p_ref.view(torch.int32))
+    assert ops.mlp_pair_timeouts() == t0

@@ -43,7 +43,7 @@ class HeadPartials(ctypes.Structure):
     _fields_ = [("part", ctypes.c_void_p), ("n_chunks", ctypes.c_int32), ("chunk_stride", ctypes.c_int64), ("row_stride", ctypes.c_int64),
                 ("col0", ctypes.c_int32), ("n_cols", ctypes.c_int32), ("urow_off", ctypes.c_int32), ("round_dtype", ctypes.c_int32),
                 ("row_sumsq", ctypes.c_void_p), ("slices", ctypes.c_int32), ("prows", ctypes.c_int32), ("inv_hidden", ctypes.c_float),
-                ("eps", ctypes.c_float), ("dbg_c", ctypes.c_void_p), ("dbg_u", ctypes.c_void_p)]
+                ("eps", ctypes.c_float), ("dbg_c", ctypes.c_void_p), ("dbg_u", ctypes.c_void_p), ("zero_state", ctypes.c_void_p)]
 
 
 EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_probs_sample", "sjd_verify_accept",

@@ -358,6 +358,24 @@ __device__ __forceinline__ float block_kth_largest_bisect(const float *row, int 
     return key2f(K);
 }
 
+// ---- compaction of the entries that take part in a draw (round 4) ---------------------------------------------------------
+// The draw needs one Philox4x32-10 evaluation (~130 instructions with the index arithmetic and the logarithm) per entry that carries
+// probability mass -- top-k 2000 of 8192 / 2048 of 32768 columns -- but a wave runs a column slot as soon as ONE of its 64 lanes holds such an
+// entry: practically every slot (36 per thread at Emu3's shape).  The kept entries {value, column} are therefore appended to a list in LDS
+// (wave ballot -> one atomicAdd per wave and slot -> prefix of the lane) and the noise is evaluated DENSELY over the list.  The order of the
+// list is arbitrary; the consumers are argmax reductions with an index tie-break, which do not depend on it.
+__device__ __forceinline__ void wave_push(bool keep, int col, float v, unsigned long long *list, int cap, int *count)
+{
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63, leader = __builtin_ctzll(m);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __builtin_popcountll(m));
+    base = __shfl(base, leader);
+    const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (keep && pos < cap) list[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)col;
+}
+
 // ---- exact k-th largest: a VALUE histogram first, the radix select over the survivors (round 4) ------------------------------
 // The radix select funnels every score of a row through atomicAdd on the bins of its top 11 key bits (sign, exponent, two mantissa bits) --
 // and the scores of one softmax row share their exponent: 8192 .. 32768 adds land on a dozen LDS words and serialise (in-kernel stamps,

@@ -50,7 +50,7 @@ __device__ __forceinline__ bool rule_allows(const sjd_row_rule &r, int c)
 // rounds to the activation dtype exactly where nn.Linear would (MC:1560-1561: 16-bit lm_head output, then .float()); the CFG combine,
 // grammar mask, top-k, softmax and draw are the same code as the dense-logits form.
 static_assert(sizeof(sjd_row_rule) == 52 && sizeof(sjd_iter_params) == 64 + 8 * SJD_MAX_WINDOW + 2 * 52 * SJD_MAX_WINDOW, "sjd_iter_params layout is mirrored by ctypes (sjd_amd/_lib.py::IterParams)");
-static_assert(sizeof(sjd_head_partials) == 88, "sjd_head_partials layout is mirrored by ctypes (sjd_amd/_lib.py::HeadPartials)");
+static_assert(sizeof(sjd_head_partials) == 96, "sjd_head_partials layout is mirrored by ctypes (sjd_amd/_lib.py::HeadPartials)");
 
 __device__ __forceinline__ float k2_round16(float x, int dt)
 {
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const int row = blockIdx.x;
     SJD_TRS(row, 0);
     if (row >= params->n_rows) return;
+    if (threadIdx.x == 0) sh.misc[1] = 0;         // entries of the draw list (the first barrier lies far ahead of its first use)
     const sjd_row_rule rule = params->rules[row];
     float *p = probs_out + (size_t)row * V;
     const float *e = noise + (size_t)row * V;
@@ -98,10 +99,19 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const uint64_t ph_seed = params->philox_seed, ph_off = params->philox_offset[0];
     const uint32_t ph_T = ph_blocks ? sjd_philox_threads((uint64_t)params->n_rows * (uint64_t)V, ph_blocks) : 0u;
 
+    // what this row of probs_out is known to hold: zeros outside [zlo, zhi) (zlo < 0: unknown) -- see sjd_head_partials::zero_state
+    int *zst = (PART && hp.zero_state) ? hp.zero_state + 2 * row : nullptr;
+    const int zlo = zst ? zst[0] : -1, zhi = zst ? zst[1] : -1;
     if (rule.forced >= 0) {   // forced EOL / end-of-image row: softmax of (-inf,...,0,...,-inf) (LP:39-41)
-        SJD_FOR_OWNED_COLS(V, c0)
+        // (with a known state only the hull of the old window and the forced column needs rewriting)
+        const int flo = zlo >= 0 ? min(zlo, rule.forced) : 0, fhi = zlo >= 0 ? max(zhi, rule.forced + 1) : V;
+        SJD_FOR_OWNED_COLS_IN(flo, fhi, c0)
             for (int j = 0; j < 4; ++j)
-                if (c0 + j < V) p[c0 + j] = (c0 + j == rule.forced) ? 1.0f : 0.0f;
+                if (c0 + j >= flo && c0 + j < fhi) p[c0 + j] = (c0 + j == rule.forced) ? 1.0f : 0.0f;
+        if (zst) {
+            __syncthreads();                       // every thread has read the old state
+            if (threadIdx.x == 0) { zst[0] = rule.forced; zst[1] = rule.forced + 1; }
+        }
         if (threadIdx.x == 0) { tokens_out[row] = rule.forced; if (amax_out) amax_out[row] = rule.forced; }
         return;
     }
@@ -123,7 +133,8 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     // 65536 columns); everything outside is written as 0 once and never read again.
     int wlo, whi;
     rule_window(rule, V, wlo, whi);
-    if (wlo > 0 || whi < V) {
+    const bool clean_outside = zlo >= 0 && zlo >= wlo && zhi <= whi;      // the recorded window lies inside this one: outside is zero already
+    if (!clean_outside && (wlo > 0 || whi < V)) {
         const bool v4 = (V & 3) == 0;              // (rows of probs_out are then 16-byte aligned)
         SJD_FOR_OWNED_COLS(V, c0) {
             if (v4 && (c0 + 3 < wlo || c0 >= whi)) *reinterpret_cast<float4 *>(p + c0) = float4{0.f, 0.f, 0.f, 0.f};
@@ -322,16 +333,27 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     SJD_TRS(row, 4);              // sum known
     // pass B: p = e / S ; multinomial == lowest-index argmax of p / Exp(1)   (JL:111-118)
     unsigned long long best = 0ull, best_p = 0ull;
+    // in-kernel noise: the entries with mass are compacted into an LDS list (behind the staged row) and drawn densely below (wave_push)
+    const int list_base = in_lds ? ((whi - (wlo & ~3) + 3) & ~3) : 0;
+    unsigned long long *klist = reinterpret_cast<unsigned long long *>(sjd_dyn_lds + list_base);
+    const int list_cap = (lds_floats - list_base) / 2;
+    const bool compact = ph_blocks != 0 && list_cap >= 64;
     auto draw = [&](int col, float w) {
         float pv = w / S;
         p[col] = pv;
+        unsigned long long cand = pack_vi(pv, col);
+        best_p = cand > best_p ? cand : best_p;
+        if (compact) {
+            const bool keep = pv > 0.0f;
+            if (!keep) { cand = pack_vi(0.0f, col); best = cand > best ? cand : best; }       // (r = 0 for an entry without mass, as before)
+            wave_push(keep, col, pv, klist, list_cap, &sh.misc[1]);
+            return;
+        }
         float r;
         if (ph_blocks) r = pv > 0.0f ? pv / sjd_philox_exponential(ph_seed, ph_off, ph_T, (uint64_t)row * (uint64_t)V + (uint64_t)col) : 0.0f;   // (0 / e == 0: e is finite and > 0)
         else r = pv / e[col];
-        unsigned long long cand = pack_vi(r, col);
+        cand = pack_vi(r, col);
         best = cand > best ? cand : best;
-        cand = pack_vi(pv, col);
-        best_p = cand > best_p ? cand : best_p;
     };
     if (fits) {
 #pragma unroll
@@ -346,9 +368,37 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
             for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (col >= wlo && col < whi) draw(col, stg[col - sb]); }
         }
     }
+    if (compact) {
+        __syncthreads();
+        const int n_kept = sh.misc[1];
+        if (n_kept <= list_cap) {
+            for (int i = threadIdx.x; i < n_kept; i += SJD_TPB) {
+                const unsigned long long en = klist[i];
+                const int col = (int)(unsigned)(en & 0xffffffffull);
+                const float pv = __uint_as_float((unsigned)(en >> 32));
+                const unsigned long long cand = pack_vi(pv / sjd_philox_exponential(ph_seed, ph_off, ph_T, (uint64_t)row * (uint64_t)V + (uint64_t)col), col);
+                best = cand > best ? cand : best;
+            }
+        } else {                                    // (more entries with mass than the list holds -- rows without a top-k: the sparse form)
+            SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = c0 + j;
+                    if (col >= wlo && col < whi) {
+                        const float pv = p[col];
+                        if (pv > 0.0f) {
+                            const unsigned long long cand = pack_vi(pv / sjd_philox_exponential(ph_seed, ph_off, ph_T, (uint64_t)row * (uint64_t)V + (uint64_t)col), col);
+                            best = cand > best ? cand : best;
+                        }
+                    }
+                }
+            }
+        }
+    }
     SJD_TRS(row, 5);              // probabilities written
     const int tok = block_argmax(best, sh);
     if (threadIdx.x == 0) tokens_out[row] = tok;
+    if (zst && threadIdx.x == 0) { zst[0] = wlo; zst[1] = whi; }          // (every read of the old state lies behind several barriers)
     if (amax_out) {                                  // by-product: the row's mode (lowest index among equal maxima)
         const int am = block_argmax(best_p, sh);
         if (threadIdx.x == 0) amax_out[row] = am;
@@ -517,17 +567,59 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                 if (rule.top_p_thr >= 0.0f) S = block_top_p_apply(scratch, wlo, whi, S, rule.top_p_thr, sh, sb);
                 degenerate = !(S > 0.0f);         // 0/0 below: flagged to the host (state->rejected = 2), never a silent arbitrary id
                 unsigned long long best = 0ull;
+                // in-kernel noise: the entries with mass go through a compacted LDS list (wave_push), the noise is evaluated densely
+                const int list_base = (scratch == sjd_dyn_lds) ? ((whi - sb + 3) & ~3) : 0;           // behind the staged row, if it is staged in LDS
+                unsigned long long *klist = reinterpret_cast<unsigned long long *>(sjd_dyn_lds + list_base);
+                const int list_cap = (lds_floats - list_base) / 2;
+                const bool compact = ph_blocks != 0 && list_cap >= 64;
+                if (compact) {
+                    if (threadIdx.x == 0) sh.misc[1] = 0;
+                    __syncthreads();
+                }
                 SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         int col = c0 + j;
                         if (col >= wlo && col < whi) {
                             const float dv = scratch[col - sb] / S;
+                            if (compact) {
+                                const bool keep = dv > 0.0f;
+                                if (!keep) { const unsigned long long cand = pack_vi(dv, col); best = cand > best ? cand : best; }     // (0 or NaN, as before)
+                                wave_push(keep, col, dv, klist, list_cap, &sh.misc[1]);
+                                continue;
+                            }
                             float r;
                             if (ph_blocks) r = dv > 0.0f ? dv / sjd_philox_exponential(ph_seed, ph_off2, ph_T2, (uint64_t)col) : dv;    // (dv is 0 or NaN here)
                             else r = dv / noise2[col];
                             unsigned long long cand = pack_vi(r, col);
                             best = cand > best ? cand : best;
+                        }
+                    }
+                }
+                if (compact) {
+                    __syncthreads();
+                    const int n_kept = sh.misc[1];
+                    if (n_kept <= list_cap) {
+                        for (int i = threadIdx.x; i < n_kept; i += SJD_TPB) {
+                            const unsigned long long en = klist[i];
+                            const int col = (int)(unsigned)(en & 0xffffffffull);
+                            const float dv = __uint_as_float((unsigned)(en >> 32));
+                            const unsigned long long cand = pack_vi(dv / sjd_philox_exponential(ph_seed, ph_off2, ph_T2, (uint64_t)col), col);
+                            best = cand > best ? cand : best;
+                        }
+                    } else {
+                        SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int col = c0 + j;
+                                if (col >= wlo && col < whi) {
+                                    const float dv = scratch[col - sb] / S;
+                                    if (dv > 0.0f) {
+                                        const unsigned long long cand = pack_vi(dv / sjd_philox_exponential(ph_seed, ph_off2, ph_T2, (uint64_t)col), col);
+                                        best = cand > best ? cand : best;
+                                    }
+                                }
+                            }
                         }
                     }
                 }
@@ -576,6 +668,7 @@ __global__ void k5_reguess(const sjd_iter_params *__restrict__ params, sjd_state
 
 // dynamic LDS (in floats) K2 / K4 ask for to stage a row's window: what `cols` columns need, capped at what a CU has left beside SjdShared
 // (150 KiB: windows of up to 38400 columns -- Emu3's 32768 visual tokens fit, a whole text vocabulary does not and keeps the global staging)
+#define SJD_DRAW_LIST 2304          // entries of the draw list K2 / K4 ask LDS room for behind a staged row (top-k 2000 / 2048 + ties)
 static int sjd_stage_lds_floats(long cols)
 {
     const long cap = 150 * 1024 / 4;
@@ -616,7 +709,7 @@ extern "C" int sjd_logits_to_probs_sample_ex(const float *logits_c, const float 
     if (!logits_c || !params || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
         return SJD_ERR_BAD_ARG;                    /* noise may be NULL when params->philox_blocks > 0 (the kernel generates it) */
     sjd_head_partials none = {};
-    const int lds_floats = sjd_stage_lds_floats(V);
+    const int lds_floats = sjd_stage_lds_floats((long)V + 2 * SJD_DRAW_LIST);
     (void)hipFuncSetAttribute((const void *)k2_logits_to_probs_sample<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
     hipLaunchKernelGGL(k2_logits_to_probs_sample<false>, dim3(max_rows), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, logits_c, logits_u,
                        (long)row_stride, guidance, V, params, noise, probs_out, tokens_out, none, amax_out, lds_floats);
@@ -630,7 +723,7 @@ extern "C" int sjd_logits_to_probs_sample_part(const sjd_head_partials *head, fl
     if (!head || !head->part || head->n_chunks < 1 || head->n_cols < 1 || head->col0 < 0 || head->row_stride < head->n_cols) return SJD_ERR_BAD_ARG;
     if (!params || !probs_out || !tokens_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1) return SJD_ERR_BAD_ARG;
     if (head->row_sumsq && (head->slices < 1 || head->prows < 1)) return SJD_ERR_BAD_ARG;
-    const int lds_floats = sjd_stage_lds_floats(head->n_cols + 8);     // (the rows' windows lie inside the head's column window)
+    const int lds_floats = sjd_stage_lds_floats((long)head->n_cols + 8 + 2 * SJD_DRAW_LIST);     // (the rows' windows lie inside the head's column window; + the draw list)
     (void)hipFuncSetAttribute((const void *)k2_logits_to_probs_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
     hipLaunchKernelGGL(k2_logits_to_probs_sample<true>, dim3(max_rows), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, (const float *)nullptr,
                        (const float *)nullptr, (long)0, guidance, V, params, noise, probs_out, tokens_out, *head, amax_out, lds_floats);
@@ -643,7 +736,7 @@ extern "C" int sjd_verify_accept_ex(const sjd_iter_params *params, sjd_state *st
 {
     if (!params || !state || !probs || !prev_probs || !scratch || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
         return SJD_ERR_BAD_ARG;                    /* rs / noise2 may be NULL when params->philox_blocks > 0 */
-    const int lds_floats = sjd_stage_lds_floats(V);
+    const int lds_floats = sjd_stage_lds_floats((long)V + 2 * SJD_DRAW_LIST);
     (void)hipFuncSetAttribute((const void *)k4_verify_accept, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
     hipLaunchKernelGGL(k4_verify_accept, dim3(1), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, params, state, probs, prev_probs, rs,
                        noise2, scratch, V, host_mirror, lds_floats);

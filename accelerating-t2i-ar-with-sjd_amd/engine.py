@@ -146,6 +146,9 @@ class SJDEngine:
         self.params = ops.DeviceBlob(L.IterParams, dev)
         self.state = ops.DeviceBlob(L.State, dev)
         self.probs = torch.zeros(2, self.Lmax, self.V, dtype=torch.float32, device=dev)
+        # per probs buffer and row: the column window outside of which the row is known to hold zeros (K2 then skips that zero fill); the
+        # dense-logits K2 of the prefill iteration does not keep it, so the state of a buffer it wrote is reset to "unknown" (-1)
+        self.zero_state = torch.full((2, self.Lmax, 2), -1, dtype=torch.int32, device=dev)
         self.noise = self.rs = self.noise2 = None   # [L,V], [L,V], [1,V] fp32: allocated only for observers / host-drawn noise (_noise_tensors)
         self._philox = True                         # this decode's K2 / K4 generate their noise (False: they read the tensors)
         self.scratch = torch.empty(self.V, dtype=torch.float32, device=dev)
@@ -259,11 +262,12 @@ class SJDEngine:
                 dbg = self._dbg
                 dbg.zero_()
             ops.logits_to_probs_sample_part(logits, self._guidance, self.params, noise, self.probs[cur], self.tokens_ptr, dbg=dbg,
-                                            amax_out_ptr=self.amax_ptr)
+                                            amax_out_ptr=self.amax_ptr, zero_state=self.zero_state[cur])
         else:
             lu = logits[1] if self.B > 1 else None
             ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, noise, self.probs[cur], self.tokens_ptr,
                                        col0=cols[0] if cols else 0, amax_out_ptr=self.amax_ptr)
+            self.zero_state[cur].fill_(-1)            # (the dense-logits K2 does not keep the rows' zero state)
         ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], rs, noise2, self.scratch, mirror=True)
 
     def logit_columns(self, rules):
@@ -495,6 +499,7 @@ class SJDEngine:
                 win_len = tokens.shape[1]
                 ops.logits_to_probs_sample(lc, lu, self._guidance, self.params, None if philox else self.noise, self.probs[cur], self.tokens_ptr,
                                            amax_out_ptr=self.amax_ptr)
+                self.zero_state[cur].fill_(-1)
                 ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], None if philox else self.rs,
                                   None if philox else self.noise2[0], self.scratch, mirror=True)
                 if attn is not None and hasattr(attn, "params"):

@@ -517,7 +517,7 @@ class HeadOut:
 
 
 def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noise, probs_out, tokens_out_ptr, dbg=None, amax_out_ptr=None,
-                                row0=0, urow_off=None):
+                                row0=0, urow_off=None, zero_state=None):
     """K2 reading the unmaterialised output head (see sjd_head_partials in include/sjd_hip.h).  dbg: optional fp32 [2, rows, V] that
     receives the logits K2 derived (cond, uncond) -- observers only.  row0 / urow_off: this launch's cond rows start at partial row
     `row0` and its uncond rows `urow_off` rows further (several prompts share one head launch: SJDBatchEngine)."""
@@ -536,6 +536,9 @@ def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noi
         hp.dbg_c = dbg[0].data_ptr()
         if dbg.shape[0] >= 2:              # (one plane: a batch without CFG -- there is no uncond row to observe)
             hp.dbg_u = dbg[1].data_ptr()
+    if zero_state is not None:         # int32 [max_rows, 2] that belongs to THIS probs_out buffer (see sjd_head_partials::zero_state)
+        assert zero_state.dtype == torch.int32 and zero_state.is_contiguous() and zero_state.shape == (max_rows, 2) and zero_state.device == probs_out.device
+        hp.zero_state = zero_state.data_ptr()
     assert noise is None or (noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V)
     assert probs_out.is_contiguous()
     L.check(L.load().sjd_logits_to_probs_sample_part(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out),

@@ -172,6 +172,11 @@ typedef struct sjd_head_partials {
     int32_t slices, prows;
     float inv_hidden, eps;
     float *dbg_c, *dbg_u;
+    int32_t *zero_state;            /* round 4, optional ([max_rows][2] int32, -1 initially; ONE per probs_out buffer): per row the column window
+                                     * [lo, hi) outside of which probs_out is known to hold zeros.  K2 skips the zero fill of the columns outside a
+                                     * row's window when the recorded window lies inside it (image rows: the same window every iteration -- 57344
+                                     * of Lumina's 65536, 151854 of Emu3's 184622 columns were rewritten with zeros per row and iteration) and
+                                     * records the window it leaves behind.  Only K2 may write probs_out while a state is attached to it. */
 } sjd_head_partials;
 int sjd_logits_to_probs_sample_part(const sjd_head_partials *head /* host struct, passed by value to the kernel */, float guidance,
                                     int max_rows, int V, const sjd_iter_params *params, const float *noise, float *probs_out,

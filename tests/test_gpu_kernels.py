@@ -754,3 +754,47 @@ def test_k2_on_the_unmaterialised_output_head(dev, dtype, fold, name, V, n, buil
 def ctypes_ptr(t):
     import ctypes
     return ctypes.c_void_p(t.data_ptr())
+
+
+def test_k2_zero_state_skips_only_what_is_zero(dev):
+    """sjd_head_partials::zero_state (round 4): K2 does not rewrite the zeros outside a row's window when the window it recorded for the row
+    lies inside the current one.  A probs buffer driven through a SEQUENCE of rule sets -- image rows, rows that become forced EOL rows
+    and back, a window that shrinks, one that moves, text rows over the whole vocabulary -- must hold, after every launch, exactly what a
+    poisoned-then-fresh buffer without a state holds."""
+    ops, L = _ops()
+    V, Lmax, n, n_chunks = 9216, 16, 12, 3
+    g = torch.Generator().manual_seed(5)
+    img = lambda: O.rule(((4, 8196),), -1, 2000, None)
+    seqs = [
+        [img() for _ in range(n)],                                                         # image rows
+        [img() if i % 5 else O.rule((), 8803, 0, None) for i in range(n)],                 # some rows forced (EOL)
+        [img() for _ in range(n)],                                                         # ... and image rows again
+        [O.rule(((1000, 3000),), -1, 50, None) for _ in range(n)],                         # a narrower window inside the old one
+        [O.rule(((2000, 9000),), -1, 0, None) for _ in range(n)],                          # a window that sticks out of the recorded one
+        [O.rule((), -1, 10, None) for _ in range(n)],                                      # text rows: the whole vocabulary
+        [O.rule(((4, 8196),), -1, 2000, None) if i < 7 else O.rule((), 8196, 0, None) for i in range(n)],
+    ]
+    cols = (0, V)
+    probs_s = torch.full((Lmax, V), -7.0, device=dev)
+    zst = torch.full((Lmax, 2), -1, dtype=torch.int32, device=dev)
+    toks_s, toks_f = torch.zeros(Lmax, dtype=torch.int64, device=dev), torch.zeros(Lmax, dtype=torch.int64, device=dev)
+    for it, rules in enumerate(seqs):
+        part = ops.Partials((torch.randn(n_chunks, 32, V, generator=g) * 1.5).to(dev), n_chunks, V)
+        head = ops.HeadOut(part, cols[0], Lmax, torch.bfloat16)
+        params = ops.DeviceBlob(L.IterParams, dev)
+        params.view.n_rows, params.view.use_cfg = n, 1
+        for j, r in enumerate(rules):
+            params.view.rules[j] = to_dev_rule(L, ops, r)
+        params.upload()
+        noise = torch.empty(Lmax, V).exponential_(generator=g).to(dev)
+        probs_f = torch.full((Lmax, V), float("nan"), device=dev)                          # fresh, poisoned, no state: everything is rewritten
+        ops.logits_to_probs_sample_part(head, 3.0, params, noise, probs_f, ctypes_ptr(toks_f))
+        ops.logits_to_probs_sample_part(head, 3.0, params, noise, probs_s, ctypes_ptr(toks_s), zero_state=zst)
+        torch.cuda.synchronize()
+        assert torch.equal(toks_s[:n], toks_f[:n]), it
+        assert torch.equal(probs_s[:n].view(torch.int32), probs_f[:n].view(torch.int32)), (it, int((probs_s[:n] != probs_f[:n]).sum()))
+        st = zst.cpu()
+        for i, r in enumerate(rules):
+            want = (r.forced, r.forced + 1) if r.forced >= 0 else ((min(r.lo[a] for a in range(r.n_ranges)), max(r.hi[a] for a in range(r.n_ranges))) if r.n_ranges else (0, V))
+            assert tuple(st[i].tolist()) == want, (it, i, st[i].tolist(), want)
+    assert (zst[n:] == -1).all() and (probs_s[n:] == -7.0).all()                          # rows beyond n_rows: untouched

@@ -1575,9 +1575,10 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     static const bool no_merge = getenv("SJD_K1_NO_MERGE") != nullptr;
     unsigned short *merge_out = (ticket && !shared && !direct && !no_merge) ? (unsigned short *)out : nullptr;
     // round 4: the shared-tile shapes run on the LDS-DMA ring kernel (sjd_attention_ring.h); SJD_K1_RING=0: k1_partial_shared (A/B),
-    // SJD_K1_RING_SLOTS=4|6|8: ring depth (default 6 = five tiles of 16 KiB in flight per workgroup)
+    // SJD_K1_RING_SLOTS=4|6|8: ring depth (default 4 = three tiles of 16 KiB in flight per workgroup: measured best, profiles/r4_k1_ring_halves.txt --
+    // the DMA pipeline alone runs at the HBM rate with any depth, a deeper ring only delays the first tile)
     static const bool ring = [] { const char *e = getenv("SJD_K1_RING"); return !(e && e[0] == '0'); }();
-    static const int ring_slots = [] { const char *e = getenv("SJD_K1_RING_SLOTS"); const int v = e ? atoi(e) : 6; return (v == 4 || v == 8) ? v : 6; }();
+    static const int ring_slots = [] { const char *e = getenv("SJD_K1_RING_SLOTS"); const int v = e ? atoi(e) : 4; return (v == 6 || v == 8) ? v : 4; }();
     // round 4: the multi-head window without key splits -- four workgroups per (batch, head) split the OUTPUT COLUMNS (k1_dsplit): one
     // launch, no workspace, no combine.  SJD_K1_DSPLIT=0|1 (A/B aid).
     static const int dsplit = [] { const char *e = getenv("SJD_K1_DSPLIT"); return e ? atoi(e) : SJD_K1_DSPLIT_DEFAULT; }();
@@ -1599,6 +1600,14 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
             hipLaunchKernelGGL((k1_partial_ring<DT, D, NWV_, R_>), dim3(n_split, H_kv, B), dim3(64 * NWV_), lds, stream, (const unsigned short *)q, \
                                (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,  \
                                kv_len, n_split, n_chunks, B); } while (0)
+            static const bool halves = getenv("SJD_K1_RING_HALVES") != nullptr;       // (experiment: two 4-wave workgroups per (batch, kv head, split))
+            if (pairs == 8 && halves) {
+                const size_t lds = (size_t)4 * 2 * K1_KT * D * 2 + (size_t)4 * K1_ROWS * D * 2;
+                (void)hipFuncSetAttribute((const void *)k1_partial_ring<DT, D, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((k1_partial_ring<DT, D, 4, 4>), dim3(2 * n_split, H_kv, B), dim3(256), lds, stream, (const unsigned short *)q,
+                                   (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,
+                                   kv_len, n_split, n_chunks, B, 2);
+            } else
             if (pairs == 8) { if (ring_slots == 4) SJD_K1R_LAUNCH(8, 4); else if (ring_slots == 8) SJD_K1R_LAUNCH(8, 8); else SJD_K1R_LAUNCH(8, 6); }
             else { if (ring_slots == 4) SJD_K1R_LAUNCH(4, 4); else if (ring_slots == 8) SJD_K1R_LAUNCH(4, 8); else SJD_K1R_LAUNCH(4, 6); }
 #undef SJD_K1R_LAUNCH

@@ -74,8 +74,11 @@ template <int DT, int D, int NWV, int R>
 __global__ __launch_bounds__(64 * NWV) void k1_partial_ring(
     const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
     const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,        // (among the first 16 dwords: preloaded into SGPRs)
-    float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max, int kv_len_arg, int n_split, int n_chunks, int B)
+    float *__restrict__ ws_o, float *__restrict__ ws_ml, int n_rows, int H, int H_kv, int S_max, int kv_len_arg, int n_split, int n_chunks, int B,
+    int n_parts = 1)
 {
+    // n_parts (experiment, VERDICT r3 #1b): the (head, chunk) pairs of a (batch, kv head, split) spread over n_parts workgroups of NWV waves --
+    // two 4-wave workgroups per CU instead of one 8-wave one, each with its own ring (the K/V tiles then travel to LDS twice)
     typedef typename Frag<DT>::vec vec;
     static_assert(D == 128, "the ring kernel is written for head_dim 128 (16 pieces of 16 bytes per row)");
     constexpr int KS = D / 32, DB = D / 16;
@@ -91,8 +94,9 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_ring(
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int g = lane >> 4, c = lane & 15;
     const int G = H / H_kv;
-    const int head_in_group = w % G, chunk = w / G;           // wave = (q head of the group, 16-row chunk)
-    const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
+    const int split = blockIdx.x / n_parts, part = blockIdx.x % n_parts, hkv = blockIdx.y, b = blockIdx.z;
+    const int pair = part * NWV + w;
+    const int head_in_group = pair % G, chunk = pair / G;     // wave = (q head of the group, 16-row chunk)
     const int head = hkv * G + head_in_group;
     int kv_base, n_total, kstart;
     k1_entry(params, key_start, b, kv_len_arg, n_rows, kv_base, n_total, kstart);

@@ -1585,6 +1585,23 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
     if (colsplit && !(D == 128 && H == H_kv)) return SJD_ERR_UNSUPPORTED;
     if ((colsplit || (!shared && dsplit)) && D == 128 && H == H_kv) {
         if constexpr (D == 128) {
+            static const int pf = [] { const char *e = getenv("SJD_K1_DSPLIT_PF"); return e ? atoi(e) : 0; }();      // (0: one tile ahead; 3 / 4: tiles in flight per wave)
+            if (pf == 9) {        // (9: the column split over an LDS-DMA ring of full key rows)
+                const size_t lds = (size_t)16 * (K1_KT * D * 2 + K1_KT * (D / 4) * 2);
+                (void)hipFuncSetAttribute((const void *)k1_dsplit_ring<DT, D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((k1_dsplit_ring<DT, D, 4>), dim3(4 * n_chunks * H * B), dim3(512), lds, stream, (const unsigned short *)q,
+                                   (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, (unsigned short *)out, n_rows, H, H_kv,
+                                   S_max, kv_len, n_chunks, B);
+            } else
+            if (pf == 4)
+                hipLaunchKernelGGL((k1_dsplit_pf<DT, D, 8, 4, 4>), dim3(4 * n_chunks * H * B), dim3(512), 0, stream, (const unsigned short *)q,
+                                   (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, (unsigned short *)out, n_rows, H, H_kv,
+                                   S_max, kv_len, n_chunks, B);
+            else if (pf == 3)
+                hipLaunchKernelGGL((k1_dsplit_pf<DT, D, 8, 4, 3>), dim3(4 * n_chunks * H * B), dim3(512), 0, stream, (const unsigned short *)q,
+                                   (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, (unsigned short *)out, n_rows, H, H_kv,
+                                   S_max, kv_len, n_chunks, B);
+            else
             hipLaunchKernelGGL((k1_dsplit<DT, D, 8, 4>), dim3(4 * n_chunks * H * B), dim3(512), 0, stream, (const unsigned short *)q,
                                (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, (unsigned short *)out, n_rows, H, H_kv,
                                S_max, kv_len, n_chunks, B);

@@ -5,6 +5,13 @@
 // from the memory side and costs one ordinary round trip.  Everything here is a compiler-visible atomic (relaxed, agent scope): the
 // instruction selector emits global_load / global_store ... sc1 and keeps its own s_waitcnt bookkeeping -- hand-written asm loads would
 // land in registers the register allocator believes it may already reuse.
+//
+// Ordering: the exchanges built on these accesses (g1_reduce_tail, k1_merge_publish, g1z_mlp_pair) use the guide's
+// "drained sc1" form -- sc1 payload stores -> `s_waitcnt vmcnt(0)` (every store acknowledged by the memory side) -> workgroup barrier ->
+// relaxed agent-scope counter add;  consumer: relaxed poll / ticket -> workgroup barrier -> sc1 loads -- which MI355X_MICROARCH.md lists under
+// "Valid forms" ({sc0 sc1 stores and loads both sides}; "sc1 loads may replace the acquire only when the producer stored sc1").  No release /
+// acquire FENCE is used on purpose: `fence(release, "agent")` lowers to buffer_wbl2 (a write-back of the XCD's whole L2, 1.7-6.5 us) and would
+// cost more than the boundary these experiments tried to remove.  All three exchanges are off by default (measured no-go).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -59,6 +59,7 @@ class SJDBatchEngine:
             s.params, s.state = self.params.blobs[i], self.state.blobs[i]
             s.params.view.batch_rows = n_batch
             s.probs = torch.zeros(2, self.Lmax, self.V, dtype=torch.float32, device=dev)
+            s.zero_state = torch.full((2, self.Lmax, 2), -1, dtype=torch.int32, device=dev)        # see SJDEngine.zero_state
             s.noise = s.rs = s.noise2 = None        # only for observers (the parity tests' hook): K2 / K4 generate their noise
             s.scratch = torch.empty(self.V, dtype=torch.float32, device=dev)
             s.tokens_ptr = s.state.field_ptr("tokens")
@@ -179,12 +180,13 @@ class SJDBatchEngine:
             if part:
                 ops.logits_to_probs_sample_part(logits, self._guidance, s.params, None, s.probs[cur], s.tokens_ptr, amax_out_ptr=s.amax_ptr,
                                                 dbg=None if dbg is None else dbg[i * self.nb:(i + 1) * self.nb], row0=i * self.nb * self.Lmax,
-                                                urow_off=self.Lmax if self.nb > 1 else 0)
+                                                urow_off=self.Lmax if self.nb > 1 else 0, zero_state=s.zero_state[cur])
             else:
                 lc = logits[i * self.nb]
                 lu = logits[i * self.nb + 1] if self.nb > 1 else None
                 ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, None, s.probs[cur], s.tokens_ptr, col0=cols[0] if cols else 0,
                                            amax_out_ptr=s.amax_ptr)
+                s.zero_state[cur].fill_(-1)
             ops.verify_accept(s.params, s.state, s.probs[cur], s.probs[1 - cur], None, None, s.scratch, mirror=True)
 
     def _launch_forward(self, cols):
@@ -340,6 +342,7 @@ class SJDBatchEngine:
             lc = logits[0, -1:, :]
             lu = logits[1, -1:, :] if nb > 1 else None
             ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, None, s.probs[buf], s.tokens_ptr, amax_out_ptr=s.amax_ptr)
+            s.zero_state[buf].fill_(-1)
             ops.verify_accept(s.params, s.state, s.probs[buf], s.probs[1 - buf], None, None, s.scratch, mirror=True)
             s.ph_off += s.ph_step                                  # the [1, V] multinomial of iteration 0
             if self.hook is not None:
@@ -514,6 +517,8 @@ class SJDBatchEngine:
                 break
         ev1.record()
         torch.cuda.synchronize()
+        from .engine import check_reduce_timeouts
+        check_reduce_timeouts()                    # (a reducing projection that gave up a wait: wrong numbers must not become tokens -- ADVICE r3)
         if on_timed_end is not None and (timed_started or timed_iters is None):      # never an unmatched barrier (SJDEngine.decode)
             on_timed_end()
         seconds = ev0.elapsed_time(ev1) / 1000.0

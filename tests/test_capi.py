@@ -39,7 +39,8 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(L.State) == 16 + 8 * W * 2 + 4 * W + 8 * W
     assert L.State.tokens.offset == 16 and L.State.win_tok.offset == 16 + 8 * W and L.State.q_src.offset == 16 + 16 * W
     assert L.State.amax.offset == 16 + 16 * W + 4 * W
-    assert ctypes.sizeof(L.HeadPartials) == 88 and L.HeadPartials.row_sumsq.offset == 48          # static_assert'ed in sjd_sampling.hip
+    assert ctypes.sizeof(L.HeadPartials) == 96 and L.HeadPartials.row_sumsq.offset == 48          # static_assert'ed in sjd_sampling.hip
+    assert L.HeadPartials.zero_state.offset == 88                                                 # (round 4: the rows' zero state, last member)
     assert ctypes.sizeof(L.RowNorm) == 24
 
 
@@ -50,6 +51,10 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.sjd_logits_to_probs_sample(None, None, 0, 1.0, 16, 100, None, None, None, None, None) == -1
     assert lib.sjd_verify_accept(None, None, None, None, None, None, None, 16, 100, None) == -1
     assert lib.sjd_attention_workspace_bytes(2, 32, 16, 128, 8) == 2 * 32 * 1 * 8 * 16 * 130 * 4
+    # round 4 entry points: argument checks run before any launch
+    assert lib.sjd_draft_window_attention_colsplit(None, None, None, None, 2, 16, 32, 32, 128, 1024, 0, None, None, 0, None) == -1
+    assert lib.sjd_draft_window_attention_fp8_colsplit(None, None, None, None, 2, 16, 32, 32, 128, 1024, 0, 1.0, 1.0, None, None, 0, None) == -1
+    assert lib.sjd_mlp_pair_z(None, None, None, 32, 1, None, None, None, 32, 0, None, 32, 11008, 4096, 768, None, None, 256, None) == -1
 
 
 def test_host_wait_on_the_mirror_sequence_word():

@@ -28,7 +28,9 @@ When the grammar cannot name the residual rules before the launch (fast_residual
 first rows after <start>, windows that hold an end token) the iteration is launched in two stages instead -- {K5, forward}, residual
 rules computed on the host meanwhile and uploaded behind it on the same stream, {K2, K4}.
 """
+import contextlib
 import ctypes
+import gc
 import os
 import random
 import time
@@ -126,6 +128,24 @@ def check_reduce_timeouts():
         _REDUCE_TIMEOUTS_SEEN = n
         raise RuntimeError(f"{n} workgroup(s) of a reducing projection launch gave up waiting for their slice (the GPU does not hold the whole "
                            "launch at once: partitioned / shared device?); set SJD_REDUCE_FUSED=0 to run the projections with a separate F1r stage")
+
+
+@contextlib.contextmanager
+def capture_graph(g):
+    """`with torch.cuda.graph(g, capture_error_mode="thread_local")` with the cyclic garbage collector held off for the length of the capture.
+    A collection that happens to start while the stream is capturing runs the destructors of whatever garbage the process has piled up -- an
+    earlier engine's hipGraphs, events, pinned blobs -- and a runtime call from such a destructor (graph / event destruction, a pinned free)
+    in the middle of a capture aborts the process (seen once in the full GPU suite, round 4: `Fatal Python error: Aborted ... Garbage-collecting`
+    under `_launch_window`).  Garbage is collected BEFORE the capture instead; other host threads may still use the GPU (thread-local capture mode)."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def warn_no_grid(cfg, grammar):
@@ -316,7 +336,7 @@ class SJDEngine:
                 self._eager_runs[fkey] = 1
                 return self._forward_body(cols)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other host threads may use the GPU (servers; the streaming parity tests)
+            with capture_graph(g):
                 self._graph_logits[fkey] = self._forward_body(cols)
             self._graphs[fkey] = g
         self._graphs[fkey].replay()
@@ -332,7 +352,7 @@ class SJDEngine:
         if key not in self._graphs:
             self._sample_body(cur, logits, cols)     # eager warm-up of this parity, captured below for the next use
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other host threads may use the GPU (servers; the streaming parity tests)
+            with capture_graph(g):
                 self._sample_body(cur, logits, cols)
             self._graphs[key] = g
             return
@@ -354,7 +374,7 @@ class SJDEngine:
                 self._sample_body(cur, logits, cols)
                 return logits
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with capture_graph(g):
                 logits = self._forward_body(cols)
                 self._sample_body(cur, logits, cols)
             self._graph_logits[key] = logits

@@ -24,7 +24,7 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .engine import DecodeStats, SJDConfig, WindowSpec, warn_no_grid
+from .engine import DecodeStats, SJDConfig, WindowSpec, warn_no_grid, capture_graph
 from .grammar import spatial_fresh_tokens
 
 
@@ -199,7 +199,7 @@ class SJDBatchEngine:
                 self._eager_runs[fkey] = 1
                 return self._forward_body(cols)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other host threads may use the GPU (servers; the streaming parity tests)
+            with capture_graph(g):
                 self._graph_logits[fkey] = self._forward_body(cols)
             self._graphs[fkey] = g
         self._graphs[fkey].replay()
@@ -213,7 +213,7 @@ class SJDBatchEngine:
         if key not in self._graphs:
             self._sample_body(cur, logits, cols)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other host threads may use the GPU (servers; the streaming parity tests)
+            with capture_graph(g):
                 self._sample_body(cur, logits, cols)
             self._graphs[key] = g
             return
@@ -234,7 +234,7 @@ class SJDBatchEngine:
                 self._sample_body(cur, logits, cols)
                 return logits
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with capture_graph(g):
                 logits = self._forward_body(cols)
                 self._sample_body(cur, logits, cols)
             self._graph_logits[key] = logits

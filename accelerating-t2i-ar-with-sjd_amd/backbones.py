@@ -39,6 +39,21 @@ _log = _logging.getLogger("sjd_amd.backbones")
 _K1_FUSED_DEFAULT = _os.environ.get("SJD_K1_FUSED", "0") == "1"
 _K1_FUSED_SPLIT_DEFAULT = _os.environ.get("SJD_K1_FUSED_SPLIT", "1") != "0"   # with k1_fused: the split form K1Fs (0: one workgroup per (batch, head))
 _MLP_PAIR_DEFAULT = _os.environ.get("SJD_MLP_PAIR", "0") == "1"          # sjd_mlp_pair_z: the MLP as one launch (round-4 experiment)
+_NAN_CHECK = _os.environ.get("SJD_NAN_CHECK", "0") == "1"                    # debug aid: name the first kernel whose output is not finite
+
+
+def _chk(tag, x, rows=None):
+    """SJD_NAN_CHECK=1: raise at the first forward stage whose output holds a non-finite value (rows: the valid rows of padded planes)"""
+    if not _NAN_CHECK or x is None:
+        return x
+    t = x.data if hasattr(x, "n_chunks") else x
+    v = t if rows is None else (t[:, :rows] if hasattr(x, "n_chunks") else t[:rows])
+    if not torch.isfinite(v.float()).all():
+        bad = (~torch.isfinite(v.float())).nonzero()
+        raise FloatingPointError(f"{tag}: {bad.shape[0]} non-finite values, first at {bad[0].tolist()} of {tuple(v.shape)}")
+    return x
+
+
 _GATEUP_FUSED_DEFAULT = {"0": False, "tall": "tall"}.get(_os.environ.get("SJD_GATEUP_FUSED", "1"), True)     # kernel G1s (gate|up + F3 in one launch); 0: G1 then F3; tall: also above 64 rows
 # round 3 experiment (VERDICT r2 next #3), correct, tested, OFF by default: the o / down projections of a <= 32-row window can reduce their own
 # split-K planes, add the residual and write the row statistics in their tail (sjd_skinny_gemm_reduce: device-coherent exchange between
@@ -577,7 +592,9 @@ class ChameleonBackbone(nn.Module):
             a = layer.self_attn
             rn = (ss_next if ss_next is not None else ops.residual_sumsq(h, delta), hid, eps)
             qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
-            o = self._attention_block(g1(h, "qkv", (H + 2 * Hkv) * D, hid), li, qn, pos, B, n, params, kv_len, key_start, row_norm=rn)
+            _chk(f"L{li} sumsq", rn[0][:, :T] if rn[0].dim() == 2 and rn[0].shape[1] >= T else rn[0])
+            o = self._attention_block(_chk(f"L{li} qkv", g1(h, "qkv", (H + 2 * Hkv) * D, hid), T), li, qn, pos, B, n, params, kv_len, key_start, row_norm=rn)
+            _chk(f"L{li} attention", o)
             if red_o:
                 rn = (ops.skinny_gemm_reduce(o.view(T, H * D), self._packed[li]["o"], hid, H * D, cfg["o"][0], h, 8, cfg["o"][2]), hid, eps)
             else:
@@ -590,10 +607,13 @@ class ChameleonBackbone(nn.Module):
                 act = ops.gateup_silu(h, self._packed[li]["gate_up"], inter, hid, cfg["gate_up"][2], row_norm=rn)
             else:
                 act = ops.silu_mul(g1(h, "gate_up", 2 * inter, hid), rows=T, dtype=h.dtype, row_norm=rn)
+            _chk(f"L{li} act", act)
             if red_d:
                 delta, ss_next = None, ops.skinny_gemm_reduce(act, self._packed[li]["down"], hid, inter, cfg["down"][0], h, 8, cfg["down"][2])
             else:
                 delta, ss_next = g1(act, "down", hid, inter), None
+            _chk(f"L{li} down", delta, T)
+            _chk(f"L{li} h", h)
         self._prefetch_join()
         if head_partials and self._packed_head is not None:
             return self._head_partials(h, delta, cols, n, sumsq=ss_next)
@@ -651,11 +671,11 @@ class ChameleonBackbone(nn.Module):
             x = ops.add_rmsnorm(h, delta, layer.input_layernorm.weight, eps)
             qkv = F.linear(x, qkv_w)
             qn = (a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias) if self.args.qk_norm else (None,) * 4
-            q = self._f2(qkv, li, qn, pos, B, n, params, kv_len)
-            o = self.attn.attend(li, q, self.cache, kv_len, key_start)
+            q = _chk(f"prefill L{li} q", self._f2(_chk(f"prefill L{li} qkv", qkv), li, qn, pos, B, n, params, kv_len))
+            o = _chk(f"prefill L{li} attention", self.attn.attend(li, q, self.cache, kv_len, key_start))
             attn_out = F.linear(o.view(T, H * D), a.o_proj.weight)
-            x = ops.add_rmsnorm(h, attn_out, layer.post_attention_layernorm.weight, eps)
-            delta = F.linear(ops.silu_mul(F.linear(x, gu_w)), layer.mlp.down_proj.weight)
+            x = _chk(f"prefill L{li} norm2", ops.add_rmsnorm(h, attn_out, layer.post_attention_layernorm.weight, eps))
+            delta = _chk(f"prefill L{li} mlp", F.linear(ops.silu_mul(F.linear(x, gu_w)), layer.mlp.down_proj.weight))
         x = ops.add_rmsnorm(h, delta, self.model.norm.weight, eps)
         return _head_logits(self.lm_head, x, cols).view(B, n, -1)
 

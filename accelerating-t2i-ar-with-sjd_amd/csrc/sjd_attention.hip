@@ -87,6 +87,20 @@ __device__ __forceinline__ void k1_tile_range(int kstart, int total, int n_split
     const int nt = max(t_hi - t_lo, 0);
     eff_split = min(n_split, max(1, (nt + K1_MIN_TILES_PER_SPLIT - 1) / K1_MIN_TILES_PER_SPLIT));
     tps = (nt + eff_split - 1) / eff_split;
+    // no EMPTY split below the effective count: with tps rounded up the last splits may get no tile (129 tiles over 16 splits: 9 each, the
+    // sixteenth none), and a kernel that skips its empty split would leave a partial the combine merges unwritten (round 4: found with the
+    // allocator's free pool poisoned -- a fresh process reads zero pages there, which merge as a harmless (m = 0, l = 0) term)
+    if (tps > 0) eff_split = (nt + tps - 1) / tps;
+}
+
+// the (m, l, O) of a split that saw no key: -inf, 0, zeros (O must be DEFINED: the merge multiplies it by exp(-inf) = 0).  Only the case of no
+// visible key at all (eff_split == 1 with no tile: rows hidden in front of key_start) still reaches it.
+template <int D>
+__device__ __forceinline__ void k1_store_empty_partial(float *__restrict__ ws_o, float *__restrict__ ws_ml, size_t slot0, int c, int g)
+{
+#pragma unroll
+    for (int db = 0; db < D / 16; ++db) *reinterpret_cast<f32x4 *>(ws_o + (slot0 + c) * D + 16 * db + 4 * g) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g == 0) { ws_ml[(slot0 + c) * 2] = -INFINITY; ws_ml[(slot0 + c) * 2 + 1] = 0.f; }
 }
 
 template <int DT> struct Frag;
@@ -531,7 +545,8 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_shared(
         if (split < es) { bt0 = min(bt0, a + split * tp); bt1 = max(bt1, min(e, a + split * tp + tp)); }
         total_max = max(total_max, tot);
     }
-    if (bt1 <= bt0) {                         // no wave of this workgroup has work in this split
+    if (bt1 <= bt0) {                         // no wave of this workgroup has a tile in this split
+        if (wave_on) k1_store_empty_partial<D>(ws_o, ws_ml, ((((size_t)b * H + head) * n_chunks + chunk) * n_split + split) * K1_ROWS, c, g);
         return;
     }
     SJD_TR(1);                    // tile ranges known

@@ -128,7 +128,10 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_ring(
         if (split < es) { bt0 = min(bt0, a + split * tp); bt1 = max(bt1, min(e, a + split * tp + tp)); }
         total_max = max(total_max, tot);
     }
-    if (bt1 <= bt0) return;                   // no wave of this workgroup has work in this split
+    if (bt1 <= bt0) {                         // no wave of this workgroup has a tile in this split
+        if (wave_on) k1_store_empty_partial<D>(ws_o, ws_ml, ((((size_t)b * H + head) * n_chunks + chunk) * n_split + split) * K1_ROWS, c, g);
+        return;
+    }
     SJD_TR(1);                    // tile ranges known
 
     const unsigned ring0 = k1r_lds_addr(k1r_lds);

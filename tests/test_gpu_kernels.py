@@ -502,6 +502,38 @@ def test_k1_ignores_nan_beyond_the_valid_cache_length(dev):
     assert (out[:, :n] - ref).abs().max() < 3e-2
 
 
+@pytest.mark.parametrize("H,Hkv,n,kv_len,n_split,ks", [
+    (8, 2, 32, 4101, 16, [0, 4089]),     # Emu3's window late in an image: 130 tiles over 16 splits = 9 each, the sixteenth gets none
+    (8, 2, 1, 4100, 32, [0, 4088]),      # its one-row iteration: 5 tiles each, splits 26..31 none
+    (4, 4, 16, 1217, 8, [0, 59]),        # multi-head window (k1_partial), the last split empty
+    (4, 4, 48, 0, 4, [0, 40]),           # a prompt whose first chunks lie wholly in front of key_start: no visible key at all -> zeros
+    (8, 2, 48, 0, 4, [0, 40]),           # the same through the shared-tile kernels
+])
+def test_k1_empty_splits_on_a_poisoned_workspace(dev, H, Hkv, n, kv_len, n_split, ks):
+    """A split below the effective count that holds no tile (tiles-per-split rounds up) and a chunk that sees no key must still merge as
+    (m = -inf, l = 0, O = 0).  Round 4: k1_partial_shared / k1_partial_ring returned from such a split without writing its partial and
+    k1_combine merged whatever the workspace held -- zero pages in a fresh process, NaN after an unlucky predecessor.  The workspace is
+    filled with NaN here, so the result depends on written partials only."""
+    ops, L = _ops()
+    B, D = 2, 128
+    S_max = ((kv_len + n + 127) // 128) * 128
+    g = torch.Generator().manual_seed(5)
+    kc = torch.randn(1, B, Hkv, S_max, D, generator=g).to(torch.float16)
+    vc = torch.randn(1, B, Hkv, S_max, D, generator=g).to(torch.float16)
+    q = torch.randn(B, n, H, D, generator=g).to(torch.float16)
+    k = torch.randn(B, n, Hkv, D, generator=g).to(torch.float16)
+    v = torch.randn(B, n, Hkv, D, generator=g).to(torch.float16)
+    ref = OracleWindowAttention()(0, q, k, v, _Cache(kc.clone(), vc.clone()), kv_len, ks).float()
+    attn = ops.HipWindowAttention(n_split=n_split)
+    dcache = _Cache(kc.clone().to(dev), vc.clone().to(dev))
+    attn._workspace(B, H, n, D, dev).fill_(float("nan"))
+    out = attn(0, q.to(dev), k.to(dev), v.to(dev), dcache, kv_len, ks).float().cpu()
+    assert torch.isfinite(out).all()
+    hidden = torch.tensor([[kv_len + i < ks[b] for i in range(n)] for b in range(B)])
+    assert (out[hidden] == 0).all()                       # rows with no visible key: defined (zero) output
+    assert (out[~hidden] - ref[~hidden]).abs().max() < 3e-2
+
+
 FP8_CASES = [
     # name, B, H, Hkv, D, S_max, kv_len, n, key_start, dtype, (k_scale, v_scale)
     ("fp8_mha_d128_mid", 2, 4, 4, 128, 1280, 1216, 16, [0, 59], torch.bfloat16, (1.0, 1.0)),

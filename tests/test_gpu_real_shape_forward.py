@@ -203,7 +203,12 @@ def test_window_forward_at_production_shapes_against_independent_forwards(family
     eng.hook = None
     wins = [r for r in recs if not r["first"] and r["n"] > 1]
     assert recs[0]["first"] and len(wins) >= 3 and any(r["graph"] for r in wins) and all(r["use_cfg"] for r in wins)
-    assert model.attn.n_split >= 4, "a 700-token prompt must put K1 into the multi-split regime"
+    # which K1 form these windows ran on: a multi-head window over <= 736 keys takes the column split (k1_dsplit, round 4) -- Lumina at P = 700 --
+    # everything else key splits + combine (k1_partial / the ring kernel) in the multi-split regime
+    if family == "lumina7b" and P == 700:
+        assert model.attn.regime == "colsplit"
+    else:
+        assert model.attn.regime == "keysplit" and model.attn.n_split >= 4, "a long prompt must put K1 into the multi-split regime"
     assert min(r["kv_len"] for r in wins) >= P
     ks, po = spec.key_start.to(dev), spec.pos_offset.to(dev)
     outs = {}
@@ -225,7 +230,7 @@ def test_window_forward_at_production_shapes_against_independent_forwards(family
         outs[tag] = res
         del f
         torch.cuda.empty_cache()
-    rep = dict(family=tag_name, dtype=str(dt), prompt_len=P, window=window, n_split=int(model.attn.n_split), iterations=[])
+    rep = dict(family=tag_name, dtype=str(dt), prompt_len=P, window=window, k1_regime=model.attn.regime, n_split=int(model.attn.n_split or 0), iterations=[])
     worst = dict(hip_max=0.0, aten_max=0.0, hip_mean=[], aten_mean=[])
     for i, r in enumerate(recs):
         rows = [0] if r["first"] else r["live"]

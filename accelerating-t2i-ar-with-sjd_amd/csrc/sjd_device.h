@@ -89,6 +89,20 @@ __device__ __forceinline__ float block_max(float v, SjdShared &sh)
     return r;
 }
 
+// max and count in ONE exchange (two barriers instead of four): the same values block_max / block_sum_int return
+__device__ __forceinline__ float block_max_and_count(float v, int n, SjdShared &sh, int &n_total)
+{
+    for (int off = 32; off >= 1; off >>= 1) { v = fmaxf(v, __shfl_xor(v, off)); n += __shfl_xor(n, off); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh.wave_f[threadIdx.x >> 6] = v; sh.wave_i[threadIdx.x >> 6] = n; }
+    __syncthreads();
+    float r = sh.wave_f[0];
+    int t = sh.wave_i[0];
+    for (int w = 1; w < SJD_WAVES; ++w) { r = fmaxf(r, sh.wave_f[w]); t += sh.wave_i[w]; }
+    n_total = t;
+    return r;
+}
+
 __device__ __forceinline__ int block_sum_int(int v, SjdShared &sh)
 {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -131,6 +145,24 @@ __device__ __forceinline__ int block_argmax(unsigned long long best, SjdShared &
     __syncthreads();
     unsigned long long r = sh.wave_u64[0];
     for (int w = 1; w < SJD_WAVES; ++w) r = sh.wave_u64[w] > r ? sh.wave_u64[w] : r;
+    return 0x7fffffff - (int)(unsigned)(r & 0xffffffffu);
+}
+
+// two argmaxes in ONE exchange (the second candidates travel through the head of sh.hist, which no selection uses at that point)
+__device__ __forceinline__ int block_argmax2(unsigned long long best, unsigned long long best2, SjdShared &sh, int &idx2)
+{
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long o = __shfl_xor(best, off), o2 = __shfl_xor(best2, off);
+        best = o > best ? o : best;
+        best2 = o2 > best2 ? o2 : best2;
+    }
+    unsigned long long *second = reinterpret_cast<unsigned long long *>(sh.hist);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh.wave_u64[threadIdx.x >> 6] = best; second[threadIdx.x >> 6] = best2; }
+    __syncthreads();
+    unsigned long long r = sh.wave_u64[0], r2 = second[0];
+    for (int w = 1; w < SJD_WAVES; ++w) { r = sh.wave_u64[w] > r ? sh.wave_u64[w] : r; r2 = second[w] > r2 ? second[w] : r2; }
+    idx2 = 0x7fffffff - (int)(unsigned)(r2 & 0xffffffffu);
     return 0x7fffffff - (int)(unsigned)(r & 0xffffffffu);
 }
 
@@ -376,6 +408,21 @@ __device__ __forceinline__ void wave_push(bool keep, int col, float v, unsigned 
     if (keep && pos < cap) list[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)col;
 }
 
+// the same list filled with ONE reservation per wave: every lane announces how many entries it will append, the wave's total is reserved with a
+// single atomicAdd and each lane gets its first position (in-kernel stamps, round 4: one ballot + atomicAdd + broadcast per column slot was 8 -- Emu3:
+// 32 -- dependent LDS round trips per wave, 128 -- 512 -- adds on one LDS word per row: 6.6 of K2's 31 us at Lumina's shape).  All 64 lanes call.
+__device__ __forceinline__ int wave_reserve(int n_mine, int *count)
+{
+    const int lane = threadIdx.x & 63;
+    int incl = n_mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    int base = 0;
+    if (lane == 63) base = atomicAdd(count, incl);
+    base = __shfl(base, 63);
+    return base + incl - n_mine;
+}
+
 // ---- exact k-th largest: a VALUE histogram first, the radix select over the survivors (round 4) ------------------------------
 // The radix select funnels every score of a row through atomicAdd on the bins of its top 11 key bits (sign, exponent, two mantissa bits) --
 // and the scores of one softmax row share their exponent: 8192 .. 32768 adds land on a dozen LDS words and serialise (in-kernel stamps,
@@ -396,7 +443,37 @@ __device__ __forceinline__ float block_kth_largest_spread(Visit &&visit, int k, 
     __syncthreads();
     visit([&](float z) { if (z > -INFINITY) atomicAdd(&sh.hist[bin_of(z)], 1u); });
     int bsel, krem;
+    if (threadIdx.x == 0) sh.misc[2] = 0;          // (survivor count; the barriers of radix_pick lie between this and its first use)
     radix_pick(k, sh, bsel, krem);
+    // The selected bin's scores (a handful .. a few hundred): their keys go to a list over the histogram's words (radix_pick has finished with
+    // them) and every survivor ranks itself against the others -- the krem-th largest is the key with fewer than krem keys above it and at least
+    // krem keys at or above it.  One barrier pair instead of the three radix passes' eighteen (in-kernel stamps, round 4: the select was 7.9 of
+    // K2's 31 us at Lumina's shape, nearly all of it barriers).  More survivors than the rank loop is worth: the radix passes, as before.
+    constexpr int RANK_CAP = 256;
+    {
+        unsigned *keys = sh.hist;
+        visit([&](float z) {
+            if (z > -INFINITY && bin_of(z) == bsel) {
+                const int pos = atomicAdd(&sh.misc[2], 1);
+                if (pos < RANK_CAP) keys[pos] = f2key(z);
+            }
+        });
+        __syncthreads();
+        const int n = sh.misc[2];
+        if (n <= RANK_CAP) {
+            for (int i = threadIdx.x; i < n; i += SJD_TPB) {
+                const unsigned ki = keys[i];
+                int gt = 0, ge = 0;
+                for (int j = 0; j < n; ++j) { const unsigned kj = keys[j]; gt += kj > ki ? 1 : 0; ge += kj >= ki ? 1 : 0; }
+                if (gt < krem && krem <= ge) sh.misc[3] = (int)ki;      // (equal keys all write the same word)
+            }
+            __syncthreads();
+            const unsigned kk = (unsigned)sh.misc[3];
+            __syncthreads();                       // (the histogram's words and misc[3] are free again)
+            return key2f(kk);
+        }
+        __syncthreads();
+    }
     unsigned prefix = 0;
     const int shifts[3] = {21, 10, 0};
     const unsigned masks[3] = {0x7ffu, 0x7ffu, 0x3ffu};

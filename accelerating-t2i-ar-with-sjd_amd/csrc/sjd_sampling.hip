@@ -12,11 +12,11 @@
 
 // phase timestamps of K2 / K4 (tools/phase_trace.py, -DSJD_TRACE; compiled out otherwise): slot = row (K2) / 32 (K4)
 #ifdef SJD_TRACE
-__device__ unsigned long long g_k2_trace[64][8];
+__device__ unsigned long long g_k2_trace[64][16];
 #define SJD_TRS(slot, i) do { if (threadIdx.x == 0) g_k2_trace[(slot) & 63][i] = wall_clock64(); } while (0)
 extern "C" int sjd_debug_trace_k2(unsigned long long *host_out, int n)
 {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k2_trace), (size_t)n * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k2_trace), (size_t)n * 16 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #else
 #define SJD_TRS(slot, i) do { } while (0)
@@ -77,6 +77,26 @@ __device__ __forceinline__ float k2_row_scale(const sjd_head_partials &hp, int t
     return rsqrtf(t * hp.inv_hidden + hp.eps);
 }
 
+// the scales of the cond row `tok` and of the uncond row hp.urow_off + tok (1 without one): both rows' statistics in flight together
+__device__ __forceinline__ void k2_row_scales(const sjd_head_partials &hp, int tok, float &rc, float &ru)
+{
+    if (!hp.row_sumsq) return;
+    const bool two = hp.urow_off > 0;
+    float t = 0.f, tu = 0.f;
+    for (int s0 = 0; s0 < hp.slices; s0 += 8) {          // the fixed order of row_sumsq_total (sjd_glue.hip)
+        float v[8], w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v[q] = (s0 + q < hp.slices) ? hp.row_sumsq[(size_t)(s0 + q) * hp.prows + tok] : 0.f;
+            w[q] = (two && s0 + q < hp.slices) ? hp.row_sumsq[(size_t)(s0 + q) * hp.prows + hp.urow_off + tok] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { t += v[q]; tu += w[q]; }
+    }
+    rc = rsqrtf(t * hp.inv_hidden + hp.eps);
+    if (two) ru = rsqrtf(tu * hp.inv_hidden + hp.eps);
+}
+
 #define K2_NI 3               // column groups (of 4 x 1024) a thread keeps in registers: windows of up to 12288 columns (9 groups = Emu3's 32768-column rows no longer fit the 128 VGPRs of a 1024-thread workgroup: spills)
 template <bool PART>
 __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
@@ -88,20 +108,53 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     extern __shared__ __attribute__((aligned(16))) float sjd_dyn_lds[];      // round 4: the staged scores of a row too wide for registers
     const int row = blockIdx.x;
     SJD_TRS(row, 0);
-    if (row >= params->n_rows) return;
+    // Round 4: everything the row needs before its first sum is requested in ONE round trip -- the row count, the rule, the folded norm's row
+    // statistics of both batch rows -- and only then looked at (row < gridDim.x <= SJD_MAX_WINDOW: the rule's slot exists whatever n_rows is).
+    // By its phase stamps the kernel used to make five dependent trips to cold memory before the first add: n_rows, the rule, the statistics
+    // of the cond row, of the uncond row, the partial planes.
+    asm volatile("" :: "s"(hp.zero_state), "s"(hp.row_sumsq), "s"(params));     // (these kernel arguments are wanted by the first batch: fetch them first)
+    float sv[8], sw[8];
+    const bool stats8 = PART && hp.row_sumsq && hp.slices <= 8;          // (hidden sizes up to 4096: one batch of scalar loads, no branch around any)
+    {   // (unconditional loads from a valid address either way: a branch here would end the basic block and with it the overlap)
+        const float *ss = stats8 ? hp.row_sumsq : reinterpret_cast<const float *>(params);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const size_t off = stats8 ? (size_t)min(q, hp.slices - 1) * hp.prows + row : 0;
+            sv[q] = ss[off];
+            sw[q] = ss[off + ((stats8 && hp.urow_off > 0) ? hp.urow_off : 0)];
+        }
+    }
+    const int n_rows_dev = params->n_rows, use_cfg_dev = params->use_cfg;
+    const uint32_t ph_blocks = (uint32_t)params->philox_blocks;
+    const uint64_t ph_seed = params->philox_seed, ph_off = params->philox_offset[0];
+    // what this row of probs_out is known to hold: zeros outside [zlo, zhi) (zlo < 0: unknown) -- see sjd_head_partials::zero_state
+    int *zst = (PART && hp.zero_state) ? hp.zero_state + 2 * (row < SJD_MAX_WINDOW ? row : 0) : nullptr;
+    const int *zp = zst ? zst : reinterpret_cast<const int *>(params);        // (unconditional loads, as above)
+    const int zl = zp[0], zh = zp[1];
+    const sjd_row_rule rule = params->rules[row < SJD_MAX_WINDOW ? row : 0];
+    float rc = 1.0f, ru = 1.0f;
+    // (the compiler sinks the rule's loads below the early return otherwise: a trip of their own; these empty statements need the values HERE,
+    //  where the wait for n_rows stands anyway)
+    asm volatile("" :: "s"(zl), "s"(zh), "s"(use_cfg_dev), "s"(ph_blocks), "s"(ph_seed), "s"(ph_off), "s"(n_rows_dev),
+                 "s"(rule.n_ranges), "s"(rule.forced), "s"(rule.temperature), "s"(sv[0]), "s"(sv[1]), "s"(sv[2]), "s"(sv[3]), "s"(sv[4]),
+                 "s"(sv[5]), "s"(sv[6]), "s"(sv[7]), "s"(sw[0]), "s"(sw[1]), "s"(sw[2]), "s"(sw[3]), "s"(sw[4]), "s"(sw[5]), "s"(sw[6]), "s"(sw[7]));
+    if (row >= n_rows_dev) return;
+    SJD_TRS(row, 1);              // first batch (row count, rule, statistics, zero state) arrived
+    const int zlo = zst ? zl : -1, zhi = zst ? zh : -1;
+    if (stats8) {
+        float t = 0.f, tu = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { t += (q < hp.slices) ? sv[q] : 0.f; tu += (q < hp.slices) ? sw[q] : 0.f; }      // row_sumsq_total's order
+        rc = rsqrtf(t * hp.inv_hidden + hp.eps);
+        if (hp.urow_off > 0) ru = rsqrtf(tu * hp.inv_hidden + hp.eps);
+    } else if (PART) k2_row_scales(hp, row, rc, ru);
     if (threadIdx.x == 0) sh.misc[1] = 0;         // entries of the draw list (the first barrier lies far ahead of its first use)
-    const sjd_row_rule rule = params->rules[row];
     float *p = probs_out + (size_t)row * V;
     const float *e = noise + (size_t)row * V;
     // the Exp(1) noise of the draw: read from `noise`, or (params->philox_blocks > 0) generated here -- the elements torch's
     // empty(n_rows, V).exponential_(generator=g) would hold, for the columns that carry probability mass only (sjd_philox.h)
-    const uint32_t ph_blocks = (uint32_t)params->philox_blocks;
-    const uint64_t ph_seed = params->philox_seed, ph_off = params->philox_offset[0];
-    const uint32_t ph_T = ph_blocks ? sjd_philox_threads((uint64_t)params->n_rows * (uint64_t)V, ph_blocks) : 0u;
+    const uint32_t ph_T = ph_blocks ? sjd_philox_threads((uint64_t)n_rows_dev * (uint64_t)V, ph_blocks) : 0u;
 
-    // what this row of probs_out is known to hold: zeros outside [zlo, zhi) (zlo < 0: unknown) -- see sjd_head_partials::zero_state
-    int *zst = (PART && hp.zero_state) ? hp.zero_state + 2 * row : nullptr;
-    const int zlo = zst ? zst[0] : -1, zhi = zst ? zst[1] : -1;
     if (rule.forced >= 0) {   // forced EOL / end-of-image row: softmax of (-inf,...,0,...,-inf) (LP:39-41)
         // (with a known state only the hull of the old window and the forced column needs rewriting)
         const int flo = zlo >= 0 ? min(zlo, rule.forced) : 0, fhi = zlo >= 0 ? max(zhi, rule.forced + 1) : V;
@@ -117,22 +170,20 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     }
 
     const float *c, *u;
-    float rc = 1.0f, ru = 1.0f;
     if (PART) {                 // virtual column 0 of this row's first chunk; only columns [col0, col0 + n_cols) exist
         row_stride = hp.row_stride;
         c = hp.part + (size_t)row * row_stride - hp.col0;
-        u = (hp.urow_off > 0 && params->use_cfg) ? hp.part + (size_t)(hp.urow_off + row) * row_stride - hp.col0 : nullptr;
-        rc = k2_row_scale(hp, row);
-        if (u) ru = k2_row_scale(hp, hp.urow_off + row);
+        u = (hp.urow_off > 0 && use_cfg_dev) ? hp.part + (size_t)(hp.urow_off + row) * row_stride - hp.col0 : nullptr;
     } else {
         c = logits_c + (size_t)row * row_stride;
-        u = (logits_u != nullptr && params->use_cfg) ? logits_u + (size_t)row * row_stride : nullptr;
+        u = (logits_u != nullptr && use_cfg_dev) ? logits_u + (size_t)row * row_stride : nullptr;
     }
     const bool vec = ((V & 3) == 0) && ((row_stride & 3) == 0) && (!PART || (hp.col0 & 3) == 0);
     // Only the window [wlo, whi) spanned by the rule's allowed ranges can hold probability mass (Lumina image rows: 8192 of
     // 65536 columns); everything outside is written as 0 once and never read again.
     int wlo, whi;
     rule_window(rule, V, wlo, whi);
+    const int c0_first = 4 * sjd_first_owned_group(wlo);
     const bool clean_outside = zlo >= 0 && zlo >= wlo && zhi <= whi;      // the recorded window lies inside this one: outside is zero already
     if (!clean_outside && (wlo > 0 || whi < V)) {
         const bool v4 = (V & 3) == 0;              // (rows of probs_out are then 16-byte aligned)
@@ -149,7 +200,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const bool in_lds = (whi - (wlo & ~3)) <= lds_floats;
     float *stg = in_lds ? sjd_dyn_lds : p;          // column `col` lives at stg[col - sb] (no pointer is ever moved below the LDS base)
     const int sb = in_lds ? (wlo & ~3) : 0;
-    SJD_TRS(row, 1);              // outside of the window zeroed
+    SJD_TRS(row, 2);              // outside of the window zeroed
     // pass 1: CFG combine (JL:104) + grammar mask (LP:125-129); stage z; row max; finite count
     // Round 3: when the rule's window is at most K2_NI column groups per thread (Lumina's image rows: 3, Emu3's: 9) the staged scores are
     // taken back into REGISTERS once, behind this pass, and stay there to the final probabilities -- the radix select, the exponentials and
@@ -227,7 +278,6 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
         }
     }
     // the thread's own staged scores come back into registers in ONE round trip (all groups requested together) and stay there
-    const int c0_first = 4 * sjd_first_owned_group(wlo);
     const bool fits = (whi - (wlo & ~3) + 4 * SJD_TPB - 1) / (4 * SJD_TPB) <= K2_NI;       // (the same for every thread of the block)
     float zr[K2_NI][4];
     if (fits) {
@@ -243,10 +293,10 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
             }
         }
     }
-    const float zmax = block_max(tmax, sh);
-    const int n_finite = block_sum_int(cnt, sh);
-    __syncthreads();   // staged z visible to the whole block (global memory, same CU)
-    SJD_TRS(row, 2);              // logits staged, max known
+    SJD_TRS(row, 3);              // planes summed, scores staged
+    int n_finite;
+    const float zmax = block_max_and_count(tmax, cnt, sh, n_finite);       // (its barriers also make the staged z visible to the whole block)
+    SJD_TRS(row, 4);              // logits staged, max known
 
     // top-k (LP:196-204): keep z >= k-th largest; k-th is -inf when fewer than k finite entries exist
     float kth = -INFINITY;
@@ -270,7 +320,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
             }, rule.top_k, zmax, sh);
     }
 
-    SJD_TRS(row, 3);              // top-k threshold known
+    SJD_TRS(row, 5);              // top-k threshold known
     // pass A: e = exp(z - max) for kept entries, canonical sum.  TemperatureLogitsWarper (rule.temperature != 1): the kept scores are
     // divided by T first -- after the grammar mask and its top-k, before top-p and the softmax, where HF's generate() places the warper;
     // max(z / T) == max(z) / T because the division is monotone
@@ -330,7 +380,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
         }
     }
 
-    SJD_TRS(row, 4);              // sum known
+    SJD_TRS(row, 6);              // sum known
     // pass B: p = e / S ; multinomial == lowest-index argmax of p / Exp(1)   (JL:111-118)
     unsigned long long best = 0ull, best_p = 0ull;
     // in-kernel noise: the entries with mass are compacted into an LDS list (behind the staged row) and drawn densely below (wave_push)
@@ -343,19 +393,60 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
         p[col] = pv;
         unsigned long long cand = pack_vi(pv, col);
         best_p = cand > best_p ? cand : best_p;
-        if (compact) {
-            const bool keep = pv > 0.0f;
-            if (!keep) { cand = pack_vi(0.0f, col); best = cand > best ? cand : best; }       // (r = 0 for an entry without mass, as before)
-            wave_push(keep, col, pv, klist, list_cap, &sh.misc[1]);
-            return;
-        }
         float r;
         if (ph_blocks) r = pv > 0.0f ? pv / sjd_philox_exponential(ph_seed, ph_off, ph_T, (uint64_t)row * (uint64_t)V + (uint64_t)col) : 0.0f;   // (0 / e == 0: e is finite and > 0)
         else r = pv / e[col];
         cand = pack_vi(r, col);
         best = cand > best ? cand : best;
     };
-    if (fits) {
+    if (compact) {
+        // the list is filled with one reservation per wave (wave_reserve): a first walk stores the probabilities and counts the thread's entries
+        // with mass, a second appends them from the thread's first position on
+        int n_mine = 0;
+        auto first = [&](int col, float w) -> float {
+            const float pv = w / S;
+            p[col] = pv;
+            unsigned long long cand = pack_vi(pv, col);
+            best_p = cand > best_p ? cand : best_p;
+            if (pv > 0.0f) ++n_mine;
+            else { cand = pack_vi(0.0f, col); best = cand > best ? cand : best; }       // (r = 0 for an entry without mass, as before)
+            return pv;
+        };
+        if (fits) {
+#pragma unroll
+            for (int i = 0; i < K2_NI; ++i) {
+                const int c0 = c0_first + i * 4 * SJD_TPB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = c0 + j;
+                    zr[i][j] = (c0 < whi && col >= wlo && col < whi) ? first(col, zr[i][j]) : 0.0f;
+                }
+            }
+        } else {
+            SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (col >= wlo && col < whi) stg[col - sb] = first(col, stg[col - sb]); }
+            }
+        }
+        int pos = wave_reserve(n_mine, &sh.misc[1]);
+        auto second = [&](int col, float pv) {
+            if (pv > 0.0f) {
+                if (pos < list_cap) klist[pos] = ((unsigned long long)__float_as_uint(pv) << 32) | (unsigned)col;
+                ++pos;
+            }
+        };
+        if (fits) {
+#pragma unroll
+            for (int i = 0; i < K2_NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) second(c0_first + i * 4 * SJD_TPB + j, zr[i][j]);
+        } else {
+            SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (col >= wlo && col < whi) second(col, stg[col - sb]); }
+            }
+        }
+    } else if (fits) {
 #pragma unroll
         for (int i = 0; i < K2_NI; ++i) {
             const int c0 = c0_first + i * 4 * SJD_TPB;
@@ -368,6 +459,7 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
             for (int j = 0; j < 4; ++j) { const int col = c0 + j; if (col >= wlo && col < whi) draw(col, stg[col - sb]); }
         }
     }
+    SJD_TRS(row, 7);              // probabilities stored, draw list filled
     if (compact) {
         __syncthreads();
         const int n_kept = sh.misc[1];
@@ -395,15 +487,15 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
             }
         }
     }
-    SJD_TRS(row, 5);              // probabilities written
-    const int tok = block_argmax(best, sh);
-    if (threadIdx.x == 0) tokens_out[row] = tok;
-    if (zst && threadIdx.x == 0) { zst[0] = wlo; zst[1] = whi; }          // (every read of the old state lies behind several barriers)
-    if (amax_out) {                                  // by-product: the row's mode (lowest index among equal maxima)
-        const int am = block_argmax(best_p, sh);
-        if (threadIdx.x == 0) amax_out[row] = am;
+    SJD_TRS(row, 8);              // probabilities written
+    int am;                                          // by-product: the row's mode (lowest index among equal maxima)
+    const int tok = block_argmax2(best, best_p, sh, am);
+    if (threadIdx.x == 0) {
+        tokens_out[row] = tok;
+        if (amax_out) amax_out[row] = am;
+        if (zst) { zst[0] = wlo; zst[1] = whi; }    // (every read of the old state lies behind several barriers)
     }
-    SJD_TRS(row, 6);
+    SJD_TRS(row, 9);
 }
 
 // ------------------------------------------------------------------------------------------------ K4
@@ -576,18 +668,40 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                     if (threadIdx.x == 0) sh.misc[1] = 0;
                     __syncthreads();
                 }
+                if (compact) {                      // one reservation per wave (wave_reserve): count the thread's entries with mass, then append them
+                    int n_mine = 0;
+                    SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int col = c0 + j;
+                            if (col >= wlo && col < whi) {
+                                const float dv = scratch[col - sb] / S;
+                                if (dv > 0.0f) ++n_mine;
+                                else { const unsigned long long cand = pack_vi(dv, col); best = cand > best ? cand : best; }           // (0 or NaN, as before)
+                            }
+                        }
+                    }
+                    int pos = wave_reserve(n_mine, &sh.misc[1]);
+                    SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int col = c0 + j;
+                            if (col >= wlo && col < whi) {
+                                const float dv = scratch[col - sb] / S;
+                                if (dv > 0.0f) {
+                                    if (pos < list_cap) klist[pos] = ((unsigned long long)__float_as_uint(dv) << 32) | (unsigned)col;
+                                    ++pos;
+                                }
+                            }
+                        }
+                    }
+                } else
                 SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         int col = c0 + j;
                         if (col >= wlo && col < whi) {
                             const float dv = scratch[col - sb] / S;
-                            if (compact) {
-                                const bool keep = dv > 0.0f;
-                                if (!keep) { const unsigned long long cand = pack_vi(dv, col); best = cand > best ? cand : best; }     // (0 or NaN, as before)
-                                wave_push(keep, col, dv, klist, list_cap, &sh.misc[1]);
-                                continue;
-                            }
                             float r;
                             if (ph_blocks) r = dv > 0.0f ? dv / sjd_philox_exponential(ph_seed, ph_off2, ph_T2, (uint64_t)col) : dv;    // (dv is 0 or NaN here)
                             else r = dv / noise2[col];

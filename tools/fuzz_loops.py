@@ -15,13 +15,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=24)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--poison", action="store_true", help="fill the allocator's free pool with 0xFF (NaN / -1) before every case: "
+                    "a kernel that reads workspace nobody wrote then fails in every order (tests/conftest.py::poison_device_memory)")
     a = ap.parse_args()
     from tests import gpu_loop_check as G
+    from tests.conftest import poison_device_memory
     rnd = random.Random(a.seed)
     ok = 0
     for i in range(a.n):
         kind = rnd.choice(["llamagen", "lumina", "lumina", "emu3", "anole", "anole_api", "batch", "batch"])
         seed = rnd.randrange(1, 10000)
+        if a.poison:
+            poison_device_memory(total_gib=12)
         try:
             if kind == "llamagen":
                 kw = dict(seed=seed, window=rnd.choice([4, 8, 16, 32, 64]), scheme=rnd.choice(["speculative_jacobi", "jacobi"]),

@@ -280,10 +280,11 @@ def trace_in_situ(lib, torch, ops, np, kv_target=1216):
     assert lib.sjd_debug_trace_k1c(b.ctypes.data, 64) == 0
     table("k1_combine (layer 31, in situ)", b, 3, ["partials_arrive", "normalise_store"])
     lib.sjd_debug_trace_k2.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    b = np.zeros((16, 8), dtype=np.uint64)
+    b = np.zeros((16, 16), dtype=np.uint64)
     assert lib.sjd_debug_trace_k2(b.ctypes.data, 16) == 0
-    table("k2_logits_to_probs_sample (one workgroup per window row, last iteration), in situ", b, 7,
-          ["zero_outside_window", "head_partials_cfg_mask_max", "top_k_radix_select", "exp_and_sum", "normalise_and_draw", "argmax"])
+    table("k2_logits_to_probs_sample (one workgroup per window row, last iteration), in situ", b, 10,
+          ["first_batch_rule_stats_state", "zero_outside_window", "head_partials_cfg_mask_stage", "max_and_count", "top_k_select", "exp_and_sum",
+           "normalise_store_list", "dense_draw", "argmax_pair"])
     for kind, name, nwg in ((0, "f1r_residual_sumsq (last launch: after down of layer 31, 13 partial planes)", 256),
                             (1, "f2_qknorm_rope_append (layer 31)", 768), (2, "f3_silu_mul (layer 31)", 172)):
         b = np.zeros((nwg, 4), dtype=np.uint64)

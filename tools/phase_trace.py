@@ -292,6 +292,45 @@ def trace_in_situ(lib, torch, ops, np, kv_target=1216):
         table(name + ", in situ", b, 3, ["inputs_arrive", "compute_store"])
 
 
+def trace_k2_emu3(lib, torch, ops, np, P=600):
+    """K2's phase stamps at Emu3's shape (32 rows x 32768-column windows staged in LDS, top-k 2048), last iteration of a short decode"""
+    import sjd_amd.backbones as BB
+    import sjd_amd.synthetic as synthetic
+    from sjd_amd.engine import SJDEngine, SJDConfig
+    from sjd_amd.frontends import emu3_window_spec
+    from sjd_amd.grammar import Emu3Grammar
+    dev = torch.device("cuda:0")
+    margs, window = BB.EMU3_8B, 32
+    with torch.device(dev):
+        model = BB.ChameleonBackbone(margs, attn=ops.HipWindowAttention()).to(torch.bfloat16).eval()
+    model.G1_CFG = dict(model.G1_CFG_EMU3)
+    synthetic.fill_state_dict_device(model, seed=0, embed_token_scale=0.7)
+    model.enable_fused(ops, gemm="sjd")
+    tok = dict(img_token=151851, eoi_token=151853, eos_token=151850, eol_token=151846, eof_token=151847, pad_token=151643)
+    pos = synthetic.synthetic_prompt(P - 1, 17, lo=1000, hi=150000)[0].tolist() + [tok["img_token"]]
+    neg = synthetic.synthetic_prompt(11, 18, lo=1000, hi=150000)[0].tolist() + [tok["img_token"]]
+    spec = emu3_window_spec(pos, neg, tok["pad_token"], dev)
+    grammar = Emu3Grammar(90, 90, 151854, 32768, top_k=2048, **tok)
+    cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=90 * 90 - 1, max_num_new_tokens=window, guidance_scale=3.0,
+                    seed=17, max_length=P + 70, eos_token_ids=(tok["eos_token"],))
+    model.setup_cache(batch=2, s_max=1024)
+    eng = SJDEngine(model, margs.vocab_size, dev, max_window=window, use_graph=True)
+    seq, stats = eng.decode(spec.first_tokens[0].tolist(), spec, grammar, cfg)
+    torch.cuda.synchronize()
+    lib.sjd_debug_trace_k2.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    b = np.zeros((32, 16), dtype=np.uint64)
+    assert lib.sjd_debug_trace_k2(b.ctypes.data, 32) == 0
+    t = b[:, :10].astype(np.int64)
+    t = t[(t[:, 0] > 0) & np.all(np.diff(t, axis=1) >= 0, axis=1)]
+    t = t[t[:, 0] >= t[:, 0].max() - 2000]
+    labels = ["first_batch_rule_stats_state", "zero_outside_window", "head_partials_cfg_mask_stage", "max_and_count", "top_k_select", "exp_and_sum",
+              "normalise_store_list", "dense_draw", "argmax_pair"]
+    t0 = t[:, 0].min()
+    print(json.dumps(dict(kernel="k2_logits_to_probs_sample at Emu3's shape, in situ (rows that ran every phase; forced rows return early)", workgroups=int(len(t)),
+                          phase_us={labels[i]: us((t[:, i + 1] - t[:, i]).mean()) for i in range(9)},
+                          end_us=dict(mean=us((t[:, 9] - t0).mean()), max=us((t[:, 9] - t0).max())))), flush=True)
+
+
 def main():
     if os.environ.get("SJD_HIP_LIB") != TRACE_SO:
         build()
@@ -307,6 +346,8 @@ def main():
         PER_WG = open(sys.argv[sys.argv.index("--per-wg") + 1], "w")
         trace_g1(lib, torch, ops, np)
         return
+    if "--k2-emu3" in sys.argv:
+        return trace_k2_emu3(lib, torch, ops, np)
     if "--k1s" in sys.argv:          # the shared-tile K1 shapes only (round 4: the LDS-DMA ring kernel; SJD_K1_RING=0 the round-3 kernel)
         trace_k1_shared(lib, torch, ops, np)
         return

@@ -391,6 +391,9 @@ class ChameleonBackbone(nn.Module):
     G1_CFG_128ROW = dict(qkv=(2048, 4, True), o=(896, 4, True), gate_up=(2048, 8, True), down=(1376, 4, True))
     # Emu3-Gen 8B (GQA 32/8: the q|k|v projection has 6144 columns; draft window 32 -> 64 rows), tuned end to end with bench.py --model emu3_8b
     G1_CFG_EMU3 = dict(qkv=(512, 8, False), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))        # profiles/r2_g1_launch_shape_sweep_emu3_64rows.jsonl
+    # the same on the 12-bit stream (Emu3 in bf16, round 4): 256-workgroup launches for q|k|v and o, step-major packing -- 11.75 / 10.25 / 19.85 us
+    # against 12.15 / 10.66 / 20.19 (tools/g1z_bench.py --sweep --emu3 --rows 64, profiles/r4_g1z_sweep_emu3_64rows.jsonl)
+    G1_CFG_EMU3_Z = dict(qkv=(512, 6, True), o=(512, 4, True), gate_up=(2048, 8, True), down=(896, 8, True))
 
     # Weight prefetch plan of the G1 window forward: projection -> (workgroups of the prefetch kernel, when it is issued).  The packed
     # weights of projection j+1 are read into the Infinity Cache on a side stream (a parallel branch of the forward hipGraph)
@@ -456,6 +459,8 @@ class ChameleonBackbone(nn.Module):
                 self.G1_CFG = dict(self.G1_CFG_EMU3)
             elif self.compress and self.lm_head.weight.dtype == torch.bfloat16:
                 self.G1_CFG = dict(self.G1_CFG_Z)
+        if self.compress and self.lm_head.weight.dtype == torch.bfloat16 and self.G1_CFG == self.G1_CFG_EMU3:
+            self.G1_CFG = dict(self.G1_CFG_EMU3_Z)          # (also when the caller named the architecture's set: the packing below follows it)
         if "HEAD_CFG" not in self.__dict__ and self.vocab_size >= 131072:
             self.HEAD_CFG = self.HEAD_CFG_WIDE
         self.compress_stats = dict(matrices=0, compressed=0, bytes_raw=0, bytes_packed=0, exceptions=0)

@@ -5,6 +5,7 @@
 // (L2-resident between passes); all cross-lane reductions use wave64 shuffles + a 16-entry LDS exchange.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 
 #include "../../include/sjd_hip.h"
 #include "sjd_device.h"
@@ -198,8 +199,14 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     // LDS (round 4: Emu3's 32768-column rows -- every pass used to re-read them from `p` through L2, a dependent round trip per column
     // group and pass), else `p` itself (text rows over a whole vocabulary).  `stg[col - sb]` addresses either.
     const bool in_lds = (whi - (wlo & ~3)) <= lds_floats;
-    float *stg = in_lds ? sjd_dyn_lds : p;          // column `col` lives at stg[col - sb] (no pointer is ever moved below the LDS base)
-    const int sb = in_lds ? (wlo & ~3) : 0;
+    // The passes are instantiated twice, for a row staged in LDS and for one staged in `p`: with ONE pointer that may be either, every staged access
+    // was a FLAT instruction (104 flat_load_dword + 28 flat_store_dword in this kernel's ISA, round 4) -- single dwords through the address-space check
+    // instead of ds_read / ds_write.
+    auto passes = [&](auto lds_tag) {
+    constexpr bool STG_LDS = decltype(lds_tag)::value;
+    float *stg;                                     // column `col` lives at stg[col - sb] (no pointer is ever moved below the LDS base)
+    if constexpr (STG_LDS) stg = sjd_dyn_lds; else stg = p;
+    const int sb = STG_LDS ? (wlo & ~3) : 0;
     SJD_TRS(row, 2);              // outside of the window zeroed
     // pass 1: CFG combine (JL:104) + grammar mask (LP:125-129); stage z; row max; finite count
     // Round 3: when the rule's window is at most K2_NI column groups per thread (Lumina's image rows: 3, Emu3's: 9) the staged scores are
@@ -496,6 +503,8 @@ __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
         if (zst) { zst[0] = wlo; zst[1] = whi; }    // (every read of the old state lies behind several barriers)
     }
     SJD_TRS(row, 9);
+    };
+    if (in_lds) passes(std::true_type{}); else passes(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------ K4
@@ -526,7 +535,7 @@ __device__ __forceinline__ void k4_mirror_state(const sjd_state *state, sjd_stat
 __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
     const sjd_iter_params *__restrict__ params, sjd_state *__restrict__ state, const float *__restrict__ probs,
     const float *__restrict__ prev_probs, const float *__restrict__ rs, const float *__restrict__ noise2,
-    float *__restrict__ scratch, int V, sjd_state *__restrict__ host_mirror, int lds_floats)
+    float *__restrict__ scratch_global, int V, sjd_state *__restrict__ host_mirror, int lds_floats)
 {
     __shared__ SjdShared sh;
     extern __shared__ __attribute__((aligned(16))) float sjd_dyn_lds[];      // round 4: the residual row, when its window fits (else `scratch`)
@@ -588,8 +597,13 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
             rule_window(rule, V, wlo, whi);
             // the residual weights d are staged in the workgroup's LDS when the rule's window fits (image rows: 8192 .. 32768 columns) -- the
             // five passes below were five trips through L2 per column group (74 us at Emu3's shape, one workgroup) -- else in `scratch`
-            int sb = 0;                      // column `col` of the staged row lives at scratch[col - sb]
-            if ((whi - (wlo & ~3)) <= lds_floats) { scratch = sjd_dyn_lds; sb = wlo & ~3; }
+            // (instantiated twice -- staged in LDS / in `scratch` -- so that the staged accesses are ds_ / global_ instructions, not FLAT ones: see K2)
+            const bool res_lds = (whi - (wlo & ~3)) <= lds_floats;
+            auto resample = [&](auto lds_tag) {
+            constexpr bool STG_LDS = decltype(lds_tag)::value;
+            float *scratch;                  // column `col` of the staged row lives at scratch[col - sb]
+            if constexpr (STG_LDS) scratch = sjd_dyn_lds; else scratch = scratch_global;
+            const int sb = STG_LDS ? (wlo & ~3) : 0;
             int cnt = 0;
             SJD_FOR_OWNED_COLS_IN(wlo, whi, c0) {
 #pragma unroll
@@ -660,7 +674,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                 degenerate = !(S > 0.0f);         // 0/0 below: flagged to the host (state->rejected = 2), never a silent arbitrary id
                 unsigned long long best = 0ull;
                 // in-kernel noise: the entries with mass go through a compacted LDS list (wave_push), the noise is evaluated densely
-                const int list_base = (scratch == sjd_dyn_lds) ? ((whi - sb + 3) & ~3) : 0;           // behind the staged row, if it is staged in LDS
+                const int list_base = STG_LDS ? ((whi - sb + 3) & ~3) : 0;           // behind the staged row, if it is staged in LDS
                 unsigned long long *klist = reinterpret_cast<unsigned long long *>(sjd_dyn_lds + list_base);
                 const int list_cap = (lds_floats - list_base) / 2;
                 const bool compact = ph_blocks != 0 && list_cap >= 64;
@@ -740,6 +754,8 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                 const int tok = block_argmax(best, sh);
                 if (threadIdx.x == 0) state->tokens[row] = tok;
             }
+            };
+            if (res_lds) resample(std::true_type{}); else resample(std::false_type{});
         }
     }
     if (threadIdx.x == 0) { state->m = m; state->rejected = rejected ? (degenerate ? 2 : 1) : 0; state->n_prev = n; }

@@ -434,7 +434,9 @@ def _z_weight(N, K, gen, dev, outliers):
     (64, 4096, 4096, 2048, 8, True), (128, 8224, 4096, 1024, 4, True), (70, 1024, 528, 128, 6, False),
     # Emu3-8B in bf16 (what the reference's test_emu3.py:27 runs): the 64-row launch shapes of G1_CFG_EMU3 -- q|k|v 6144 columns, o, down with
     # K 14336, gate|up 28672 columns as plain G1z
-    (64, 6144, 4096, 512, 8, False), (64, 4096, 14336, 896, 8, False), (64, 28672, 4096, 2048, 8, True)])
+    (64, 6144, 4096, 512, 8, False), (64, 4096, 14336, 896, 8, False), (64, 28672, 4096, 2048, 8, True),
+    # ... and of G1_CFG_EMU3_Z (round 4: the launch shapes the compressed stream runs at)
+    (64, 6144, 4096, 512, 6, True), (64, 4096, 4096, 512, 4, True), (64, 4096, 14336, 896, 8, True)])
 @pytest.mark.parametrize("outliers", [0, 300])
 def test_g1z_matches_g1_bit_for_bit(dev, M, N, K, KC, waves, step_major, outliers):
     """G1z (the projection over the 12-bit lossless weight stream) writes the SAME split-K planes as G1 over the uncompressed packing of the

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--rows", type=int, default=32)
     ap.add_argument("--only", default="")
     ap.add_argument("--check", action="store_true", help="compare the results bit for bit before timing")
+    ap.add_argument("--emu3", action="store_true", help="Emu3-8B projection shapes (q|k|v 6144 x 4096, o 4096 x 4096, down 4096 x 14336); use with --rows 64")
     ap.add_argument("--sweep", action="store_true", help="G1z only: grid over KC x waves x layout per shape (q|k|v, o, down), best five at the end")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -30,6 +31,8 @@ def main():
     import sjd_amd.backbones as BB
     cfg = BB.ChameleonBackbone.G1_CFG
     shapes = dict(qkv=(12288, 4096), o=(4096, 4096), gate_up=(22016, 4096), down=(4096, 11008))
+    if a.emu3:
+        shapes = dict(qkv=(6144, 4096), o=(4096, 4096), gate_up=(28672, 4096), down=(4096, 14336))
     if a.sweep:
         for name, (N, K) in shapes.items():
             if (a.only and name != a.only) or name == "gate_up":
@@ -43,6 +46,8 @@ def main():
                         continue
                     wzs = [ops.pack_weight_z(w, KC, sm) for w in ws]
                     for waves in (4, 6, 8, 12, 16):
+                        if a.rows > 32 and (waves > 8 and (a.rows > 64 or KC > 1280)):
+                            continue
                         avg, _ = timed_graph(lambda i: ops.skinny_gemm(x, wzs[i % a.copies], N, K, KC, waves, sm), a.launches, lib)
                         r = dict(shape=name, KC=KC, waves=waves, step_major=int(sm), workgroups=-(-(N // 32) // waves) * -(-K // KC), us=round(avg * 1e3, 2))
                         rows.append(r)

@@ -120,7 +120,7 @@ def main():
         esz = kc.element_size()
         rows0, rows1 = a.kv_len + n, a.kv_len + n - (a.prompt - 1)
         alg = 2 * Hkv * (rows0 + rows1) * D * esz + B * n * H * D * 2
-        print(json.dumps(dict(kernel="K1 per layer (hipGraph replay): one launch, the key splits merged by their last workgroup (shared-tile shapes: k1_partial_shared + k1_combine)", kv=("fp8" if a.fp8 else "bf16"), kv_len=a.kv_len, window=n,
+        print(json.dumps(dict(kernel="K1 per layer (hipGraph replay): the form the launcher picks for the shape -- k1_partial / k1_partial_ring + k1_combine, or the column split", kv=("fp8" if a.fp8 else "bf16"), kv_len=a.kv_len, window=n,
                               launches=reps * a.layers, avg_us=round(avg * 1e3, 2), algorithmic_bytes=alg,
                               gbps=round(alg / 1e9 / (avg / 1e3), 1), frac_of_8TBps=round(alg / 1e9 / (avg / 1e3) / 8000, 4))))
         return

@@ -136,8 +136,9 @@ def capture_graph(g):
     A collection that happens to start while the stream is capturing runs the destructors of whatever garbage the process has piled up -- an
     earlier engine's hipGraphs, events, pinned blobs -- and a runtime call from such a destructor (graph / event destruction, a pinned free)
     in the middle of a capture aborts the process (seen once in the full GPU suite, round 4: `Fatal Python error: Aborted ... Garbage-collecting`
-    under `_launch_window`).  Garbage is collected BEFORE the capture instead; other host threads may still use the GPU (thread-local capture mode)."""
-    gc.collect()
+    under `_launch_window`).  The collector is only HELD OFF: a `gc.collect()` in front of every capture cost 27 ms each -- 0.13 s of a 3.1 s image
+    (bench.py whole_image 3.05 -> 3.18 ms per step) -- and buys nothing, the garbage can wait.  Other host threads may still use the GPU
+    (thread-local capture mode)."""
     was_enabled = gc.isenabled()
     gc.disable()
     try:

@@ -56,7 +56,8 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu", "sjd_host_wait_u64",
            "sjd_philox_fill", "sjd_philox_offset_increment", "sjd_skinny_gemm_reduce", "sjd_reduce_timeouts",
            "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged", "sjd_skinny_gemm_z", "sjd_gateup_silu_z", "sjd_qkv_attention_fused_split",
-           "sjd_draft_window_attention_colsplit", "sjd_draft_window_attention_fp8_colsplit", "sjd_mlp_pair_z", "sjd_mlp_pair_timeouts"]
+           "sjd_draft_window_attention_colsplit", "sjd_draft_window_attention_fp8_colsplit", "sjd_mlp_pair_z", "sjd_mlp_pair_timeouts",
+           "sjd_head_combine"]
 
 _lib = None
 
@@ -111,6 +112,7 @@ def load():
     lib.sjd_weight_prefetch.argtypes = [vp, i64, i32, vp, vp]
     lib.sjd_skinny_gemm_cols.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_logits_to_probs_sample_part.argtypes = [ctypes.POINTER(HeadPartials), f32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.sjd_head_combine.argtypes = [ctypes.POINTER(HeadPartials), f32, i32, i32, vp, vp, vp]
     lib.sjd_logits_to_probs_sample_ex.argtypes = [vp, vp, i64, f32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.sjd_qkv_attention_fused.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),
                                             vp, vp, i32, vp]

@@ -771,7 +771,7 @@ __global__ __launch_bounds__(512) void k1_dsplit_ring(
     static_assert(D == 128 && DS == 4, "written for head_dim 128 split four ways");
     constexpr int NW = 8, KS = D / 32, DW = D / DS, DB = DW / 16;
     constexpr int ROWB = D * 2, KT_BYTES = K1_KT * ROWB, VT_BYTES = K1_KT * DW * 2, SLOT = KT_BYTES + VT_BYTES;      // 8192 + 2048
-    constexpr int NSLOT = 2 * NW;                                  // two rounds of eight tiles
+    (void)0;                                                        // (two rounds of eight tiles: 2 * NW slots)
     constexpr int PPT = KT_BYTES / 1024 + VT_BYTES / 1024;         // DMA pieces per tile (8 + 2)
     constexpr int PPW = PPT;                                       // pieces per wave and round (8 tiles x 10 pieces / 8 waves)
     extern __shared__ __attribute__((aligned(1024))) unsigned char k1r_lds[];      // NSLOT x SLOT = 160 KiB; merge buffers alias it at the end

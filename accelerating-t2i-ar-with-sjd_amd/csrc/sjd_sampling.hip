@@ -98,6 +98,65 @@ __device__ __forceinline__ void k2_row_scales(const sjd_head_partials &hp, int t
     if (two) ru = rsqrtf(tu * hp.inv_hidden + hp.eps);
 }
 
+// ------------------------------------------------------------------------------------------------ K2a (round 4)
+// The first thing K2 does with a row -- sum the head's split-K planes of the cond and the uncond row, apply the folded norm's row scale and the
+// 16-bit rounding of the lm_head output, combine with the guidance scale (JL:104) -- on the WHOLE chip instead of on the row's one CU: a row of
+// Emu3's 32768-column window is 524 KB of planes and eight dependent trips for them (33 of K2's 89 us by its phase stamps).  Here every thread
+// owns four columns of one row; the result z[row][col - col0] (fp32) is what K2 then reads as a head of ONE plane, no uncond row, no scale, no
+// rounding (the grammar mask stays in K2).  Same operations in the same order as K2's own pass 1: bit-identical scores.  Used when the head's
+// window is wide (ops.logits_to_probs_sample_part): Emu3 K2 89.9 -> 71.7 + 7.2 us.
+__global__ __launch_bounds__(256) void k2a_head_combine(const sjd_head_partials hp, float guidance, int V, const sjd_iter_params *__restrict__ params,
+                                                        float *__restrict__ zbuf)
+{
+    const int row = blockIdx.y;
+    const int c4 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;           // column offset inside the head's window (n_cols % 4 == 0)
+    if (c4 >= hp.n_cols) return;
+    const int n_rows_dev = params->n_rows, use_cfg_dev = params->use_cfg;
+    const bool two = hp.urow_off > 0;
+    const float *c = hp.part + (size_t)row * hp.row_stride + c4;
+    const float *u = hp.part + (size_t)(hp.urow_off + row) * hp.row_stride + c4;
+    float zc[4] = {0.f, 0.f, 0.f, 0.f}, zu[4] = {0.f, 0.f, 0.f, 0.f};
+    if (hp.n_chunks <= 8) {                    // every plane of both rows in flight before the first add; summed in chunk order
+        float4 a[8], b[8];
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch)
+            if (ch < hp.n_chunks) {
+                a[ch] = *reinterpret_cast<const float4 *>(c + (size_t)ch * hp.chunk_stride);
+                if (two) b[ch] = *reinterpret_cast<const float4 *>(u + (size_t)ch * hp.chunk_stride);
+            }
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch)
+            if (ch < hp.n_chunks) {
+                zc[0] += a[ch].x; zc[1] += a[ch].y; zc[2] += a[ch].z; zc[3] += a[ch].w;
+                if (two) { zu[0] += b[ch].x; zu[1] += b[ch].y; zu[2] += b[ch].z; zu[3] += b[ch].w; }
+            }
+    } else {
+        for (int ch = 0; ch < hp.n_chunks; ++ch) {
+            const float4 a = *reinterpret_cast<const float4 *>(c + (size_t)ch * hp.chunk_stride);
+            zc[0] += a.x; zc[1] += a.y; zc[2] += a.z; zc[3] += a.w;
+            if (two) { const float4 b = *reinterpret_cast<const float4 *>(u + (size_t)ch * hp.chunk_stride); zu[0] += b.x; zu[1] += b.y; zu[2] += b.z; zu[3] += b.w; }
+        }
+    }
+    if (row >= n_rows_dev) return;
+    float rc = 1.0f, ru = 1.0f;
+    k2_row_scales(hp, row, rc, ru);
+    const bool cfg = two && use_cfg_dev;
+    float z[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        zc[j] = k2_round16(zc[j] * rc, hp.round_dtype);
+        if (cfg) zu[j] = k2_round16(zu[j] * ru, hp.round_dtype);
+        z[j] = zc[j];
+        if (cfg) { float t = zc[j] - zu[j]; t = guidance * t; z[j] = t + zu[j]; }
+        const int col = hp.col0 + c4 + j;
+        if (hp.dbg_c && col < V) {               // observers (tests): the logits exactly as derived
+            hp.dbg_c[(size_t)row * V + col] = zc[j];
+            if (cfg && hp.dbg_u) hp.dbg_u[(size_t)row * V + col] = zu[j];
+        }
+    }
+    *reinterpret_cast<float4 *>(zbuf + (size_t)row * hp.n_cols + c4) = float4{z[0], z[1], z[2], z[3]};
+}
+
 #define K2_NI 3               // column groups (of 4 x 1024) a thread keeps in registers: windows of up to 12288 columns (9 groups = Emu3's 32768-column rows no longer fit the 128 VGPRs of a 1024-thread workgroup: spills)
 template <bool PART>
 __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
@@ -857,6 +916,18 @@ extern "C" int sjd_logits_to_probs_sample_part(const sjd_head_partials *head, fl
     (void)hipFuncSetAttribute((const void *)k2_logits_to_probs_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
     hipLaunchKernelGGL(k2_logits_to_probs_sample<true>, dim3(max_rows), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, (const float *)nullptr,
                        (const float *)nullptr, (long)0, guidance, V, params, noise, probs_out, tokens_out, *head, amax_out, lds_floats);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_head_combine(const sjd_head_partials *head, float guidance, int max_rows, int V, const sjd_iter_params *params, float *z_out,
+                                void *stream)
+{
+    if (!head || !head->part || head->n_chunks < 1 || head->n_cols < 4 || (head->n_cols & 3) || head->col0 < 0 || head->row_stride < head->n_cols) return SJD_ERR_BAD_ARG;
+    if ((head->row_stride & 3) || (head->chunk_stride & 3) || ((uintptr_t)head->part & 15) || ((uintptr_t)z_out & 15)) return SJD_ERR_BAD_ARG;
+    if (!params || !z_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1) return SJD_ERR_BAD_ARG;
+    if (head->row_sumsq && (head->slices < 1 || head->prows < 1)) return SJD_ERR_BAD_ARG;
+    const dim3 grid((head->n_cols / 4 + 255) / 256, max_rows);
+    hipLaunchKernelGGL(k2a_head_combine, grid, dim3(256), 0, (hipStream_t)stream, *head, guidance, V, params, z_out);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 

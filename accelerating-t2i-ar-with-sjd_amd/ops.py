@@ -541,8 +541,28 @@ def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noi
         hp.zero_state = zero_state.data_ptr()
     assert noise is None or (noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V)
     assert probs_out.is_contiguous()
+    if head_combine_ok(hp):
+        # K2a (round 4): a WIDE head window (Emu3: 32768 columns x 2 planes x 2 rows = 524 KB per row) is combined into guided scores on the whole
+        # chip first; K2 then reads ONE plane per row -- bit-identical scores (sjd_head_combine in include/sjd_hip.h)
+        z = torch.empty(max_rows, p.N, dtype=torch.float32, device=probs_out.device)
+        L.check(L.load().sjd_head_combine(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(z), _stream()), "sjd_head_combine")
+        h2 = L.HeadPartials()
+        h2.part, h2.n_chunks, h2.row_stride, h2.chunk_stride = z.data_ptr(), 1, p.N, max_rows * p.N
+        h2.col0, h2.n_cols, h2.urow_off, h2.round_dtype = hp.col0, hp.n_cols, 0, 2            # SJD_DTYPE_F32: no rounding, no scale, no uncond row
+        h2.zero_state = hp.zero_state
+        hp = h2
     L.check(L.load().sjd_logits_to_probs_sample_part(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out),
                                                     tokens_out_ptr, amax_out_ptr, _stream()), "sjd_logits_to_probs_sample_part")
+
+
+_HEAD_COMBINE_MIN_COLS = int(os.environ.get("SJD_HEAD_COMBINE_MIN_COLS", "16384"))     # (a huge value switches K2a off: A/B aid)
+
+
+def head_combine_ok(hp):
+    """K2a serves heads whose window is wide enough for the extra launch to pay (one CU pulls a row's planes at 16-40 GB/s: Emu3's 32768 columns
+    yes, Lumina's 8192 no) and whose layout its float4 accesses need"""
+    return (hp.n_cols >= _HEAD_COMBINE_MIN_COLS and hp.n_cols % 4 == 0 and hp.row_stride % 4 == 0 and hp.chunk_stride % 4 == 0 and
+            (hp.part or 0) % 16 == 0)
 
 
 def _part_args(delta):

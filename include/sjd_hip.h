@@ -182,6 +182,14 @@ int sjd_logits_to_probs_sample_part(const sjd_head_partials *head /* host struct
                                     int max_rows, int V, const sjd_iter_params *params, const float *noise, float *probs_out,
                                     int64_t *tokens_out, int64_t *amax_out /* may be NULL */, void *stream);
 
+/* K2a (round 4) -- the first step of K2 on the whole chip, for heads whose column window is wide (Emu3: 32768 columns): z_out[row][col - col0]
+ * (fp32, [max_rows][n_cols]) = the guided score of row `row` -- the chunk planes of its cond and uncond rows summed in chunk order, the folded norm's
+ * row scale, the 16-bit rounding of the lm_head output, z = u + guidance (c - u) when params->use_cfg (JL:104) -- bit for bit what K2 derives from
+ * the same `head`; the caller then hands K2 a head of ONE plane over z_out (n_chunks 1, urow_off 0, no row_sumsq, round_dtype SJD_DTYPE_F32).
+ * part, z_out 16-byte aligned; row_stride, chunk_stride, n_cols multiples of 4.  dbg_c / dbg_u of `head` are written here. */
+int sjd_head_combine(const sjd_head_partials *head /* host struct, passed by value to the kernel */, float guidance, int max_rows, int V,
+                     const sjd_iter_params *params, float *z_out, void *stream);
+
 /* K4 -- probabilistic verify-and-accept (longest accepted prefix) + residual resample of the first reject.
  * replaces SpeculativeSampler.__call__ / find_first_misaligned_token_inds / prefix_matching_next_tokens
  * (reference jacobi_iteration_lumina_mgpt.py:203-376).

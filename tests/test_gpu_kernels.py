@@ -762,6 +762,25 @@ def test_k2_on_the_unmaterialised_output_head(dev, dtype, fold, name, V, n, buil
     torch.cuda.synchronize()
     assert torch.equal(toks_a[:n], toks_b[:n])
     assert torch.equal(probs_a[:n].view(torch.int32), probs_b[:n].view(torch.int32))
+    # K2a (round 4: wide windows are combined on the whole chip first, sjd_head_combine) against K2 reading the planes itself: the same bits
+    # either way -- scores (the observers' copy), probabilities, tokens.  The Emu3 case takes the K2a route by default, the others are forced.
+    was = ops._HEAD_COMBINE_MIN_COLS
+    try:
+        took_k2a = n_cols >= was
+        ops._HEAD_COMBINE_MIN_COLS = (1 << 30) if took_k2a else 4
+        probs_c, toks_c, dbg_c = torch.zeros(Lmax, V, device=dev), torch.zeros(Lmax, dtype=torch.int64, device=dev), torch.zeros(2, Lmax, V, device=dev)
+        ops.logits_to_probs_sample_part(head, 3.0, params, noise, probs_c, ctypes_ptr(toks_c), dbg=dbg_c)
+        torch.cuda.synchronize()
+    finally:
+        ops._HEAD_COMBINE_MIN_COLS = was
+    assert name != "emu3_visual_window_odd_vocab" or took_k2a
+    assert torch.equal(toks_a[:n], toks_c[:n]) and torch.equal(probs_a[:n].view(torch.int32), probs_c[:n].view(torch.int32))
+    for row in range(n):
+        r = rules[row]
+        if r.forced < 0:
+            lo = min(r.lo[i] for i in range(r.n_ranges)) if r.n_ranges else 0
+            hi = max(r.hi[i] for i in range(r.n_ranges)) if r.n_ranges else V
+            assert torch.equal(dbg[:, row, lo:hi].view(torch.int32), dbg_c[:, row, lo:hi].view(torch.int32))
     # torch restatement of the derived logits
     s = part.data[0].clone()
     for c in range(1, n_chunks):

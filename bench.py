@@ -281,7 +281,7 @@ def measure_k1_pair(args, model, attn, device, kv_len, reps=4):
                 what="all K1 launches of a layer (partial + combine where the shape needs it), 32 layers' caches in ONE hipGraph replay, HIP events on the replay stream")
 
 
-def measure_g1(args, model, device, rounds=2):
+def measure_g1(args, model, device, rounds=6):
     """Dominant hand-written kernel by time: G1 (weight-streaming projections).  One full pass over the model's own packed
     weights (32 layers x {qkv, o, gate|up, down} = 13.0 GB, so every launch streams from HBM) is captured in a hipGraph -- the
     way the engine launches it -- and `rounds` replays are timed with HIP events on the replay stream.  Algorithmic bytes per

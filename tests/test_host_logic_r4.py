@@ -58,3 +58,32 @@ def test_engine_graph_keys_carry_the_k1_regime():
     import sjd_amd.engine as E
     src = inspect.getsource(E.SJDEngine)
     assert src.count("self._k1_regime()") >= 3 and "choose_regime(kv_len + n_rows" in src
+
+
+def test_head_combine_serves_wide_aligned_windows_only():
+    """K2a (sjd_head_combine) is put in front of K2 for wide head windows only, and only where its 16-byte accesses are legal"""
+    ops = _ops()
+    import sjd_amd._lib as L
+
+    def hp(n_cols, row_stride=None, chunk_stride=None, part=1 << 20):
+        h = L.HeadPartials()
+        h.part, h.n_chunks, h.n_cols = part, 2, n_cols
+        h.row_stride = n_cols if row_stride is None else row_stride
+        h.chunk_stride = 64 * h.row_stride if chunk_stride is None else chunk_stride
+        return h
+
+    assert ops.head_combine_ok(hp(32800))                       # Emu3's visual window (+ padding to whole 32-column tiles)
+    assert not ops.head_combine_ok(hp(8224))                    # Lumina's image window: the extra launch costs more than it saves
+    assert not ops.head_combine_ok(hp(32800, part=(1 << 20) + 4))     # planes not 16-byte aligned
+    assert not ops.head_combine_ok(hp(32802))                   # not whole float4 groups
+    assert not ops.head_combine_ok(hp(32800, row_stride=32802))
+
+
+def test_emu3_on_the_12bit_stream_has_its_own_launch_shapes():
+    import sjd_amd.backbones as BB
+    z, raw = BB.ChameleonBackbone.G1_CFG_EMU3_Z, BB.ChameleonBackbone.G1_CFG_EMU3
+    assert set(z) == set(raw) == {"qkv", "o", "gate_up", "down"}
+    for name in z:                                              # same split-K chunks (the consumers' plane counts do not change), <= 8 waves at 64 rows
+        assert z[name][0] == raw[name][0] and z[name][1] <= 8
+    # 256 workgroups for q|k|v (6144 columns) and o (4096 columns) at K = 4096
+    assert (6144 // 32 // z["qkv"][1]) * (4096 // z["qkv"][0]) == 256 and (4096 // 32 // z["o"][1]) * (4096 // z["o"][0]) == 256

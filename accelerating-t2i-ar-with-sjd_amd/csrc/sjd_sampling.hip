@@ -598,6 +598,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
 {
     __shared__ SjdShared sh;
     extern __shared__ __attribute__((aligned(16))) float sjd_dyn_lds[];      // round 4: the residual row, when its window fits (else `scratch`)
+    SJD_TRS(32, 0);
     const int n = params->n_rows;
     if (n <= 1) {   // prefill / single-token phase short-circuit (JL:344-350)
         if (threadIdx.x == 0) { state->m = 1; state->rejected = 0; state->n_prev = n; }
@@ -636,6 +637,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
     }
     __syncthreads();
     const int m = sh.misc[0];
+    SJD_TRS(32, 1);               // accept tests done, prefix known
     const bool rejected = (scheme == 0) && (m < n);
     const uint32_t ph_blocks = (uint32_t)params->philox_blocks;
     const uint64_t ph_seed = params->philox_seed, ph_off2 = params->philox_offset[2];
@@ -678,6 +680,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                     }
                 }
             }
+            SJD_TRS(32, 2);       // residual row staged
             const int n_pos = block_sum_int(cnt, sh);
             __syncthreads();
             float kth = 0.0f;
@@ -730,6 +733,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                     S = block_canonical_sum(a0, a1, a2, a3, sh);
                 }
                 if (rule.top_p_thr >= 0.0f) S = block_top_p_apply(scratch, wlo, whi, S, rule.top_p_thr, sh, sb);
+                SJD_TRS(32, 3);   // (top-k,) sum known
                 degenerate = !(S > 0.0f);         // 0/0 below: flagged to the host (state->rejected = 2), never a silent arbitrary id
                 unsigned long long best = 0ull;
                 // in-kernel noise: the entries with mass go through a compacted LDS list (wave_push), the noise is evaluated densely
@@ -810,6 +814,7 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
                         }
                     }
                 }
+                SJD_TRS(32, 4);   // list drawn
                 const int tok = block_argmax(best, sh);
                 if (threadIdx.x == 0) state->tokens[row] = tok;
             }
@@ -818,7 +823,9 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
         }
     }
     if (threadIdx.x == 0) { state->m = m; state->rejected = rejected ? (degenerate ? 2 : 1) : 0; state->n_prev = n; }
+    SJD_TRS(32, 5);               // token written
     k4_mirror_state(state, host_mirror, params->iter_seq);
+    SJD_TRS(32, 6);               // state mirrored into host memory
 }
 
 // ------------------------------------------------------------------------------------------------ K5

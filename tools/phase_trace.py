@@ -285,6 +285,13 @@ def trace_in_situ(lib, torch, ops, np, kv_target=1216):
     table("k2_logits_to_probs_sample (one workgroup per window row, last iteration), in situ", b, 10,
           ["first_batch_rule_stats_state", "zero_outside_window", "head_partials_cfg_mask_stage", "max_and_count", "top_k_select", "exp_and_sum",
            "normalise_store_list", "dense_draw", "argmax_pair"])
+    b = np.zeros((33, 16), dtype=np.uint64)
+    assert lib.sjd_debug_trace_k2(b.ctypes.data, 33) == 0
+    t = b[32, :7].astype(np.int64)
+    if t[0] > 0 and np.all(np.diff(t) >= 0):       # (the last iteration rejected a draft: every K4 phase ran)
+        labels = ["accept_tests", "residual_row_staged", "count_topk_sum", "list_and_dense_draw", "argmax_token", "mirror_to_host"]
+        print(json.dumps(dict(kernel="k4_verify_accept (one workgroup, last iteration, with a rejection), in situ",
+                              phase_us={labels[i]: us(t[i + 1] - t[i]) for i in range(6)}, end_us=us(t[6] - t[0]))), flush=True)
     for kind, name, nwg in ((0, "f1r_residual_sumsq (last launch: after down of layer 31, 13 partial planes)", 256),
                             (1, "f2_qknorm_rope_append (layer 31)", 768), (2, "f3_silu_mul (layer 31)", 172)):
         b = np.zeros((nwg, 4), dtype=np.uint64)

@@ -178,7 +178,7 @@ def test_window_forward_at_production_shapes_against_independent_forwards(family
         grammar = Emu3Grammar(90, 90, 151854, 32768, top_k=2048, **tok)
         cfg = SJDConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=90 * 90 - 1, max_num_new_tokens=window, guidance_scale=3.0,
                         seed=seed, max_length=P + 400, eos_token_ids=(tok["eos_token"],))
-    if dt == torch.bfloat16:
+    if dt == torch.bfloat16 and os.environ.get("SJD_G1Z", "1") != "0":          # (SJD_G1Z=0: the uncompressed stream, an A/B aid)
         # every layer matrix streams in the 12-bit form (the synthetic 184640-row output head may be declined: its units of 32 x 2048 weights
         # carry more than 127 out-of-window values -- it is logged and streams uncompressed, bit-identical either way)
         assert model.compress_stats["compressed"] >= model.compress_stats["matrices"] - 1, model.compress_stats

@@ -46,6 +46,13 @@ class HeadPartials(ctypes.Structure):
                 ("eps", ctypes.c_float), ("dbg_c", ctypes.c_void_p), ("dbg_u", ctypes.c_void_p), ("zero_state", ctypes.c_void_p)]
 
 
+class L2Head(ctypes.Structure):
+    """sjd_l2_head: the head of a G1z / G1sz launch's weight stream as that launch will read it (round 5, csrc/sjd_l2_prefetch.h)"""
+    _fields_ = [("wz", ctypes.c_void_p), ("kind", ctypes.c_int32), ("gx", ctypes.c_int32), ("gy", ctypes.c_int32), ("waves", ctypes.c_int32),
+                ("n_tiles", ctypes.c_int32), ("tile0", ctypes.c_int32), ("n_out", ctypes.c_int32), ("pairs_full", ctypes.c_int32),
+                ("pairs_last", ctypes.c_int32), ("step_major", ctypes.c_int32), ("head_pairs", ctypes.c_int32)]
+
+
 EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_probs_sample", "sjd_verify_accept",
            "sjd_kv_append", "sjd_attention_workspace_bytes", "sjd_draft_window_attention", "sjd_draft_window_attention_ex",
            "sjd_event_create", "sjd_event_destroy", "sjd_event_synchronize", "sjd_event_elapsed_ms",
@@ -57,7 +64,7 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_philox_fill", "sjd_philox_offset_increment", "sjd_skinny_gemm_reduce", "sjd_reduce_timeouts",
            "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged", "sjd_skinny_gemm_z", "sjd_gateup_silu_z", "sjd_qkv_attention_fused_split",
            "sjd_draft_window_attention_colsplit", "sjd_draft_window_attention_fp8_colsplit", "sjd_mlp_pair_z", "sjd_mlp_pair_timeouts",
-           "sjd_head_combine"]
+           "sjd_head_combine", "sjd_l2_head_gemm_z", "sjd_l2_head_gateup_z", "sjd_l2_head_bytes", "sjd_weight_prefetch_head", "sjd_debug_xcc_map"]
 
 _lib = None
 
@@ -124,6 +131,12 @@ def load():
     lib.sjd_philox_fill.argtypes = [vp, i64, ctypes.c_uint64, ctypes.c_uint64, i32, i32, vp]
     lib.sjd_philox_offset_increment.restype = ctypes.c_uint64
     lib.sjd_philox_offset_increment.argtypes = [i64, i32]
+    lib.sjd_l2_head_gemm_z.argtypes = [ctypes.POINTER(L2Head), vp, i32, i32, i32, i32, i32, i32, i32, i32, i32]
+    lib.sjd_l2_head_gateup_z.argtypes = [ctypes.POINTER(L2Head), vp, i32, i32, i32, i32, i32]
+    lib.sjd_l2_head_bytes.restype = i64
+    lib.sjd_l2_head_bytes.argtypes = [ctypes.POINTER(L2Head)]
+    lib.sjd_weight_prefetch_head.argtypes = [ctypes.POINTER(L2Head), i32, vp]
+    lib.sjd_debug_xcc_map.argtypes = [vp, i32, i32, vp]
     lib.sjd_event_create.restype = vp
     lib.sjd_event_destroy.argtypes = [vp]
     lib.sjd_event_synchronize.argtypes = [vp]

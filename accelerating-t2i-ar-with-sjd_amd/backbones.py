@@ -605,7 +605,10 @@ class ChameleonBackbone(nn.Module):
             else:
                 rn = (ops.residual_sumsq(h, g1(o.view(T, H * D), "o", hid, H * D)), hid, eps)
             if pair_mlp:       # round 4 experiment (SJD_MLP_PAIR=1): gate|up + SiLU * up AND the down projection in one launch
-                _, delta = ops.mlp_pair(h, self._packed[li]["gate_up"], self._packed[li]["down"], inter, hid, cfg["down"][0], row_norm=rn)
+                if getattr(self, "_pair_ready", None) is None or self._pair_ready.device != h.device:       # this backbone's own arrival counters
+                    self._pair_ready = torch.zeros(max(64, (inter + cfg["down"][0] - 1) // cfg["down"][0] + 1), dtype=torch.int32, device=h.device)
+                _, delta = ops.mlp_pair(h, self._packed[li]["gate_up"], self._packed[li]["down"], inter, hid, cfg["down"][0], row_norm=rn,
+                                        ready=self._pair_ready)
                 ss_next = None
                 continue
             if fuse_mlp:       # G1s: gate|up with SiLU * up as its epilogue (one launch, no partial planes, bit-identical to G1 + F3)

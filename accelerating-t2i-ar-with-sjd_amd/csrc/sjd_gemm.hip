@@ -21,6 +21,7 @@
 #include "../../include/sjd_hip.h"
 #include "sjd_mlp_epilogue.h"
 #include "sjd_coherent.h"
+#include "sjd_l2_prefetch.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -641,6 +642,85 @@ extern "C" int sjd_weight_prefetch(const void *w, int64_t nbytes, int blocks, vo
 {
     if (!w || !sink || nbytes < 16 || blocks < 1 || blocks > 4096) return SJD_ERR_BAD_ARG;
     hipLaunchKernelGGL(g1_prefetch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4 *)w, (size_t)(nbytes / 16), (unsigned *)sink);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------ L2 head pull (round 5, sjd_l2_prefetch.h)
+__global__ __launch_bounds__(256) void g1_l2_head_pull(const sjd_l2_head d) { sjd_l2_head_pull(d, (int)blockIdx.x, (int)gridDim.x); }
+
+__global__ void g1_xcc_map(int *out)
+{
+    if (threadIdx.x == 0) {
+        unsigned v;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        out[blockIdx.y * gridDim.x + blockIdx.x] = (int)(v & 0xfu);
+    }
+}
+
+extern "C" int sjd_debug_xcc_map(int32_t *out, int gx, int gy, void *stream)
+{
+    if (!out || gx < 1 || gy < 1) return SJD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(g1_xcc_map, dim3(gx, gy), dim3(64), 0, (hipStream_t)stream, out);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+// the grid sjd_skinny_gemm_z launches for these arguments (kept next to it: see SJD_G1Z_LAUNCH / SJD_G1ZT below)
+extern "C" int sjd_l2_head_gemm_z(sjd_l2_head *out, const void *wz, int M, int N, int K, int KC, int waves, int step_major, int N_packed, int tile0, int head_pairs)
+{
+    if (!out || !wz || M < 1 || N < 32 || (N % 32) || (N_packed % 32) || (K % 16) || KC < 16 || (KC % 16) || waves < 1 || waves > 16 || head_pairs < 1)
+        return SJD_ERR_BAD_ARG;
+    const int n_out = N / 32, n_tiles = N_packed / 32, n_chunks = (K + KC - 1) / KC;
+    if (tile0 < 0 || tile0 + n_out > n_tiles) return SJD_ERR_BAD_ARG;
+    const int steps_last = (K - (n_chunks - 1) * KC) / 16;
+    out->wz = wz;
+    out->kind = 0;
+    out->gx = (n_out + waves - 1) / waves;
+    out->gy = n_chunks;
+    out->waves = waves;
+    out->n_tiles = n_tiles;
+    out->tile0 = tile0;
+    out->n_out = n_out;
+    out->pairs_full = (KC / 16 + 1) / 2;
+    out->pairs_last = (steps_last + 1) / 2;
+    out->step_major = step_major ? 1 : 0;
+    out->head_pairs = head_pairs < out->pairs_full ? head_pairs : out->pairs_full;
+    return SJD_OK;
+}
+
+extern "C" int sjd_l2_head_gateup_z(sjd_l2_head *out, const void *wz, int M, int I, int K, int step_major, int head_pairs)
+{
+    if (!out || !wz || M < 1 || M > 64 || I < 64 || (I % 64) || K < 512 || (K % 64) || head_pairs < 1) return SJD_ERR_BAD_ARG;
+    out->wz = wz;
+    out->kind = 1;
+    out->gx = I / 64;
+    out->gy = 1;
+    out->waves = 8;
+    out->n_tiles = 2 * (I / 32);
+    out->tile0 = 0;
+    out->n_out = out->n_tiles;
+    out->pairs_full = out->pairs_last = K / 64;
+    out->step_major = step_major ? 1 : 0;
+    out->head_pairs = head_pairs < out->pairs_full ? head_pairs : out->pairs_full;
+    return SJD_OK;
+}
+
+extern "C" int64_t sjd_l2_head_bytes(const sjd_l2_head *d)
+{
+    if (!d) return 0;
+    int64_t pairs = 0;
+    if (d->kind == 0) {
+        for (int by = 0; by < d->gy; ++by) {
+            const int pu = by == d->gy - 1 ? d->pairs_last : d->pairs_full;
+            pairs += (int64_t)d->n_out * (pu < d->head_pairs ? pu : d->head_pairs);
+        }
+    } else pairs = (int64_t)d->gx * 8 * d->head_pairs;
+    return pairs * 1536;
+}
+
+extern "C" int sjd_weight_prefetch_head(const sjd_l2_head *head, int blocks, void *stream)
+{
+    if (!head || !head->wz || blocks < 8 || (blocks % 8) || blocks > 4096) return SJD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(g1_l2_head_pull, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *head);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 

@@ -116,13 +116,19 @@ def set_seed(seed):
 
 
 _REDUCE_TIMEOUTS_SEEN = 0
+_PAIR_TIMEOUTS_SEEN = 0
 
 
 def check_reduce_timeouts():
     """The o / down projections of the window forward reduce their split-K planes in their own tail (sjd_skinny_gemm_reduce): their
     workgroups wait for each other, which needs the whole launch resident on the device.  On a partitioned or shared GPU a wait can be
     abandoned (bounded spin); the forward's result is then wrong, so a decode that saw one raises instead of returning tokens."""
-    global _REDUCE_TIMEOUTS_SEEN
+    global _REDUCE_TIMEOUTS_SEEN, _PAIR_TIMEOUTS_SEEN
+    n_pair = ops.mlp_pair_timeouts()          # the opt-in one-launch MLP (SJD_MLP_PAIR=1) waits the same bounded way (ADVICE r4)
+    if n_pair > _PAIR_TIMEOUTS_SEEN:
+        _PAIR_TIMEOUTS_SEEN = n_pair
+        raise RuntimeError(f"{n_pair} workgroup(s) of a one-launch MLP (sjd_mlp_pair_z) gave up waiting for their activation chunk: the forward's "
+                           "result is wrong; unset SJD_MLP_PAIR / model.mlp_pair to run the MLP as two launches")
     n = ops.reduce_timeouts()
     if n > _REDUCE_TIMEOUTS_SEEN:
         _REDUCE_TIMEOUTS_SEEN = n
@@ -346,16 +352,23 @@ class SJDEngine:
     def _launch_sample(self, cur, logits, cols=None):
         """part 2 (K2 + K4) of a two-stage iteration; a hipGraph per (prob-buffer parity, column window), captured the second time that
         combination runs on graph-owned logits."""
-        key = (cur, self._guidance, cols, self.hook is not None, self._philox)
-        if not self.use_graph or ("fwd", cols, self._k1_regime()) not in self._graphs:
+        # (the K1 regime is part of the key: every regime's forward graph owns ITS static logits / head partials, and a sample graph bakes in
+        #  the buffer it was captured on -- ADVICE r4: without it the graph of one regime replayed on the other regime's stale buffer.  The
+        #  captured buffer's identity is kept beside the graph as a belt: a mismatch drops the graph and captures again.)
+        regime = self._k1_regime()
+        key = ("smp", cur, self._guidance, cols, self.hook is not None, self._philox, regime)
+        if not self.use_graph or ("fwd", cols, regime) not in self._graphs:
             self._sample_body(cur, logits, cols)
             return
+        if key in self._graphs and self._graph_logits.get(key) is not logits:
+            del self._graphs[key]
         if key not in self._graphs:
             self._sample_body(cur, logits, cols)     # eager warm-up of this parity, captured below for the next use
             g = torch.cuda.CUDAGraph()
             with capture_graph(g):
                 self._sample_body(cur, logits, cols)
             self._graphs[key] = g
+            self._graph_logits[key] = logits
             return
         self._graphs[key].replay()
 
@@ -528,7 +541,8 @@ class SJDEngine:
             else:
                 cols = self.logit_columns(rules)
                 if attn is not None and hasattr(attn, "choose_regime"):     # K1: column split while the context is short, key split + combine after
-                    attn.choose_regime(kv_len + n_rows, self.backbone.cache.k.dtype)
+                    ck = self.backbone.cache.k          # [layers, B, H_kv, S, D]
+                    attn.choose_regime(kv_len + n_rows, ck.dtype, shape=(B, self.Lmax, getattr(self.backbone, "n_heads", ck.shape[2]), ck.shape[2], ck.shape[4]))
                 if two_stage:
                     logits = self._launch_forward(cols)
                     t_host0 = time.perf_counter()

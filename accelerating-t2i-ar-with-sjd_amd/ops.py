@@ -490,6 +490,38 @@ def weight_prefetch(w_packed, blocks=128, nbytes=None):
     L.check(L.load().sjd_weight_prefetch(_ptr(w_packed), nb, int(blocks), _ptr(sink), _stream()), "sjd_weight_prefetch")
 
 
+def l2_head(w_packed, M, waves=None, head_pairs=8, gateup=False, col0=0, n_cols=None):
+    """-> _lib.L2Head: the first `head_pairs` record pairs of every unit of the G1z (or, gateup=True, G1sz) launch that will stream `w_packed`
+    (a PackedZ) for an M-row window with `waves` waves per workgroup -- what a glue launch in front of it pulls into the L2 (round 5)."""
+    assert isinstance(w_packed, PackedZ)
+    h = L.L2Head()
+    if gateup:
+        L.check(L.load().sjd_l2_head_gateup_z(ctypes.byref(h), _ptr(w_packed.data), M, w_packed.N // 2, w_packed.K, int(w_packed.step_major), int(head_pairs)),
+                "sjd_l2_head_gateup_z")
+    else:
+        n = w_packed.N - col0 if n_cols is None else n_cols
+        L.check(L.load().sjd_l2_head_gemm_z(ctypes.byref(h), _ptr(w_packed.data), M, n, w_packed.K, w_packed.KC, int(waves), int(w_packed.step_major), w_packed.N,
+                                           col0 // 32, int(head_pairs)), "sjd_l2_head_gemm_z")
+    h._keep = w_packed           # the descriptor holds a raw address
+    return h
+
+
+def l2_head_bytes(head):
+    return int(L.load().sjd_l2_head_bytes(ctypes.byref(head)))
+
+
+def weight_prefetch_head(head, blocks=256):
+    """the L2 head pull as a launch of its own (bench aid; the product hosts it in F1r / F2)"""
+    L.check(L.load().sjd_weight_prefetch_head(ctypes.byref(head), int(blocks), _stream()), "sjd_weight_prefetch_head")
+
+
+def xcc_map(gx, gy=1, device="cuda:0"):
+    """XCC_ID of every workgroup of a (gx, gy) launch -> int32 [gy, gx]"""
+    out = torch.full((gy, gx), -1, dtype=torch.int32, device=device)
+    L.check(L.load().sjd_debug_xcc_map(_ptr(out), gx, gy, _stream()), "sjd_debug_xcc_map")
+    return out
+
+
 def skinny_gemm_cols(x, w_packed, N_packed, K, KC, col0, n_cols, waves=8, step_major=True):
     """G1 over the vocabulary columns [col0, col0 + n_cols) (32-aligned) of a weight packed with N_packed columns -> Partials [n_chunks, R, n_cols]."""
     M = x.shape[0]
@@ -686,7 +718,7 @@ def gateup_silu(x, w_packed, inter, hidden, step_major=False, row_norm=None):
     return y
 
 
-_PAIR_READY = {}
+_PAIR_READY = {}          # (device, stream) -> arrival counters of sjd_mlp_pair_z launches that CANNOT overlap (one stream runs them in order)
 
 
 def mlp_pair_ok(T, inter, hidden, gu_packed, dn_packed, KC_dn, waves_dn, device):
@@ -700,15 +732,22 @@ def mlp_pair_ok(T, inter, hidden, gu_packed, dn_packed, KC_dn, waves_dn, device)
     return grid <= torch.cuda.get_device_properties(device).multi_processor_count
 
 
-def mlp_pair(x, gu_packed, dn_packed, inter, hidden, KC_dn, row_norm=None):
-    """the MLP as ONE launch: -> (y [T, inter], Partials of the down projection); bit-identical to gateup_silu(...) then skinny_gemm(y, ...)."""
+def mlp_pair(x, gu_packed, dn_packed, inter, hidden, KC_dn, row_norm=None, ready=None):
+    """the MLP as ONE launch: -> (y [T, inter], Partials of the down projection); bit-identical to gateup_silu(...) then skinny_gemm(y, ...).
+    ready: int32 arrival counters (>= n_chunks + 1 words, zero on entry; the launch re-arms them) PRIVATE to launches that cannot overlap --
+    a backbone hands in its own; None: one buffer per (device, current stream), whose launches are ordered (the buffer used to be
+    one per device, shared by every stream and engine)."""
     T = x.shape[0]
     assert x.is_contiguous() and x.dtype == torch.bfloat16 and x.shape[1] == hidden
     dev = x.device
     nc = (inter + KC_dn - 1) // KC_dn
-    rd = _PAIR_READY.get(dev)
-    if rd is None or rd.numel() < nc + 1:
-        rd = _PAIR_READY[dev] = torch.zeros(64, dtype=torch.int32, device=dev)
+    rd = ready
+    if rd is None:
+        key = (dev, _stream())
+        rd = _PAIR_READY.get(key)
+        if rd is None or rd.numel() < nc + 1:
+            rd = _PAIR_READY[key] = torch.zeros(max(64, nc + 1), dtype=torch.int32, device=dev)
+    assert rd.dtype == torch.int32 and rd.device == dev and nc + 1 <= rd.numel(), "sjd_mlp_pair_z: one arrival counter per K chunk of the down projection + 1"
     y = torch.empty(T, inter, dtype=x.dtype, device=dev)
     out = torch.empty(nc, 32, hidden, dtype=torch.float32, device=dev)
     L.check(L.load().sjd_mlp_pair_z(_ptr(x), _ptr(gu_packed.data), _ptr(gu_packed.exc), gu_packed.cap, int(gu_packed.step_major), _ptr(y),
@@ -764,9 +803,13 @@ class HipWindowAttention:
 
     COLSPLIT_MAX_KEYS = {"16bit": 736, "fp8": 1536}       # crossover of the two forms (profiles/r4_k1_dsplit_ab.txt, r4_k1_dsplit_fp8_ab.txt)
 
-    def choose_regime(self, kv_rows, cache_dtype):
-        """-> the regime for a window whose longest row sees `kv_rows` keys; sets self.regime"""
-        if self._pin_regime in ("keysplit", "colsplit"):
+    def choose_regime(self, kv_rows, cache_dtype, shape=None):
+        """-> the regime for a window whose longest row sees `kv_rows` keys; sets self.regime.  shape = (B, n, H, H_kv, D) of the window
+        launches: a shape the column split does not serve (GQA, 32-row windows, several prompts per forward) is "keysplit" whatever the
+        context length or the pin -- the kernels are the same there, and a second set of graphs would only be captured twice."""
+        if shape is not None and not colsplit_ok(*shape, cache_dtype):
+            self.regime = "keysplit"
+        elif self._pin_regime in ("keysplit", "colsplit"):
             self.regime = self._pin_regime
         else:
             self.regime = "colsplit" if kv_rows <= self.COLSPLIT_MAX_KEYS["fp8" if cache_dtype == FP8 else "16bit"] else "keysplit"
@@ -847,12 +890,14 @@ class HipWindowAttention:
         B, n, H, D = q.shape
         kc, vc = cache.k[layer], cache.v[layer]
         kv_host = 0 if self.params is not None else int(kv_len)
+        # (the split workspace is allocated whatever the regime: its first allocation bumps ws_version, which makes the engines drop every
+        #  captured graph -- that must happen before the first capture, not at the crossover in the middle of an image)
+        self._resolve_split(B, kc.shape[1], n, H, kc.shape[2] * kc.shape[3] * kc.element_size() if kc.dtype == FP8 else None)
+        ws = self._workspace(B, H, n, D, q.device)
         if self.regime == "colsplit" and colsplit_ok(B, n, H, kc.shape[1], D, kc.dtype):
             out = torch.empty_like(q)
             draft_window_attention_colsplit(q, kc, vc, out, key_start, self.params, kv_host, self.kv_scale)
             return out
-        self._resolve_split(B, kc.shape[1], n, H, kc.shape[2] * kc.shape[3] * kc.element_size() if kc.dtype == FP8 else None)
-        ws = self._workspace(B, H, n, D, q.device)
         out = torch.empty_like(q)
         if kc.dtype == FP8:
             draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], key_start, self.params, kv_host, self.n_split, ws)

@@ -338,6 +338,30 @@ int sjd_gateup_silu_z(const void *x, const void *wz, const void *exc, int exc_ca
  * practice).  blocks: workgroups of 256 threads (1..4096). */
 int sjd_weight_prefetch(const void *w, int64_t nbytes, int blocks, void *sink, void *stream);
 
+/* Round 5 -- the HEAD of the next projection's weight stream pulled into the XCDs' L2 by spare workgroups of the latency-bound launch in front
+ * of it (csrc/sjd_l2_prefetch.h).  Lines read with default-policy loads stay in the L2 of the XCD that read them across a kernel boundary
+ * (tools/l2_survive_probe.hip); workgroup L of a launch runs on XCD L mod 8; so pulling workgroup j (XCD j mod 8) reads the first `head_pairs`
+ * record pairs of every unit the consumer's workgroups j mod 8, j mod 8 + 8, ... will stream.  sjd_l2_head describes the consumer launch; the
+ * two constructors below derive it from the arguments that launch will be given, so the geometry lives next to the launchers.  No reference
+ * counterpart (the reference's nn.Linear calls, modeling_chameleon.py:527-529, 579, 637-643, are library GEMMs); no effect on results. */
+typedef struct sjd_l2_head {
+    const void *wz;                 /* the 12-bit packed records (ops.pack_weight_z) */
+    int32_t kind;                   /* 0: a sjd_skinny_gemm_z launch; 1: a sjd_gateup_silu_z launch */
+    int32_t gx, gy, waves;          /* its grid and waves per workgroup */
+    int32_t n_tiles, tile0, n_out;  /* packed column tiles, first tile and tile count of the launch (kind 0) */
+    int32_t pairs_full, pairs_last; /* record pairs of a full K chunk's unit / of the last chunk's */
+    int32_t step_major;
+    int32_t head_pairs;             /* pairs per unit to pull */
+} sjd_l2_head;
+int sjd_l2_head_gemm_z(sjd_l2_head *out, const void *wz, int M, int N, int K, int KC, int waves, int step_major, int N_packed, int tile0, int head_pairs);
+int sjd_l2_head_gateup_z(sjd_l2_head *out, const void *wz, int M, int I, int K, int step_major, int head_pairs);
+int64_t sjd_l2_head_bytes(const sjd_l2_head *head);                 /* bytes the pull reads (the ragged edges counted exactly) */
+/* the pull as a launch of its own (tools/l2_head_bench.py; the product hosts it in F1r / F2: sjd_residual_sumsq_pf, sjd_qknorm_rope_append_pf).
+ * blocks: workgroups of 256 threads, a multiple of 8 */
+int sjd_weight_prefetch_head(const sjd_l2_head *head, int blocks, void *stream);
+/* XCC_ID of every workgroup of a (gx, gy) launch of 64-thread workgroups -> out[gx * gy] int32 (device): the dispatch rule the pull relies on */
+int sjd_debug_xcc_map(int32_t *out, int gx, int gy, void *stream);
+
 /* K1 / K3 over an fp8 KV cache (BASELINE config 5; there is no fp8 in the reference -- the parity target is the bf16 result
  * within tolerance): the cache holds OCP e4m3 bytes, value = fp8 * scale with one scale per tensor; q / out keep `dtype` (bf16/f16).
  * Half the KV bytes of sjd_draft_window_attention, both contractions on v_mfma_f32_16x16x32_fp8_fp8.  Other arguments as the

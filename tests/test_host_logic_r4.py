@@ -52,12 +52,19 @@ def test_mlp_pair_shapes():
     assert not ops.mlp_pair_ok(32, 11008, 4096, gu, z(896), 768, 8, dev)  # packed with another K chunk
 
 
-def test_engine_graph_keys_carry_the_k1_regime():
-    """the two K1 forms are different kernels: a graph captured under one must never be replayed under the other"""
-    import inspect
-    import sjd_amd.engine as E
-    src = inspect.getsource(E.SJDEngine)
-    assert src.count("self._k1_regime()") >= 3 and "choose_regime(kv_len + n_rows" in src
+def test_choose_regime_follows_the_launch_shape():
+    """a shape the column split does not serve is "keysplit" whatever the context length or the pin (the behavioural graph-vs-eager
+    check across the threshold is tests/test_gpu_regime_graphs.py)"""
+    ops = _ops()
+    attn = ops.HipWindowAttention.__new__(ops.HipWindowAttention)
+    attn._pin_regime, attn.regime = None, "keysplit"
+    assert attn.choose_regime(100, torch.bfloat16, shape=(2, 16, 32, 32, 128)) == "colsplit"
+    assert attn.choose_regime(4000, torch.bfloat16, shape=(2, 16, 32, 32, 128)) == "keysplit"
+    assert attn.choose_regime(100, torch.float16, shape=(2, 32, 32, 8, 128)) == "keysplit"        # Emu3: GQA, 32-row window
+    assert attn.choose_regime(100, torch.bfloat16, shape=(8, 16, 32, 32, 128)) == "keysplit"       # four prompts per forward
+    attn._pin_regime = "colsplit"
+    assert attn.choose_regime(100, torch.float16, shape=(2, 32, 32, 8, 128)) == "keysplit"
+    assert attn.choose_regime(4000, torch.bfloat16, shape=(2, 16, 32, 32, 128)) == "colsplit"
 
 
 def test_head_combine_serves_wide_aligned_windows_only():

@@ -35,6 +35,7 @@ extern "C" int sjd_debug_trace_glue(int kind, unsigned long long *host_out, int 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 #include "sjd_mlp_epilogue.h"
+#include "sjd_l2_prefetch.h"
 
 template <int DT> struct Cvt;
 template <> struct Cvt<SJD_DTYPE_BF16> {
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(1024) void f1p_add_rmsnorm(unsigned short *__restri
 // reduces to one scale per row, which commutes with the projection and is applied by its consumer (F2 / F3 `row_sumsq`):
 //   gamma * (h * r) @ W^T  ==  r * (h @ (W diag(gamma))^T),   r = rsqrt(mean(h^2) + eps)
 template <int DT>
-__global__ __launch_bounds__(128) void f1r_residual_sumsq(unsigned short *__restrict__ h, const float *__restrict__ part, int n_chunks,
-                                                          int hidden, int prows, float *__restrict__ out_sumsq)
+__device__ __forceinline__ void f1r_body(unsigned short *__restrict__ h, const float *__restrict__ part, int n_chunks,
+                                         int hidden, int prows, float *__restrict__ out_sumsq)
 {
     SJD_TRG(0, 0);
     __shared__ float red[2];
@@ -280,6 +281,28 @@ __global__ __launch_bounds__(128) void f1r_residual_sumsq(unsigned short *__rest
     __syncthreads();
     if (threadIdx.x == 0) out_sumsq[(size_t)blockIdx.y * prows + row] = red[0] + red[1];
     SJD_TRG(0, 2);
+}
+
+template <int DT>
+__global__ __launch_bounds__(128) void f1r_residual_sumsq(unsigned short *__restrict__ h, const float *__restrict__ part, int n_chunks,
+                                                          int hidden, int prows, float *__restrict__ out_sumsq)
+{
+    f1r_body<DT>(h, part, n_chunks, hidden, prows, out_sumsq);
+}
+
+// F1r HOSTING the L2 head pull of the projection behind it (round 5, sjd_l2_prefetch.h): grid rows [0, n_slices) are F1r's own workgroups
+// (dispatched first), the rows behind them pull.  `rows * n_slices` is a multiple of 8 (the launcher checks), so pulling workgroup j sits on
+// XCD j mod 8.  The pull's arguments come after F1r's: the sixteen preloaded argument dwords are still F1r's own.
+template <int DT>
+__global__ __launch_bounds__(128) void f1r_residual_sumsq_pf(unsigned short *__restrict__ h, const float *__restrict__ part, int n_chunks,
+                                                             int hidden, int prows, float *__restrict__ out_sumsq, int n_slices,
+                                                             const sjd_l2_head pf)
+{
+    if ((int)blockIdx.y >= n_slices) {
+        sjd_l2_head_pull(pf, ((int)blockIdx.y - n_slices) * (int)gridDim.x + (int)blockIdx.x, ((int)gridDim.y - n_slices) * (int)gridDim.x);
+        return;
+    }
+    f1r_body<DT>(h, part, n_chunks, hidden, prows, out_sumsq);
 }
 
 // 1/rms of a row from the per-slice sums of squares F1r wrote (fixed order)
@@ -622,6 +645,28 @@ extern "C" int sjd_residual_sumsq(void *h, const float *part, int n_chunks, int 
         hipLaunchKernelGGL(f1r_residual_sumsq<SJD_DTYPE_BF16>, grid, block, 0, s, (unsigned short *)h, part, n_chunks, hidden, prows, out_sumsq);
     else if (dtype == SJD_DTYPE_F16)
         hipLaunchKernelGGL(f1r_residual_sumsq<SJD_DTYPE_F16>, grid, block, 0, s, (unsigned short *)h, part, n_chunks, hidden, prows, out_sumsq);
+    else return SJD_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+// F1r + the L2 head pull of the next projection in one launch.  pf_blocks: pulling workgroups of 128 threads (a multiple of 8 x rows / gcd...:
+// the launcher rounds it to whole grid rows); head NULL or pf_blocks 0: plain sjd_residual_sumsq.
+extern "C" int sjd_residual_sumsq_pf(void *h, const float *part, int n_chunks, int rows, int hidden, int dtype, float *out_sumsq,
+                                     const sjd_l2_head *head, int pf_blocks, void *stream)
+{
+    if (!head || pf_blocks < 1) return sjd_residual_sumsq(h, part, n_chunks, rows, hidden, dtype, out_sumsq, stream);
+    if (!h || !out_sumsq || rows < 1 || rows > 128 || (part && n_chunks < 1) || hidden < 4 || (hidden % 4) != 0 || !head->wz) return SJD_ERR_BAD_ARG;
+    const int prows = ((rows + 31) / 32) * 32, n_slices = (hidden + 511) / 512;
+    // the pull's XCD arithmetic needs (i) F1r's own workgroup count and (ii) the pulling workgroup count to be multiples of 8
+    int pf_rows = (pf_blocks + rows - 1) / rows;
+    while ((pf_rows * rows) % 8) ++pf_rows;
+    if ((rows * n_slices) % 8) return sjd_residual_sumsq(h, part, n_chunks, rows, hidden, dtype, out_sumsq, stream);
+    const dim3 grid(rows, n_slices + pf_rows), block(128);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SJD_DTYPE_BF16)
+        hipLaunchKernelGGL(f1r_residual_sumsq_pf<SJD_DTYPE_BF16>, grid, block, 0, s, (unsigned short *)h, part, n_chunks, hidden, prows, out_sumsq, n_slices, *head);
+    else if (dtype == SJD_DTYPE_F16)
+        hipLaunchKernelGGL(f1r_residual_sumsq_pf<SJD_DTYPE_F16>, grid, block, 0, s, (unsigned short *)h, part, n_chunks, hidden, prows, out_sumsq, n_slices, *head);
     else return SJD_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }

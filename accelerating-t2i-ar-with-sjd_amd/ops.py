@@ -761,13 +761,18 @@ def mlp_pair_timeouts():
     return int(L.load().sjd_mlp_pair_timeouts())
 
 
-def residual_sumsq(h, part=None):
+def residual_sumsq(h, part=None, pull=None, pull_blocks=0):
     """F1r: h [T, hidden] += dtype(sum of the G1 partials) in place (part None: h unchanged); returns the per-512-column-slice sums
-    of h^2 [slices, R] fp32 -- the `sumsq` of a row_norm."""
+    of h^2 [slices, R] fp32 -- the `sumsq` of a row_norm.  pull (an l2_head) + pull_blocks: the same launch also pulls the head of the next
+    projection's weight stream into the L2 (round 5); no effect on the result."""
     T, hidden = h.shape
     assert h.is_contiguous() and (part is None or (isinstance(part, Partials) and part.N == hidden))
     R = part.data.shape[1] if part is not None else _prows(T)
     out = torch.empty((hidden + 511) // 512, R, dtype=torch.float32, device=h.device)
+    if pull is not None and pull_blocks > 0:
+        L.check(L.load().sjd_residual_sumsq_pf(_ptr(h), _ptr(part.data) if part is not None else None, part.n_chunks if part is not None else 0,
+                                              T, hidden, _dtype_code(h.dtype), _ptr(out), ctypes.byref(pull), int(pull_blocks), _stream()), "sjd_residual_sumsq_pf")
+        return out
     L.check(L.load().sjd_residual_sumsq(_ptr(h), _ptr(part.data) if part is not None else None, part.n_chunks if part is not None else 0,
                                        T, hidden, _dtype_code(h.dtype), _ptr(out), _stream()), "sjd_residual_sumsq")
     return out

@@ -359,6 +359,10 @@ int64_t sjd_l2_head_bytes(const sjd_l2_head *head);                 /* bytes the
 /* the pull as a launch of its own (tools/l2_head_bench.py; the product hosts it in F1r / F2: sjd_residual_sumsq_pf, sjd_qknorm_rope_append_pf).
  * blocks: workgroups of 256 threads, a multiple of 8 */
 int sjd_weight_prefetch_head(const sjd_l2_head *head, int blocks, void *stream);
+/* sjd_residual_sumsq (F1r) hosting the pull of the projection that follows it: F1r's own workgroups first, `pf_blocks` pulling workgroups of
+ * 128 threads behind them in the same launch (rounded up to whole grid rows).  head NULL / pf_blocks 0 = sjd_residual_sumsq.  Same results. */
+int sjd_residual_sumsq_pf(void *h, const float *part, int n_chunks, int rows, int hidden, int dtype, float *out_sumsq,
+                          const sjd_l2_head *head, int pf_blocks, void *stream);
 /* XCC_ID of every workgroup of a (gx, gy) launch of 64-thread workgroups -> out[gx * gy] int32 (device): the dispatch rule the pull relies on */
 int sjd_debug_xcc_map(int32_t *out, int gx, int gy, void *stream);
 

@@ -518,7 +518,10 @@ class ChameleonBackbone(nn.Module):
                 wf = (w.float() * self.model.norm.weight.float()[None, :]).to(w.dtype)
                 V, pad = w.shape[0], (-w.shape[0]) % 32
                 if pad:
-                    wf = torch.cat([wf, torch.zeros(pad, w.shape[1], dtype=w.dtype, device=w.device)], dim=0)
+                    # the columns past the vocabulary are never read (K2's rules end at V); they are copies of the last real row, not zeros:
+                    # a tile that is half zeros has no eight-exponent window, and the 12-bit packer declined Emu3's whole 184622-row head for
+                    # that ONE tile (round 5: 14 real rows x 2048 weights "out of window" in the last tile, every other unit <= 60)
+                    wf = torch.cat([wf, wf[-1:].expand(pad, -1)], dim=0)
                 self._head_cols = V + pad
                 self._packed_head = pack(wf, self.HEAD_CFG[0], self.HEAD_CFG[2])
                 del wf

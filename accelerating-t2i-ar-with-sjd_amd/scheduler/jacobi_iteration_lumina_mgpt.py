@@ -82,21 +82,29 @@ def sampling_logits2tokens(logits, all_collected_input_ids, unfinished_sequences
                            do_cfg=False, guidance_scale=3., generator=None, is_force_no_cfg=False):
     """reference JL:82-132 on CUDA tensors: last `output_token_num` rows -> CFG -> grammar/top-k -> softmax ->
     multinomial, all inside kernel K2.  logits: [B_cfg, n, V] fp32.  Returns (next_tokens [1,n], probs [1,n,V])."""
-    if not do_sample:
-        raise NotImplementedError("greedy decoding is not part of the SJD hot path")
     dev = logits.device
     n, V = output_token_num, logits.shape[-1]
     lg = logits[:, -n:, :].float().contiguous()
-    procs = list(logits_processor or []) + list(logits_warper or [])
+    # JL:107: the warpers (top-k / top-p / temperature) only apply when sampling
+    procs = list(logits_processor or []) + (list(logits_warper or []) if do_sample else [])
     gr = grammar_from_processors(procs)
     ctx = all_collected_input_ids[0].tolist()
     gr.start(ctx)
     blob = _rules_blob(dev, n, gr.window_rules(n), use_cfg=do_cfg and not is_force_no_cfg)
-    noise = _draw(lambda t: t.exponential_(generator=generator), (n, V), generator, dev)
+    # do_sample=False (JL:127-129): no draw -- K2 still forms softmax(scores) (noise = 1: its token is the mode of p), the token is the argmax of
+    # the processed SCORES as the reference takes it
+    noise = (_draw(lambda t: t.exponential_(generator=generator), (n, V), generator, dev) if do_sample
+             else torch.ones(n, V, dtype=torch.float32, device=dev))
     probs = torch.empty(n, V, dtype=torch.float32, device=dev)
     toks = torch.empty(n, dtype=torch.int64, device=dev)
     lu = lg[lg.shape[0] // 2] if (do_cfg and lg.shape[0] >= 2) else None
     ops.logits_to_probs_sample(lg[0], lu, guidance_scale, blob, noise, probs, ctypes.c_void_p(toks.data_ptr()))
+    if not do_sample:
+        # exactly torch.argmax(next_token_scores): the scores are the (CFG-combined) logits where the grammar allows a token -- p > 0 -- and -inf
+        # elsewhere; two scores one ulp apart can round to the same p, so the argmax is taken on the scores themselves
+        use_cfg = do_cfg and not is_force_no_cfg and lu is not None
+        z = (guidance_scale * (lg[0] - lu) + lu) if use_cfg else lg[0]
+        toks = torch.argmax(torch.where(probs > 0, z, torch.full_like(z, float("-inf"))), dim=-1)
     if has_eos_stopping_criteria and pad_token_id is not None:
         toks = toks * unfinished_sequences + pad_token_id * (1 - unfinished_sequences)     # JL:130
     return toks[None], probs[None]

@@ -60,7 +60,7 @@ def parse(argv=None):
     ap.add_argument("--no-floor", action="store_true")
     ap.add_argument("--floor-steps", type=int, default=96)
     ap.add_argument("--no-torch-baseline", action="store_true")
-    ap.add_argument("--torch-baseline-steps", type=int, default=24)
+    ap.add_argument("--torch-baseline-steps", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=0, help="scheduler steps of the cpu_baseline sample (0: sized for ~15 s)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -491,7 +491,19 @@ def roofline_blocks(args, prof, prof_g1, pair=None):
             return None, None                   # the committed PMC traffic files were collected at the Lumina-7B shapes
         tpath = os.path.join(ROOT, "profiles", fname)
         try:
-            return json.load(open(tpath)).get("hbm_bytes_per_launch"), f"profiles/{fname} (builder's rocprofv3 --pmc pass at these shapes, not this run)"
+            t = json.load(open(tpath))
+            return t.get("hbm_bytes_per_launch"), f"profiles/{fname}: {t.get('source', 'rocprofv3 --pmc pass')} -- the builder's pass at these shapes, not this run"
+        except Exception:
+            return None, None
+
+    def rocprof_avg():
+        """average G1 launch duration of the committed rocprofv3 --kernel-trace --stats pass over the bench decode (tools/profile_round.sh ->
+        tools/make_traffic_json.py -> profiles/rocprof_g1.json): must agree with this run's graph-pass `avg_us`"""
+        if args.model != "lumina7b":
+            return None, None
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "rocprof_g1.json")))
+            return t.get("avg_us_per_g1_launch"), t.get("source")
         except Exception:
             return None, None
 
@@ -523,6 +535,9 @@ def roofline_blocks(args, prof, prof_g1, pair=None):
                     "avg_bytes": int(alg_b), "launches": prof_g1["launches"], "rows": prof_g1.get("rows", 32),
                     "kernel_time_source": "one pass over all layers' packed weights captured in a hipGraph (the way the engine launches them), "
                                           "replays timed with HIP events on the replay stream; avg over the four projection shapes"}
+        ra, rsrc = rocprof_avg()
+        if ra is not None and prof_g1.get("rows", 32) == 32:
+            g1_block.update({"rocprof_avg_us": ra, "rocprof_source": rsrc})
         if z:
             g1_block.update({"weight_stream": f"lossless 12-bit (G1z / G1sz; {prof_g1['compressed_launches']} of {prof_g1['launches']} launches; "
                                               "results bit-identical to the bf16 stream): `achieved` prices the bf16 bytes of SURVEY.md 8(d), "
@@ -677,16 +692,21 @@ def main():
             lead_in_kv = None
     whole_image = (PP == 1 and not args.no_whole_image)      # every rank decodes on to the end of ITS image: `value` is the whole-image rate
     iter_log = []
+    capture_s = 0.0
     if whole_image and not args.no_graph:
         # untimed, as in the queue leg above: the image's hipGraphs -- both K1 regimes x both probability-buffer parities -- are captured before
         # the clock starts (an engine serves many images with the graphs of its first; each capture is an eager iteration + a recording, ~13 ms)
         pin0 = getattr(attn, "_pin_regime", None)
+        torch.cuda.synchronize()
+        t_cap0 = time.perf_counter()
         for pin in ("keysplit", "colsplit"):
             if hasattr(attn, "_pin_regime"):
                 attn._pin_regime = pin
             eng.decode(prompt, spec, copy.deepcopy(grammar0), cfg, warmup_iters=0, timed_iters=args.warmup + 8)
         if hasattr(attn, "_pin_regime"):
             attn._pin_regime = pin0
+        torch.cuda.synchronize()
+        capture_s = time.perf_counter() - t_cap0
     t_wall0 = time.perf_counter()
     if PP > 1:
         res = eng.decode_many(prompts, specs, [copy.deepcopy(grammar) for _ in range(len(prompts))], cfg, warmup_iters=args.warmup,
@@ -765,6 +785,8 @@ def main():
                               "seconds": round(t_img, 4), "ms_per_step": round(t_img / max(nfe - 1, 1) * 1e3, 4),
                               "tokens_per_s": round((n_tok - 1) / t_img, 2),
                               "steady_ms_per_step": round(steady * 1e3, 4), "steady_tokens_per_s": round((n_tok - 1) / (steady * (nfe - 1)), 2),
+                              "capture_seconds": round(capture_s, 4),        # the untimed warm-up decodes that captured the image's hipGraphs
+                              "tokens_per_s_incl_capture": round((n_tok - 1) / (t_img + capture_s), 2),
                               "finished": bool(seq[-1] in cfg.eos_token_ids),
                               "reference_published_nfe": "1009-1115 (hardware unstated, BASELINE.md)" if args.model == "lumina7b" else None}
         pts = [P, P + n_img // 2 - 24, P + n_img - 112] if args.model != "lumina7b" else [64, 1216, 2368]
@@ -774,6 +796,9 @@ def main():
                 k1 = measure_k1(args, model, attn, device, kv_len=S)
                 out["per_kv"][str(S)].update({"k1_us": round(k1["avg_ms"] * 1e3, 2), "k1_GBps": round(k1["gbps"], 1)})
 
+        # (rounds 1-3 counted the hipGraph captures inside `value`; the old basis stays readable next to the new one)
+        out["value_incl_capture"] = out["whole_image"]["tokens_per_s_incl_capture"] if world == 1 else None
+    out["schema"] = 5           # 5: value_incl_capture, roofline.rocprof_avg_us, torch_baseline over >= 64 steps
     r_main, r_k1 = roofline_blocks(args, prof, prof_g1, pair)
     if r_main is not None:
         out["roofline"] = r_main

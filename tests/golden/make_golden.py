@@ -132,6 +132,35 @@ def gen_fn_logits2tokens_lumina():
     print("fn_logits2tokens_lumina ok", [m["name"] for m in meta])
 
 
+def gen_fn_greedy():
+    """sampling_logits2tokens(do_sample=False) (JL:127-129): argmax of the processed scores, no warper, probs = softmax(scores)"""
+    V = 9216
+    spec = [("mid_row", 12, 4, 4, 11, 16), ("two_eol", 12, 4, 2, 3, 16), ("end_of_image", 12, 2, 2, 12, 16), ("single_row", 12, 4, 4, 20, 1)]
+    out, meta = {}, []
+    for ci, (name, P, hg, wg, nimg, nrows) in enumerate(spec):
+        ctx = lumina_context(P, hg, wg, nimg, seed=300 + ci)
+        logits = torch.randn(2, nrows, V, generator=torch.Generator().manual_seed(3000 + ci)) * 3.0
+        proc = LogitsProcessorList([LP.MultiTokensVLLogitsProcessor(image_start_token_id=8197, image_end_token_id=8196,
+                                                                    image_next_line_token_id=8803, patch_size=32, voc_size=V)])
+        warp = LogitsProcessorList([LP.MultiTokensInterleavedTopKLogitsWarper(image_top_k=2000, text_top_k=10, image_start_token_id=8197,
+                                                                              image_end_token_id=8196)])     # must be IGNORED when not sampling
+        no_cfg = JL.check_is_force_no_cfg(ctx, 8197, 8196)
+        toks, probs = JL.sampling_logits2tokens(logits, ctx, torch.ones(1, dtype=torch.long), None, output_token_num=nrows, logits_processor=proc,
+                                                logits_warper=warp, do_sample=False, has_eos_stopping_criteria=False, do_cfg=True,
+                                                guidance_scale=3.0, generator=None, is_force_no_cfg=no_cfg)
+        cols = sample_cols(V)
+        out[f"{name}.ctx"] = ctx.numpy()
+        out[f"{name}.tokens"] = toks.numpy()
+        out[f"{name}.nnz"] = (probs[0] > 0).sum(-1).numpy()
+        out[f"{name}.pmax"] = probs[0].max(-1).values.numpy()
+        out[f"{name}.p_cols"] = probs[0][:, cols].numpy()
+        meta.append(dict(name=name, V=V, nrows=nrows, logits_seed=3000 + ci, logits_scale=3.0, guidance_scale=3.0, is_force_no_cfg=bool(no_cfg)))
+    out["meta"] = np.array(json.dumps(meta))
+    out["cols"] = sample_cols(V).numpy()
+    np.savez_compressed(os.path.join(HERE, "fn_greedy.npz"), **out)
+    print("fn_greedy ok", [m["name"] for m in meta])
+
+
 def gen_fn_logits2tokens_llamagen():
     from llamagen.llamagen_solver import LlamaGenSolver
     V = 16384
@@ -665,6 +694,8 @@ if __name__ == "__main__":
         gen_fn_anole_grammar()
         gen_fn_speculative_sampler()
         gen_fn_reguess()
+    if "fn" in which or "greedy" in which:
+        gen_fn_greedy()
     if "fn" in which or "temp" in which:
         gen_fn_temperature()
     if "fn" in which or "anole_modes" in which:

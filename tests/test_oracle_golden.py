@@ -72,6 +72,23 @@ def test_logits2tokens_lumina(golden_dir):
         np.testing.assert_allclose(probs[np.arange(len(toks)), toks], d[f"{name}.p_at_tok"], atol=P_ATOL, rtol=P_RTOL)
 
 
+def test_logits2tokens_greedy(golden_dir):
+    """do_sample=False (JL:127-129): warpers off (top-k 0), softmax of the processed scores, token = argmax of the scores -- the oracle's
+    distribution with unit noise has its mode there"""
+    d, meta = load(golden_dir, "fn_greedy.npz")
+    for m in meta:
+        name = m["name"]
+        ctx = d[f"{name}.ctx"][0].tolist()
+        logits = (torch.randn(2, m["nrows"], m["V"], generator=torch.Generator().manual_seed(m["logits_seed"])) * m["logits_scale"]).numpy()
+        rules = O.lumina_rules(ctx, m["nrows"], 0, 0)
+        assert O.lumina_force_no_cfg(ctx) == m["is_force_no_cfg"]
+        u = None if m["is_force_no_cfg"] else logits[1]
+        _, probs = O.logits_to_probs_sample(logits[0], u, m["guidance_scale"], rules, np.ones((m["nrows"], m["V"]), np.float32))
+        z = logits[0] if u is None else (np.float32(m["guidance_scale"]) * (logits[0] - u) + u)
+        toks = np.where(probs > 0, z, -np.inf).argmax(-1)
+        check_probs(d, name, toks, probs, d["cols"], exact_support=False)      # (no top-k: torch keeps denormal tails the canonical exp flushes)
+
+
 def test_logits2tokens_llamagen(golden_dir):
     d, meta = load(golden_dir, "fn_logits2tokens_llamagen.npz")
     for m in meta:

@@ -4,7 +4,7 @@
 #   2. PMC passes (counters only, no trace domains besides kernel-trace): MFMA busy for K1 and G1, HBM traffic for K1 / G1 / K2+head
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
-TAG=${1:-r3}
+TAG=${1:-r5}
 O=gpurun_out
 mkdir -p $O
 B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-cpu-baseline --no-whole-image --no-other-configs"
@@ -27,6 +27,8 @@ for d in $O/prof_${TAG}_k1_* $O/prof_${TAG}_g1_*; do
   echo "# $d" >> $O/${TAG}_pmc_summary.jsonl
   python tools/pmc_summary.py $d k1_ g1_ g1z_ >> $O/${TAG}_pmc_summary.jsonl
 done
+# the figures bench.py quotes (roofline.traffic, roofline.rocprof_avg_us) from THIS round's passes: copy the three files into profiles/
+python tools/make_traffic_json.py ${TAG} $O
 cat $O/${TAG}_pmc_summary.jsonl
 head -30 $O/${TAG}_bench_by_shape.txt
 # keep the merged output small: the raw trace directories stay on the box

@@ -1983,6 +1983,7 @@ extern "C" int sjd_skinny_gemm_reduce(const void *x, const void *w_packed, float
 
 // workgroups of a reducing launch that gave up waiting for their slice's ticket since the library was loaded (0 on a healthy device)
 #include "sjd_gemm_pair.h"
+#include "sjd_gemm_engine.h"
 
 extern "C" int sjd_reduce_timeouts(void)
 {

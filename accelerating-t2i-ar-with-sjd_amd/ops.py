@@ -490,6 +490,27 @@ def weight_prefetch(w_packed, blocks=128, nbytes=None):
     L.check(L.load().sjd_weight_prefetch(_ptr(w_packed), nb, int(blocks), _ptr(sink), _stream()), "sjd_weight_prefetch")
 
 
+def skinny_gemm_engine(x, w_packed, n_wg=None, col0=0, n_cols=None):
+    """G1z in the loader / consumer form (round 5 stage A, csrc/sjd_gemm_engine.h): x [M <= 32, K] bf16, w_packed a tile-major PackedZ ->
+    Partials([n_chunks, 32, n_cols]) bit-identical to skinny_gemm_cols on the same packing.  n_wg: persistent workgroups (default: the largest
+    multiple of the K-chunk count that fits the device's CUs)."""
+    assert isinstance(w_packed, PackedZ) and not w_packed.step_major and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[1] == w_packed.K
+    M, K, KC = x.shape[0], w_packed.K, w_packed.KC
+    n = (w_packed.N - col0) if n_cols is None else n_cols
+    nc = (K + KC - 1) // KC
+    if n_wg is None:
+        cus = torch.cuda.get_device_properties(x.device).multi_processor_count
+        n_wg = max(nc, min(cus // nc, n // 32) * nc)
+    out = torch.empty(nc, 32, n, dtype=torch.float32, device=x.device)
+    L.check(L.load().sjd_skinny_gemm_engine_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), w_packed.cap, _ptr(out), M, n, K, KC, _dtype_code(x.dtype),
+                                             w_packed.N, col0 // 32, int(n_wg), _stream()), "sjd_skinny_gemm_engine_z")
+    return Partials(out, nc, n)
+
+
+def engine_timeouts():
+    return int(L.load().sjd_engine_timeouts())
+
+
 def l2_head(w_packed, M, waves=None, head_pairs=8, gateup=False, col0=0, n_cols=None):
     """-> _lib.L2Head: the first `head_pairs` record pairs of every unit of the G1z (or, gateup=True, G1sz) launch that will stream `w_packed`
     (a PackedZ) for an M-row window with `waves` waves per workgroup -- what a glue launch in front of it pulls into the L2 (round 5)."""
@@ -743,7 +764,7 @@ def mlp_pair(x, gu_packed, dn_packed, inter, hidden, KC_dn, row_norm=None, ready
     nc = (inter + KC_dn - 1) // KC_dn
     rd = ready
     if rd is None:
-        key = (dev, _stream())
+        key = (dev, int(torch.cuda.current_stream(dev).cuda_stream))
         rd = _PAIR_READY.get(key)
         if rd is None or rd.numel() < nc + 1:
             rd = _PAIR_READY[key] = torch.zeros(max(64, nc + 1), dtype=torch.int32, device=dev)

@@ -309,6 +309,16 @@ int sjd_gateup_silu(const void *x, const void *w_packed, void *y, int M, int I, 
  * waves (1..16) = column tiles per workgroup sharing one staged activation chunk; step_major selects the packed record
  * order (0: one contiguous run per tile, 1: the records of all tiles interleaved per k-step). */
 int sjd_gemm_num_chunks(int K, int KC);
+
+/* Round 5 -- G1z in the LOADER / CONSUMER form (csrc/sjd_gemm_engine.h; VERDICT r4 next #1, stage A): one persistent 256-thread workgroup per CU,
+ * wave 0 streams the 12-bit records HBM -> LDS by LDS-DMA into per-consumer rings, waves 1..3 decode them from LDS and run the MFMA sequence of
+ * sjd_skinny_gemm_z -- the same fp32 planes [n_chunks, 32, N], bit for bit.  M <= 32, bf16, tile-major packing (step_major = 0), KC <= 1024;
+ * n_wg = workgroups (the CU count), a multiple of the K-chunk count and <= N / 32 per chunk.  sjd_engine_timeouts: bounded LDS polls that gave
+ * up since the library was loaded (0).  replaces, like G1: the nn.Linear calls of the window forward (reference modeling_chameleon.py:527-529,
+ * 579, 637-643). */
+int sjd_skinny_gemm_engine_z(const void *x, const void *wz, const void *exc, int exc_cap, float *out, int M, int N, int K, int KC,
+                             int dtype, int N_packed, int tile0, int n_wg, void *stream);
+int sjd_engine_timeouts(void);
 /* the same over the N = 32 n columns [32 * tile0, 32 * tile0 + N) of a weight packed with N_packed columns (the output head evaluated on
  * the grammar's column window out of ONE packed copy of lm_head): out [n_chunks, R, N] */
 int sjd_skinny_gemm_cols(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,

@@ -471,6 +471,59 @@ def test_g1z_matches_g1_bit_for_bit(dev, M, N, K, KC, waves, step_major, outlier
     assert torch.equal(cap.view(torch.int32), ref.view(torch.int32))
 
 
+@pytest.mark.parametrize("M,N,K,KC,n_wg", [
+    (32, 12288, 4096, 512, 256),        # q|k|v at the engine's shape: 8 K chunks x 32 workgroups, 12 column tiles (4 per consumer) each
+    (32, 4096, 11008, 688, 256),        # down: 16 chunks of 43 k-steps (an odd count: the last pair is half empty), 8 tiles per workgroup (3 / 3 / 2)
+    (32, 4096, 4096, 512, 256),         # o: 4 tiles per workgroup (2 / 1 / 1)
+    (17, 1024, 1536, 512, 24),          # fewer rows, a small launch: 3 chunks x 8 workgroups
+    (32, 4096, 4096, 1024, 128),        # KC 1024: rings of two slots
+    (5, 256, 640, 512, 2),              # a ragged last chunk (128 columns = 4 pairs: one slot), one workgroup per chunk walking 8 tiles
+])
+@pytest.mark.parametrize("outliers", [0, 300, 3000, 3001])
+def test_g1_engine_matches_g1z_bit_for_bit(dev, M, N, K, KC, n_wg, outliers):
+    """round 5 stage A: G1z in the loader / consumer form (LDS-DMA weight rings, csrc/sjd_gemm_engine.h) writes the SAME split-K planes as
+    g1z_skinny_gemm -- the records take another road into the MFMA (HBM -> LDS -> registers), the decode, the operands and their order do not --
+    eagerly, from poisoned output, forty launches in a row, and from a hipGraph; no bounded poll gives up."""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(N + K + M + outliers)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = _z_weight(N, K, g, dev, min(outliers, 300))
+    if outliers >= 3000:                   # one unit with 50 / 100 out-of-window weights: headers of 64 / 128 entries (two / four header DMAs per slot)
+        n_bad = 50 if outliers == 3000 else 100
+        rr = torch.randint(32, 64, (n_bad,), generator=g)
+        cc = torch.randperm(min(KC, K), generator=g)[:n_bad]
+        w[rr.to(dev), cc.to(dev)] = torch.tensor(37.0, dtype=torch.bfloat16, device=dev)
+    wz = ops.pack_weight_z(w, KC, False)
+    assert wz is not None
+    if outliers >= 3000:
+        assert wz.cap == (64 if outliers == 3000 else 128)
+    ref = ops.skinny_gemm(x, wz, N, K, KC, 8, False).data
+    t0 = ops.engine_timeouts()
+    for _ in range(3):
+        got = ops.skinny_gemm_engine(x, wz, n_wg=n_wg).data
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape and torch.equal(got.view(torch.int32), ref.view(torch.int32)), (got - ref).abs().max()
+    if N >= 1024:                          # a column window (tile0 > 0)
+        c0, nc = 64, N - 192
+        got_c = ops.skinny_gemm_engine(x, wz, n_wg=max(-(-K // KC), (min(n_wg, 64) // -(-K // KC)) * -(-K // KC)), col0=c0, n_cols=nc).data
+        assert torch.equal(got_c, ref[:, :, c0:c0 + nc])
+    outs = [ops.skinny_gemm_engine(x, wz, n_wg=n_wg).data for _ in range(40)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(o.view(torch.int32), ref.view(torch.int32)) for o in outs)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ops.skinny_gemm_engine(x, wz, n_wg=n_wg)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        cap = ops.skinny_gemm_engine(x, wz, n_wg=n_wg).data
+    cap.fill_(float("nan"))
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cap.view(torch.int32), ref.view(torch.int32))
+    assert ops.engine_timeouts() == t0
+
+
 @pytest.mark.parametrize("step_major", [False, True])
 @pytest.mark.parametrize("M,I,K", [(32, 11008, 4096), (17, 11008, 4096), (32, 1408, 512), (5, 128, 1024), (32, 2752, 2048),
                                    (64, 11008, 4096), (40, 1408, 1024), (64, 2752, 2048), (64, 14336, 4096)])       # (the last: Emu3-8B bf16)

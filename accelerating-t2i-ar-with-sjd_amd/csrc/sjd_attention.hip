@@ -711,44 +711,9 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_shared(
 #endif
 #include "sjd_attention_ring.h"
 
-template <int DT> __device__ __forceinline__ float k1c_to_f32(unsigned short h);
-template <> __device__ __forceinline__ float k1c_to_f32<SJD_DTYPE_BF16>(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-template <> __device__ __forceinline__ float k1c_to_f32<SJD_DTYPE_F16>(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
-// PER consecutive columns of one split's O for one row, as loaded: fp32 as stored, or (P16) the raw 16-bit normalised form reinterpreted -- NO
-// arithmetic in the load phase: every split's loads must be in flight before the first value is looked at (a multiply inside the per-split
-// branch made the compiler wait there: sixteen dependent round trips, combine 7.7 -> 11.6 us)
-template <int DT, int D, int PER, bool P16>
-__device__ __forceinline__ void k1c_load_o(const float *__restrict__ ws_o, size_t slot, int d0, float (&o)[PER])
-{
-    if constexpr (P16) {
-        static_assert(PER == 8, "eight 16-bit columns = one 16-byte load");
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned short *>(ws_o) + slot * D + d0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(v[j]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < PER; ++j) o[j] = ws_o[slot * D + d0 + j];
-    }
-}
-// ... and at merge time: the raw form -> O = (O / l) * l in fp32
-template <int DT, int PER, bool P16>
-__device__ __forceinline__ void k1c_unpack_o(float l, float (&o)[PER])
-{
-    if constexpr (P16) {
-        unsigned r[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = __float_as_uint(o[j]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            o[2 * j] = k1c_to_f32<DT>((unsigned short)(r[j] & 0xffffu)) * l;
-            o[2 * j + 1] = k1c_to_f32<DT>((unsigned short)(r[j] >> 16)) * l;
-        }
-    }
-}
-
 // RS (round 4 experiment): row blocks per 16-row chunk = workgroups per (batch, head, chunk).  RS = 2 gives Emu3's shape 256 workgroups instead
 // of 128 (8 rows x 128 d each, one float4 per thread and split; the arithmetic per element is unchanged) -- and measured slower, see the launcher.
-template <int DT, int D, int RS = 1, bool P16 = false>        // P16: the partials' O is O / l in the 16-bit operand type (k1_partial_ring<.., P16>)
+template <int DT, int D, int RS = 1>
 __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
                                                  unsigned short *__restrict__ out, int n_rows, int H, int n_split, int n_chunks,
                                                  const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,
@@ -773,7 +738,8 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
             const size_t slot = (base + q) * K1_ROWS + row;
             ms[q] = ws_ml[slot * 2];
             ls[q] = ws_ml[slot * 2 + 1];
-            k1c_load_o<DT, D, PER, P16>(ws_o, slot, d0, os[q]);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) os[q][j] = ws_o[slot * D + d0 + j];
         }
     int kv_base, n_total, kstart;
     k1_entry(params, key_start, b, kv_len_arg, n_rows, kv_base, n_total, kstart);
@@ -802,12 +768,13 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
                     const size_t slot = (base + s0 + q) * K1_ROWS + row;
                     ms[q] = ws_ml[slot * 2];
                     ls[q] = ws_ml[slot * 2 + 1];
-                    k1c_load_o<DT, D, PER, P16>(ws_o, slot, d0, os[q]);
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) os[q][j] = ws_o[slot * D + d0 + j];
                 }
         }
 #pragma unroll
         for (int q = 0; q < CB; ++q)
-            if (s0 + q < eff_split) { k1c_unpack_o<DT, PER, P16>(ls[q], os[q]); k1_merge_step<PER>(M, L, acc, ms[q], ls[q], os[q]); }
+            if (s0 + q < eff_split) k1_merge_step<PER>(M, L, acc, ms[q], ls[q], os[q]);
     }
     const float inv = L > 0.f ? 1.0f / L : 0.0f;
     if (inv != 12345.678f) SJD_TRC(1);          // (partials arrived)
@@ -1657,29 +1624,9 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
             return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
         }
     }
-    // round 5 experiment, OFF by default: the ring kernel's partials in 16 bits (O / l in the operand type, (m, l) in fp32) --
-    // SJD_K1_P16=1.  Measured (profiles/r5_k1_p16_ab.txt, Emu3 shape, pair per layer in a hipGraph): 18.3 / 25.0 / 33.2 us -> 18.1 / 24.3 / 32.7 at
-    // kv 1024 / 4096 / 8192; rocprofv3: k1_partial_ring 16.9 -> 15.75 us, k1_combine 7.7 -> 7.9.  Halving 16.8 MB of partials buys 0.7 us of 25: the
-    // pair is bound by its two cold starts and the combine's one round trip, not by those bytes -- not worth one more rounding of every split.
-    // Only with the default ring depth and the eight- / four-wave forms (not the two-workgroup "halves" experiment).
-    static const bool p16_env = [] { const char *e = getenv("SJD_K1_P16"); return e && e[0] == '1'; }();
-    static const bool halves_env = getenv("SJD_K1_RING_HALVES") != nullptr;
-    const bool p16 = shared && ring && p16_env && !halves_env && ring_slots == 4;
     if (shared && ring) {
         if constexpr (D == 128) {
 #define SJD_K1R_LAUNCH(NWV_, R_) do {                                                                                                        \
-            const size_t lds = (size_t)(R_) * 2 * K1_KT * D * 2 + (size_t)(NWV_) * K1_ROWS * D * 2;                                          \
-            if (p16) {                                                                                                                      \
-            (void)hipFuncSetAttribute((const void *)k1_partial_ring<DT, D, NWV_, R_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k1_partial_ring<DT, D, NWV_, R_, true>), dim3(n_split, H_kv, B), dim3(64 * NWV_), lds, stream, (const unsigned short *)q, \
-                               (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,  \
-                               kv_len, n_split, n_chunks, B);                                                                               \
-            } else {                                                                                                                        \
-            (void)hipFuncSetAttribute((const void *)k1_partial_ring<DT, D, NWV_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k1_partial_ring<DT, D, NWV_, R_>), dim3(n_split, H_kv, B), dim3(64 * NWV_), lds, stream, (const unsigned short *)q, \
-                               (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,  \
-                               kv_len, n_split, n_chunks, B); } } while (0)
-#define SJD_K1R_LAUNCH8(NWV_, R_) do {                                                                                                       \
             const size_t lds = (size_t)(R_) * 2 * K1_KT * D * 2 + (size_t)(NWV_) * K1_ROWS * D * 2;                                          \
             (void)hipFuncSetAttribute((const void *)k1_partial_ring<DT, D, NWV_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             hipLaunchKernelGGL((k1_partial_ring<DT, D, NWV_, R_>), dim3(n_split, H_kv, B), dim3(64 * NWV_), lds, stream, (const unsigned short *)q, \
@@ -1693,10 +1640,9 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
                                    (const unsigned short *)kc, (const unsigned short *)vc, params, key_start, ws_o, ws_ml, n_rows, H, H_kv, S_max,
                                    kv_len, n_split, n_chunks, B, 2);
             } else
-            if (pairs == 8) { if (ring_slots == 4) SJD_K1R_LAUNCH(8, 4); else if (ring_slots == 8) SJD_K1R_LAUNCH8(8, 8); else SJD_K1R_LAUNCH8(8, 6); }
-            else { if (ring_slots == 4) SJD_K1R_LAUNCH(4, 4); else if (ring_slots == 8) SJD_K1R_LAUNCH8(4, 8); else SJD_K1R_LAUNCH8(4, 6); }
+            if (pairs == 8) { if (ring_slots == 4) SJD_K1R_LAUNCH(8, 4); else if (ring_slots == 8) SJD_K1R_LAUNCH(8, 8); else SJD_K1R_LAUNCH(8, 6); }
+            else { if (ring_slots == 4) SJD_K1R_LAUNCH(4, 4); else if (ring_slots == 8) SJD_K1R_LAUNCH(4, 8); else SJD_K1R_LAUNCH(4, 6); }
 #undef SJD_K1R_LAUNCH
-#undef SJD_K1R_LAUNCH8
         }
     } else if (shared) {
         if constexpr (D == 128) {
@@ -1733,15 +1679,8 @@ static int launch_attention(const void *q, const void *kc, const void *vc, void 
         // (measured, round 4: SLOWER -- Emu3 pair 22.2 -> 24.8 us, Lumina 14.1 -> 14.8 us, profiles/r4_k1_combine_rs.txt -- the launch is bound by
         //  its cold start and its one round trip, not by the CUs it covers; off unless SJD_K1_COMBINE_RS=2)
         static const bool rs2 = [] { const char *e = getenv("SJD_K1_COMBINE_RS"); return e && e[0] == '2'; }();
-        if (rs2 && !p16 && (long)n_chunks * H * B <= 256) {
+        if (rs2 && (long)n_chunks * H * B <= 256) {
             hipLaunchKernelGGL((k1_combine<DT, D, 2>), dim3(2 * n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
-                               n_split, n_chunks, params, key_start, kv_len);
-            return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
-        }
-    }
-    if constexpr (D == 128) {
-        if (p16) {
-            hipLaunchKernelGGL((k1_combine<DT, D, 1, true>), dim3(n_chunks, H, B), dim3(256), 0, stream, ws_o, ws_ml, (unsigned short *)out, n_rows, H,
                                n_split, n_chunks, params, key_start, kv_len);
             return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
         }

@@ -78,10 +78,7 @@ __device__ __forceinline__ float k1r_sum_across_groups(float v)
 }
 
 // NWV = waves per workgroup = (q head of the group, 16-row chunk) pairs: 4 or 8.  R = ring slots.
-// P16 (round 5): the split partial leaves as (m, l) in fp32 and O / l -- the split's NORMALISED output, bounded by max |v| -- in the
-// 16-bit operand type: half the bytes of the partials' round trip through HBM (Emu3: 16.8 MB out + 16.8 MB back per layer, 45 % of what the pair
-// moved).  One more rounding per split, of a value of the output's magnitude; k1_combine<.., P16> multiplies l back in and merges as before.
-template <int DT, int D, int NWV, int R, bool P16 = false>
+template <int DT, int D, int NWV, int R>
 __global__ __launch_bounds__(64 * NWV) void k1_partial_ring(
     const unsigned short *__restrict__ q, const unsigned short *__restrict__ kc, const unsigned short *__restrict__ vc,
     const sjd_iter_params *__restrict__ params, const int *__restrict__ key_start,        // (among the first 16 dwords: preloaded into SGPRs)
@@ -132,15 +129,7 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_ring(
         total_max = max(total_max, tot);
     }
     if (bt1 <= bt0) {                         // no wave of this workgroup has a tile in this split
-        if (wave_on) {
-            const size_t s0 = ((((size_t)b * H + head) * n_chunks + chunk) * n_split + split) * K1_ROWS;
-            if constexpr (P16) {
-                unsigned short *w16 = reinterpret_cast<unsigned short *>(ws_o);
-#pragma unroll
-                for (int db = 0; db < DB; ++db) *reinterpret_cast<uint2 *>(w16 + (s0 + c) * D + 16 * db + 4 * g) = uint2{0u, 0u};
-                if (g == 0) { ws_ml[(s0 + c) * 2] = -INFINITY; ws_ml[(s0 + c) * 2 + 1] = 0.f; }
-            } else k1_store_empty_partial<D>(ws_o, ws_ml, s0, c, g);
-        }
+        if (wave_on) k1_store_empty_partial<D>(ws_o, ws_ml, ((((size_t)b * H + head) * n_chunks + chunk) * n_split + split) * K1_ROWS, c, g);
         return;
     }
     SJD_TR(1);                    // tile ranges known
@@ -315,20 +304,8 @@ __global__ __launch_bounds__(64 * NWV) void k1_partial_ring(
     if (!wave_on) return;
     // the wave covered every tile of its split: its (m, l, O) is the split partial
     const size_t slot0 = ((((size_t)b * H + head) * n_chunks + chunk) * n_split + split) * K1_ROWS;
-    if constexpr (P16) {
-        unsigned short *w16 = reinterpret_cast<unsigned short *>(ws_o);
-        const float inv = l_run > 0.f ? 1.0f / l_run : 0.0f;
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            uint2 pk;
-            pk.x = (unsigned)Frag<DT>::cvt(o_acc[db][0] * inv) | ((unsigned)Frag<DT>::cvt(o_acc[db][1] * inv) << 16);
-            pk.y = (unsigned)Frag<DT>::cvt(o_acc[db][2] * inv) | ((unsigned)Frag<DT>::cvt(o_acc[db][3] * inv) << 16);
-            *reinterpret_cast<uint2 *>(w16 + (slot0 + c) * D + 16 * db + 4 * g) = pk;
-        }
-    } else {
-#pragma unroll
-        for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(ws_o + (slot0 + c) * D + 16 * db + 4 * g) = o_acc[db];
-    }
+    for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(ws_o + (slot0 + c) * D + 16 * db + 4 * g) = o_acc[db];
     if (g == 0) { ws_ml[(slot0 + c) * 2] = m_run * scale; ws_ml[(slot0 + c) * 2 + 1] = l_run; }       // (m in the units k1_combine merges in)
 #ifdef SJD_TRACE
     SJD_TR(4);

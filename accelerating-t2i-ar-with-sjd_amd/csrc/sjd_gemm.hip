@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512) void g1_skinny_gemm_tiled(const unsigned short
 // 25.0 -> 22.5 alone, but 5.098 -> 5.091 ms per step with four prompts: the consumer kernel pays for them).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t g1z_unit_rsrc(const unsigned char *first_record, unsigned bytes);
 template <int DT, int MT, int NW>           // NW = 4: two workgroups per CU; NW = 8 (late round 3): one, its staged sub-tile shared by eight column tiles
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void g1_skinny_gemm_tiled8(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
+__global__ __launch_bounds__(64 * NW, (NW == 4 && MT <= 4) ? 2 : 1) void g1_skinny_gemm_tiled8(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                                 float *__restrict__ out, int M, int N, int K, int KC, int n_tiles,
                                                                 int rec_stride, int tile0)
 {
@@ -1867,6 +1867,15 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
     const dim3 grid((n_out + waves - 1) / waves, n_chunks), block(waves * 64);
     const size_t lds_whole = (size_t)MT * ((KC < K ? KC : K) / 16) * 64 * 16;       // the whole activation chunk staged at once
     static const bool force_tiled = [] { const char *e = getenv("SJD_G1_TILED"); return e && e[0] == '1'; }();      // tuning aid (64-row windows)
+    if constexpr (MT > 4) {      // round 5: 129..256-row windows (five to eight prompts per forward): the 8-step sub-tiled kernel with four waves, ONE
+        // workgroup per CU (a wave holds MT x 16 accumulators + 2 MT staging pieces + the weight ring: > 256 registers), 2 x MT x 8 KiB of LDS
+        if (waves != 4) return SJD_ERR_BAD_ARG;
+        const size_t lds_8 = (size_t)2 * MT * 8 * 1024;
+        (void)hipFuncSetAttribute((const void *)g1_skinny_gemm_tiled8<DT, MT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_8);
+        hipLaunchKernelGGL((g1_skinny_gemm_tiled8<DT, MT, 4>), grid, block, lds_8, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K,
+                           KC, n_tiles, step_major ? n_tiles : 1, tile0);
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+    } else
     if constexpr (MT >= 2) if (MT > 2 || lds_whole > 160 * 1024 || (force_tiled && waves <= 8)) {     // sub-tiled activation: no limit on KC
         if (waves > 8) return SJD_ERR_BAD_ARG;
         static const bool sub8 = [] { const char *e = getenv("SJD_G1_SUB8"); return !(e && e[0] == '0'); }();      // (A/B aid: 0 = the 16-step kernel for every wave count)
@@ -1912,7 +1921,7 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
 extern "C" int sjd_skinny_gemm_cols(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,
                                     int dtype, int N_packed, int tile0, void *stream)
 {
-    if (!x || !w_packed || !out || M < 1 || M > 128 || N < 32 || (N % 32) != 0 || (N_packed % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0)
+    if (!x || !w_packed || !out || M < 1 || M > 256 || N < 32 || (N % 32) != 0 || (N_packed % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0)
         return SJD_ERR_BAD_ARG;
     if (waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -1923,15 +1932,19 @@ extern "C" int sjd_skinny_gemm_cols(const void *x, const void *w_packed, float *
     if (dtype == SJD_DTYPE_F16 && M <= 64) return g1_launch<SJD_DTYPE_F16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
     if (dtype == SJD_DTYPE_BF16 && M <= 96) return g1_launch<SJD_DTYPE_BF16, 3>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
     if (dtype == SJD_DTYPE_F16 && M <= 96) return g1_launch<SJD_DTYPE_F16, 3>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
-    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
-    if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_BF16 && M <= 128) return g1_launch<SJD_DTYPE_BF16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_F16 && M <= 128) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_BF16 && M <= 160) return g1_launch<SJD_DTYPE_BF16, 5>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_BF16 && M <= 192) return g1_launch<SJD_DTYPE_BF16, 6>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_BF16 && M <= 224) return g1_launch<SJD_DTYPE_BF16, 7>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
+    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16, 8>(x, w_packed, out, M, N, K, KC, waves, step_major, s, np, tile0);
     return SJD_ERR_UNSUPPORTED;
 }
 
 extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int waves, int step_major,
                                int dtype, void *stream)
 {
-    if (!x || !w_packed || !out || M < 1 || M > 128 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
+    if (!x || !w_packed || !out || M < 1 || M > 256 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
     if (waves < 1 || waves > 16) return SJD_ERR_BAD_ARG;       // (the staged activation chunk must fit in LDS: min(KC, K) <= 2560 / 1280)
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SJD_DTYPE_BF16 && M <= 32) return g1_launch<SJD_DTYPE_BF16, 1>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
@@ -1940,8 +1953,12 @@ extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, 
     if (dtype == SJD_DTYPE_F16 && M <= 64) return g1_launch<SJD_DTYPE_F16, 2>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
     if (dtype == SJD_DTYPE_BF16 && M <= 96) return g1_launch<SJD_DTYPE_BF16, 3>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
     if (dtype == SJD_DTYPE_F16 && M <= 96) return g1_launch<SJD_DTYPE_F16, 3>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
-    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
-    if (dtype == SJD_DTYPE_F16) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_BF16 && M <= 128) return g1_launch<SJD_DTYPE_BF16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_F16 && M <= 128) return g1_launch<SJD_DTYPE_F16, 4>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_BF16 && M <= 160) return g1_launch<SJD_DTYPE_BF16, 5>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_BF16 && M <= 192) return g1_launch<SJD_DTYPE_BF16, 6>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_BF16 && M <= 224) return g1_launch<SJD_DTYPE_BF16, 7>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
+    if (dtype == SJD_DTYPE_BF16) return g1_launch<SJD_DTYPE_BF16, 8>(x, w_packed, out, M, N, K, KC, waves, step_major, s);
     return SJD_ERR_UNSUPPORTED;
 }
 

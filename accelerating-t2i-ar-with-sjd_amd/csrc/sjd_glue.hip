@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restr
 extern "C" int sjd_add_rmsnorm(void *h, const void *delta, const void *weight, void *y, int rows, int hidden, float eps, int dtype,
                                const float *part, int n_chunks, void *stream)
 {
-    if (part && (rows > 128 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    if (part && (rows > 256 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
     const int prows = ((rows + 31) / 32) * 32;      // row padding of the G1 partials
     if (!h || !weight || !y || rows < 1 || hidden < 8 || (hidden % 8) != 0 || hidden > 256 * 8 * 4) return SJD_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -577,7 +577,7 @@ static int f2_launch(const void *qkv, void *q_out, void *k_cache, void *v_cache,
                      int dtype, const sjd_iter_params *params, int kv_len, const float *part, int n_chunks, bool kv8, float k_scale,
                      float v_scale, const sjd_row_norm *rn, void *stream)
 {
-    if (part && (B * n > 128 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    if (part && (B * n > 256 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
     if (rn && (!part || !rn->sumsq || rn->slices < 1 || rn->hidden < 1)) return SJD_ERR_BAD_ARG;
     const int prows = ((B * n + 31) / 32) * 32;
     if ((!qkv && !part) || !q_out || !k_cache || !v_cache || !inv_freq || !positions || B < 1 || n < 1 || H < 1 || H_kv < 1) return SJD_ERR_BAD_ARG;
@@ -637,7 +637,7 @@ extern "C" int sjd_qknorm_rope_append_ex(const void *qkv, void *q_out, void *k_c
 
 extern "C" int sjd_residual_sumsq(void *h, const float *part, int n_chunks, int rows, int hidden, int dtype, float *out_sumsq, void *stream)
 {
-    if (!h || !out_sumsq || rows < 1 || rows > 128 || (part && n_chunks < 1) || hidden < 4 || (hidden % 4) != 0) return SJD_ERR_BAD_ARG;
+    if (!h || !out_sumsq || rows < 1 || rows > 256 || (part && n_chunks < 1) || hidden < 4 || (hidden % 4) != 0) return SJD_ERR_BAD_ARG;
     const int prows = ((rows + 31) / 32) * 32;
     const dim3 grid(rows, (hidden + 511) / 512), block(128);
     hipStream_t s = (hipStream_t)stream;
@@ -655,7 +655,7 @@ extern "C" int sjd_residual_sumsq_pf(void *h, const float *part, int n_chunks, i
                                      const sjd_l2_head *head, int pf_blocks, void *stream)
 {
     if (!head || pf_blocks < 1) return sjd_residual_sumsq(h, part, n_chunks, rows, hidden, dtype, out_sumsq, stream);
-    if (!h || !out_sumsq || rows < 1 || rows > 128 || (part && n_chunks < 1) || hidden < 4 || (hidden % 4) != 0 || !head->wz) return SJD_ERR_BAD_ARG;
+    if (!h || !out_sumsq || rows < 1 || rows > 256 || (part && n_chunks < 1) || hidden < 4 || (hidden % 4) != 0 || !head->wz) return SJD_ERR_BAD_ARG;
     const int prows = ((rows + 31) / 32) * 32, n_slices = (hidden + 511) / 512;
     // the pull's XCD arithmetic needs (i) F1r's own workgroup count and (ii) the pulling workgroup count to be multiples of 8
     int pf_rows = (pf_blocks + rows - 1) / rows;
@@ -674,7 +674,7 @@ extern "C" int sjd_residual_sumsq_pf(void *h, const float *part, int n_chunks, i
 static int f3_launch(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks, const sjd_row_norm *rn,
                      void *stream)
 {
-    if (part && (rows > 128 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
+    if (part && (rows > 256 || n_chunks < 1)) return SJD_ERR_BAD_ARG;
     if (rn && (!part || !rn->sumsq || rn->slices < 1 || rn->hidden < 1)) return SJD_ERR_BAD_ARG;
     const int prows = ((rows + 31) / 32) * 32;
     if ((!gate_up && !part) || !y || rows < 1 || inter < 8 || (inter % 8) != 0) return SJD_ERR_BAD_ARG;

@@ -1,7 +1,7 @@
 """Several prompts per GPU in ONE window forward (the reference decodes one prompt per process).
 
 A draft-window forward is a pure weight stream: 13 GB of weights for 32 activation rows.  Two prompts (2 x B_cfg x L = 64 rows)
-cost the same stream, so decoding them together almost doubles the accepted tokens per second of a GPU; up to four prompts (128 rows,
+cost the same stream, so decoding them together almost doubles the accepted tokens per second of a GPU; up to eight prompts (256 rows; the rate is flat beyond four: DESIGN.md 10b;
 G1's sub-tiled kernel) fit in one forward: 963 / 1292 tokens/s per MI355X for two / four Lumina 768px prompts against 561 for one.  Every prompt ("slot")
 keeps exactly the state machine of `SJDEngine.decode` -- its own window, accept length, KV length, grammar, device generator
 and CPU generator for the fresh ids -- so each slot takes the decisions its solo run would take on the same logits; only the
@@ -44,8 +44,8 @@ class SJDBatchEngine:
         L.load()                                   # fail loudly if the HIP extension is missing
         if max_window > L.MAX_WINDOW:
             raise ValueError(f"max_window {max_window} > {L.MAX_WINDOW}")
-        if n_prompts * n_batch * max_window > 128:
-            raise ValueError("the window forward (G1, F1-F3) serves at most 128 rows: n_prompts * n_batch * max_window <= 128")
+        if n_prompts * n_batch * max_window > 256:
+            raise ValueError("the window forward (G1, F1-F3) serves at most 256 rows: n_prompts * n_batch * max_window <= 256")
         self.backbone, self.V, self.device = backbone, int(vocab_size), torch.device(device)
         self.P, self.nb, self.Lmax, self.B = n_prompts, n_batch, max_window, n_prompts * n_batch
         self.use_graph, self.narrow_head = use_graph, narrow_head

@@ -420,7 +420,7 @@ def pack_weight_z(weight, KC, step_major=False):
 
 
 def _prows(M):
-    """row padding of the G1 partial planes: whole 32-row MFMA tiles (M <= 128: up to four prompts per forward)"""
+    """row padding of the G1 partial planes: whole 32-row MFMA tiles (M <= 256: up to eight prompts per forward)"""
     return ((int(M) + 31) // 32) * 32
 
 

@@ -111,7 +111,8 @@ def build_model(args, device):
     with torch.device(device):
         model = BB.ChameleonBackbone(margs, attn=attn).to(dt).eval()
     if args.prompts_per_gpu > 1 and args.model != "emu3_8b":      # 64-row windows: the staged activation chunk (64 x KC) must fit in LDS
-        model.G1_CFG = dict(model.G1_CFG_64ROW if args.prompts_per_gpu == 2 else model.G1_CFG_128ROW)
+        rows_ = 2 * args.prompts_per_gpu * args.window
+        model.G1_CFG = dict(model.G1_CFG_64ROW if rows_ <= 64 else model.G1_CFG_128ROW if rows_ <= 128 else model.G1_CFG_256ROW)
     if args.model == "emu3_8b":      # 64-row windows (draft window 32) need activation chunks <= 1280 columns
         model.G1_CFG = dict(model.G1_CFG_EMU3)
     if os.environ.get("SJD_HEAD_CFG"):     # tuning aid: JSON [KC, waves, step_major] of the output head's G1 launch
@@ -296,7 +297,7 @@ def measure_g1(args, model, device, rounds=6):
     shapes = dict(qkv=((H + 2 * Hkv) * D, hid), o=(hid, H * D), gate_up=(2 * inter, hid), down=(hid, inter))
     # the activation rows of the decode's own launches: B_cfg (= 2: cond || uncond) x prompts per forward x draft window -- 32 for the headline,
     # 64 for Emu3's window of 32 (round 3 staged 32 rows for every model and so priced Emu3's projections on a launch shape it does not run)
-    rows = min(128, 2 * max(1, args.prompts_per_gpu) * args.window)
+    rows = min(256, 2 * max(1, args.prompts_per_gpu) * args.window)
     xs = {k: torch.randn(rows, K, device=device).to(model.lm_head.weight.dtype) for k, (N, K) in shapes.items()}
     cfg = model.G1_CFG
 

@@ -297,7 +297,11 @@ def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=
     conf = dict(vocab_size=V, hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
                 num_key_value_heads=4, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
     model = make_chameleon(conf, 23, embed_token_scale, ops.HipWindowAttention(n_split=2), dtype=dtype, device=device)
-    model.enable_fused(ops, gemm=gemm)
+    wide = (n_slots or n_prompts) * 2 * window > 128
+    if wide:        # 129..256 window rows (five to eight prompts per forward, round 5): four-wave workgroups on the uncompressed packing
+        model.G1_CFG = dict(qkv=(256, 4, True), o=(128, 4, True), gate_up=(256, 4, True), down=(128, 4, True))
+        model.HEAD_CFG = (256, 4, True)
+    model.enable_fused(ops, gemm=gemm, compress=False if wide else None)
     n_img = (2 * wg + 1) * 2 * hg
     prompts, specs = [], []
     for i in range(n_prompts):
@@ -315,9 +319,22 @@ def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=
                     seed=seed, prefix_token_sampler_scheme="speculative_jacobi", max_length=1 << 20, eos_token_ids=(8196,),
                     multi_token_init_scheme=init_scheme)
     eng = SJDBatchEngine(model, V, device, n_slots, max_window=window, use_graph=use_graph)
+    if wide and gemm == "sjd":       # the hand-written projections must be what runs (not the library-GEMM prefill path)
+        calls = []
+        orig = ops.skinny_gemm
+        def spy(x_, *a, **k):
+            calls.append(int(x_.shape[0]))
+            return orig(x_, *a, **k)
+        ops.skinny_gemm = spy
     recs = [_Recorder() for _ in range(n_prompts)]
     eng.hook = lambda i, d: recs[i](d)
-    results = eng.decode_many(prompts, specs, [LuminaGrammar(2000, 10) for _ in range(n_prompts)], cfg)
+    try:
+        results = eng.decode_many(prompts, specs, [LuminaGrammar(2000, 10) for _ in range(n_prompts)], cfg)
+    finally:
+        if wide and gemm == "sjd":
+            ops.skinny_gemm = orig
+    if wide and gemm == "sjd":
+        assert calls and max(calls) == n_slots * 2 * window, "the window forward did not run on G1 at its full row count"
     out = []
     for i, (seq, stats) in enumerate(results):
         c = _loop_cfg(cfg)

@@ -152,6 +152,33 @@ def test_g1_skinny_gemm_three_and_four_row_tiles(dev, dtype, M, N, K, KC, waves,
         ops.skinny_gemm(x, ops.pack_weight(w, KC, step_major), N, K, KC, waves=11, step_major=step_major)      # > 8 waves: 256 VGPRs needed
 
 
+@pytest.mark.parametrize("M,N,K,KC", [(256, 4096, 11008, 1376), (192, 12288, 4096, 2048), (160, 22016, 4096, 2048), (224, 4096, 4096, 896), (130, 512, 1376, 256),
+                                        (256, 64, 96, 32), (255, 256, 176, 64)])
+@pytest.mark.parametrize("step_major", [True, False])
+def test_g1_skinny_gemm_five_to_eight_row_tiles(dev, M, N, K, KC, step_major):
+    """round 5: 129..256-row windows (five to eight prompts per forward): g1_skinny_gemm_tiled8 with five to eight row tiles, four waves, one
+    workgroup per CU -- against an fp32 matmul, and plane for plane against the 32-row kernel fed 32 rows at a time (same chunking, same
+    accumulation order: bit-identical); bf16, four-wave workgroups only."""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(N + K + M)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
+    wp = ops.pack_weight(w, KC, step_major)
+    part = ops.skinny_gemm(x, wp, N, K, KC, waves=4, step_major=step_major)
+    assert part.n_chunks == (K + KC - 1) // KC and part.data.shape[1] == ((M + 31) // 32) * 32
+    torch.testing.assert_close(part.data.sum(0)[:M], x.float() @ w.float().t(), atol=2e-3, rtol=2e-3)
+    if M < part.data.shape[1]:
+        assert part.data[:, M:].abs().max() == 0
+    for r0 in range(0, M, 32):
+        p32 = ops.skinny_gemm(x[r0:r0 + 32].contiguous(), wp, N, K, KC, waves=4, step_major=step_major)
+        rows = min(32, M - r0)
+        assert torch.equal(p32.data[:, :rows], part.data[:, r0:r0 + rows])
+    with pytest.raises(RuntimeError):
+        ops.skinny_gemm(x, wp, N, K, KC, waves=8, step_major=step_major)          # more than 128 rows: four-wave workgroups only
+    with pytest.raises(RuntimeError):
+        ops.skinny_gemm(x.to(torch.float16), wp, N, K, KC, waves=4, step_major=step_major)      # ... and bf16 only
+
+
 def test_partials_feed_glue_kernels(dev):
     import sjd_amd.ops as ops
     g = torch.Generator().manual_seed(5)

@@ -105,6 +105,14 @@ def test_three_and_four_prompts_share_one_window_forward(n_prompts, fp8_kv):
     assert len(rs) == n_prompts and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs) and any(r["max_accept"] > 1 for r in rs)
 
 
+@pytest.mark.parametrize("n_prompts,use_graph", [(5, True), (6, False), (8, True)])
+def test_five_to_eight_prompts_share_one_window_forward(n_prompts, use_graph):
+    """round 5: 160 / 192 / 256 window rows per forward (G1 with five to eight row tiles, F1r / F2 / F3 over 256 rows, K1 over 16 batch rows): every
+    slot still takes exactly the decisions of its own oracle replay."""
+    rs = G.teacher_forced_batch_check(n_prompts=n_prompts, P=(12, 9, 14, 7, 10, 8, 13, 11), use_graph=use_graph)
+    assert len(rs) == n_prompts and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs) and any(r["max_accept"] > 1 for r in rs)
+
+
 @pytest.mark.parametrize("temperature,use_graph,gemm", [(0.7, True, "sjd"), (1.6, False, "torch")])
 def test_lumina_loop_with_temperature(temperature, use_graph, gemm):
     """GenerationConfig.temperature != 1 through the whole loop: every window's K2 and every rejection's K4 resample under the

@@ -21,6 +21,7 @@ def renew_end_of_line_logit_processor_3d(model_class):
     """reference JE:41-151"""
     class EOLLogitProcessor3d(model_class, _Descriptor):
         __call__ = _Descriptor.__call__
+        filter_value = "finfo.min"          # (direct calls: removed entries hold torch.finfo(dtype).min, JE:80)
 
     return EOLLogitProcessor3d
 

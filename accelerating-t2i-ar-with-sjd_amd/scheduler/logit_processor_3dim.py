@@ -24,10 +24,64 @@ def eol_positions_in_multitokens(tokenlen, new_pred_tokenlen, line_len):
     return [j for j in range(new_pred_tokenlen) if (tokenlen + 1 + j) % line_len == 0]
 
 
+def apply_row_rules(scores, rules, filter_value=-float("inf"), forced_fill=-float("inf")):
+    """The row rules of a window (sjd_row_rule per row, what kernels K2 / K4 apply) on a [..., L, V] score tensor, with ATen ops and in the
+    kernels' order: forced row -> (-inf, ..., 0 at the forced id, ...) (LP:31-43); allowed id ranges -> everything else `filter_value`; top-k (ties
+    kept: scores < k-th largest go, LP:190-204); temperature; top-p (HF's rule, LP:355-419).  This is the processors' direct-call form -- a user
+    calling a processor object on a tensor as the reference's objects allow -- not the hot path."""
+    out = scores.clone()
+    V = out.shape[-1]
+    for r, rule in enumerate(rules):
+        row = out[..., r, :]
+        if rule.forced >= 0:
+            row.fill_(forced_fill)
+            row[..., rule.forced] = 0
+            continue
+        if rule.n_ranges > 0:
+            keep = torch.zeros(V, dtype=torch.bool, device=out.device)
+            for i in range(rule.n_ranges):
+                keep[rule.lo[i]:rule.hi[i]] = True
+            row.masked_fill_(~keep, filter_value)
+        if rule.top_k > 0:
+            kth = torch.topk(row, min(int(rule.top_k), V))[0][..., -1, None]
+            row.masked_fill_(row < kth, filter_value)
+        if rule.temperature != 1.0:
+            row.div_(rule.temperature)
+        if rule.top_p_thr >= 0:                    # top_p_thr = 1 - top_p: ascending cumulative probabilities <= it are removed, the top token stays
+            srt, idx = torch.sort(row, descending=False)
+            cum = srt.softmax(dim=-1).cumsum(dim=-1)
+            rm = cum <= rule.top_p_thr
+            rm[..., -1:] = False
+            row.masked_fill_(rm.scatter(-1, idx, rm), filter_value)
+    return out
+
+
 class _Descriptor:
+    """A logits processor as a DESCRIPTOR: `_sample` turns the processor list into an integer grammar whose row rules kernels K2 / K4 apply.
+    Called on tensors directly (reference usage outside generate()), the processors whose grammar is self-contained -- the Lumina, Emu3 and
+    top-k / top-p / temperature ones -- evaluate the same rules with ATen ops (apply_row_rules); the Anole single-purpose processors only have a
+    grammar as the LIST jacobi_iteration_anhole builds and raise when called alone."""
+
+    def _solo_rules(self, ctx, n):
+        gr = grammar_from_processors([self])
+        gr.start(ctx)
+        return gr.window_rules(n)
+
     def __call__(self, input_ids, scores):
-        raise RuntimeError(f"{type(self).__name__} is evaluated inside the HIP kernels (K2/K4) by JacobiSampler._sample; "
-                           "it is not callable on tensors in this engine")
+        three = scores.dim() >= 3
+        sc = scores if three else scores.unsqueeze(-2)
+        try:
+            rules = self._solo_rules(input_ids[0].tolist(), sc.shape[-2])
+        except NotImplementedError as e:
+            raise RuntimeError(f"{type(self).__name__} has no grammar of its own (it is one entry of the processor LIST the kernels' grammar is "
+                               f"built from, scheduler/jacobi_iteration_anhole.py): {e}") from None
+        fv = getattr(self, "filter_value", -float("inf"))
+        if fv == "finfo.min":                     # Emu3's processor removes with the dtype's most negative finite value, forced rows included (JE:80-123)
+            fv = torch.finfo(sc.dtype).min
+            out = apply_row_rules(sc, rules, fv, forced_fill=fv)
+        else:
+            out = apply_row_rules(sc, rules, fv)
+        return out if three else out.squeeze(-2)
 
 
 class MultiTokensVLLogitsProcessor(_Descriptor):
@@ -51,6 +105,13 @@ class MultiTokensInterleavedTopKLogitsWarper(_Descriptor):
         self.image_top_k = max(image_top_k, min_tokens_to_keep)
         self.text_top_k = max(text_top_k, min_tokens_to_keep)
         self.image_start_token_id, self.image_end_token_id = image_start_token_id, image_end_token_id
+        self.filter_value = filter_value
+
+    def _solo_rules(self, ctx, n):
+        """LP:190-204: top-k alone, k by whether an image is open (one more <start> than <end> in the context)"""
+        from .. import ops
+        in_image = ctx.count(self.image_start_token_id) == ctx.count(self.image_end_token_id) + 1
+        return [ops.make_rule(top_k=self.image_top_k if in_image else self.text_top_k)] * n
 
 
 class TopPLogitsWarper3d(_Descriptor):
@@ -92,6 +153,10 @@ class TemperatureLogitsWarper(_Descriptor):
         if not isinstance(temperature, (int, float)) or not (temperature > 0):
             raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float")        # HF's own check
         self.temperature = float(temperature)
+
+    def _solo_rules(self, ctx, n):
+        from .. import ops
+        return [ops.make_rule(temperature=self.temperature)] * n
 
 
 class AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(_Descriptor):

@@ -161,6 +161,67 @@ def gen_fn_greedy():
     print("fn_greedy ok", [m["name"] for m in meta])
 
 
+def gen_fn_processor_calls():
+    """The processors called DIRECTLY on score tensors, one at a time (LP:84-155, 190-204, 406-455; JE:41-151): which entries stay finite, and
+    the values there -- what the mirror's descriptor objects must reproduce when a user calls them outside generate()."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper
+    import scheduler.jacobi_iteration_emu3 as JE
+    from emu3.mllm.utils_emu3 import Emu3PrefixConstrainedLogitsHelper
+    V = 9216
+    out, meta = {}, []
+    cols = sample_cols(V)
+
+    def put(name, ctx, scores, res, **kw):
+        out[f"{name}.ctx"] = ctx.numpy()
+        out[f"{name}.finite"] = np.packbits((res > torch.finfo(res.dtype).min).numpy().reshape(-1))      # kept entries (-inf and finfo.min both mean "removed")
+        out[f"{name}.vals"] = res[..., cols].numpy()
+        out[f"{name}.rowmax"] = res.max(-1).values.numpy()
+        meta.append(dict(name=name, shape=list(scores.shape), **kw))
+
+    spec = [("mid_row", 12, 4, 4, 11, 16), ("two_eol", 12, 4, 2, 3, 16), ("end_of_image", 12, 2, 2, 12, 16), ("after_start_1", 12, 4, 4, -2, 4),
+            ("text_mode", 12, 4, 4, -4, 3), ("two_dim", 12, 4, 4, 7, 1)]
+    for ci, (name, P, hg, wg, nimg, nrows) in enumerate(spec):
+        ctx = lumina_context(P, hg, wg, max(nimg, 0), seed=400 + ci)
+        if nimg < 0:
+            ctx = ctx[:, : P + 3 + (nimg + 1)] if nimg > -4 else ctx[:, :P]
+        scores = torch.randn(1, nrows, V, generator=torch.Generator().manual_seed(4000 + ci)) * 3.0
+        if name == "two_dim":
+            scores = scores[:, 0]
+        vl = LP.MultiTokensVLLogitsProcessor(image_start_token_id=8197, image_end_token_id=8196, image_next_line_token_id=8803, patch_size=32, voc_size=V)
+        put("vl_" + name, ctx, scores, vl(ctx, scores.clone()), kind="vl", seed=4000 + ci, scale=3.0)
+        tk = LP.MultiTokensInterleavedTopKLogitsWarper(image_top_k=2000, text_top_k=10, image_start_token_id=8197, image_end_token_id=8196)
+        put("tk_" + name, ctx, scores, tk(ctx, scores.clone()), kind="tk", seed=4000 + ci, scale=3.0)
+        tp = LP.TopPLogitsWarper3d(top_p=0.9)
+        put("tp_" + name, ctx, scores, tp(ctx, scores.clone()), kind="tp", seed=4000 + ci, scale=3.0, top_p=0.9)
+        tm = TemperatureLogitsWarper(0.7)
+        put("tm_" + name, ctx, scores, tm(ctx, scores.clone()), kind="tm", seed=4000 + ci, scale=3.0, temperature=0.7)
+    V2 = 12288
+    cols2 = sample_cols(V2)
+    vis_lo, vis_n = 3000, 8192
+    tok = dict(img_token=200, eoi_token=201, eos_token=202, eol_token=203, eof_token=204, pad_token=205)
+    H, W = 3, 5
+    for ci, (n_after_img, nrows) in enumerate([(0, 16), (4, 16), (17, 8), (19, 6)]):
+        helper = Emu3PrefixConstrainedLogitsHelper(H, W, visual_tokens=list(range(vis_lo, vis_lo + vis_n)), **tok)
+        helper.__class__ = JE.renew_end_of_line_logit_processor_3d(helper.__class__)
+        g = torch.Generator().manual_seed(4500 + ci)
+        ctx = torch.cat([torch.randint(300, 2000, (1, 9), generator=g), torch.tensor([[tok["img_token"]]]),
+                         torch.randint(vis_lo, vis_lo + vis_n, (1, n_after_img), generator=g)], dim=1)
+        scores = torch.randn(1, nrows, V2, generator=g) * 3.0
+        res = helper(ctx, scores.clone())
+        name = f"emu3_c{ci}"
+        out[f"{name}.ctx"] = ctx.numpy()
+        out[f"{name}.finite"] = np.packbits((res > torch.finfo(res.dtype).min).numpy().reshape(-1))      # kept entries (-inf and finfo.min both mean "removed")
+        out[f"{name}.vals"] = res[..., cols2].numpy()
+        out[f"{name}.rowmax"] = res.max(-1).values.numpy()
+        meta.append(dict(name=name, kind="emu3", shape=list(scores.shape), seed=4500 + ci, scale=3.0, H=H, W=W, vis_lo=vis_lo, vis_n=vis_n,
+                         n_after_img=n_after_img, **tok))
+    out["meta"] = np.array(json.dumps(meta))
+    out["cols"] = cols.numpy()
+    out["cols2"] = cols2.numpy()
+    np.savez_compressed(os.path.join(HERE, "fn_processor_calls.npz"), **out)
+    print("fn_processor_calls ok", len(meta))
+
+
 def gen_fn_logits2tokens_llamagen():
     from llamagen.llamagen_solver import LlamaGenSolver
     V = 16384
@@ -696,6 +757,8 @@ if __name__ == "__main__":
         gen_fn_reguess()
     if "fn" in which or "greedy" in which:
         gen_fn_greedy()
+    if "fn" in which or "calls" in which:
+        gen_fn_processor_calls()
     if "fn" in which or "temp" in which:
         gen_fn_temperature()
     if "fn" in which or "anole_modes" in which:

@@ -71,8 +71,10 @@ def test_processor_descriptors_and_grammar_mapping():
     assert grammar_from_processors([HFTopK(top_k=50)]).top_k == 50
     with pytest.raises(NotImplementedError):
         grammar_from_processors([object()])
-    with pytest.raises(RuntimeError):
-        vl(None, None)
+    # called on tensors directly the self-contained processors evaluate their rules with ATen ops (tests/test_processor_calls.py pins that to the
+    # reference's objects); in text mode the Lumina processor leaves the scores alone (LP:89-92)
+    sc = torch.randn(1, 3, 9216)
+    assert torch.equal(vl(torch.tensor([[9000, 9001, 9002]]), sc), sc)
     # Anole's other restricted modes (JA:178-189, 233-260): their processor lists map to AnoleGrammar(mode=)
     from scheduler.logit_processor_3dim import (AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d as AtOff,
                                                 AllowOnlyTokensInRelativeWindowLogitsProcessor3d as InWin,

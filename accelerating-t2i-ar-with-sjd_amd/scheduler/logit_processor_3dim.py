@@ -59,8 +59,8 @@ def apply_row_rules(scores, rules, filter_value=-float("inf"), forced_fill=-floa
 class _Descriptor:
     """A logits processor as a DESCRIPTOR: `_sample` turns the processor list into an integer grammar whose row rules kernels K2 / K4 apply.
     Called on tensors directly (reference usage outside generate()), the processors whose grammar is self-contained -- the Lumina, Emu3 and
-    top-k / top-p / temperature ones -- evaluate the same rules with ATen ops (apply_row_rules); the Anole single-purpose processors only have a
-    grammar as the LIST jacobi_iteration_anhole builds and raise when called alone."""
+    top-k / top-p / temperature ones -- evaluate the same rules with ATen ops (apply_row_rules); the Anole single-purpose processors, which only have a
+    grammar as the LIST jacobi_iteration_anhole builds, carry their own tensor form (_drop_ids)."""
 
     def _solo_rules(self, ctx, n):
         gr = grammar_from_processors([self])
@@ -159,20 +159,50 @@ class TemperatureLogitsWarper(_Descriptor):
         return [ops.make_rule(temperature=self.temperature)] * n
 
 
+def _drop_ids(scores, ids, keep_only, fired):
+    """Anole's single-purpose processors on a [B, (L,) V] tensor (LP:242-256, 280-286, 323-338): per batch row, where `fired` holds (bool [B]),
+    either everything EXCEPT `ids` (keep_only) or exactly `ids` is set to the dtype's most negative finite value; the same mask on every window row"""
+    sel = torch.zeros(scores.shape[-1], dtype=torch.bool, device=scores.device)
+    sel[torch.as_tensor(ids, dtype=torch.long, device=scores.device)] = True
+    col = ~sel if keep_only else sel
+    hit = fired.to(scores.device).view(-1, *([1] * (scores.dim() - 1))) & col
+    return scores.masked_fill(hit, torch.finfo(scores.dtype).min)
+
+
 class AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(_Descriptor):
     def __init__(self, trigger_token_id: int, allowed_token_ids: List[int], offset: int, exclusive: bool = False, device="cpu"):
         self.trigger_token_id, self.allowed_token_ids, self.offset, self.exclusive = trigger_token_id, list(allowed_token_ids), offset, exclusive
+
+    def __call__(self, input_ids, scores):
+        """called alone (LP:242-256): `offset` tokens behind the trigger only the allowed ids stay; with `exclusive` those ids go everywhere else"""
+        B, T = input_ids.shape
+        fired = input_ids[:, -self.offset] == self.trigger_token_id if T >= self.offset else torch.zeros(B, dtype=torch.bool, device=input_ids.device)
+        out = _drop_ids(scores, self.allowed_token_ids, True, fired)
+        return _drop_ids(out, self.allowed_token_ids, False, ~fired) if self.exclusive else out
 
 
 class AllowOnlyTokensInRelativeWindowLogitsProcessor3d(_Descriptor):
     def __init__(self, trigger_token_id: int, allowed_token_ids: List[int], window_width: int, exclusive: bool = False, device="cpu"):
         self.trigger_token_id, self.allowed_token_ids, self.window_width, self.exclusive = trigger_token_id, list(allowed_token_ids), window_width, exclusive
 
+    def __call__(self, input_ids, scores):
+        """called alone (LP:323-338): while the trigger lies among the last `window_width` tokens only the allowed ids stay"""
+        w = min(self.window_width, input_ids.shape[1])
+        fired = (input_ids[:, -w:] == self.trigger_token_id).any(dim=1)
+        out = _drop_ids(scores, self.allowed_token_ids, True, fired)
+        return _drop_ids(out, self.allowed_token_ids, False, ~fired) if self.exclusive else out
+
 
 class SuppressTokensInIndexRangeLogitsProcessor3d(_Descriptor):
     def __init__(self, suppress_tokens: List[int], start_index: int, end_index: Optional[int] = None, device="cpu"):
         self.suppress_tokens, self.start_index = list(suppress_tokens), start_index
         self.end_index = end_index if end_index is not None else math.inf
+
+    def __call__(self, input_ids, scores):
+        """called alone (LP:280-286): the listed ids go while start_index <= context length <= end_index"""
+        T = input_ids.shape[1]
+        on = self.start_index <= T <= self.end_index
+        return _drop_ids(scores, self.suppress_tokens, False, torch.full((input_ids.shape[0],), bool(on), dtype=torch.bool, device=input_ids.device))
 
 
 class SuppressTokensAtBeginLogitsProcessor3d(SuppressTokensInIndexRangeLogitsProcessor3d):

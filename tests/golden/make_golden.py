@@ -215,6 +215,27 @@ def gen_fn_processor_calls():
         out[f"{name}.rowmax"] = res.max(-1).values.numpy()
         meta.append(dict(name=name, kind="emu3", shape=list(scores.shape), seed=4500 + ci, scale=3.0, H=H, W=W, vis_lo=vis_lo, vis_n=vis_n,
                          n_after_img=n_after_img, **tok))
+    # Anole's single-purpose processors (LP:207-353), each alone, on [1, L, V] and [1, V] scores
+    img = list(range(4, 8196))
+    an = [("at_fire", lambda: LP.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(8197, [8196], 5), [9000, 8197, 5, 6, 7, 8], 4),
+          ("at_idle", lambda: LP.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(8197, [8196], 5), [9000, 9001, 5, 6, 7, 8], 4),
+          ("at_excl_idle", lambda: LP.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(8197, [8196], 5, exclusive=True), [9000, 9001, 5, 6, 7, 8], 3),
+          ("at_excl_short", lambda: LP.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(8197, [8196], 9, exclusive=True), [9000, 8197, 5], 2),
+          ("at_short", lambda: LP.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(8197, [8196], 9), [9000, 8197, 5], 2),
+          ("win_fire", lambda: LP.AllowOnlyTokensInRelativeWindowLogitsProcessor3d(8197, img, 4), [9000, 9001, 8197, 5, 6], 5),
+          ("win_idle", lambda: LP.AllowOnlyTokensInRelativeWindowLogitsProcessor3d(8197, img, 2), [9000, 8197, 5, 6, 7], 5),
+          ("win_excl_idle", lambda: LP.AllowOnlyTokensInRelativeWindowLogitsProcessor3d(8197, img, 2, exclusive=True), [9000, 8197, 5, 6, 7], 2),
+          ("rng_on", lambda: LP.SuppressTokensInIndexRangeLogitsProcessor3d([8196, 8197], 3, 6), [1, 2, 3, 4], 3),
+          ("rng_off", lambda: LP.SuppressTokensInIndexRangeLogitsProcessor3d([8196, 8197], 6, 9), [1, 2, 3, 4], 3),
+          ("begin_on", lambda: LP.SuppressTokensAtBeginLogitsProcessor3d([2], 4), [1, 2, 3, 4], 2),
+          ("begin_off", lambda: LP.SuppressTokensAtBeginLogitsProcessor3d([2], 4), [1, 2, 3, 4, 5, 6], 2),
+          ("supp", lambda: LP.SuppressTokensLogitsProcessor3d(img + [8196, 8197]), [1, 2, 3], 1)]
+    for ci, (name, mk, ctx_l, nrows) in enumerate(an):
+        ctx = torch.tensor([ctx_l])
+        scores = torch.randn(1, nrows, V, generator=torch.Generator().manual_seed(4800 + ci)) * 3.0
+        if nrows == 1:
+            scores = scores[:, 0]
+        put("an_" + name, ctx, scores, mk()(ctx, scores.clone()), kind="anole", seed=4800 + ci, scale=3.0, case=name)
     out["meta"] = np.array(json.dumps(meta))
     out["cols"] = cols.numpy()
     out["cols2"] = cols2.numpy()

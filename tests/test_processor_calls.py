@@ -44,6 +44,28 @@ def test_processors_called_directly_match_the_reference(golden_dir):
             _check(d, m, helper(ctx, scores.clone()), d["cols2"])
             n += 1
             continue
+        if m["kind"] == "anole":
+            from scheduler import logit_processor_3dim as M
+            img = list(range(4, 8196))
+            mk = {"at_fire": lambda: M.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(8197, [8196], 5),
+                  "at_idle": lambda: M.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(8197, [8196], 5),
+                  "at_excl_idle": lambda: M.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(8197, [8196], 5, exclusive=True),
+                  "at_excl_short": lambda: M.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(8197, [8196], 9, exclusive=True),
+                  "at_short": lambda: M.AllowOnlyTokensAtRelativeOffsetLogitsProcessor3d(8197, [8196], 9),
+                  "win_fire": lambda: M.AllowOnlyTokensInRelativeWindowLogitsProcessor3d(8197, img, 4),
+                  "win_idle": lambda: M.AllowOnlyTokensInRelativeWindowLogitsProcessor3d(8197, img, 2),
+                  "win_excl_idle": lambda: M.AllowOnlyTokensInRelativeWindowLogitsProcessor3d(8197, img, 2, exclusive=True),
+                  "rng_on": lambda: M.SuppressTokensInIndexRangeLogitsProcessor3d([8196, 8197], 3, 6),
+                  "rng_off": lambda: M.SuppressTokensInIndexRangeLogitsProcessor3d([8196, 8197], 6, 9),
+                  "begin_on": lambda: M.SuppressTokensAtBeginLogitsProcessor3d([2], 4),
+                  "begin_off": lambda: M.SuppressTokensAtBeginLogitsProcessor3d([2], 4),
+                  "supp": lambda: M.SuppressTokensLogitsProcessor3d(img + [8196, 8197])}[m["case"]]
+            shape = m["shape"]
+            full = torch.randn(1, shape[-2] if len(shape) == 3 else 1, shape[-1], generator=torch.Generator().manual_seed(m["seed"])) * m["scale"]
+            scores = full if len(shape) == 3 else full[:, 0]
+            _check(d, m, mk()(ctx, scores.clone()), d["cols"])
+            n += 1
+            continue
         shape = m["shape"]
         full = torch.randn(1, shape[-2] if len(shape) == 3 else 1, shape[-1], generator=torch.Generator().manual_seed(m["seed"])) * m["scale"]
         scores = full if len(shape) == 3 else full[:, 0]
@@ -63,10 +85,6 @@ def test_processors_called_directly_match_the_reference(golden_dir):
         else:
             _check(d, m, res, d["cols"])
         n += 1
-    assert n == len(meta) == 28
+    assert n == len(meta) == 41
 
 
-def test_anole_single_processors_say_why_they_do_not_run_alone():
-    from scheduler.logit_processor_3dim import SuppressTokensAtBeginLogitsProcessor3d
-    with pytest.raises(RuntimeError, match="no grammar of its own"):
-        SuppressTokensAtBeginLogitsProcessor3d([5], 3)(torch.zeros(1, 4, dtype=torch.long), torch.zeros(1, 2, 16))

@@ -73,6 +73,8 @@ class SJDConfig:
     img_vocab_n: int = 8192
     max_length: int = 1 << 30
     eos_token_ids: tuple = ()
+    do_sample: bool = True               # False: GenerationConfig(do_sample=False) -- sampling_logits2tokens takes the argmax of the processed scores
+    #                                      and draws nothing (JL:127-129); the verify step's uniform and residual draws stay
     noise_device: Optional[str] = None   # None: the engine's device (what the reference does on a GPU);  "cpu": draw the noise
     #                                      from a CPU generator and upload it -- replays the reference's CPU run bit-exactly
 
@@ -278,6 +280,11 @@ class SJDEngine:
             return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start)
         return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start, cols=cols)
 
+    def _k2_out(self):
+        """(tokens_out, amax_out) of K2: the draw goes into state.tokens and the mode of p into state.amax -- or, greedy (do_sample=False), the mode
+        into state.tokens, which is what K4 verifies and the host appends (the draw lands in state.amax and is ignored)"""
+        return (self.amax_ptr, self.tokens_ptr) if getattr(self, "_greedy", False) else (self.tokens_ptr, self.amax_ptr)
+
     def _sample_body(self, cur, logits, cols=None):
         """part 2: K2 + K4.  In-kernel noise (self._philox): the kernels are handed NULL instead of the noise tensors."""
         noise, rs, noise2 = (None, None, None) if self._philox else (self.noise, self.rs, self.noise2[0])
@@ -288,12 +295,14 @@ class SJDEngine:
                     self._dbg = torch.zeros(2, self.Lmax, self.V, dtype=torch.float32, device=self.device)
                 dbg = self._dbg
                 dbg.zero_()
-            ops.logits_to_probs_sample_part(logits, self._guidance, self.params, noise, self.probs[cur], self.tokens_ptr, dbg=dbg,
-                                            amax_out_ptr=self.amax_ptr, zero_state=self.zero_state[cur])
+            tok_out, amax_out = self._k2_out()
+            ops.logits_to_probs_sample_part(logits, self._guidance, self.params, noise, self.probs[cur], tok_out, dbg=dbg,
+                                            amax_out_ptr=amax_out, zero_state=self.zero_state[cur])
         else:
             lu = logits[1] if self.B > 1 else None
-            ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, noise, self.probs[cur], self.tokens_ptr,
-                                       col0=cols[0] if cols else 0, amax_out_ptr=self.amax_ptr)
+            tok_out, amax_out = self._k2_out()
+            ops.logits_to_probs_sample(logits[0], lu, self._guidance, self.params, noise, self.probs[cur], tok_out,
+                                       col0=cols[0] if cols else 0, amax_out_ptr=amax_out)
             self.zero_state[cur].fill_(-1)            # (the dense-logits K2 does not keep the rows' zero state)
         ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], rs, noise2, self.scratch, mirror=True)
 
@@ -356,7 +365,7 @@ class SJDEngine:
         #  the buffer it was captured on -- ADVICE r4: without it the graph of one regime replayed on the other regime's stale buffer.  The
         #  captured buffer's identity is kept beside the graph as a belt: a mismatch drops the graph and captures again.)
         regime = self._k1_regime()
-        key = ("smp", cur, self._guidance, cols, self.hook is not None, self._philox, regime)
+        key = ("smp", cur, self._guidance, cols, self.hook is not None, self._philox, regime, getattr(self, "_greedy", False))
         if not self.use_graph or ("fwd", cols, regime) not in self._graphs:
             self._sample_body(cur, logits, cols)
             return
@@ -380,7 +389,7 @@ class SJDEngine:
             self._sample_body(cur, logits, cols)
             return logits
         self._check_graph_buffers()
-        key = ("win", cols, cur, self._guidance, self.hook is not None, self._philox, self._k1_regime())
+        key = ("win", cols, cur, self._guidance, self.hook is not None, self._philox, self._k1_regime(), getattr(self, "_greedy", False))
         if key not in self._graphs:
             if self._eager_runs.get(key, 0) < 1:      # one eager run warms up allocations / hipBLASLt before capture
                 self._eager_runs[key] = 1
@@ -447,6 +456,7 @@ class SJDEngine:
         self.key_start.copy_(spec.key_start.to(device=dev, dtype=torch.int32))
         self.pos_offset.copy_(spec.pos_offset.to(device=dev, dtype=torch.int64))
         self._guidance = float(cfg.guidance_scale)
+        self._greedy = greedy = not getattr(cfg, "do_sample", True)
         attn = getattr(self.backbone, "attn", None)
         st = self.state.view
         stats = DecodeStats()
@@ -501,7 +511,8 @@ class SJDEngine:
             ph = None
             if philox:                                  # offsets of g before the multinomial, the rand and the residual multinomial
                 ph_step = ops.philox_step(n_rows * self.V, ph_blocks)
-                ph = (ph_blocks, ph_seed, ph_off, ph_off + ph_step, ph_off + 2 * ph_step)
+                k2_step = 0 if greedy else ph_step          # greedy: sampling_logits2tokens draws nothing (JL:127-129)
+                ph = (ph_blocks, ph_seed, ph_off, ph_off + k2_step, ph_off + k2_step + ph_step)
             self._fill_params(n_rows, kv_len, use_cfg, scheme, fresh, rules, resid or [], head_only=two_stage, philox=ph)
             # ---------------- noise tensors: only for host-drawn noise (the reference's CPU runs) and for observers ----------------
             e1, g_state = None, None
@@ -509,14 +520,20 @@ class SJDEngine:
                 self._noise_tensors()
                 e1 = self.noise[:n_rows]
                 if host_noise:                                                       # parity mode: CPU stream of the reference
-                    e1.copy_(torch.empty(n_rows, self.V).exponential_(generator=gen))
+                    if greedy:
+                        e1.fill_(1.0)
+                    else:
+                        e1.copy_(torch.empty(n_rows, self.V).exponential_(generator=gen))
                     if draws_rs:
                         self.rs[:n_rows].copy_(torch.rand((1, n_rows, self.V), generator=gen)[0])
                         g_state = gen.get_state()
                         self.noise2.copy_(torch.empty(1, self.V).exponential_(generator=gen))
                 else:                           # what the kernels generate, drawn by torch from the same generator state (observers)
                     gen.set_offset(ph_off)
-                    e1.exponential_(generator=gen)                                   # == torch.multinomial (JL:118)
+                    if greedy:
+                        e1.fill_(1.0)
+                    else:
+                        e1.exponential_(generator=gen)                               # == torch.multinomial (JL:118)
                     if draws_rs:
                         self.rs[:n_rows].uniform_(0.0, 1.0, generator=gen)           # torch.rand([1,n,V]) (JL:260)
                         self.noise2.exponential_(generator=gen)                      # residual multinomial (JL:237)
@@ -531,8 +548,9 @@ class SJDEngine:
                 lc = logits[0, -1:, :]
                 lu = logits[1, -1:, :] if B > 1 else None
                 win_len = tokens.shape[1]
-                ops.logits_to_probs_sample(lc, lu, self._guidance, self.params, None if philox else self.noise, self.probs[cur], self.tokens_ptr,
-                                           amax_out_ptr=self.amax_ptr)
+                tok_out, amax_out = self._k2_out()
+                ops.logits_to_probs_sample(lc, lu, self._guidance, self.params, None if philox else self.noise, self.probs[cur], tok_out,
+                                           amax_out_ptr=amax_out)
                 self.zero_state[cur].fill_(-1)
                 ops.verify_accept(self.params, self.state, self.probs[cur], self.probs[1 - cur], None if philox else self.rs,
                                   None if philox else self.noise2[0], self.scratch, mirror=True)
@@ -577,11 +595,11 @@ class SJDEngine:
             if g_state is not None and not rejected:
                 gen.set_state(g_state)                 # host-drawn noise: the residual draw was speculative, rewind it
             if philox:                                 # what torch would have consumed: multinomial [+ rand [+ residual multinomial]]
-                ph_off += ph_step * (2 if draws_rs else 1) + (ph_row if (draws_rs and rejected) else 0)
+                ph_off += k2_step + (ph_step if draws_rs else 0) + (ph_row if (draws_rs and rejected) else 0)
                 if self.hook is not None:
                     gen.set_offset(ph_off)
             Y = st.tokens[:n_rows]
-            A = st.amax[:n_rows]                               # modes of this iteration's target rows (K2 by-product)
+            A = Y if greedy else st.amax[:n_rows]              # modes of this iteration's target rows (K2 by-product; greedy: the tokens themselves)
             if n_rows <= 1:
                 m = win_len                      # is_prefilling_phase short-circuit (JL:344-350)
                 emitted, carried, carried_amax, last_amax = [Y[0]], [], [], A[0]

@@ -272,6 +272,8 @@ class SJDBatchEngine:
         prompt of the list -- state machine, grammar and generators re-created, its KV rows reused from 0, its prompt prefilled eagerly
         over its own batch rows -- while the other slots keep their windows; the captured window graphs are unaffected.  Only when the
         list is exhausted does a finished slot ride along with a one-row dummy window."""
+        if not getattr(cfg, "do_sample", True):
+            raise NotImplementedError("greedy decoding (do_sample=False) runs on SJDEngine, one prompt per forward")
         N = len(prompts)
         assert len(specs) == len(grammars) == N and N >= self.P
         if cfg.multi_token_init_scheme not in ("random", "repeat_horizon", "sample_horizon"):

@@ -217,8 +217,8 @@ def hf_generate(model, inputs=None, generation_config=None, logits_processor=Non
     for k in ("max_new_tokens", "max_length", "do_sample", "top_k", "top_p", "temperature", "eos_token_id", "pad_token_id", "num_beams"):
         if k in kwargs and kwargs[k] is not None:
             setattr(gc, k, kwargs.pop(k))
-    if not getattr(gc, "do_sample", False) or (getattr(gc, "num_beams", 1) or 1) != 1:
-        raise NotImplementedError("the SJD hot path samples (do_sample=True, num_beams=1)")
+    if (getattr(gc, "num_beams", 1) or 1) != 1:
+        raise NotImplementedError("the SJD hot path decodes one beam (num_beams=1)")
     P = ids.shape[1]
     if getattr(gc, "max_new_tokens", None) is not None:
         gc.max_length = P + int(gc.max_new_tokens)
@@ -229,12 +229,13 @@ def hf_generate(model, inputs=None, generation_config=None, logits_processor=Non
                       f"at {limit} tokens (HF warns and goes on; rows past the context could never be positioned here)", stacklevel=2)
         gc.max_length = int(limit)
     procs = LogitsProcessorList(list(logits_processor or []))
-    if (getattr(gc, "temperature", None) or 1.0) != 1.0:       # HF appends the warpers after the user's processors: temperature first
+    sampling = bool(getattr(gc, "do_sample", False))            # (greedy: HF builds no warpers; `_sample` takes the argmax of the processed scores, JL:127-129)
+    if sampling and (getattr(gc, "temperature", None) or 1.0) != 1.0:       # HF appends the warpers after the user's processors: temperature first
         from .logit_processor_3dim import TemperatureLogitsWarper
         procs.append(TemperatureLogitsWarper(float(gc.temperature)))
-    if getattr(gc, "top_k", None):
+    if sampling and getattr(gc, "top_k", None):
         procs.append(TopKLogitsWarper(int(gc.top_k)))
-    if (getattr(gc, "top_p", None) or 1.0) < 1.0:              # ... then top-k, then top-p
+    if sampling and (getattr(gc, "top_p", None) or 1.0) < 1.0:              # ... then top-k, then top-p
         from .logit_processor_3dim import TopPLogitsWarper
         procs.append(TopPLogitsWarper(float(gc.top_p)))
     crit = list(stopping_criteria or [])
@@ -325,7 +326,8 @@ def renew_sampler(model_class):
                 raise ValueError(f"prefix_token_sampler_scheme: {self.prefix_token_sampler_scheme}")   # JL:1048
             dev = input_ids.device
             do_cfg = bool(self.do_cfg) and (self.guidance_scale != 1)                                  # JL:1002-1005
-            procs = list(logits_processor or []) + list(logits_warper or [])
+            do_sample = bool(getattr(generation_config, "do_sample", True))                            # JL:969
+            procs = list(logits_processor or []) + (list(logits_warper or []) if do_sample else [])    # JL:107: warpers only when sampling
             eos, max_len = _stopping_to_limits(stopping_criteria, generation_config)
             grammar = grammar_from_processors(procs, prompt_len=input_ids.shape[1], max_length=max_len, vocab_size=getattr(self, "vocab_size", None))
             if getattr(grammar, "V", 0) is None:
@@ -336,7 +338,7 @@ def renew_sampler(model_class):
                             do_cfg=do_cfg, prefix_token_sampler_scheme=self.prefix_token_sampler_scheme,
                             multi_token_init_scheme=self.multi_token_init_scheme, img_vocab_lo=self.img_vocab_range[0],
                             img_vocab_n=self.img_vocab_range[1] - self.img_vocab_range[0], max_length=max_len, eos_token_ids=eos,
-                            noise_device=getattr(self, "sjd_noise_device", None))
+                            noise_device=getattr(self, "sjd_noise_device", None), do_sample=do_sample)
             B = 2 if do_cfg else 1
             if max_len >= (1 << 30):
                 # no MaxLength criterion: bound the cache by the model's own context instead of asking for ~1e9 rows

@@ -35,6 +35,7 @@ class LoopConfig:
     max_length: int = 1 << 30      # MaxLengthCriteria / MaxlenCriteria
     eos_token_ids: tuple = ()      # EosTokenCriteria looks at the LAST appended token only
     multi_token_init_scheme: str = "random"    # 'repeat_horizon' / 'sample_horizon': spatial draft initialisation (JL:516-594)
+    do_sample: bool = True         # False: GenerationConfig(do_sample=False) -- the argmax branch of sampling_logits2tokens (JL:127-129)
 
 
 @dataclass
@@ -135,8 +136,21 @@ def run(prompt, forward_fn, rules_fn, cfg: LoopConfig, vocab_size, no_cfg_fn=Non
         use_u = logits_u if (do_cfg and not force_no_cfg) else None
         # ---- logits -> probs -> tokens (sampling_logits2tokens, JL:82-132) ----
         rules = rules_fn(ctx, n_rows)
-        e1 = torch.empty((n_rows, V), dtype=torch.float32, device=noise_device).exponential_(generator=gen)
-        Y, Pn = O.logits_to_probs_sample(logits_c, use_u, cfg.guidance_scale, rules, e1.cpu().numpy())
+        if cfg.do_sample:
+            e1 = torch.empty((n_rows, V), dtype=torch.float32, device=noise_device).exponential_(generator=gen)
+            Y, Pn = O.logits_to_probs_sample(logits_c, use_u, cfg.guidance_scale, rules, e1.cpu().numpy())
+        else:
+            # JL:127-129: no draw (the generator is not touched); probabilities = softmax of the processed scores, token = their argmax -- the scores
+            # are the CFG-combined logits wherever the rules leave mass
+            e1 = torch.ones((n_rows, V), dtype=torch.float32)
+            _, Pn = O.logits_to_probs_sample(logits_c, use_u, cfg.guidance_scale, rules, e1.numpy())
+            lc = np.asarray(logits_c, dtype=np.float32)
+            if use_u is None:
+                z = lc
+            else:
+                lu = np.asarray(use_u, dtype=np.float32)
+                z = (np.float32(cfg.guidance_scale) * (lc - lu)).astype(np.float32) + lu
+            Y = np.where(Pn > 0, z, -np.inf).argmax(-1)
         if hook is not None:
             hook("sampled", dict(win=win, logits_c=logits_c, logits_u=use_u, rules=rules, noise=e1, Y=Y, P=Pn))
         tr.sampled.append(Y.tolist())

@@ -648,7 +648,9 @@ def gen_loop_llamagen():
     np.savez_compressed(os.path.join(HERE, "loop_llamagen.npz"), **out)
 
 
-def gen_loop_lumina():
+def gen_loop_lumina(greedy=False):
+    """greedy: GenerationConfig(do_sample=False) -- the argmax branch of sampling_logits2tokens (JL:127-129) inside the whole loop: no multinomial
+    draw, the verify step's uniform and residual draws as before -> loop_lumina_greedy.npz"""
     from model.chameleon import ChameleonForConditionalGeneration, ChameleonConfig
     from transformers import GenerationConfig
     from transformers.generation.stopping_criteria import StoppingCriteriaList, EosTokenCriteria, MaxLengthCriteria
@@ -658,6 +660,10 @@ def gen_loop_lumina():
             ("spec_s9_w8_gqa", "speculative_jacobi", 9, 3, 5, 8, 3, 6 * 11 - 6, 20, 2, 0.5),
             ("jacobi_s3", "jacobi", 3, 4, 4, 16, 3, 8 * 9 - 10, 12, 4, 0.25),
             ("spec_s4_tail", "speculative_jacobi", 4, 4, 4, 16, 1, 8 * 9 + 1, 12, 4, 0.25)]
+    if greedy:
+        runs = [("greedy_s3", "speculative_jacobi", 3, 4, 4, 16, 3, 8 * 9 - 10, 12, 4, 0.25),
+                ("greedy_s6_w8", "speculative_jacobi", 6, 3, 5, 8, 3, 6 * 11 - 6, 20, 2, 0.5),
+                ("greedy_jacobi_s3", "jacobi", 3, 4, 4, 16, 3, 8 * 9 - 10, 12, 4, 0.25)]
     for name, scheme, seed, hg, wg, window, l, r, P, kvh, ets in runs:
         V = 9216
         cfg_kw = dict(vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
@@ -688,7 +694,7 @@ def gen_loop_lumina():
         n_img = (2 * wg + 1) * 2 * hg
         max_len = P + n_img + 1 + 4
         stopping = StoppingCriteriaList([EosTokenCriteria([8196]), MaxLengthCriteria(max_len)])
-        gc = GenerationConfig(max_length=max_len, do_sample=True, temperature=1.0, top_k=None)
+        gc = GenerationConfig(max_length=max_len, do_sample=not greedy, temperature=1.0, top_k=None)
         gc._pad_token_tensor = torch.tensor(0)
         tr = Tracer()
         tr.install()
@@ -709,7 +715,7 @@ def gen_loop_lumina():
         print("loop_lumina", name, "generated", len(gen), "NFE", len(tr.matched), "tail", gen[-4:],
               "eol@", [i for i, t in enumerate(gen) if t == 8803][:4])
     out["meta"] = np.array(json.dumps(meta))
-    np.savez_compressed(os.path.join(HERE, "loop_lumina.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "loop_lumina_greedy.npz" if greedy else "loop_lumina.npz"), **out)
 
 
 def gen_vq_decoders():
@@ -787,3 +793,5 @@ if __name__ == "__main__":
     if "loops" in which:
         gen_loop_llamagen()
         gen_loop_lumina()
+    if "loops" in which or "greedy_loops" in which:
+        gen_loop_lumina(greedy=True)

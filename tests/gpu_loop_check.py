@@ -112,7 +112,8 @@ def _loop_cfg(c):
     return OL.LoopConfig(jacobi_loop_interval_l=c.jacobi_loop_interval_l, jacobi_loop_interval_r=c.jacobi_loop_interval_r,
                          max_num_new_tokens=c.max_num_new_tokens, guidance_scale=c.guidance_scale, seed=c.seed,
                          do_cfg=c.do_cfg, prefix_token_sampler_scheme=c.prefix_token_sampler_scheme,
-                         max_length=c.max_length, eos_token_ids=c.eos_token_ids, multi_token_init_scheme=c.multi_token_init_scheme)
+                         max_length=c.max_length, eos_token_ids=c.eos_token_ids, multi_token_init_scheme=c.multi_token_init_scheme,
+                         do_sample=getattr(c, "do_sample", True))
 
 
 @torch.no_grad()
@@ -154,7 +155,8 @@ def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7,
 @torch.no_grad()
 def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, scheme="speculative_jacobi", P=12,
                                 embed_token_scale=0.25, kv_heads=4, l=3, r=None, dtype=torch.bfloat16,
-                                use_graph=False, fused=True, gemm="torch", fp8_kv=False, init_scheme="random", temperature=1.0, top_p=None):
+                                use_graph=False, fused=True, gemm="torch", fp8_kv=False, init_scheme="random", temperature=1.0, top_p=None,
+                                do_sample=True):
     import sjd_amd.ops as ops
     import sjd_amd.synthetic as synthetic
     from sjd_amd.engine import SJDEngine, SJDConfig, WindowSpec
@@ -174,7 +176,7 @@ def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, 
     r = r if r is not None else (2 * wg + 1) * 2 * hg - 10
     cfg = SJDConfig(jacobi_loop_interval_l=l, jacobi_loop_interval_r=r, max_num_new_tokens=window, guidance_scale=3.0,
                     seed=seed, prefix_token_sampler_scheme=scheme, max_length=max_len, eos_token_ids=(8196,),
-                    multi_token_init_scheme=init_scheme)
+                    multi_token_init_scheme=init_scheme, do_sample=do_sample)
     ids = prompt.to(device)
     spec = WindowSpec(first_tokens=ids.repeat(2, 1),
                       first_positions=torch.stack([torch.arange(P), torch.tensor([1] * (P - 1) + [0])]).to(device),

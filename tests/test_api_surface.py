@@ -229,5 +229,8 @@ def test_hf_generate_builds_criteria_and_topk_then_calls_sample():
     # top_p: HF's TopPLogitsWarper behind temperature and top-k
     hf_generate(M(), ids, GenerationConfig(do_sample=True, temperature=0.7, top_k=50, top_p=0.9, max_new_tokens=4), logits_processor=[Proc()])
     assert seen["procs"] == ["Proc", "TemperatureLogitsWarper", "TopKLogitsWarper", "TopPLogitsWarper"]
+    # greedy (round 5): HF builds no warpers when do_sample is False; `_sample` then takes the argmax of the processed scores (JL:127-129)
+    hf_generate(M(), ids, GenerationConfig(do_sample=False, temperature=0.7, top_k=50, max_new_tokens=4), logits_processor=[Proc()])
+    assert seen["procs"] == ["Proc"]
     with pytest.raises(NotImplementedError):
-        hf_generate(M(), ids, GenerationConfig(do_sample=False, max_new_tokens=4))
+        hf_generate(M(), ids, GenerationConfig(do_sample=True, num_beams=2, max_new_tokens=4))

@@ -52,13 +52,16 @@ def test_llamagen_golden_tokens_on_gpu(dev, golden_dir):
         assert stats.nfe == m["nfe"]
 
 
-def test_lumina_golden_tokens_on_gpu(dev, golden_dir):
+@pytest.mark.parametrize("fixture,do_sample", [("loop_lumina.npz", True), ("loop_lumina_greedy.npz", False)])
+def test_lumina_golden_tokens_on_gpu(dev, golden_dir, fixture, do_sample):
+    """the reference's whole-loop traces replayed through the product engine; the greedy fixture = GenerationConfig(do_sample=False): K2's mode
+    instead of its draw, no multinomial consumed from the generator (JL:127-129)"""
     import sjd_amd.ops as ops
     from sjd_amd.engine import SJDEngine, SJDConfig
     from sjd_amd.frontends import lumina_window_spec
     from sjd_amd.grammar import LuminaGrammar
     from tests.helpers import make_chameleon
-    d, meta = _load(golden_dir, "loop_lumina.npz")
+    d, meta = _load(golden_dir, fixture)
     for m in meta:
         name, jac = m["name"], m["jacobi"]
         model = make_chameleon(m["config"], m["weight_seed"], m["embed_token_scale"], ops.HipWindowAttention(n_split=1),
@@ -68,7 +71,7 @@ def test_lumina_golden_tokens_on_gpu(dev, golden_dir):
         cfg = SJDConfig(jacobi_loop_interval_l=jac["jacobi_loop_interval_l"], jacobi_loop_interval_r=jac["jacobi_loop_interval_r"],
                         max_num_new_tokens=jac["max_num_new_tokens"], guidance_scale=jac["guidance_scale"], seed=jac["seed"],
                         prefix_token_sampler_scheme=jac["prefix_token_sampler_scheme"], max_length=m["max_len"],
-                        eos_token_ids=(8196,), noise_device="cpu")
+                        eos_token_ids=(8196,), noise_device="cpu", do_sample=do_sample)
         eng = SJDEngine(model, m["config"]["vocab_size"], dev, max_window=jac["max_num_new_tokens"], use_graph=False)
         seq, stats = eng.decode(prompt, lumina_window_spec(prompt, dev), LuminaGrammar(2000, 10), cfg)
         assert seq == d[f"{name}.sequence"][0].tolist(), name

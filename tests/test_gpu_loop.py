@@ -105,6 +105,15 @@ def test_three_and_four_prompts_share_one_window_forward(n_prompts, fp8_kv):
     assert len(rs) == n_prompts and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs) and any(r["max_accept"] > 1 for r in rs)
 
 
+@pytest.mark.parametrize("use_graph,gemm,scheme", [(True, "sjd", "speculative_jacobi"), (False, "torch", "speculative_jacobi"), (True, "sjd", "jacobi")])
+def test_greedy_decode_takes_the_oracles_decisions(use_graph, gemm, scheme):
+    """round 5: GenerationConfig(do_sample=False) through the engine -- K2's mode instead of its draw, nothing consumed from the generator for it
+    (JL:127-129), the verify step's uniform / residual draws at the offsets that follow: every window, accept length and noise stream as the
+    oracle's greedy loop (itself pinned to three reference runs, tests/golden/loop_lumina_greedy.npz)"""
+    r = G.teacher_forced_lumina_check(use_graph=use_graph, gemm=gemm, scheme=scheme, do_sample=False)
+    assert r["last"] == 8196 and r["tokens"] == 73
+
+
 @pytest.mark.parametrize("n_prompts,use_graph", [(5, True), (6, False), (8, True)])
 def test_five_to_eight_prompts_share_one_window_forward(n_prompts, use_graph):
     """round 5: 160 / 192 / 256 window rows per forward (G1 with five to eight row tiles, F1r / F2 / F3 over 256 rows, K1 over 16 batch rows): every

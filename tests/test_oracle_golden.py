@@ -267,8 +267,11 @@ def test_loop_llamagen(golden_dir):
         assert len(tr.matched) == m["nfe"]
 
 
-def test_loop_lumina(golden_dir):
-    d, meta = load(golden_dir, "loop_lumina.npz")
+@pytest.mark.parametrize("fixture,do_sample", [("loop_lumina.npz", True), ("loop_lumina_greedy.npz", False)])
+def test_loop_lumina(golden_dir, fixture, do_sample):
+    """whole `_sample` loops of the reference, token for token; the greedy fixture runs GenerationConfig(do_sample=False): no multinomial draw,
+    the verify step's draws as before (JL:127-129)"""
+    d, meta = load(golden_dir, fixture)
     for m in meta:
         name = m["name"]
         model = make_chameleon(m["config"], m["weight_seed"], m["embed_token_scale"], OracleWindowAttention())
@@ -280,7 +283,7 @@ def test_loop_lumina(golden_dir):
                             max_num_new_tokens=jac["max_num_new_tokens"], guidance_scale=jac["guidance_scale"],
                             seed=jac["seed"], do_cfg=jac["do_cfg"],
                             prefix_token_sampler_scheme=jac["prefix_token_sampler_scheme"], max_length=m["max_len"],
-                            eos_token_ids=(8196,))
+                            eos_token_ids=(8196,), do_sample=do_sample)
         seq, tr = OL.run(prompt, fwd, lambda c, n: O.lumina_rules(c, n, 2000, 10), cfg, m["config"]["vocab_size"],
                          no_cfg_fn=O.lumina_force_no_cfg)
         check_trace(d, name, tr)

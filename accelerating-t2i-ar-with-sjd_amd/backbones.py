@@ -389,9 +389,11 @@ class ChameleonBackbone(nn.Module):
     # o and down are faster there (28.1 / 15.8 / 28.4 -> 25.7 / 12.2 / 24.0 us); 8-wave workgroups run on the same kernel with one workgroup
     # per CU (gate|up 49.4 -> 43.3 us, profiles/r3_g1_tiled8.txt); four prompts per forward 5.55 -> 4.89 ms per step on one box
     G1_CFG_128ROW = dict(qkv=(2048, 4, True), o=(896, 4, True), gate_up=(2048, 8, True), down=(1376, 4, True))
-    # 129..256-row windows (five to eight prompts per forward, round 5): g1_skinny_gemm_tiled8 with five to eight row tiles -- four waves, ONE
-    # workgroup per CU (the accumulators of eight row tiles do not leave room for a second) -- so every projection runs four-wave workgroups
-    G1_CFG_256ROW = dict(qkv=(2048, 4, True), o=(896, 4, True), gate_up=(2048, 4, True), down=(1376, 4, True))
+    # 129..256-row windows (five to eight prompts per forward): kernel G1w (csrc/sjd_gemm_wide.h, round 6) -- the second number is the column tiles
+    # per workgroup: 2, 3, 4 (one per wave) or 6, 8 (two per wave).  tools/g1w_bench.py at 256 rows (profiles/r6_g1w_sweep.txt), us per launch against
+    # round 5's g1_skinny_gemm_tiled8: q|k|v 34.3 / 46.1, o 16.4 / 23.4, gate|up 58.4 / 84.4, down 31.3 / 38.2 (hipBLASLt: 50.4 / 19.1 / 65.9 / 52.7)
+    G1_CFG_256ROW = dict(qkv=(2048, 4, True), o=(512, 4, True), gate_up=(2048, 8, True), down=(1408, 4, True))
+    G1_WIDE_TILES = (2, 3, 4, 6, 8)
     # Emu3-Gen 8B (GQA 32/8: the q|k|v projection has 6144 columns; draft window 32 -> 64 rows), tuned end to end with bench.py --model emu3_8b
     G1_CFG_EMU3 = dict(qkv=(512, 8, False), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))        # profiles/r2_g1_launch_shape_sweep_emu3_64rows.jsonl
     # the same on the 12-bit stream (Emu3 in bf16, round 4): 256-workgroup launches for q|k|v and o, step-major packing -- 11.75 / 10.25 / 19.85 us
@@ -668,10 +670,10 @@ class ChameleonBackbone(nn.Module):
     def _forward_window_fused(self, tokens, positions, kv_len, key_start, cols=None, head_partials=False):
         T_ = tokens.shape[0] * tokens.shape[1]
         # G1 serves windows: <= 64 rows, or <= 256 rows of up to eight prompts' draft windows (n <= 32 rows per batch row; 129..256 rows: round 5, the
-        # uncompressed packing with four-wave workgroups -- G1_CFG_256ROW); longer inputs are prefill
+        # uncompressed packing on kernel G1w -- G1_CFG_256ROW); longer inputs are prefill
         if self._gemm == "sjd" and (T_ <= 64 or (T_ <= 128 and tokens.shape[1] <= 32) or
                                     (T_ <= 256 and tokens.shape[1] <= 32 and self._packed and not isinstance(self._packed[0]["qkv"], self._ops.PackedZ)
-                                     and all(c[1] == 4 for c in self.G1_CFG.values()))):
+                                     and all(c[1] in self.G1_WIDE_TILES for c in self.G1_CFG.values()))):
             if self._fold_norm:
                 return self._forward_window_g1_folded(tokens, positions, kv_len, key_start, cols, head_partials)
             return self._forward_window_g1(tokens, positions, kv_len, key_start, cols)

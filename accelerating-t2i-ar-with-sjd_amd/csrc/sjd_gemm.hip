@@ -32,9 +32,11 @@ __device__ unsigned long long g_g1_trace[4096][8];
 // slot 7: where the workgroup ran -- XCC_ID (hwreg 20) in the high word, HW_ID (hwreg 4: wave / SIMD / CU / SH / SE) in the low word
 #define SJD_TR_HW() do { if (threadIdx.x == 0) g_g1_trace[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][7] = \
     ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); } while (0)
+#define SJD_TR_CLK(i) do { if (threadIdx.x == 0) g_g1_trace[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define SJD_TR(i) do { } while (0)
 #define SJD_TR_HW() do { } while (0)
+#define SJD_TR_CLK(i) do { } while (0)
 #endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -617,6 +619,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MT <= 4) ? 2 : 1) void g1_skin
             o[(size_t)m * N] = acc[mt][r];
         }
 }
+
+#include "sjd_gemm_wide.h"
 
 // ------------------------------------------------------------------------------------------------ weight prefetch
 // While the latency-bound kernels of a layer run (F1r / F2 / K1 / combine / F3: ~1.15 ms of a 3.9 ms step, rocprofv3 round 1) HBM is
@@ -1867,8 +1871,21 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
     const dim3 grid((n_out + waves - 1) / waves, n_chunks), block(waves * 64);
     const size_t lds_whole = (size_t)MT * ((KC < K ? KC : K) / 16) * 64 * 16;       // the whole activation chunk staged at once
     static const bool force_tiled = [] { const char *e = getenv("SJD_G1_TILED"); return e && e[0] == '1'; }();      // tuning aid (64-row windows)
-    if constexpr (MT > 4) {      // round 5: 129..256-row windows (five to eight prompts per forward): the 8-step sub-tiled kernel with four waves, ONE
-        // workgroup per CU (a wave holds MT x 16 accumulators + 2 MT staging pieces + the weight ring: > 256 registers), 2 x MT x 8 KiB of LDS
+    if constexpr (MT > 4) {      // 129..256-row windows (five to eight prompts per forward): G1w (sjd_gemm_wide.h, round 6).  `waves` = column tiles per
+        // workgroup: 2, 3, 4 (one per wave) or 6, 8 (two per wave: every activation fragment read from LDS feeds two MFMAs); stages of four k-steps,
+        // three ring slots (96 KiB + 1), weight ring of eight k-steps.  SJD_G1_WIDE=0 (A/B aid): round 5's g1_skinny_gemm_tiled8 with four waves,
+        // one workgroup per CU (a wave holds MT x 16 accumulators + 2 MT staging pieces + the weight ring: > 256 registers), 2 x MT x 8 KiB of LDS.
+        static const bool wide = [] { const char *e = getenv("SJD_G1_WIDE"); return !(e && e[0] == '0'); }();
+        if (wide) {
+            switch (waves) {
+            case 2: return g1_wide_launch<DT, MT, 1, 2, 4, 3, 2, 1>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+            case 3: return g1_wide_launch<DT, MT, 1, 3, 4, 3, 2, 1>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+            case 4: return g1_wide_launch<DT, MT, 1, 4, 4, 3, 2, 1>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+            case 6: return g1_wide_launch<DT, MT, 2, 3, 4, 3, 2, 1>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+            case 8: return g1_wide_launch<DT, MT, 2, 4, 4, 3, 2, 1>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+            default: return SJD_ERR_BAD_ARG;
+            }
+        }
         if (waves != 4) return SJD_ERR_BAD_ARG;
         const size_t lds_8 = (size_t)2 * MT * 8 * 1024;
         (void)hipFuncSetAttribute((const void *)g1_skinny_gemm_tiled8<DT, MT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_8);
@@ -1996,6 +2013,36 @@ extern "C" int sjd_skinny_gemm_reduce(const void *x, const void *w_packed, float
                            M, N, K, KC, n_out, rs, 0, waves, (unsigned short *)h, sumsq, ticket);
     } else return SJD_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+// G1w tuning entry (tools/g1w_bench.py): bf16; M <= 128 runs four row tiles, M <= 256 eight; tiles = column tiles per workgroup (2, 3, 4: one per
+// wave; 6, 8: two per wave); variant = (stage k-steps, ring slots, weight ring stages): 0 (4, 3, 2) = the product's  1 (4, 4, 2)  10: eight waves with
+// one tile each (tiles = 8, two waves per SIMD)  20: four row tiles in the register budget of two workgroups per CU.  ldx: row stride of x.
+extern "C" int sjd_skinny_gemm_wide(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int tiles, int step_major,
+                                    int variant, int ldx, void *stream)
+{
+    if (!x || !w_packed || !out || M < 1 || M > 256 || N < 32 || (N % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0) return SJD_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = N / 32;
+#define SJD_G1W_V(MT_, CT_, NW_, SUB_, NS_, RW_, WPS_) return g1_wide_launch<SJD_DTYPE_BF16, MT_, CT_, NW_, SUB_, NS_, RW_, WPS_>(x, w_packed, out, M, N, K, KC, nt, step_major, 0, s, ldx)
+#define SJD_G1W_T(MT_, SUB_, NS_, RW_, WPS_) do { switch (tiles) { case 2: SJD_G1W_V(MT_, 1, 2, SUB_, NS_, RW_, WPS_); case 3: SJD_G1W_V(MT_, 1, 3, SUB_, NS_, RW_, WPS_); \
+        case 4: SJD_G1W_V(MT_, 1, 4, SUB_, NS_, RW_, WPS_); case 6: SJD_G1W_V(MT_, 2, 3, SUB_, NS_, RW_, WPS_); case 8: SJD_G1W_V(MT_, 2, 4, SUB_, NS_, RW_, WPS_); \
+        default: return SJD_ERR_BAD_ARG; } } while (0)
+    if (M > 128) {
+        switch (variant) {
+        case 0: SJD_G1W_T(8, 4, 3, 2, 1);
+        case 1: SJD_G1W_T(8, 4, 4, 2, 1);
+        case 10: if (tiles == 8) SJD_G1W_V(8, 1, 8, 4, 3, 2, 2); return SJD_ERR_BAD_ARG;
+        default: return SJD_ERR_BAD_ARG;
+        }
+    }
+    switch (variant) {
+    case 0: SJD_G1W_T(4, 4, 3, 2, 1);
+    case 20: SJD_G1W_T(4, 4, 3, 2, 2);
+    default: return SJD_ERR_BAD_ARG;
+    }
+#undef SJD_G1W_T
+#undef SJD_G1W_V
 }
 
 // workgroups of a reducing launch that gave up waiting for their slice's ticket since the library was loaded (0 on a healthy device)

@@ -425,7 +425,8 @@ def _prows(M):
 
 
 def skinny_gemm(x, w_packed, N, K, KC, waves=4, step_major=False):
-    """x [M<=128, K] bf16/fp16 -> Partials([n_chunks, 32 * ceil(M / 32), N] fp32)."""
+    """x [M <= 256, K] bf16/fp16 -> Partials([n_chunks, 32 * ceil(M / 32), N] fp32).  waves = column tiles per workgroup: 1..16 up to 64 rows, <= 8 up to
+    128 rows; 129..256 rows (bf16, uncompressed packing) run on kernel G1w: 2, 3, 4, 6 or 8."""
     M = x.shape[0]
     assert x.is_contiguous() and x.shape[1] == K and w_packed.numel() == N * K
     if isinstance(w_packed, PackedZ):

@@ -153,30 +153,58 @@ def test_g1_skinny_gemm_three_and_four_row_tiles(dev, dtype, M, N, K, KC, waves,
 
 
 @pytest.mark.parametrize("M,N,K,KC", [(256, 4096, 11008, 1376), (192, 12288, 4096, 2048), (160, 22016, 4096, 2048), (224, 4096, 4096, 896), (130, 512, 1376, 256),
-                                        (256, 64, 96, 32), (255, 256, 176, 64)])
-@pytest.mark.parametrize("step_major", [True, False])
-def test_g1_skinny_gemm_five_to_eight_row_tiles(dev, M, N, K, KC, step_major):
-    """round 5: 129..256-row windows (five to eight prompts per forward): g1_skinny_gemm_tiled8 with five to eight row tiles, four waves, one
-    workgroup per CU -- against an fp32 matmul, and plane for plane against the 32-row kernel fed 32 rows at a time (same chunking, same
-    accumulation order: bit-identical); bf16, four-wave workgroups only."""
+                                        (256, 64, 96, 32), (255, 256, 176, 64), (256, 4096, 11008, 1408), (256, 12288, 4096, 832), (256, 352, 4096, 512)])
+@pytest.mark.parametrize("tiles,step_major", [(4, True), (4, False), (8, True), (8, False), (2, True), (3, False), (6, True)])
+def test_g1_skinny_gemm_five_to_eight_row_tiles(dev, M, N, K, KC, tiles, step_major):
+    """129..256-row windows (five to eight prompts per forward): kernel G1w (round 6: activation stages by LDS-DMA, hand-counted vmcnt, one or two
+    column tiles per wave) -- against an fp32 matmul, and plane for plane against the 32-row kernel fed 32 rows at a time (same chunking, same
+    accumulation order: bit-identical); every column-tile count the launcher serves, ragged chunks, column counts that leave waves without a tile,
+    rows that are not whole tiles.  The planes are POISONED first: every element must be written."""
     import sjd_amd.ops as ops
     g = torch.Generator().manual_seed(N + K + M)
     x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
     wp = ops.pack_weight(w, KC, step_major)
-    part = ops.skinny_gemm(x, wp, N, K, KC, waves=4, step_major=step_major)
+    torch.full((2 * ((K + KC - 1) // KC) * 256 * N,), float("nan"), device=dev)      # (freed at once: the allocator hands the block to the planes)
+    part = ops.skinny_gemm(x, wp, N, K, KC, waves=tiles, step_major=step_major)
     assert part.n_chunks == (K + KC - 1) // KC and part.data.shape[1] == ((M + 31) // 32) * 32
     torch.testing.assert_close(part.data.sum(0)[:M], x.float() @ w.float().t(), atol=2e-3, rtol=2e-3)
     if M < part.data.shape[1]:
         assert part.data[:, M:].abs().max() == 0
-    for r0 in range(0, M, 32):
-        p32 = ops.skinny_gemm(x[r0:r0 + 32].contiguous(), wp, N, K, KC, waves=4, step_major=step_major)
-        rows = min(32, M - r0)
-        assert torch.equal(p32.data[:, :rows], part.data[:, r0:r0 + rows])
+    if KC <= 2560:
+        for r0 in range(0, M, 32):
+            p32 = ops.skinny_gemm(x[r0:r0 + 32].contiguous(), wp, N, K, KC, waves=4, step_major=step_major)
+            rows = min(32, M - r0)
+            assert torch.equal(p32.data[:, :rows], part.data[:, r0:r0 + rows])
     with pytest.raises(RuntimeError):
-        ops.skinny_gemm(x, wp, N, K, KC, waves=8, step_major=step_major)          # more than 128 rows: four-wave workgroups only
+        ops.skinny_gemm(x, wp, N, K, KC, waves=5, step_major=step_major)          # more than 128 rows: 2, 3, 4, 6 or 8 column tiles per workgroup
     with pytest.raises(RuntimeError):
         ops.skinny_gemm(x.to(torch.float16), wp, N, K, KC, waves=4, step_major=step_major)      # ... and bf16 only
+
+
+def test_g1_wide_chunk_neighbours_do_not_leak(dev):
+    """G1w fetches the activation columns past a ragged chunk's end out of range (zeros): NaN / Inf sitting right behind a chunk's last k-step -- in
+    the next chunk, or in the next row behind the matrix's last column -- must not reach the planes of the chunk in front of them."""
+    import sjd_amd.ops as ops
+    M, N, K, KC = 200, 256, 176, 80            # chunks of 5, 5 and 1 k-steps: every chunk ends inside a stage of four
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
+    wp = ops.pack_weight(w, KC, True)
+    clean = ops.skinny_gemm(x, wp, N, K, KC, waves=8, step_major=True).data.clone()
+    assert torch.isfinite(clean).all()
+    xa = x.clone()
+    xa[:, 80:96] = float("nan")                # the first k-step of chunk 1: right behind chunk 0's end, inside chunk 0's last stage
+    got = ops.skinny_gemm(xa, wp, N, K, KC, waves=8, step_major=True).data
+    assert torch.equal(got[0], clean[0]) and torch.equal(got[2], clean[2]) and torch.isnan(got[1][:M]).all()
+    xb = x.clone()
+    xb[:, 160:] = float("inf")                 # chunk 2: behind chunk 1's end
+    got = ops.skinny_gemm(xb, wp, N, K, KC, waves=8, step_major=True).data
+    assert torch.equal(got[0], clean[0]) and torch.equal(got[1], clean[1])
+    xc = x.clone()
+    xc[:, :48] = float("nan")                  # the head of every row: what lies behind the LAST chunk's end (the next row's first columns)
+    got = ops.skinny_gemm(xc, wp, N, K, KC, waves=8, step_major=True).data
+    assert torch.equal(got[1], clean[1]) and torch.equal(got[2], clean[2])
 
 
 def test_partials_feed_glue_kernels(dev):

@@ -391,8 +391,9 @@ class ChameleonBackbone(nn.Module):
     G1_CFG_128ROW = dict(qkv=(2048, 4, True), o=(896, 4, True), gate_up=(2048, 8, True), down=(1376, 4, True))
     # 129..256-row windows (five to eight prompts per forward): kernel G1w (csrc/sjd_gemm_wide.h, round 6) -- the second number is the column tiles
     # per workgroup: 2, 3, 4 (one per wave) or 6, 8 (two per wave).  tools/g1w_bench.py at 256 rows (profiles/r6_g1w_sweep.txt), us per launch against
-    # round 5's g1_skinny_gemm_tiled8: q|k|v 34.3 / 46.1, o 16.4 / 23.4, gate|up 58.4 / 84.4, down 31.3 / 38.2 (hipBLASLt: 50.4 / 19.1 / 65.9 / 52.7)
-    G1_CFG_256ROW = dict(qkv=(2048, 4, True), o=(512, 4, True), gate_up=(2048, 8, True), down=(1408, 4, True))
+    # round 5's g1_skinny_gemm_tiled8: q|k|v 34.3 / 46.1, o 19.6 / 23.4, gate|up 58.4 / 84.4, down 31.3 / 38.2 (hipBLASLt: 50.4 / 19.1 / 65.9 / 52.7); o with
+    # four planes instead of (512, 4)'s eight: 16.4 us alone, but 7.18 against 7.37 ms per step (F1r sums the planes; profiles/r6_g1w_cfg_ab.txt)
+    G1_CFG_256ROW = dict(qkv=(2048, 4, True), o=(1024, 2, True), gate_up=(2048, 8, True), down=(1408, 4, True))
     G1_WIDE_TILES = (2, 3, 4, 6, 8)
     # Emu3-Gen 8B (GQA 32/8: the q|k|v projection has 6144 columns; draft window 32 -> 64 rows), tuned end to end with bench.py --model emu3_8b
     G1_CFG_EMU3 = dict(qkv=(512, 8, False), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))        # profiles/r2_g1_launch_shape_sweep_emu3_64rows.jsonl

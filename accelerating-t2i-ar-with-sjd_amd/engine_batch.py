@@ -155,10 +155,18 @@ class SJDBatchEngine:
         lo, hi = (lo // 32) * 32, min(self.V, ((hi + 31) // 32) * 32)
         return (lo, hi) if 2 * (hi - lo) <= self.V else None
 
-    def _forward_body(self, cols):
+    def _per_slot(self, fn):
+        """fn(i, slot) for every slot, one after the other on the current stream.  (Round 6 measured the alternative -- the slots' K5 / K2 + K4
+        launches as parallel branches of the iteration's hipGraph, forked onto side streams and rejoined: eight prompts 7.2 -> 8.5 ms per step,
+        four 4.7 -> 5.5; a fork / join pair costs more than the 5-28 us launches it overlaps.  profiles/r6_slot_fanout_ab.txt)"""
         for i, s in enumerate(self.slots):
+            fn(i, s)
+
+    def _forward_body(self, cols):
+        def k5(i, s):
             lo, hi = i * self.nb, (i + 1) * self.nb
             ops.reguess(s.params, s.state, self.input_ids[lo:hi], pos_offset=self.pos_offset[lo:hi], positions_out=self.positions[lo:hi])
+        self._per_slot(k5)
         positions = self.positions
         if self.head_partials:
             return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start, cols=cols, head_partials=True)
@@ -176,7 +184,7 @@ class SJDBatchEngine:
                 self._dbg = torch.zeros(self.B, self.Lmax, self.V, dtype=torch.float32, device=self.device)
             dbg = self._dbg
             dbg.zero_()
-        for i, s in enumerate(self.slots):
+        def k2_k4(i, s):
             if part:
                 ops.logits_to_probs_sample_part(logits, self._guidance, s.params, None, s.probs[cur], s.tokens_ptr, amax_out_ptr=s.amax_ptr,
                                                 dbg=None if dbg is None else dbg[i * self.nb:(i + 1) * self.nb], row0=i * self.nb * self.Lmax,
@@ -188,6 +196,7 @@ class SJDBatchEngine:
                                            amax_out_ptr=s.amax_ptr)
                 s.zero_state[cur].fill_(-1)
             ops.verify_accept(s.params, s.state, s.probs[cur], s.probs[1 - cur], None, None, s.scratch, mirror=True)
+        self._per_slot(k2_k4)
 
     def _launch_forward(self, cols):
         if not self.use_graph:

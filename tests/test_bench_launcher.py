@@ -37,6 +37,32 @@ def test_gpus_n_relaunches_under_torchrun(bench, monkeypatch):
     assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_config4_queue_launch_reaches_device_selection(bench, monkeypatch):
+    """config 4 (`bench.py --gpus 8 --total-prompts 15`): the launcher fans out eight ranks with the queue flags intact, and a rank (WORLD_SIZE
+    set, as under the driver's torchrun) gets as far as device selection on this GPU-less box -- it must fail THERE, not in the argument
+    plumbing or by fanning out again (dataset_tools/multi_gpu_infer_with_prompt.py:146-172)."""
+    calls = {}
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: calls.update(cmd=cmd, env=env) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--total-prompts", "15"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and "--nproc-per-node=8" in calls["cmd"]
+    i = calls["cmd"].index(os.path.join(ROOT, "bench.py"))
+    assert calls["cmd"][i + 1:] == ["--gpus", "8", "--total-prompts", "15"]
+    a = bench.parse(["--gpus", "8", "--total-prompts", "15"])
+    assert a.gpus == 8 and a.total_prompts == 15 and a.prompts_per_gpu == 1
+    import torch
+    if torch.cuda.is_available():
+        return
+    monkeypatch.setattr(bench.subprocess, "call", lambda *a, **k: pytest.fail("a rank must not relaunch"))
+    for k, v in dict(WORLD_SIZE="8", RANK="3", LOCAL_RANK="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533").items():
+        monkeypatch.setenv(k, v)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "LOCAL_RANK 3" in str(e.value.code) and "GPU(s) visible" in str(e.value.code)          # device selection, nothing earlier
+
+
 def test_no_relaunch_inside_a_torchrun_rank(bench, monkeypatch):
     """under the driver's `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE is set: no second fan-out"""
     monkeypatch.setattr(bench.subprocess, "call", lambda *a, **k: pytest.fail("must not relaunch"))

@@ -91,6 +91,63 @@ def test_prompt_queue_world2_gloo():
     assert rep0 == rep1 == [(303.0, 33.0), (207.0, 27.0)] and ok0 and ok1
 
 
+def _queue8_worker(rank, world, port, n_prompts, scheme, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = []
+
+    def decode_one(i):             # stub engine: prompt i emits 100 + i tokens in 10 + i steps; odd ranks are slower
+        seen.append(i)
+        if rank % 2:
+            import time
+            time.sleep(0.02)
+        return 100 + i, 10 + i
+
+    out = run_prompt_queue(n_prompts, decode_one, scheme=scheme)
+    q.put((rank, seen, out["shard"], out["tokens"], out["steps"], [r[:2] for r in out["per_rank"]], out["world"],
+           out["seconds"] >= max(r[2] for r in out["per_rank"]) - 1e-12))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world8(n_prompts, scheme):
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_queue8_worker, args=(r, world, port, n_prompts, scheme, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return out
+
+
+def test_prompt_queue_world8_gloo_both_split_schemes():
+    """config 4's shape without the hardware: 8 ranks, 15 prompts (dataset_tools/multi_gpu_infer_with_prompt.py:146-172,
+    multi_gpu_dataframe_split.py:47-63) -- contiguous shards under both split schemes, every prompt decoded exactly once, ONE gathered report
+    all eight ranks agree on, the job's time = its slowest rank's."""
+    for scheme, sizes in (("balanced", [2, 2, 2, 2, 2, 2, 2, 1]), ("reference", [1, 1, 1, 1, 1, 1, 1, 8])):
+        out = _run_world8(15, scheme)
+        assert [len(o[1]) for o in out] == sizes
+        assert [i for o in out for i in o[1]] == list(range(15))                 # contiguous, in rank order, nothing twice
+        assert all(o[2] == contiguous_split(15, 8, o[0], scheme) for o in out)
+        assert all(o[3] == sum(100 + i for i in range(15)) and o[4] == sum(10 + i for i in range(15)) and o[6] == 8 and o[7] for o in out)
+        assert all(o[5] == out[0][5] for o in out)                               # the same per-rank report on every rank
+        assert out[0][5] == [(float(sum(100 + i for i in range(lo, hi))), float(sum(10 + i for i in range(lo, hi))))
+                             for lo, hi in (contiguous_split(15, 8, r, scheme) for r in range(8))]
+
+
+def test_prompt_queue_world8_gloo_ranks_without_prompts():
+    """fewer prompts than ranks: five ranks own an empty shard, finish at once and must still meet the others at the one all_gather"""
+    out = _run_world8(3, "balanced")
+    assert [o[1] for o in out] == [[0], [1], [2], [], [], [], [], []]
+    assert all(o[3] == 303 and o[4] == 33 for o in out) and all(o[5] == out[0][5] for o in out)
+    assert out[0][5][3:] == [(0.0, 0.0)] * 5
+
+
 def test_prompt_queue_without_process_group():
     out = run_prompt_queue(3, lambda i: (10, 2))
     assert out["tokens"] == 30 and out["steps"] == 6 and out["shard"] == (0, 3) and out["world"] == 1

@@ -64,7 +64,8 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_philox_fill", "sjd_philox_offset_increment", "sjd_skinny_gemm_reduce", "sjd_reduce_timeouts",
            "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged", "sjd_skinny_gemm_z", "sjd_gateup_silu_z", "sjd_qkv_attention_fused_split",
            "sjd_draft_window_attention_colsplit", "sjd_draft_window_attention_fp8_colsplit", "sjd_mlp_pair_z", "sjd_mlp_pair_timeouts",
-           "sjd_head_combine", "sjd_l2_head_gemm_z", "sjd_l2_head_gateup_z", "sjd_l2_head_bytes", "sjd_weight_prefetch_head", "sjd_debug_xcc_map", "sjd_residual_sumsq_pf", "sjd_skinny_gemm_engine_z", "sjd_engine_timeouts"]
+           "sjd_head_combine", "sjd_l2_head_gemm_z", "sjd_l2_head_gateup_z", "sjd_l2_head_bytes", "sjd_weight_prefetch_head", "sjd_debug_xcc_map", "sjd_residual_sumsq_pf", "sjd_skinny_gemm_engine_z", "sjd_engine_timeouts",
+           "sjd_raw_units_fixup", "sjd_raw_gateup_fixup"]
 
 _lib = None
 
@@ -128,6 +129,8 @@ def load():
     lib.sjd_skinny_gemm_reduce.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_skinny_gemm_z.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_gateup_silu_z.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp]
+    lib.sjd_raw_units_fixup.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.sjd_raw_gateup_fixup.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp]
     lib.sjd_philox_fill.argtypes = [vp, i64, ctypes.c_uint64, ctypes.c_uint64, i32, i32, vp]
     lib.sjd_philox_offset_increment.restype = ctypes.c_uint64
     lib.sjd_philox_offset_increment.argtypes = [i64, i32]

@@ -471,16 +471,16 @@ class ChameleonBackbone(nn.Module):
             self.HEAD_CFG = self.HEAD_CFG_WIDE
         self.compress_stats = dict(matrices=0, compressed=0, bytes_raw=0, bytes_packed=0, exceptions=0)
 
-        def pack(w, kc, sm):
+        def pack(w, kc, sm, gateup=False):
             st = self.compress_stats
             st["matrices"] += 1
             st["bytes_raw"] += w.numel() * w.element_size()
-            z = ops.pack_weight_z(w, kc, sm) if self.compress else None
+            z = ops.pack_weight_z(w, kc, sm, gateup=gateup) if self.compress else None
             if z is None:
                 if self.compress:      # asked for and declined: say so (a checkpoint with folded norm gains may land here; the plain stream is
                     st["declined"] = st.get("declined", 0) + 1          # bit-identical but 25 % more bytes -- VERDICT r3 weak #12)
                     why = ("dtype %s (the 12-bit form encodes bf16)" % str(w.dtype).replace("torch.", "") if w.dtype != torch.bfloat16
-                           else "KC %d > 4096" % kc if kc > 4096 else "a (k-chunk, 32-column) unit has more than %d out-of-window weights" % ops.Z_MAX_EXC)
+                           else "KC %d > 4096" % kc)
                     seen = st.setdefault("declined_reasons", {})
                     seen[why] = seen.get(why, 0) + 1
                     if seen[why] == 1:         # once per reason; the count is in compress_stats["declined_reasons"]
@@ -492,6 +492,9 @@ class ChameleonBackbone(nn.Module):
             st["compressed"] += 1
             st["bytes_packed"] += z.nbytes()
             st["exceptions"] += z.n_exceptions
+            st["units"] = st.get("units", 0) + z.stats.get("units", 0)
+            st["raw_units"] = st.get("raw_units", 0) + z.stats.get("raw_units", 0)            # (round 6: units that travel verbatim, ops.PackedZ)
+            st["max_exceptions_per_unit"] = max(st.get("max_exceptions_per_unit", 0), z.stats.get("max_exceptions", 0))
             return z
         self._packed = []
         self._fused = []
@@ -514,7 +517,7 @@ class ChameleonBackbone(nn.Module):
                         qkv_p, gu_p = qkv, gu
                     self._packed.append(dict(qkv=pack(qkv_p, c["qkv"][0], c["qkv"][2]),
                                              o=pack(a.o_proj.weight, c["o"][0], c["o"][2]),
-                                             gate_up=pack(gu_p, c["gate_up"][0], c["gate_up"][2]),
+                                             gate_up=pack(gu_p, c["gate_up"][0], c["gate_up"][2], gateup=2 * c["gate_up"][0] == gu_p.shape[1]),
                                              down=pack(m.down_proj.weight, c["down"][0], c["down"][2])))
             self._packed_head = None
             if gemm == "sjd" and self._fold_norm and self.lm_head.bias is None:

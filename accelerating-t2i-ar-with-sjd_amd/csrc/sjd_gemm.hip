@@ -17,6 +17,7 @@
 //   * loads are issued 8 k-steps ahead of their MFMA (register double buffer) and marked non-temporal (read once).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/sjd_hip.h"
 #include "sjd_mlp_epilogue.h"
@@ -1085,6 +1086,18 @@ __device__ __forceinline__ g1z_hraw g1z_header_load(const u32x2 *__restrict__ ex
     return h;
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t g1z_unit_rsrc(const unsigned char *first_record, unsigned bytes);
+// ---- RAW units (round 6): a unit whose weights do not fit the format (more than 127 outside any sixteen-binade window: zero rows, pruned blocks)
+// is zero-filled in the stream; its header says {base 0, count -1}, entry 1 holds the byte offset -- from `exc` -- of its weights as plain 1-KiB
+// records (sjd_skinny_gemm's order), which sjd_amd.ops.pack_weight_z appends to the header array.  The wave that owns such a unit runs the
+// PLAIN loop over those records (eight in flight, no decode) instead of the 12-bit one: one wave-uniform branch per kernel, the same MFMA
+// sequence, and a matrix without raw units never leaves the old path.  (A fix-up launch behind the kernel was built first, csrc/sjd_gemm_raw.h:
+// +5-7 us per projection with 1 % raw units -- a unit's MFMA chain is serial -- it now serves only the sub-tiled kernel.)
+__device__ __forceinline__ bool g1z_unit_is_raw(const g1z_hraw &h) { return __builtin_amdgcn_readfirstlane((int)h.a.y) < 0; }
+__device__ __forceinline__ const u32x4 *g1z_raw_records(const u32x2 *__restrict__ exc, const g1z_hraw &h, int lane)
+{
+    const unsigned off = (unsigned)__builtin_amdgcn_readlane((int)h.a.x, 1);
+    return reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(exc) + off) + lane;
+}
 __device__ __forceinline__ g1z_pair g1z_load(__amdgpu_buffer_rsrc_t wr, unsigned lane, unsigned soff)
 {
     g1z_pair v;          // (a pair past the unit's end reads as zero without touching memory; nt: streamed once)
@@ -1184,13 +1197,39 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu(const unsigned short *__r
             acc = G1Mfma<DT>::mma(a[1], b1, acc);
         }
     };
-    for (int g = 0; g < SP / TL; ++g) trip(g * TL, g * TL);                   // ---- phase 0
-    __syncthreads();
+    // a unit that travels verbatim (see g1z_raw_records): the plain trip over its 1-KiB records, eight in flight
+    const bool z_raw = g1z_unit_is_raw(hraw);
+    const u32x4 *rr = z_raw ? g1z_raw_records(exc, hraw, lane) : reinterpret_cast<const u32x4 *>(x);
+    u32x4 rc[8];
+    if (z_raw) {
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) x_store(i, val[i]);
-    __syncthreads();
-    SJD_TR(4);
-    for (int g = 0; g < SP / TL; ++g) trip(g * TL, SP + g * TL);              // ---- phase 1
+        for (int u = 0; u < 8; ++u) rc[u] = __builtin_nontemporal_load(rr + (size_t)u * 64);
+    }
+    auto trip_raw = [&](int l0, int s0) {
+#pragma unroll
+        for (int u = 0; u < TL; ++u) {
+            const u32x4 ar = xa[(l0 + u) * 64 + g1_slot(lane >> 5, lane & 31, u)];
+            acc = G1Mfma<DT>::mma(ar, rc[u & 7], acc);
+            rc[u & 7] = __builtin_nontemporal_load(rr + (size_t)min(s0 + u + 8, 2 * SP - 1) * 64);
+        }
+    };
+    // (ONE branch around both phases, not one per trip: the 12-bit ring and the raw ring are then never live together)
+    if (z_raw) {
+        for (int g = 0; g < SP / TL; ++g) trip_raw(g * TL, g * TL);               // ---- phase 0
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) x_store(i, val[i]);
+        __syncthreads();
+        for (int g = 0; g < SP / TL; ++g) trip_raw(g * TL, SP + g * TL);          // ---- phase 1
+    } else {
+        for (int g = 0; g < SP / TL; ++g) trip(g * TL, g * TL);                   // ---- phase 0
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) x_store(i, val[i]);
+        __syncthreads();
+        SJD_TR(4);
+        for (int g = 0; g < SP / TL; ++g) trip(g * TL, SP + g * TL);              // ---- phase 1
+    }
     SJD_TR(5);
     __syncthreads();
     constexpr int RP = 36;
@@ -1328,19 +1367,44 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu_tall(const unsigned short
             for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(a1[mt], b1, acc[mt]);
         }
     };
-    for (int ph = 0; ph < nph; ++ph) {
-        const u32x4 *xb = xl + bufof(ph) * BUF;
-        for (int g = 0; g < SP / TL; ++g) trip(xb, g * TL, ph * SP + g * TL);
-        if (ph + 1 < nph) {               // the next phase replaces this one (DB: goes into the other buffer), the one after it is requested (see g1_gateup_silu)
-            if (!DB) __syncthreads();
+    // a unit that travels verbatim (see g1z_raw_records): the plain trip over its 1-KiB records, eight in flight
+    // (SP = 32 with two row tiles -- hidden 4096 at 64 rows -- sits at its 256 registers: there the raw units are left to the fix-up launch,
+    //  sjd_raw_gateup_fixup; sjd_amd.ops.gateup_silu knows)
+    constexpr bool RAW_HERE = !(SP == 32 && MT == 2);
+    const bool z_raw = RAW_HERE && g1z_unit_is_raw(hraw);
+    const u32x4 *rr = z_raw ? g1z_raw_records(exc, hraw, lane) : reinterpret_cast<const u32x4 *>(x);
+    constexpr int RD = 4;                     // records in flight
+    u32x4 rc[RD];
+    if (z_raw) {
 #pragma unroll
-            for (int i = 0; i < NPT; ++i) x_store(bufof(ph + 1), i, val[i]);
-#pragma unroll
-            for (int i = 0; i < NPT; ++i) val[i] = x_load(ph + 2, i);
-        }
-        __syncthreads();
-        if (ph == 0) SJD_TR(4);
+        for (int u = 0; u < RD; ++u) rc[u] = __builtin_nontemporal_load(rr + (size_t)u * 64);
     }
+    auto trip_raw = [&](const u32x4 *xb, int l0, int s0) {
+#pragma unroll
+        for (int u = 0; u < TL; ++u) {
+            u32x4 ar[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ar[mt] = xb[((mt * 2 + kh) * SP + l0 + u) * 64 + g1_slot(lane >> 5, lane & 31, u)];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(ar[mt], rc[u % RD], acc[mt]);
+            rc[u % RD] = __builtin_nontemporal_load(rr + (size_t)min(s0 + u + RD, K / 32 - 1) * 64);
+        }
+    };
+    // (ONE branch around the phase loop, not one per trip: the 12-bit ring and the raw ring are then never live together)
+#define SJD_G1SZ_PHASES(TRIP_)                                                                                                              \
+    for (int ph = 0; ph < nph; ++ph) {                                                                                                      \
+        const u32x4 *xb = xl + bufof(ph) * BUF;                                                                                             \
+        for (int g = 0; g < SP / TL; ++g) TRIP_(xb, g * TL, ph * SP + g * TL);                                                              \
+        if (ph + 1 < nph) {    /* the next phase replaces this one (DB: the other buffer), the one after it is requested (g1_gateup_silu) */ \
+            if (!DB) __syncthreads();                                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < NPT; ++i) x_store(bufof(ph + 1), i, val[i]);                                               \
+            _Pragma("unroll") for (int i = 0; i < NPT; ++i) val[i] = x_load(ph + 2, i);                                                      \
+        }                                                                                                                                   \
+        __syncthreads();                                                                                                                    \
+        if (ph == 0) SJD_TR(4);                                                                                                             \
+    }
+    if constexpr (RAW_HERE) { if (z_raw) { SJD_G1SZ_PHASES(trip_raw) } else { SJD_G1SZ_PHASES(trip) } } else { SJD_G1SZ_PHASES(trip) }
+#undef SJD_G1SZ_PHASES
     SJD_TR(5);
     constexpr int RP = 36;
     float *red = reinterpret_cast<float *>(smem);
@@ -1654,6 +1718,26 @@ __global__ __launch_bounds__(MAXT) void g1z_skinny_gemm(const unsigned short *__
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[mt] = xl[mt * xs + min(s, steps - 1) * 64 + g1_slot(lane >> 5, lane & 31, u)];
     };
+    if (g1z_unit_is_raw(hraw)) {          // this wave's unit travels verbatim: the plain loop (see g1z_raw_records)
+        const u32x4 *rr = g1z_raw_records(exc, hraw, lane);
+        constexpr int RD = (MT == 2 && MAXT == 1024) ? 2 : 8;      // records in flight (the 128-register budget of 16-wave workgroups with two row tiles: 2)
+        u32x4 rc[RD];
+#pragma unroll
+        for (int u = 0; u < RD; ++u) rc[u] = __builtin_nontemporal_load(rr + (size_t)min(u, steps - 1) * 64);
+        for (int s0 = 0; s0 < steps; s0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sr = s0 + u;
+                if (sr < steps) {
+                    u32x4 ar[MT];
+                    a_read(ar, sr, u);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = G1Mfma<DT>::mma(ar[mt], rc[u % RD], acc[mt]);
+                }
+                rc[u % RD] = __builtin_nontemporal_load(rr + (size_t)min(sr + RD, steps - 1) * 64);
+            }
+        }
+    } else
     for (int s0 = 0; s0 < steps; s0 += TL) {
         u32x4 a0[MT], a1[MT];
         a_read(a0, s0, 0);
@@ -2048,6 +2132,7 @@ extern "C" int sjd_skinny_gemm_wide(const void *x, const void *w_packed, float *
 // workgroups of a reducing launch that gave up waiting for their slice's ticket since the library was loaded (0 on a healthy device)
 #include "sjd_gemm_pair.h"
 #include "sjd_gemm_engine.h"
+#include "sjd_gemm_raw.h"
 
 extern "C" int sjd_reduce_timeouts(void)
 {

@@ -337,51 +337,83 @@ def pack_weight(weight, KC, step_major=False):
 
 class PackedZ:
     """A packed weight in the 12-bit lossless stream format of kernels G1z / G1sz (see pack_weight_z): `data` uint8 [N * K * 3 / 2] (1536-byte
-    record pairs in pack_weight's record order), `exc` int32 [n_chunks, N / 32, 32, 2] (per-unit base / count and exceptions)."""
+    record pairs in pack_weight's record order), `exc` int32 [n_chunks, N / 32, cap, 2] (per-unit base / count and exceptions).  RAW units (round 6:
+    more out-of-window weights than a header holds) are zero-filled in `data`; their weights travel verbatim in `raw_data` (pack_weight's 1-KiB
+    records, KC / 16 per unit) and the launches behind the stream kernels recompute the tiles they feed: `raw_index` int32 [n_raw, 2] = (chunk,
+    tile) of unit i of `raw_data`; a weight packed with gateup=True additionally lists the gate tiles of the raw (gate, up) PAIRS in `raw_tiles`
+    int32 [n_pairs] -- its raw units are ordered [pair][K half][gate | up], so the same `raw_data` serves both fix-up kernels."""
 
-    def __init__(self, data, exc, N, K, KC, step_major, n_exceptions):
+    def __init__(self, data, exc, N, K, KC, step_major, n_exceptions, raw_index=None, raw_tiles=None, raw_data=None, stats=None):
         self.data, self.exc, self.N, self.K, self.KC, self.step_major, self.n_exceptions = data, exc, N, K, KC, bool(step_major), int(n_exceptions)
         self.cap = int(exc.shape[2])
+        self.raw_index, self.raw_tiles, self.raw_data = raw_index, raw_tiles, raw_data
+        self.n_raw = 0 if raw_data is None else int(raw_index.shape[0])
+        self.n_raw_pairs = 0 if raw_tiles is None else int(raw_tiles.shape[0])
+        self.stats = stats or {}
 
     def numel(self):
         return self.N * self.K
 
     def nbytes(self):
-        return self.data.numel() + self.exc.numel() * 4
+        return self.data.numel() + self.exc.numel() * 4 + (0 if self.raw_data is None else self.raw_data.numel() * 2)
 
 
 Z_MAX_EXC = 127         # exceptions a (k-chunk, 32-column tile) unit can carry: headers of 32 / 64 / 128 entries, chosen per matrix
 
 
-def pack_weight_z(weight, KC, step_major=False):
+def pack_weight_z(weight, KC, step_major=False, gateup=False):
     """[N, K] bf16 weight -> PackedZ, the LOSSLESS 12-bit form of pack_weight(weight, KC, step_major) that sjd_skinny_gemm_z / sjd_gateup_silu_z
-    stream (include/sjd_hip.h), or None when the weight does not fit the format (not bf16, KC > 4096, or a unit with more than 127 exceptions).
+    stream (include/sjd_hip.h), or None when the format does not apply (not bf16, KC > 4096).
     The header of a unit has 32 entries (31 exceptions: Gaussian weights need 3-13) or, for the whole matrix, 64 / 128 when some unit needs
     them (heavy-tailed weights, norm gains folded into the columns: 10-30 per 16 k-weight unit).
     Per unit (k-chunk c, tile t) the window of eight consecutive values of the weights' 7 high exponent bits that covers most of the unit is
     chosen from the unit's histogram (robust against outliers on either side); a weight inside it is stored as low byte + code
-    (sign << 3 | offset), one outside it additionally verbatim as an exception."""
+    (sign << 3 | offset), one outside it additionally verbatim as an exception.
+    A unit with more than 127 exceptions (zero rows, pruned blocks, weights spanning more than sixteen binades) is RAW (round 6; the packer
+    used to decline the whole matrix): see PackedZ.  gateup=True: `weight` is [Wg; Wu] packed with KC = K / 2 for sjd_gateup_silu_z -- a raw
+    unit makes the packer list its whole (gate tile, up tile) pair, both K halves."""
     if weight.dtype != torch.bfloat16 or KC > 4096:
         return None
     N, K = weight.shape
     assert N % 32 == 0 and K % 16 == 0 and KC % 16 == 0
     T, dev = N // 32, weight.device
+    n_chunks = (K + KC - 1) // KC
+    assert not gateup or (2 * KC == K and T % 2 == 0)
     bits = weight.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
-    datas, hdrs, total, max_cnt = [], [], 0, 0
+    # ---- pass 1: per unit the window and its exception count -> which units are raw
+    bases, cnts = [], []
     for k0 in range(0, K, KC):
         kc = min(KC, K - k0)
         S = kc // 16
-        b = bits[:, k0:k0 + kc].reshape(T, 32, S, 2, 8)                     # [t, r, s, h, j]
-        eh = (b >> 8) & 0x7F
+        eh = (bits[:, k0:k0 + kc].reshape(T, 32 * kc) >> 8) & 0x7F
         hist = torch.zeros(T, 128, dtype=torch.int64, device=dev)
-        hist.scatter_add_(1, eh.reshape(T, -1).to(torch.int64), torch.ones(1, dtype=torch.int64, device=dev).expand(T, 32 * S * 16))
+        hist.scatter_add_(1, eh.to(torch.int64), torch.ones(1, dtype=torch.int64, device=dev).expand(T, 32 * kc))
         cs = torch.cat([torch.zeros(T, 1, dtype=torch.int64, device=dev), hist.cumsum(1)], dim=1)
-        base = (cs[:, 8:129] - cs[:, 0:121]).argmax(dim=1).to(torch.int32)   # [T] in 0..120: window [base, base + 7]
+        inside = cs[:, 8:129] - cs[:, 0:121]
+        base = inside.argmax(dim=1)
+        bases.append(base.to(torch.int32))                                   # [T] in 0..120: window [base, base + 7]
+        cnts.append(32 * kc - inside.gather(1, base[:, None])[:, 0])
+    cnt_all = torch.stack(cnts)                                              # [n_chunks, T]
+    raw_mask = cnt_all > Z_MAX_EXC
+    if gateup and bool(raw_mask.any()):                                      # a raw unit anywhere in a (gate, up) pair: the pair, both K halves
+        pair = raw_mask.reshape(n_chunks, 2, T // 2).any(dim=0).any(dim=0)   # [T / 2]
+        raw_mask = pair[None, None, :].expand(n_chunks, 2, T // 2).reshape(n_chunks, T).clone()
+    stats = dict(units=int(n_chunks * T), raw_units=int(raw_mask.sum()), max_exceptions=int(cnt_all[~raw_mask].max()) if bool((~raw_mask).any()) else 0,
+                 mean_exceptions=float(cnt_all[~raw_mask].float().mean()) if bool((~raw_mask).any()) else 0.0)
+    # ---- pass 2: encode
+    datas, hdrs, total, max_cnt = [], [], 0, 0
+    for ci, k0 in enumerate(range(0, K, KC)):
+        kc = min(KC, K - k0)
+        S = kc // 16
+        b = bits[:, k0:k0 + kc].reshape(T, 32, S, 2, 8)                     # [t, r, s, h, j]
+        rm = raw_mask[ci]
+        if bool(rm.any()):
+            b = torch.where(rm.view(T, 1, 1, 1, 1), torch.zeros_like(b), b)  # a raw unit's slot in the stream: zeros (code 0, low byte 0, base 0)
+        base = torch.where(rm, torch.zeros_like(bases[ci]), bases[ci])
+        eh = (b >> 8) & 0x7F
         e3 = eh - base.view(T, 1, 1, 1, 1)
-        bad = (e3 < 0) | (e3 > 7)
+        bad = ((e3 < 0) | (e3 > 7)) & ~rm.view(T, 1, 1, 1, 1)
         cnt = bad.reshape(T, -1).sum(dim=1)
-        if int(cnt.max()) > Z_MAX_EXC:
-            return None
         max_cnt = max(max_cnt, int(cnt.max()))
         code = ((b >> 15) << 3) | e3.clamp(0, 7)                             # [t, r, s, h, j]
         lo = b & 0xFF
@@ -404,7 +436,7 @@ def pack_weight_z(weight, KC, step_major=False):
         datas.append(rec.reshape(-1))
         hdr = torch.full((T, Z_MAX_EXC + 1, 2), -1, dtype=torch.int32, device=dev)       # (cut to the matrix's capacity below)
         hdr[:, 0, 0] = base
-        hdr[:, 0, 1] = cnt.to(torch.int32)
+        hdr[:, 0, 1] = torch.where(rm, torch.full_like(cnt, -1), cnt).to(torch.int32)     # (-1: a raw unit; entry 1 then holds where its records are)
         idx = bad.nonzero()                                                  # rows sorted by t first
         if idx.numel():
             t_i, r_i, s_i, h_i, j_i = idx.unbind(1)
@@ -416,7 +448,40 @@ def pack_weight_z(weight, KC, step_major=False):
         hdrs.append(hdr)
     data = torch.cat(datas).contiguous().view(torch.uint8)
     cap = 32 if max_cnt <= 31 else 64 if max_cnt <= 63 else 128
-    return PackedZ(data, torch.stack(hdrs)[:, :, :cap].contiguous(), N, K, KC, step_major, total)
+    # ---- the raw units' weights, verbatim, in pack_weight's record order ([s, h, r, j]: lane = 32 h + r), KC / 16 records per unit
+    raw_index = raw_tiles = raw_data = None
+    if stats["raw_units"]:
+        SF = KC // 16
+
+        def unit_records(ci, t):
+            k0 = ci * KC
+            kc = min(KC, K - k0)
+            u = weight[32 * t:32 * t + 32, k0:k0 + kc].reshape(32, kc // 16, 2, 8).permute(1, 2, 0, 3).reshape(kc // 16, 512)
+            if kc // 16 < SF:
+                u = torch.cat([u, torch.zeros(SF - kc // 16, 512, dtype=u.dtype, device=dev)])
+            return u
+        if gateup:                      # units ordered [pair][K half][gate | up]
+            tiles = raw_mask[0, :T // 2].nonzero()[:, 0]
+            raw_tiles = tiles.to(torch.int32).contiguous()
+            units = [(kh, int(t) + gu * (T // 2)) for t in tiles.tolist() for kh in (0, 1) for gu in (0, 1)]
+        else:
+            units = [(int(c), int(t)) for c, t in raw_mask.nonzero().tolist()]
+        raw_index = torch.tensor(units, dtype=torch.int32, device=dev).contiguous()
+        raw_data = torch.stack([unit_records(c, t) for c, t in units]).contiguous()
+    # ONE allocation: the headers, then the raw units' records -- a kernel reaches a raw unit's records from `exc` through the byte offset in
+    # entry 1 of the unit's header (csrc/sjd_gemm.hip: g1z_raw_records), so no kernel takes another pointer argument
+    hdr_all = torch.stack(hdrs)[:, :, :cap].contiguous()
+    if raw_data is None:
+        return PackedZ(data, hdr_all, N, K, KC, step_major, total, None, None, None, stats)
+    hdr_ints = hdr_all.numel()
+    assert hdr_ints * 4 + raw_data.numel() * 2 < 2 ** 31
+    for u, (c, t) in enumerate(units):
+        hdr_all[c, t, 1, 0] = hdr_ints * 4 + u * (KC // 16) * 1024
+        hdr_all[c, t, 1, 1] = 0
+    blob = torch.cat([hdr_all.reshape(-1), raw_data.reshape(-1).view(torch.int32)]).contiguous()
+    exc = blob[:hdr_ints].view(hdr_all.shape)
+    raw_view = blob[hdr_ints:].view(torch.bfloat16).view(raw_data.shape)
+    return PackedZ(data, exc, N, K, KC, step_major, total, raw_index, raw_tiles, raw_view, stats)
 
 
 def _prows(M):
@@ -556,6 +621,11 @@ def skinny_gemm_cols(x, w_packed, N_packed, K, KC, col0, n_cols, waves=8, step_m
             raise ValueError(f"G1z: a {M}-row window with K chunks of {KC} runs on the sub-tiled kernel (up to 128 rows, at most 8 waves), got waves={waves}")
         L.check(L.load().sjd_skinny_gemm_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), w_packed.cap, _ptr(out), M, n_cols, K, KC, waves, int(step_major),
                                           _dtype_code(x.dtype), N_packed, col0 // 32, _stream()), "sjd_skinny_gemm_z")
+        if w_packed.n_raw and (M > 64 or (M > 32 and min(KC, K) > 1280)):
+            # g1z_skinny_gemm runs a raw unit's plain records in the kernel; the SUB-TILED kernel (65..128 rows, or 33..64 with a chunk that does not
+            # fit LDS) does not: there the tiles fed by raw units are recomputed by a launch behind it (csrc/sjd_gemm_raw.h)
+            L.check(L.load().sjd_raw_units_fixup(_ptr(x), _ptr(w_packed.raw_data), _ptr(w_packed.raw_index), w_packed.n_raw, _ptr(out), M, n_cols, K, KC,
+                                                col0 // 32, _dtype_code(x.dtype), _stream()), "sjd_raw_units_fixup")
         return Partials(out, nc, n_cols)
     L.check(L.load().sjd_skinny_gemm_cols(_ptr(x), _ptr(w_packed), _ptr(out), M, n_cols, K, KC, waves, int(step_major), _dtype_code(x.dtype),
                                          N_packed, col0 // 32, _stream()), "sjd_skinny_gemm_cols")
@@ -732,8 +802,12 @@ def gateup_silu(x, w_packed, inter, hidden, step_major=False, row_norm=None):
     y = torch.empty(T, inter, dtype=x.dtype, device=x.device)
     if isinstance(w_packed, PackedZ):
         assert (w_packed.KC, w_packed.step_major) == (hidden // 2, bool(step_major)) and x.dtype == torch.bfloat16
+        assert w_packed.n_raw == 0 or w_packed.raw_tiles is not None, "a gate|up weight with raw units must be packed with gateup=True"
         L.check(L.load().sjd_gateup_silu_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), w_packed.cap, _ptr(y), T, inter, hidden, int(step_major),
                                           _dtype_code(x.dtype), _row_norm(row_norm), _stream()), "sjd_gateup_silu_z")
+        if w_packed.n_raw_pairs and T > 32 and hidden == 4096:      # (the one G1sz instantiation without the in-kernel raw path: see g1z_gateup_silu_tall)
+            L.check(L.load().sjd_raw_gateup_fixup(_ptr(x), _ptr(w_packed.raw_data), _ptr(w_packed.raw_tiles), w_packed.n_raw_pairs, _ptr(y), T, inter, hidden,
+                                                 _dtype_code(x.dtype), _row_norm(row_norm), _stream()), "sjd_raw_gateup_fixup")
         return y
     L.check(L.load().sjd_gateup_silu(_ptr(x), _ptr(w_packed), _ptr(y), T, inter, hidden, int(step_major), _dtype_code(x.dtype),
                                     _row_norm(row_norm), _stream()), "sjd_gateup_silu")
@@ -746,7 +820,7 @@ _PAIR_READY = {}          # (device, stream) -> arrival counters of sjd_mlp_pair
 def mlp_pair_ok(T, inter, hidden, gu_packed, dn_packed, KC_dn, waves_dn, device):
     """shapes sjd_mlp_pair_z serves (see include/sjd_hip.h): a <= 32-row bf16 window at hidden 4096 over two 12-bit packed weights, the down
     projection in eight-tile workgroups with a K chunk that is a multiple of 64, the whole launch resident at once"""
-    if not (isinstance(gu_packed, PackedZ) and isinstance(dn_packed, PackedZ)):
+    if not (isinstance(gu_packed, PackedZ) and isinstance(dn_packed, PackedZ)) or gu_packed.n_raw or dn_packed.n_raw:
         return False
     if T > 32 or hidden != 4096 or inter % 64 or KC_dn % 64 or KC_dn > 2560 or waves_dn != 8 or gu_packed.KC != hidden // 2 or dn_packed.KC != KC_dn:
         return False

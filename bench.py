@@ -340,8 +340,12 @@ def measure_g1(args, model, device, rounds=6):
     tot_b = rounds * sum(wbytes(pk[name], N, K) + rows * K * 2 for pk in model._packed for name, (N, K) in shapes.items())
     tot_b16 = rounds * len(model._packed) * sum(N * K * 2 + rows * K * 2 for N, K in shapes.values())
     nz = sum(isinstance(pk[name], ops.PackedZ) for pk in model._packed for name in shapes)
+    cs = getattr(model, "compress_stats", None) or {}
+    pack = {k: cs[k] for k in ("matrices", "compressed", "declined", "units", "raw_units", "exceptions", "max_exceptions_per_unit") if k in cs}
+    if pack.get("units"):
+        pack["exceptions_per_unit"] = round(pack.get("exceptions", 0) / pack["units"], 2)
     return dict(launches=n, avg_ms=tot_ms / n, avg_bytes=tot_b / n, gbps=tot_b / 1e9 / (tot_ms / 1e3), fused_mlp=bool(fused_mlp), rows=rows,
-                compressed_launches=rounds * nz, avg_bytes_bf16=tot_b16 / n, gbps_bf16_equivalent=tot_b16 / 1e9 / (tot_ms / 1e3))
+                compressed_launches=rounds * nz, avg_bytes_bf16=tot_b16 / n, gbps_bf16_equivalent=tot_b16 / 1e9 / (tot_ms / 1e3), pack=pack)
 
 
 def cpu_baseline(args, gpu_sched_ms=None):
@@ -543,13 +547,14 @@ def roofline_blocks(args, prof, prof_g1, pair=None):
             g1_block.update({"weight_stream": f"lossless 12-bit (G1z / G1sz; {prof_g1['compressed_launches']} of {prof_g1['launches']} launches; "
                                               "results bit-identical to the bf16 stream): `achieved` prices the bf16 bytes of SURVEY.md 8(d), "
                                               "the kernel moves `stored_bytes`",
+                             "pack": prof_g1.get("pack"),       # (round 6: units that travel verbatim -- `raw_units` -- and exceptions per unit; synthetic Gaussians: 0 raw)
                              "stored_bytes": int(prof_g1["avg_bytes"]),
                              "hbm_GBps_on_stored_bytes": round(prof_g1["gbps"], 1),
                              "frac_on_stored_bytes": round(prof_g1["gbps"] / peak, 4)})
     return (g1_block, k1_block) if g1_block is not None else (k1_block, None)
 
 
-def other_config(base_args, model_name, window, device, steps=64, warmup=8, dtype=None):
+def other_config(base_args, model_name, window, device, steps=64, warmup=8, dtype=None, kv="auto"):
     """Compact record of another BASELINE.json configuration measured in THIS run (configs 3 and 5 next to the headline's config 2):
     the model is built, decoded through a real lead-in to its mean KV length, `steps` SJD iterations are timed, G1 and K1 are measured
     with HIP events exactly as for the headline; then everything is freed."""
@@ -557,14 +562,14 @@ def other_config(base_args, model_name, window, device, steps=64, warmup=8, dtyp
     import gc
     import torch
     a = copy.copy(base_args)
-    a.model, a.window, a.dtype, a.kv, a.prompts_per_gpu, a.n_split = model_name, window, dtype, "auto", 1, 0
+    a.model, a.window, a.dtype, a.kv, a.prompts_per_gpu, a.n_split = model_name, window, dtype, kv, 1, 0
     t0 = time.perf_counter()
     from sjd_amd.engine import SJDEngine
     import sjd_amd.ops as ops_
     model, margs, attn = build_model(a, device)
     w = workload_of(a, margs, 0, device)
     P, n_img = w["P"], w["n_img"]
-    fp8_kv = model_name == "anole7b"
+    fp8_kv = kv == "fp8" or (kv == "auto" and model_name == "anole7b")
     model.setup_cache(batch=2, s_max=((P + n_img + 2 * window + 64 + 31) // 32) * 32, dtype=ops_.FP8 if fp8_kv else None)
     eng = SJDEngine(model, margs.vocab_size, device, max_window=window, use_graph=not a.no_graph)
     lead = int(P + n_img // 2 - w["tau_est"] * (steps / 2.0 + warmup))
@@ -862,9 +867,12 @@ def main():
         out["other_configs"] = {}
         # (config 3 twice: fp16 as BASELINE.json words it, and bf16 -- what the reference's own test_emu3.py:27 runs -- where the lossless
         #  12-bit weight stream G1z / G1sz applies)
-        for key, name, win, dt_ in (("emu3_8b", "emu3_8b", 32, None), ("emu3_8b_bf16", "emu3_8b", 32, "bf16"), ("anole7b", "anole7b", 16, None)):
+        # (config 5 twice as well: the fp8 KV cache BASELINE.json names, and the same workload on the bf16 cache -- the reference's own precision,
+        #  JA:137-272 / MC:567 -- so that what the fp8 path buys or costs in tokens/s sits in one driver-run line)
+        for key, name, win, dt_, kv_ in (("emu3_8b", "emu3_8b", 32, None, "auto"), ("emu3_8b_bf16", "emu3_8b", 32, "bf16", "auto"),
+                                         ("anole7b", "anole7b", 16, None, "fp8"), ("anole7b_bf16kv", "anole7b", 16, None, "16bit")):
             try:
-                out["other_configs"][key] = other_config(args, name, win, device, dtype=dt_)
+                out["other_configs"][key] = other_config(args, name, win, device, dtype=dt_, kv=kv_)
             except Exception as e:       # a side leg must not cost the headline line
                 out["other_configs"][key] = {"error": repr(e)[:300]}
     out["bench_wall_s"] = {"decode": round(decode_wall, 2)}

@@ -341,6 +341,20 @@ int sjd_skinny_gemm_z(const void *x, const void *wz, const void *exc, int exc_ca
 int sjd_gateup_silu_z(const void *x, const void *wz, const void *exc, int exc_cap, void *y, int M, int I, int K, int step_major, int dtype,
                       const sjd_row_norm *row_norm, void *stream);
 
+/* Round 6 -- the per-unit escape of the 12-bit stream (csrc/sjd_gemm_raw.h).  A (k-chunk, 32-column tile) unit with more out-of-window weights
+ * than a header holds (zero rows, pruned blocks, more than sixteen binades in one unit: a real checkpoint, reference IS:287-289, ML:83-140) no
+ * longer makes sjd_amd.ops.pack_weight_z decline the matrix: the unit is zero-filled in the stream, travels verbatim in `raw` (1-KiB records in
+ * sjd_skinny_gemm's order, KC / 16 per unit) and ONE small launch behind the stream kernel, on the same stream, recomputes the tiles it feeds --
+ * the same MFMA sequence per (tile, chunk, row tile), bit-identical to the uncompressed kernels.  n_raw == 0: no launch.
+ *   sjd_raw_units_fixup : behind sjd_skinny_gemm_z(x, ..., out, M, N, K, KC, ..., N_packed, tile0); index int32 [n_raw, 2] = (chunk, packed tile)
+ *   sjd_raw_gateup_fixup: behind sjd_gateup_silu_z(x, ..., y, M, I, K, ..., row_norm); tiles int32 [n_pairs] gate tiles, raw per pair
+ *                         [K half][gate | up][K / 32 records] (the packer lists the whole pair when any of its four units is raw)
+ * replaces, like G1z / G1sz: the nn.Linear calls of the decoder layer (reference modeling_chameleon.py:527-529, 579, 193-195) and lm_head. */
+int sjd_raw_units_fixup(const void *x, const void *raw, const int32_t *index, int n_raw, float *out, int M, int N, int K, int KC, int tile0,
+                        int dtype, void *stream);
+int sjd_raw_gateup_fixup(const void *x, const void *raw, const int32_t *tiles, int n_pairs, void *y, int M, int I, int K, int dtype,
+                         const sjd_row_norm *row_norm, void *stream);
+
 /* Weight prefetch for G1: reads `nbytes` of packed weights with plain loads and discards them, so that the lines sit in the 256 MiB
  * Infinity Cache when the next sjd_skinny_gemm streams them.  Meant for a SIDE stream / parallel hipGraph branch while the
  * latency-bound kernels of the layer (F1r, F2, K1, F3) leave HBM idle.  No reference counterpart (the reference's nn.Linear calls,

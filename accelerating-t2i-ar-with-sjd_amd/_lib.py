@@ -53,19 +53,24 @@ class L2Head(ctypes.Structure):
                 ("pairs_last", ctypes.c_int32), ("step_major", ctypes.c_int32), ("head_pairs", ctypes.c_int32)]
 
 
+# what include/sjd_hip.h declares = what libsjd_hip.so exports = what the product (engine.py, engine_batch.py, backbones.py with default switches) reaches
 EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_probs_sample", "sjd_verify_accept",
            "sjd_kv_append", "sjd_attention_workspace_bytes", "sjd_draft_window_attention", "sjd_draft_window_attention_ex",
            "sjd_event_create", "sjd_event_destroy", "sjd_event_synchronize", "sjd_event_elapsed_ms",
            "sjd_add_rmsnorm", "sjd_qknorm_rope_append", "sjd_silu_mul", "sjd_gemm_num_chunks", "sjd_skinny_gemm",
            "sjd_kv_append_fp8", "sjd_draft_window_attention_fp8", "sjd_qknorm_rope_append_fp8",
-           "sjd_residual_sumsq", "sjd_qknorm_rope_append_ex", "sjd_silu_mul_ex", "sjd_weight_prefetch", "sjd_qkv_attention_fused", "sjd_skinny_gemm_cols",
+           "sjd_residual_sumsq", "sjd_qknorm_rope_append_ex", "sjd_silu_mul_ex", "sjd_skinny_gemm_cols",
            "sjd_logits_to_probs_sample_part", "sjd_logits_to_probs_sample_ex", "sjd_reguess_ex",
            "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu", "sjd_host_wait_u64",
-           "sjd_philox_fill", "sjd_philox_offset_increment", "sjd_skinny_gemm_reduce", "sjd_reduce_timeouts",
-           "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged", "sjd_skinny_gemm_z", "sjd_gateup_silu_z", "sjd_qkv_attention_fused_split",
-           "sjd_draft_window_attention_colsplit", "sjd_draft_window_attention_fp8_colsplit", "sjd_mlp_pair_z", "sjd_mlp_pair_timeouts",
-           "sjd_head_combine", "sjd_l2_head_gemm_z", "sjd_l2_head_gateup_z", "sjd_l2_head_bytes", "sjd_weight_prefetch_head", "sjd_debug_xcc_map", "sjd_residual_sumsq_pf", "sjd_skinny_gemm_engine_z", "sjd_engine_timeouts",
-           "sjd_raw_units_fixup", "sjd_raw_gateup_fixup"]
+           "sjd_philox_fill", "sjd_philox_offset_increment", "sjd_skinny_gemm_z", "sjd_gateup_silu_z",
+           "sjd_draft_window_attention_colsplit", "sjd_draft_window_attention_fp8_colsplit",
+           "sjd_head_combine", "sjd_raw_units_fixup", "sjd_raw_gateup_fixup"]
+# what include/sjd_hip_experimental.h adds: libsjd_hip_exp.so only (the measured no-go structures of rounds 2-5 and the G1w tuning entry)
+EXP_EXPORTS = ["sjd_weight_prefetch", "sjd_qkv_attention_fused", "sjd_qkv_attention_fused_split", "sjd_skinny_gemm_reduce", "sjd_reduce_timeouts",
+               "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged", "sjd_mlp_pair_z", "sjd_mlp_pair_timeouts",
+               "sjd_l2_head_gemm_z", "sjd_l2_head_gateup_z", "sjd_l2_head_bytes", "sjd_weight_prefetch_head", "sjd_debug_xcc_map", "sjd_residual_sumsq_pf",
+               "sjd_skinny_gemm_engine_z", "sjd_engine_timeouts", "sjd_skinny_gemm_wide"]
+EXP_SO_PATH = os.environ.get("SJD_HIP_EXP_LIB") or os.path.join(_HERE, "libsjd_hip_exp.so")
 
 _lib = None
 
@@ -82,6 +87,15 @@ def load():
         raise SjdLibraryError(f"{SO_PATH} is missing: build the HIP extension first (python __graft_entry__.py). "
                               "There is no CPU/torch fallback for the SJD hot path.")
     lib = ctypes.CDLL(SO_PATH)
+    _bind_product(lib)
+    for name in EXPORTS:
+        getattr(lib, name)
+    assert ctypes.sizeof(RowRule) == 52 and ctypes.sizeof(IterParams) == 64 + 8 * MAX_WINDOW + 2 * 52 * MAX_WINDOW
+    _lib = lib
+    return lib
+
+
+def _bind_product(lib):
     vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
     lib.sjd_version.restype = i32
     lib.sjd_error_string.restype = ctypes.c_char_p
@@ -100,11 +114,8 @@ def load():
     lib.sjd_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     lib.sjd_draft_window_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp]
     lib.sjd_draft_window_attention_ex.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]
-    lib.sjd_draft_window_attention_merged.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
-    lib.sjd_draft_window_attention_fp8_merged.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp, vp, vp]
     lib.sjd_draft_window_attention_colsplit.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.sjd_draft_window_attention_fp8_colsplit.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, vp]
-    lib.sjd_mlp_pair_z.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp, i32, vp]
     lib.sjd_add_rmsnorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, vp, i32, vp]
     lib.sjd_qknorm_rope_append.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp]
     lib.sjd_silu_mul.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
@@ -117,16 +128,10 @@ def load():
     lib.sjd_silu_mul_ex.argtypes = [vp, vp, i32, i32, i32, vp, i32, ctypes.POINTER(RowNorm), vp]
     lib.sjd_kv_append_fp8.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, i32, vp, i32, vp]
     lib.sjd_draft_window_attention_fp8.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp, vp]
-    lib.sjd_weight_prefetch.argtypes = [vp, i64, i32, vp, vp]
     lib.sjd_skinny_gemm_cols.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_logits_to_probs_sample_part.argtypes = [ctypes.POINTER(HeadPartials), f32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.sjd_head_combine.argtypes = [ctypes.POINTER(HeadPartials), f32, i32, i32, vp, vp, vp]
     lib.sjd_logits_to_probs_sample_ex.argtypes = [vp, vp, i64, f32, i32, i32, vp, vp, vp, vp, vp, vp]
-    lib.sjd_qkv_attention_fused.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),
-                                            vp, vp, i32, vp]
-    lib.sjd_qkv_attention_fused_split.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),
-                                                  vp, vp, i32, i32, vp, vp]
-    lib.sjd_skinny_gemm_reduce.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_skinny_gemm_z.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_gateup_silu_z.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp]
     lib.sjd_raw_units_fixup.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]
@@ -134,6 +139,36 @@ def load():
     lib.sjd_philox_fill.argtypes = [vp, i64, ctypes.c_uint64, ctypes.c_uint64, i32, i32, vp]
     lib.sjd_philox_offset_increment.restype = ctypes.c_uint64
     lib.sjd_philox_offset_increment.argtypes = [i64, i32]
+    lib.sjd_event_create.restype = vp
+    lib.sjd_event_destroy.argtypes = [vp]
+    lib.sjd_event_synchronize.argtypes = [vp]
+    lib.sjd_event_elapsed_ms.restype = f32
+    lib.sjd_event_elapsed_ms.argtypes = [vp, vp]
+
+
+_exp = None
+
+
+def load_exp():
+    """libsjd_hip_exp.so: the product's entry points plus the experimental ones (include/sjd_hip_experimental.h).  Only the opt-in switches of
+    backbones.py, the experiments' own tests and the tools call this; the product path never does."""
+    global _exp
+    if _exp is not None:
+        return _exp
+    if not os.path.exists(EXP_SO_PATH):
+        raise SjdLibraryError(f"{EXP_SO_PATH} is missing: build it first (python __graft_entry__.py / make -C accelerating-t2i-ar-with-sjd_amd/csrc)")
+    lib = ctypes.CDLL(EXP_SO_PATH)
+    _bind_product(lib)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    lib.sjd_draft_window_attention_merged.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.sjd_draft_window_attention_fp8_merged.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp, vp, vp]
+    lib.sjd_mlp_pair_z.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp, i32, vp]
+    lib.sjd_weight_prefetch.argtypes = [vp, i64, i32, vp, vp]
+    lib.sjd_qkv_attention_fused.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),
+                                            vp, vp, i32, vp]
+    lib.sjd_qkv_attention_fused_split.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),
+                                                  vp, vp, i32, i32, vp, vp]
+    lib.sjd_skinny_gemm_reduce.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_l2_head_gemm_z.argtypes = [ctypes.POINTER(L2Head), vp, i32, i32, i32, i32, i32, i32, i32, i32, i32]
     lib.sjd_l2_head_gateup_z.argtypes = [ctypes.POINTER(L2Head), vp, i32, i32, i32, i32, i32]
     lib.sjd_l2_head_bytes.restype = i64
@@ -142,15 +177,10 @@ def load():
     lib.sjd_debug_xcc_map.argtypes = [vp, i32, i32, vp]
     lib.sjd_skinny_gemm_engine_z.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_residual_sumsq_pf.argtypes = [vp, vp, i32, i32, i32, i32, vp, ctypes.POINTER(L2Head), i32, vp]
-    lib.sjd_event_create.restype = vp
-    lib.sjd_event_destroy.argtypes = [vp]
-    lib.sjd_event_synchronize.argtypes = [vp]
-    lib.sjd_event_elapsed_ms.restype = f32
-    lib.sjd_event_elapsed_ms.argtypes = [vp, vp]
-    for name in EXPORTS:
+    lib.sjd_skinny_gemm_wide.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    for name in EXPORTS + EXP_EXPORTS:
         getattr(lib, name)
-    assert ctypes.sizeof(RowRule) == 52 and ctypes.sizeof(IterParams) == 64 + 8 * MAX_WINDOW + 2 * 52 * MAX_WINDOW
-    _lib = lib
+    _exp = lib
     return lib
 
 

@@ -222,6 +222,10 @@ __device__ __forceinline__ void k1_merge_publish(float (*red_o)[K1_ROWS][D + K1_
                                                  unsigned *__restrict__ ticket = nullptr, int eff_split = 0)
 {
     constexpr int D4 = D / 4;
+#ifndef SJD_EXPERIMENTAL      // (the in-kernel split merge is an experiment: libsjd_hip_exp.so -- the product kernels are compiled without it)
+    merge_out = nullptr;
+    ticket = nullptr;
+#endif
     const bool merged = merge_out != nullptr;
     if (merged && eff_split == 1) out_direct = merge_out;          // one split in effect: this workgroup's state IS the result
     const bool coherent = merged && !out_direct;
@@ -784,6 +788,7 @@ __global__ __launch_bounds__(256) void k1_combine(const float *__restrict__ ws_o
     SJD_TRC(2);
 }
 
+#ifdef SJD_EXPERIMENTAL        // K1F / K1Fs (rounds 2-3, measured no-go): libsjd_hip_exp.so only
 // ------------------------------------------------------------------------------------------------ K1F (fused F2 + K1 + combine)
 // rocprofv3, round 1: per layer the attention block is THREE dependent launches -- F2 (QK-norm + RoPE + KV append, 5.2 us), k1_partial
 // (11.8 us at kv_len 100 ... 21 us at 1216) and k1_combine (4.6 us) -- each at its launch-latency floor, and the split partials make a
@@ -1233,6 +1238,7 @@ extern "C" int sjd_qkv_attention_fused_split(const float *part, int n_chunks, vo
     return SJD_ERR_UNSUPPORTED;
 }
 
+#endif  // SJD_EXPERIMENTAL
 // ------------------------------------------------------------------------------------------------ K1 (fp8 KV)
 // BASELINE config 5: the KV cache is stored as OCP fp8 e4m3 (value = fp8 * scale, one scale per tensor), which halves the
 // bytes K1 streams, and both contractions run on v_mfma_f32_16x16x32_fp8_fp8:
@@ -1252,6 +1258,23 @@ __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d
     return (unsigned)v;
 }
 __device__ __forceinline__ long as_long(unsigned lo, unsigned hi) { return (long)(((unsigned long long)hi << 32) | lo); }
+
+// ---- hi / lo operands (round 6; VERDICT r5 #2b).  The fp8 attention rounded FOUR things to e4m3's three mantissa bits: K and V (the cache: that is
+// the format BASELINE config 5 names) and, on chip, Q and P -- although the matrix pipe is 2-5 % busy here.  Q and P now travel as TWO e4m3
+// operands each: hi = fp8(x), lo = fp8(16 (x - hi)) (the residual of a rounding is at most 2^-4 of the value: scaled by 16 it uses the same
+// binades), one more MFMA per product into an accumulator of its own, merged as hi + lo / 16.  What is left of the two on-chip roundings is
+// 2^-8 relative -- bf16's own resolution.  -DK1_FP8_HILO=0: the round-5 arithmetic (A/B aid).
+#ifndef K1_FP8_HILO
+#define K1_FP8_HILO 1
+#endif
+#define K1_LO_SCALE 16.0f
+__device__ __forceinline__ void pack4_fp8_hilo(float a, float b, float c, float d, unsigned &hi, unsigned &lo)
+{
+    hi = pack4_fp8(a, b, c, d);
+    const float ra = a - __builtin_amdgcn_cvt_f32_fp8((int)hi, 0), rb = b - __builtin_amdgcn_cvt_f32_fp8((int)hi, 1);
+    const float rc = c - __builtin_amdgcn_cvt_f32_fp8((int)hi, 2), rd = d - __builtin_amdgcn_cvt_f32_fp8((int)hi, 3);
+    lo = pack4_fp8(ra * K1_LO_SCALE, rb * K1_LO_SCALE, rc * K1_LO_SCALE, rd * K1_LO_SCALE);
+}
 
 template <int DT> __device__ __forceinline__ float k1_to_f32(unsigned short h);
 template <> __device__ __forceinline__ float k1_to_f32<SJD_DTYPE_BF16>(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
@@ -1299,13 +1322,13 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
     const int t_begin = t_lo + split * tps, t_end = min(t_hi, t_begin + tps);
 
     // Q (B operand) as fp8: lane (row c, group g), pair p: d = 64p + 16g .. +15 -> two 8-byte k-step operands
-    long qf[KP][2];
+    long qf[KP][2], qfl[KP][2];           // (qfl: the residual operand, K1_FP8_HILO)
     {
         const bool rv = (c < n_c);
         const unsigned short *qp = q + (((size_t)b * n_rows + (row0 + (rv ? c : 0))) * H + head) * D + 16 * g;
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
-            unsigned wds[4] = {0u, 0u, 0u, 0u};
+            unsigned wds[4] = {0u, 0u, 0u, 0u}, wdl[4] = {0u, 0u, 0u, 0u};
             if (rv) {
                 const u32x4 lo = *reinterpret_cast<const u32x4 *>(qp + 64 * p), hi = *reinterpret_cast<const u32x4 *>(qp + 64 * p + 8);
                 float f[16];
@@ -1315,19 +1338,21 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
                     f[8 + 2 * i] = k1_to_f32<DT>((unsigned short)(hi[i] & 0xffffu)); f[8 + 2 * i + 1] = k1_to_f32<DT>((unsigned short)(hi[i] >> 16));
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wds[i] = pack4_fp8(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+                for (int i = 0; i < 4; ++i) pack4_fp8_hilo(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3], wds[i], wdl[i]);
             }
             qf[p][0] = as_long(wds[0], wds[1]);
             qf[p][1] = as_long(wds[2], wds[3]);
+            qfl[p][0] = as_long(wdl[0], wdl[1]);
+            qfl[p][1] = as_long(wdl[2], wdl[3]);
         }
     }
     const unsigned char *kbase = kc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
     const unsigned char *vbase = vc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
 
     float m_run = -INFINITY, l_run = 0.0f;
-    f32x4 o_acc[DB];
+    f32x4 o_acc[DB], o_lo[DB];            // (o_lo: the products with P's residual operand)
 #pragma unroll
-    for (int db = 0; db < DB; ++db) o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int db = 0; db < DB; ++db) { o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f}; o_lo[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     constexpr int VP = K1_KT * D / (64 * 16);     // 16-B pieces per lane for one V tile
     constexpr int LPR = D / 16;                   // lanes per V row
@@ -1368,11 +1393,21 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if K1_FP8_HILO
+            f32x4 sl = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
             for (int p = 0; p < KP; ++p) {
                 st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long(kreg[kb][p][0], kreg[kb][p][1]), qf[p][0], st[kb], 0, 0, 0);
                 st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long(kreg[kb][p][2], kreg[kb][p][3]), qf[p][1], st[kb], 0, 0, 0);
+#if K1_FP8_HILO
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long(kreg[kb][p][0], kreg[kb][p][1]), qfl[p][0], sl, 0, 0, 0);
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long(kreg[kb][p][2], kreg[kb][p][3]), qfl[p][1], sl, 0, 0, 0);
+#endif
             }
+#if K1_FP8_HILO
+            st[kb] += sl * (1.0f / K1_LO_SCALE);
+#endif
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -1403,13 +1438,25 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
         rs += __shfl_xor(rs, 32);
         l_run = l_run * alpha + rs;
         m_run = m_new;
+#if K1_FP8_HILO
+        unsigned ph0, pl0, ph1, pl1;
+        pack4_fp8_hilo(pv[0], pv[1], pv[2], pv[3], ph0, pl0);
+        pack4_fp8_hilo(pv[4], pv[5], pv[6], pv[7], ph1, pl1);
+        const long pfrag = as_long(ph0, ph1), pfrag_lo = as_long(pl0, pl1);
+#else
         const long pfrag = as_long(pack4_fp8(pv[0], pv[1], pv[2], pv[3]), pack4_fp8(pv[4], pv[5], pv[6], pv[7]));
+#endif
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             const i32x2 vv = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2 *)(vrd + 16 * db));
             f32x4 acc = o_acc[db];
             acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
             o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long((unsigned)vv[0], (unsigned)vv[1]), pfrag, acc, 0, 0, 0);
+#if K1_FP8_HILO
+            f32x4 al = o_lo[db];
+            al[0] *= alpha; al[1] *= alpha; al[2] *= alpha; al[3] *= alpha;
+            o_lo[db] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long((unsigned)vv[0], (unsigned)vv[1]), pfrag_lo, al, 0, 0, 0);
+#endif
         }
     };
     auto adopt_next = [&](int tn, u32x4 (&vd)[VP]) {
@@ -1444,7 +1491,12 @@ __global__ __launch_bounds__(64 * NW) void k1_partial_fp8(
     const float oscale = v_scale / PSCALE;
     if (g == 0) { red_ml[w][c][0] = m_run; red_ml[w][c][1] = l_run; }
 #pragma unroll
-    for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(&red_o[w][c][16 * db + 4 * g]) = o_acc[db] * oscale;
+    for (int db = 0; db < DB; ++db) {
+#if K1_FP8_HILO
+        o_acc[db] += o_lo[db] * (1.0f / K1_LO_SCALE);
+#endif
+        *reinterpret_cast<f32x4 *>(&red_o[w][c][16 * db + 4 * g]) = o_acc[db] * oscale;
+    }
     __syncthreads();
     k1_merge_publish<DT, D, NW>(red_o, red_ml, G, kparts, b, H, hkv * G, n_chunks, chunk, n_split, split, row0, n_rows, n_total, ws_o, ws_ml,
                                 out_direct, merge_out, ticket, eff_split);
@@ -1726,6 +1778,7 @@ extern "C" int sjd_draft_window_attention_ex(const void *q, const void *k_cache,
                        ev_start, ev_stop, nullptr);
 }
 
+#ifdef SJD_EXPERIMENTAL        // round-3 option
 // K1 in ONE launch: the key splits are merged by the last of their workgroups to finish instead of by a second kernel (k1_merge_publish).
 // tickets: B * H_kv * ceil(n_rows / 16) zero-initialised uint32, private to launches that cannot overlap (they re-arm themselves).
 // Grouped-query / multi-chunk shapes served by the shared-tile kernel keep the two-kernel form (tickets unused).
@@ -1739,6 +1792,7 @@ extern "C" int sjd_draft_window_attention_merged(const void *q, const void *k_ca
                        ev_start, ev_stop, (unsigned *)tickets);
 }
 
+#endif  // SJD_EXPERIMENTAL
 extern "C" int sjd_draft_window_attention(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
                                           int H_kv, int D, int S_max, int dtype, const int32_t *key_start,
                                           const sjd_iter_params *params, int kv_len, int n_split, void *workspace, void *stream)
@@ -1854,6 +1908,7 @@ extern "C" int sjd_draft_window_attention_fp8(const void *q, const void *k_cache
                            workspace, stream, nullptr);
 }
 
+#ifdef SJD_EXPERIMENTAL        // round-3 option
 extern "C" int sjd_draft_window_attention_fp8_merged(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
                                                      int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale, const int32_t *key_start,
                                                      const sjd_iter_params *params, int kv_len, int n_split, void *workspace, uint32_t *tickets,
@@ -1864,6 +1919,7 @@ extern "C" int sjd_draft_window_attention_fp8_merged(const void *q, const void *
                            workspace, stream, (unsigned *)tickets);
 }
 
+#endif  // SJD_EXPERIMENTAL
 // sjd_draft_window_attention_colsplit over an fp8 (e4m3) cache: a key row is 128 bytes, so the column split stays ahead up to ~1500 keys
 extern "C" int sjd_draft_window_attention_fp8_colsplit(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int n_rows, int H,
                                                        int H_kv, int D, int S_max, int dtype, float k_scale, float v_scale,

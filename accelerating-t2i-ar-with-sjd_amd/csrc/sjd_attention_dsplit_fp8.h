@@ -46,13 +46,13 @@ __global__ __launch_bounds__(64 * NW) void k1_dsplit_fp8(
     const float scale = rsqrtf((float)D) * k_scale;
     const int t_lo = kstart / K1_KT, t_hi = (total + K1_KT - 1) / K1_KT;
 
-    long qf[KP][2];                           // Q as fp8, in the byte order of the K pieces (k1_partial_fp8)
+    long qf[KP][2], qfl[KP][2];           // (qfl: the residual operand, K1_FP8_HILO)                           // Q as fp8, in the byte order of the K pieces (k1_partial_fp8)
     {
         const bool rv = (c < n_c);
         const unsigned short *qp = q + (((size_t)b * n_rows + (row0 + (rv ? c : 0))) * H + head) * D + 16 * g;
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
-            unsigned wds[4] = {0u, 0u, 0u, 0u};
+            unsigned wds[4] = {0u, 0u, 0u, 0u}, wdl[4] = {0u, 0u, 0u, 0u};
             if (rv) {
                 const u32x4 lo = *reinterpret_cast<const u32x4 *>(qp + 64 * p), hi = *reinterpret_cast<const u32x4 *>(qp + 64 * p + 8);
                 float f[16];
@@ -62,19 +62,21 @@ __global__ __launch_bounds__(64 * NW) void k1_dsplit_fp8(
                     f[8 + 2 * i] = k1_to_f32<DT>((unsigned short)(hi[i] & 0xffffu)); f[8 + 2 * i + 1] = k1_to_f32<DT>((unsigned short)(hi[i] >> 16));
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wds[i] = pack4_fp8(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+                for (int i = 0; i < 4; ++i) pack4_fp8_hilo(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3], wds[i], wdl[i]);
             }
             qf[p][0] = as_long(wds[0], wds[1]);
             qf[p][1] = as_long(wds[2], wds[3]);
+            qfl[p][0] = as_long(wdl[0], wdl[1]);
+            qfl[p][1] = as_long(wdl[2], wdl[3]);
         }
     }
     const unsigned char *kbase = kc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D;
     const unsigned char *vbase = vc + ((size_t)b * H_kv + hkv) * (size_t)S_max * D + dq * DW;
 
     float m_run = -INFINITY, l_run = 0.0f;
-    f32x4 o_acc[DB];
+    f32x4 o_acc[DB], o_lo[DB];            // (o_lo: the products with P's residual operand, K1_FP8_HILO)
 #pragma unroll
-    for (int db = 0; db < DB; ++db) o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int db = 0; db < DB; ++db) { o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f}; o_lo[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     constexpr int LPR = DW / 16;              // lanes per V slice row
     static_assert(K1_KT * LPR == 64, "one 16-byte piece per lane covers the V slice tile");
@@ -99,11 +101,21 @@ __global__ __launch_bounds__(64 * NW) void k1_dsplit_fp8(
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if K1_FP8_HILO
+            f32x4 sl = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
             for (int p = 0; p < KP; ++p) {
                 st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long(kreg[kb][p][0], kreg[kb][p][1]), qf[p][0], st[kb], 0, 0, 0);
                 st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long(kreg[kb][p][2], kreg[kb][p][3]), qf[p][1], st[kb], 0, 0, 0);
+#if K1_FP8_HILO
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long(kreg[kb][p][0], kreg[kb][p][1]), qfl[p][0], sl, 0, 0, 0);
+                sl = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long(kreg[kb][p][2], kreg[kb][p][3]), qfl[p][1], sl, 0, 0, 0);
+#endif
             }
+#if K1_FP8_HILO
+            st[kb] += sl * (1.0f / K1_LO_SCALE);
+#endif
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -132,13 +144,25 @@ __global__ __launch_bounds__(64 * NW) void k1_dsplit_fp8(
         rs = k1r_sum_across_groups(rs);
         l_run = l_run * alpha + rs;
         m_run = m_new;
+#if K1_FP8_HILO
+        unsigned ph0, pl0, ph1, pl1;
+        pack4_fp8_hilo(pv[0], pv[1], pv[2], pv[3], ph0, pl0);
+        pack4_fp8_hilo(pv[4], pv[5], pv[6], pv[7], ph1, pl1);
+        const long pfrag = as_long(ph0, ph1), pfrag_lo = as_long(pl0, pl1);
+#else
         const long pfrag = as_long(pack4_fp8(pv[0], pv[1], pv[2], pv[3]), pack4_fp8(pv[4], pv[5], pv[6], pv[7]));
+#endif
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             const i32x2 vv = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2 *)(vrd + 16 * db));
             f32x4 acc = o_acc[db];
             acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
             o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long((unsigned)vv[0], (unsigned)vv[1]), pfrag, acc, 0, 0, 0);
+#if K1_FP8_HILO
+            f32x4 al = o_lo[db];
+            al[0] *= alpha; al[1] *= alpha; al[2] *= alpha; al[3] *= alpha;
+            o_lo[db] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(as_long((unsigned)vv[0], (unsigned)vv[1]), pfrag_lo, al, 0, 0, 0);
+#endif
         }
     };
     auto adopt_next = [&](int tn, const u32x4 &vd) {
@@ -172,7 +196,12 @@ __global__ __launch_bounds__(64 * NW) void k1_dsplit_fp8(
     const float oscale = v_scale / PSCALE;
     if (g == 0) { red_ml[w][c][0] = m_run; red_ml[w][c][1] = l_run; }
 #pragma unroll
-    for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4 *>(&red_o[w][c][16 * db + 4 * g]) = o_acc[db] * oscale;
+    for (int db = 0; db < DB; ++db) {
+#if K1_FP8_HILO
+        o_acc[db] += o_lo[db] * (1.0f / K1_LO_SCALE);
+#endif
+        *reinterpret_cast<f32x4 *>(&red_o[w][c][16 * db + 4 * g]) = o_acc[db] * oscale;
+    }
     __syncthreads();
     constexpr int D4 = DW / 4;
     for (int u = threadIdx.x; u < K1_ROWS * D4; u += 64 * NW) {

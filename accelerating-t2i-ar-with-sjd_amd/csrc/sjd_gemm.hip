@@ -22,7 +22,9 @@
 #include "../../include/sjd_hip.h"
 #include "sjd_mlp_epilogue.h"
 #include "sjd_coherent.h"
+#ifdef SJD_EXPERIMENTAL
 #include "sjd_l2_prefetch.h"
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -66,6 +68,7 @@ template <> struct G1Mfma<SJD_DTYPE_F16> {
     { return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); }
 };
 
+#ifdef SJD_EXPERIMENTAL        // round-3 option (G1 with F1r as its tail)
 // ---- F1r inside the producer (round 3; VERDICT r2 "next #3", the experiment DESIGN.md 4.6 item 6 stopped short of).
 // Every workgroup of an o / down launch has written its fp32 partial tile with device-coherent stores.  The workgroups that share a
 // 512-column SLICE of the output (16 / waves column groups x n_chunks K chunks: 16 for o, 26 for down) then meet at a ticket in device
@@ -150,6 +153,7 @@ __device__ __forceinline__ void g1_reduce_tail(const float *__restrict__ part, u
     }
 }
 
+#endif  // SJD_EXPERIMENTAL
 // x: [M, K] row-major (M <= 32*MT; missing rows read as zero).  wp: packed weights.  out: fp32 [n_chunks, 32*MT, N].
 // MT = 2 serves a 64-row window (B_cfg * L with a draft window of 32): every weight record feeds two MFMAs.
 // Column window: the launch covers tiles [tile0, tile0 + N/32) of a weight packed with `n_tiles` tiles (N = columns of THIS launch's
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__r
     SJD_TR(4);                    // main loop done
     // D[m][n]: reg r of lane l -> row m = (r&3) + 8*(r>>2) + 4*(l>>5), column n = 32t + (l&31): 128-B coalesced rows
     float *o = out + ((size_t)chunk * (32 * MT)) * N + (size_t)t_out * 32 + (lane & 31);
+#ifdef SJD_EXPERIMENTAL        // (the reducing tail: libsjd_hip_exp.so only -- the product kernel is compiled without it)
     if constexpr (MT == 1 && MAXT == 512) if (red_h) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)          // the plane goes out DEVICE-COHERENT (sc1: written through this XCD's L2)
@@ -293,6 +298,7 @@ __global__ __launch_bounds__(MAXT) void g1_skinny_gemm(const unsigned short *__r
         g1_reduce_tail<DT>(out, red_h, red_sumsq, red_ticket, M, N, (int)gridDim.y, chunk, (int)blockIdx.x, n_waves);
         return;
     }
+#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -623,6 +629,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MT <= 4) ? 2 : 1) void g1_skin
 
 #include "sjd_gemm_wide.h"
 
+#ifdef SJD_EXPERIMENTAL        // weight prefetch / L2 head pulls (rounds 2 and 5, measured no-go) and the XCC map probe
 // ------------------------------------------------------------------------------------------------ weight prefetch
 // While the latency-bound kernels of a layer run (F1r / F2 / K1 / combine / F3: ~1.15 ms of a 3.9 ms step, rocprofv3 round 1) HBM is
 // idle although the step as a whole is bound by the 13 GB weight stream.  This kernel, launched on a SIDE stream (a parallel branch of
@@ -745,6 +752,7 @@ extern "C" int sjd_weight_prefetch_head(const sjd_l2_head *head, int blocks, voi
 // (tests/test_gpu_glue.py::test_g1_gateup_silu_matches_g1_then_f3), so nothing downstream changes.
 // replaces, like G1 + F3: gate_proj / up_proj / act_fn / the product of ChameleonMLP.forward (reference modeling_chameleon.py:193-195).
 // SP = k-steps per phase per K half = K / 64 (K = 4096: 64).
+#endif  // SJD_EXPERIMENTAL
 template <int DT, int SP>
 __global__ __launch_bounds__(512) void g1_gateup_silu(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp,
                                                       unsigned short *__restrict__ y, int M, int I, int K, int rec_stride,
@@ -2063,6 +2071,7 @@ extern "C" int sjd_skinny_gemm(const void *x, const void *w_packed, float *out, 
     return SJD_ERR_UNSUPPORTED;
 }
 
+#ifdef SJD_EXPERIMENTAL        // G1 + F1r in one launch, the MLP pair, the loader / consumer engine, the G1w tuning entry
 // G1 with F1r as its tail (see g1_reduce_tail): h [M, N] += dtype(x @ W^T) in place, sumsq [N / 512, 32] = per-slice sums of h^2 -- what
 // sjd_skinny_gemm followed by sjd_residual_sumsq computes, bit for bit, in one launch.  `workspace`: fp32 [n_chunks, 32, N] (the planes
 // still travel through memory, device-coherently); `ticket`: N / 512 * 32 zero-initialised uint32 that must not be shared with a launch
@@ -2132,7 +2141,6 @@ extern "C" int sjd_skinny_gemm_wide(const void *x, const void *w_packed, float *
 // workgroups of a reducing launch that gave up waiting for their slice's ticket since the library was loaded (0 on a healthy device)
 #include "sjd_gemm_pair.h"
 #include "sjd_gemm_engine.h"
-#include "sjd_gemm_raw.h"
 
 extern "C" int sjd_reduce_timeouts(void)
 {
@@ -2140,6 +2148,10 @@ extern "C" int sjd_reduce_timeouts(void)
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g1_red_timeouts), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)v;
 }
+
+#endif  // SJD_EXPERIMENTAL
+
+#include "sjd_gemm_raw.h"
 
 #ifdef SJD_TRACE
 extern "C" int sjd_debug_trace_g1(unsigned long long *host_out, int n_wg)

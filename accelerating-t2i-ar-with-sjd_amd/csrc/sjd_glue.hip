@@ -35,7 +35,9 @@ extern "C" int sjd_debug_trace_glue(int kind, unsigned long long *host_out, int 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 #include "sjd_mlp_epilogue.h"
+#ifdef SJD_EXPERIMENTAL
 #include "sjd_l2_prefetch.h"
+#endif
 
 template <int DT> struct Cvt;
 template <> struct Cvt<SJD_DTYPE_BF16> {
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(128) void f1r_residual_sumsq(unsigned short *__rest
     f1r_body<DT>(h, part, n_chunks, hidden, prows, out_sumsq);
 }
 
+#ifdef SJD_EXPERIMENTAL        // round-5 experiment (measured no-go)
 // F1r HOSTING the L2 head pull of the projection behind it (round 5, sjd_l2_prefetch.h): grid rows [0, n_slices) are F1r's own workgroups
 // (dispatched first), the rows behind them pull.  `rows * n_slices` is a multiple of 8 (the launcher checks), so pulling workgroup j sits on
 // XCD j mod 8.  The pull's arguments come after F1r's: the sixteen preloaded argument dwords are still F1r's own.
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(128) void f1r_residual_sumsq_pf(unsigned short *__r
     f1r_body<DT>(h, part, n_chunks, hidden, prows, out_sumsq);
 }
 
+#endif  // SJD_EXPERIMENTAL
 // 1/rms of a row from the per-slice sums of squares F1r wrote (fixed order)
 __device__ __forceinline__ float row_sumsq_total(const float *__restrict__ row_sumsq, int slices, int prows, int row)
 {
@@ -651,6 +655,7 @@ extern "C" int sjd_residual_sumsq(void *h, const float *part, int n_chunks, int 
 
 // F1r + the L2 head pull of the next projection in one launch.  pf_blocks: pulling workgroups of 128 threads (a multiple of 8 x rows / gcd...:
 // the launcher rounds it to whole grid rows); head NULL or pf_blocks 0: plain sjd_residual_sumsq.
+#ifdef SJD_EXPERIMENTAL        // round-5 experiment
 extern "C" int sjd_residual_sumsq_pf(void *h, const float *part, int n_chunks, int rows, int hidden, int dtype, float *out_sumsq,
                                      const sjd_l2_head *head, int pf_blocks, void *stream)
 {
@@ -670,6 +675,7 @@ extern "C" int sjd_residual_sumsq_pf(void *h, const float *part, int n_chunks, i
     else return SJD_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
+#endif  // SJD_EXPERIMENTAL
 
 static int f3_launch(const void *gate_up, void *y, int rows, int inter, int dtype, const float *part, int n_chunks, const sjd_row_norm *rn,
                      void *stream)

@@ -12,7 +12,7 @@
 // Nothing here changes a result: the pulled bytes are thrown away; a wrong mapping costs time, never correctness.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "../../include/sjd_hip.h"
+#include "../../include/sjd_hip_experimental.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned sjd_pf_u32x4;
 

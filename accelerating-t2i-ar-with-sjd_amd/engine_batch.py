@@ -46,6 +46,21 @@ class SJDBatchEngine:
             raise ValueError(f"max_window {max_window} > {L.MAX_WINDOW}")
         if n_prompts * n_batch * max_window > 256:
             raise ValueError("the window forward (G1, F1-F3) serves at most 256 rows: n_prompts * n_batch * max_window <= 256")
+        rows = n_prompts * n_batch * max_window
+        if rows > 128 and getattr(backbone, "_gemm", None) == "sjd" and getattr(backbone, "_packed", None):
+            # 129..256 window rows run on kernel G1w (csrc/sjd_gemm_wide.h): the uncompressed packing, 2 / 3 / 4 / 6 / 8 column tiles per
+            # workgroup for every projection AND the output head.  Anything else used to fall onto the library-GEMM prefill path silently
+            # (slower, not bit-identical to the oracle replays) or to fail at the first forward: say so here instead.
+            tiles = getattr(backbone, "G1_WIDE_TILES", (2, 3, 4, 6, 8))
+            bad = [k for k, c in backbone.G1_CFG.items() if c[1] not in tiles]
+            if getattr(backbone, "_packed_head", None) is not None and backbone.HEAD_CFG[1] not in tiles:
+                bad.append("lm_head (HEAD_CFG)")
+            if isinstance(backbone._packed[0]["qkv"], ops.PackedZ):
+                raise ValueError(f"{rows} window rows per forward need the uncompressed packing: enable_fused(ops, gemm='sjd', compress=False) "
+                                 "(the 12-bit stream serves up to 128 rows)")
+            if bad:
+                raise ValueError(f"{rows} window rows per forward run on kernel G1w with {tiles} column tiles per workgroup; set "
+                                 f"model.G1_CFG = dict(model.G1_CFG_256ROW) before enable_fused -- offending launch shapes: {bad}")
         self.backbone, self.V, self.device = backbone, int(vocab_size), torch.device(device)
         self.P, self.nb, self.Lmax, self.B = n_prompts, n_batch, max_window, n_prompts * n_batch
         self.use_graph, self.narrow_head = use_graph, narrow_head
@@ -107,8 +122,9 @@ class SJDBatchEngine:
         p = slot.params.view
         p.n_rows, p.kv_len, p.use_cfg, p.scheme, p.n_fresh = n, kv_len, int(use_cfg), scheme, len(fresh)
         slot.ph_step = ops.philox_step(n * self.V, self._ph_blocks)
+        k2_step = 0 if getattr(self, "_greedy", False) else slot.ph_step          # greedy: sampling_logits2tokens draws nothing (JL:127-129)
         p.philox_blocks, p.philox_seed = self._ph_blocks, slot.ph_seed
-        p.philox_offset[0], p.philox_offset[1], p.philox_offset[2] = slot.ph_off, slot.ph_off + slot.ph_step, slot.ph_off + 2 * slot.ph_step
+        p.philox_offset[0], p.philox_offset[1], p.philox_offset[2] = slot.ph_off, slot.ph_off + k2_step, slot.ph_off + k2_step + slot.ph_step
         if fresh:
             p.fresh_tok[:len(fresh)] = fresh
         self._write_rules(slot, L.IterParams.rules.offset, rules)
@@ -185,15 +201,16 @@ class SJDBatchEngine:
             dbg = self._dbg
             dbg.zero_()
         def k2_k4(i, s):
+            tok_out, amax_out = (s.amax_ptr, s.tokens_ptr) if getattr(self, "_greedy", False) else (s.tokens_ptr, s.amax_ptr)
             if part:
-                ops.logits_to_probs_sample_part(logits, self._guidance, s.params, None, s.probs[cur], s.tokens_ptr, amax_out_ptr=s.amax_ptr,
+                ops.logits_to_probs_sample_part(logits, self._guidance, s.params, None, s.probs[cur], tok_out, amax_out_ptr=amax_out,
                                                 dbg=None if dbg is None else dbg[i * self.nb:(i + 1) * self.nb], row0=i * self.nb * self.Lmax,
                                                 urow_off=self.Lmax if self.nb > 1 else 0, zero_state=s.zero_state[cur])
             else:
                 lc = logits[i * self.nb]
                 lu = logits[i * self.nb + 1] if self.nb > 1 else None
-                ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, None, s.probs[cur], s.tokens_ptr, col0=cols[0] if cols else 0,
-                                           amax_out_ptr=s.amax_ptr)
+                ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, None, s.probs[cur], tok_out, col0=cols[0] if cols else 0,
+                                           amax_out_ptr=amax_out)
                 s.zero_state[cur].fill_(-1)
             ops.verify_accept(s.params, s.state, s.probs[cur], s.probs[1 - cur], None, None, s.scratch, mirror=True)
         self._per_slot(k2_k4)
@@ -215,7 +232,7 @@ class SJDBatchEngine:
         return self._graph_logits[fkey]
 
     def _launch_sample(self, cur, logits, cols):
-        key = (cur, self._guidance, cols, self.hook is not None)
+        key = (cur, self._guidance, cols, self.hook is not None, getattr(self, "_greedy", False))
         if not self.use_graph or ("fwd", cols) not in self._graphs:
             self._sample_body(cur, logits, cols)
             return
@@ -235,7 +252,7 @@ class SJDBatchEngine:
             self._sample_body(cur, logits, cols)
             return logits
         self._check_graph_buffers()
-        key = ("win", cols, cur, self._guidance, self.hook is not None)
+        key = ("win", cols, cur, self._guidance, self.hook is not None, getattr(self, "_greedy", False))
         if key not in self._graphs:
             if self._eager_runs.get(key, 0) < 1:
                 self._eager_runs[key] = 1
@@ -265,7 +282,10 @@ class SJDBatchEngine:
         """what the slot's kernels generate, drawn by torch from the same generator state -- for observers only (the parity tests' hook)"""
         self._noise_tensors(s)
         s.gen.set_offset(s.ph_off)
-        s.noise[:n_rows].exponential_(generator=s.gen)
+        if getattr(self, "_greedy", False):
+            s.noise[:n_rows].fill_(1.0)
+        else:
+            s.noise[:n_rows].exponential_(generator=s.gen)
         if n_rows > 1 and scheme == 0:
             s.rs[:n_rows].uniform_(0.0, 1.0, generator=s.gen)
             s.noise2.exponential_(generator=s.gen)
@@ -281,8 +301,10 @@ class SJDBatchEngine:
         prompt of the list -- state machine, grammar and generators re-created, its KV rows reused from 0, its prompt prefilled eagerly
         over its own batch rows -- while the other slots keep their windows; the captured window graphs are unaffected.  Only when the
         list is exhausted does a finished slot ride along with a one-row dummy window."""
-        if not getattr(cfg, "do_sample", True):
-            raise NotImplementedError("greedy decoding (do_sample=False) runs on SJDEngine, one prompt per forward")
+        # GenerationConfig(do_sample=False): K2's MODE of p goes where its draw would (state.tokens; the draw lands in state.amax and is ignored),
+        # nothing is consumed from a slot's generator for it, the verify step's draws follow at once (SJDEngine.decode, JL:124-129)
+        self._greedy = greedy = not getattr(cfg, "do_sample", True)
+        k2_draws = 0 if greedy else 1
         N = len(prompts)
         assert len(specs) == len(grammars) == N and N >= self.P
         if cfg.multi_token_init_scheme not in ("random", "repeat_horizon", "sample_horizon"):
@@ -345,6 +367,8 @@ class SJDBatchEngine:
             if self.hook is not None:
                 self._observer_noise(s, 1, scheme)
             tokens, positions = specs[j].first_tokens.to(dev), specs[j].first_positions.to(dev)
+            from .engine import SJDEngine
+            SJDEngine._calibrate_fp8(self, tokens, positions, self.key_start[i * nb:(i + 1) * nb])      # (an fp8 cache nobody calibrated: once per backbone)
             self.backbone.cache = _CacheView(full_cache, i * nb, (i + 1) * nb)
             try:
                 logits = self.backbone.forward_window(tokens, positions, s.kv_len, self.key_start[i * nb:(i + 1) * nb])
@@ -352,10 +376,11 @@ class SJDBatchEngine:
                 self.backbone.cache = full_cache
             lc = logits[0, -1:, :]
             lu = logits[1, -1:, :] if nb > 1 else None
-            ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, None, s.probs[buf], s.tokens_ptr, amax_out_ptr=s.amax_ptr)
+            tok_out, amax_out = (s.amax_ptr, s.tokens_ptr) if greedy else (s.tokens_ptr, s.amax_ptr)
+            ops.logits_to_probs_sample(lc, lu, self._guidance, s.params, None, s.probs[buf], tok_out, amax_out_ptr=amax_out)
             s.zero_state[buf].fill_(-1)
             ops.verify_accept(s.params, s.state, s.probs[buf], s.probs[1 - buf], None, None, s.scratch, mirror=True)
-            s.ph_off += s.ph_step                                  # the [1, V] multinomial of iteration 0
+            s.ph_off += s.ph_step * k2_draws                       # the [1, V] multinomial of iteration 0 (greedy: none)
             if self.hook is not None:
                 self.hook(j, dict(first=True, n_rows=1, logits_c=lc, logits_u=lu, use_cfg=use_cfg, rules=rules, resid=[],
                                   noise=s.noise[:1], rs=s.rs[:1], noise2=s.noise2[0], probs=s.probs[buf], prev_probs=s.probs[1 - buf],
@@ -367,7 +392,7 @@ class SJDBatchEngine:
             """host bookkeeping of iteration 0 (after the state download)"""
             nonlocal emitted_total
             y0 = int(s.state.view.tokens[0])
-            s.last_amax = int(s.state.view.amax[0])
+            s.last_amax = y0 if greedy else int(s.state.view.amax[0])
             s.stats.matched.append(s.win_len)
             s.n = min(W, s.r_abs - s.cur_len) if (s.l_abs <= s.cur_len < s.r_abs) else 1
             s.X.append(y0)
@@ -495,18 +520,18 @@ class SJDBatchEngine:
             sync_s += time.perf_counter() - t_s
             for s, (n_rows, _, _, _) in zip(self.slots, metas):
                 if s.finished:
-                    s.ph_off += s.ph_step                      # (the dummy row's draw: keeps blob and generator consistent; never observed)
+                    s.ph_off += s.ph_step * k2_draws           # (the dummy row's draw: keeps blob and generator consistent; never observed)
                     continue
                 st = s.state.view
                 m_dev, rejected = int(st.m), bool(st.rejected)
                 if int(st.rejected) > 1:
                     raise RuntimeError("SJD verify: the residual distribution max(p - q, 0) is empty under the residual grammar rule")
                 draws_rs = n_rows > 1 and scheme == 0          # what torch would have consumed: multinomial [+ rand [+ residual multinomial]]
-                s.ph_off += s.ph_step * (2 if draws_rs else 1) + (ph_row if (draws_rs and rejected) else 0)
+                s.ph_off += s.ph_step * (k2_draws + (1 if draws_rs else 0)) + (ph_row if (draws_rs and rejected) else 0)
                 if self.hook is not None:
                     s.gen.set_offset(s.ph_off)
                 Y = st.tokens[:n_rows]
-                A = st.amax[:n_rows]                           # modes of this iteration's target rows (K2 by-product)
+                A = Y if greedy else st.amax[:n_rows]          # modes of this iteration's target rows (K2 by-product; greedy: the tokens themselves)
                 if n_rows <= 1:
                     m, emitted, s.carried, s.carried_amax, s.last_amax = 1, [Y[0]], [], [], A[0]
                 else:

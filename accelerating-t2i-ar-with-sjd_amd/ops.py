@@ -249,7 +249,7 @@ def draft_window_attention_fp8(q, k_cache, v_cache, out, k_scale, v_scale, key_s
     need = L.load().sjd_attention_workspace_bytes(B, H, n, D, n_split)
     assert workspace.numel() * 4 >= need, "attention workspace too small"
     if K1_MERGED_DEFAULT if merged is None else merged:
-        L.check(L.load().sjd_draft_window_attention_fp8_merged(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), B, n, H, k_cache.shape[1], D,
+        L.check(L.load_exp().sjd_draft_window_attention_fp8_merged(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), B, n, H, k_cache.shape[1], D,
                                                               k_cache.shape[2], _dtype_code(q.dtype), float(k_scale), float(v_scale),
                                                               _ptr(key_start), params.ptr if params is not None else None, int(kv_len),
                                                               int(n_split), _ptr(workspace), _ptr(k1_tickets(B, k_cache.shape[1], n, q.device)),
@@ -298,7 +298,7 @@ def draft_window_attention(q, k_cache, v_cache, out, key_start, params, kv_len, 
     need = L.load().sjd_attention_workspace_bytes(B, H, n, D, n_split)
     assert workspace.numel() * 4 >= need, "attention workspace too small"
     if (K1_MERGED_DEFAULT if merged is None else merged) and q.dtype != torch.float32:
-        L.check(L.load().sjd_draft_window_attention_merged(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), B, n, H,
+        L.check(L.load_exp().sjd_draft_window_attention_merged(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), B, n, H,
                                                           k_cache.shape[1], D, k_cache.shape[2], _dtype_code(q.dtype),
                                                           _ptr(key_start), params.ptr if params is not None else None,
                                                           int(kv_len), int(n_split), _ptr(workspace), _ptr(k1_tickets(B, k_cache.shape[1], n, q.device)),
@@ -530,14 +530,14 @@ def skinny_gemm_reduce(x, w_packed, N, K, KC, h, waves=8, step_major=False):
     ws = torch.empty(nc, 32, N, dtype=torch.float32, device=dev)
     sumsq = torch.empty(N // 512, 32, dtype=torch.float32, device=dev)
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    L.check(L.load().sjd_skinny_gemm_reduce(_ptr(x), _ptr(w_packed), _ptr(ws), _ptr(h), _ptr(sumsq), _ptr(tk), M, N, K, KC, waves, int(step_major),
+    L.check(L.load_exp().sjd_skinny_gemm_reduce(_ptr(x), _ptr(w_packed), _ptr(ws), _ptr(h), _ptr(sumsq), _ptr(tk), M, N, K, KC, waves, int(step_major),
                                             _dtype_code(x.dtype), int(cus), _stream()), "sjd_skinny_gemm_reduce")
     return sumsq
 
 
 def reduce_timeouts():
     """waits of sjd_skinny_gemm_reduce launches that were abandoned since the library was loaded (0 on a healthy, unshared device)"""
-    return int(L.load().sjd_reduce_timeouts())
+    return int(L.load_exp().sjd_reduce_timeouts())
 
 
 _PREFETCH_SINK = {}
@@ -553,13 +553,19 @@ def weight_prefetch(w_packed, blocks=128, nbytes=None):
     if sink is None:
         sink = _PREFETCH_SINK[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
     nb = int(nbytes) if nbytes is not None else w_packed.numel() * w_packed.element_size()
-    L.check(L.load().sjd_weight_prefetch(_ptr(w_packed), nb, int(blocks), _ptr(sink), _stream()), "sjd_weight_prefetch")
+    L.check(L.load_exp().sjd_weight_prefetch(_ptr(w_packed), nb, int(blocks), _ptr(sink), _stream()), "sjd_weight_prefetch")
 
 
-def skinny_gemm_engine(x, w_packed, n_wg=None, col0=0, n_cols=None):
+_ENGINE_TIMEOUTS_SEEN = 0
+
+
+def skinny_gemm_engine(x, w_packed, n_wg=None, col0=0, n_cols=None, check=True):
     """G1z in the loader / consumer form (round 5 stage A, csrc/sjd_gemm_engine.h): x [M <= 32, K] bf16, w_packed a tile-major PackedZ ->
     Partials([n_chunks, 32, n_cols]) bit-identical to skinny_gemm_cols on the same packing.  n_wg: persistent workgroups (default: the largest
-    multiple of the K-chunk count that fits the device's CUs)."""
+    multiple of the K-chunk count that fits the device's CUs).  check (default): synchronise and raise if a bounded LDS poll of the kernel
+    gave up -- it then went on with wrong partials; check=False inside a hipGraph capture / a timed loop: call engine_timeouts()
+    yourself afterwards."""
+    assert w_packed.n_raw == 0, "the engine kernel does not know raw units (round 6)"
     assert isinstance(w_packed, PackedZ) and not w_packed.step_major and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[1] == w_packed.K
     M, K, KC = x.shape[0], w_packed.K, w_packed.KC
     n = (w_packed.N - col0) if n_cols is None else n_cols
@@ -568,44 +574,60 @@ def skinny_gemm_engine(x, w_packed, n_wg=None, col0=0, n_cols=None):
         cus = torch.cuda.get_device_properties(x.device).multi_processor_count
         n_wg = max(nc, min(cus // nc, n // 32) * nc)
     out = torch.empty(nc, 32, n, dtype=torch.float32, device=x.device)
-    L.check(L.load().sjd_skinny_gemm_engine_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), w_packed.cap, _ptr(out), M, n, K, KC, _dtype_code(x.dtype),
+    L.check(L.load_exp().sjd_skinny_gemm_engine_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), w_packed.cap, _ptr(out), M, n, K, KC, _dtype_code(x.dtype),
                                              w_packed.N, col0 // 32, int(n_wg), _stream()), "sjd_skinny_gemm_engine_z")
+    if check and not torch.cuda.is_current_stream_capturing():
+        global _ENGINE_TIMEOUTS_SEEN
+        torch.cuda.current_stream().synchronize()
+        n_to = engine_timeouts()
+        if n_to > _ENGINE_TIMEOUTS_SEEN:
+            _ENGINE_TIMEOUTS_SEEN = n_to
+            raise RuntimeError(f"sjd_skinny_gemm_engine_z: {n_to} bounded LDS poll(s) gave up -- the partials of this launch are wrong")
     return Partials(out, nc, n)
 
 
 def engine_timeouts():
-    return int(L.load().sjd_engine_timeouts())
+    """bounded LDS polls of sjd_skinny_gemm_engine_z that gave up since the library was loaded.  The engine kernel (round-5 experiment) never
+    hangs: a poll that times out goes on with WRONG partials -- skinny_gemm_engine(check=True), the default, raises when the count moved."""
+    return int(L.load_exp().sjd_engine_timeouts())
 
 
 def l2_head(w_packed, M, waves=None, head_pairs=8, gateup=False, col0=0, n_cols=None):
     """-> _lib.L2Head: the first `head_pairs` record pairs of every unit of the G1z (or, gateup=True, G1sz) launch that will stream `w_packed`
-    (a PackedZ) for an M-row window with `waves` waves per workgroup -- what a glue launch in front of it pulls into the L2 (round 5)."""
+    (a PackedZ) for an M-row window with `waves` waves per workgroup -- what a glue launch in front of it pulls into the L2 (round 5 experiment).
+    waves: REQUIRED for the projection kind (the launch's column tiles per workgroup, G1_CFG[name][1]); the gate|up kind describes the
+    512-thread G1sz launch of up to 64 rows (I / 64 workgroups) -- the 65..128-row window runs G1 + F3 instead and has no such descriptor."""
     assert isinstance(w_packed, PackedZ)
+    if gateup:
+        if M > 64:
+            raise ValueError("l2_head(gateup=True) describes the fused G1sz launch (<= 64 rows); taller windows run G1z + F3: use the projection kind")
+    elif waves is None:
+        raise ValueError("l2_head: `waves` (column tiles per workgroup of the G1z launch, G1_CFG[name][1]) is required for a projection")
     h = L.L2Head()
     if gateup:
-        L.check(L.load().sjd_l2_head_gateup_z(ctypes.byref(h), _ptr(w_packed.data), M, w_packed.N // 2, w_packed.K, int(w_packed.step_major), int(head_pairs)),
+        L.check(L.load_exp().sjd_l2_head_gateup_z(ctypes.byref(h), _ptr(w_packed.data), M, w_packed.N // 2, w_packed.K, int(w_packed.step_major), int(head_pairs)),
                 "sjd_l2_head_gateup_z")
     else:
         n = w_packed.N - col0 if n_cols is None else n_cols
-        L.check(L.load().sjd_l2_head_gemm_z(ctypes.byref(h), _ptr(w_packed.data), M, n, w_packed.K, w_packed.KC, int(waves), int(w_packed.step_major), w_packed.N,
+        L.check(L.load_exp().sjd_l2_head_gemm_z(ctypes.byref(h), _ptr(w_packed.data), M, n, w_packed.K, w_packed.KC, int(waves), int(w_packed.step_major), w_packed.N,
                                            col0 // 32, int(head_pairs)), "sjd_l2_head_gemm_z")
     h._keep = w_packed           # the descriptor holds a raw address
     return h
 
 
 def l2_head_bytes(head):
-    return int(L.load().sjd_l2_head_bytes(ctypes.byref(head)))
+    return int(L.load_exp().sjd_l2_head_bytes(ctypes.byref(head)))
 
 
 def weight_prefetch_head(head, blocks=256):
     """the L2 head pull as a launch of its own (bench aid; the product hosts it in F1r / F2)"""
-    L.check(L.load().sjd_weight_prefetch_head(ctypes.byref(head), int(blocks), _stream()), "sjd_weight_prefetch_head")
+    L.check(L.load_exp().sjd_weight_prefetch_head(ctypes.byref(head), int(blocks), _stream()), "sjd_weight_prefetch_head")
 
 
 def xcc_map(gx, gy=1, device="cuda:0"):
     """XCC_ID of every workgroup of a (gx, gy) launch -> int32 [gy, gx]"""
     out = torch.full((gy, gx), -1, dtype=torch.int32, device=device)
-    L.check(L.load().sjd_debug_xcc_map(_ptr(out), gx, gy, _stream()), "sjd_debug_xcc_map")
+    L.check(L.load_exp().sjd_debug_xcc_map(_ptr(out), gx, gy, _stream()), "sjd_debug_xcc_map")
     return out
 
 
@@ -753,7 +775,7 @@ def qkv_attention_fused(qkv_part, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_
         assert isinstance(qkv_part, Partials) and qkv_part.N == 3 * H * D and qkv_part.data.shape[1] == 32 and workspace is not None
         act = dtype or k_cache.dtype
         out = torch.empty(B, n, H, D, dtype=act, device=k_cache.device)
-        L.check(L.load().sjd_qkv_attention_fused_split(_ptr(qkv_part.data), qkv_part.n_chunks, _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(qn_w),
+        L.check(L.load_exp().sjd_qkv_attention_fused_split(_ptr(qkv_part.data), qkv_part.n_chunks, _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(qn_w),
                                                       _ptr(qn_b), _ptr(kn_w), _ptr(kn_b), _ptr(inv_freq), _ptr(positions), B, n, H, D,
                                                       k_cache.shape[2], _dtype_code(act), _row_norm(row_norm), _ptr(key_start),
                                                       params.ptr if params is not None else None, int(kv_len), int(n_split), _ptr(workspace),
@@ -765,7 +787,7 @@ def qkv_attention_fused(qkv_part, k_cache, v_cache, qn_w, qn_b, kn_w, kn_b, inv_
     assert key_start is None or (key_start.dtype == torch.int32 and key_start.is_cuda)
     act = dtype or k_cache.dtype
     out = torch.empty(B, n, H, D, dtype=act, device=k_cache.device)
-    L.check(L.load().sjd_qkv_attention_fused(_ptr(qkv_part.data), qkv_part.n_chunks, _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(qn_w),
+    L.check(L.load_exp().sjd_qkv_attention_fused(_ptr(qkv_part.data), qkv_part.n_chunks, _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(qn_w),
                                             _ptr(qn_b), _ptr(kn_w), _ptr(kn_b), _ptr(inv_freq), _ptr(positions), B, n, H, D, k_cache.shape[2],
                                             _dtype_code(act), _row_norm(row_norm), _ptr(key_start), params.ptr if params is not None else None,
                                             int(kv_len), _stream()), "sjd_qkv_attention_fused")
@@ -846,7 +868,7 @@ def mlp_pair(x, gu_packed, dn_packed, inter, hidden, KC_dn, row_norm=None, ready
     assert rd.dtype == torch.int32 and rd.device == dev and nc + 1 <= rd.numel(), "sjd_mlp_pair_z: one arrival counter per K chunk of the down projection + 1"
     y = torch.empty(T, inter, dtype=x.dtype, device=dev)
     out = torch.empty(nc, 32, hidden, dtype=torch.float32, device=dev)
-    L.check(L.load().sjd_mlp_pair_z(_ptr(x), _ptr(gu_packed.data), _ptr(gu_packed.exc), gu_packed.cap, int(gu_packed.step_major), _ptr(y),
+    L.check(L.load_exp().sjd_mlp_pair_z(_ptr(x), _ptr(gu_packed.data), _ptr(gu_packed.exc), gu_packed.cap, int(gu_packed.step_major), _ptr(y),
                                    _ptr(dn_packed.data), _ptr(dn_packed.exc), dn_packed.cap, int(dn_packed.step_major), _ptr(out), T, inter, hidden,
                                    int(KC_dn), _row_norm(row_norm), _ptr(rd), torch.cuda.get_device_properties(dev).multi_processor_count, _stream()),
             "sjd_mlp_pair_z")
@@ -854,7 +876,7 @@ def mlp_pair(x, gu_packed, dn_packed, inter, hidden, KC_dn, row_norm=None, ready
 
 
 def mlp_pair_timeouts():
-    return int(L.load().sjd_mlp_pair_timeouts())
+    return int(L.load_exp().sjd_mlp_pair_timeouts())
 
 
 def residual_sumsq(h, part=None, pull=None, pull_blocks=0):
@@ -866,7 +888,7 @@ def residual_sumsq(h, part=None, pull=None, pull_blocks=0):
     R = part.data.shape[1] if part is not None else _prows(T)
     out = torch.empty((hidden + 511) // 512, R, dtype=torch.float32, device=h.device)
     if pull is not None and pull_blocks > 0:
-        L.check(L.load().sjd_residual_sumsq_pf(_ptr(h), _ptr(part.data) if part is not None else None, part.n_chunks if part is not None else 0,
+        L.check(L.load_exp().sjd_residual_sumsq_pf(_ptr(h), _ptr(part.data) if part is not None else None, part.n_chunks if part is not None else 0,
                                               T, hidden, _dtype_code(h.dtype), _ptr(out), ctypes.byref(pull), int(pull_blocks), _stream()), "sjd_residual_sumsq_pf")
         return out
     L.check(L.load().sjd_residual_sumsq(_ptr(h), _ptr(part.data) if part is not None else None, part.n_chunks if part is not None else 0,
@@ -896,11 +918,18 @@ class HipWindowAttention:
         self.profile_records = []   # (ev0, ev1, algorithmic_bytes)
         self._ev_pool = []
         self.kv_scale = (1.0, 1.0)  # (k, v) scales of an fp8 cache: stored byte = fp8(x / scale)
+        # round 6: per-LAYER (k, v) scales from the amax of a calibration prefill (ChameleonBackbone.calibrate_kv_scales; the engines run it on
+        # the first prompt of an fp8 cache): a list of (k, v) tuples, one per layer; None = `kv_scale` for every layer
+        self.layer_scales = None
         # K1 regime of the NEXT window launches (round 4): "colsplit" = no key splits, four workgroups per (batch, head) split the output
         # columns (one launch; wins while the context is short), "keysplit" = key splits + k1_combine.  The engines set it per iteration from
         # the host-side kv_len (choose_regime) and key their hipGraphs on it.  SJD_K1_REGIME=keysplit|colsplit pins it (A/B aid).
         self.regime = "keysplit"
         self._pin_regime = os.environ.get("SJD_K1_REGIME")
+
+    def scale_of(self, layer):
+        """(k_scale, v_scale) of `layer`'s fp8 cache"""
+        return self.kv_scale if self.layer_scales is None else self.layer_scales[layer]
 
     COLSPLIT_MAX_KEYS = {"16bit": 736, "fp8": 1536}       # crossover of the two forms (profiles/r4_k1_dsplit_ab.txt, r4_k1_dsplit_fp8_ab.txt)
 
@@ -958,11 +987,12 @@ class HipWindowAttention:
         kv_host = 0 if self.params is not None else int(kv_len)
         colsplit = self.regime == "colsplit" and colsplit_ok(B, n, H, kc.shape[1], D, kc.dtype)
         if kc.dtype == FP8:
-            kv_append_fp8(k, v, kc, vc, self.kv_scale[0], self.kv_scale[1], self.params, kv_host)
+            sk, sv = self.scale_of(layer)
+            kv_append_fp8(k, v, kc, vc, sk, sv, self.params, kv_host)
             if colsplit:
-                draft_window_attention_colsplit(q, kc, vc, out, ks, self.params, kv_host, self.kv_scale)
+                draft_window_attention_colsplit(q, kc, vc, out, ks, self.params, kv_host, (sk, sv))
             else:
-                draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], ks, self.params, kv_host, self.n_split, ws)
+                draft_window_attention_fp8(q, kc, vc, out, sk, sv, ks, self.params, kv_host, self.n_split, ws)
             return out
         kv_append(k, v, kc, vc, self.params, kv_host)
         if colsplit:
@@ -997,11 +1027,12 @@ class HipWindowAttention:
         ws = self._workspace(B, H, n, D, q.device)
         if self.regime == "colsplit" and colsplit_ok(B, n, H, kc.shape[1], D, kc.dtype):
             out = torch.empty_like(q)
-            draft_window_attention_colsplit(q, kc, vc, out, key_start, self.params, kv_host, self.kv_scale)
+            draft_window_attention_colsplit(q, kc, vc, out, key_start, self.params, kv_host, self.scale_of(layer))
             return out
         out = torch.empty_like(q)
         if kc.dtype == FP8:
-            draft_window_attention_fp8(q, kc, vc, out, self.kv_scale[0], self.kv_scale[1], key_start, self.params, kv_host, self.n_split, ws)
+            sk, sv = self.scale_of(layer)
+            draft_window_attention_fp8(q, kc, vc, out, sk, sv, key_start, self.params, kv_host, self.n_split, ws)
         else:
             draft_window_attention(q, kc, vc, out, key_start, self.params, kv_host, self.n_split, ws)
         return out

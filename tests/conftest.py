@@ -25,9 +25,14 @@ def poison_device_memory(total_gib=24):
     if not torch.cuda.is_available():
         return
     torch.cuda.synchronize()
+    # scaled to the device: never more than a quarter of what is free right now -- the extension's own hipMalloc'd buffers,
+    # hipBLASLt workspaces and a neighbour on a shared GPU allocate OUTSIDE the caching allocator and must still find room
+    free_b, _ = torch.cuda.mem_get_info()
+    total_gib = max(1, min(int(total_gib), int(free_b // 4) >> 30))
     held = []
     try:
-        for nbytes, count in ((1 << 30, max(2, total_gib - 8)), (64 << 20, 64), (8 << 20, 256), (1 << 20, 1024), (64 << 10, 2048), (4 << 10, 2048)):
+        for nbytes, count in ((1 << 30, max(0, total_gib - 8 if total_gib > 10 else total_gib - 2)), (64 << 20, 64 if total_gib >= 8 else 8),
+                              (8 << 20, 256 if total_gib >= 8 else 64), (1 << 20, 1024), (64 << 10, 2048), (4 << 10, 2048)):
             for _ in range(count):
                 held.append(torch.full((nbytes,), 0xFF, dtype=torch.uint8, device="cuda:0"))
     except torch.OutOfMemoryError:
@@ -42,15 +47,21 @@ def poison_device_memory(total_gib=24):
 _POISON_BY_DEFAULT = ("test_gpu_kernels", "test_gpu_real_shape_forward", "test_gpu_glue", "test_gpu_fp8_model_bound")
 
 
+_POISON_COUNT = {}
+
+
 @pytest.fixture(autouse=True)
 def _poison_before_gpu_tests(request):
-    """Poison the allocator's free pool before a gpu test.  Default: the K1 / workspace modules above, with an 8 GiB pool (the free blocks a test's
-    torch.empty() calls are served from).  SJD_TEST_POISON=1: every gpu test, 24 GiB (tools/profile_round.sh runs the suite once this way);
-    SJD_TEST_POISON=0: never."""
+    """Poison the allocator's free pool before a gpu test.  Default: the K1 / workspace modules above -- the FULL 8 GiB pool before a module's
+    first test and before every 16th after it, a light refresh (the small size classes a test's torch.empty() calls are served from, ~0.3 GiB)
+    before the others: the full fill in front of every test cost the suite minutes.  SJD_TEST_POISON=1: the full 24 GiB fill before
+    every gpu test (the poisoned run of the round, profiles/r*_full_gpu_suite_poisoned.txt); SJD_TEST_POISON=0: never -- for small or shared GPUs."""
     mode = os.environ.get("SJD_TEST_POISON", "")
     if mode != "0" and request.node.get_closest_marker("gpu") is not None:
+        mod = request.node.module.__name__.rsplit(".", 1)[-1]
         if mode == "1":
             poison_device_memory()
-        elif request.node.module.__name__.rsplit(".", 1)[-1] in _POISON_BY_DEFAULT:
-            poison_device_memory(total_gib=8)
+        elif mod in _POISON_BY_DEFAULT:
+            n = _POISON_COUNT[mod] = _POISON_COUNT.get(mod, -1) + 1
+            poison_device_memory(total_gib=8 if n % 16 == 0 else 1)
     yield

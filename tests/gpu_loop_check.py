@@ -284,7 +284,7 @@ def teacher_forced_emu3_check(device="cuda:0", H=3, W=5, window=32, seed=5, embe
 
 @torch.no_grad()
 def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=16, seed=3, P=(12, 9), embed_token_scale=0.25,
-                               dtype=torch.bfloat16, use_graph=True, gemm="sjd", fp8_kv=False, n_slots=None, init_scheme="random"):
+                               dtype=torch.bfloat16, use_graph=True, gemm="sjd", fp8_kv=False, n_slots=None, init_scheme="random", do_sample=True):
     """Several prompts per window forward (SJDBatchEngine): every slot's recorded logits, replayed into the CPU oracle with the slot's
     seed, must give that slot's token sequence and accept lengths -- i.e. sharing the forward changes nothing in any prompt's
     state machine (own window, kv_len, grammar, generators).  n_slots < n_prompts: continuous batching -- a slot that finished its
@@ -319,7 +319,7 @@ def teacher_forced_batch_check(device="cuda:0", n_prompts=2, hg=4, wg=4, window=
     model.setup_cache(batch=2 * n_slots, s_max=((max_len + 64 + 31) // 32) * 32, dtype=ops.FP8 if fp8_kv else None)
     cfg = SJDConfig(jacobi_loop_interval_l=3, jacobi_loop_interval_r=n_img - 10, max_num_new_tokens=window, guidance_scale=3.0,
                     seed=seed, prefix_token_sampler_scheme="speculative_jacobi", max_length=1 << 20, eos_token_ids=(8196,),
-                    multi_token_init_scheme=init_scheme)
+                    multi_token_init_scheme=init_scheme, do_sample=do_sample)
     eng = SJDBatchEngine(model, V, device, n_slots, max_window=window, use_graph=use_graph)
     if wide and gemm == "sjd":       # the hand-written projections must be what runs (not the library-GEMM prefill path)
         calls = []

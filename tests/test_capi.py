@@ -14,16 +14,55 @@ def _ensure_built():
     return L
 
 
+_DECL = re.compile(r"^(?:int|int64_t|uint64_t|void \*|void|float|const char \*)\s*(sjd_[a-z0-9_]+)\s*\(", re.M)      # a declaration, not a mention in a comment
+
+
+def _nm_exports(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if " T sjd_" in ln and not ln.split()[-1].startswith("sjd_debug_trace")}
+
+
 def test_exports_match_header():
+    """the PRODUCT library: include/sjd_hip.h == _lib.EXPORTS == what libsjd_hip.so exports (nm), and nothing experimental among it"""
     L = _ensure_built()
     lib = L.load()
     hdr = open(os.path.join(ROOT, "include", "sjd_hip.h")).read()
-    declared = set(re.findall(r"\b(sjd_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(_DECL.findall(hdr))
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    assert _nm_exports(L.SO_PATH) == declared, _nm_exports(L.SO_PATH) ^ declared
+    assert len(declared) <= 45 and not (declared & set(L.EXP_EXPORTS))                            # VERDICT r5 #6: the experiments live elsewhere
     for name in declared:
         assert getattr(lib, name) is not None
+    for name in L.EXP_EXPORTS:
+        assert not hasattr(lib, name), name
     assert lib.sjd_version() == int(re.search(r"#define SJD_VERSION (\d+)", hdr).group(1))
     assert lib.sjd_error_string(-2) == b"unsupported configuration"
+
+
+def test_experimental_library_is_a_superset_with_its_own_header():
+    """libsjd_hip_exp.so (same sources, -DSJD_EXPERIMENTAL): everything the product exports plus exactly what include/sjd_hip_experimental.h declares"""
+    L = _ensure_built()
+    exp = L.load_exp()
+    hdr = open(os.path.join(ROOT, "include", "sjd_hip_experimental.h")).read()
+    declared = set(_DECL.findall(hdr))
+    assert declared == set(L.EXP_EXPORTS), declared ^ set(L.EXP_EXPORTS)
+    assert _nm_exports(L.EXP_SO_PATH) == declared | set(L.EXPORTS)
+    for name in declared | set(L.EXPORTS):
+        assert getattr(exp, name) is not None
+    assert exp.sjd_mlp_pair_z(None, None, None, 32, 1, None, None, None, 32, 0, None, 32, 11008, 4096, 768, None, None, 256, None) == -1
+
+
+def test_product_package_does_not_load_the_experimental_library():
+    """importing the product modules and building an engine's host side must not pull libsjd_hip_exp.so in (a fresh interpreter: this process
+    has loaded it in the test above)"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import sjd_amd, sjd_amd._lib as L, sjd_amd.ops, sjd_amd.engine as E, sjd_amd.engine_batch, sjd_amd.backbones; "
+            "L.load(); E.check_reduce_timeouts(); assert L._exp is None; "
+            "assert 'libsjd_hip_exp' not in open('/proc/self/maps').read(); print('ok')" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
 def test_struct_layouts_match_header():
@@ -54,7 +93,6 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     # round 4 entry points: argument checks run before any launch
     assert lib.sjd_draft_window_attention_colsplit(None, None, None, None, 2, 16, 32, 32, 128, 1024, 0, None, None, 0, None) == -1
     assert lib.sjd_draft_window_attention_fp8_colsplit(None, None, None, None, 2, 16, 32, 32, 128, 1024, 0, 1.0, 1.0, None, None, 0, None) == -1
-    assert lib.sjd_mlp_pair_z(None, None, None, 32, 1, None, None, None, 32, 0, None, 32, 11008, 4096, 768, None, None, 256, None) == -1
 
 
 def test_host_wait_on_the_mirror_sequence_word():

@@ -10,14 +10,27 @@ logits K2 reads, and measured against three forwards on the same weights and the
   aten16    the independent ATen bf16 forward of tests/test_gpu_real_shape_forward.py (hipBLASLt + SDPA over a torch.cat cache)
   fp32      the same independent forward in fp32
 
-Stated tolerance (asserted below, on the image-vocabulary columns of every window row, context 600 .. 700 keys):
-  * max |hip_fp8 - fp32| <= 3.5 x max |aten16 - fp32| and mean <= 2.5 x mean: the fp8 cache costs a small multiple of what 16-bit arithmetic
-    itself costs (measured round 5: 0.635 against 0.226 = 2.8 x; 0.0576 against 0.0326 = 1.8 x; logit std 3.0),
-  * the argmax of hip_fp8 agrees with hip_bf16's on >= 85 % of the rows (measured 93.8 %; hip_bf16 against aten16: 94.9 %),
-  * the sampling distribution K2 would form (CFG 3.0, top-k 2000, softmax) moves by <= 0.15 in total variation on average (measured 0.106;
-    bf16 against fp32: 0.056),
-  * a 256-step SJD decode accepts within 15 % of the tokens per step on either cache (measured 2.05 on fp8 against 2.21 on bf16).
-The measured numbers go to gpurun_out/r5_fp8_model_bound.json (committed under profiles/)."""
+Stated tolerance (asserted below, on the image-vocabulary columns of every window row, context 600 .. 700 keys).  Round 6 (VERDICT r5 #2b) removed
+the two ON-CHIP roundings -- Q and P travel as hi / lo e4m3 operand pairs -- and calibrates per-layer K / V scales from the prompt's amax; measured
+under the three arithmetics on one box (profiles/r6_fp8_model_bound_{a_r5,b_hilo,c_hilo_calibrated}.json):
+
+                                  round 5      hi / lo      hi / lo + calibrated     bf16 cache
+  max  |logit - fp32|             0.635        0.573        0.557                    0.227   (aten16 0.226)
+  mean |logit - fp32|             0.0576       0.0554       0.0542                   0.0329  (aten16 0.0326)
+  argmax agreement with bf16      93.8 %       93.4 %       95.3 %                   (bf16 vs aten16: 95.3 %)
+  K2 total variation vs bf16      0.106        0.101        0.098                    (bf16 vs fp32: 0.056)
+  tokens / step, 256 steps        2.05         1.98         2.04                     2.21
+
+i.e. what is left IS the cache format: K and V stored with three mantissa bits (kernel level: the attention now equals exact attention over
+the dequantised cache to 2^-8, tests/test_gpu_kernels.py::test_k1_k3_fp8_kv_cache, tolerances a fifth of round 5's).  VERDICT r5's targets
+(mean <= 1.5 x bf16's, max <= 2 x, acceptance within 3 %) are NOT reached -- 1.65 x, 2.45 x, -8 % -- and cannot be with an e4m3 cache; DESIGN.md
+section 6 says so plainly: config 5's fp8 path exists because BASELINE.json names it, at a tokens/s cost that bench.py reports next to the bf16
+cache (other_configs.anole7b vs anole7b_bf16kv).  Asserted:
+  * max |hip_fp8 - fp32| <= 3.0 x max |aten16 - fp32| and mean <= 2.0 x mean,
+  * the argmax of hip_fp8 agrees with hip_bf16's on >= 90 % of the rows,
+  * the sampling distribution K2 would form (CFG 3.0, top-k 2000, softmax) moves by <= 0.12 in total variation on average,
+  * a 256-step SJD decode accepts within 12 % of the tokens per step on either cache.
+The measured numbers go to gpurun_out/r6_fp8_model_bound*.json (committed under profiles/)."""
 import json
 import os
 
@@ -54,9 +67,15 @@ def test_fp8_kv_cache_moves_the_logits_by_a_stated_bound():
     wins = [(P + 3 * i, torch.randint(4, 8196, (1, window), generator=g).expand(2, window).contiguous().to(dev)) for i in range(8)]
     cols = (0, 8224)                               # the image vocabulary 4..8195, 32-aligned
 
+    calibrate = os.environ.get("SJD_FP8_CALIBRATE", "1") != "0"
+
     def hip_logits(cache_dtype):
         model.setup_cache(batch=2, s_max=s_max, dtype=cache_dtype)
         model.attn.params = None                   # kv_len from the host
+        model.attn.layer_scales = None
+        if cache_dtype == ops.FP8 and calibrate:   # round 6: per-layer (k, v) scales from this prompt's amax (what the engines do on their first prompt)
+            scales = model.calibrate_kv_scales(spec.first_tokens.to(dev), spec.first_positions.to(dev), ks)
+            rep_scales.extend([round(s_[0], 5), round(s_[1], 5)] for s_ in scales)
         model.forward_window(spec.first_tokens.to(dev), spec.first_positions.to(dev), 0, ks)
         out = []
         for kv, ids in wins:
@@ -67,6 +86,7 @@ def test_fp8_kv_cache_moves_the_logits_by_a_stated_bound():
             out.append(lg.float().clone())
         return out
 
+    rep_scales = []
     hip8 = hip_logits(ops.FP8)
     hip16 = hip_logits(None)
     outs = {}
@@ -86,7 +106,9 @@ def test_fp8_kv_cache_moves_the_logits_by_a_stated_bound():
         kth = z.topk(2000, dim=-1).values[:, -1:]
         return torch.softmax(z.masked_fill(z < kth, float("-inf")), dim=-1)
 
-    rep = dict(family="anole7b", prompt_len=P, window=window, cache="fp8 e4m3 vs bf16", windows=[])
+    rep = dict(family="anole7b", prompt_len=P, window=window, cache="fp8 e4m3 vs bf16", windows=[], calibrated=calibrate,
+               kv_scales_first_and_last_layer=[rep_scales[0], rep_scales[-1]] if rep_scales else None,
+               arithmetic=os.environ.get("SJD_FP8_TAG", "hi/lo e4m3 operands for Q and P (round 6)"))
     acc = dict(e8=[], e16=[], ea=[], d=[], agree=[], agree_a=[], tv=[], tv16=[], m8=0.0, m16=0.0, ma=0.0)
     for i, (kv, _) in enumerate(wins):
         a8, a16, aa, f32 = hip8[i][..., 4:8196], hip16[i][..., 4:8196], outs["aten16"][i][..., 4:8196], outs["fp32"][i][..., 4:8196]
@@ -116,6 +138,7 @@ def test_fp8_kv_cache_moves_the_logits_by_a_stated_bound():
     dec = {}
     for tag, cdt in (("fp8", ops.FP8), ("bf16", None)):
         model.setup_cache(batch=2, s_max=((P0 + n_img + 2 * window + 64 + 31) // 32) * 32, dtype=cdt)
+        model.attn.layer_scales = None             # (the engine calibrates an fp8 cache on its first prompt unless SJD_FP8_CALIBRATE=0)
         eng = SJDEngine(model, V, dev, max_window=window, use_graph=True)
         cfg = SJDConfig(jacobi_loop_interval_l=0, jacobi_loop_interval_r=1024 - window - 2, max_num_new_tokens=window, guidance_scale=3.0, seed=1234,
                         prefix_token_sampler_scheme="speculative_jacobi", max_length=P0 + n_img, eos_token_ids=(8196,))
@@ -126,11 +149,12 @@ def test_fp8_kv_cache_moves_the_logits_by_a_stated_bound():
     print("fp8 model bound:", json.dumps(rep))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "r5_fp8_model_bound.json"), "w") as fh:
+        with open(os.path.join(out_dir, "r6_fp8_model_bound%s.json" % os.environ.get("SJD_FP8_FILE_TAG", "")), "w") as fh:
             json.dump(rep, fh, indent=1)
     s = rep["summary"]
-    assert s["fp8_max"] <= 3.5 * s["aten16_max"] + 1e-3 and s["fp8_mean"] <= 2.5 * s["aten16_mean"] + 1e-4, s
+    loose = os.environ.get("SJD_FP8_FILE_TAG", "") in ("_a_r5", "_b_hilo")          # (the A/B legs of tools/_r6_fp8.sh: round 5's bounds)
+    assert s["fp8_max"] <= (3.5 if loose else 3.0) * s["aten16_max"] + 1e-3 and s["fp8_mean"] <= (2.5 if loose else 2.0) * s["aten16_mean"] + 1e-4, s
     assert s["bf16_max"] <= 1.5 * s["aten16_max"] + 1e-3 and s["bf16_mean"] <= 1.5 * s["aten16_mean"] + 1e-4, s
-    assert s["argmax_agree_fp8_bf16"] >= 0.85, s
-    assert s["k2_total_variation_fp8_vs_bf16"] <= 0.15, s
-    assert abs(dec["fp8"]["tokens_per_step"] - dec["bf16"]["tokens_per_step"]) <= 0.15 * dec["bf16"]["tokens_per_step"], dec
+    assert s["argmax_agree_fp8_bf16"] >= (0.85 if loose else 0.90), s
+    assert s["k2_total_variation_fp8_vs_bf16"] <= (0.15 if loose else 0.12), s
+    assert abs(dec["fp8"]["tokens_per_step"] - dec["bf16"]["tokens_per_step"]) <= (0.15 if loose else 0.12) * dec["bf16"]["tokens_per_step"], dec

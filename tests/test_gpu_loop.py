@@ -114,6 +114,34 @@ def test_greedy_decode_takes_the_oracles_decisions(use_graph, gemm, scheme):
     assert r["last"] == 8196 and r["tokens"] == 73
 
 
+@pytest.mark.parametrize("n_prompts,use_graph,n_slots", [(2, True, None), (3, False, None), (5, True, 2)])
+def test_greedy_batch_decode_takes_the_oracles_decisions(n_prompts, use_graph, n_slots):
+    """round 6: GenerationConfig(do_sample=False) in SJDBatchEngine (it raised): every slot emits K2's mode instead of its draw, consumes nothing from
+    its generator for it, and still decodes exactly as its own greedy oracle replay -- also with continuous batching (5 prompts on 2 slots)"""
+    rs = G.teacher_forced_batch_check(n_prompts=n_prompts, P=(12, 9, 14, 7, 10), use_graph=use_graph, n_slots=n_slots, do_sample=False)
+    assert len(rs) == n_prompts and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs)
+
+
+def test_batch_engine_names_what_256_rows_need(dev="cuda:0"):
+    """more than 128 window rows on launch shapes / a packing kernel G1w does not serve used to fall back silently or fail mid-decode"""
+    import sjd_amd.ops as ops
+    from sjd_amd.engine_batch import SJDBatchEngine
+    from tests.helpers import make_chameleon
+    conf = dict(vocab_size=9216, hidden_size=512, intermediate_size=256, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=4,
+                max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    m = make_chameleon(conf, 23, 0.25, ops.HipWindowAttention(n_split=2), dtype=torch.bfloat16, device=dev)
+    m.G1_CFG = dict(qkv=(256, 5, True), o=(128, 4, True), gate_up=(256, 4, True), down=(128, 4, True))
+    m.enable_fused(ops, gemm="sjd", compress=False)
+    with pytest.raises(ValueError, match="G1w"):
+        SJDBatchEngine(m, 9216, dev, 6, max_window=16)
+    m2 = make_chameleon(conf, 23, 0.25, ops.HipWindowAttention(n_split=2), dtype=torch.bfloat16, device=dev)
+    m2.G1_CFG = dict(qkv=(256, 4, True), o=(128, 4, True), gate_up=(256, 4, True), down=(128, 4, True))
+    m2.enable_fused(ops, gemm="sjd", compress=True)
+    with pytest.raises(ValueError, match="uncompressed"):
+        SJDBatchEngine(m2, 9216, dev, 6, max_window=16)
+    SJDBatchEngine(m2, 9216, dev, 4, max_window=16)             # 128 rows: the 12-bit stream serves them
+
+
 @pytest.mark.parametrize("n_prompts,use_graph", [(5, True), (6, False), (8, True)])
 def test_five_to_eight_prompts_share_one_window_forward(n_prompts, use_graph):
     """round 5: 160 / 192 / 256 window rows per forward (G1 with five to eight row tiles, F1r / F2 / F3 over 256 rows, K1 over 16 batch rows): every

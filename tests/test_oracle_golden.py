@@ -89,6 +89,30 @@ def test_logits2tokens_greedy(golden_dir):
         check_probs(d, name, toks, probs, d["cols"], exact_support=False)      # (no top-k: torch keeps denormal tails the canonical exp flushes)
 
 
+def test_greedy_mode_of_p_vs_argmax_of_scores():
+    """greedy decoding in the engine emits K2's lowest-index MODE of the softmaxed p; the reference (JL:128) and oracle/loop.py take
+    torch.argmax of the processed scores.  This pins where the two can differ: only when the top scores are distinct floats whose exponentials
+    round to the same fp32 -- a gap below 2^-25, which exists between floats only below |z| = 0.5 -- and that they agree everywhere else, incl.
+    one-ulp near-ties at ordinary logit magnitudes (the documented deviation of SJDEngine._k2_out)."""
+    V = 64
+    rules = O.lumina_rules([8197, 8808, 8808, 5, 6], 1, 0, 0)                    # inside an image: ids 4..8195 allowed
+    ones = np.ones((1, 9216), np.float32)
+
+    def mode_and_argmax(z_top, z_next):
+        z = np.full((1, 9216), -30.0, np.float32)
+        z[0, 40], z[0, 20] = z_top, z_next                                           # the larger score sits at the HIGHER index
+        _, p = O.logits_to_probs_sample(z, None, 1.0, rules, ones)
+        return int(p[0].argmax()), int(np.where(p[0] > 0, z[0], -np.inf).argmax())
+
+    for top in (3.0, 17.25, 1.0, 0.75):                                              # |z| >= 0.5: an ulp apart is already distinguishable in p
+        nxt = np.nextafter(np.float32(top), np.float32(-np.inf))
+        assert mode_and_argmax(top, nxt) == (40, 40)
+    top = np.float32(0.01)                                                           # |z| < 0.5: one ulp (9e-10) vanishes in exp(z - zmax): p ties,
+    nxt = np.nextafter(top, np.float32(-np.inf))                                     # the mode falls on the LOWER index, the score argmax on the larger score
+    assert mode_and_argmax(top, nxt) == (20, 40)
+    assert mode_and_argmax(top, np.float32(top - 1e-6)) == (40, 40)                  # ... a gap of 1e-6 is seen again
+
+
 def test_logits2tokens_llamagen(golden_dir):
     d, meta = load(golden_dir, "fn_logits2tokens_llamagen.npz")
     for m in meta:

@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 C=${1:-832:8:1}; V=${2:-0}; SHAPE=${4:-qkv}
-[ -n "$3" ] && export SJD_HIP_LIB=$3
+[ -n "$3" ] && export SJD_HIP_EXP_LIB=$3
 O=gpurun_out
 B="python tools/g1w_bench.py --only $SHAPE --cand $C --variants $V --no-blas --no-old --launches 6 --copies 3"
 : > $O/gw_pmc.jsonl

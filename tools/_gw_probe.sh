@@ -8,7 +8,7 @@ echo "## product" >> $O
 python tools/g1w_bench.py --only $SHAPE --cand $CAND --variants $VARS --no-blas --no-old >> $O 2>&1
 for v in "$@"; do
   echo "## $v" >> $O
-  SJD_HIP_LIB=tools/_exp/gw_$v/libsjd_hip.so python tools/g1w_bench.py --only $SHAPE --cand $CAND --variants $VARS --no-blas --no-old >> $O 2>&1
+  SJD_HIP_EXP_LIB=tools/_exp/gw_$v/libsjd_hip_exp.so python tools/g1w_bench.py --only $SHAPE --cand $CAND --variants $VARS --no-blas --no-old >> $O 2>&1
 done
 grep -v "best\|amdgpu.ids" $O | python -c "
 import sys, json

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    lib = L.load()
+    lib = L.load_exp()
     import sjd_amd.backbones as BB
     prod = BB.ChameleonBackbone.G1_CFG_Z
     # (shape, N, K, engine KC, engine workgroups)

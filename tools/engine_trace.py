@@ -2,7 +2,7 @@ import sys, os, ctypes, json
 sys.path.insert(0, os.getcwd())
 import torch
 import sjd_amd._lib as L, sjd_amd.ops as ops
-lib = L.load()
+lib = L.load_exp()
 dev = torch.device("cuda:0")
 N, K, KC = 12288, 4096, 512
 x = torch.randn(32, K, device=dev).to(torch.bfloat16)

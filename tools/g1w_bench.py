@@ -59,12 +59,11 @@ def main():
     ap.add_argument("--no-old", action="store_true")
     ap.add_argument("--no-blas", action="store_true")
     ap.add_argument("--pad", type=int, default=0, help="row stride of x = K + pad elements (L2 channel spread experiment)")
-    ap.add_argument("--trace", action="store_true", help="SJD_HIP_LIB is a -DSJD_TRACE build: per-workgroup wall / shader-clock stamps of the last launch")
+    ap.add_argument("--trace", action="store_true", help="SJD_HIP_EXP_LIB is a -DSJD_TRACE build: per-workgroup wall / shader-clock stamps of the last launch")
     ap.add_argument("--cand", default="", help="KC:tiles:step_major[,...] instead of the built-in candidates")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    lib = L.load()
-    lib.sjd_skinny_gemm_wide.argtypes = [VP, VP, VP] + [ctypes.c_int] * 8 + [VP]
+    lib = L.load_exp()          # (the tuning entry sjd_skinny_gemm_wide lives in libsjd_hip_exp.so; SJD_HIP_EXP_LIB: a probe build of it)
     M = a.rows
     stream = lambda: VP(torch.cuda.current_stream().cuda_stream)
     for name, (N, K) in SHAPES.items():

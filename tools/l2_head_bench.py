@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--between", type=int, default=0, help="small dependent launches between the pull and the consumer (F2 -> K1 -> combine -> o)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    lib = L.load()
+    lib = L.load_exp()
     import sjd_amd.backbones as BB
     ok = True
     for gx, gy in ((256, 1), (64, 4), (172, 1), (22, 8), (16, 15), (1024, 1), (3, 5)):

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--blocks", default="512,1024,2048")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    lib = L.load()
+    lib = L.load_exp()
     import sjd_amd.backbones as BB
     cfg = BB.ChameleonBackbone.G1_CFG_Z
     rows, hid, inter = 32, 4096, 11008

@@ -56,6 +56,21 @@ if k:
            "hbm_bytes_per_launch": int(rd + wr), "traffic_over_algorithmic": round((rd + wr) / alg, 3)}
     json.dump(out, open(os.path.join(pdir, "k1_traffic.json"), "w"), indent=2)
     print("k1_traffic.json", out["hbm_bytes_per_launch"], out["traffic_over_algorithmic"])
+# ---- Emu3's K1 (round 6): k1_partial_ring + k1_combine at GQA 32 / 8, window 32, kv 4186, 16 key splits -- the pair's traffic against its
+# algorithmic bytes (2 B_cfg H_kv (kv + L) D e for K and V, once per kv head, + the q rows)
+kr, r_ = pick("k1_partial_ring<")
+kc, c_ = pick("k1_combine<")
+if r_ and c_:
+    kv, L_, Hkv, H, D_, B_ = 4186, 32, 8, 32, 128, 2
+    alg = 2 * B_ * Hkv * (kv + L_) * D_ * 2 + B_ * L_ * H * D_ * 2
+    rd = (r_["FETCH_SIZE"] + c_["FETCH_SIZE"]) * 1024 * 2
+    wr = (r_["WRITE_SIZE"] + c_["WRITE_SIZE"]) * 1024
+    out = {"kernel": "k1_partial_ring<bf16, D=128> + k1_combine (Emu3's shape)", "workload": "tools/k1_bench.py --kv-len 4186 --n-split 16 --heads 32 --kv-heads 8 --window 32 --launches 96 --graph",
+           "source": src, "fetch_correction": corr, "partial_FETCH_KB_raw": r_["FETCH_SIZE"], "partial_WRITE_KB_raw": r_["WRITE_SIZE"],
+           "combine_FETCH_KB_raw": c_["FETCH_SIZE"], "combine_WRITE_KB_raw": c_["WRITE_SIZE"], "hbm_read_bytes_per_pair": int(rd), "hbm_write_bytes_per_pair": int(wr),
+           "hbm_bytes_per_pair": int(rd + wr), "algorithmic_bytes_per_pair": alg, "traffic_over_algorithmic": round((rd + wr) / alg, 3)}
+    json.dump(out, open(os.path.join(pdir, "k1_emu3_traffic.json"), "w"), indent=2)
+    print("k1_emu3_traffic.json", out["hbm_bytes_per_pair"], out["traffic_over_algorithmic"])
 # ---- rocprofv3 --kernel-trace --stats of the bench decode: average duration of a G1 launch (the dominant kernel)
 stats = os.path.join(pdir, f"{tag}_bench_kernel_stats.csv")
 if os.path.exists(stats):

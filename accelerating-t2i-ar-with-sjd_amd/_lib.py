@@ -38,6 +38,13 @@ class RowNorm(ctypes.Structure):
     _fields_ = [("sumsq", ctypes.c_void_p), ("slices", ctypes.c_int32), ("hidden", ctypes.c_int32), ("eps", ctypes.c_float)]
 
 
+class Slots(ctypes.Structure):
+    """sjd_slots: the strides between the slots of a continuous batch (K5 / K2 / K4 of every slot in one launch each)"""
+    _fields_ = [("n_slots", ctypes.c_int32), ("head_rows", ctypes.c_int32), ("params_stride", ctypes.c_int64), ("state_stride", ctypes.c_int64),
+                ("probs_stride", ctypes.c_int64), ("zero_state_stride", ctypes.c_int64), ("scratch_stride", ctypes.c_int64),
+                ("mirror_stride", ctypes.c_int64), ("dbg_stride", ctypes.c_int64)]
+
+
 class HeadPartials(ctypes.Structure):
     """sjd_head_partials: the unmaterialised output head K2 reads (split-K partials of the lm_head projection)"""
     _fields_ = [("part", ctypes.c_void_p), ("n_chunks", ctypes.c_int32), ("chunk_stride", ctypes.c_int64), ("row_stride", ctypes.c_int64),
@@ -64,7 +71,8 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
            "sjd_verify_accept_ex", "sjd_upload_async", "sjd_stream_synchronize", "sjd_gateup_silu", "sjd_host_wait_u64",
            "sjd_philox_fill", "sjd_philox_offset_increment", "sjd_skinny_gemm_z", "sjd_gateup_silu_z",
            "sjd_draft_window_attention_colsplit", "sjd_draft_window_attention_fp8_colsplit",
-           "sjd_head_combine", "sjd_raw_units_fixup", "sjd_raw_gateup_fixup"]
+           "sjd_head_combine", "sjd_raw_units_fixup", "sjd_raw_gateup_fixup",
+           "sjd_reguess_slots", "sjd_logits_to_probs_sample_part_slots", "sjd_verify_accept_slots"]
 # what include/sjd_hip_experimental.h adds: libsjd_hip_exp.so only (the measured no-go structures of rounds 2-5 and the G1w tuning entry)
 EXP_EXPORTS = ["sjd_weight_prefetch", "sjd_qkv_attention_fused", "sjd_qkv_attention_fused_split", "sjd_skinny_gemm_reduce", "sjd_reduce_timeouts",
                "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged", "sjd_mlp_pair_z", "sjd_mlp_pair_timeouts",
@@ -131,6 +139,9 @@ def _bind_product(lib):
     lib.sjd_skinny_gemm_cols.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_logits_to_probs_sample_part.argtypes = [ctypes.POINTER(HeadPartials), f32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.sjd_head_combine.argtypes = [ctypes.POINTER(HeadPartials), f32, i32, i32, vp, vp, vp]
+    lib.sjd_reguess_slots.argtypes = [vp, vp, vp, i32, i32, vp, vp, ctypes.POINTER(Slots), vp]
+    lib.sjd_logits_to_probs_sample_part_slots.argtypes = [ctypes.POINTER(HeadPartials), f32, i32, i32, vp, vp, vp, vp, ctypes.POINTER(Slots), vp]
+    lib.sjd_verify_accept_slots.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, ctypes.POINTER(Slots), vp]
     lib.sjd_logits_to_probs_sample_ex.argtypes = [vp, vp, i64, f32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.sjd_skinny_gemm_z.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_gateup_silu_z.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp]

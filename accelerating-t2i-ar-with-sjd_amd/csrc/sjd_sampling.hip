@@ -158,14 +158,31 @@ __global__ __launch_bounds__(256) void k2a_head_combine(const sjd_head_partials 
 }
 
 #define K2_NI 3               // column groups (of 4 x 1024) a thread keeps in registers: windows of up to 12288 columns (9 groups = Emu3's 32768-column rows no longer fit the 128 VGPRs of a 1024-thread workgroup: spills)
-template <bool PART>
+// SLOTS (round 6): blockIdx.y = the slot of a continuous batch (sjd_slots in include/sjd_hip.h) -- every per-slot pointer moves by the slot's
+// stride before anything else happens, the rest is the one-slot kernel.  The one-slot instantiation is untouched (hp binds to the kernel argument).
+template <bool PART, bool SLOTS = false>
 __global__ __launch_bounds__(SJD_TPB) void k2_logits_to_probs_sample(
     const float *__restrict__ logits_c, const float *__restrict__ logits_u, long row_stride, float guidance, int V,
     const sjd_iter_params *__restrict__ params, const float *__restrict__ noise, float *__restrict__ probs_out,
-    int64_t *__restrict__ tokens_out, const sjd_head_partials hp, int64_t *__restrict__ amax_out, int lds_floats)
+    int64_t *__restrict__ tokens_out, const sjd_head_partials hp_arg, int64_t *__restrict__ amax_out, int lds_floats, const sjd_slots sb)
 {
     __shared__ SjdShared sh;
     extern __shared__ __attribute__((aligned(16))) float sjd_dyn_lds[];      // round 4: the staged scores of a row too wide for registers
+    sjd_head_partials hp_slot;
+    if constexpr (SLOTS) {
+        const size_t s = blockIdx.y;
+        hp_slot = hp_arg;
+        hp_slot.part += s * (size_t)sb.head_rows * (size_t)hp_arg.row_stride;
+        if (hp_slot.row_sumsq) hp_slot.row_sumsq += s * (size_t)sb.head_rows;
+        if (hp_slot.zero_state) hp_slot.zero_state += s * (size_t)sb.zero_state_stride;
+        if (hp_slot.dbg_c) hp_slot.dbg_c += s * (size_t)sb.dbg_stride;
+        if (hp_slot.dbg_u) hp_slot.dbg_u += s * (size_t)sb.dbg_stride;
+        params = reinterpret_cast<const sjd_iter_params *>(reinterpret_cast<const char *>(params) + s * (size_t)sb.params_stride);
+        probs_out += s * (size_t)sb.probs_stride;
+        tokens_out = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(tokens_out) + s * (size_t)sb.state_stride);
+        if (amax_out) amax_out = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(amax_out) + s * (size_t)sb.state_stride);
+    }
+    const sjd_head_partials &hp = SLOTS ? hp_slot : hp_arg;
     const int row = blockIdx.x;
     SJD_TRS(row, 0);
     // Round 4: everything the row needs before its first sum is requested in ONE round trip -- the row count, the rule, the folded norm's row
@@ -591,13 +608,23 @@ __device__ __forceinline__ void k4_mirror_state(const sjd_state *state, sjd_stat
 }
 
 // replaces SpeculativeSampler.__call__ / find_first_misaligned_token_inds (reference JL:247-333)
+template <bool SLOTS = false>
 __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
     const sjd_iter_params *__restrict__ params, sjd_state *__restrict__ state, const float *__restrict__ probs,
     const float *__restrict__ prev_probs, const float *__restrict__ rs, const float *__restrict__ noise2,
-    float *__restrict__ scratch_global, int V, sjd_state *__restrict__ host_mirror, int lds_floats)
+    float *__restrict__ scratch_global, int V, sjd_state *__restrict__ host_mirror, int lds_floats, const sjd_slots sb)
 {
     __shared__ SjdShared sh;
     extern __shared__ __attribute__((aligned(16))) float sjd_dyn_lds[];      // round 4: the residual row, when its window fits (else `scratch`)
+    if constexpr (SLOTS) {        // blockIdx.y = the slot (see k2_logits_to_probs_sample)
+        const size_t s = blockIdx.y;
+        params = reinterpret_cast<const sjd_iter_params *>(reinterpret_cast<const char *>(params) + s * (size_t)sb.params_stride);
+        state = reinterpret_cast<sjd_state *>(reinterpret_cast<char *>(state) + s * (size_t)sb.state_stride);
+        probs += s * (size_t)sb.probs_stride;
+        prev_probs += s * (size_t)sb.probs_stride;
+        scratch_global += s * (size_t)sb.scratch_stride;
+        if (host_mirror) host_mirror = reinterpret_cast<sjd_state *>(reinterpret_cast<char *>(host_mirror) + s * (size_t)sb.mirror_stride);
+    }
     SJD_TRS(32, 0);
     const int n = params->n_rows;
     if (n <= 1) {   // prefill / single-token phase short-circuit (JL:344-350)
@@ -833,10 +860,19 @@ __global__ __launch_bounds__(SJD_TPB) void k4_verify_accept(
 // 606-701): window = [last emitted | carried unverified samples | fresh random ids]
 // positions_out (optional): the position ids of the window rows, kv_len + i + pos_offset[b] (reference JL:1062-1073 builds them on the
 // host from cache_position; three ATen element-wise launches per iteration before round 2's end)
+template <bool SLOTS = false>
 __global__ void k5_reguess(const sjd_iter_params *__restrict__ params, sjd_state *__restrict__ state,
                            int64_t *__restrict__ input_ids_out, int n_batch, int max_rows, const int64_t *__restrict__ pos_offset,
-                           int64_t *__restrict__ positions_out)
+                           int64_t *__restrict__ positions_out, const sjd_slots sb)
 {
+    if constexpr (SLOTS) {        // blockIdx.x = the slot: its n_batch rows of the shared [n_slots * n_batch, max_rows] id / position tensors
+        const size_t s = blockIdx.x;
+        params = reinterpret_cast<const sjd_iter_params *>(reinterpret_cast<const char *>(params) + s * (size_t)sb.params_stride);
+        state = reinterpret_cast<sjd_state *>(reinterpret_cast<char *>(state) + s * (size_t)sb.state_stride);
+        input_ids_out += s * (size_t)n_batch * (size_t)max_rows;
+        if (pos_offset) pos_offset += s * (size_t)n_batch;
+        if (positions_out) positions_out += s * (size_t)n_batch * (size_t)max_rows;
+    }
     const int i = threadIdx.x;
     const int n = params->n_rows;
     const int m = state->m, n_prev = state->n_prev;
@@ -876,8 +912,8 @@ extern "C" int sjd_reguess_ex(const sjd_iter_params *params, sjd_state *state, i
                               const int64_t *pos_offset, int64_t *positions_out, void *stream)
 {
     if (!params || !state || !input_ids_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || n_batch < 1) return SJD_ERR_BAD_ARG;
-    hipLaunchKernelGGL(k5_reguess, dim3(1), dim3(64), 0, (hipStream_t)stream, params, state, input_ids_out, n_batch, max_rows, pos_offset,
-                       positions_out);
+    hipLaunchKernelGGL(k5_reguess<false>, dim3(1), dim3(64), 0, (hipStream_t)stream, params, state, input_ids_out, n_batch, max_rows, pos_offset,
+                       positions_out, sjd_slots{});
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
@@ -908,7 +944,7 @@ extern "C" int sjd_logits_to_probs_sample_ex(const float *logits_c, const float 
     const int lds_floats = sjd_stage_lds_floats((long)V + 2 * SJD_DRAW_LIST);
     (void)hipFuncSetAttribute((const void *)k2_logits_to_probs_sample<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
     hipLaunchKernelGGL(k2_logits_to_probs_sample<false>, dim3(max_rows), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, logits_c, logits_u,
-                       (long)row_stride, guidance, V, params, noise, probs_out, tokens_out, none, amax_out, lds_floats);
+                       (long)row_stride, guidance, V, params, noise, probs_out, tokens_out, none, amax_out, lds_floats, sjd_slots{});
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
@@ -922,7 +958,7 @@ extern "C" int sjd_logits_to_probs_sample_part(const sjd_head_partials *head, fl
     const int lds_floats = sjd_stage_lds_floats((long)head->n_cols + 8 + 2 * SJD_DRAW_LIST);     // (the rows' windows lie inside the head's column window; + the draw list)
     (void)hipFuncSetAttribute((const void *)k2_logits_to_probs_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
     hipLaunchKernelGGL(k2_logits_to_probs_sample<true>, dim3(max_rows), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, (const float *)nullptr,
-                       (const float *)nullptr, (long)0, guidance, V, params, noise, probs_out, tokens_out, *head, amax_out, lds_floats);
+                       (const float *)nullptr, (long)0, guidance, V, params, noise, probs_out, tokens_out, *head, amax_out, lds_floats, sjd_slots{});
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
@@ -945,9 +981,9 @@ extern "C" int sjd_verify_accept_ex(const sjd_iter_params *params, sjd_state *st
     if (!params || !state || !probs || !prev_probs || !scratch || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1)
         return SJD_ERR_BAD_ARG;                    /* rs / noise2 may be NULL when params->philox_blocks > 0 */
     const int lds_floats = sjd_stage_lds_floats((long)V + 2 * SJD_DRAW_LIST);
-    (void)hipFuncSetAttribute((const void *)k4_verify_accept, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
-    hipLaunchKernelGGL(k4_verify_accept, dim3(1), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, params, state, probs, prev_probs, rs,
-                       noise2, scratch, V, host_mirror, lds_floats);
+    (void)hipFuncSetAttribute((const void *)k4_verify_accept<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
+    hipLaunchKernelGGL(k4_verify_accept<false>, dim3(1), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, params, state, probs, prev_probs, rs,
+                       noise2, scratch, V, host_mirror, lds_floats, sjd_slots{});
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
@@ -955,6 +991,52 @@ extern "C" int sjd_verify_accept(const sjd_iter_params *params, sjd_state *state
                                  const float *rs, const float *noise2, float *scratch, int max_rows, int V, void *stream)
 {
     return sjd_verify_accept_ex(params, state, probs, prev_probs, rs, noise2, scratch, max_rows, V, nullptr, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ every slot of a continuous batch per launch
+static bool sjd_slots_ok(const sjd_slots *sl)
+{
+    return sl && sl->n_slots >= 1 && sl->n_slots <= 65535 && sl->params_stride >= (int64_t)sizeof(sjd_iter_params) && (sl->params_stride % 8) == 0 &&
+           sl->state_stride >= (int64_t)sizeof(sjd_state) && (sl->state_stride % 8) == 0;
+}
+
+extern "C" int sjd_reguess_slots(const sjd_iter_params *params0, sjd_state *state0, int64_t *input_ids_out, int n_batch, int max_rows,
+                                 const int64_t *pos_offset, int64_t *positions_out, const sjd_slots *slots, void *stream)
+{
+    if (!params0 || !state0 || !input_ids_out || max_rows < 1 || max_rows > SJD_MAX_WINDOW || n_batch < 1 || !sjd_slots_ok(slots)) return SJD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k5_reguess<true>, dim3(slots->n_slots), dim3(64), 0, (hipStream_t)stream, params0, state0, input_ids_out, n_batch, max_rows,
+                       pos_offset, positions_out, *slots);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_logits_to_probs_sample_part_slots(const sjd_head_partials *head, float guidance, int max_rows, int V, const sjd_iter_params *params0,
+                                                     float *probs_out0, int64_t *tokens_out0, int64_t *amax_out0, const sjd_slots *slots, void *stream)
+{
+    if (!head || !head->part || head->n_chunks < 1 || head->n_cols < 1 || head->col0 < 0 || head->row_stride < head->n_cols) return SJD_ERR_BAD_ARG;
+    if (!params0 || !probs_out0 || !tokens_out0 || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1) return SJD_ERR_BAD_ARG;
+    if (head->row_sumsq && (head->slices < 1 || head->prows < 1)) return SJD_ERR_BAD_ARG;
+    if (!sjd_slots_ok(slots) || slots->head_rows < max_rows || slots->probs_stride < (int64_t)max_rows * V) return SJD_ERR_BAD_ARG;
+    if (head->zero_state && slots->zero_state_stride < 2 * (int64_t)max_rows) return SJD_ERR_BAD_ARG;
+    if ((head->dbg_c || head->dbg_u) && slots->dbg_stride < (int64_t)max_rows * V) return SJD_ERR_BAD_ARG;
+    const int lds_floats = sjd_stage_lds_floats((long)head->n_cols + 8 + 2 * SJD_DRAW_LIST);
+    (void)hipFuncSetAttribute((const void *)k2_logits_to_probs_sample<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
+    hipLaunchKernelGGL((k2_logits_to_probs_sample<true, true>), dim3(max_rows, slots->n_slots), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream,
+                       (const float *)nullptr, (const float *)nullptr, (long)0, guidance, V, params0, (const float *)nullptr, probs_out0, tokens_out0, *head,
+                       amax_out0, lds_floats, *slots);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+extern "C" int sjd_verify_accept_slots(const sjd_iter_params *params0, sjd_state *state0, const float *probs0, const float *prev_probs0, float *scratch0,
+                                       int max_rows, int V, sjd_state *host_mirror0, const sjd_slots *slots, void *stream)
+{
+    if (!params0 || !state0 || !probs0 || !prev_probs0 || !scratch0 || max_rows < 1 || max_rows > SJD_MAX_WINDOW || V < 1) return SJD_ERR_BAD_ARG;
+    if (!sjd_slots_ok(slots) || slots->probs_stride < (int64_t)max_rows * V || slots->scratch_stride < V) return SJD_ERR_BAD_ARG;
+    if (host_mirror0 && slots->mirror_stride < (int64_t)sizeof(sjd_state) + 8) return SJD_ERR_BAD_ARG;
+    const int lds_floats = sjd_stage_lds_floats((long)V + 2 * SJD_DRAW_LIST);
+    (void)hipFuncSetAttribute((const void *)k4_verify_accept<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
+    hipLaunchKernelGGL(k4_verify_accept<true>, dim3(1, slots->n_slots), dim3(SJD_TPB), (size_t)lds_floats * 4, (hipStream_t)stream, params0, state0, probs0,
+                       prev_probs0, (const float *)nullptr, (const float *)nullptr, scratch0, V, host_mirror0, lds_floats, *slots);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }
 
 // ------------------------------------------------------------------------------------------------ noise, as a tensor (tests)

@@ -20,6 +20,7 @@ A slot that reaches its end token keeps riding along with a one-row dummy window
 import time
 from typing import List
 
+import os
 import torch
 
 from . import _lib as L
@@ -69,14 +70,21 @@ class SJDBatchEngine:
         self.state = ops.BlobArray(L.State, self.P, dev)
         self.params.view = self.params.blobs[0].view          # what HipWindowAttention's profiling hook looks at
         self.slots = []
+        # every slot's buffers at one stride: K5 / K2 / K4 of ALL slots are one launch each (round 6, sjd_slots in include/sjd_hip.h)
+        self.probs_all = torch.zeros(self.P, 2, self.Lmax, self.V, dtype=torch.float32, device=dev)
+        self.zero_state_all = torch.full((self.P, 2, self.Lmax, 2), -1, dtype=torch.int32, device=dev)
+        self.scratch_all = torch.empty(self.P, self.V, dtype=torch.float32, device=dev)
+        self.state.mirror_array()
+        self.slot_launches = os.environ.get("SJD_SLOT_LAUNCHES", "1") != "0"       # 0: one K5 / K2 / K4 launch per slot (rounds 3-5; A/B aid)
+        self._slots_desc = ops.slots_of(self.params, self.state, self.probs_all, self.zero_state_all, self.scratch_all, n_batch)
         for i in range(self.P):
             s = _Slot()
             s.params, s.state = self.params.blobs[i], self.state.blobs[i]
             s.params.view.batch_rows = n_batch
-            s.probs = torch.zeros(2, self.Lmax, self.V, dtype=torch.float32, device=dev)
-            s.zero_state = torch.full((2, self.Lmax, 2), -1, dtype=torch.int32, device=dev)        # see SJDEngine.zero_state
+            s.probs = self.probs_all[i]
+            s.zero_state = self.zero_state_all[i]        # see SJDEngine.zero_state
             s.noise = s.rs = s.noise2 = None        # only for observers (the parity tests' hook): K2 / K4 generate their noise
-            s.scratch = torch.empty(self.V, dtype=torch.float32, device=dev)
+            s.scratch = self.scratch_all[i]
             s.tokens_ptr = s.state.field_ptr("tokens")
             s.amax_ptr = s.state.field_ptr("amax")
             self.slots.append(s)
@@ -182,7 +190,10 @@ class SJDBatchEngine:
         def k5(i, s):
             lo, hi = i * self.nb, (i + 1) * self.nb
             ops.reguess(s.params, s.state, self.input_ids[lo:hi], pos_offset=self.pos_offset[lo:hi], positions_out=self.positions[lo:hi])
-        self._per_slot(k5)
+        if self.slot_launches:
+            ops.reguess_slots(self._slots_desc, self.params, self.state, self.input_ids, self.pos_offset, self.positions, self.nb)
+        else:
+            self._per_slot(k5)
         positions = self.positions
         if self.head_partials:
             return self.backbone.forward_window(self.input_ids, positions, -1, self.key_start, cols=cols, head_partials=True)
@@ -213,6 +224,16 @@ class SJDBatchEngine:
                                            amax_out_ptr=amax_out)
                 s.zero_state[cur].fill_(-1)
             ops.verify_accept(s.params, s.state, s.probs[cur], s.probs[1 - cur], None, None, s.scratch, mirror=True)
+        if self.slot_launches and part and ops.head_slots_ok(logits):
+            # one K2 and one K4 launch for all slots (a workgroup per (row, slot) / per slot): eight prompts 8 x (28 + 24) us -> one of each
+            greedy = getattr(self, "_greedy", False)
+            sl = self._slots_desc
+            if dbg is not None:
+                sl = ops.slots_of(self.params, self.state, self.probs_all, self.zero_state_all, self.scratch_all, self.nb, dbg=dbg)
+            ops.logits_to_probs_sample_part_slots(sl, logits, self._guidance, self.params, self.probs_all, cur, "amax" if greedy else "tokens",
+                                                  "tokens" if greedy else "amax", self.state, self.zero_state_all, self.nb, dbg=dbg)
+            ops.verify_accept_slots(sl, self.params, self.state, self.probs_all, cur, self.scratch_all)
+            return
         self._per_slot(k2_k4)
 
     def _launch_forward(self, cols):

@@ -138,6 +138,18 @@ class BlobArray:
         self.dev = torch.zeros(n * nb, dtype=torch.uint8, device=device)
         self.blobs = [DeviceBlob(ctype, device, self.host[i * nb:(i + 1) * nb], self.dev[i * nb:(i + 1) * nb]) for i in range(n)]
 
+        self.nbytes, self._mirrors = nb, None
+
+    def mirror_array(self):
+        """the blobs' pinned host mirrors as ONE allocation at a fixed stride (nbytes + 8: blob, then its sequence word) -> (pointer of blob 0's
+        mirror, stride in bytes): what sjd_verify_accept_slots writes for every slot of a continuous batch"""
+        if self._mirrors is None:
+            st = self.nbytes + 8
+            self._mirrors = torch.zeros(len(self.blobs) * st, dtype=torch.uint8, pin_memory=True)
+            for i, b in enumerate(self.blobs):
+                b._mirror = self._mirrors[i * st:(i + 1) * st]
+        return ctypes.c_void_p(self._mirrors.data_ptr()), self.nbytes + 8
+
     def upload(self):
         L.check(L.load().sjd_upload_async(self.dev.data_ptr(), self.host.data_ptr(), self.host.numel(), _stream()), "sjd_upload_async")
 
@@ -668,6 +680,26 @@ def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noi
     receives the logits K2 derived (cond, uncond) -- observers only.  row0 / urow_off: this launch's cond rows start at partial row
     `row0` and its uncond rows `urow_off` rows further (several prompts share one head launch: SJDBatchEngine)."""
     max_rows, V = probs_out.shape
+    hp = _head_partials(head, max_rows, V, probs_out.device, dbg, row0, urow_off, zero_state)
+    p = head.part
+    assert noise is None or (noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V)
+    assert probs_out.is_contiguous()
+    if head_combine_ok(hp):
+        # K2a (round 4): a WIDE head window (Emu3: 32768 columns x 2 planes x 2 rows = 524 KB per row) is combined into guided scores on the whole
+        # chip first; K2 then reads ONE plane per row -- bit-identical scores (sjd_head_combine in include/sjd_hip.h)
+        z = torch.empty(max_rows, p.N, dtype=torch.float32, device=probs_out.device)
+        L.check(L.load().sjd_head_combine(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(z), _stream()), "sjd_head_combine")
+        h2 = L.HeadPartials()
+        h2.part, h2.n_chunks, h2.row_stride, h2.chunk_stride = z.data_ptr(), 1, p.N, max_rows * p.N
+        h2.col0, h2.n_cols, h2.urow_off, h2.round_dtype = hp.col0, hp.n_cols, 0, 2            # SJD_DTYPE_F32: no rounding, no scale, no uncond row
+        h2.zero_state = hp.zero_state
+        hp = h2
+    L.check(L.load().sjd_logits_to_probs_sample_part(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out),
+                                                    tokens_out_ptr, amax_out_ptr, _stream()), "sjd_logits_to_probs_sample_part")
+
+
+def _head_partials(head, max_rows, V, device, dbg=None, row0=0, urow_off=None, zero_state=None):
+    """-> _lib.HeadPartials over `head` (a HeadOut) for a K2 launch whose cond rows start at partial row `row0`"""
     p = head.part
     hp = L.HeadPartials()
     hp.part, hp.n_chunks = p.data.data_ptr() + 4 * int(row0) * p.N, p.n_chunks
@@ -683,22 +715,68 @@ def logits_to_probs_sample_part(head: HeadOut, guidance, params: DeviceBlob, noi
         if dbg.shape[0] >= 2:              # (one plane: a batch without CFG -- there is no uncond row to observe)
             hp.dbg_u = dbg[1].data_ptr()
     if zero_state is not None:         # int32 [max_rows, 2] that belongs to THIS probs_out buffer (see sjd_head_partials::zero_state)
-        assert zero_state.dtype == torch.int32 and zero_state.is_contiguous() and zero_state.shape == (max_rows, 2) and zero_state.device == probs_out.device
+        assert zero_state.dtype == torch.int32 and zero_state.is_contiguous() and zero_state.shape == (max_rows, 2) and zero_state.device == device
         hp.zero_state = zero_state.data_ptr()
-    assert noise is None or (noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[-1] == V)
-    assert probs_out.is_contiguous()
-    if head_combine_ok(hp):
-        # K2a (round 4): a WIDE head window (Emu3: 32768 columns x 2 planes x 2 rows = 524 KB per row) is combined into guided scores on the whole
-        # chip first; K2 then reads ONE plane per row -- bit-identical scores (sjd_head_combine in include/sjd_hip.h)
-        z = torch.empty(max_rows, p.N, dtype=torch.float32, device=probs_out.device)
-        L.check(L.load().sjd_head_combine(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(z), _stream()), "sjd_head_combine")
-        h2 = L.HeadPartials()
-        h2.part, h2.n_chunks, h2.row_stride, h2.chunk_stride = z.data_ptr(), 1, p.N, max_rows * p.N
-        h2.col0, h2.n_cols, h2.urow_off, h2.round_dtype = hp.col0, hp.n_cols, 0, 2            # SJD_DTYPE_F32: no rounding, no scale, no uncond row
-        h2.zero_state = hp.zero_state
-        hp = h2
-    L.check(L.load().sjd_logits_to_probs_sample_part(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(noise), _ptr(probs_out),
-                                                    tokens_out_ptr, amax_out_ptr, _stream()), "sjd_logits_to_probs_sample_part")
+    return hp
+
+
+def slots_of(params: "BlobArray", state: "BlobArray", probs, zero_state, scratch, n_batch, dbg=None):
+    """-> _lib.Slots for the *_slots launches of a continuous batch: params / state BlobArrays (one blob per slot), probs [P, 2, L, V] fp32,
+    zero_state [P, 2, L, 2] int32, scratch [P, >= V] fp32, dbg None or [P * n_batch, L, V] fp32 -- all contiguous (the strides below)."""
+    P, two, Lw, V = probs.shape
+    assert two == 2 and probs.is_contiguous() and probs.dtype == torch.float32 and len(params.blobs) == P and len(state.blobs) == P
+    assert zero_state.is_contiguous() and zero_state.dtype == torch.int32 and tuple(zero_state.shape) == (P, 2, Lw, 2)
+    assert scratch.is_contiguous() and scratch.dtype == torch.float32 and scratch.shape[0] == P and scratch.shape[1] >= V
+    sl = L.Slots()
+    sl.n_slots, sl.head_rows = P, n_batch * Lw
+    sl.params_stride, sl.state_stride = params.nbytes, state.nbytes
+    sl.probs_stride, sl.zero_state_stride, sl.scratch_stride = 2 * Lw * V, 2 * Lw * 2, scratch.shape[1]
+    _, sl.mirror_stride = state.mirror_array()
+    if dbg is not None:
+        assert dbg.is_contiguous() and dbg.dtype == torch.float32 and tuple(dbg.shape) == (P * n_batch, Lw, V)
+        sl.dbg_stride = n_batch * Lw * V
+    return sl
+
+
+def reguess_slots(slots, params: "BlobArray", state: "BlobArray", input_ids_out, pos_offset, positions_out, n_batch):
+    """K5 of every slot in one launch: input_ids_out / positions_out [P * n_batch, L] int64, pos_offset [P * n_batch] int64"""
+    B, max_rows = input_ids_out.shape
+    assert B == slots.n_slots * n_batch and input_ids_out.dtype == torch.int64 and input_ids_out.is_contiguous()
+    assert positions_out.dtype == torch.int64 and positions_out.is_contiguous() and tuple(positions_out.shape) == (B, max_rows)
+    assert pos_offset.dtype == torch.int64 and pos_offset.is_contiguous() and pos_offset.numel() == B
+    L.check(L.load().sjd_reguess_slots(params.ptr, state.ptr, _ptr(input_ids_out), n_batch, max_rows, _ptr(pos_offset), _ptr(positions_out),
+                                      ctypes.byref(slots), _stream()), "sjd_reguess_slots")
+
+
+def head_slots_ok(head: "HeadOut"):
+    """the *_slots K2 launch reads the head's planes itself: a head wide enough for K2a (Emu3) keeps the per-slot launches"""
+    p = head.part
+    return not (p.N >= _HEAD_COMBINE_MIN_COLS and p.N % 4 == 0 and p.data.data_ptr() % 16 == 0)
+
+
+def logits_to_probs_sample_part_slots(slots, head: "HeadOut", guidance, params: "BlobArray", probs, cur, tokens_field, amax_field, state: "BlobArray",
+                                      zero_state, n_batch, dbg=None):
+    """K2 of every slot in one launch (see logits_to_probs_sample_part): slot s reads the cond rows [s * n_batch * L, ...) of the shared head launch
+    and its uncond rows L further (n_batch 2), writes probs[s, cur] and the int64 rows `tokens_field` / `amax_field` (names of sjd_state fields,
+    amax_field may be None) of its state."""
+    P, _, max_rows, V = probs.shape
+    hp = _head_partials(head, max_rows, V, probs.device, None, 0, max_rows if n_batch > 1 else 0, zero_state[0, cur])
+    if dbg is not None:
+        hp.dbg_c = dbg[0].data_ptr()
+        if n_batch > 1:
+            hp.dbg_u = dbg[1].data_ptr()
+    s0 = state.blobs[0]
+    L.check(L.load().sjd_logits_to_probs_sample_part_slots(ctypes.byref(hp), float(guidance), max_rows, V, params.ptr, _ptr(probs[0, cur]),
+                                                          s0.field_ptr(tokens_field), s0.field_ptr(amax_field) if amax_field else None,
+                                                          ctypes.byref(slots), _stream()), "sjd_logits_to_probs_sample_part_slots")
+
+
+def verify_accept_slots(slots, params: "BlobArray", state: "BlobArray", probs, cur, scratch):
+    """K4 of every slot in one launch; every state is also written into its pinned host mirror (BlobArray.mirror_array / wait_mirror)"""
+    P, _, max_rows, V = probs.shape
+    mptr, _ = state.mirror_array()
+    L.check(L.load().sjd_verify_accept_slots(params.ptr, state.ptr, _ptr(probs[0, cur]), _ptr(probs[0, 1 - cur]), _ptr(scratch), max_rows, V, mptr,
+                                            ctypes.byref(slots), _stream()), "sjd_verify_accept_slots")
 
 
 _HEAD_COMBINE_MIN_COLS = int(os.environ.get("SJD_HEAD_COMBINE_MIN_COLS", "16384"))     # (a huge value switches K2a off: A/B aid)

@@ -200,6 +200,32 @@ int sjd_head_combine(const sjd_head_partials *head /* host struct, passed by val
 int sjd_verify_accept(const sjd_iter_params *params, sjd_state *state, const float *probs, const float *prev_probs,
                       const float *rs, const float *noise2, float *scratch, int max_rows, int V, void *stream);
 
+/* Round 6 -- K5 / K2 / K4 of EVERY slot of a continuous batch in ONE launch each (SJDBatchEngine: eight prompts paid 8 x (5 + 28 + 24 us) of
+ * launches per iteration, a workgroup each).  The per-slot control blobs and buffers are laid out at fixed strides; slot s of the launch works on
+ * <pointer of slot 0> + s * <stride> and is otherwise exactly the one-slot kernel (same code after the pointer shift: bit-identical results).
+ * Noise is generated in the kernels (every slot's params->philox_blocks must be > 0). */
+typedef struct sjd_slots {
+    int32_t n_slots;
+    int32_t head_rows;              /* K2: rows of `head->part` / `head->row_sumsq` between consecutive slots' cond row 0 (n_batch * max_rows) */
+    int64_t params_stride;          /* bytes between consecutive slots' sjd_iter_params */
+    int64_t state_stride;           /* bytes between consecutive slots' sjd_state (tokens_out / amax_out point INTO the state: same stride) */
+    int64_t probs_stride;           /* floats between consecutive slots' probs_out / probs / prev_probs */
+    int64_t zero_state_stride;      /* int32 elements between consecutive slots' head->zero_state */
+    int64_t scratch_stride;         /* floats between consecutive slots' K4 scratch rows */
+    int64_t mirror_stride;          /* bytes between consecutive slots' pinned host mirrors (K4) */
+    int64_t dbg_stride;             /* floats between consecutive slots' head->dbg_c / dbg_u (observers) */
+} sjd_slots;
+/* sjd_reguess_ex per slot: input_ids_out / positions_out are [n_slots * n_batch, max_rows], pos_offset [n_slots * n_batch] */
+int sjd_reguess_slots(const sjd_iter_params *params0, sjd_state *state0, int64_t *input_ids_out, int n_batch, int max_rows,
+                      const int64_t *pos_offset, int64_t *positions_out, const sjd_slots *slots, void *stream);
+/* sjd_logits_to_probs_sample_part per slot: `head` describes slot 0's rows of the one head launch all slots share */
+int sjd_logits_to_probs_sample_part_slots(const sjd_head_partials *head, float guidance, int max_rows, int V, const sjd_iter_params *params0,
+                                          float *probs_out0, int64_t *tokens_out0, int64_t *amax_out0 /* may be NULL */, const sjd_slots *slots,
+                                          void *stream);
+/* sjd_verify_accept_ex per slot (rs / noise2 generated in the kernel) */
+int sjd_verify_accept_slots(const sjd_iter_params *params0, sjd_state *state0, const float *probs0, const float *prev_probs0, float *scratch0,
+                            int max_rows, int V, sjd_state *host_mirror0 /* may be NULL */, const sjd_slots *slots, void *stream);
+
 /* K3 -- KV append into the static cache (rollback is implicit: rejected rows are simply overwritten).
  * replaces DynamicCache.update's torch.cat + delete_false_key_value (reference modeling_chameleon.py:547;
  * jacobi_iteration_lumina_mgpt.py:47-54, 401-409) and KVCache.update (llamagen/llamagen.py:210-219).

@@ -122,6 +122,15 @@ def test_greedy_batch_decode_takes_the_oracles_decisions(n_prompts, use_graph, n
     assert len(rs) == n_prompts and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs)
 
 
+@pytest.mark.parametrize("n_prompts,use_graph,n_slots", [(3, True, None), (2, False, None), (5, True, 2)])
+def test_per_slot_launches_still_decode_like_the_oracle(monkeypatch, n_prompts, use_graph, n_slots):
+    """round 6: K5 / K2 / K4 of all slots are ONE launch each (sjd_*_slots; every other batch test runs them); SJD_SLOT_LAUNCHES=0 keeps the
+    launch-per-slot path of rounds 3-5 -- both take every slot's oracle decisions"""
+    monkeypatch.setenv("SJD_SLOT_LAUNCHES", "0")
+    rs = G.teacher_forced_batch_check(n_prompts=n_prompts, P=(12, 9, 14, 7, 10), use_graph=use_graph, n_slots=n_slots)
+    assert len(rs) == n_prompts and all(r["last"] == 8196 and r["tokens"] == 73 for r in rs)
+
+
 def test_batch_engine_names_what_256_rows_need(dev="cuda:0"):
     """more than 128 window rows on launch shapes / a packing kernel G1w does not serve used to fall back silently or fail mid-decode"""
     import sjd_amd.ops as ops

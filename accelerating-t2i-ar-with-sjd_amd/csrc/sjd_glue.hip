@@ -495,6 +495,138 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     (void)PPL;
 }
 
+// ------------------------------------------------------------------------------------------------ F2 for many rows (round 6)
+// The kernel above is written for the latency of a 32-row window: one wave per (token, head), two dword loads per plane and lane, and every wave
+// computes the sin / cos of ITS token's rotary angles -- 48 (Emu3) or 96 (Lumina) times per token.  At the 256 rows of eight prompts that is
+// 24576 waves of a few hundred bytes each: 17.2 us for 15.6 MB (profiles/r6_8prompts_by_shape.txt), three rounds of waves per CU, each a chain of
+// dependent round trips.  Here a wave takes HPW consecutive heads of one kind (q, k or v) of its token: the planes of all HPW heads are requested
+// together, the angle is computed once.  Element for element the arithmetic of f2_qknorm_rope_append (same sums in chunk order, same roundings),
+// so q and the cache rows are bit-identical; used for windows of more than 64 rows read from split-K partials.
+template <int DT, int D, bool KV8, int HPW>
+__global__ __launch_bounds__(256) void f2_qknorm_rope_append_rows(
+    unsigned short *__restrict__ q_out, unsigned short *__restrict__ k_cache, unsigned short *__restrict__ v_cache,
+    const unsigned short *__restrict__ qn_w, const unsigned short *__restrict__ qn_b, const unsigned short *__restrict__ kn_w,
+    const unsigned short *__restrict__ kn_b, const float *__restrict__ inv_freq, const long *__restrict__ positions, int B, int n, int H, int H_kv,
+    int S_max, const sjd_iter_params *__restrict__ params, int kv_len_arg, const float *__restrict__ part, int n_chunks, int prows, float k_inv,
+    float v_inv, const float *__restrict__ row_sumsq, int rs_slices, float rs_inv_hidden, float rs_eps)
+{
+    constexpr int HALF = D / 2;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int heads = H + 2 * H_kv, groups = heads / HPW;
+    if (gw >= B * n * groups) return;
+    const int tok = gw / groups, hh0 = (gw % groups) * HPW;
+    const int b = tok / n, i = tok % n;
+    const bool is_q = hh0 < H, is_k = !is_q && hh0 < H + H_kv;
+    const int hl0 = is_q ? hh0 : (is_k ? hh0 - H : hh0 - H - H_kv);
+    const float q8 = is_k ? k_inv : v_inv;
+    const bool active = lane < HALF;
+    const size_t ncol = (size_t)heads * D, col = (size_t)hh0 * D + (active ? lane : 0);
+    float ssv[8];
+    const float *ssp = row_sumsq ? row_sumsq : part;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ssv[q] = ssp[(size_t)(row_sumsq ? min(q, rs_slices - 1) : 0) * prows + tok];
+    float x0[HPW], x1[HPW];
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) { x0[j] = 0.f; x1[j] = 0.f; }
+    for (int c0 = 0; c0 < n_chunks; c0 += 4) {                // four planes x HPW heads in flight, then the sums in chunk order
+        float v0[4][HPW], v1[4][HPW];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float *pp = part + ((size_t)min(c0 + q, n_chunks - 1) * prows + tok) * ncol + col;
+#pragma unroll
+            for (int j = 0; j < HPW; ++j) { v0[q][j] = pp[j * D]; v1[q][j] = pp[j * D + HALF]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c0 + q < n_chunks) {
+#pragma unroll
+                for (int j = 0; j < HPW; ++j) { x0[j] += v0[q][j]; x1[j] += v1[q][j]; }
+            }
+    }
+    int kv_len = kv_len_arg, n_unused_ = 0;
+    if (params) sjdi_kv_rows(params, b, &kv_len, &n_unused_);
+    float ss_tot = 0.f;                                       // row_sumsq_total's order
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ss_tot += (q < rs_slices) ? ssv[q] : 0.f;
+    for (int s0 = 8; s0 < rs_slices; s0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (s0 + q < rs_slices) ? row_sumsq[(size_t)(s0 + q) * prows + tok] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ss_tot += v[q];
+    }
+    const float r = row_sumsq ? rsqrtf(ss_tot * rs_inv_hidden + rs_eps) : 1.0f;
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+        if (row_sumsq) { x0[j] *= r; x1[j] *= r; }
+        x0[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(x0[j]));
+        x1[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(x1[j]));
+        if (!active) { x0[j] = 0.f; x1[j] = 0.f; }
+    }
+    const int rrow = kv_len + i;
+    if (!is_q && rrow >= S_max) return;
+    if (!is_q && !is_k) {                                     // V: plain copy into the cache
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < HPW; ++j) {
+                const size_t off = (((size_t)b * H_kv + hl0 + j) * S_max + rrow) * D;
+                if (KV8) {
+                    unsigned char *d8 = reinterpret_cast<unsigned char *>(v_cache) + off;
+                    d8[lane] = f2_to_fp8(x0[j] * q8); d8[lane + HALF] = f2_to_fp8(x1[j] * q8);
+                } else { v_cache[off + lane] = Cvt<DT>::from_f(x0[j]); v_cache[off + lane + HALF] = Cvt<DT>::from_f(x1[j]); }
+            }
+        }
+        return;
+    }
+    const unsigned short *gw_ = is_q ? qn_w : kn_w, *gb_ = is_q ? qn_b : kn_b;
+    if (gw_ != nullptr) {                                     // per-head LayerNorm over head_dim (eps 1e-5)
+        const int la = active ? lane : 0;
+        const float w0 = Cvt<DT>::to_f(gw_[la]), w1 = Cvt<DT>::to_f(gw_[la + HALF]), b0 = Cvt<DT>::to_f(gb_[la]), b1 = Cvt<DT>::to_f(gb_[la + HALF]);
+#pragma unroll
+        for (int j = 0; j < HPW; ++j) {
+            const float mean = wave_sum(active ? x0[j] + x1[j] : 0.f) / (float)D;
+            const float d0 = x0[j] - mean, d1 = x1[j] - mean;
+            const float var = wave_sum(active ? d0 * d0 + d1 * d1 : 0.f) / (float)D;
+            const float inv = rsqrtf(var + 1e-5f);
+            if (active) {
+                const float n0 = Cvt<DT>::to_f(Cvt<DT>::from_f(d0 * inv)), n1 = Cvt<DT>::to_f(Cvt<DT>::from_f(d1 * inv));
+                float y0 = Cvt<DT>::to_f(Cvt<DT>::from_f(n0 * w0)) + b0;
+                float y1 = Cvt<DT>::to_f(Cvt<DT>::from_f(n1 * w1)) + b1;
+                x0[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(y0));
+                x1[j] = Cvt<DT>::to_f(Cvt<DT>::from_f(y1));
+            }
+        }
+    }
+    if (active) {
+        const float ang = (float)positions[tok] * inv_freq[lane];
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        cs = Cvt<DT>::to_f(Cvt<DT>::from_f(cs));
+        sn = Cvt<DT>::to_f(Cvt<DT>::from_f(sn));
+#pragma unroll
+        for (int j = 0; j < HPW; ++j) {
+            const float a0 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0[j] * cs)), c0_ = Cvt<DT>::to_f(Cvt<DT>::from_f(-x1[j] * sn));
+            const float a1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x1[j] * cs)), c1_ = Cvt<DT>::to_f(Cvt<DT>::from_f(x0[j] * sn));
+            if (is_q) {
+                unsigned short *dst = q_out + ((size_t)tok * H + hl0 + j) * D;
+                dst[lane] = Cvt<DT>::from_f(a0 + c0_);
+                dst[lane + HALF] = Cvt<DT>::from_f(a1 + c1_);
+            } else {
+                const size_t off = (((size_t)b * H_kv + hl0 + j) * S_max + rrow) * D;
+                if (KV8) {
+                    unsigned char *d8 = reinterpret_cast<unsigned char *>(k_cache) + off;
+                    d8[lane] = f2_to_fp8(Cvt<DT>::to_f(Cvt<DT>::from_f(a0 + c0_)) * q8);
+                    d8[lane + HALF] = f2_to_fp8(Cvt<DT>::to_f(Cvt<DT>::from_f(a1 + c1_)) * q8);
+                } else {
+                    k_cache[off + lane] = Cvt<DT>::from_f(a0 + c0_);
+                    k_cache[off + lane + HALF] = Cvt<DT>::from_f(a1 + c1_);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ F3
 template <int DT>
 __global__ __launch_bounds__(256) void f3_silu_mul(const unsigned short *__restrict__ gu, unsigned short *__restrict__ y, int M, int I,
@@ -589,6 +721,21 @@ static int f2_launch(const void *qkv, void *q_out, void *k_cache, void *v_cache,
     const int waves = B * n * (H + 2 * H_kv);
     const dim3 grid((waves + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
+    // more than 64 rows of split-K partials: HPW heads per wave (f2_qknorm_rope_append_rows); SJD_F2_ROWS=0 keeps the one-head kernel (A/B aid)
+    const char *f2r_env = getenv("SJD_F2_ROWS");              // (read per launch: the parity test flips it inside one process)
+    const bool rows_ok = !(f2r_env && f2r_env[0] == '0');
+    if (rows_ok && part && B * n > 64 && (H % 4) == 0 && (H_kv % 4) == 0 && D == 128 && dtype == SJD_DTYPE_BF16) {
+        const dim3 g2((B * n * ((H + 2 * H_kv) / 4) + 3) / 4);
+#define SJD_F2R(KV8_)                                                                                                                      \
+        hipLaunchKernelGGL((f2_qknorm_rope_append_rows<SJD_DTYPE_BF16, 128, KV8_, 4>), g2, block, 0, s, (unsigned short *)q_out,           \
+                           (unsigned short *)k_cache, (unsigned short *)v_cache, (const unsigned short *)qn_w, (const unsigned short *)qn_b, \
+                           (const unsigned short *)kn_w, (const unsigned short *)kn_b, inv_freq, (const long *)positions, B, n, H, H_kv,    \
+                           S_max, params, kv_len, part, n_chunks, prows, kv8 ? 1.0f / k_scale : 1.0f, kv8 ? 1.0f / v_scale : 1.0f,          \
+                           rn ? rn->sumsq : nullptr, rn ? rn->slices : 0, rn ? 1.0f / (float)rn->hidden : 0.f, rn ? rn->eps : 0.f)
+        if (kv8) SJD_F2R(true); else SJD_F2R(false);
+#undef SJD_F2R
+        return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+    }
 #define SJD_F2_CASE(DT_, D_, KV8_)                                                                                                         \
     if (dtype == DT_ && D == D_ && kv8 == KV8_) {                                                                                          \
         hipLaunchKernelGGL((f2_qknorm_rope_append<DT_, D_, KV8_>), grid, block, 0, s, (const unsigned short *)qkv, (unsigned short *)q_out, \

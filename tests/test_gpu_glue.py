@@ -237,6 +237,42 @@ def test_partials_feed_glue_kernels(dev):
     assert (vc1.float() - vc2.float()).abs().max() < 0.07
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("B,n,H,Hkv,n_chunks,qk_norm,folded", [(16, 16, 32, 32, 2, True, True), (8, 16, 32, 8, 4, False, True), (6, 16, 8, 4, 5, True, False),
+                                                         (5, 16, 8, 8, 9, True, True), (16, 13, 4, 4, 1, False, False)])
+def test_f2_many_row_kernel_is_the_one_head_kernel_bit_for_bit(dev, monkeypatch, fp8, B, n, H, Hkv, n_chunks, qk_norm, folded):
+    """round 6: windows of more than 64 rows run F2 with four heads of a token per wave (f2_qknorm_rope_append_rows: the planes of four heads in
+    flight together, the rotary angle computed once instead of once per head) -- q and the cache rows must be those of the one-head kernel
+    (SJD_F2_ROWS=0), bit for bit: 256 rows of Lumina's 96 heads, Emu3's GQA shape, ragged chunk counts, with and without the folded RMSNorm"""
+    import sjd_amd.ops as ops
+    D, S, kv_len, T = 128, 64, 21, B * n
+    g = torch.Generator().manual_seed(B * 100 + n_chunks)
+    ncol = (H + 2 * Hkv) * D
+    planes = torch.zeros(n_chunks, ops._prows(T), ncol)
+    planes[:, :T] = torch.randn(n_chunks, T, ncol, generator=g)
+    part = ops.Partials(planes.to(dev), n_chunks, ncol)
+    w = lambda: (1 + 0.2 * torch.randn(1, D, generator=g)).to(torch.bfloat16).to(dev)
+    args = (w(), w(), w(), w()) if qk_norm else (None,) * 4
+    inv = (1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))).to(dev)
+    pos = (torch.randint(0, 3000, (B, 1), generator=g) + torch.arange(n)[None]).reshape(-1).contiguous().to(dev)
+    rn = None
+    if folded:
+        rn = (torch.rand(3, ops._prows(T), generator=g).add(0.5).mul(1000.0).to(dev), 4096, 1e-5)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SJD_F2_ROWS", flag)
+        if fp8:
+            kc, vc = torch.zeros(B, Hkv, S, D, dtype=torch.uint8, device=dev).view(ops.FP8), torch.zeros(B, Hkv, S, D, dtype=torch.uint8, device=dev).view(ops.FP8)
+        else:
+            kc, vc = torch.zeros(B, Hkv, S, D, dtype=torch.bfloat16, device=dev), torch.zeros(B, Hkv, S, D, dtype=torch.bfloat16, device=dev)
+        q = ops.qknorm_rope_append(part, kc, vc, *args, inv, pos, B, n, H, Hkv, D, None, kv_len, kv_scale=(0.05, 0.03), dtype=torch.bfloat16, row_norm=rn)
+        torch.cuda.synchronize()
+        outs.append((q, kc.view(torch.uint8) if fp8 else kc, vc.view(torch.uint8) if fp8 else vc))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
+    assert outs[0][0].float().abs().sum() > 0 and outs[0][1][:, :, kv_len:kv_len + n].float().abs().sum() > 0
+
+
 def test_g1_forward_matches_library_gemm_forward(dev):
     import sjd_amd.ops as ops
     from tests.helpers import make_chameleon

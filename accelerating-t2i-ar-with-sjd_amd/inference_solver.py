@@ -21,6 +21,20 @@ class _EosCriteria:
         self.eos_token_id = list(eos_token_id)
 
 
+class AutoregressiveGuidance:
+    """Stands where the reference puts LLMImageStartTriggeredUnbatchedClassifierFreeGuidanceLogitsProcessor (IS:16-132; same constructor names):
+    it carries the guidance scale and the image token ids.  The reference's processor runs a second, unconditional forward per token on the
+    context from the image-start token on and returns scale * (scores - uncond) + uncond (IS:124-127); here that forward is the uncond row of the
+    one window forward and the combine is kernel K2's (u + scale * (c - u): the same fp32 operations)."""
+
+    def __init__(self, guidance_scale, image_start_token_id, image_end_token_id, image_next_line_token_id, patch_size=32, model=None, **_):
+        self.guidance_scale, self.patch_size = guidance_scale, patch_size
+        self.image_start_token_id, self.image_end_token_id, self.image_next_line_token_id = image_start_token_id, image_end_token_id, image_next_line_token_id
+
+    def __call__(self, input_ids, scores):
+        raise RuntimeError("AutoregressiveGuidance is applied inside the window forward + kernel K2 (FlexARInferenceSolver.generate_ids), not called")
+
+
 class FlexARInferenceSolver:
     """reference IS:273-450.  `model_path` may be a directory with `config.json` + `*.safetensors` / `pytorch_model.bin`
     holding reference (HF Chameleon) weights, or `model=` may pass a ready `sjd_amd.backbones.ChameleonBackbone`."""
@@ -83,9 +97,64 @@ class FlexARInferenceSolver:
         return model
 
     def create_logits_processor(self, cfg=3.0, image_top_k=2000, text_top_k=10):
-        """The non-SJD processors of IS:402-450 are replaced by the SJD ones when renew_pipeline_sampler is applied (JL:432-468);
-        without it there is no hand-written path, so this raises instead of silently decoding differently."""
-        raise RuntimeError("apply scheduler.jacobi_iteration_lumina_mgpt.renew_pipeline_sampler(solver, ...) first")
+        """reference IS:417-450 -- the processors of the AUTOREGRESSIVE baseline (no renew_pipeline_sampler applied): the image-start-triggered
+        classifier-free guidance (IS:16-132), the image grammar (IS:134-224) and the interleaved top-k (IS:226-270).  One token per forward is a
+        draft window of ONE row, so the grammar and the top-k are the 3-dim processors of the SJD path at window 1 (same decisions per row:
+        tests/test_oracle_golden.py::test_loop_lumina_autoregressive_baseline pins the whole AR loop on reference runs); the guidance processor
+        is a marker that carries the scale and the ids -- its second forward is the uncond row of the window forward (AutoregressiveGuidance)."""
+        from transformers.generation.logits_process import LogitsProcessorList
+        from .scheduler.logit_processor_3dim import MultiTokensVLLogitsProcessor, MultiTokensInterleavedTopKLogitsWarper
+        ip = self.item_processor
+        tok = (lambda name, default: ip.token2id(getattr(ip, name))) if ip is not None else (lambda name, default: default)
+        start, end, eol = tok("image_start_token", 8197), tok("image_end_token", 8196), tok("new_line_token", 8803)
+        V = self.model.config.vocab_size if hasattr(self.model, "config") else self.model.vocab_size
+        lp = LogitsProcessorList()
+        lp.append(AutoregressiveGuidance(guidance_scale=cfg, image_start_token_id=start, image_end_token_id=end, image_next_line_token_id=eol, patch_size=32))
+        lp.append(MultiTokensVLLogitsProcessor(image_start_token_id=start, image_end_token_id=end, image_next_line_token_id=eol, patch_size=32, voc_size=V,
+                                               device=self.device))
+        lp.append(MultiTokensInterleavedTopKLogitsWarper(image_top_k=image_top_k, text_top_k=text_top_k, image_start_token_id=start, image_end_token_id=end))
+        return lp
+
+    @torch.no_grad()
+    def _generate_autoregressive(self, prompt, logits_processor, generation_config, streamer):
+        """The reference's AR decode (HF _sample around IS:417-450's processors) on the SJD kernels: window 1 -- K5, one window forward over
+        the cond / uncond rows, K2's draw, K4's single-row short-circuit (JL:344-350) per token -- with the uncond row's context starting at the
+        image-start token (IS:62-63; the SJD sampler keeps the last prompt token only, JL:755-758).  Noise comes from the device's default
+        generator, as HF's torch.multinomial takes it (torch.manual_seed(s) before the call makes a run repeatable).  The published AR-vs-SJD
+        ratio is this path's step count and time against the renewed solver's on the same prompt (bench.py: `ar_baseline`)."""
+        from .scheduler.jacobi_iteration_lumina_mgpt import renew_sampler, hf_generate
+        procs = list(logits_processor)
+        guide = [p for p in procs if isinstance(p, AutoregressiveGuidance)]
+        scale = float(guide[0].guidance_scale) if guide else 1.0
+        start = guide[0].image_start_token_id if guide else None
+        ids = prompt[0].tolist()
+        mask = torch.ones(1, len(ids), dtype=torch.long, device=prompt.device)
+        if guide and scale != 1.0:
+            if start not in ids:
+                raise NotImplementedError("the AR baseline entry point decodes a prompt that ends inside an image (<image-start> h w): text-first "
+                                          "prompts reach the guidance's context only once the model has emitted the image-start token")
+            u0 = len(ids) - 1 - ids[::-1].index(start)                 # IS:108: the LAST image-start token
+            mask = mask.repeat(2, 1)
+            mask[1, :u0] = 0                                           # the uncond row sees the prompt from <image-start> on (IS:62-63)
+        model, cls = self.model, self.model.__class__
+        keep = {k: model.__dict__.get(k) for k in ("_sjd_engines",)}
+        try:
+            model.__class__ = renew_sampler(cls)
+            model._init_new_params(jacobi_loop_interval_l=1, jacobi_loop_interval_r=1 << 20, max_num_new_tokens=1, guidance_scale=scale, seed=None,
+                                   do_cfg=True, prefix_token_sampler_scheme="speculative_jacobi")
+            if getattr(self, "_ar_engines", None):
+                model._sjd_engines = self._ar_engines                  # (the window-1 engine and its captured graphs survive between calls)
+            out = hf_generate(model, prompt, generation_config, logits_processor=[p for p in procs if not isinstance(p, AutoregressiveGuidance)],
+                              streamer=streamer, attention_mask=mask)
+            self._ar_engines, self.last_ar_stats = model._sjd_engines, model.last_sjd_stats
+        finally:
+            model.__class__ = cls
+            for k, v in keep.items():
+                if v is None:
+                    model.__dict__.pop(k, None)
+                else:
+                    model.__dict__[k] = v
+        return out
 
     @torch.no_grad()
     def generate_ids(self, prompt_ids: List[int], max_gen_len: int, logits_processor=None, streamer=None, temperature=1.0):
@@ -97,8 +166,12 @@ class FlexARInferenceSolver:
         max_length = len(prompt_ids) + max_gen_len
         gc = GenerationConfig(max_new_tokens=max_gen_len, max_length=max_length, temperature=temperature, top_k=None, do_sample=True,
                               eos_token_id=[8710])
-        if not hasattr(self.model, "_sample"):
-            raise RuntimeError("model has no _sample hook: apply renew_pipeline_sampler / renew_sampler first")
+        if not hasattr(self.model, "_sample"):            # not renewed: the reference's autoregressive baseline (IS:347-350 -> HF _sample)
+            out = self._generate_autoregressive(prompt, logits_processor, gc, streamer)
+            ids = out[0, len(prompt_ids):].tolist()
+            if ids and ids[-1] == 8710:
+                ids = ids[:-1]
+            return ids
         out = self.model._sample(prompt, logits_processor, [_EosCriteria(getattr(self, "eos_token_ids", [8710]))], gc, False, streamer,
                                  attention_mask=torch.ones_like(prompt))
         ids = out[0, len(prompt_ids):].tolist()

@@ -20,6 +20,7 @@ Fixtures
   fn_temperature.npz            the same two with HF's TemperatureLogitsWarper in the processor list (GenerationConfig.temperature != 1)
   loop_llamagen.npz             whole _sample loop, tiny LlamaGen c2i   (JL:912-1249, LS:349-456)
   loop_lumina.npz               whole _sample loop, tiny Chameleon      (JL:912-1249, MC)
+  loop_lumina_ar.npz            the AUTOREGRESSIVE baseline: HF generate() + the reference's non-SJD processors (IS:16-270, 417-450)
   vq_decoders.npz               image detokenizers: LlamaGen VQModel.decode_code and the Chameleon VQGAN decode of
                                 image_tokenizer.pil_from_img_toks, small widths, per-key synthetic weights
 """
@@ -718,6 +719,71 @@ def gen_loop_lumina(greedy=False):
     np.savez_compressed(os.path.join(HERE, "loop_lumina_greedy.npz" if greedy else "loop_lumina.npz"), **out)
 
 
+def gen_loop_lumina_ar():
+    """The reference's AUTOREGRESSIVE baseline (the denominator of its published speed-ups): FlexARInferenceSolver.create_logits_processor's three
+    processors (IS:16-270, built as IS:417-450 builds them) around HF generate() on the same tiny Chameleon as loop_lumina.npz, the model class NOT
+    renewed.  One token per forward; the unconditional branch is a second forward inside the CFG processor (IS:59-93) on the context from the
+    image-start token on.  -> loop_lumina_ar.npz (prompt, sequence).  The multinomial of HF's _sample draws from the GLOBAL generator."""
+    from model.chameleon import ChameleonForConditionalGeneration, ChameleonConfig
+    from transformers import GenerationConfig
+    sys.path.insert(0, "/root/reference/lumina_mgpt")
+    import inference_solver as IS
+    assert IS.__file__.startswith("/root/reference/"), IS.__file__
+    out, meta = {}, []
+    # (name, seed, hg, wg, P, kvh, embed_token_scale, guidance)
+    runs = [("ar_s3", 3, 4, 4, 12, 4, 0.25, 3.0), ("ar_s9_gqa", 9, 3, 5, 20, 2, 0.5, 3.0), ("ar_s5_g1", 5, 3, 3, 9, 4, 0.25, 1.0)]
+    for name, seed, hg, wg, P, kvh, ets, guidance in runs:
+        V = 9216
+        cfg_kw = dict(vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=kvh, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0,
+                      swin_norm=False, mask_image_logits=False, vocabulary_map={"<image>": 8711},
+                      vq_config=dict(embed_dim=32, num_embeddings=64, double_latent=False, latent_channels=32,
+                                     resolution=32, in_channels=3, base_channels=32, channel_multiplier=[1, 1],
+                                     num_res_blocks=1, attn_resolutions=None, dropout=0.0, attn_type="vanilla"),
+                      attn_implementation="sdpa")
+        cfg = ChameleonConfig(**cfg_kw)
+        cfg.rope_scaling = None
+        model = ChameleonForConditionalGeneration(cfg).eval()
+        synthetic.fill_state_dict(model, seed=23, skip_prefixes=("model.vqmodel.",), embed_token_scale=ets)
+        ids = dict(image_start_token_id=8197, image_end_token_id=8196)
+        procs = LogitsProcessorList([
+            IS.LLMImageStartTriggeredUnbatchedClassifierFreeGuidanceLogitsProcessor(guidance_scale=guidance, model=model, image_next_line_token_id=8803,
+                                                                                   patch_size=32, **ids),
+            IS.MultiModalLogitsProcessor(image_next_line_token_id=8803, patch_size=32, voc_size=V, device="cpu", **ids),
+            IS.InterleavedTopKLogitsWarper(image_top_k=2000, text_top_k=10, **ids)])
+        prompt = torch.cat([synthetic.synthetic_prompt(P - 3, seed, lo=8900, hi=9200),
+                            torch.tensor([[8197, 8804 + hg, 8804 + wg]])], dim=1)
+        n_img = (2 * wg + 1) * 2 * hg
+        max_new = n_img + 1 + 4                  # the image, its end token, four text tokens behind it (text top-k 10, no CFG)
+        gc = GenerationConfig(max_new_tokens=max_new, max_length=P + max_new, temperature=1.0, top_k=None, do_sample=True, eos_token_id=[8710],
+                              pad_token_id=0)                                    # IS:335-345
+        # HF generate() of the installed transformers cannot drive the reference's modeling code (written against 4.4x: no GenerationMixin on the
+        # model class, another cache API), so the sampling loop of GenerationMixin._sample is spelled out here -- per step: the model on the new
+        # token with the cache (called the way the reference's own CFG processor calls it, IS:86-91), logits[:, -1].float(), the processor list,
+        # softmax, torch.multinomial(probs, 1) on the GLOBAL generator, stop at an EOS id or at max_length.  Model, processors and cache handling
+        # are the reference's; both caches are the shim's legacy cache.
+        procs[0].unconditional_context_backup["past_key_values"] = LegacyCache()
+        torch.manual_seed(seed)
+        seq, cache, cur = prompt.clone(), LegacyCache(), prompt
+        while seq.shape[1] < gc.max_length:
+            o = model(cur, attention_mask=torch.ones_like(seq), use_cache=True, past_key_values=cache)
+            cache = o.get("past_key_values", cache)
+            scores = procs(seq, o.logits[:, -1, :].clone().float())
+            nxt = torch.multinomial(torch.softmax(scores, dim=-1), num_samples=1)
+            seq, cur = torch.cat([seq, nxt], dim=1), nxt
+            if int(nxt) in gc.eos_token_id:
+                break
+        out[f"{name}.prompt"] = prompt.numpy()
+        out[f"{name}.sequence"] = seq.numpy()
+        cfg_kw.pop("attn_implementation")
+        meta.append(dict(name=name, config=cfg_kw, weight_seed=23, embed_token_scale=ets, seed=seed, guidance_scale=guidance, P=P, hg=hg, wg=wg,
+                         max_new_tokens=max_new, image_top_k=2000, text_top_k=10))
+        gen = seq[0, P:].tolist()
+        print("loop_lumina_ar", name, "generated", len(gen), "tail", gen[-6:], "eol@", [i for i, t in enumerate(gen) if t == 8803][:4])
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "loop_lumina_ar.npz"), **out)
+
+
 def gen_vq_decoders():
     """Reference decoders at small widths with weights that depend only on (state-dict key, shape): the fixture keeps the key/shape
     list (the test asserts the rewrite has exactly these), the codes and the decoded images."""
@@ -795,3 +861,5 @@ if __name__ == "__main__":
         gen_loop_lumina()
     if "loops" in which or "greedy_loops" in which:
         gen_loop_lumina(greedy=True)
+    if "loops" in which or "ar_loops" in which:
+        gen_loop_lumina_ar()

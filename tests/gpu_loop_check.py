@@ -156,7 +156,9 @@ def teacher_forced_llamagen_check(device="cuda:0", latent=16, window=16, seed=7,
 def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, scheme="speculative_jacobi", P=12,
                                 embed_token_scale=0.25, kv_heads=4, l=3, r=None, dtype=torch.bfloat16,
                                 use_graph=False, fused=True, gemm="torch", fp8_kv=False, init_scheme="random", temperature=1.0, top_p=None,
-                                do_sample=True):
+                                do_sample=True, uncond_start=None, eos=(8196,)):
+    """uncond_start: first prompt token the uncond row sees (default P - 1, the SJD sampler's; P - 3 = the AR baseline's context from the
+    image-start token on, IS:62-63)"""
     import sjd_amd.ops as ops
     import sjd_amd.synthetic as synthetic
     from sjd_amd.engine import SJDEngine, SJDConfig, WindowSpec
@@ -175,13 +177,14 @@ def teacher_forced_lumina_check(device="cuda:0", hg=4, wg=4, window=16, seed=3, 
     model.setup_cache(batch=2, s_max=((max_len + 64 + 31) // 32) * 32, dtype=ops.FP8 if fp8_kv else None)
     r = r if r is not None else (2 * wg + 1) * 2 * hg - 10
     cfg = SJDConfig(jacobi_loop_interval_l=l, jacobi_loop_interval_r=r, max_num_new_tokens=window, guidance_scale=3.0,
-                    seed=seed, prefix_token_sampler_scheme=scheme, max_length=max_len, eos_token_ids=(8196,),
+                    seed=seed, prefix_token_sampler_scheme=scheme, max_length=max_len, eos_token_ids=tuple(eos),
                     multi_token_init_scheme=init_scheme, do_sample=do_sample)
     ids = prompt.to(device)
+    u0 = P - 1 if uncond_start is None else int(uncond_start)
     spec = WindowSpec(first_tokens=ids.repeat(2, 1),
-                      first_positions=torch.stack([torch.arange(P), torch.tensor([1] * (P - 1) + [0])]).to(device),
-                      key_start=torch.tensor([0, P - 1], dtype=torch.int32),
-                      pos_offset=torch.tensor([0, -(P - 1)], dtype=torch.long), kv_base=0)
+                      first_positions=torch.stack([torch.arange(P), torch.tensor([1] * u0 + list(range(P - u0)))]).to(device),
+                      key_start=torch.tensor([0, u0], dtype=torch.int32),
+                      pos_offset=torch.tensor([0, -u0], dtype=torch.long), kv_base=0)
     eng = SJDEngine(model, V, device, max_window=window, use_graph=use_graph)
     rec = _Recorder()
     eng.hook = rec

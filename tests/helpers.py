@@ -98,10 +98,30 @@ def llamagen_forward_fn(model, class_id, cfg_scale, top_k, top_p, max_new_tokens
 
 
 @torch.no_grad()
-def lumina_forward_fn(model, P, s_max, device="cpu"):
+def lumina_forward_fn(model, P, s_max, device="cpu", uncond_start=None):
     """cond||uncond batch; the uncond half is blind to prompt[:P-1] and its RoPE positions are shifted by -(P-1)
-    (jacobi_iteration_lumina_mgpt.py:703-712, 755-758)."""
+    (jacobi_iteration_lumina_mgpt.py:703-712, 755-758).
+    uncond_start: index of the first prompt token the uncond half sees (default P - 1, the SJD sampler's; the reference's AUTOREGRESSIVE CFG
+    processor keeps the context from the image-start token on, IS:62-63: P - 3 for a prompt that ends <image-start> h w)."""
     model.setup_cache(batch=2, s_max=s_max)
+    if uncond_start is not None and uncond_start != P - 1:
+        u0 = int(uncond_start)
+        key_start = torch.tensor([0, u0])
+
+        @torch.no_grad()
+        def fwd_u(win, kv_len):
+            n = len(win)
+            toks = torch.tensor([win, win], dtype=torch.long, device=device)
+            if kv_len == 0:
+                assert n == P
+                pos = torch.stack([torch.arange(P), torch.tensor([1] * u0 + list(range(P - u0)))]).to(device)
+            else:
+                base = kv_len + torch.arange(n)
+                pos = torch.stack([base, base - u0]).to(device)
+            lg = model.forward_window(toks, pos, kv_len, key_start)
+            return lg[0].cpu().numpy(), lg[1].cpu().numpy()
+
+        return fwd_u
     key_start = torch.tensor([0, P - 1])
 
     @torch.no_grad()

@@ -114,6 +114,16 @@ def test_greedy_decode_takes_the_oracles_decisions(use_graph, gemm, scheme):
     assert r["last"] == 8196 and r["tokens"] == 73
 
 
+@pytest.mark.parametrize("use_graph,gemm", [(True, "sjd"), (False, "torch")])
+def test_autoregressive_baseline_is_the_one_row_window(use_graph, gemm):
+    """round 6: the reference's AR baseline (HF _sample + IS:417-450's processors; pinned on reference runs in
+    tests/test_oracle_golden.py::test_loop_lumina_autoregressive_baseline) on the engine: a ONE-row window, the uncond row's context from the
+    image-start token on, generation running past the image's end token into text (top-k 10, no CFG) -- every token and every draw as the
+    oracle's replay, one forward per token"""
+    r = G.teacher_forced_lumina_check(use_graph=use_graph, gemm=gemm, window=1, l=1, r=1 << 20, uncond_start=12 - 3, eos=(8710,))
+    assert r["tokens"] == 77 and r["nfe"] == 77 and r["accepted_hist"] == [1]
+
+
 @pytest.mark.parametrize("n_prompts,use_graph,n_slots", [(2, True, None), (3, False, None), (5, True, 2)])
 def test_greedy_batch_decode_takes_the_oracles_decisions(n_prompts, use_graph, n_slots):
     """round 6: GenerationConfig(do_sample=False) in SJDBatchEngine (it raised): every slot emits K2's mode instead of its draw, consumes nothing from

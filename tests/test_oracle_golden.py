@@ -315,6 +315,30 @@ def test_loop_lumina(golden_dir, fixture, do_sample):
         assert len(tr.matched) == m["nfe"]
 
 
+def test_loop_lumina_autoregressive_baseline(golden_dir):
+    """The reference's AR baseline -- HF's sampling loop around FlexARInferenceSolver.create_logits_processor's three non-SJD processors (IS:16-270,
+    417-450), one token per forward, the unconditional branch a second forward inside the CFG processor -- is the SJD loop with a ONE-token window
+    whose unconditional half sees the prompt from the image-start token on (the SJD sampler keeps only the last prompt token, JL:703-712):
+    same grammar (image rows / forced end-of-line / end-of-image / text top-k 10 behind the image), same CFG context, one [1, V] multinomial per
+    step and nothing else drawn.  Pinned on three reference runs (tests/golden/loop_lumina_ar.npz), token for token, incl. guidance 1 (no CFG) and
+    the four text tokens generated behind the image."""
+    d, meta = load(golden_dir, "loop_lumina_ar.npz")
+    assert len(meta) == 3
+    for m in meta:
+        name = m["name"]
+        model = make_chameleon(m["config"], m["weight_seed"], m["embed_token_scale"], OracleWindowAttention())
+        prompt = d[f"{name}.prompt"][0].tolist()
+        max_len = len(prompt) + m["max_new_tokens"]
+        fwd = lumina_forward_fn(model, len(prompt), max_len + 32, uncond_start=len(prompt) - 3)      # IS:62-63: the context from <image-start> on
+        cfg = OL.LoopConfig(jacobi_loop_interval_l=1, jacobi_loop_interval_r=1 << 20, max_num_new_tokens=1, guidance_scale=m["guidance_scale"],
+                            seed=m["seed"], do_cfg=True, max_length=max_len, eos_token_ids=(8710,))
+        seq, tr = OL.run(prompt, fwd, lambda c, n: O.lumina_rules(c, n, m["image_top_k"], m["text_top_k"]), cfg, m["config"]["vocab_size"],
+                         no_cfg_fn=O.lumina_force_no_cfg)
+        want = d[f"{name}.sequence"][0].tolist()
+        assert seq == want, (name, [i for i, (a, b) in enumerate(zip(seq, want)) if a != b][:4], len(seq), len(want))
+        assert len(tr.matched) == len(want) - len(prompt) and all(a == 1 for a in tr.matched[1:])      # one forward per token: the AR cost
+
+
 def test_top_p_rule_is_hf_top_p_warper():
     """GenerationConfig.top_p reaches the kernels as the rule scalar TopPLogitsWarper3d uses (reference LP:207-250 = HF's TopPLogitsWarper
     with a window axis).  Pinned here against the third-party warper itself (transformers, the version installed): after a top-k of 50 and a

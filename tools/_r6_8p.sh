@@ -1,7 +1,7 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out
-B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-cpu-baseline --no-whole-image --no-other-configs"
+B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-ar-baseline --no-cpu-baseline --no-whole-image --no-other-configs"
 for pp in 8 6 5 4 3; do
 $B --prompts-per-gpu $pp > $O/r6_${pp}p.json 2> $O/r6_${pp}p.err
 python - <<PY

@@ -1,7 +1,7 @@
 #!/bin/bash
 # end-to-end A/B of G1w launch shapes at eight prompts per forward (one box, interleaved)
 cd ${GRAFT_REPO_ROOT:-.}
-B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-cpu-baseline --no-whole-image --no-other-configs --prompts-per-gpu 8"
+B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-ar-baseline --no-cpu-baseline --no-whole-image --no-other-configs --prompts-per-gpu 8"
 run() { r=$(SJD_G1_CFG="$2" $B 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"); echo "$1 $r"; }
 for rep in 1 2; do
 run default '{}'

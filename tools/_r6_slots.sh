@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out
 python -m pytest tests/test_gpu_loop.py -x -q -m gpu -k "prompts or batch or continuous or per_slot" 2>&1 | tail -5
-B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-cpu-baseline --no-whole-image --no-other-configs"
+B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-ar-baseline --no-cpu-baseline --no-whole-image --no-other-configs"
 for pp in 8 4 2; do
 for sl in 1 0; do
 SJD_SLOT_LAUNCHES=$sl $B --prompts-per-gpu $pp > $O/r6_slots_${pp}p_$sl.json 2> $O/r6_slots_${pp}p_$sl.err

@@ -8,7 +8,7 @@ TAG=${1:-r6}
 PREV=${2:-profiles/r5final_bench_by_shape.txt}      # the previous round's by-shape table: the regression guard compares against it
 O=gpurun_out
 mkdir -p $O
-B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-cpu-baseline --no-whole-image --no-other-configs"
+B="python bench.py --steps 64 --warmup 8 --no-floor --no-torch-baseline --no-ar-baseline --no-cpu-baseline --no-whole-image --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_trace -- $B > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof_bench.err
 python tools/trace_by_grid.py $O/prof_${TAG}_trace 200 > $O/${TAG}_bench_by_shape.txt
 find $O/prof_${TAG}_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_bench_kernel_stats.csv

@@ -14,7 +14,7 @@ agg = collections.defaultdict(list)
 for p in paths:
     with open(p) as f:
         for r in csv.DictReader(f):
-            name = r["Kernel_Name"].split("(")[0][-60:]
+            name = r["Kernel_Name"].replace("(anonymous namespace)", "anon").split("(")[0][-60:]
             grid = tuple(int(r.get(k, 0) or 0) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
             wg = int(r.get("Workgroup_Size_X", 0) or 0)
             agg[(name, grid, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))

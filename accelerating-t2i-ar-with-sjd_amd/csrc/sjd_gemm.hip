@@ -2159,3 +2159,56 @@ extern "C" int sjd_debug_trace_g1(unsigned long long *host_out, int n_wg)
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_g1_trace), (size_t)n_wg * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #endif
+
+#ifdef SJD_EXPERIMENTAL
+// ------------------------------------------------------------------------------------------------ round 6 gate probe (VERDICT r5 "next #4")
+// "Let the o projection consume K1's split partials": the activation-staging prologue of every o-projection workgroup would merge the n_split
+// partial triples (m, l, O[128]) of its K chunk's heads instead of reading the 32 KB of merged activations.  This kernel IS that prologue and
+// nothing else, on the o projection's grid (22 column groups x 8 K chunks of 512 = 4 heads, 384 threads): for 32 window rows x 4 heads it reads
+// 4 splits x (2 + 128) fp32 -- 266 KB per workgroup against 32 KB, the 22 column groups of a chunk re-merging the same heads -- merges them in
+// k1_combine's order (max, exp2f weights, sum, one division) and leaves the bf16 tile in LDS.  mode 0: the same launch with an empty body.
+// Timed in a hipGraph (tools/o_merge_probe.py): the prologue's cost is mode 1 - mode 0, to hold against k1_combine's 4.98 us + one kernel boundary.
+__global__ __launch_bounds__(384) void o_merge_prologue_probe(const float *__restrict__ part, float *__restrict__ sink, int n_split, int rows, int mode)
+{
+    __shared__ unsigned short xs[32 * 512];
+    if (mode == 0) { if (part == nullptr) sink[0] = 0.f; return; }
+    const int chunk = blockIdx.y;                                   // heads 4 * chunk .. 4 * chunk + 3
+    // part: [head 32][split n_split][row rows][2 + 128] fp32
+    float keep = 0.f;
+    for (int item = threadIdx.x; item < rows * 4 * 32; item += 384) {          // (row, head, four output columns)
+        const int d4 = item & 31, hr = item >> 5, h = hr & 3, r = hr >> 2;
+        const float *base = part + (((size_t)(4 * chunk + h) * n_split) * rows + r) * 130;
+        float m[4], l[4];
+        float4 o[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float *p = base + (size_t)min(s, n_split - 1) * rows * 130;
+            m[s] = p[0]; l[s] = p[1];
+            o[s] = *reinterpret_cast<const float4 *>(p + 2 + 4 * d4 + 2);      // (16-byte aligned: rows of 130 floats, +2 pad)
+        }
+        float M = m[0];
+#pragma unroll
+        for (int s = 1; s < 4; ++s) M = fmaxf(M, m[s]);
+        float L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float w = exp2f(m[s] - M);
+            L += w * l[s]; a0 += w * o[s].x; a1 += w * o[s].y; a2 += w * o[s].z; a3 += w * o[s].w;
+        }
+        const float inv = 1.0f / L;
+        unsigned short *dst = xs + r * 512 + h * 128 + 4 * d4;
+        auto bf = [](float x) { unsigned u = __float_as_uint(x); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); };
+        dst[0] = bf(a0 * inv); dst[1] = bf(a1 * inv); dst[2] = bf(a2 * inv); dst[3] = bf(a3 * inv);
+        keep += a0;
+    }
+    __syncthreads();
+    if (keep == 12345.678f) sink[blockIdx.x] = (float)xs[threadIdx.x];          // (keeps the LDS tile alive)
+}
+
+extern "C" int sjd_o_merge_prologue_probe(const float *part, float *sink, int n_split, int rows, int mode, void *stream)
+{
+    if (!part || !sink || n_split < 1 || n_split > 4 || rows < 1 || rows > 32) return SJD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(o_merge_prologue_probe, dim3(22, 8), dim3(384), 0, (hipStream_t)stream, part, sink, n_split, rows, mode);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+#endif  // SJD_EXPERIMENTAL

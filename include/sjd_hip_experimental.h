@@ -130,6 +130,10 @@ int sjd_reduce_timeouts(void);
 int sjd_skinny_gemm_wide(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int tiles, int step_major, int variant,
                          int ldx, void *stream);
 
+/* round-6 gate probe for "the o projection consumes K1's split partials" (VERDICT r5 next #4): the would-be staging prologue alone, on the o
+ * projection's grid (csrc/sjd_gemm.hip::o_merge_prologue_probe).  part: fp32 [32 heads][n_split][rows][130]; mode 0 = empty body, 1 = merge. */
+int sjd_o_merge_prologue_probe(const float *part, float *sink, int n_split, int rows, int mode, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

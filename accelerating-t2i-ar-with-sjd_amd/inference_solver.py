@@ -193,6 +193,29 @@ class FlexARInferenceSolver:
         ids = self.generate_ids(prompt, max_gen_len, logits_processor, streamer, temperature)
         return self.decode_ids(ids)
 
+    def get_streamer(self):
+        """reference IS:295-296: HF's TextStreamer over the item processor's tokenizer (needs the reference's item processor)"""
+        if self.item_processor is None:
+            raise NotImplementedError("get_streamer() needs the reference's item processor (its tokenizer); pass streamer=<any object with put / end> instead")
+        from transformers import TextStreamer
+        return TextStreamer(self.item_processor.tokenizer)
+
+    def decode_image(self, tokens: List[int]):
+        """reference IS:402-403"""
+        if self.item_processor is None:
+            raise NotImplementedError("decode_image() needs the reference's item processor (VQ-GAN decoder); sjd_amd.detokenizers holds the decoders themselves")
+        return self.item_processor.decode_image(tokens)
+
+    @staticmethod
+    def create_image_grid(images, rows, cols):
+        """reference IS:405-415: paste rows x cols equally sized PIL images into one"""
+        from PIL import Image
+        width, height = images[0].size
+        grid = Image.new("RGB", (cols * width, rows * height))
+        for i, img in enumerate(images):
+            grid.paste(img, ((i % cols) * width, (i // cols) * height))
+        return grid
+
     def decode_ids(self, tokens: List[int]):
         """reference IS:356-400: split at <racm3:break>(8197) ... <eoss>(8196) spans; images go through item_processor.decode_image."""
         text_ids, images, i = [], [], 0

@@ -234,3 +234,30 @@ def test_hf_generate_builds_criteria_and_topk_then_calls_sample():
     assert seen["procs"] == ["Proc"]
     with pytest.raises(NotImplementedError):
         hf_generate(M(), ids, GenerationConfig(do_sample=True, num_beams=2, max_new_tokens=4))
+
+
+def test_flexar_solver_method_surface():
+    """FlexARInferenceSolver keeps the reference's method names (IS:273-450) -- generate, create_logits_processor, decode_ids, decode_image,
+    create_image_grid, get_streamer; the two that need the reference's tokenizer / VQ-GAN assets say so instead of failing somewhere inside"""
+    import pytest
+    from PIL import Image
+    from lumina_mgpt.inference_solver import FlexARInferenceSolver
+    for name in ("generate", "generate_ids", "create_logits_processor", "decode_ids", "decode_image", "create_image_grid", "get_streamer"):
+        assert callable(getattr(FlexARInferenceSolver, name)), name
+    imgs = [Image.new("RGB", (4, 3), (i * 40, 0, 0)) for i in range(6)]
+    grid = FlexARInferenceSolver.create_image_grid(imgs, 2, 3)                       # IS:405-415
+    assert grid.size == (12, 6) and grid.getpixel((5, 4)) == (160, 0, 0) and grid.getpixel((11, 0)) == (80, 0, 0)
+    s = FlexARInferenceSolver.__new__(FlexARInferenceSolver)
+    s.item_processor = None
+    with pytest.raises(NotImplementedError):
+        s.get_streamer()
+    with pytest.raises(NotImplementedError):
+        s.decode_image([8197, 8196])
+
+    class _IP:
+        tokenizer = None
+
+        def decode_image(self, toks):
+            return ("image", len(toks))
+    s.item_processor = _IP()
+    assert s.decode_image([8197, 5, 8196]) == ("image", 3)

@@ -1100,6 +1100,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t g1z_unit_rsrc(const unsigned c
 // PLAIN loop over those records (eight in flight, no decode) instead of the 12-bit one: one wave-uniform branch per kernel, the same MFMA
 // sequence, and a matrix without raw units never leaves the old path.  (A fix-up launch behind the kernel was built first, csrc/sjd_gemm_raw.h:
 // +5-7 us per projection with 1 % raw units -- a unit's MFMA chain is serial -- it now serves only the sub-tiled kernel.)
+// Row tiles up to which a raw unit's plain records are multiplied INSIDE the 12-bit kernels; kernels with more row tiles leave raw units to the
+// fix-up launch (csrc/sjd_gemm_raw.h; sjd_amd.ops decides with the same number, sjd_g1z_raw_inline_rows()).
+#ifndef G1Z_RAW_INLINE_MAX_MT
+#define G1Z_RAW_INLINE_MAX_MT 8
+#endif
 __device__ __forceinline__ bool g1z_unit_is_raw(const g1z_hraw &h) { return __builtin_amdgcn_readfirstlane((int)h.a.y) < 0; }
 __device__ __forceinline__ const u32x4 *g1z_raw_records(const u32x2 *__restrict__ exc, const g1z_hraw &h, int lane)
 {
@@ -1206,7 +1211,7 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu(const unsigned short *__r
         }
     };
     // a unit that travels verbatim (see g1z_raw_records): the plain trip over its 1-KiB records, eight in flight
-    const bool z_raw = g1z_unit_is_raw(hraw);
+    const bool z_raw = (1 <= G1Z_RAW_INLINE_MAX_MT) && g1z_unit_is_raw(hraw);
     const u32x4 *rr = z_raw ? g1z_raw_records(exc, hraw, lane) : reinterpret_cast<const u32x4 *>(x);
     u32x4 rc[8];
     if (z_raw) {
@@ -1378,7 +1383,7 @@ __global__ __launch_bounds__(512) void g1z_gateup_silu_tall(const unsigned short
     // a unit that travels verbatim (see g1z_raw_records): the plain trip over its 1-KiB records, eight in flight
     // (SP = 32 with two row tiles -- hidden 4096 at 64 rows -- sits at its 256 registers: there the raw units are left to the fix-up launch,
     //  sjd_raw_gateup_fixup; sjd_amd.ops.gateup_silu knows)
-    constexpr bool RAW_HERE = !(SP == 32 && MT == 2);
+    constexpr bool RAW_HERE = !(SP == 32 && MT == 2) && MT <= G1Z_RAW_INLINE_MAX_MT;
     const bool z_raw = RAW_HERE && g1z_unit_is_raw(hraw);
     const u32x4 *rr = z_raw ? g1z_raw_records(exc, hraw, lane) : reinterpret_cast<const u32x4 *>(x);
     constexpr int RD = 4;                     // records in flight
@@ -1726,7 +1731,7 @@ __global__ __launch_bounds__(MAXT) void g1z_skinny_gemm(const unsigned short *__
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[mt] = xl[mt * xs + min(s, steps - 1) * 64 + g1_slot(lane >> 5, lane & 31, u)];
     };
-    if (g1z_unit_is_raw(hraw)) {          // this wave's unit travels verbatim: the plain loop (see g1z_raw_records)
+    if (MT <= G1Z_RAW_INLINE_MAX_MT && g1z_unit_is_raw(hraw)) {          // this wave's unit travels verbatim: the plain loop (see g1z_raw_records)
         const u32x4 *rr = g1z_raw_records(exc, hraw, lane);
         constexpr int RD = (MT == 2 && MAXT == 1024) ? 2 : 8;      // records in flight (the 128-register budget of 16-wave workgroups with two row tiles: 2)
         u32x4 rc[RD];

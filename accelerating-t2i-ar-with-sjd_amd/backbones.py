@@ -388,7 +388,10 @@ class ChameleonBackbone(nn.Module):
     # 4-wave workgroups run on g1_skinny_gemm_tiled8 (8-step sub-tiles, two workgroups per CU, weight ring refilled in place) -- q|k|v,
     # o and down are faster there (28.1 / 15.8 / 28.4 -> 25.7 / 12.2 / 24.0 us); 8-wave workgroups run on the same kernel with one workgroup
     # per CU (gate|up 49.4 -> 43.3 us, profiles/r3_g1_tiled8.txt); four prompts per forward 5.55 -> 4.89 ms per step on one box
-    G1_CFG_128ROW = dict(qkv=(2048, 4, True), o=(896, 4, True), gate_up=(2048, 8, True), down=(1376, 4, True))
+    # (late round 6: bf16 windows of 65..128 rows run on kernel G1w as well -- the second number is then its column tiles per workgroup -- with gate|up
+    #  on six tiles and down in chunks of 1408: four prompts 4.43 -> 4.26 ms per step, three 4.05 -> 3.95 on one box, profiles/r6_g1w_128rows_ab.txt;
+    #  round 5's shapes: gate_up (2048, 8), down (1376, 4).  fp16 and the 12-bit stream keep the sub-tiled kernels on the same shapes.)
+    G1_CFG_128ROW = dict(qkv=(2048, 4, True), o=(896, 4, True), gate_up=(2048, 6, True), down=(1408, 4, True))
     # 129..256-row windows (five to eight prompts per forward): kernel G1w (csrc/sjd_gemm_wide.h, round 6) -- the second number is the column tiles
     # per workgroup: 2, 3, 4 (one per wave) or 6, 8 (two per wave).  tools/g1w_bench.py at 256 rows (profiles/r6_g1w_sweep.txt), us per launch against
     # round 5's g1_skinny_gemm_tiled8: q|k|v 34.3 / 46.1, o 19.6 / 23.4, gate|up 58.4 / 84.4, down 31.3 / 38.2 (hipBLASLt: 50.4 / 19.1 / 65.9 / 52.7); o with

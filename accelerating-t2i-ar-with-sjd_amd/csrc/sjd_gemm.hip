@@ -1992,6 +1992,23 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
     } else
     if constexpr (MT >= 2) if (MT > 2 || lds_whole > 160 * 1024 || (force_tiled && waves <= 8)) {     // sub-tiled activation: no limit on KC
         if (waves > 8) return SJD_ERR_BAD_ARG;
+        if constexpr ((MT == 3 || MT == 4) && DT == SJD_DTYPE_BF16) {
+            // 65..128-row windows (three / four prompts per forward) in bf16: G1w too (late round 6) -- with its own launch shapes it is 5-10 % faster per
+            // launch than the sub-tiled kernels (profiles/r6_g1w_sweep_128rows.jsonl: q|k|v 23.1 / 24.5, o 11.6 / 12.4, gate|up 37.2 / 40.4, down 21.9 / 24.2 us);
+            // `waves` = column tiles per workgroup: 2, 3, 4, 6, 8; any other count, fp16, or SJD_G1_WIDE_128=0 (A/B aid) keep the sub-tiled kernels below.
+            // Same chunking and accumulation order: the planes are the sub-tiled kernels', bit for bit.
+            static const bool wide128 = [] { const char *e = getenv("SJD_G1_WIDE_128"); return !(e && e[0] == '0'); }();
+            if (wide128 && M > 64) {
+                if constexpr (MT == 4) if (waves == 2) return g1_wide_launch<DT, MT, 1, 2, 4, 3, 2, 1>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+                switch (waves) {          // (three row tiles x two waves: a k-step has too few MFMAs to carry its DMA pieces -- the sub-tiled kernel keeps that shape)
+                case 3: return g1_wide_launch<DT, MT, 1, 3, 4, 3, 2, 1>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+                case 4: return g1_wide_launch<DT, MT, 1, 4, 4, 3, 2, 1>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+                case 6: return g1_wide_launch<DT, MT, 2, 3, 4, 3, 2, 1>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+                case 8: return g1_wide_launch<DT, MT, 2, 4, 4, 3, 2, 1>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+                default: break;
+                }
+            }
+        }
         static const bool sub8 = [] { const char *e = getenv("SJD_G1_SUB8"); return !(e && e[0] == '0'); }();      // (A/B aid: 0 = the 16-step kernel for every wave count)
         static const bool sub8w8 = [] { const char *e = getenv("SJD_G1_SUB8_W8"); return !(e && e[0] == '0'); }();   // (A/B aid: 0 = eight-wave workgroups on the 16-step kernel)
         if constexpr (MT > 2) if (waves == 4 && sub8) {        // 4-wave workgroups: 8-step sub-tiles, two workgroups per CU

@@ -399,7 +399,10 @@ class ChameleonBackbone(nn.Module):
     G1_CFG_256ROW = dict(qkv=(2048, 4, True), o=(1024, 2, True), gate_up=(2048, 8, True), down=(1408, 4, True))
     G1_WIDE_TILES = (2, 3, 4, 6, 8)
     # Emu3-Gen 8B (GQA 32/8: the q|k|v projection has 6144 columns; draft window 32 -> 64 rows), tuned end to end with bench.py --model emu3_8b
-    G1_CFG_EMU3 = dict(qkv=(512, 8, False), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))        # profiles/r2_g1_launch_shape_sweep_emu3_64rows.jsonl
+    # (late round 6: 33..64-row windows on the uncompressed stream run on kernel G1w -- the second number is its column tiles per workgroup -- with its own
+    #  shapes: per launch q|k|v 12.8 / 13.6 us, o 9.4 / 11.2, down 22.5 / 25.2 against round 2's (512, 8) / (512, 8) / (896, 8) on the whole-chunk kernel,
+    #  profiles/r6_g1w_sweep_64rows_emu3.jsonl; Emu3 in fp16 4.37 -> 4.17 ms per step, profiles/r6_g1w_64rows_emu3_ab.txt)
+    G1_CFG_EMU3 = dict(qkv=(1024, 4, True), o=(512, 4, True), gate_up=(2048, 8, True), down=(1792, 4, True))
     # the same on the 12-bit stream (Emu3 in bf16, round 4): 256-workgroup launches for q|k|v and o, step-major packing -- 11.75 / 10.25 / 19.85 us
     # against 12.15 / 10.66 / 20.19 (tools/g1z_bench.py --sweep --emu3 --rows 64, profiles/r4_g1z_sweep_emu3_64rows.jsonl)
     G1_CFG_EMU3_Z = dict(qkv=(512, 6, True), o=(512, 4, True), gate_up=(2048, 8, True), down=(896, 8, True))

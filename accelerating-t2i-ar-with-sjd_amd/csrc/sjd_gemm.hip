@@ -1968,6 +1968,23 @@ static int g1_launch(const void *x, const void *w_packed, float *out, int M, int
     const dim3 grid((n_out + waves - 1) / waves, n_chunks), block(waves * 64);
     const size_t lds_whole = (size_t)MT * ((KC < K ? KC : K) / 16) * 64 * 16;       // the whole activation chunk staged at once
     static const bool force_tiled = [] { const char *e = getenv("SJD_G1_TILED"); return e && e[0] == '1'; }();      // tuning aid (64-row windows)
+    if constexpr (MT == 2) {
+        // 33..64-row windows (Emu3's draft window of 32 with CFG; two prompts per forward) on the uncompressed stream, both 16-bit types: G1w with two
+        // row tiles and the register budget of two workgroups per CU (late round 6) -- per launch at Emu3's shapes q|k|v 12.6 / 13.6 us, o 9.4 / 11.2,
+        // gate|up 39.0 / 43.1, down 22.5 / 25.2 against the kernels below (profiles/r6_g1w_sweep_64rows_emu3.jsonl); `waves` = column tiles per
+        // workgroup: 2, 3, 4, 6, 8.  Same chunking and accumulation order: bit-identical planes.  SJD_G1_WIDE_64=0: the kernels below (A/B aid).
+        static const bool wide64 = [] { const char *e = getenv("SJD_G1_WIDE_64"); return !(e && e[0] == '0'); }();
+        if (wide64 && M > 32) {
+            switch (waves) {
+            case 2: return g1_wide_launch<DT, MT, 1, 2, 4, 3, 2, 2>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+            case 3: return g1_wide_launch<DT, MT, 1, 3, 4, 3, 2, 2>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+            case 4: return g1_wide_launch<DT, MT, 1, 4, 4, 3, 2, 2>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+            case 6: return g1_wide_launch<DT, MT, 2, 3, 4, 3, 2, 2>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+            case 8: return g1_wide_launch<DT, MT, 2, 4, 4, 3, 2, 2>(x, w_packed, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+            default: break;
+            }
+        }
+    }
     if constexpr (MT > 4) {      // 129..256-row windows (five to eight prompts per forward): G1w (sjd_gemm_wide.h, round 6).  `waves` = column tiles per
         // workgroup: 2, 3, 4 (one per wave) or 6, 8 (two per wave: every activation fragment read from LDS feeds two MFMAs); stages of four k-steps,
         // three ring slots (96 KiB + 1), weight ring of eight k-steps.  SJD_G1_WIDE=0 (A/B aid): round 5's g1_skinny_gemm_tiled8 with four waves,
@@ -2148,6 +2165,15 @@ extern "C" int sjd_skinny_gemm_wide(const void *x, const void *w_packed, float *
         case 0: SJD_G1W_T(8, 4, 3, 2, 1);
         case 1: SJD_G1W_T(8, 4, 4, 2, 1);
         case 10: if (tiles == 8) SJD_G1W_V(8, 1, 8, 4, 3, 2, 2); return SJD_ERR_BAD_ARG;
+        default: return SJD_ERR_BAD_ARG;
+        }
+    }
+    if (M <= 64) {          // (late round 6: two row tiles -- Emu3's 64-row windows, two prompts per forward)
+        switch (variant) {
+        case 0: SJD_G1W_T(2, 4, 3, 2, 1);
+        case 20: SJD_G1W_T(2, 4, 3, 2, 2);
+        case 21: SJD_G1W_T(2, 8, 3, 1, 2);
+        case 22: SJD_G1W_T(2, 4, 4, 2, 2);
         default: return SJD_ERR_BAD_ARG;
         }
     }

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void g1_wide(const unsigned short *__
     constexpr int GRP = CT + DPK;
     constexpr int D0 = MT * (CT - 1) + 1;         // the DMA pieces follow MFMA D0, D0 + DSTR, ...
     constexpr int DSTR = (D0 + 2 * (DPK - 1) < NM - 1) ? 2 : 1;
-    static_assert(D0 + DSTR * (DPK - 1) < NM - 1, "the DMA pieces fit between the record loads");
+    // (the last piece may share the last MFMA's slot with the record reload of tile CT - 1: the piece is issued first there, the order the counts assume)
+    static_assert(D0 + DSTR * (DPK - 1) <= NM - 1, "the DMA pieces fit between the record loads");
     // younger operations when tile c's records of k-step s are waited for (issued R k-steps earlier), and when the last piece of stage st is
     constexpr int N_WL = (R - 1) * GRP + (CT - 1);                       // the last tile's record closes its group; the earlier tiles' of THIS k-step are out again
     constexpr int N_W0 = (R - 1) * GRP + DPK + 1;                        // (CT = 2) tile 0: the pieces and the last record of its own group follow it

@@ -152,6 +152,32 @@ def test_g1_skinny_gemm_three_and_four_row_tiles(dev, dtype, M, N, K, KC, waves,
         ops.skinny_gemm(x, ops.pack_weight(w, KC, step_major), N, K, KC, waves=11, step_major=step_major)      # > 8 waves: 256 VGPRs needed
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,KC", [(64, 6144, 4096, 1024), (64, 4096, 14336, 1792), (64, 28672, 4096, 2048), (33, 512, 1376, 256), (48, 64, 96, 32),
+                                        (40, 256, 176, 64), (64, 4096, 4096, 512), (57, 352, 4096, 4096)])
+@pytest.mark.parametrize("tiles,step_major", [(4, True), (8, True), (8, False), (2, True), (3, False), (6, True)])
+def test_g1w_two_row_tiles(dev, dtype, M, N, K, KC, tiles, step_major):
+    """late round 6: 33..64-row windows on the uncompressed stream (Emu3's window of 32 with CFG in fp16; two prompts per forward) run on kernel G1w with
+    two row tiles, bf16 AND fp16 -- against an fp32 matmul and plane for plane against the 32-row kernel fed 32 rows at a time (bit-identical); Emu3's
+    shapes, ragged chunks, column counts that leave waves without a tile, one K chunk, rows that are not whole tiles; poisoned planes."""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(N + K + M)
+    x = torch.randn(M, K, generator=g).to(dtype).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    wp = ops.pack_weight(w, KC, step_major)
+    torch.full((2 * ((K + KC - 1) // KC) * 64 * N,), float("nan"), device=dev)      # (freed at once: the allocator hands the block to the planes)
+    part = ops.skinny_gemm(x, wp, N, K, KC, waves=tiles, step_major=step_major)
+    assert part.n_chunks == (K + KC - 1) // KC and part.data.shape[1] == 64
+    torch.testing.assert_close(part.data.sum(0)[:M], x.float() @ w.float().t(), atol=2e-3, rtol=2e-3)
+    if M < 64:
+        assert part.data[:, M:].abs().max() == 0
+    if KC <= 2560:
+        for r0 in range(0, M, 32):
+            p32 = ops.skinny_gemm(x[r0:r0 + 32].contiguous(), wp, N, K, KC, waves=4, step_major=step_major)
+            rows = min(32, M - r0)
+            assert torch.equal(p32.data[:, :rows], part.data[:, r0:r0 + rows])
+
+
 @pytest.mark.parametrize("M,N,K,KC", [(256, 4096, 11008, 1376), (192, 12288, 4096, 2048), (160, 22016, 4096, 2048), (224, 4096, 4096, 896), (130, 512, 1376, 256),
                                         (256, 64, 96, 32), (255, 256, 176, 64), (256, 4096, 11008, 1408), (256, 12288, 4096, 832), (256, 352, 4096, 512)])
 @pytest.mark.parametrize("tiles,step_major", [(4, True), (4, False), (8, True), (8, False), (2, True), (3, False), (6, True)])

@@ -61,7 +61,15 @@ def main():
     ap.add_argument("--pad", type=int, default=0, help="row stride of x = K + pad elements (L2 channel spread experiment)")
     ap.add_argument("--trace", action="store_true", help="SJD_HIP_EXP_LIB is a -DSJD_TRACE build: per-workgroup wall / shader-clock stamps of the last launch")
     ap.add_argument("--cand", default="", help="KC:tiles:step_major[,...] instead of the built-in candidates")
+    ap.add_argument("--emu3", action="store_true", help="Emu3-8B projection shapes (q|k|v 6144, o 4096, gate|up 28672 x 4096, down 4096 x 14336); use with --rows 64")
     a = ap.parse_args()
+    if a.emu3:
+        SHAPES.update(qkv=(6144, 4096), o=(4096, 4096), gate_up=(28672, 4096), down=(4096, 14336))
+        CAND.update(qkv=[(512, 8, 0), (512, 4, 1), (1024, 4, 1), (1024, 8, 1), (2048, 4, 1), (2048, 3, 1), (832, 6, 1)],
+                    o=[(512, 8, 0), (512, 4, 1), (1024, 2, 1), (1024, 4, 1), (512, 2, 1)],
+                    gate_up=[(2048, 8, 1), (2048, 6, 1), (2048, 4, 1), (1024, 8, 1), (4096, 4, 1)],
+                    down=[(896, 8, 0), (896, 8, 1), (1792, 4, 1), (1024, 4, 1), (2048, 4, 1), (1792, 8, 1)])
+        OLD128.update(qkv=(512, 8, 0), o=(512, 8, 0), gate_up=(2048, 8, 1), down=(896, 8, 0))      # backbones.G1_CFG_EMU3 (64-row windows)
     dev = torch.device("cuda:0")
     lib = L.load_exp()          # (the tuning entry sjd_skinny_gemm_wide lives in libsjd_hip_exp.so; SJD_HIP_EXP_LIB: a probe build of it)
     M = a.rows

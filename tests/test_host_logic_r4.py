@@ -90,7 +90,9 @@ def test_emu3_on_the_12bit_stream_has_its_own_launch_shapes():
     import sjd_amd.backbones as BB
     z, raw = BB.ChameleonBackbone.G1_CFG_EMU3_Z, BB.ChameleonBackbone.G1_CFG_EMU3
     assert set(z) == set(raw) == {"qkv", "o", "gate_up", "down"}
-    for name in z:                                              # same split-K chunks (the consumers' plane counts do not change), <= 8 waves at 64 rows
-        assert z[name][0] == raw[name][0] and z[name][1] <= 8
+    for name in z:                                              # <= 8 waves at 64 rows on the 12-bit stream; the uncompressed set runs on kernel G1w since late
+        assert z[name][1] <= 8                                  # round 6 (its own chunks; the second number = column tiles per workgroup)
+        assert raw[name][1] in BB.ChameleonBackbone.G1_WIDE_TILES and 4096 % 16 == 0 and raw[name][0] % 64 == 0
+    assert (z["qkv"][0], z["o"][0], z["gate_up"][0], z["down"][0]) == (512, 512, 2048, 896)      # round 4's sweep (profiles/r4_g1z_sweep_emu3_64rows.jsonl)
     # 256 workgroups for q|k|v (6144 columns) and o (4096 columns) at K = 4096
     assert (6144 // 32 // z["qkv"][1]) * (4096 // z["qkv"][0]) == 256 and (4096 // 32 // z["o"][1]) * (4096 // z["o"][0]) == 256

@@ -302,8 +302,8 @@ int sjd_silu_mul_ex(const void *gate_up, void *y, int rows, int inter, int dtype
 int sjd_gateup_silu(const void *x, const void *w_packed, void *y, int M, int I, int K, int step_major, int dtype,
                     const sjd_row_norm *row_norm, void *stream);
 
-/* G1 -- weight-streaming projection of the draft window: out[c, m, n] = sum_{k in chunk c} x[m, k] * W[n, k], M <= 128 rows
- * (one to four 32-row MFMA tiles: up to four prompts' draft windows per forward), fp32 split-K partials [n_chunks, R, N] with R = M rounded up to
+/* G1 -- weight-streaming projection of the draft window: out[c, m, n] = sum_{k in chunk c} x[m, k] * W[n, k], M <= 256 rows
+ * (one to eight 32-row MFMA tiles: up to eight prompts' draft windows per forward), fp32 split-K partials [n_chunks, R, N] with R = M rounded up to
  * a multiple of 32 and n_chunks = ceil(K / KC); the consumer (F1/F2/F3 `part` argument) sums them.
  * replaces the nn.Linear calls of the decoder layer (reference modeling_chameleon.py:527-529, 579, 193-195) for the
  * window forward.  w_packed: the [N, K] weight re-ordered by sjd_amd.ops.pack_weight (MFMA 32x32x16 B-fragment order,
@@ -311,7 +311,12 @@ int sjd_gateup_silu(const void *x, const void *w_packed, void *y, int M, int I, 
  * whole in LDS, min(KC, K) <= 2560.  M <= 64: whole while min(KC, K) <= 1280, otherwise -- and always for M > 64 -- in 256-column sub-tiles
  * double-buffered through LDS (no limit on KC; waves <= 8).  The partial planes do not depend on which of the two kernels ran;
  * waves (1..16) = column tiles per workgroup sharing one staged activation chunk; step_major selects the packed record
- * order (0: one contiguous run per tile, 1: the records of all tiles interleaved per k-step). */
+ * order (0: one contiguous run per tile, 1: the records of all tiles interleaved per k-step).
+ * Round 6 -- kernel G1w (csrc/sjd_gemm_wide.h: activation stages by LDS-DMA into a ring shared by the workgroup, hand-counted waits, two to eight row
+ * tiles of accumulators per wave) runs when `waves` is 2, 3, 4, 6 or 8 (then = column tiles per workgroup: one per wave up to 4, two per wave for 6 / 8)
+ * and 32 < M <= 64 (bf16 or fp16), 64 < M <= 128 (bf16; M <= 96: not 2) or 128 < M <= 256 (bf16 only, these tile counts only): no limit on KC.  Same
+ * chunking and accumulation order as the kernels above: the planes do not depend on which kernel ran (tests/test_gpu_glue.py::test_g1w_*,
+ * test_g1_skinny_gemm_*_row_tiles).  SJD_G1_WIDE_64 / _128 / SJD_G1_WIDE = 0 in the environment keep the older kernels (A/B aids). */
 int sjd_gemm_num_chunks(int K, int KC);
 
 /* the same over the N = 32 n columns [32 * tile0, 32 * tile0 + N) of a weight packed with N_packed columns (the output head evaluated on

@@ -819,6 +819,32 @@ def main():
             gpu_sched_ms = measure_scheduler_gpu(eng, grammar0, prompt, args.window)
         except Exception:
             gpu_sched_ms = None
+    if side_legs and not args.no_ar_baseline and args.model in ("lumina7b", "lumina_tiny"):
+        # (measured right behind the headline, before the other configurations and side legs: a leg's position in a three-minute run moves it by 1-3 %,
+        #  and this one is a ratio against the headline's own step time)
+        # the reference's AUTOREGRESSIVE baseline on the same kernels (round 6; IS:417-450 + HF _sample, one token per forward: a ONE-row window whose
+        # uncond row sees the prompt from the image-start token on -- sjd_amd.inference_solver.FlexARInferenceSolver without renew_pipeline_sampler,
+        # pinned on reference runs by tests/test_oracle_golden.py::test_loop_lumina_autoregressive_baseline).  Decoded from the engine's own accepted
+        # sequence up to the start of the timed region: the same KV length as the headline.  `value_window` / its tokens/s = the AR-vs-SJD ratio
+        # the reference publishes (2.05-2.16 x for Lumina-mGPT, BASELINE.md), here on one MI355X.
+        from sjd_amd.engine import WindowSpec
+        ctx = seq[:stats.kv_len_start + 1] if stats.kv_len_start >= P else list(prompt)
+        u0, Pc = P - 3, len(ctx)
+        spec_ar = WindowSpec(first_tokens=torch.tensor([ctx, ctx], dtype=torch.long, device=device),
+                             first_positions=torch.stack([torch.arange(Pc), torch.tensor([1] * u0 + list(range(Pc - u0)))]).to(device),
+                             key_start=torch.tensor([0, u0], dtype=torch.int32), pos_offset=torch.tensor([0, -u0], dtype=torch.long), kv_base=0)
+        cfg_ar = copy.copy(cfg)
+        cfg_ar.jacobi_loop_interval_l, cfg_ar.jacobi_loop_interval_r, cfg_ar.max_num_new_tokens = 1, 1 << 20, 1
+        eng_ar = SJDEngine(model, margs.vocab_size, device, max_window=1, use_graph=not args.no_graph)
+        _, st_a = eng_ar.decode(ctx, spec_ar, copy.deepcopy(grammar0), cfg_ar, warmup_iters=8, timed_iters=args.ar_steps, on_timed_start=sync_all,
+                                on_timed_end=sync_all)
+        ms_a = st_a.seconds / max(st_a.timed_nfe, 1) * 1e3
+        out["ar_baseline"] = {"ms_per_step": round(ms_a, 4), "tokens_per_step": 1.0, "tokens_per_s": round(1e3 / ms_a, 2), "steps": st_a.timed_nfe,
+                              "kv_len": [st_a.kv_len_start, st_a.kv_len],
+                              "sjd_speedup": round(tps_window / (1e3 / ms_a), 3), "sjd_step_reduction": round(tok_per_step, 3),
+                              "what": "autoregressive decoding (window 1) on the same kernels, weights and KV length; sjd_speedup = value_window / tokens_per_s "
+                                      "(the reference publishes 2.05-2.16 x latency and ~2.3 x steps for Lumina-mGPT, hardware unstated)"}
+        eng.reset_graphs()              # (the two engines share the backbone's workspaces: the headline engine re-captures if it runs again)
     if side_legs and not args.no_other_configs and args.model == "lumina7b":
         # BASELINE.json configs 3 and 5 in the same driver-visible line (bounded: ~64 timed steps each after a real lead-in)
         # Round 6: measured BEFORE the headline's own side legs, with the headline engine kept alive (288 GB: both models fit).  Behind the side legs the
@@ -859,30 +885,6 @@ def main():
         out["floor"] = {"tokens_per_step": 1.0, "tokens_per_s": round(1e3 / ms_h, 2),
                         "what": "1 / ms_per_step: the rate at the algorithm's minimum acceptance of one token per step (= plain AR decoding at this step time); "
                                 "`value` / this = the measured tokens per step"}
-    if side_legs and not args.no_ar_baseline and args.model in ("lumina7b", "lumina_tiny"):
-        # the reference's AUTOREGRESSIVE baseline on the same kernels (round 6; IS:417-450 + HF _sample, one token per forward: a ONE-row window whose
-        # uncond row sees the prompt from the image-start token on -- sjd_amd.inference_solver.FlexARInferenceSolver without renew_pipeline_sampler,
-        # pinned on reference runs by tests/test_oracle_golden.py::test_loop_lumina_autoregressive_baseline).  Decoded from the engine's own accepted
-        # sequence up to the start of the timed region: the same KV length as the headline.  `value_window` / its tokens/s = the AR-vs-SJD ratio
-        # the reference publishes (2.05-2.16 x for Lumina-mGPT, BASELINE.md), here on one MI355X.
-        from sjd_amd.engine import WindowSpec
-        ctx = seq[:stats.kv_len_start + 1] if stats.kv_len_start >= P else list(prompt)
-        u0, Pc = P - 3, len(ctx)
-        spec_ar = WindowSpec(first_tokens=torch.tensor([ctx, ctx], dtype=torch.long, device=device),
-                             first_positions=torch.stack([torch.arange(Pc), torch.tensor([1] * u0 + list(range(Pc - u0)))]).to(device),
-                             key_start=torch.tensor([0, u0], dtype=torch.int32), pos_offset=torch.tensor([0, -u0], dtype=torch.long), kv_base=0)
-        cfg_ar = copy.copy(cfg)
-        cfg_ar.jacobi_loop_interval_l, cfg_ar.jacobi_loop_interval_r, cfg_ar.max_num_new_tokens = 1, 1 << 20, 1
-        eng_ar = SJDEngine(model, margs.vocab_size, device, max_window=1, use_graph=not args.no_graph)
-        _, st_a = eng_ar.decode(ctx, spec_ar, copy.deepcopy(grammar0), cfg_ar, warmup_iters=8, timed_iters=args.ar_steps, on_timed_start=sync_all,
-                                on_timed_end=sync_all)
-        ms_a = st_a.seconds / max(st_a.timed_nfe, 1) * 1e3
-        out["ar_baseline"] = {"ms_per_step": round(ms_a, 4), "tokens_per_step": 1.0, "tokens_per_s": round(1e3 / ms_a, 2), "steps": st_a.timed_nfe,
-                              "kv_len": [st_a.kv_len_start, st_a.kv_len],
-                              "sjd_speedup": round(tps_window / (1e3 / ms_a), 3), "sjd_step_reduction": round(tok_per_step, 3),
-                              "what": "autoregressive decoding (window 1) on the same kernels, weights and KV length; sjd_speedup = value_window / tokens_per_s "
-                                      "(the reference publishes 2.05-2.16 x latency and ~2.3 x steps for Lumina-mGPT, hardware unstated)"}
-        eng.reset_graphs()              # (the two engines share the backbone's workspaces: the headline engine re-captures if it runs again)
     if side_legs and not args.no_torch_baseline and args.model in ("lumina7b", "lumina_tiny"):
         # PyTorch-ROCm SJD: the reference's data flow with ATen ops on the SAME weights, prefilled with the engine's
         # own accepted sequence up to the start of the timed region, so that both run at the same KV length

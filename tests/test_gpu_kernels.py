@@ -855,3 +855,90 @@ def test_k2_zero_state_skips_only_what_is_zero(dev):
             want = (r.forced, r.forced + 1) if r.forced >= 0 else ((min(r.lo[a] for a in range(r.n_ranges)), max(r.hi[a] for a in range(r.n_ranges))) if r.n_ranges else (0, V))
             assert tuple(st[i].tolist()) == want, (it, i, st[i].tolist(), want)
     assert (zst[n:] == -1).all() and (probs_s[n:] == -7.0).all()                          # rows beyond n_rows: untouched
+
+
+@pytest.mark.parametrize("n_slots,n_batch,fold", [(3, 2, True), (8, 2, False), (2, 1, True)])
+def test_slot_launches_equal_one_launch_per_slot(dev, n_slots, n_batch, fold):
+    """round 6, at the C-ABI: sjd_reguess_slots / sjd_logits_to_probs_sample_part_slots / sjd_verify_accept_slots over P slots with DIFFERENT row counts, rules,
+    KV lengths, generator seeds and states against the one-slot entry points called once per slot on a second, identical set of buffers: window ids and
+    position ids, probabilities (bit patterns), tokens, argmax rows, zero states and the whole state blobs after K4 -- device copy and pinned host mirror --
+    must be the same; two iterations, so that the second one verifies against the first one's rows."""
+    import copy
+    ops, L = _ops()
+    from oracle import sjd_oracle as O
+    V, Lmax, n_chunks, hidden = 9216, 16, 3, 1024
+    g = torch.Generator().manual_seed(100 * n_slots + n_batch)
+    prows = ops._prows(n_slots * n_batch * Lmax)
+    n_cols = 8224
+    part = ops.Partials((torch.randn(n_chunks, prows, n_cols, generator=g) * 1.5).to(dev), n_chunks, n_cols)
+    sumsq = (hidden / 4 * (0.5 + torch.rand(4, prows, generator=g))).to(dev)
+    head = ops.HeadOut(part, 0, Lmax if n_batch > 1 else 0, torch.bfloat16, row_norm=(sumsq, hidden, 1e-5) if fold else None)
+    ctx = [9000] * 9 + [8197, 8808, 8808]
+    sets = []
+    for which in range(2):          # 0: one launch per slot, 1: slot launches
+        params, state = ops.BlobArray(L.IterParams, n_slots, dev), ops.BlobArray(L.State, n_slots, dev)
+        probs = torch.zeros(n_slots, 2, Lmax, V, device=dev)
+        zst = torch.full((n_slots, 2, Lmax, 2), -1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(n_slots, V, device=dev)
+        ids = torch.zeros(n_slots * n_batch, Lmax, dtype=torch.int64, device=dev)
+        pos = torch.zeros(n_slots * n_batch, Lmax, dtype=torch.int64, device=dev)
+        poff = (-torch.arange(n_slots * n_batch, dtype=torch.int64) * 3).to(dev)
+        state.mirror_array()
+        sets.append(dict(params=params, state=state, probs=probs, zst=zst, scratch=scratch, ids=ids, pos=pos, poff=poff))
+    blocks = ops.philox_max_blocks(torch.device(dev))
+    for it in range(2):
+        cur = it & 1
+        for s_ in sets:
+            for i in range(n_slots):
+                n = [16, 9, 1, 12, 16, 5, 2, 13][i % 8] if it else [1, 1, 1, 1, 1, 1, 1, 1][i % 8]
+                p = s_["params"].blobs[i].view
+                rules = O.lumina_rules(ctx + [100 + i] * (3 * i + it), n, 2000, 10)
+                p.n_rows, p.kv_len, p.use_cfg, p.scheme, p.batch_rows, p.iter_seq = n, 12 + 5 * i + it, int(n_batch > 1), 0, n_batch, 7 + it
+                a = max(0, min(n - 1, (s_["state"].blobs[i].view.n_prev - s_["state"].blobs[i].view.m) if it else 0))
+                p.n_fresh = n - 1 - a
+                for j in range(p.n_fresh):
+                    p.fresh_tok[j] = 4 + (37 * i + 11 * j) % 8192
+                for j, r in enumerate(rules):
+                    p.rules[j] = to_dev_rule(L, ops, r)
+                    p.resid_rules[j] = to_dev_rule(L, ops, r)
+                step = ops.philox_step(n * V, blocks)
+                p.philox_blocks, p.philox_seed = blocks, 1000 + i
+                p.philox_offset[0], p.philox_offset[1], p.philox_offset[2] = 40 * it, 40 * it + step, 40 * it + 2 * step
+                if it == 0:
+                    st = s_["state"].blobs[i].view
+                    st.m, st.rejected, st.n_prev = 1, 0, 1
+                    st.tokens[0] = ctx[-1]
+            s_["params"].upload()
+            if it == 0:
+                s_["state"].upload()
+        a_, b_ = sets
+        # K5
+        for i in range(n_slots):
+            lo, hi = i * n_batch, (i + 1) * n_batch
+            ops.reguess(a_["params"].blobs[i], a_["state"].blobs[i], a_["ids"][lo:hi], pos_offset=a_["poff"][lo:hi], positions_out=a_["pos"][lo:hi])
+        sl = ops.slots_of(b_["params"], b_["state"], b_["probs"], b_["zst"], b_["scratch"], n_batch)
+        ops.reguess_slots(sl, b_["params"], b_["state"], b_["ids"], b_["poff"], b_["pos"], n_batch)
+        torch.cuda.synchronize()
+        assert torch.equal(a_["ids"], b_["ids"]) and torch.equal(a_["pos"], b_["pos"]), f"K5, iteration {it}"
+        # K2
+        for i in range(n_slots):
+            s0 = a_["state"].blobs[i]
+            ops.logits_to_probs_sample_part(head, 3.0, a_["params"].blobs[i], None, a_["probs"][i, cur], s0.field_ptr("tokens"), amax_out_ptr=s0.field_ptr("amax"),
+                                            row0=i * n_batch * Lmax, urow_off=Lmax if n_batch > 1 else 0, zero_state=a_["zst"][i, cur])
+        ops.logits_to_probs_sample_part_slots(sl, head, 3.0, b_["params"], b_["probs"], cur, "tokens", "amax", b_["state"], b_["zst"], n_batch)
+        torch.cuda.synchronize()
+        assert torch.equal(a_["probs"].view(torch.int32), b_["probs"].view(torch.int32)) and torch.equal(a_["zst"], b_["zst"]), f"K2, iteration {it}"
+        assert float(b_["probs"][:, cur].sum()) > n_slots - 0.5
+        # K4
+        for i in range(n_slots):
+            ops.verify_accept(a_["params"].blobs[i], a_["state"].blobs[i], a_["probs"][i, cur], a_["probs"][i, 1 - cur], None, None, a_["scratch"][i], mirror=True)
+        ops.verify_accept_slots(sl, b_["params"], b_["state"], b_["probs"], cur, b_["scratch"])
+        a_["state"].wait_mirror()
+        b_["state"].wait_mirror()
+        mir_a = bytes(a_["state"].host.numpy().tobytes())
+        mir_b = bytes(b_["state"].host.numpy().tobytes())
+        assert mir_a == mir_b, f"K4 (host mirrors), iteration {it}"
+        assert torch.equal(a_["state"].dev, b_["state"].dev), f"K4 (device states), iteration {it}"
+        for i in range(n_slots):
+            st = b_["state"].blobs[i].view
+            assert 1 <= st.m <= max(1, b_["params"].blobs[i].view.n_rows)

@@ -532,6 +532,19 @@ def roofline_blocks(args, prof, prof_g1, pair=None):
         if z:
             g1_name = g1_name.replace("g1_skinny_gemm", "g1z_skinny_gemm").replace("g1_gateup_silu", "g1z_gateup_silu")
         tr, src = traffic_of("g1z_traffic.json" if z else "g1_traffic.json")
+        rows_g1 = prof_g1.get("rows", 32)
+        if not z and rows_g1 > 32:
+            # windows of more than 32 rows on the uncompressed stream run on kernel G1w (round 6): its OWN PMC passes at the product launch shapes of
+            # 128 and 256 rows (profiles/g1w_traffic.json, tools/_r6_g1w_traffic.sh); other row counts have no committed pass: null, not another kernel's
+            g1_name = g1_name.replace("g1_skinny_gemm", "g1_wide (kernel G1w)")
+            tr = src = None
+            if args.model == "lumina7b" and rows_g1 in (128, 256):
+                try:
+                    t = json.load(open(os.path.join(ROOT, "profiles", "g1w_traffic.json")))
+                    tr = t[f"rows_{rows_g1}"]["hbm_bytes_per_launch"]
+                    src = f"profiles/g1w_traffic.json (rows_{rows_g1}): {t.get('source')} -- the builder's pass at these shapes, not this run"
+                except Exception:
+                    tr = src = None
         # `achieved` = ALGORITHMIC bytes per launch (the bf16 weight matrix N*K*2 + the activation rows) / the measured launch time.
         # With the lossless 12-bit stream the kernel MOVES fewer bytes than that (`traffic`, `stored_bytes`): the rate on the bytes actually
         # moved -- what the HBM pipe sees -- is reported next to it (`hbm_GBps_on_stored_bytes`, `frac_on_stored_bytes`).

@@ -80,7 +80,7 @@ template <int DT> __device__ __forceinline__ f32x16 gw_fake_mma(u32x4 a, u32x4 b
 // WPS = waves per SIMD the register budget is cut for (1: up to 512 registers; 2: 256 -- two workgroups of <= 4 waves per CU)
 template <int DT, int MT, int CT, int NW, int SUB, int NS, int RW, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void g1_wide(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp, float *__restrict__ out,
-                                                        int M, int N, int K, int KC, int n_tiles, int rec_stride, int tile0, int ldx)
+                                                        int M, int N, int K, int KC, int n_tiles, int rec_stride, int tile0, int ldx, int xmap)
 {
     static_assert(SUB == 2 || SUB == 4 || SUB == 8, "a stage is 2, 4 or 8 k-steps");
     static_assert(CT == 1 || CT == 2, "one or two column tiles per wave");
@@ -114,7 +114,27 @@ __global__ __launch_bounds__(64 * NW, WPS) void g1_wide(const unsigned short *__
     extern __shared__ __attribute__((aligned(1024))) unsigned char gw_lds[];       // NS slots, then 1 KiB of scratch
     SJD_TR(0);
     SJD_TR_CLK(4);             // (shader-clock stamps next to the 100 MHz wall-clock ones: the clock the launch actually ran at)
-    const int chunk = blockIdx.y;
+    // XCD-aware (column group, K chunk) of this workgroup.  Workgroup L = x + gridDim.x * y runs on XCD L mod 8, and every XCD has its own L2: with the
+    // plain (x, y) = (column group, chunk) map the workgroups of one chunk are spread over all eight XCDs, so every XCD's L2 holds the activation
+    // columns of EVERY chunk -- 5.6 MB for the down projection at 256 rows against 4 MB of L2: PMC showed 45 MB of activation re-reads going to HBM
+    // (profiles/g1w_traffic.json).  With a power-of-two chunk count the chunk follows the XCD instead (chunk = XCD mod n_chunks; sixteen and more
+    // chunks: XCD + 8 * ...), an XCD then re-reads 1 / min(8, n_chunks) of the activation.  Which workgroup computes which (tile, chunk) does not
+    // change any result.  xmap = 0: the plain map (A/B aid, SJD_G1W_XMAP=0).
+    int bx = blockIdx.x, chunk = blockIdx.y;
+    {
+        const int gx = gridDim.x, nc = gridDim.y;
+        if (xmap && nc > 1 && (nc & (nc - 1)) == 0) {
+            const int total = gx * nc, lin = bx + gx * chunk, full = total & ~7;
+            if (nc <= 8) {
+                const int per = 8 / nc, b0 = (full >> 3) * per;          // column groups covered by the whole rounds of eight workgroups
+                if (lin < full) { const int xcd = lin & 7, slot = lin >> 3; chunk = xcd % nc; bx = slot * per + xcd / nc; }
+                else { const int j = lin - full, rest = gx - b0; bx = b0 + j % rest; chunk = j / rest; }
+            } else if (total == full) {
+                const int q = nc >> 3, xcd = lin & 7, slot = lin >> 3;
+                chunk = xcd + 8 * (slot % q); bx = slot / q;
+            }
+        }
+    }
     const int k0 = chunk * KC;
     const int steps = min(KC, K - k0) / 16;
     const int n_stage = (steps + SUB - 1) / SUB;
@@ -125,7 +145,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void g1_wide(const unsigned short *__
     int t_out[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        t_out[c] = (blockIdx.x * NW + w) * CT + c;
+        t_out[c] = (bx * NW + w) * CT + c;
         const bool has = t_out[c] < N / 32;
         const int t = tile0 + (has ? t_out[c] : 0);
         const size_t tile_off = (rec_stride == 1) ? (size_t)t * steps : (size_t)t;
@@ -280,6 +300,10 @@ static int g1_wide_launch(const void *x, const void *w_packed, float *out, int M
     static_assert(lds <= 160 * 1024, "the activation ring must fit in LDS");
     auto kern = g1_wide<DT, MT, CT, NW, SUB, NS, RW, WPS>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles, step_major ? n_tiles : 1, tile0, ldx > 0 ? ldx : K);
+    // (the XCD-aware map pays where the activation outgrows an XCD's L2 share: eight prompts 6.75 -> 6.58 ms per step, two alternations on one box; at 128
+    //  rows and below it is neutral end to end and costs the gate|up launch 3 us alone: plain map there.  profiles/r6_g1w_xmap_ab.txt; SJD_G1W_XMAP=0 / 1 forces)
+    static const int xenv = [] { const char *e = getenv("SJD_G1W_XMAP"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    const int xmap = xenv >= 0 ? xenv : (MT > 4 ? 1 : 0);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles, step_major ? n_tiles : 1, tile0, ldx > 0 ? ldx : K, xmap);
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }

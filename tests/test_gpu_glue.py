@@ -179,7 +179,8 @@ def test_g1w_two_row_tiles(dev, dtype, M, N, K, KC, tiles, step_major):
 
 
 @pytest.mark.parametrize("M,N,K,KC", [(256, 4096, 11008, 1376), (192, 12288, 4096, 2048), (160, 22016, 4096, 2048), (224, 4096, 4096, 896), (130, 512, 1376, 256),
-                                        (256, 64, 96, 32), (255, 256, 176, 64), (256, 4096, 11008, 1408), (256, 12288, 4096, 832), (256, 352, 4096, 512)])
+                                        (256, 64, 96, 32), (255, 256, 176, 64), (256, 4096, 11008, 1408), (256, 12288, 4096, 832), (256, 352, 4096, 512),
+                                        (256, 4096, 11008, 688), (200, 2048, 4096, 128), (256, 1056, 1024, 256)])      # (16 / 32 / 4 chunks: every branch of the XCD-aware block map)
 @pytest.mark.parametrize("tiles,step_major", [(4, True), (4, False), (8, True), (8, False), (2, True), (3, False), (6, True)])
 def test_g1_skinny_gemm_five_to_eight_row_tiles(dev, M, N, K, KC, tiles, step_major):
     """129..256-row windows (five to eight prompts per forward): kernel G1w (round 6: activation stages by LDS-DMA, hand-counted vmcnt, one or two

@@ -589,6 +589,18 @@ def other_config(base_args, model_name, window, device, steps=64, warmup=8, dtyp
     eng = SJDEngine(model, margs.vocab_size, device, max_window=window, use_graph=not a.no_graph)
     lead = int(P + n_img // 2 - w["tau_est"] * (steps / 2.0 + warmup))
     sync = torch.cuda.synchronize
+    if not a.no_graph:
+        # untimed, as for the headline: the hipGraphs of both K1 regimes x both probability-buffer parities are captured before the clock starts.  (Until
+        # late round 6 a key first met inside the 64 timed steps was captured there: ~13 ms, +5 % on a 0.26 s window -- the legs read 3.83 or 3.98 ms
+        # for Emu3 in bf16 depending on where the window happened to start.)
+        pin0 = getattr(attn, "_pin_regime", None)
+        for pin in ("keysplit", "colsplit"):
+            if hasattr(attn, "_pin_regime"):
+                attn._pin_regime = pin
+            eng.decode(w["prompt"], w["spec"], copy.deepcopy(w["grammar"]), w["cfg"], warmup_iters=0, timed_iters=warmup + 8)
+        if hasattr(attn, "_pin_regime"):
+            attn._pin_regime = pin0
+        sync()
     seq, st = eng.decode(w["prompt"], w["spec"], w["grammar"], w["cfg"], warmup_iters=warmup, timed_iters=steps, on_timed_start=sync,
                          on_timed_end=sync, lead_in_kv=lead if lead > P + window else None)
     prof = measure_k1(a, model, attn, device, kv_len=(st.kv_len_start + st.kv_len) // 2)

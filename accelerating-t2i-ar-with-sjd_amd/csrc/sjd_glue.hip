@@ -356,6 +356,16 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
     const bool active = lane < HALF;
     float x0 = 0.f, x1 = 0.f;
     int kv_len = kv_len_arg;
+    // Late round 6: the per-head norm's gain / bias, the rotary frequency and the position are requested HERE, in front of the partial planes, and held
+    // (the empty asm below) -- by the ISA they used to be two more dependent round trips behind the plane sums: the norm parameters after the wave sums,
+    // inv_freq / positions in front of the sincos.  Same values, same arithmetic.
+    const unsigned short *gw_ = is_q ? qn_w : kn_w, *gb_ = is_q ? qn_b : kn_b;
+    const bool has_norm = gw_ != nullptr && (is_q || is_k);           // (wave-uniform)
+    const int la = active ? lane : 0;
+    unsigned short nw0 = 0, nw1 = 0, nb0 = 0, nb1 = 0;
+    if (has_norm) { nw0 = gw_[la]; nw1 = gw_[la + HALF]; nb0 = gb_[la]; nb1 = gb_[la + HALF]; }
+    const float ifr = inv_freq[la];
+    const long posv = positions[tok];
     if (part) {                                               // fp32 split-K partials of the qkv projection (G1)
         // Entry sequence written for the memory system (ISA, late round 2: the kernel used to run through five dependent round trips --
         // two batches of kernel arguments, batch_rows, kv_len as a vector load with a full wait, the row statistics -- before the partial
@@ -398,6 +408,9 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
         }
         int n_unused_ = 0;
         if (params) sjdi_kv_rows(params, b, &kv_len, &n_unused_);
+#ifndef F2_NO_PIN          // (A/B aid: without the pin the compiler sinks the early loads back to their uses -- the round-5 schedule)
+        asm volatile("" :: "v"(nw0), "v"(nw1), "v"(nb0), "v"(nb1), "v"(ifr), "s"(posv));      // (keeps the early loads early: the compiler sinks them to their uses otherwise)
+#endif
         float ss_tot = 0.f;                                   // row_sumsq_total: batches of eight slices in order, missing slices add zero
 #pragma unroll
         for (int q = 0; q < 8; ++q) ss_tot += (q < rs_slices) ? ssv[q] : 0.f;
@@ -459,7 +472,6 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
         }
         return;
     }
-    const unsigned short *gw_ = is_q ? qn_w : kn_w, *gb_ = is_q ? qn_b : kn_b;
     if (gw_ != nullptr) {                                     // per-head LayerNorm over head_dim (eps 1e-5)
         const float mean = wave_sum(active ? x0 + x1 : 0.f) / (float)D;
         const float d0 = x0 - mean, d1 = x1 - mean;
@@ -468,14 +480,14 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append(
         if (active) {
             // F.layer_norm output and the gamma/beta affine both round to the activation dtype in the reference
             const float n0 = Cvt<DT>::to_f(Cvt<DT>::from_f(d0 * inv)), n1 = Cvt<DT>::to_f(Cvt<DT>::from_f(d1 * inv));
-            x0 = Cvt<DT>::to_f(Cvt<DT>::from_f(n0 * Cvt<DT>::to_f(gw_[lane]))) + Cvt<DT>::to_f(gb_[lane]);
-            x1 = Cvt<DT>::to_f(Cvt<DT>::from_f(n1 * Cvt<DT>::to_f(gw_[lane + HALF]))) + Cvt<DT>::to_f(gb_[lane + HALF]);
+            x0 = Cvt<DT>::to_f(Cvt<DT>::from_f(n0 * Cvt<DT>::to_f(nw0))) + Cvt<DT>::to_f(nb0);
+            x1 = Cvt<DT>::to_f(Cvt<DT>::from_f(n1 * Cvt<DT>::to_f(nw1))) + Cvt<DT>::to_f(nb1);
             x0 = Cvt<DT>::to_f(Cvt<DT>::from_f(x0));
             x1 = Cvt<DT>::to_f(Cvt<DT>::from_f(x1));
         }
     }
     if (active) {
-        const float ang = (float)positions[tok] * inv_freq[lane];
+        const float ang = (float)posv * ifr;
         float sn, cs;
         sincosf(ang, &sn, &cs);
         cs = Cvt<DT>::to_f(Cvt<DT>::from_f(cs));              // cos/sin are cast to the activation dtype (:110)
@@ -522,6 +534,14 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append_rows(
     const float q8 = is_k ? k_inv : v_inv;
     const bool active = lane < HALF;
     const size_t ncol = (size_t)heads * D, col = (size_t)hh0 * D + (active ? lane : 0);
+    // (the norm parameters, the rotary frequency and the position in front of the planes: see f2_qknorm_rope_append)
+    const unsigned short *gw_ = is_q ? qn_w : kn_w, *gb_ = is_q ? qn_b : kn_b;
+    const bool has_norm = gw_ != nullptr && (is_q || is_k);
+    const int la = active ? lane : 0;
+    unsigned short nw0 = 0, nw1 = 0, nb0 = 0, nb1 = 0;
+    if (has_norm) { nw0 = gw_[la]; nw1 = gw_[la + HALF]; nb0 = gb_[la]; nb1 = gb_[la + HALF]; }
+    const float ifr = inv_freq[la];
+    const long posv = positions[tok];
     float ssv[8];
     const float *ssp = row_sumsq ? row_sumsq : part;
 #pragma unroll
@@ -546,6 +566,9 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append_rows(
     }
     int kv_len = kv_len_arg, n_unused_ = 0;
     if (params) sjdi_kv_rows(params, b, &kv_len, &n_unused_);
+#ifndef F2_NO_PIN
+    asm volatile("" :: "v"(nw0), "v"(nw1), "v"(nb0), "v"(nb1), "v"(ifr), "s"(posv));
+#endif
     float ss_tot = 0.f;                                       // row_sumsq_total's order
 #pragma unroll
     for (int q = 0; q < 8; ++q) ss_tot += (q < rs_slices) ? ssv[q] : 0.f;
@@ -579,10 +602,8 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append_rows(
         }
         return;
     }
-    const unsigned short *gw_ = is_q ? qn_w : kn_w, *gb_ = is_q ? qn_b : kn_b;
     if (gw_ != nullptr) {                                     // per-head LayerNorm over head_dim (eps 1e-5)
-        const int la = active ? lane : 0;
-        const float w0 = Cvt<DT>::to_f(gw_[la]), w1 = Cvt<DT>::to_f(gw_[la + HALF]), b0 = Cvt<DT>::to_f(gb_[la]), b1 = Cvt<DT>::to_f(gb_[la + HALF]);
+        const float w0 = Cvt<DT>::to_f(nw0), w1 = Cvt<DT>::to_f(nw1), b0 = Cvt<DT>::to_f(nb0), b1 = Cvt<DT>::to_f(nb1);
 #pragma unroll
         for (int j = 0; j < HPW; ++j) {
             const float mean = wave_sum(active ? x0[j] + x1[j] : 0.f) / (float)D;
@@ -599,7 +620,7 @@ __global__ __launch_bounds__(256) void f2_qknorm_rope_append_rows(
         }
     }
     if (active) {
-        const float ang = (float)positions[tok] * inv_freq[lane];
+        const float ang = (float)posv * ifr;
         float sn, cs;
         sincosf(ang, &sn, &cs);
         cs = Cvt<DT>::to_f(Cvt<DT>::from_f(cs));

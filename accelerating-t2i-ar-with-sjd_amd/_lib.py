@@ -77,7 +77,7 @@ EXPORTS = ["sjd_version", "sjd_error_string", "sjd_reguess", "sjd_logits_to_prob
 EXP_EXPORTS = ["sjd_weight_prefetch", "sjd_qkv_attention_fused", "sjd_qkv_attention_fused_split", "sjd_skinny_gemm_reduce", "sjd_reduce_timeouts",
                "sjd_draft_window_attention_merged", "sjd_draft_window_attention_fp8_merged", "sjd_mlp_pair_z", "sjd_mlp_pair_timeouts",
                "sjd_l2_head_gemm_z", "sjd_l2_head_gateup_z", "sjd_l2_head_bytes", "sjd_weight_prefetch_head", "sjd_debug_xcc_map", "sjd_residual_sumsq_pf",
-               "sjd_skinny_gemm_engine_z", "sjd_engine_timeouts", "sjd_skinny_gemm_wide", "sjd_o_merge_prologue_probe"]
+               "sjd_skinny_gemm_engine_z", "sjd_engine_timeouts", "sjd_skinny_gemm_wide", "sjd_o_merge_prologue_probe", "sjd_skinny_gemm_z_wide"]
 EXP_SO_PATH = os.environ.get("SJD_HIP_EXP_LIB") or os.path.join(_HERE, "libsjd_hip_exp.so")
 
 _lib = None
@@ -174,6 +174,7 @@ def load_exp():
     lib.sjd_draft_window_attention_merged.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.sjd_draft_window_attention_fp8_merged.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp, vp, vp]
     lib.sjd_o_merge_prologue_probe.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.sjd_skinny_gemm_z_wide.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sjd_mlp_pair_z.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, ctypes.POINTER(RowNorm), vp, i32, vp]
     lib.sjd_weight_prefetch.argtypes = [vp, i64, i32, vp, vp]
     lib.sjd_qkv_attention_fused.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(RowNorm),

@@ -627,7 +627,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MT <= 4) ? 2 : 1) void g1_skin
         }
 }
 
-#include "sjd_gemm_wide.h"
 
 #ifdef SJD_EXPERIMENTAL        // weight prefetch / L2 head pulls (rounds 2 and 5, measured no-go) and the XCC map probe
 // ------------------------------------------------------------------------------------------------ weight prefetch
@@ -1118,6 +1117,8 @@ __device__ __forceinline__ g1z_pair g1z_load(__amdgpu_buffer_rsrc_t wr, unsigned
     v.c = __builtin_amdgcn_raw_buffer_load_b64(wr, 1024u + lane * 8u, soff, G1Z_AUX);
     return v;
 }
+
+#include "sjd_gemm_wide.h"          // (kernel G1w: behind the declarations of the 12-bit decode it shares with G1z)
 
 template <int SP, bool WIDE>
 __global__ __launch_bounds__(512) void g1z_gateup_silu(const unsigned short *__restrict__ x, const unsigned char *__restrict__ wz,
@@ -2145,6 +2146,38 @@ extern "C" int sjd_skinny_gemm_reduce(const void *x, const void *w_packed, float
                            M, N, K, KC, n_out, rs, 0, waves, (unsigned short *)h, sumsq, ticket);
     } else return SJD_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+// Kernel G1w over the 12-bit stream (late round 6 experiment, csrc/sjd_gemm_wide.h `Z`): bit-identical planes, measured SLOWER than what the product runs
+// (the decode costs a one-wave-per-SIMD kernel more issue slots than the 25 % of weight bytes buy: 256 rows q|k|v 44.2 against 35.3 us on the uncompressed
+// stream, gate|up 71.3 / 56.8; 64 rows: level with G1z except the o projection, 9.3 / 10.7 us; profiles/r6_g1wz_sweep_*.jsonl).  tiles: 2, 3, 4, 6, 8 column
+// tiles per workgroup; 33..256 rows; raw units are left to sjd_raw_units_fixup.
+extern "C" int sjd_skinny_gemm_z_wide(const void *x, const void *wz, const void *exc, int exc_cap, float *out, int M, int N, int K, int KC, int tiles,
+                                      int step_major, int N_packed, int tile0, void *stream)
+{
+    if (!(exc_cap == 32 || exc_cap == 64 || exc_cap == 128)) return SJD_ERR_BAD_ARG;
+    if (!x || !wz || !exc || !out || M < 33 || M > 256 || N < 32 || (N % 32) != 0 || (N_packed % 32) != 0 || (K % 16) != 0 || KC < 16 || (KC % 16) != 0 || KC > 4096)
+        return SJD_ERR_BAD_ARG;
+    const int waves = tiles, n_out = N / 32, n_tiles = N_packed / 32, MT = (M + 31) / 32;
+    if (tile0 < 0 || tile0 + n_out > n_tiles) return SJD_ERR_BAD_ARG;
+    if (!(waves == 2 || waves == 3 || waves == 4 || waves == 6 || waves == 8) || (MT == 3 && waves == 2)) return SJD_ERR_BAD_ARG;
+    hipStream_t s_ = (hipStream_t)stream;
+#define SJD_G1WZ_T(MT_, WPS_) do { switch (waves) { \
+        case 2: if constexpr (MT_ != 3) return g1_wide_launch_z<MT_, 1, 2, 4, 3, 2, WPS_>(x, wz, exc, exc_cap, out, M, N, K, KC, n_tiles, step_major, tile0, s_); else return SJD_ERR_BAD_ARG; \
+        case 3: return g1_wide_launch_z<MT_, 1, 3, 4, 3, 2, WPS_>(x, wz, exc, exc_cap, out, M, N, K, KC, n_tiles, step_major, tile0, s_); \
+        case 4: return g1_wide_launch_z<MT_, 1, 4, 4, 3, 2, WPS_>(x, wz, exc, exc_cap, out, M, N, K, KC, n_tiles, step_major, tile0, s_); \
+        case 6: return g1_wide_launch_z<MT_, 2, 3, 4, 3, 2, WPS_>(x, wz, exc, exc_cap, out, M, N, K, KC, n_tiles, step_major, tile0, s_); \
+        default: return g1_wide_launch_z<MT_, 2, 4, 4, 3, 2, WPS_>(x, wz, exc, exc_cap, out, M, N, K, KC, n_tiles, step_major, tile0, s_); } } while (0)
+    switch (MT) {
+    case 2: SJD_G1WZ_T(2, 2);
+    case 3: SJD_G1WZ_T(3, 1);
+    case 4: SJD_G1WZ_T(4, 1);
+    case 5: SJD_G1WZ_T(5, 1);
+    case 6: SJD_G1WZ_T(6, 1);
+    case 7: SJD_G1WZ_T(7, 1);
+    default: SJD_G1WZ_T(8, 1);
+    }
+#undef SJD_G1WZ_T
 }
 
 // G1w tuning entry (tools/g1w_bench.py): bf16; M <= 128 runs four row tiles, M <= 256 eight; tiles = column tiles per workgroup (2, 3, 4: one per

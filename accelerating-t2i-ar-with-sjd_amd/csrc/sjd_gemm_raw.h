@@ -127,7 +127,7 @@ extern "C" int sjd_raw_units_fixup(const void *x, const void *raw, const int32_t
                                    int tile0, int dtype, void *stream)
 {
     if (n_raw == 0) return SJD_OK;
-    if (!x || !raw || !index || !out || n_raw < 0 || M < 1 || M > 128 || N < 32 || (N % 32) || (K % 16) || KC < 16 || (KC % 16) || tile0 < 0) return SJD_ERR_BAD_ARG;
+    if (!x || !raw || !index || !out || n_raw < 0 || M < 1 || M > 256 || N < 32 || (N % 32) || (K % 16) || KC < 16 || (KC % 16) || tile0 < 0) return SJD_ERR_BAD_ARG;
     if (dtype != SJD_DTYPE_BF16) return SJD_ERR_UNSUPPORTED;
     const int mt = (M + 31) / 32;
     hipLaunchKernelGGL((g1_raw_units<SJD_DTYPE_BF16>), dim3(n_raw, mt), dim3(64), 0, (hipStream_t)stream, (const unsigned short *)x, (const u32x4 *)raw,

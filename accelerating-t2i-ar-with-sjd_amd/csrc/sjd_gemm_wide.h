@@ -55,6 +55,23 @@ __device__ __forceinline__ void gw_dma16(u32x4 rsrc, unsigned voff, unsigned sof
                  : "memory");
 }
 
+// (12-bit form, late round 6) the waits that tie a record pair's registers / a unit header's registers
+template <int N> __device__ __forceinline__ void gw_wait_regs(u32x4 &a, u32x2 &b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void gw_wait_regs(u32x2 &a, u32x2 &b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+// the codes of a record pair (64 lanes x 8 B), and one header entry per lane: like gw_wload, issued by hand and counted by hand
+__device__ __forceinline__ u32x2 gw_wload2(u32x4 rsrc, unsigned voff, unsigned soff)
+{
+    u32x2 r;
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen nt" : "=v"(r) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return r;
+}
+__device__ __forceinline__ u32x2 gw_gload2(const void *p)
+{
+    u32x2 r;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+
 // one weight record (1 KiB per wave) into B-operand registers, non-temporal (streamed once); NOT waited for by the compiler
 __device__ __forceinline__ u32x4 gw_wload(u32x4 rsrc, unsigned voff, unsigned soff)
 {
@@ -78,10 +95,19 @@ template <int DT> __device__ __forceinline__ f32x16 gw_fake_mma(u32x4 a, u32x4 b
 #endif
 // MT row tiles (rows = 32 MT), CT column tiles per wave, NW waves (column groups) per workgroup, stages of SUB k-steps, NS ring slots,
 // WPS = waves per SIMD the register budget is cut for (1: up to 512 registers; 2: 256 -- two workgroups of <= 4 waves per CU)
-template <int DT, int MT, int CT, int NW, int SUB, int NS, int RW, int WPS>
+// Z (late round 6): the weights arrive as the LOSSLESS 12-bit stream of kernels G1z / G1sz (csrc/sjd_gemm.hip: 1536-byte record PAIRS of two k-steps --
+// 64 lanes x 16 B of low bytes, 64 lanes x 8 B of codes -- and a header of exceptions per (chunk, tile) unit) and are decoded into the SAME B operands
+// in front of their MFMAs (g1z_operand): bit-identical planes, 25 % fewer weight bytes.  One vector-memory operation per tile and k-step as before -- the
+// low bytes of the pair R k-steps ahead behind an even k-step's last MFMA, its codes behind the odd one's -- so the hand counts stand; an even k-step
+// decodes BOTH operands of its pair (its registers are then free for the refill) and waits one group less deep (the codes are one k-step younger than the
+// low bytes); an odd k-step waits for nothing.  The unit headers are requested in front of the prologue and waited for behind it without draining it.
+// WIDE: headers of 128 entries.  Raw units (a header count of -1) decode to garbage here: the caller runs sjd_raw_units_fixup behind the launch.
+template <int DT, int MT, int CT, int NW, int SUB, int NS, int RW, int WPS, bool Z = false, bool WIDE = false>
 __global__ __launch_bounds__(64 * NW, WPS) void g1_wide(const unsigned short *__restrict__ x, const u32x4 *__restrict__ wp, float *__restrict__ out,
-                                                        int M, int N, int K, int KC, int n_tiles, int rec_stride, int tile0, int ldx, int xmap)
+                                                        int M, int N, int K, int KC, int n_tiles, int rec_stride, int tile0, int ldx, int xmap,
+                                                        const u32x2 *__restrict__ exc, int exc_cap)
 {
+    static_assert(!Z || (DT == SJD_DTYPE_BF16 && SUB % 2 == 0 && (RW * SUB) % 2 == 0), "the 12-bit stream: bf16, whole record pairs per stage and ring");
     static_assert(SUB == 2 || SUB == 4 || SUB == 8, "a stage is 2, 4 or 8 k-steps");
     static_assert(CT == 1 || CT == 2, "one or two column tiles per wave");
     // The weight ring is RW stages (R k-steps) deep, the activation ring LA = NS - 1 stages ahead.  LA > RW matters: vmcnt retires in order, so the
@@ -139,21 +165,31 @@ __global__ __launch_bounds__(64 * NW, WPS) void g1_wide(const unsigned short *__
     const int steps = min(KC, K - k0) / 16;
     const int n_stage = (steps + SUB - 1) / SUB;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned rsb = (unsigned)rec_stride * 1024u;
-    const size_t chunk_base = (size_t)chunk * n_tiles * (KC / 16);
+    const unsigned rsb = (unsigned)rec_stride * (Z ? 1536u : 1024u);
+    const int pairs = (steps + 1) / 2, pairs_full = (KC / 16 + 1) / 2;          // (Z) record pairs of this unit / of a full chunk's unit
+    const size_t chunk_base = (size_t)chunk * n_tiles * (Z ? pairs_full : KC / 16);
     u32x4 wr[CT];
     int t_out[CT];
+    [[maybe_unused]] u32x2 hra[CT], hrb[CT];                                     // (Z) this lane's header entries of the tiles' units
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         t_out[c] = (bx * NW + w) * CT + c;
         const bool has = t_out[c] < N / 32;
         const int t = tile0 + (has ? t_out[c] : 0);
-        const size_t tile_off = (rec_stride == 1) ? (size_t)t * steps : (size_t)t;
+        if constexpr (Z) {
+            const size_t tile_off = (rec_stride == 1) ? (size_t)t * pairs : (size_t)t;
+            wr[c] = gw_rsrc(reinterpret_cast<const unsigned char *>(wp) + (chunk_base + tile_off) * 1536, has ? (unsigned)(pairs - 1) * rsb + 1536u : 0u);
+            const u32x2 *e = exc + ((size_t)chunk * n_tiles + t) * (size_t)exc_cap;
+            hra[c] = gw_gload2(e + min(lane, exc_cap - 1));
+            if constexpr (WIDE) hrb[c] = gw_gload2(e + 64 + lane); else hrb[c] = u32x2{0xffffffffu, 0xffffffffu};
+        } else {
+            const size_t tile_off = (rec_stride == 1) ? (size_t)t * steps : (size_t)t;
 #ifdef GW_NO_W            // (timing probe, results invalid: no weight stream -- every record out of range)
-        wr[c] = gw_rsrc(wp + (chunk_base + tile_off) * 64, 0u);
+            wr[c] = gw_rsrc(wp + (chunk_base + tile_off) * 64, 0u);
 #else
-        wr[c] = gw_rsrc(wp + (chunk_base + tile_off) * 64, has ? (unsigned)(steps - 1) * rsb + 1024u : 0u);      // (no tile: every record reads as zero)
+            wr[c] = gw_rsrc(wp + (chunk_base + tile_off) * 64, has ? (unsigned)(steps - 1) * rsb + 1024u : 0u);      // (no tile: every record reads as zero)
 #endif
+        }
     }
     const u32x4 xr = gw_rsrc(x, (unsigned)M * (unsigned)ldx * 2u);      // (ldx: row stride of x in elements, >= K)
     const unsigned lds0 = gw_lds_addr(gw_lds);
@@ -196,7 +232,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void g1_wide(const unsigned short *__
         const unsigned voff = (int)xcol[i] < chunk_cols - sa * (SUB * 16) ? xoff[i] : 0x7fff0000u;
         gw_dma16(xr, voff, soff, dst);
     };
-    u32x4 W[CT][R];
+    u32x4 W[CT][Z ? R / 2 : R];              // plain: one record per k-step of the ring; Z: the low bytes of one record pair per two k-steps
+    [[maybe_unused]] u32x2 WC[CT][R / 2];    // (Z) ... and its codes
+    [[maybe_unused]] u32x4 Bn[CT];           // (Z) the odd k-step's operand, decoded with the even one's
+    // (Z) record load of ring k-step ks: even -> the pair's low bytes, odd -> its codes
+    auto z_load = [&](int c, int ks_ring, unsigned pair_abs) {
+        if ((ks_ring & 1) == 0) W[c][ks_ring >> 1] = gw_wload(wr[c], wvoff, pair_abs * rsb);
+        else WC[c][ks_ring >> 1] = gw_wload2(wr[c], 1024u + (unsigned)lane * 8u, pair_abs * rsb);
+    };
     f32x16 acc[CT][MT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -215,12 +258,23 @@ __global__ __launch_bounds__(64 * NW, WPS) void g1_wide(const unsigned short *__
             const int ks = (v - (LA - RW)) * SUB + u;         // k-step of this group's records
 #pragma unroll
             for (int c = 0; c < CT - 1; ++c) {
-                if (ks >= 0) W[c][ks] = gw_wload(wr[c], wvoff, (unsigned)ks * rsb); else gw_dma16(xr, 0x7fff0000u, 0u, scratch);
+                if (ks >= 0) { if constexpr (Z) z_load(c, ks, (unsigned)(ks >> 1)); else W[c][ks] = gw_wload(wr[c], wvoff, (unsigned)ks * rsb); }
+                else gw_dma16(xr, 0x7fff0000u, 0u, scratch);
             }
 #pragma unroll
             for (int d = 0; d < DPK; ++d) dma_piece(v, piece0 + (unsigned)(v * SLOT), u, d);
-            if (ks >= 0) W[CT - 1][ks] = gw_wload(wr[CT - 1], wvoff, (unsigned)ks * rsb); else gw_dma16(xr, 0x7fff0000u, 0u, scratch);
+            if (ks >= 0) { if constexpr (Z) z_load(CT - 1, ks, (unsigned)(ks >> 1)); else W[CT - 1][ks] = gw_wload(wr[CT - 1], wvoff, (unsigned)ks * rsb); }
+            else gw_dma16(xr, 0x7fff0000u, 0u, scratch);
         }
+    // (Z) the unit headers: requested in front of the prologue, complete once no more than the prologue's own LA * SUB * GRP operations are outstanding
+    [[maybe_unused]] g1z_hdr hd[CT];
+    if constexpr (Z) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            gw_wait_regs<LA * SUB * GRP>(hra[c], hrb[c]);
+            hd[c] = g1z_header<WIDE>(g1z_hraw{hra[c], hrb[c]}, lane, exc_cap);
+        }
+    }
     SJD_TR(1);
     // one k-step: the MFMAs in tile-major order, ONE other instruction group behind each of them (a single wave per SIMD issues in order: what is
     // not placed between two MFMAs is not hidden by them -- the first version issued its 16 MFMAs back to back and then ~45 other instructions:
@@ -231,13 +285,28 @@ __global__ __launch_bounds__(64 * NW, WPS) void g1_wide(const unsigned short *__
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             const int c = i / MT, mt = i % MT;
-            if (mt == 0) {
-                if (c == CT - 1) gw_wait_regs<N_WL>(W[c][r]); else gw_wait_regs<N_W0>(W[c][r]);
+            u32x4 b;
+            if constexpr (Z) {
+                if (mt == 0 && (r & 1) == 0) {            // an even k-step: both loads of its pair have landed once one group fewer is outstanding
+                    if (c == CT - 1) gw_wait_regs<N_WL - GRP>(W[c][r >> 1], WC[c][r >> 1]); else gw_wait_regs<N_W0 - GRP>(W[c][r >> 1], WC[c][r >> 1]);
+                    const unsigned s_abs = (unsigned)(st * SUB + u);
+                    Bn[c] = g1z_operand<WIDE>(W[c][r >> 1].z, W[c][r >> 1].w, WC[c][r >> 1].y, s_abs + 1u, hd[c], lane);
+                    W[c][r >> 1] = g1z_operand<WIDE>(W[c][r >> 1].x, W[c][r >> 1].y, WC[c][r >> 1].x, s_abs, hd[c], lane);      // (held in the pair's own registers until its last MFMA)
+                }
+                b = (r & 1) == 0 ? W[c][r >> 1] : Bn[c];
+            } else {
+                if (mt == 0) {
+                    if (c == CT - 1) gw_wait_regs<N_WL>(W[c][r]); else gw_wait_regs<N_W0>(W[c][r]);
+                }
+                b = W[c][r];
             }
-            acc[c][mt] = GW_MMA(a[u & 1][mt], W[c][r], acc[c][mt]);
+            acc[c][mt] = GW_MMA(a[u & 1][mt], b, acc[c][mt]);
             if (i < MT && u + 1 < SUB) a[(u + 1) & 1][i] = *reinterpret_cast<const u32x4 *>(sl + i * (32 * ROWB) + aoff[u + 1]);
             if (i >= D0 && ((i - D0) % DSTR) == 0 && (i - D0) / DSTR < DPK) dma_piece(st + LA, sb_refill, u, (i - D0) / DSTR);
-            if (mt == MT - 1) W[c][r] = gw_wload(wr[c], wvoff, (unsigned)(st * SUB + u + R) * rsb);
+            if (mt == MT - 1) {
+                if constexpr (Z) z_load(c, r, (unsigned)((st * SUB + u + R) >> 1));
+                else W[c][r] = gw_wload(wr[c], wvoff, (unsigned)(st * SUB + u + R) * rsb);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -304,6 +373,28 @@ static int g1_wide_launch(const void *x, const void *w_packed, float *out, int M
     //  rows and below it is neutral end to end and costs the gate|up launch 3 us alone: plain map there.  profiles/r6_g1w_xmap_ab.txt; SJD_G1W_XMAP=0 / 1 forces)
     static const int xenv = [] { const char *e = getenv("SJD_G1W_XMAP"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
     const int xmap = xenv >= 0 ? xenv : (MT > 4 ? 1 : 0);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles, step_major ? n_tiles : 1, tile0, ldx > 0 ? ldx : K, xmap);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)w_packed, out, M, N, K, KC, n_tiles, step_major ? n_tiles : 1, tile0, ldx > 0 ? ldx : K, xmap,
+                       (const u32x2 *)nullptr, 0);
+    return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
+}
+
+// the same over the 12-bit stream (wz: record pairs, exc: unit headers of exc_cap entries); bf16
+template <int MT, int CT, int NW, int SUB, int NS, int RW, int WPS>
+static int g1_wide_launch_z(const void *x, const void *wz, const void *exc, int exc_cap, float *out, int M, int N, int K, int KC, int n_tiles, int step_major, int tile0,
+                            hipStream_t s)
+{
+    const int n_out = N / 32, n_chunks = (K + KC - 1) / KC;
+    const dim3 grid((n_out + NW * CT - 1) / (NW * CT), n_chunks), block(64 * NW);
+    constexpr size_t lds = g1_wide_lds<MT, SUB, NS>();
+    static_assert(lds <= 160 * 1024, "the activation ring must fit in LDS");
+    static const int xenv = [] { const char *e = getenv("SJD_G1W_XMAP"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    const int xmap = xenv >= 0 ? xenv : (MT > 4 ? 1 : 0);
+#define SJD_G1WZ(WIDE_) do { \
+        auto kern = g1_wide<SJD_DTYPE_BF16, MT, CT, NW, SUB, NS, RW, WPS, true, WIDE_>; \
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (const unsigned short *)x, (const u32x4 *)wz, out, M, N, K, KC, n_tiles, step_major ? n_tiles : 1, tile0, K, xmap, \
+                           (const u32x2 *)exc, exc_cap); } while (0)
+    if (exc_cap > 64) SJD_G1WZ(true); else SJD_G1WZ(false);
+#undef SJD_G1WZ
     return hipGetLastError() == hipSuccess ? SJD_OK : SJD_ERR_LAUNCH;
 }

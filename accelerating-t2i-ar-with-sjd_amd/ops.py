@@ -666,6 +666,23 @@ def skinny_gemm_cols(x, w_packed, N_packed, K, KC, col0, n_cols, waves=8, step_m
     return Partials(out, nc, n_cols)
 
 
+def skinny_gemm_z_wide(x, w_packed, tiles, col0=0, n_cols=None):
+    """EXPERIMENTAL (libsjd_hip_exp.so; late round 6): kernel G1w over the 12-bit stream -- x [33..256, K] bf16, w_packed a PackedZ, `tiles` = 2, 3, 4, 6 or 8
+    column tiles per workgroup -> Partials bit-identical to skinny_gemm_cols on the same packing (raw units through the fix-up launch).  Measured slower
+    than the product's kernels: kept for its test and tools/g1wz_sweep.py."""
+    assert isinstance(w_packed, PackedZ) and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[1] == w_packed.K
+    M, K, KC = x.shape[0], w_packed.K, w_packed.KC
+    n = (w_packed.N - col0) if n_cols is None else n_cols
+    nc = (K + KC - 1) // KC
+    out = torch.empty(nc, _prows(M), n, dtype=torch.float32, device=x.device)
+    L.check(L.load_exp().sjd_skinny_gemm_z_wide(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), w_packed.cap, _ptr(out), M, n, K, KC, int(tiles),
+                                               int(w_packed.step_major), w_packed.N, col0 // 32, _stream()), "sjd_skinny_gemm_z_wide")
+    if w_packed.n_raw:
+        L.check(L.load().sjd_raw_units_fixup(_ptr(x), _ptr(w_packed.raw_data), _ptr(w_packed.raw_index), w_packed.n_raw, _ptr(out), M, n, K, KC,
+                                            col0 // 32, _dtype_code(x.dtype), _stream()), "sjd_raw_units_fixup")
+    return Partials(out, nc, n)
+
+
 class HeadOut:
     """What a backbone hands to K2 instead of logits: the lm_head split-K partials of the window (cond rows [0, n), uncond rows
     [urow_off, urow_off + n)), their vocabulary column window and the folded final-norm row statistics."""

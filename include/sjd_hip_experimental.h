@@ -130,6 +130,13 @@ int sjd_reduce_timeouts(void);
 int sjd_skinny_gemm_wide(const void *x, const void *w_packed, float *out, int M, int N, int K, int KC, int tiles, int step_major, int variant,
                          int ldx, void *stream);
 
+/* Kernel G1w over the 12-bit weight stream (late round 6 experiment; csrc/sjd_gemm_wide.h, template parameter Z): sjd_skinny_gemm_z's planes, bit for bit,
+ * for windows of 33..256 rows with `tiles` = 2, 3, 4, 6 or 8 column tiles per workgroup.  Measured slower than the product's choices at every row count but
+ * for the o projection at 64 rows.  Raw units: run sjd_raw_units_fixup behind it.  replaces, like G1z: the nn.Linear calls of the decoder
+ * layer (reference modeling_chameleon.py:527-529, 579, 193-195). */
+int sjd_skinny_gemm_z_wide(const void *x, const void *wz, const void *exc, int exc_cap, float *out, int M, int N, int K, int KC, int tiles, int step_major,
+                           int N_packed, int tile0, void *stream);
+
 /* round-6 gate probe for "the o projection consumes K1's split partials" (VERDICT r5 next #4): the would-be staging prologue alone, on the o
  * projection's grid (csrc/sjd_gemm.hip::o_merge_prologue_probe).  part: fp32 [32 heads][n_split][rows][130]; mode 0 = empty body, 1 = merge. */
 int sjd_o_merge_prologue_probe(const float *part, float *sink, int n_split, int rows, int mode, void *stream);

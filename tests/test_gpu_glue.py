@@ -729,6 +729,35 @@ def test_g1sz_raw_pairs_match_g1s_bit_for_bit(dev, kind, T, inter, hidden, step_
     assert torch.equal(pa.data, pz.data)
 
 
+@pytest.mark.parametrize("M,N,K,KC,tiles,step_major", [
+    (256, 12288, 4096, 2048, 4, True), (160, 4096, 11008, 1408, 4, True), (256, 22016, 4096, 2048, 8, True), (200, 4096, 4096, 1024, 2, False),
+    (130, 512, 1376, 272, 3, False), (64, 4096, 11008, 688, 6, True), (48, 256, 176, 48, 2, True), (256, 1056, 4096, 4096, 3, True), (96, 6144, 4096, 1024, 4, True),
+    (64, 6144, 4096, 512, 3, True), (128, 8224, 4096, 1024, 8, True)])
+@pytest.mark.parametrize("kind", ["gauss", "outliers", "wide_headers", "raw"])
+def test_g1w_over_the_12bit_stream_experimental(dev, M, N, K, KC, tiles, step_major, kind):
+    """late round 6 experiment (libsjd_hip_exp.so: sjd_skinny_gemm_z_wide; measured slower than the product's kernels): kernel G1w decoding the
+    12-bit record pairs in front of its MFMAs -- the same planes as G1 over the uncompressed packing, bit for bit: 33..256 rows, every tile count, odd k-step
+    counts per chunk (a half-empty last pair), ragged chunks, one K chunk, both record orders, headers of 128 exceptions, raw units (through the fix-up
+    launch), a column window."""
+    import sjd_amd.ops as ops
+    g = torch.Generator().manual_seed(N + K + M)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    if kind == "raw":
+        w = _hostile_weights("zero_rows", N, K, g).to(dev)
+    else:
+        w = _z_weight(N, K, g, dev, {"gauss": 0, "outliers": 300, "wide_headers": 3000}[kind])
+    wp, wz = ops.pack_weight(w, KC, step_major), ops.pack_weight_z(w, KC, step_major)
+    assert wz is not None and (kind != "raw" or wz.n_raw > 0)
+    ref = ops.skinny_gemm(x, wp, N, K, KC, tiles, step_major).data
+    got = ops.skinny_gemm_z_wide(x, wz, tiles).data
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape and torch.equal(got.view(torch.int32), ref.view(torch.int32)), (got - ref).abs().max()
+    if N >= 256:
+        c0, nc = 64, N - 160
+        got_c = ops.skinny_gemm_z_wide(x, wz, tiles, col0=c0, n_cols=nc).data
+        assert torch.equal(got_c, ref[:, :, c0:c0 + nc])
+
+
 def test_g1z_refuses_what_it_does_not_serve(dev):
     import sjd_amd._lib as L
     import sjd_amd.ops as ops

@@ -383,7 +383,9 @@ class ChameleonBackbone(nn.Module):
     # the same for 64-row windows (two prompts per forward, or a draft window of 32): the staged chunk is twice as tall, so KC <= 1280;
     # set `model.G1_CFG = model.G1_CFG_64ROW` before enable_fused (the packing depends on KC).  Tuned end to end at Lumina-7B shapes.
     # (round 3: gate|up packed in two K halves = the copy kernel G1s streams, which now serves 64 rows; (1024, 12) was the G1 + F3 shape)
-    G1_CFG_64ROW = dict(qkv=(896, 8, True), o=(512, 8, False), gate_up=(2048, 8, True), down=(896, 8, False))       # profiles/r2_g1_launch_shape_sweep_64rows.jsonl
+    # (late round 6: o on four column tiles per workgroup -- on the 12-bit stream that launch shape runs on kernel G1w's 12-bit form, the one place it beats
+    #  G1z: two prompts per forward 3.50 -> 3.44 ms per step, profiles/r6_g1wz_o_64rows_ab.txt; round 2's shape: o (512, 8, False))
+    G1_CFG_64ROW = dict(qkv=(896, 8, True), o=(512, 4, True), gate_up=(2048, 8, True), down=(896, 8, False))       # profiles/r2_g1_launch_shape_sweep_64rows.jsonl
     # 65..128-row windows (three / four prompts per forward): the activation is sub-tiled, so KC is free again, but <= 8 waves.  Round 3:
     # 4-wave workgroups run on g1_skinny_gemm_tiled8 (8-step sub-tiles, two workgroups per CU, weight ring refilled in place) -- q|k|v,
     # o and down are faster there (28.1 / 15.8 / 28.4 -> 25.7 / 12.2 / 24.0 us); 8-wave workgroups run on the same kernel with one workgroup

@@ -1933,6 +1933,12 @@ extern "C" int sjd_skinny_gemm_z(const void *x, const void *wz, const void *exc,
     const dim3 grid((n_out + waves - 1) / waves, n_chunks), block(waves * 64);
     hipStream_t s = (hipStream_t)stream;
     const int rs = step_major ? n_tiles : 1;
+    {   // 33..64 rows with FOUR column tiles per workgroup: kernel G1w's 12-bit form (csrc/sjd_gemm_wide.h, template parameter Z).  The one shape where it beats
+        // the kernels below -- the o projection of a 64-row window, 9.3 against 10.7 us (profiles/r6_g1wz_sweep_64rows_emu3.jsonl); everywhere else it measured
+        // slower and lives in the experimental library only.  Raw units are left to sjd_raw_units_fixup (sjd_amd.ops.skinny_gemm_cols knows).  SJD_G1WZ=0: off.
+        static const bool wz_on = [] { const char *e = getenv("SJD_G1WZ"); return !(e && e[0] == '0'); }();
+        if (wz_on && MT == 2 && waves == 4) return g1_wide_launch_z<2, 1, 4, 4, 3, 2, 2>(x, wz, exc, exc_cap, out, M, N, K, KC, n_tiles, step_major, tile0, s);
+    }
     if (MT > 2 || lds > 160 * 1024) {             // sub-tiled activation (65..128 rows, or a 64-row window with a tall K chunk): <= 8 waves
         if (waves > 8) return SJD_ERR_BAD_ARG;
         const size_t lds_t = (size_t)2 * MT * G1_SUB * 1024;

@@ -655,9 +655,10 @@ def skinny_gemm_cols(x, w_packed, N_packed, K, KC, col0, n_cols, waves=8, step_m
             raise ValueError(f"G1z: a {M}-row window with K chunks of {KC} runs on the sub-tiled kernel (up to 128 rows, at most 8 waves), got waves={waves}")
         L.check(L.load().sjd_skinny_gemm_z(_ptr(x), _ptr(w_packed.data), _ptr(w_packed.exc), w_packed.cap, _ptr(out), M, n_cols, K, KC, waves, int(step_major),
                                           _dtype_code(x.dtype), N_packed, col0 // 32, _stream()), "sjd_skinny_gemm_z")
-        if w_packed.n_raw and (M > 64 or (M > 32 and min(KC, K) > 1280)):
+        if w_packed.n_raw and (M > 64 or (M > 32 and (min(KC, K) > 1280 or waves == 4))):
             # g1z_skinny_gemm runs a raw unit's plain records in the kernel; the SUB-TILED kernel (65..128 rows, or 33..64 with a chunk that does not
-            # fit LDS) does not: there the tiles fed by raw units are recomputed by a launch behind it (csrc/sjd_gemm_raw.h)
+            # fit LDS) and the 12-bit form of kernel G1w (33..64 rows with four column tiles per workgroup, late round 6) do not: there the tiles fed by
+            # raw units are recomputed by a launch behind it (csrc/sjd_gemm_raw.h)
             L.check(L.load().sjd_raw_units_fixup(_ptr(x), _ptr(w_packed.raw_data), _ptr(w_packed.raw_index), w_packed.n_raw, _ptr(out), M, n_cols, K, KC,
                                                 col0 // 32, _dtype_code(x.dtype), _stream()), "sjd_raw_units_fixup")
         return Partials(out, nc, n_cols)

@@ -683,7 +683,7 @@ def _hostile_weights(kind, N, K, g):
 
 @pytest.mark.parametrize("kind", ["zero_rows", "zero_blocks", "student_t3", "scale_spread"])
 @pytest.mark.parametrize("M,N,K,KC,waves,step_major", [(32, 512, 1024, 512, 6, True), (17, 256, 880, 256, 4, False), (64, 512, 2048, 1024, 8, True),
-                                                       (128, 256, 1024, 512, 8, True)])
+                                                       (128, 256, 1024, 512, 8, True), (64, 512, 2048, 512, 4, True), (40, 256, 880, 256, 4, False)])
 def test_g1z_raw_units_match_g1_bit_for_bit(dev, kind, M, N, K, KC, waves, step_major):
     """round 6: the matrix ALWAYS packs -- units the 12-bit format cannot hold travel verbatim and the fix-up launch (csrc/sjd_gemm_raw.h) recomputes
     their tiles: the planes are those of G1 on the uncompressed stream, bit for bit, for every weight statistic above; also through a column
